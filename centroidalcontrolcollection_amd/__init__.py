@@ -1,0 +1,9 @@
+"""centroidalcontrolcollection_amd -- MI355X-native batched centroidal-MPC planOnce() path.
+
+Drop-in for ONE hot path of isri-aist/CentroidalControlCollection: many independent planOnce() problem
+instances solved at once by hand-written HIP kernels (gfx950) behind the C-ABI of include/ccc_amd.h.
+See DESIGN.md (scope, kernels, rooflines) and INTEGRATION.md (how the reference binds to it).
+"""
+from .linear_mpc_zmp import InitialParam, LinearMpcZmp, RefData  # noqa: F401
+
+__all__ = ["LinearMpcZmp", "RefData", "InitialParam"]

@@ -1,0 +1,94 @@
+"""ctypes binding of the C-ABI in include/ccc_amd.h (libccc_amd.so).
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 device is visible, every entry
+point raises.  PyTorch is used by callers only as plumbing (device buffers, streams, torch.distributed).
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_lib = None
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+# return codes / status (include/ccc_amd.h)
+CCC_OK = 0
+CCC_ERR_INVALID_ARGUMENT = 1
+CCC_ERR_UNSUPPORTED = 2
+CCC_ERR_HIP = 3
+CCC_ERR_NO_DEVICE = 4
+CCC_STATUS_SOLVED = 0
+CCC_STATUS_INFEASIBLE = 1
+CCC_STATUS_MAX_ITER = 2
+
+# every symbol include/ccc_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ccc_last_error_string",
+    "ccc_abi_version",
+    "ccc_zmp_create",
+    "ccc_zmp_destroy",
+    "ccc_zmp_horizon_steps",
+    "ccc_zmp_get_seq",
+    "ccc_zmp_plan_batch_device",
+    "ccc_zmp_plan_batch",
+]
+
+
+class CccError(RuntimeError):
+    """Raised when a C-ABI call returns a non-zero code (the reference throws std::runtime_error)."""
+
+    def __init__(self, code, message):
+        super().__init__("libccc_amd error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libccc_amd.so (built in-tree by build.build_lib); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "libccc_amd.so not found at %s: build it with `python -m centroidalcontrolcollection_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    try:
+        # torch bundles its own libamdhip64.so.7; importing it first makes both share one HIP runtime
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, the C-ABI does not need it
+        pass
+    L = ctypes.CDLL(path)
+    L.ccc_last_error_string.restype = ctypes.c_char_p
+    L.ccc_last_error_string.argtypes = []
+    L.ccc_abi_version.restype = ctypes.c_int
+    L.ccc_abi_version.argtypes = []
+    L.ccc_zmp_create.restype = ctypes.c_int
+    L.ccc_zmp_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                 ctypes.POINTER(ctypes.c_void_p)]
+    L.ccc_zmp_destroy.restype = None
+    L.ccc_zmp_destroy.argtypes = [ctypes.c_void_p]
+    L.ccc_zmp_horizon_steps.restype = ctypes.c_int
+    L.ccc_zmp_horizon_steps.argtypes = [ctypes.c_void_p]
+    L.ccc_zmp_get_seq.restype = ctypes.c_int
+    L.ccc_zmp_get_seq.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
+    L.ccc_zmp_plan_batch_device.restype = ctypes.c_int
+    L.ccc_zmp_plan_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p]
+    L.ccc_zmp_plan_batch.restype = ctypes.c_int
+    L.ccc_zmp_plan_batch.argtypes = [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p, ctypes.c_double,
+                                     c_double_p, c_double_p, c_int32_p]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != CCC_OK:
+        msg = load().ccc_last_error_string()
+        raise CccError(code, msg.decode() if msg else "")

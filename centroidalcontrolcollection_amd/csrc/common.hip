@@ -1,0 +1,41 @@
+// common.hip -- error reporting and device selection of libccc_amd.
+#include "common.h"
+
+#include <cstring>
+
+namespace ccc_amd
+{
+std::string & last_error()
+{
+  static thread_local std::string err;
+  return err;
+}
+
+int select_device(int device)
+{
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if(e != hipSuccess || count <= 0)
+    return fail(CCC_ERR_NO_DEVICE, "no HIP device visible (%s): libccc_amd has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if(device < 0 || device >= count)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device, count);
+  hipDeviceProp_t prop;
+  CCC_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if(std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(CCC_ERR_NO_DEVICE, "device %d is %s; libccc_amd is built for gfx950 (MI355X) only", device,
+                prop.gcnArchName);
+  CCC_HIP_CHECK(hipSetDevice(device));
+  return CCC_OK;
+}
+} // namespace ccc_amd
+
+extern "C" const char * ccc_last_error_string(void)
+{
+  return ccc_amd::last_error().c_str();
+}
+
+extern "C" int ccc_abi_version(void)
+{
+  return 1;
+}

@@ -1,0 +1,247 @@
+"""Input generators for the LinearMpcZmp path: restated reference test fixtures + the synthetic batch.
+
+Restates (numpy, host-side; these produce INPUTS, they are not on the timed path):
+  /root/reference/tests/src/FootstepManager.h:35-76     Footstep
+  /root/reference/tests/src/FootstepManager.h:81-127    Footstance.midPos / supportRegion
+  /root/reference/tests/src/FootstepManager.h:130-254   FootstepManager.update / appendFootstep / zmpLimits
+  /root/reference/tests/src/FootstepManager.h:356-365   makeLinearMpcZmpRefData (the second +1e-6)
+  /root/reference/tests/src/SimModels.h:11-41,76-137    ComZmpSimModel1d / ComZmpSim2d (exact ZOH of the LIPM)
+and the synthetic workload of SURVEY.md section 8(d) / BASELINE.md section 3 (`make_zmp_batch`).
+"""
+import bisect
+import math
+
+import numpy as np
+
+from .linear_mpc_zmp import InitialParam, RefData
+
+G = 9.80665  # include/CCC/Constants.h:10
+LEFT, RIGHT = 0, 1
+
+
+def opposite(foot):
+    return RIGHT if foot == LEFT else LEFT
+
+
+class Footstep:
+    """FootstepManager.h:35-76."""
+
+    def __init__(self, foot, pos, transit_start_time, transit_duration, swing_duration):
+        self.foot = foot
+        self.pos = np.asarray(pos, dtype=np.float64)
+        self.transit_start_time = transit_start_time
+        self.swing_start_time = transit_start_time + 0.5 * transit_duration
+        self.swing_end_time = transit_start_time + 0.5 * transit_duration + swing_duration
+        self.transit_end_time = transit_start_time + transit_duration + swing_duration
+
+
+def _mid_pos(stance):
+    if len(stance) == 1:
+        return next(iter(stance.values())).copy()
+    return 0.5 * (stance[LEFT] + stance[RIGHT])
+
+
+def _support_region(stance):
+    if len(stance) == 1:
+        v = next(iter(stance.values()))
+        return [v.copy(), v.copy()]
+    return [np.minimum(stance[LEFT], stance[RIGHT]), np.maximum(stance[LEFT], stance[RIGHT])]
+
+
+class FootstepManager:
+    """FootstepManager.h:130-254 (only what the LinearMpcZmp path uses)."""
+
+    def __init__(self, initial_footstance=None):
+        self.footstance_ = initial_footstance or {LEFT: np.array([0.0, 0.1]), RIGHT: np.array([0.0, -0.1])}
+        self.footstep_list_ = []
+        self.horizon_duration_ = 10.0
+        self.foot_size_ = np.array([0.1, 0.05])
+        self._stance_times = []
+        self._stances = []
+
+    def appendFootstep(self, footstep):
+        if self.footstep_list_ and footstep.transit_start_time < self.footstep_list_[-1].transit_end_time:
+            raise RuntimeError("[FootstepManager::appendFootstep] transit_start_time of specified footstep must be "
+                               "after transit_end_time of last footstep.")
+        self.footstep_list_.append(footstep)
+
+    def update(self, current_time):
+        # :147-160
+        if self.footstep_list_ and self.footstep_list_[0].swing_end_time <= current_time:
+            self.footstance_[self.footstep_list_[0].foot] = self.footstep_list_[0].pos
+        while self.footstep_list_ and self.footstep_list_[0].transit_end_time < current_time:
+            self.footstep_list_.pop(0)
+        # :162-206  (std::map::emplace keeps the FIRST value of a key)
+        entries = {}
+
+        def emplace(t, stance):
+            if t not in entries:
+                entries[t] = {k: v.copy() for k, v in stance.items()}
+
+        if not self.footstep_list_:
+            emplace(current_time, self.footstance_)
+            emplace(current_time + self.horizon_duration_, self.footstance_)
+        else:
+            if current_time < self.footstep_list_[0].transit_start_time:
+                emplace(current_time, self.footstance_)
+            tmp = {k: v.copy() for k, v in self.footstance_.items()}
+            last_zmp_key = -math.inf
+            for fs in self.footstep_list_:
+                if not fs.transit_start_time <= current_time + self.horizon_duration_:
+                    break
+                emplace(fs.transit_start_time, tmp)
+                tmp.pop(fs.foot, None)
+                emplace(fs.swing_start_time, tmp)
+                tmp.setdefault(fs.foot, fs.pos.copy())
+                emplace(fs.swing_end_time, tmp)
+                last_zmp_key = fs.transit_end_time
+            # the reference compares against the last key of ref_zmp_list_ (:201)
+            if max(max(entries), last_zmp_key) < current_time + self.horizon_duration_:
+                emplace(current_time + self.horizon_duration_, tmp)
+        self._stance_times = sorted(entries)
+        self._stances = [entries[t] for t in self._stance_times]
+
+    def zmpLimits(self, t):
+        # :242-254
+        t = t + 1e-6
+        k = bisect.bisect_right(self._stance_times, t) - 1
+        region = _support_region(self._stances[k])
+        return [region[0] - 0.5 * self.foot_size_, region[1] + 0.5 * self.foot_size_]
+
+    def makeLinearMpcZmpRefData(self, t):
+        # :356-365
+        t = t + 1e-6
+        lim = self.zmpLimits(t)
+        return RefData(lim[0], lim[1])
+
+
+class ComZmpSim2d:
+    """SimModels.h:76-137 with the 1-D model of :11-41, ZOH-discretised exactly:
+    x'' = w^2 (x - zmp)  ->  [x, v]+ = [[ch, sh/w],[w sh, ch]] [x, v] + [1 - ch, -w sh] zmp."""
+
+    def __init__(self, com_height, sim_dt):
+        w = math.sqrt(G / com_height)
+        ch, sh = math.cosh(w * sim_dt), math.sinh(w * sim_dt)
+        self.Ad = np.array([[ch, sh / w], [w * sh, ch]])
+        self.Bd = np.array([1 - ch, -w * sh])
+        self.x = np.zeros(2)
+        self.y = np.zeros(2)
+
+    def pos(self):
+        return np.array([self.x[0], self.y[0]])
+
+    def vel(self):
+        return np.array([self.x[1], self.y[1]])
+
+    def update(self, zmp):
+        self.x = self.Ad @ self.x + self.Bd * zmp[0]
+        self.y = self.Ad @ self.y + self.Bd * zmp[1]
+
+    def addDisturb(self, impulse_per_mass):
+        # SimModels.h:125-129 adds impulse.x() to BOTH axes (reference quirk, kept)
+        self.x[1] += impulse_per_mass[0]
+        self.y[1] += impulse_per_mass[0]
+
+
+def zmp_limits_timeline(foot0, foot_pos, foot_id, swing_start, swing_end, times, foot_size=(0.1, 0.05)):
+    """Vectorised FootstepManager::zmpLimits for many independent footstep timelines.
+
+    foot0 [n,2(L/R),2], foot_pos [n,K,2], foot_id [n,K] (0 = left, 1 = right), swing_start/swing_end [n,K],
+    times [n,T] (already including the two +1e-6 of FootstepManager.h:245,360).
+    Returns (zmin, zmax) each [n,T,2].  A foot is off the ground during [swing_start, swing_end) and
+    sits at its new position from swing_end on (FootstepManager.h:179-196)."""
+    n, K = foot_id.shape
+    T = times.shape[1]
+    pos = np.repeat(foot0[:, None, :, :], T, axis=1).copy()  # [n,T,2 feet,2]
+    on_ground = np.ones((n, T, 2), dtype=bool)
+    for k in range(K):
+        f = foot_id[:, k]
+        landed = times >= swing_end[:, k:k + 1]
+        swinging = (times >= swing_start[:, k:k + 1]) & ~landed
+        for foot in (0, 1):
+            sel = (f == foot)[:, None]
+            upd = landed & sel
+            pos[:, :, foot, :] = np.where(upd[..., None], foot_pos[:, k][:, None, :], pos[:, :, foot, :])
+            on_ground[:, :, foot] &= ~(swinging & sel)
+    big = 1e30
+    lo = np.where(on_ground[..., None], pos, big).min(axis=2)
+    hi = np.where(on_ground[..., None], pos, -big).max(axis=2)
+    half = 0.5 * np.asarray(foot_size)
+    return lo - half, hi + half
+
+
+def make_zmp_batch(n, horizon_steps=32, horizon_dt=0.0625, com_height=1.0, seed=20250928, num_footsteps=6):
+    """Synthetic LinearMpcZmp workload of SURVEY.md section 8(d): random 6-step footstep sequences of the
+    shape of TestLinearMpcZmp.cpp:30-43, evaluated at a random time, with a random initial CoM state.
+    PRNG: numpy.random.default_rng(seed) (PCG64).  Returns dict(x0 [n,2,3], zlim [n,2,2,N])."""
+    rng = np.random.default_rng(seed)
+    K, N = num_footsteps, horizon_steps
+    foot0 = np.empty((n, 2, 2))
+    foot0[:, LEFT] = [0.0, 0.1]
+    foot0[:, RIGHT] = [0.0, -0.1]
+    first_foot = rng.integers(0, 2, size=n)
+    foot_id = (first_foot[:, None] + np.arange(K)[None, :]) % 2
+    step_x = rng.uniform(-0.1, 0.3, size=(n, K))
+    lateral = 0.1 + rng.uniform(-0.02, 0.05, size=(n, K))
+    foot_pos = np.empty((n, K, 2))
+    foot_pos[:, :, 0] = np.cumsum(step_x, axis=1)
+    foot_pos[:, :, 1] = np.where(foot_id == LEFT, lateral, -lateral)
+    transit_duration, swing_duration, period = 0.2, 0.8, 1.0
+    t_first = rng.uniform(0.3, 2.0, size=n)
+    transit_start = t_first[:, None] + period * np.arange(K)[None, :]
+    swing_start = transit_start + 0.5 * transit_duration
+    swing_end = swing_start + swing_duration
+    t_eval = rng.uniform(0.0, 8.0, size=n)
+    times = t_eval[:, None] + horizon_dt * np.arange(N)[None, :] + 2e-6
+    zmin, zmax = zmp_limits_timeline(foot0, foot_pos, foot_id, swing_start, swing_end, times)
+    zlim = np.empty((n, 2, 2, N))
+    zlim[:, :, 0, :] = np.transpose(zmin, (0, 2, 1))
+    zlim[:, :, 1, :] = np.transpose(zmax, (0, 2, 1))
+    # initial state: CoM near the middle of the current support region
+    mid = 0.5 * (zmin[:, 0, :] + zmax[:, 0, :])
+    pos = mid + rng.uniform(-0.03, 0.03, size=(n, 2))
+    vel = rng.uniform(-0.2, 0.2, size=(n, 2))
+    zmp_prev = pos + rng.uniform(-0.02, 0.02, size=(n, 2))
+    acc = G / com_height * (pos - zmp_prev)  # TestLinearMpcZmp.cpp:69
+    x0 = np.stack([pos, vel, acc], axis=2)  # [n,2 axes,3]
+    return dict(x0=np.ascontiguousarray(x0), zlim=np.ascontiguousarray(zlim), t_eval=t_eval)
+
+
+def reference_scenario_footsteps():
+    """The six footsteps of TestLinearMpcZmp.cpp:30-43."""
+    td, sd = 0.2, 0.8
+    return [
+        Footstep(LEFT, (0.2, 0.1), 2.0, td, sd),
+        Footstep(RIGHT, (0.4, -0.1), 3.0, td, sd),
+        Footstep(LEFT, (0.6, 0.1), 4.0, td, sd),
+        Footstep(RIGHT, (0.8, -0.1), 5.0, td, sd),
+        Footstep(LEFT, (0.6, 0.1), 6.0, td, sd),
+        Footstep(RIGHT, (0.6, -0.1), 7.0, td, sd),
+    ]
+
+
+def run_closed_loop(plan_once, com_height=1.0, sim_dt=0.005, end_time=10.0, disturb_times=(4.5, 8.5),
+                    disturb=(0.05, 0.05)):
+    """The control loop of TestLinearMpcZmp.cpp:55-102 around any `plan_once(ref_func, InitialParam, t, sim_dt)`.
+    Returns a list of per-cycle records and the final state, for the property assertions of :86-87,:106-109."""
+    fm = FootstepManager()
+    for fs in reference_scenario_footsteps():
+        fm.appendFootstep(fs)
+    sim = ComZmpSim2d(com_height, sim_dt)
+    planned = sim.pos()
+    t = 0.0
+    log = []
+    while t < end_time:
+        fm.update(t)
+        ip = InitialParam(sim.pos(), sim.vel(), G / com_height * (sim.pos() - planned))
+        planned = np.asarray(plan_once(fm.makeLinearMpcZmpRefData, ip, t, sim_dt))
+        lim = fm.zmpLimits(t)
+        log.append(dict(t=t, com=sim.pos(), zmp=planned.copy(), zmin=lim[0], zmax=lim[1]))
+        t += sim_dt
+        sim.update(planned)
+        for dtm in disturb_times:
+            if dtm <= t < dtm + sim_dt:
+                sim.addDisturb(disturb)
+                break
+    lim = fm.zmpLimits(t)
+    return log, dict(t=t, com=sim.pos(), zmp=planned, zmin=lim[0], zmax=lim[1])

@@ -1,0 +1,183 @@
+"""GPU parity tests of the LinearMpcZmp HIP path (csrc/zmp.hip) -- all calls go through the C-ABI.
+
+Bar (BASELINE.json north_star): per-instance ZMP within 1e-9 of the CPU oracle, fp64."""
+import numpy as np
+import pytest
+
+from centroidalcontrolcollection_amd import LinearMpcZmp, _lib
+from centroidalcontrolcollection_amd import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+ZMP_TOL = 1e-9  # north_star: "per-instance CoM/ZMP within 1e-9 of the CPU reference"
+JERK_RTOL = 1e-7  # relative to max(1, |jerk|_inf) of the instance: the QP solution itself
+
+
+def _oracle():
+    from oracle import oracle
+
+    return oracle
+
+
+def _jerk_err(a, b):
+    scale = np.maximum(1.0, np.abs(b).max(axis=-1, keepdims=True))
+    return (np.abs(a - b) / scale).max()
+
+
+@pytest.fixture(scope="module")
+def mpc32():
+    return LinearMpcZmp(1.0, 2.0, 0.0625)
+
+
+def test_model_matrices_match_oracle(mpc32):
+    o = _oracle().LinearMpcZmp(1.0, 2.0, 0.0625)
+    assert mpc32.horizon_steps_ == o.horizon_steps == 32
+    A, B = mpc32.seq()
+    Ao, Bo = o.seq()
+    assert np.abs(A - Ao).max() <= 1e-15 and np.abs(B - Bo).max() <= 1e-16
+
+
+def test_golden_vectors_n32(mpc32, golden_zmp):
+    r = mpc32.planOnceBatch(golden_zmp["n32_x0"], golden_zmp["n32_zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == _lib.CCC_STATUS_SOLVED)
+    assert np.abs(r["zmp"] - golden_zmp["n32_zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], golden_zmp["n32_jerk"]) <= JERK_RTOL
+
+
+def test_parity_with_oracle_config2_batch4096(mpc32):
+    """BASELINE.json configs[1]: LinearMpcZmp batch=4096 random footstep sequences, N=32, fp64."""
+    b = fx.make_zmp_batch(4096, 32, 0.0625, seed=20250928)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.0625).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(ref["status"] == 0) and np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+
+
+def test_default_control_dt_is_horizon_dt(mpc32):
+    # src/LinearMpcZmp.cpp:72-75
+    b = fx.make_zmp_batch(64, 32, 0.0625, seed=3)
+    a = mpc32.planOnceBatch(b["x0"], b["zlim"], -1.0)["zmp"]
+    c = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.0625)["zmp"]
+    assert np.array_equal(a, c)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.0625).plan_batch(b["x0"], b["zlim"], -1.0)
+    assert np.abs(a - ref["zmp"]).max() <= ZMP_TOL
+
+
+def test_ragged_batches_and_empty(mpc32):
+    b = fx.make_zmp_batch(131, 32, 0.0625, seed=9)
+    full = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005)["zmp"]
+    for n in (1, 2, 3, 63, 64, 65, 131):
+        part = mpc32.planOnceBatch(b["x0"][:n], b["zlim"][:n], 0.005)["zmp"]
+        assert np.array_equal(part, full[:n])
+    empty = mpc32.planOnceBatch(np.zeros((0, 2, 3)), np.zeros((0, 2, 2, 32)), 0.005)
+    assert empty["zmp"].shape == (0, 2)
+
+
+def test_unconstrained_and_fully_clamped_instances(mpc32):
+    N = 32
+    x0 = np.zeros((2, 2, 3))
+    zlim = np.empty((2, 2, 2, N))
+    zlim[0, :, 0], zlim[0, :, 1] = -10.0, 10.0  # nothing active: jerk = 0
+    zlim[1, :, 0], zlim[1, :, 1] = 0.02, 0.02 + 1e-9  # every row active (32 active constraints)
+    r = mpc32.planOnceBatch(x0, zlim, 0.005, want_jerk=True)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.0625).plan_batch(x0, zlim, 0.005)
+    assert np.all(r["status"] == 0)
+    assert np.all(r["jerk"][0] == 0.0) and np.all(r["pivots"][0] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= 1e-6
+
+
+def test_infeasible_instance_is_flagged(mpc32):
+    b = fx.make_zmp_batch(8, 32, 0.0625, seed=5)
+    zlim = b["zlim"].copy()
+    zlim[3, 1, 0, 7] = zlim[3, 1, 1, 7] + 0.5  # zmin > zmax on the y axis of instance 3
+    r = mpc32.planOnceBatch(b["x0"], zlim, 0.005)
+    assert r["status"][3, 1] == _lib.CCC_STATUS_INFEASIBLE
+    assert r["status"].sum() == _lib.CCC_STATUS_INFEASIBLE
+    ok = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005)
+    keep = np.ones((8, 2), bool)
+    keep[3, 1] = False
+    assert np.array_equal(r["zmp"][keep], ok["zmp"][keep])
+
+
+def test_device_entry_full_size_properties(mpc32):
+    """BASELINE metric size (batch 65536) through the device-pointer entry: size-independent properties
+    (primal feasibility, clamp, translation equivariance, determinism) + oracle parity on a sample."""
+    import torch
+
+    n, N = 65536, 32
+    b = fx.make_zmp_batch(n, N, 0.0625, seed=20250928)
+    dev = torch.device("cuda:0")
+    x0 = torch.from_numpy(b["x0"]).to(dev)
+    zlim = torch.from_numpy(b["zlim"]).to(dev)
+    zmp = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    jerk = torch.empty((n, 2, N), dtype=torch.float64, device=dev)
+    status = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    mpc32.plan_batch_device(x0, zlim, 0.005, zmp, jerk, status)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert np.all((st & 0xff) == 0)
+    zmp_h, jerk_h = zmp.cpu().numpy(), jerk.cpu().numpy()
+    # primal feasibility of the whole planned sequence: lo <= A_seq x0 + B_seq u <= hi
+    A_seq, B_seq = mpc32.seq()
+    pred = np.einsum("ik,nak->nai", A_seq, b["x0"]) + np.einsum("ij,naj->nai", B_seq, jerk_h)
+    assert (b["zlim"][:, :, 0, :] - pred).max() <= 1e-9 and (pred - b["zlim"][:, :, 1, :]).max() <= 1e-9
+    # planned ZMP inside the step-0 limits (src/LinearMpcZmp.cpp:78)
+    assert np.all(zmp_h >= b["zlim"][:, :, 0, 0]) and np.all(zmp_h <= b["zlim"][:, :, 1, 0])
+    # determinism: a second launch gives the same bits
+    zmp2 = torch.empty_like(zmp)
+    mpc32.plan_batch_device(x0, zlim, 0.005, zmp2)
+    torch.cuda.synchronize()
+    assert torch.equal(zmp, zmp2)
+    # translation equivariance: shifting CoM position and all limits by c shifts the planned ZMP by c
+    shift = 0.37
+    x0s = x0.clone()
+    x0s[:, :, 0] += shift
+    zmp3 = torch.empty_like(zmp)
+    mpc32.plan_batch_device(x0s, zlim + shift, 0.005, zmp3)
+    torch.cuda.synchronize()
+    assert (zmp3 - shift - zmp).abs().max().item() <= 1e-9
+    # oracle parity on a strided sample of 2048 instances
+    sel = np.arange(0, n, 32)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.0625).plan_batch(b["x0"][sel], b["zlim"][sel], 0.005, nthreads=8)
+    assert np.abs(zmp_h[sel] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(jerk_h[sel], ref["jerk"]) <= JERK_RTOL
+
+
+def test_n50_one_axis_per_wavefront_path():
+    """32 < N <= 64 runs one QP per wavefront (LG = 64 instantiation)."""
+    dt = 0.04
+    mpc = LinearMpcZmp(1.0, 2.0, dt)
+    assert mpc.horizon_steps_ == 50
+    b = fx.make_zmp_batch(512, 50, dt, seed=17)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+
+
+def test_short_horizon_n5():
+    mpc = LinearMpcZmp(1.0, 0.05, 0.01)
+    assert mpc.horizon_steps_ == 5
+    b = fx.make_zmp_batch(256, 5, 0.01, seed=23)
+    ref = _oracle().LinearMpcZmp(1.0, 0.05, 0.01).plan_batch(b["x0"], b["zlim"], 0.005)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+
+
+def test_plan_once_callback_surface_closed_loop():
+    """The reference's own test scenario (TestLinearMpcZmp.cpp:15-126) through planOnce(callback, ...), with a
+    50-step horizon (2 s @ 40 ms): property assertions of :86-87 and :106-109."""
+    mpc = LinearMpcZmp(1.0, 2.0, 0.04)
+    log, fin = fx.run_closed_loop(mpc.planOnce, end_time=10.0)
+    for rec in log:
+        assert np.all(rec["zmp"] - rec["zmin"] >= 0) and np.all(rec["zmax"] - rec["zmp"] >= 0)
+    assert np.all(fin["zmp"] - fin["zmin"] >= 0) and np.all(fin["zmax"] - fin["zmp"] >= 0)
+    assert np.all(fin["com"] - fin["zmin"] >= 0) and np.all(fin["zmax"] - fin["com"] >= 0)
+
+
+def test_bad_shapes_raise(mpc32):
+    with pytest.raises(ValueError):
+        mpc32.planOnceBatch(np.zeros((4, 2, 3)), np.zeros((4, 2, 2, 31)))
