@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the batched LinearMpcZmp planOnce() path on MI355X.
+
+Metric (BASELINE.json): planOnce() solves/sec whole-node + p50 latency, LinearMpcZmp N=32 batch=65536, fp64.
+A "step" is one pass of the hot path over one batch of synthetic instances already resident in HBM:
+one launch of the dual active-set kernel (csrc/zmp.hip) through the C-ABI (ccc_zmp_plan_batch_device),
+plus -- for N > 1 GPUs -- the RCCL all-gather of the planned ZMPs (north_star).  Weak scaling: every rank
+solves its own batch of 65536 instances (seed = 20250928 + rank); value = all ranks' solves / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+ALGO_BYTES_PER_SOLVE = 1088  # 48 B state + 1024 B limits in, 16 B ZMP out
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def cpu_baseline(batch, seconds_budget=20.0):
+    """Time the CPU oracle (plain-C port of the reference path, oracle/) on this host's cores on a bounded
+    sample of the same workload; also returns its answers for a parity spot check."""
+    from oracle import oracle
+
+    o = oracle.LinearMpcZmp(1.0, 2.0, 0.0625)
+    cores = os.cpu_count() or 1
+    n_all = batch["x0"].shape[0]
+    # single thread: 4096 instances (~0.5 s), gives the per-core rate
+    n1 = min(4096, n_all)
+    t0 = time.perf_counter()
+    o.plan_batch(batch["x0"][:n1], batch["zlim"][:n1], 0.005, want_jerk=False, nthreads=1)
+    rate1 = n1 / (time.perf_counter() - t0)
+    # all cores: a sample sized for ~seconds_budget/2 of wall time, capped at the batch
+    o.plan_batch(batch["x0"][:256], batch["zlim"][:256], 0.005, want_jerk=False, nthreads=cores)  # spin up the team
+    n_mt = int(min(n_all, max(4096, rate1 * cores * seconds_budget * 0.25)))
+    t0 = time.perf_counter()
+    r = o.plan_batch(batch["x0"][:n_mt], batch["zlim"][:n_mt], 0.005, want_jerk=False, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return dict(value=n_mt / dt, unit="solves/s", cores=cores, kind="port",
+                sample="first %d of the %d-instance rank-0 batch, OpenMP over instances, %d threads; "
+                       "C restatement of the reference path (oracle/), not QLD" % (n_mt, n_all, cores),
+                value_1thread=rate1), r["zmp"], n_mt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from centroidalcontrolcollection_amd import LinearMpcZmp
+    from centroidalcontrolcollection_amd import fixtures as fx
+
+    N, dt, n = 32, 0.0625, args.batch
+    mpc = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
+    batch = fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + rank)
+    x0 = torch.from_numpy(batch["x0"]).to(dev)
+    zlim = torch.from_numpy(batch["zlim"]).to(dev)
+    zmp = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    status = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    gathered = torch.empty((world * n, 2), dtype=torch.float64, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, None, stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, zmp)
+
+    # one untimed launch with the status array for pivot statistics / status check
+    mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, status, stream)
+    torch.cuda.synchronize(dev)
+    st = status.cpu().numpy()
+    n_bad = int(((st & 0xff) != 0).sum())
+    pivots_per_solve = float((st >> 8).sum()) / n
+
+    for _ in range(args.warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = np.array([a.elapsed_time(b) for a, b in evs])  # HIP events on the launch stream
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * n * args.steps / elapsed
+        kavg = float(kern_ms.mean()) * 1e-3
+        achieved = ALGO_BYTES_PER_SOLVE * n / kavg / 1e9
+        out = {
+            "metric": "LinearMpcZmp planOnce() solves/sec (N=32, fp64, inputs resident in HBM)",
+            "value": value,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "p50_ms": float(np.median(kern_ms)) if world == 1 else ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "LinearMpcZmp N=32 (2 s horizon @ 62.5 ms), batch=%d per GPU, random 6-step "
+                                   "footstep sequences (SURVEY.md 8d)" % n,
+                       "batch_per_gpu": n, "horizon_steps": N, "parallelism": "batch-sharded x%d" % world,
+                       "collective": "all_gather(zmp)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "zmp_plan_kernel<32,4>", "kernel_avg_ms": kavg * 1e3,
+                         "note": "algorithmic bytes = 1088 B/solve x batch; the kernel is fp64-VALU/LDS-latency "
+                                 "bound (iterative active set), see DESIGN.md"},
+            "pivots_per_solve": pivots_per_solve,
+            "unsolved": n_bad,
+        }
+        if not args.no_cpu_baseline:
+            cb, ref_zmp, n_chk = cpu_baseline(batch)
+            out["cpu_baseline"] = cb
+            out["parity_max_abs_err"] = float(np.abs(zmp.cpu().numpy()[:n_chk] - ref_zmp).max())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

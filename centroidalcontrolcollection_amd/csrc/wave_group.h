@@ -1,20 +1,113 @@
-// wave_group.h -- lane-group collectives inside one 64-wide CDNA wavefront.
+// wave_group.h -- lane-group collectives inside one 64-wide CDNA4 wavefront.
 //
 // A "group" is LG consecutive lanes (LG = 32: two groups per wavefront, LG = 64: the whole wavefront)
-// that cooperate on one small problem, one lane per row.  Everything here is register-to-register
-// (ds_bpermute / DPP); no LDS storage and no barriers are involved.
+// that cooperate on one small problem, one lane per row.  Reductions run on the VALU cross-lane paths
+// of gfx950 (DPP quad_perm / row_mirror inside a 16-lane row, v_permlane16_swap / v_permlane32_swap
+// across rows) -- no LDS round trips, no barriers.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 namespace ccc_amd
 {
+// DPP controls (gfx9 encoding)
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7-i inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15-i inside each 16-lane row
+
+template<int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// a = rows {0,0,2,2} of v, b = rows {1,1,3,3} of v (a row = 16 lanes)
+__device__ __forceinline__ void rows_pair16(double v, double & a, double & b)
+{
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  a = __hiloint2double((int)rh[0], (int)rl[0]);
+  b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
+// a = lanes 0-31 of v in both halves, b = lanes 32-63 of v in both halves
+__device__ __forceinline__ void halves_pair32(double v, double & a, double & b)
+{
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  a = __hiloint2double((int)rh[0], (int)rl[0]);
+  b = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
 template<int LG>
 struct WaveGroup
 {
   static_assert(LG == 32 || LG == 64, "a group is half a wavefront or a whole one");
 
-  // value held by lane `src` (group-relative) of the caller's group
+  // max over the group, replicated in every lane of the group
+  static __device__ __forceinline__ double max(double v)
+  {
+    v = fmax(v, dpp_f64<kDppQuadXor1>(v));
+    v = fmax(v, dpp_f64<kDppQuadXor2>(v));
+    v = fmax(v, dpp_f64<kDppRowHalfMirror>(v));
+    v = fmax(v, dpp_f64<kDppRowMirror>(v));
+    double a, b;
+    rows_pair16(v, a, b);
+    v = fmax(a, b);
+    if(LG == 64)
+    {
+      halves_pair32(v, a, b);
+      v = fmax(a, b);
+    }
+    return v;
+  }
+
+  static __device__ __forceinline__ double min(double v)
+  {
+    return -max(-v);
+  }
+
+  static __device__ __forceinline__ double sum(double v)
+  {
+    v += dpp_f64<kDppQuadXor1>(v);
+    v += dpp_f64<kDppQuadXor2>(v);
+    v += dpp_f64<kDppRowHalfMirror>(v);
+    v += dpp_f64<kDppRowMirror>(v);
+    double a, b;
+    rows_pair16(v, a, b);
+    v = a + b;
+    if(LG == 64)
+    {
+      halves_pair32(v, a, b);
+      v = a + b;
+    }
+    return v;
+  }
+
+  // lowest group-relative lane index for which pred holds (LG if none), replicated in the group
+  static __device__ __forceinline__ int first(bool pred)
+  {
+    const unsigned long long m = __ballot(pred);
+    if(LG == 64) return m ? (int)__ffsll((long long)m) - 1 : 64;
+    const unsigned mine = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+    return mine ? __ffs((int)mine) - 1 : 32;
+  }
+
+  static __device__ __forceinline__ bool any(bool pred)
+  {
+    const unsigned long long m = __ballot(pred);
+    if(LG == 64) return m != 0ull;
+    const unsigned mine = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+    return mine != 0u;
+  }
+
+  // value held by lane `src` (group-relative) of the caller's group (LDS crossbar; use sparingly)
   static __device__ __forceinline__ double bcast(double v, int src)
   {
     return __shfl(v, src, LG);
@@ -22,57 +115,6 @@ struct WaveGroup
   static __device__ __forceinline__ int bcast(int v, int src)
   {
     return __shfl(v, src, LG);
-  }
-
-  // (max key, lowest index attaining it) over the group, replicated in every lane
-  static __device__ __forceinline__ void argmax(double & key, int & idx)
-  {
-#pragma unroll
-    for(int off = LG / 2; off > 0; off >>= 1)
-    {
-      double ok = __shfl_xor(key, off, LG);
-      int oi = __shfl_xor(idx, off, LG);
-      bool take = (ok > key) || (ok == key && oi < idx);
-      key = take ? ok : key;
-      idx = take ? oi : idx;
-    }
-  }
-
-  static __device__ __forceinline__ void argmin(double & key, int & idx)
-  {
-#pragma unroll
-    for(int off = LG / 2; off > 0; off >>= 1)
-    {
-      double ok = __shfl_xor(key, off, LG);
-      int oi = __shfl_xor(idx, off, LG);
-      bool take = (ok < key) || (ok == key && oi < idx);
-      key = take ? ok : key;
-      idx = take ? oi : idx;
-    }
-  }
-
-  static __device__ __forceinline__ double sum(double v)
-  {
-#pragma unroll
-    for(int off = LG / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, LG);
-    return v;
-  }
-
-  static __device__ __forceinline__ bool any(bool pred)
-  {
-    unsigned long long m = __ballot(pred);
-    if(LG == 64) return m != 0ull;
-    unsigned long long mine = (threadIdx.x & 32) ? (m >> 32) : (m & 0xffffffffull);
-    return mine != 0ull;
-  }
-
-  // maximum over the whole wavefront of a value that is uniform inside each group
-  static __device__ __forceinline__ int wave_max_of_group_uniform(int v)
-  {
-    int a = __builtin_amdgcn_readlane(v, 0);
-    if(LG == 64) return a;
-    int b = __builtin_amdgcn_readlane(v, 32);
-    return a > b ? a : b;
   }
 };
 } // namespace ccc_amd

@@ -12,14 +12,15 @@
 //   (G mu)_i = lo_i if mu_i > 0,  = hi_i if mu_i < 0,  in [lo_i, hi_i] if mu_i = 0.
 // The kernel runs the Goldfarb-Idnani dual active-set iteration directly on that system: the working
 // set W grows by the most violated row and shrinks by the dual ratio test.  Instead of a QR/Cholesky
-// factorisation it keeps the columns {T[:,w] : w in W} of the symmetric sweep tableau of G swept on W
-// (T_WW = -G_WW^-1, T_iW = G_iW G_WW^-1) -- one lane per row, columns in LDS -- from which column p of
-// the tableau (search direction + Schur complement) costs |W| FMAs per lane, and adding/dropping a
-// row is one rank-1 update of |W| columns.  A closing iterative-refinement step against the
-// untouched G removes the drift of the incremental updates.
+// factorisation it keeps the symmetric sweep tableau T of G swept on W (T_WW = -G_WW^-1,
+// T_iW = G_iW G_WW^-1, T_ij = Schur complement otherwise): ONE LANE PER ROW, the row in that lane's
+// VGPRs.  Column p of T (search direction, Schur complement, ratio test) is row p by symmetry, so the
+// lane that owns row p publishes it through a 300-byte LDS scratch and every lane of the group reads
+// its own element plus the broadcast of the whole row; adding / dropping a row is then one rank-1
+// update T -= g v' of register-resident data (N FMAs per lane, no data-dependent loop bounds).
 //
-// Mapping: one lane per horizon step; N <= 32: the two axes of one instance are the two 32-lane
-// halves of ONE wavefront (one planOnce() per wavefront); 32 < N <= 64: one axis per wavefront.
+// Mapping: N <= 32: the two axes of one instance are the two 32-lane halves of ONE wavefront (one
+// planOnce() per wavefront); 32 < N <= 64: one axis per wavefront.
 #include "common.h"
 #include "wave_group.h"
 
@@ -41,6 +42,15 @@ struct ZmpDev
 
 constexpr double kInf = __builtin_huge_val();
 
+// scratch doubles per group: the published row [0, NP), then sign / reciprocal pivot
+template<int NP>
+struct ZmpScratch
+{
+  static constexpr int kSig = NP;
+  static constexpr int kRp = NP + 1;
+  static constexpr int kSize = NP + 8; // keeps every group's base 16-byte aligned
+};
+
 template<int LG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                              const double * __restrict__ zlim, double control_dt,
@@ -48,6 +58,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
                                                              int * __restrict__ status)
 {
   using Grp = WaveGroup<LG>;
+  using Scr = ZmpScratch<LG>;
   constexpr int NP = LG;
   constexpr int QPW = 64 / LG; // QPs per wavefront
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -55,7 +66,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
   double * bs = smem + NP * NP; // [NP]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & (LG - 1), grp = lane / LG;
-  double * Yw = smem + NP * NP + NP + wave * (LG * 64); // this wavefront's tableau columns: Y[slot][lane]
+  double * scr = smem + NP * NP + NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
+  const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
   for(int k = tid; k < NP * NP; k += WAVES * 64) Gs[k] = P.G[k];
   for(int k = tid; k < NP; k += WAVES * 64) bs[k] = P.b[k];
@@ -95,211 +107,232 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
     int st = CCC_STATUS_SOLVED;
     if(Grp::any(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
 
-    // ---- dual active-set state (per lane: row li of the KKT system)
-    double z = 0.0, mu = 0.0, dact = 0.0;
+    // ---- tableau T = G (W empty): lane li holds row li = column li of the symmetric G; the diagonal
+    //      lives in dg (the in-row copy T[li] is never read by its owner and is patched on publication)
+    double T[NP];
+#pragma unroll
+    for(int j = 0; j < NP; ++j) T[j] = Gs[j * NP + li];
+    double dg = Gs[li * NP + li];
+    double dgm = dg; // bitwise mirror of the (unreadable) in-row register T[li], see the refinement below
+
+    double z = 0.0, mu = 0.0; // z = (G mu)_li, mu = multiplier of row li
+    double dact = 0.0;         // bound row li sits on while it is in W
     bool inW = false;
-    int slot_idx = 0; // lane s: row stored in slot s
-    int myslot = 0;   // lane i in W: slot holding column i
-    int q = 0;        // |W| (group uniform)
-    int p = 0;
-    double sig = 0.0, dsel = 0.0;
+    int p = 0;                  // entering row (group uniform)
+    double psig = 0.0, pd = 0.0; // meaningful in lane p only: side (+1 lower, -1 upper) and bound it moves to
     bool done = !valid || st != CCC_STATUS_SOLVED;
     bool need_select = true;
     int passes = 0;
 
     for(int round = 0; round < 3; ++round)
     {
-      for(;;)
+    for(;;)
+    {
+      // -- Goldfarb-Idnani step 1: the most violated row enters
+      if(__ballot(need_select && !done) != 0ull)
       {
-        // -- select the most violated row (Goldfarb-Idnani step 1)
+        const double sl = (lo - z) - tl, sh = (z - hi) - th;
+        const double score = (inW || !row) ? -kInf : fmax(sl, sh);
+        const double m = Grp::max(score);
+        const int cand = Grp::first(score == m);
+        if(need_select && !done)
         {
-          const double sl = (lo - z) - tl, sh = (z - hi) - th;
-          double score = (inW || !row) ? -kInf : fmax(sl, sh);
-          int cand = li;
-          Grp::argmax(score, cand);
-          const double my_sig = (sl >= sh) ? 1.0 : -1.0;
-          const double my_d = (sl >= sh) ? lo : hi;
-          const double csig = Grp::bcast(my_sig, cand);
-          const double cd = Grp::bcast(my_d, cand);
-          if(need_select && !done)
+          if(m > 0.0)
           {
-            if(score > 0.0)
+            p = cand;
+            if(li == cand)
             {
-              p = cand;
-              sig = csig;
-              dsel = cd;
+              psig = (sl >= sh) ? 1.0 : -1.0;
+              pd = (sl >= sh) ? lo : hi;
             }
-            else
-              done = true;
-          }
-        }
-        if(__ballot(!done) == 0ull) break;
-
-        const int qmax = Grp::wave_max_of_group_uniform(done ? 0 : q);
-
-        // -- column p of the swept tableau: c_W = G_WW^-1 G_Wp, c_i = Schur complement column otherwise
-        double c = (inW || !row) ? 0.0 : Gs[p * NP + li];
-        {
-          const double gws = (li < q) ? Gs[slot_idx * NP + p] : 0.0;
-          for(int s = 0; s < qmax; ++s)
-          {
-            const double gw = Grp::bcast(gws, s);
-            const double y = Yw[s * 64 + lane];
-            c = (s < q) ? fma(-y, gw, c) : c;
-          }
-        }
-        const double delta = Grp::bcast(c, p);
-        const double zp = Grp::bcast(z, p);
-        // -- step lengths: full step t2 (row p reaches its bound), dual ratio test t1
-        const double t2 = sig * (dsel - zp) / delta;
-        const double dm = -sig * c;
-        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-        double t1 = blocking ? -mu / dm : kInf;
-        int k = li;
-        Grp::argmin(t1, k);
-        const bool drop = t1 < t2;
-        const double t = drop ? t1 : t2;
-        if(!done)
-        {
-          if(inW)
-            mu = fma(t, dm, mu);
-          else
-            z = fma(sig * t, c, z);
-          if(li == p) mu += sig * t;
-        }
-        // -- pivot: sweep p in (add) or sweep k out (drop); both are one rank-1 update of the stored columns
-        const int pi = drop ? k : p;
-        int sk = Grp::bcast(myslot, k);
-        sk = drop ? sk : 0;
-        const double v = drop ? Yw[sk * 64 + lane] : c;
-        const double rp = 1.0 / Grp::bcast(v, pi);
-        const double vw = __shfl(v, slot_idx, LG); // lane s: v at the row stored in slot s
-        for(int s = 0; s < qmax; ++s)
-        {
-          const double f = Grp::bcast(vw, s) * rp;
-          const double y = Yw[s * 64 + lane];
-          const double yn = (li == pi) ? (drop ? -f : f) : fma(-v, f, y);
-          if(!done && s < q && !(drop && s == sk)) Yw[s * 64 + lane] = yn;
-        }
-        const int last = q > 0 ? q - 1 : 0;
-        const int wl = Grp::bcast(slot_idx, last);
-        if(!done)
-        {
-          if(!drop)
-          {
-            Yw[q * 64 + lane] = (li == p) ? -rp : c * rp;
-            if(li == q) slot_idx = p;
-            if(li == p)
-            {
-              myslot = q;
-              inW = true;
-              z = dsel;
-              dact = dsel;
-            }
-            q += 1;
-            need_select = true;
           }
           else
-          {
-            if(sk != last)
-            {
-              Yw[sk * 64 + lane] = Yw[last * 64 + lane];
-              if(li == sk) slot_idx = wl;
-              if(li == wl) myslot = sk;
-            }
-            if(li == k)
-            {
-              inW = false;
-              mu = 0.0;
-            }
-            q -= 1;
-            need_select = false;
-          }
-          if(++passes > maxpass)
-          {
             done = true;
-            st = CCC_STATUS_MAX_ITER;
-          }
         }
+      }
+      if(__ballot(!done) == 0ull) break;
+
+      // -- lane p publishes row p (= column p of T): search direction for W, Schur complement elsewhere
+      if(li == p && !done)
+      {
+#pragma unroll
+        for(int j = 0; j < NP; j += 2) *reinterpret_cast<double2 *>(scr + j) = make_double2(T[j], T[j + 1]);
+        scr[p] = dg;
+        scr[Scr::kSig] = psig;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double c = scr[li];
+      const double sig = scr[Scr::kSig];
+
+      // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
+      const double dm = -sig * c;
+      const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+      const bool isp = (li == p);
+      const double num = isp ? psig * (pd - z) : -mu;
+      const double den = isp ? dg : dm;
+      const double ratio = (!done && (isp || blocking)) ? num / den : kInf;
+      const double t = Grp::min(ratio);
+      int kk = Grp::first(ratio == t);
+      if(!done && kk >= LG)
+      { // NaN step: numerical breakdown, report instead of spinning
+        done = true;
+        st = CCC_STATUS_MAX_ITER;
+      }
+      kk = kk >= LG ? 0 : kk;
+      const bool isadd = (kk == p);
+      const double s = isadd ? 1.0 : -1.0;
+      if(!done)
+      {
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, c, z);
+        if(isp) mu += sig * t;
       }
 
-      // -- closing refinement against the original G: rho = d_W - (G mu)_W, mu_W += G_WW^-1 rho,
-      //    then z = G mu recomputed from scratch for the final optimality check
-      const bool ok = valid && st == CCC_STATUS_SOLVED;
-      const int qmax = Grp::wave_max_of_group_uniform(ok ? q : 0);
-      double acc = 0.0;
+      // -- pivot row kk (add: p itself, already published; drop: the blocking row): patch the diagonal so that
+      //    the generic update writes column kk, and publish 1/pivot
+      if(li == kk && !done)
       {
-        const double muw = __shfl(mu, slot_idx, LG);
-        for(int s = 0; s < qmax; ++s)
+        if(!isadd)
         {
-          const int w = Grp::bcast(slot_idx, s);
-          const double m = Grp::bcast(muw, s);
-          const double gv = Gs[w * NP + li];
-          acc = (s < q) ? fma(gv, m, acc) : acc;
+#pragma unroll
+          for(int j = 0; j < NP; j += 2) *reinterpret_cast<double2 *>(scr + j) = make_double2(T[j], T[j + 1]);
+        }
+        scr[kk] = dg - s;
+        scr[Scr::kRp] = 1.0 / dg;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double v = scr[li];
+      const double rp = scr[Scr::kRp];
+      // T'_ij = T_ij - (v_i rp) v_j ; column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ; row kk: g = 1 - s rp
+      double g = (li == kk) ? (1.0 - s * rp) : v * rp;
+      g = done ? 0.0 : g;
+#pragma unroll
+      for(int j0 = 0; j0 < NP; j0 += 8)
+      { // 8 broadcast values in flight at a time: keeps the row + state inside 128 VGPRs (4 waves/SIMD)
+        const double2 v0 = scr2[j0 / 2 + 0], v1 = scr2[j0 / 2 + 1], v2 = scr2[j0 / 2 + 2], v3 = scr2[j0 / 2 + 3];
+        T[j0 + 0] = fma(-g, v0.x, T[j0 + 0]);
+        T[j0 + 1] = fma(-g, v0.y, T[j0 + 1]);
+        T[j0 + 2] = fma(-g, v1.x, T[j0 + 2]);
+        T[j0 + 3] = fma(-g, v1.y, T[j0 + 3]);
+        T[j0 + 4] = fma(-g, v2.x, T[j0 + 4]);
+        T[j0 + 5] = fma(-g, v2.y, T[j0 + 5]);
+        T[j0 + 6] = fma(-g, v3.x, T[j0 + 6]);
+        T[j0 + 7] = fma(-g, v3.y, T[j0 + 7]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if(!done)
+      {
+        dg = (li == kk) ? -rp : fma(-g, v, dg);
+        dgm = fma(-g, v, dgm);
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(li == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(++passes > maxpass)
+        {
+          done = true;
+          st = CCC_STATUS_MAX_ITER;
         }
       }
-      const double rho = (inW && ok) ? dact - acc : 0.0;
-      {
-        const double rhow = __shfl(rho, slot_idx, LG);
-        double dmu = 0.0;
-        for(int s = 0; s < qmax; ++s)
-        {
-          const double r = Grp::bcast(rhow, s);
-          const double y = Yw[s * 64 + lane];
-          dmu = (s < q) ? fma(-y, r, dmu) : dmu;
-        }
-        if(inW && ok) mu += dmu;
-      }
-      acc = 0.0;
-      {
-        const double muw = __shfl(mu, slot_idx, LG);
-        for(int s = 0; s < qmax; ++s)
-        {
-          const int w = Grp::bcast(slot_idx, s);
-          const double m = Grp::bcast(muw, s);
-          const double gv = Gs[w * NP + li];
-          acc = (s < q) ? fma(gv, m, acc) : acc;
-        }
-      }
-      if(ok) z = inW ? dact : acc;
-      // a row that the refreshed z shows violated re-opens the iteration (rare: only rows that sat
-      // within the drift of the incremental updates of their bound)
-      const double sl = (lo - z) - tl, sh = (z - hi) - th;
-      const bool viol = ok && row && !inW && fmax(sl, sh) > 0.0;
-      const bool reopen = Grp::any(viol);
-      done = !reopen;
-      need_select = true;
-      if(__ballot(reopen) == 0ull) break;
+      __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- outputs: jerk[0] = (B' mu)_0, src/LinearMpcZmp.cpp:69-78
+    // ---- closing iterative refinement against the untouched G (removes the drift of the rank-1 updates):
+    //      rho = d_W - (G mu)_W ;  mu_W += G_WW^-1 rho = -T_WW rho ;  z = G mu recomputed; a row the fresh z
+    //      shows violated re-opens the iteration (rare: rows that sat within the drift of their bound)
+    {
+      const bool ok = valid && st == CCC_STATUS_SOLVED;
+      const bool act = inW && ok;
+      scr[li] = act ? mu : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      double acc = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        const double2 mb = scr2[j / 2];
+        acc = fma(Gs[j * NP + li], mb.x, acc);
+        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
+      }
+      const double rho = act ? dact - acc : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      scr[li] = rho;
+      __builtin_amdgcn_wave_barrier();
+      double tr = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        const double2 rb = scr2[j / 2];
+        tr = fma(T[j], rb.x, tr);
+        tr = fma(T[j + 1], rb.y, tr);
+      }
+      tr = fma(dg - dgm, rho, tr); // replace the stale in-row diagonal by the true one
+      if(act) mu -= tr;
+      __builtin_amdgcn_wave_barrier();
+      scr[li] = act ? mu : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      acc = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        const double2 mb = scr2[j / 2];
+        acc = fma(Gs[j * NP + li], mb.x, acc);
+        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
+      }
+      if(ok) z = inW ? dact : acc;
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const bool reopen = Grp::any(ok && row && !inW && fmax(sl, sh) > 0.0);
+      done = !reopen;
+      need_select = true;
+      __builtin_amdgcn_wave_barrier();
+      if(__ballot(reopen) == 0ull) break;
+    }
+    }
+
+    // ---- outputs: jerk[0] = (B' mu)_0, then src/LinearMpcZmp.cpp:72-78
     const double u0 = Grp::sum(row ? bi * mu : 0.0);
-    const double zmin0 = Grp::bcast(zl, 0), zmax0 = Grp::bcast(zh, 0);
     if(valid && li == 0)
     {
       const double cdt = control_dt < 0 ? P.dt : control_dt;
       const double com_acc = ax + cdt * u0;
       const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
       double zv = com_pos + P.c2 * com_acc;
-      zv = zv < zmin0 ? zmin0 : (zmax0 < zv ? zmax0 : zv);
+      zv = zv < zl ? zl : (zh < zv ? zh : zv);
       zmp[qp] = zv;
       if(status) status[qp] = (passes << 8) | st;
     }
     if(jerk)
     {
-      // u_j = sum_{w in W, w >= j} b[w - j] mu_w
-      const int qmax = Grp::wave_max_of_group_uniform(valid ? q : 0);
-      const double muw = __shfl(mu, slot_idx, LG);
+      // u_j = sum_{i >= j} b[i - j] mu_i   (mu is zero outside W)
+      scr[li] = row ? mu : 0.0;
+      __builtin_amdgcn_wave_barrier();
       double uj = 0.0;
-      for(int s = 0; s < qmax; ++s)
+#pragma unroll 4
+      for(int i = 0; i < NP; ++i)
       {
-        const int w = Grp::bcast(slot_idx, s);
-        const double m = Grp::bcast(muw, s);
-        const int dlt = w - li;
+        const double m = scr[i];
+        const int dlt = i - li;
         const double bv = bs[dlt >= 0 ? dlt : 0];
-        uj = (s < q && dlt >= 0) ? fma(bv, m, uj) : uj;
+        uj = (dlt >= 0) ? fma(bv, m, uj) : uj;
       }
       if(row) jerk[qp * N + li] = uj;
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -390,7 +423,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
            double * jerk, int32_t * status, hipStream_t stream)
 {
   constexpr int QPW = 64 / LG;
-  const size_t lds = ((size_t)LG * LG + LG + (size_t)WAVES * LG * 64) * sizeof(double);
+  const size_t lds = ((size_t)LG * LG + LG + (size_t)WAVES * QPW * ZmpScratch<LG>::kSize) * sizeof(double);
   static bool attr_set = false;
   if(!attr_set)
   {
@@ -401,10 +434,9 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   const int64_t nqp = 2 * n;
   const int64_t ntask = (nqp + QPW - 1) / QPW;
   const int64_t want = (ntask + WAVES - 1) / WAVES;
-  // resident blocks: LDS-bound (160 KiB per CU)
-  const int per_cu = (int)std::max<size_t>(1, (160 * 1024) / lds);
-  const int64_t resident = (int64_t)h->num_cu * per_cu;
-  const int grid = (int)std::min<int64_t>(want, resident * 4);
+  // a few blocks per resident slot: the hardware dispatcher then evens out the data-dependent pivot counts
+  const int64_t resident = (int64_t)h->num_cu * (16 / WAVES);
+  const int grid = (int)std::min<int64_t>(want, resident * 8);
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
