@@ -99,6 +99,15 @@ struct WaveGroup
     return mine ? __ffs((int)mine) - 1 : 32;
   }
 
+  // pred as evaluated by lane `src` (group-relative, group uniform) of the caller's group
+  static __device__ __forceinline__ bool bit(bool pred, int src)
+  {
+    const unsigned long long m = __ballot(pred);
+    if(LG == 64) return (m >> src) & 1ull;
+    const unsigned mine = (threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m;
+    return (mine >> src) & 1u;
+  }
+
   static __device__ __forceinline__ bool any(bool pred)
   {
     const unsigned long long m = __ballot(pred);

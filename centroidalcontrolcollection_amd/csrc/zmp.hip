@@ -42,14 +42,48 @@ struct ZmpDev
 
 constexpr double kInf = __builtin_huge_val();
 
-// scratch doubles per group: the published row [0, NP), then sign / reciprocal pivot
+// scratch doubles per group: the broadcast pivot row [0, NP), then the reciprocal pivot
 template<int NP>
 struct ZmpScratch
 {
-  static constexpr int kSig = NP;
-  static constexpr int kRp = NP + 1;
+  static constexpr int kRp = NP;
   static constexpr int kSize = NP + 8; // keeps every group's base 16-byte aligned
 };
+
+typedef double v16d __attribute__((ext_vector_type(16)));
+
+// Row li of the tableau in this lane's VGPRs, as 16-wide register tuples so that a wave-uniform column index
+// is one s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off (no LDS, no scratch memory).
+template<int NP>
+struct RowRegs
+{
+  v16d t[NP / 16];
+
+  // element `u` of the row, u uniform across the wavefront (held in an SGPR)
+  __device__ __forceinline__ double at_uniform(int u) const
+  {
+    double r = t[0][u & 15];
+#pragma unroll
+    for(int k = 1; k < NP / 16; ++k)
+    {
+      const double e = t[k][u & 15];
+      r = ((u >> 4) == k) ? e : r;
+    }
+    return r;
+  }
+};
+
+// element idx of the row where idx is uniform inside each LG-lane group (lane i of a group gets T[i][idx])
+template<int LG, int NP>
+__device__ __forceinline__ double row_at_group_uniform(const RowRegs<NP> & T, int idx)
+{
+  const int u0 = __builtin_amdgcn_readlane(idx, 0);
+  const double c0 = T.at_uniform(u0);
+  if(LG == 64) return c0;
+  const int u1 = __builtin_amdgcn_readlane(idx, 32);
+  const double c1 = T.at_uniform(u1);
+  return (threadIdx.x & 32) ? c1 : c0;
+}
 
 template<int LG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
@@ -64,18 +98,18 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double * Gs = smem;           // [NP][NP]
   double * bs = smem + NP * NP; // [NP]
+  double * As = bs + NP;        // [NP][3]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & (LG - 1), grp = lane / LG;
-  double * scr = smem + NP * NP + NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
+  double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
   const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
   for(int k = tid; k < NP * NP; k += WAVES * 64) Gs[k] = P.G[k];
   for(int k = tid; k < NP; k += WAVES * 64) bs[k] = P.b[k];
+  for(int k = tid; k < 3 * NP; k += WAVES * 64) As[k] = P.A[k];
   __syncthreads();
 
   const int N = P.N;
-  const double a0 = P.A[li * 3 + 0], a1 = P.A[li * 3 + 1], a2 = P.A[li * 3 + 2];
-  const double bi = bs[li];
   const int maxpass = 20 * N + 100;
 
   const long ntask = (nqp + QPW - 1) / QPW;
@@ -86,180 +120,182 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
     const bool row = valid && li < N;
 
     // ---- src/LinearMpcZmp.cpp:54-66: lo/hi of the box on B u
-    double px = 0, vx = 0, ax = 0, zl = 0, zh = 0;
-    if(valid)
-    {
-      px = x0[qp * 3 + 0];
-      vx = x0[qp * 3 + 1];
-      ax = x0[qp * 3 + 2];
-    }
+    double lo = -kInf, hi = kInf;
     if(row)
     {
-      zl = zlim[qp * 2 * N + li];
-      zh = zlim[qp * 2 * N + N + li];
+      const double fr = As[li * 3 + 0] * x0[qp * 3 + 0] + As[li * 3 + 1] * x0[qp * 3 + 1]
+                        + As[li * 3 + 2] * x0[qp * 3 + 2]; // (A_seq x0)_i
+      lo = zlim[qp * 2 * N + li] - fr;
+      hi = zlim[qp * 2 * N + N + li] - fr;
     }
-    const double fr = a0 * px + a1 * vx + a2 * ax; // (A_seq x0)_i
-    const double lo = row ? zl - fr : -kInf;
-    const double hi = row ? zh - fr : kInf;
-    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
-    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
 
     int st = CCC_STATUS_SOLVED;
     if(Grp::any(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
 
-    // ---- tableau T = G (W empty): lane li holds row li = column li of the symmetric G; the diagonal
-    //      lives in dg (the in-row copy T[li] is never read by its owner and is patched on publication)
-    double T[NP];
+    // ---- tableau T = G (W empty): lane li holds row li = column li of the symmetric G.  The diagonal lives
+    //      in dg: the in-row copy T[li][li] is never read by its owner (dgm mirrors its bits for the
+    //      closing refinement).
+    RowRegs<NP> T;
 #pragma unroll
-    for(int j = 0; j < NP; ++j) T[j] = Gs[j * NP + li];
+    for(int j = 0; j < NP; ++j) T.t[j / 16][j % 16] = Gs[j * NP + li];
     double dg = Gs[li * NP + li];
-    double dgm = dg; // bitwise mirror of the (unreadable) in-row register T[li], see the refinement below
+    double dgm = dg;
 
     double z = 0.0, mu = 0.0; // z = (G mu)_li, mu = multiplier of row li
-    double dact = 0.0;         // bound row li sits on while it is in W
     bool inW = false;
-    int p = 0;                  // entering row (group uniform)
-    double psig = 0.0, pd = 0.0; // meaningful in lane p only: side (+1 lower, -1 upper) and bound it moves to
+    bool side = false;        // while in W: true = sits on lo, false = sits on hi
+    int p = 0;                // entering row   (group uniform)
+    double sig = 0.0;         // its side +1/-1 (group uniform)
     bool done = !valid || st != CCC_STATUS_SOLVED;
     bool need_select = true;
     int passes = 0;
 
+    // -- Goldfarb-Idnani step 1: the most violated row enters (group-uniform result in p / sig / done)
+    auto select_entering = [&]() {
+      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
+      const double score = (inW || !row) ? -kInf : fmax(sl, sh);
+      const double m = Grp::max(score);
+      const int cand = Grp::first(score == m);
+      const bool cand_lower = Grp::bit(sl >= sh, cand);
+      if(need_select && !done)
+      {
+        if(m > 0.0)
+        {
+          p = cand;
+          sig = cand_lower ? 1.0 : -1.0;
+        }
+        else
+          done = true;
+      }
+    };
+
     for(int round = 0; round < 3; ++round)
     {
-    for(;;)
-    {
-      // -- Goldfarb-Idnani step 1: the most violated row enters
-      if(__ballot(need_select && !done) != 0ull)
-      {
-        const double sl = (lo - z) - tl, sh = (z - hi) - th;
-        const double score = (inW || !row) ? -kInf : fmax(sl, sh);
-        const double m = Grp::max(score);
-        const int cand = Grp::first(score == m);
-        if(need_select && !done)
+      select_entering();
+      // one trip = one pivot (a row enters W or leaves it).  Written as an explicit guarded do-while: with a
+      // top-tested loop hipcc keeps a second copy of the register-resident row and moves it back every trip
+      if(__ballot(!done) != 0ull) do
         {
-          if(m > 0.0)
+          // -- column p of T = {T[i][p]}: search direction on W, Schur complement elsewhere
+          const bool isp = (li == p);
+          double c = row_at_group_uniform<LG, NP>(T, p);
+          c = isp ? dg : c;
+
+          // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
+          const double dm = -sig * c;
+          const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+          const double pd = sig > 0.0 ? lo : hi;
+          const double num = isp ? sig * (pd - z) : -mu;
+          const double den = isp ? dg : dm;
+          const double ratio = (!done && (isp || blocking)) ? num / den : kInf;
+          const double t = Grp::min(ratio);
+          int kk = Grp::first(ratio == t);
+          if(!done && kk >= LG)
+          { // NaN step: numerical breakdown, report instead of spinning
+            done = true;
+            st = CCC_STATUS_MAX_ITER;
+          }
+          kk = kk >= LG ? 0 : kk;
+          const bool isadd = (kk == p);
+          const bool isk = (li == kk);
+          const double s = isadd ? 1.0 : -1.0;
+          if(!done)
           {
-            p = cand;
-            if(li == cand)
+            if(inW)
+              mu = fma(t, dm, mu);
+            else
+              z = fma(sig * t, c, z);
+            if(isp) mu += sig * t;
+          }
+
+          // -- pivot row kk (add: p itself; drop: the blocking row).  Every lane publishes its element of
+          //    column kk; lane kk publishes (pivot - s) instead, which makes the generic update write column kk:
+          //    T'_ij = T_ij - (v_i rp) v_j ;  column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ;  row kk: g = 1 - s rp
+          double v = c;
+          if(__ballot(!done && !isadd) != 0ull)
+          {
+            const double vk = row_at_group_uniform<LG, NP>(T, kk);
+            v = isadd ? c : vk;
+          }
+          v = isk ? dg - s : v;
+          scr[li] = v;
+          if(isk) scr[Scr::kRp] = 1.0 / dg;
+          __builtin_amdgcn_wave_barrier();
+          const double rp = scr[Scr::kRp];
+          double g = isk ? (1.0 - s * rp) : v * rp;
+          g = done ? 0.0 : g;
+          const double ng = -g;
+          {
+            // rank-1 update of the register-resident row, in place.  Software pipeline: two chunks of 8
+            // broadcast values in flight (32 VGPRs) so that row + state fit the VGPR budget; the empty asm
+            // statements pin the issue order, the tied operands keep the FMAs in place.
+            constexpr int CH = 8, NCH = NP / CH;
+            double2 buf[2][CH / 2];
+#pragma unroll
+            for(int ch = 0; ch < 2 && ch < NCH; ++ch)
+#pragma unroll
+              for(int q = 0; q < CH / 2; ++q) buf[ch][q] = scr2[ch * (CH / 2) + q];
+#pragma unroll
+            for(int ch = 0; ch < NCH; ++ch)
             {
-              psig = (sl >= sh) ? 1.0 : -1.0;
-              pd = (sl >= sh) ? lo : hi;
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for(int q = 0; q < CH / 2; ++q)
+              {
+                const int j = ch * CH + 2 * q;
+                double t0 = T.t[j / 16][j % 16], t1 = T.t[(j + 1) / 16][(j + 1) % 16];
+                asm("v_fma_f64 %0, %2, %3, %0\n\tv_fma_f64 %1, %2, %4, %1"
+                    : "+v"(t0), "+v"(t1)
+                    : "v"(ng), "v"(buf[ch & 1][q].x), "v"(buf[ch & 1][q].y));
+                T.t[j / 16][j % 16] = t0;
+                T.t[(j + 1) / 16][(j + 1) % 16] = t1;
+              }
+              if(ch + 2 < NCH)
+              {
+#pragma unroll
+                for(int q = 0; q < CH / 2; ++q) buf[ch & 1][q] = scr2[(ch + 2) * (CH / 2) + q];
+              }
             }
           }
-          else
-            done = true;
-        }
-      }
-      if(__ballot(!done) == 0ull) break;
-
-      // -- lane p publishes row p (= column p of T): search direction for W, Schur complement elsewhere
-      if(li == p && !done)
-      {
-#pragma unroll
-        for(int j = 0; j < NP; j += 2) *reinterpret_cast<double2 *>(scr + j) = make_double2(T[j], T[j + 1]);
-        scr[p] = dg;
-        scr[Scr::kSig] = psig;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const double c = scr[li];
-      const double sig = scr[Scr::kSig];
-
-      // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
-      const double dm = -sig * c;
-      const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-      const bool isp = (li == p);
-      const double num = isp ? psig * (pd - z) : -mu;
-      const double den = isp ? dg : dm;
-      const double ratio = (!done && (isp || blocking)) ? num / den : kInf;
-      const double t = Grp::min(ratio);
-      int kk = Grp::first(ratio == t);
-      if(!done && kk >= LG)
-      { // NaN step: numerical breakdown, report instead of spinning
-        done = true;
-        st = CCC_STATUS_MAX_ITER;
-      }
-      kk = kk >= LG ? 0 : kk;
-      const bool isadd = (kk == p);
-      const double s = isadd ? 1.0 : -1.0;
-      if(!done)
-      {
-        if(inW)
-          mu = fma(t, dm, mu);
-        else
-          z = fma(sig * t, c, z);
-        if(isp) mu += sig * t;
-      }
-
-      // -- pivot row kk (add: p itself, already published; drop: the blocking row): patch the diagonal so that
-      //    the generic update writes column kk, and publish 1/pivot
-      if(li == kk && !done)
-      {
-        if(!isadd)
-        {
-#pragma unroll
-          for(int j = 0; j < NP; j += 2) *reinterpret_cast<double2 *>(scr + j) = make_double2(T[j], T[j + 1]);
-        }
-        scr[kk] = dg - s;
-        scr[Scr::kRp] = 1.0 / dg;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const double v = scr[li];
-      const double rp = scr[Scr::kRp];
-      // T'_ij = T_ij - (v_i rp) v_j ; column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ; row kk: g = 1 - s rp
-      double g = (li == kk) ? (1.0 - s * rp) : v * rp;
-      g = done ? 0.0 : g;
-#pragma unroll
-      for(int j0 = 0; j0 < NP; j0 += 8)
-      { // 8 broadcast values in flight at a time: keeps the row + state inside 128 VGPRs (4 waves/SIMD)
-        const double2 v0 = scr2[j0 / 2 + 0], v1 = scr2[j0 / 2 + 1], v2 = scr2[j0 / 2 + 2], v3 = scr2[j0 / 2 + 3];
-        T[j0 + 0] = fma(-g, v0.x, T[j0 + 0]);
-        T[j0 + 1] = fma(-g, v0.y, T[j0 + 1]);
-        T[j0 + 2] = fma(-g, v1.x, T[j0 + 2]);
-        T[j0 + 3] = fma(-g, v1.y, T[j0 + 3]);
-        T[j0 + 4] = fma(-g, v2.x, T[j0 + 4]);
-        T[j0 + 5] = fma(-g, v2.y, T[j0 + 5]);
-        T[j0 + 6] = fma(-g, v3.x, T[j0 + 6]);
-        T[j0 + 7] = fma(-g, v3.y, T[j0 + 7]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if(!done)
-      {
-        dg = (li == kk) ? -rp : fma(-g, v, dg);
-        dgm = fma(-g, v, dgm);
-        if(isadd)
-        {
-          if(isp)
+          if(!done)
           {
-            inW = true;
-            z = pd;
-            dact = pd;
+            dg = isk ? -rp : fma(ng, v, dg);
+            dgm = fma(ng, v, dgm);
+            if(isadd)
+            {
+              if(isp)
+              {
+                inW = true;
+                side = sig > 0.0;
+                z = pd;
+              }
+              need_select = true;
+            }
+            else
+            {
+              if(isk)
+              {
+                inW = false;
+                mu = 0.0;
+              }
+              need_select = false;
+            }
+            if(++passes > maxpass)
+            {
+              done = true;
+              st = CCC_STATUS_MAX_ITER;
+            }
           }
-          need_select = true;
-        }
-        else
-        {
-          if(li == kk)
-          {
-            inW = false;
-            mu = 0.0;
-          }
-          need_select = false;
-        }
-        if(++passes > maxpass)
-        {
-          done = true;
-          st = CCC_STATUS_MAX_ITER;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+          __builtin_amdgcn_wave_barrier();
+          if(__ballot(need_select && !done) != 0ull) select_entering();
+        } while(__ballot(!done) != 0ull);
 
-    // ---- closing iterative refinement against the untouched G (removes the drift of the rank-1 updates):
-    //      rho = d_W - (G mu)_W ;  mu_W += G_WW^-1 rho = -T_WW rho ;  z = G mu recomputed; a row the fresh z
-    //      shows violated re-opens the iteration (rare: rows that sat within the drift of their bound)
-    {
+      // ---- closing iterative refinement against the untouched G (removes the drift of the rank-1 updates):
+      //      rho = d_W - (G mu)_W ;  mu_W += G_WW^-1 rho = -T_WW rho ;  z = G mu recomputed; a row the fresh z
+      //      shows violated re-opens the iteration (rare: rows that sat within the drift of their bound)
       const bool ok = valid && st == CCC_STATUS_SOLVED;
       const bool act = inW && ok;
+      const double dact = side ? lo : hi;
       scr[li] = act ? mu : 0.0;
       __builtin_amdgcn_wave_barrier();
       double acc = 0.0;
@@ -279,8 +315,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
       for(int j = 0; j < NP; j += 2)
       {
         const double2 rb = scr2[j / 2];
-        tr = fma(T[j], rb.x, tr);
-        tr = fma(T[j + 1], rb.y, tr);
+        tr = fma(T.t[j / 16][j % 16], rb.x, tr);
+        tr = fma(T.t[(j + 1) / 16][(j + 1) % 16], rb.y, tr);
       }
       tr = fma(dg - dgm, rho, tr); // replace the stale in-row diagonal by the true one
       if(act) mu -= tr;
@@ -296,19 +332,20 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
         acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
       }
       if(ok) z = inW ? dact : acc;
-      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
       const bool reopen = Grp::any(ok && row && !inW && fmax(sl, sh) > 0.0);
       done = !reopen;
       need_select = true;
       __builtin_amdgcn_wave_barrier();
       if(__ballot(reopen) == 0ull) break;
     }
-    }
 
     // ---- outputs: jerk[0] = (B' mu)_0, then src/LinearMpcZmp.cpp:72-78
-    const double u0 = Grp::sum(row ? bi * mu : 0.0);
+    const double u0 = Grp::sum(row ? bs[li] * mu : 0.0);
     if(valid && li == 0)
     {
+      const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
+      const double zl = zlim[qp * 2 * N], zh = zlim[qp * 2 * N + N];
       const double cdt = control_dt < 0 ? P.dt : control_dt;
       const double com_acc = ax + cdt * u0;
       const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
@@ -334,6 +371,234 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
       if(row) jerk[qp * N + li] = uj;
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long horizons (64 < N <= 128, e.g. the reference test's 2 s @ 20 ms = 100 steps): one QP per
+// 128-thread workgroup, thread i = row i, the whole sweep tableau resident in LDS ([j][i], i fastest:
+// own-row accesses are conflict free, the pivot row is broadcast from a staging copy).  Same dual
+// active-set iteration and closing refinement as zmp_plan_kernel; built for coverage of the drop-in
+// surface, not for the headline throughput.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlkNP = 128;
+
+struct BlockRed
+{
+  double val[2];
+  int idx[2];
+};
+
+// (min value over the 128-thread block, lowest thread index attaining it; index kBlkNP if every candidate is NaN)
+__device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & vmin, int & imin)
+{
+  const int tid = threadIdx.x, w = tid >> 6;
+  const double wm = WaveGroup<64>::min(v);
+  const int wi = WaveGroup<64>::first(v == wm);
+  __syncthreads(); // red may still be read by the previous reduction
+  if((tid & 63) == 0)
+  {
+    red->val[w] = wm;
+    red->idx[w] = wi < 64 ? wi + 64 * w : kBlkNP;
+  }
+  __syncthreads();
+  const double a = red->val[0], b = red->val[1];
+  const int ia = red->idx[0], ib = red->idx[1];
+  const bool first = (ia < kBlkNP) && (a <= b || ib >= kBlkNP);
+  vmin = first ? a : b;
+  imin = first ? ia : ib;
+}
+
+__global__ __launch_bounds__(kBlkNP) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                                const double * __restrict__ zlim,
+                                                                double control_dt, double * __restrict__ zmp,
+                                                                double * __restrict__ jerk,
+                                                                int * __restrict__ status)
+{
+  constexpr int NP = kBlkNP;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double * T = smem;              // [NP][NP]
+  double * cb = smem + NP * NP;   // [NP] staging of the pivot row / of mu / of rho
+  BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
+  const int i = threadIdx.x;
+  const int N = P.N;
+  const double a0 = P.A[i * 3 + 0], a1 = P.A[i * 3 + 1], a2 = P.A[i * 3 + 2];
+  const double bi = P.b[i];
+  const int maxpass = 20 * N + 100;
+
+  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  {
+    const bool row = i < N;
+    const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
+    double zl = 0, zh = 0;
+    if(row)
+    {
+      zl = zlim[qp * 2 * N + i];
+      zh = zlim[qp * 2 * N + N + i];
+    }
+    const double fr = a0 * px + a1 * vx + a2 * ax;
+    const double lo = row ? zl - fr : -kInf;
+    const double hi = row ? zh - fr : kInf;
+    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
+    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
+    int st = CCC_STATUS_SOLVED;
+    if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
+
+    for(int j = 0; j < NP; ++j) T[j * NP + i] = P.G[j * NP + i];
+    __syncthreads();
+
+    double z = 0.0, mu = 0.0, dact = 0.0;
+    bool inW = false;
+    int p = 0;
+    double psig = 0.0, pd = 0.0;
+    bool done = st != CCC_STATUS_SOLVED; // block uniform
+    bool need_select = true;
+    int passes = 0;
+
+    for(int round = 0; round < 3 && !done; ++round)
+    {
+      while(!done)
+      {
+        if(need_select)
+        {
+          const double sl = (lo - z) - tl, sh = (z - hi) - th;
+          const double score = (inW || !row) ? -kInf : fmax(sl, sh);
+          double m;
+          int cand;
+          block_argmin(-score, red, m, cand);
+          m = -m;
+          if(!(m > 0.0)) break;
+          p = cand;
+          if(i == cand)
+          {
+            psig = (sl >= sh) ? 1.0 : -1.0;
+            pd = (sl >= sh) ? lo : hi;
+            cb[0] = psig;
+          }
+          __syncthreads();
+        }
+        else
+        {
+          if(i == p) cb[0] = psig;
+          __syncthreads();
+        }
+        const double sig = cb[0];
+        const double c = T[p * NP + i]; // column p = row p (symmetric)
+        const double dm = -sig * c;
+        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const bool isp = (i == p);
+        const double num = isp ? psig * (pd - z) : -mu;
+        const double den = isp ? c : dm;
+        const double ratio = (isp || blocking) ? num / den : kInf;
+        double t;
+        int kk;
+        block_argmin(ratio, red, t, kk);
+        if(kk >= NP)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+          break;
+        }
+        const bool isadd = (kk == p);
+        const double s = isadd ? 1.0 : -1.0;
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, c, z);
+        if(isp) mu += sig * t;
+        // pivot on row/column kk
+        const double v = T[kk * NP + i];
+        cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+        if(i == kk)
+        {
+          for(int j = 0; j < NP; ++j) T[j * NP + i] = s * cb[j] * rp; // row kk, stored as column i = kk of [j][i]
+        }
+        else
+        {
+          for(int j = 0; j < NP; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+        }
+        __syncthreads();
+        // column kk (entries [kk][i]) and the pivot itself
+        T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        __syncthreads();
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(++passes > maxpass)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+        }
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      // closing refinement (see zmp_plan_kernel)
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      double acc = 0.0;
+      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      const double rho = inW ? dact - acc : 0.0;
+      __syncthreads();
+      cb[i] = rho;
+      __syncthreads();
+      double tr = 0.0;
+      for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
+      if(inW) mu -= tr;
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      acc = 0.0;
+      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      z = inW ? dact : acc;
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
+      need_select = true;
+      if(!reopen) break;
+    }
+
+    // outputs
+    __syncthreads();
+    cb[i] = row ? mu : 0.0;
+    __syncthreads();
+    if(i == 0)
+    {
+      double u0 = 0.0;
+      for(int r = 0; r < N; ++r) u0 = fma(P.b[r], cb[r], u0);
+      const double cdt = control_dt < 0 ? P.dt : control_dt;
+      const double com_acc = ax + cdt * u0;
+      const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
+      double zv = com_pos + P.c2 * com_acc;
+      zv = zv < zl ? zl : (zh < zv ? zh : zv);
+      zmp[qp] = zv;
+      if(status) status[qp] = (passes << 8) | st;
+    }
+    if(jerk && row)
+    {
+      double uj = 0.0;
+      for(int r = i; r < N; ++r) uj = fma(P.b[r - i], cb[r], uj);
+      jerk[qp * N + i] = uj;
+    }
+    __syncthreads();
+    (void)bi;
   }
 }
 } // namespace ccc_amd
@@ -423,7 +688,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
            double * jerk, int32_t * status, hipStream_t stream)
 {
   constexpr int QPW = 64 / LG;
-  const size_t lds = ((size_t)LG * LG + LG + (size_t)WAVES * QPW * ZmpScratch<LG>::kSize) * sizeof(double);
+  const size_t lds = ((size_t)LG * LG + 4 * LG + (size_t)WAVES * QPW * ZmpScratch<LG>::kSize) * sizeof(double);
   static bool attr_set = false;
   if(!attr_set)
   {
@@ -443,6 +708,25 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
+int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
+                 double * jerk, int32_t * status, hipStream_t stream)
+{
+  const size_t lds = ((size_t)kBlkNP * kBlkNP + kBlkNP) * sizeof(double) + sizeof(BlockRed);
+  static bool attr_set = false;
+  if(!attr_set)
+  {
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t nqp = 2 * n;
+  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
+  ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  hipLaunchKernelGGL(zmp_plan_block_kernel, dim3(grid), dim3(kBlkNP), lds, stream, P, (long)nqp, x0, zlim, control_dt,
+                     zmp, jerk, status);
+  CCC_HIP_CHECK(hipGetLastError());
+  return CCC_OK;
+}
 } // namespace
 
 extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double horizon_dt, int device,
@@ -453,14 +737,14 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(!(com_height > 0) || !(horizon_duration > 0) || !(horizon_dt > 0))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_create: com_height, horizon_duration, horizon_dt must be > 0");
   const int N = (int)std::ceil(horizon_duration / horizon_dt); // src/LinearMpcZmp.cpp:13
-  if(N > 64)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > 64 is not built into this library yet", N);
+  if(N > 128)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > 128 exceeds the LDS-resident tableau", N);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   ccc_zmp * h = new ccc_zmp();
   h->device = device;
   h->N = N;
-  h->NP = N <= 32 ? 32 : 64;
+  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
   h->horizon_dt = horizon_dt;
@@ -524,7 +808,8 @@ extern "C" int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double 
   CCC_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if(h->NP == 32) return launch<32, 4>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
-  return launch<64, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
+  if(h->NP == 64) return launch<64, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
+  return launch_block(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
 }
 
 static int ensure_staging(ccc_zmp * h, int64_t n)

@@ -1,6 +1,15 @@
-cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
-mkdir -p gpurun_out/r01_trace gpurun_out/r01_pmc1 gpurun_out/r01_pmc2
-rocprofv3 --kernel-trace --stats -d gpurun_out/r01_trace -o zmp -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r01_trace/bench.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d gpurun_out/r01_pmc1 -o zmp -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01_pmc1/bench.log 2>&1
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SMEM -d gpurun_out/r01_pmc2 -o zmp -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01_pmc2/bench.log 2>&1
-ls -R gpurun_out | head -40
+#!/bin/bash
+# Profile the headline bench on the GPU box (run through gpurun from the repo root):
+#   pass 1: rocprofv3 --kernel-trace --stats   (per-kernel durations)
+#   pass 2..4: PMC counters, each in its own run (no trace domains combined with --pmc)
+# Raw output goes to gpurun_out/<tag>_*/ ; scripts/summarize_prof.py turns it into profiles/<tag>_*.
+TAG=${1:-r01}
+cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
+B="python bench.py --no-cpu-baseline"
+for d in trace pmc_sq1 pmc_sq2 pmc_fetch pmc_write; do mkdir -p gpurun_out/${TAG}_$d; done
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o zmp -- $B --steps 50 --warmup 5 > gpurun_out/${TAG}_trace/bench.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/${TAG}_pmc_sq1 -o zmp -- $B --steps 3 --warmup 1 > gpurun_out/${TAG}_pmc_sq1/bench.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/${TAG}_pmc_sq2 -o zmp -- $B --steps 3 --warmup 1 > gpurun_out/${TAG}_pmc_sq2/bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_fetch -o zmp -- $B --steps 3 --warmup 1 > gpurun_out/${TAG}_pmc_fetch/bench.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_write -o zmp -- $B --steps 3 --warmup 1 > gpurun_out/${TAG}_pmc_write/bench.log 2>&1
+find gpurun_out -name "*.csv" | head -30

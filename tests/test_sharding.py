@@ -1,0 +1,71 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU path: contiguous batch shards + all-gather of the outputs.
+The local solve is the CPU oracle here (checker standing in for the GPU kernel); what is under test is the
+sharding / gather logic of centroidalcontrolcollection_amd/sharding.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from centroidalcontrolcollection_amd import sharding
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 65536, 65537):
+        for w in (1, 2, 3, 8):
+            b = sharding.shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in b]
+            assert max(sizes) - min(sizes) <= 1
+    assert sharding.shard_bounds(65536, 8)[3] == (24576, 32768)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from centroidalcontrolcollection_amd import fixtures as fx
+        from oracle import oracle
+
+        b = fx.make_zmp_batch(n, 32, 0.0625, seed=77)
+        o = oracle.LinearMpcZmp(1.0, 2.0, 0.0625)
+
+        def solve_local(x0, zlim):
+            if x0.shape[0] == 0:
+                return torch.empty((0, 2), dtype=torch.float64)
+            r = o.plan_batch(x0.numpy(), zlim.numpy(), 0.005, want_jerk=False)
+            return torch.from_numpy(r["zmp"])
+
+        zmp = sharding.plan_sharded(solve_local, torch.from_numpy(b["x0"]), torch.from_numpy(b["zlim"]))
+        full = o.plan_batch(b["x0"], b["zlim"], 0.005, want_jerk=False)["zmp"]
+        q.put((rank, float(np.abs(zmp.numpy() - full).max()), tuple(zmp.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 37])
+def test_two_rank_gloo_shard_and_gather(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, shape in res:
+        assert shape == (n, 2)
+        assert err == 0.0

@@ -167,6 +167,36 @@ def test_short_horizon_n5():
     assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
 
 
+def test_golden_vectors_n100_block_kernel(golden_zmp):
+    """64 < N <= 128 runs the workgroup-per-QP kernel; the reference test's horizon (2 s @ 20 ms = 100 steps)."""
+    mpc = LinearMpcZmp(1.0, 2.0, 0.02)
+    assert mpc.horizon_steps_ == 100
+    r = mpc.planOnceBatch(golden_zmp["n100_x0"], golden_zmp["n100_zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == _lib.CCC_STATUS_SOLVED)
+    assert np.abs(r["zmp"] - golden_zmp["n100_zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], golden_zmp["n100_jerk"]) <= JERK_RTOL
+    b = fx.make_zmp_batch(300, 100, 0.02, seed=29)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+
+
+def test_reference_scenario_n100_closed_loop():
+    """BASELINE.json configs[0]: TestLinearMpcZmp.cpp:15-126 exactly (2 s horizon @ 20 ms, sim_dt 5 ms, 10 s, two
+    kicks) through planOnce(callback, ...): the reference's per-cycle and final property assertions, and the
+    final CoM agrees with the oracle-driven replay."""
+    mpc = LinearMpcZmp(1.0, 2.0, 0.02)
+    log, fin = fx.run_closed_loop(mpc.planOnce, end_time=10.0)
+    assert len(log) == 2000
+    for rec in log:
+        assert np.all(rec["zmp"] - rec["zmin"] >= 0) and np.all(rec["zmax"] - rec["zmp"] >= 0)
+    assert np.all(fin["zmp"] - fin["zmin"] >= 0) and np.all(fin["zmax"] - fin["zmp"] >= 0)
+    assert np.all(fin["com"] - fin["zmin"] >= 0) and np.all(fin["zmax"] - fin["com"] >= 0)
+    assert np.abs(fin["com"] - np.array([0.64215196, -0.05244137])).max() < 1e-6  # oracle replay, SURVEY.md App. C
+
+
 def test_plan_once_callback_surface_closed_loop():
     """The reference's own test scenario (TestLinearMpcZmp.cpp:15-126) through planOnce(callback, ...), with a
     50-step horizon (2 s @ 40 ms): property assertions of :86-87 and :106-109."""
