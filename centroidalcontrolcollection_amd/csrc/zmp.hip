@@ -152,14 +152,18 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 
     // -- Goldfarb-Idnani step 1: the most violated row enters (group-uniform result in p / sig / done)
     auto select_entering = [&]() {
+      // Any violated row is a valid entering row; "most violated" is only a heuristic, so the argmax runs on
+      // fp32 keys (one v_max_f32 + DPP per butterfly step) while the violated / not-violated decision stays exact.
       const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
-      const double score = (inW || !row) ? -kInf : fmax(sl, sh);
-      const double m = Grp::max(score);
-      const int cand = Grp::first(score == m);
+      const double score = fmax(sl, sh);
+      const bool violated = row && !inW && score > 0.0;
+      const float key = violated ? fmaxf((float)score, 1.17549435e-38f) : -1.0f;
+      const float m = Grp::max(key);
+      const int cand = Grp::first(key == m);
       const bool cand_lower = Grp::bit(sl >= sh, cand);
       if(need_select && !done)
       {
-        if(m > 0.0)
+        if(m > 0.0f)
         {
           p = cand;
           sig = cand_lower ? 1.0 : -1.0;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
           const double pd = sig > 0.0 ? lo : hi;
           const double num = isp ? sig * (pd - z) : -mu;
           const double den = isp ? dg : dm;
-          const double ratio = (!done && (isp || blocking)) ? num / den : kInf;
+          const double ratio = (!done && (isp || blocking)) ? num * fast_rcp(den) : kInf;
           const double t = Grp::min(ratio);
           int kk = Grp::first(ratio == t);
           if(!done && kk >= LG)
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
           }
           v = isk ? dg - s : v;
           scr[li] = v;
-          if(isk) scr[Scr::kRp] = 1.0 / dg;
+          if(isk) scr[Scr::kRp] = fast_rcp(dg);
           __builtin_amdgcn_wave_barrier();
           const double rp = scr[Scr::kRp];
           double g = isk ? (1.0 - s * rp) : v * rp;
