@@ -137,7 +137,11 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
     //      closing refinement).
     RowRegs<NP> T;
 #pragma unroll
-    for(int j = 0; j < NP; ++j) T.t[j / 16][j % 16] = Gs[j * NP + li];
+    for(int j = 0; j < NP; ++j)
+    {
+      if(j % 8 == 0) asm volatile("" ::: "memory");
+      T.t[j / 16][j % 16] = Gs[j * NP + li];
+    }
     double dg = Gs[li * NP + li];
     double dgm = dg;
 
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 #pragma unroll
       for(int j = 0; j < NP; j += 2)
       {
+        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
         const double2 mb = scr2[j / 2];
         acc = fma(Gs[j * NP + li], mb.x, acc);
         acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 #pragma unroll
       for(int j = 0; j < NP; j += 2)
       {
+        if(j % 8 == 0) asm volatile("" ::: "memory");
         const double2 rb = scr2[j / 2];
         tr = fma(T.t[j / 16][j % 16], rb.x, tr);
         tr = fma(T.t[(j + 1) / 16][(j + 1) % 16], rb.y, tr);
@@ -331,6 +337,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 #pragma unroll
       for(int j = 0; j < NP; j += 2)
       {
+        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
         const double2 mb = scr2[j / 2];
         acc = fma(Gs[j * NP + li], mb.x, acc);
         acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
