@@ -29,6 +29,19 @@ ALGO_BYTES_PER_SOLVE = 1088  # 48 B state + 1024 B limits in, 16
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+def measured_traffic(n):
+    """HBM bytes per launch from the PMC passes of scripts/prof_zmp.sh (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE,
+    summarised by scripts/summarize_prof.py into profiles/zmp_hbm_traffic.json); None if not collected for this batch."""
+    path = os.path.join(ROOT, "profiles", "zmp_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("algorithmic_bytes_per_launch") == ALGO_BYTES_PER_SOLVE * n:
+            return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(batch, seconds_budget=20.0):
     """Time the CPU oracle (plain-C port of the reference path, oracle/) on this host's cores on a bounded
     sample of the same workload; also returns its answers for a parity spot check."""
@@ -151,7 +164,8 @@ def main():
                        "batch_per_gpu": n, "horizon_steps": N, "parallelism": "batch-sharded x%d" % world,
                        "collective": "all_gather(zmp)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
                          "kernel": "zmp_plan_kernel<32,4>", "kernel_avg_ms": kavg * 1e3,
                          "note": "algorithmic bytes = 1088 B/solve x batch; the kernel is fp64-VALU/LDS-latency "
                                  "bound (iterative active set), see DESIGN.md"},

@@ -211,3 +211,24 @@ def test_plan_once_callback_surface_closed_loop():
 def test_bad_shapes_raise(mpc32):
     with pytest.raises(ValueError):
         mpc32.planOnceBatch(np.zeros((4, 2, 3)), np.zeros((4, 2, 2, 31)))
+
+
+def test_cpp_header_shim_reference_scenario():
+    """Host C++ against include/CCC/LinearMpcZmp.h (examples/closed_loop_linear_mpc_zmp.cpp): the reference's
+    TestLinearMpcZmp scenario at its own horizon (N=100) and at the headline horizon (N=32)."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "closed_loop_linear_mpc_zmp")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    for dt, steps in (("0.02", 100), ("0.0625", 32)):
+        out = subprocess.run([exe, dt], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "horizon_steps=%d" % steps in out.stdout and "violations=0" in out.stdout and "com_inside=1" in out.stdout
+    # same closed loop through the Python mirror: final CoM agrees (same kernels, same inputs)
+    fin_cpp = [float(v) for v in subprocess.run([exe, "0.02"], capture_output=True, text=True).stdout.split("final_com=")[1].split()[:2]]
+    assert np.abs(np.array(fin_cpp) - np.array([0.64215196, -0.05244137])).max() < 1e-6
