@@ -1,0 +1,221 @@
+"""Input generators for the DDP paths (DdpCentroidal / DdpSingleRigidBody): restated reference fixtures + synthetic batches.
+
+Restates (numpy, host side -- these produce INPUTS, they are not on the timed path):
+  /root/reference/tests/src/ContactManager.h:10-21          makeContactFromRect (4 vertices, mu = 0.5)
+  ForceColl::SurfaceContact / FrictionPyramid (EXTERNAL, not in the reference tree; convention fixed here, see
+      `friction_pyramid`: 4 ridges per vertex, normalize([mu cos th, mu sin th, 1]), th = 2 pi i / 4 -- SURVEY.md B.2)
+  ForceColl::calcTotalWrench (EXTERNAL; [moment; force] about an origin, tests/src/TestDdpCentroidal.cpp:119-121)
+  /root/reference/tests/src/SimModels.h:233-340             CentroidalSim (exact ZOH of the 18-state linear model)
+  /root/reference/tests/src/TestDdpCentroidal.cpp:35-80     the contact / reference schedule of the closed-loop test
+and the synthetic workloads of SURVEY.md section 8(d) (`make_centroidal_batch`, `make_srb_batch`).
+
+Flattened problem layout (shared by oracle and C-ABI), per instance:
+  phase_dim [P] i32, phase_vertex [P,M,3], phase_ridge [P,M,3], step_phase [N] i32, ref_pos [N+1,3]
+  (+ ref_ori [N+1,3], inertia [3,3] for the single-rigid-body model).
+"""
+import math
+
+import numpy as np
+
+G = 9.80665
+
+
+def friction_pyramid(mu=0.5, ridge_num=4):
+    """Ridge directions of one vertex in the contact frame (z = normal)."""
+    out = []
+    for i in range(ridge_num):
+        th = 2.0 * math.pi * i / ridge_num
+        v = np.array([mu * math.cos(th), mu * math.sin(th), 1.0])
+        out.append(v / np.linalg.norm(v))
+    return np.array(out)
+
+
+def contact_from_rect(rect_min, rect_max, mu=0.5):
+    """ContactManager.h:10-21: vertices (min,min),(min.x,max.y),(max,max),(max.x,min.y) at z=0, identity pose.
+    Returns (vertex [16,3], ridge [16,3]) in contact -> vertex -> ridge order (DdpCentroidal.cpp:49-60)."""
+    verts = [(rect_min[0], rect_min[1], 0.0), (rect_min[0], rect_max[1], 0.0), (rect_max[0], rect_max[1], 0.0),
+             (rect_max[0], rect_min[1], 0.0)]
+    pyr = friction_pyramid(mu)
+    V, R = [], []
+    for v in verts:
+        for r in pyr:
+            V.append(v)
+            R.append(r)
+    return np.array(V, dtype=np.float64), np.array(R, dtype=np.float64)
+
+
+def total_wrench(vertex, ridge, scales, origin):
+    """ForceColl::calcTotalWrench: returns (moment [3], force [3]) of sum_r scales_r * ridge_r at vertex_r about origin."""
+    m = len(scales)
+    f = (np.asarray(scales)[:, None] * ridge[:m]).sum(axis=0) if m else np.zeros(3)
+    n = (np.asarray(scales)[:, None] * np.cross(vertex[:m] - origin, ridge[:m])).sum(axis=0) if m else np.zeros(3)
+    return n, f
+
+
+class CentroidalSim:
+    """SimModels.h:233-340: state (pos, ori, vel, ang_vel, lin_momentum, ang_momentum); input wrench (force, moment about
+    the CoM).  The continuous model is a chain of integrators, so the ZOH of StateSpaceModel.h:205-214 is exact:
+    x += v dt + a dt^2/2, v += a dt, momentum += wrench dt."""
+
+    def __init__(self, mass, moment_of_inertia, sim_dt):
+        self.mass, self.inertia, self.dt = float(mass), np.asarray(moment_of_inertia, dtype=np.float64), float(sim_dt)
+        self.pos, self.ori = np.zeros(3), np.zeros(3)
+        self.vel, self.ang_vel = np.zeros(3), np.zeros(3)
+        self.lin_mom, self.ang_mom = np.zeros(3), np.zeros(3)
+
+    def update(self, force, moment):
+        dt = self.dt
+        a = np.asarray(force) / self.mass + np.array([0.0, 0.0, -G])
+        al = np.asarray(moment) / self.inertia
+        self.pos = self.pos + self.vel * dt + 0.5 * a * dt * dt
+        self.ori = self.ori + self.ang_vel * dt + 0.5 * al * dt * dt
+        self.vel = self.vel + a * dt
+        self.ang_vel = self.ang_vel + al * dt
+        self.lin_mom = self.lin_mom + (np.asarray(force) + np.array([0.0, 0.0, -self.mass * G])) * dt
+        self.ang_mom = self.ang_mom + np.asarray(moment) * dt
+
+    def addDisturb(self, lin_impulse_per_mass, ang_impulse_per_mass):
+        # SimModels.h:326-330: velocities only (the momentum states are separate integrators)
+        self.vel = self.vel + np.asarray(lin_impulse_per_mass)
+        self.ang_vel = self.ang_vel + np.asarray(ang_impulse_per_mass)
+
+
+def empty_problem(n, N, P, M, srb=False):
+    prob = dict(phase_dim=np.zeros((n, P), dtype=np.int32), phase_vertex=np.zeros((n, P, M, 3)),
+                phase_ridge=np.zeros((n, P, M, 3)), step_phase=np.zeros((n, N), dtype=np.int32),
+                ref_pos=np.zeros((n, N + 1, 3)))
+    if srb:
+        prob["ref_ori"] = np.zeros((n, N + 1, 3))
+        prob["inertia"] = np.tile(np.eye(3), (n, 1, 1))
+    return prob
+
+
+def reference_schedule(t, second_rect_x=(0.4, 0.6)):
+    """TestDdpCentroidal.cpp:35-80 at time t (the +1e-6 of :39,:60 included): (phase id, ref pos)."""
+    t = t + 1e-6
+    if t < 1.4:
+        return 0, np.array([0.0, 0.0, 1.0])
+    if t < 1.6:
+        return 1, np.array([0.25, 0.0, 1.2])
+    return 2, np.array([0.5, 0.0, 1.0])
+
+
+def reference_problem(current_time, N, dt, P=4, M=16, rect_half=(0.1, 0.1), srb=False, inertia=None,
+                      ori_ref_func=None):
+    """One flattened instance of the reference closed-loop scenario sampled at current_time + i*dt, i = 0..N."""
+    prob = empty_problem(1, N, P, M, srb)
+    hx, hy = rect_half
+    V0, R0 = contact_from_rect((-hx, -hy), (hx, hy))
+    V2, R2 = contact_from_rect((0.5 - hx, -hy), (0.5 + hx, hy))
+    prob["phase_dim"][0, :3] = [16, 0, 16]
+    prob["phase_vertex"][0, 0], prob["phase_ridge"][0, 0] = V0, R0
+    prob["phase_vertex"][0, 2], prob["phase_ridge"][0, 2] = V2, R2
+    for i in range(N + 1):
+        ph, ref = reference_schedule(current_time + i * dt)
+        if i < N:
+            prob["step_phase"][0, i] = ph
+        prob["ref_pos"][0, i] = ref
+        if srb and ori_ref_func is not None:
+            prob["ref_ori"][0, i] = ori_ref_func(current_time + i * dt)
+    if srb and inertia is not None:
+        prob["inertia"][0] = inertia
+    return prob
+
+
+def centroidal_weights(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0)):
+    """WeightParam of TestDdpCentroidal.cpp:28-31 on top of the defaults of DdpCentroidal.h:66-80."""
+    return dict(run=list(running_pos) + [0.0] * 3 + [1.0] * 3, term=list(terminal_pos) + [0.0] * 3 + [1.0] * 3,
+                force=1e-6)
+
+
+def srb_weights(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0), running_ori=0.5, terminal_ori=0.5):
+    """WeightParam of TestDdpSingleRigidBody.cpp:28-33 on top of the defaults of DdpSingleRigidBody.h:89-97."""
+    return dict(run=list(running_pos) + [running_ori] * 3 + [0.01] * 6,
+                term=list(terminal_pos) + [terminal_ori] * 3 + [0.01] * 6, force=1e-6)
+
+
+def make_centroidal_batch(n, N=100, dt=0.03, mass=100.0, P=4, M=16, seed=20250928, srb=False):
+    """Synthetic DDP workload of SURVEY.md section 8(d): rect 0.2x0.2 contact at the origin, a 0.2 s flight window
+    starting at U(0.9, 1.9) s, then the rect shifted by U(0.2, 0.6) in x; reference CoM height 1.0 (1.2 in flight);
+    x0: c = ref + U(-0.05, 0.05)^3, v ~ U(-0.1, 0.1)^3, L = 0.  PRNG numpy default_rng(seed) (PCG64).
+    Returns (prob, x0 [n,S])."""
+    rng = np.random.default_rng(seed)
+    prob = empty_problem(n, N, P, M, srb)
+    hx, hy = (0.1, 0.5) if srb else (0.1, 0.1)
+    V0, R0 = contact_from_rect((-hx, -hy), (hx, hy))
+    t_flight = rng.uniform(0.9, 1.9, size=n)
+    shift = rng.uniform(0.2, 0.6, size=n)
+    prob["phase_dim"][:, 0] = 16
+    prob["phase_dim"][:, 2] = 16
+    prob["phase_vertex"][:, 0] = V0
+    prob["phase_ridge"][:, 0] = R0
+    prob["phase_vertex"][:, 2] = V0[None] + np.concatenate([shift[:, None, None], np.zeros((n, 1, 2))], axis=2)
+    prob["phase_ridge"][:, 2] = R0
+    t = dt * np.arange(N + 1)[None, :] + 1e-6
+    ph = np.where(t < t_flight[:, None], 0, np.where(t < t_flight[:, None] + 0.2, 1, 2))
+    prob["step_phase"][:] = ph[:, :N]
+    ref = np.zeros((n, N + 1, 3))
+    ref[:, :, 0] = np.where(ph == 0, 0.0, np.where(ph == 1, 0.5 * shift[:, None], shift[:, None]))
+    ref[:, :, 2] = np.where(ph == 1, 1.2, 1.0)
+    prob["ref_pos"][:] = ref
+    c0 = ref[:, 0, :] + rng.uniform(-0.05, 0.05, size=(n, 3))
+    v0 = rng.uniform(-0.1, 0.1, size=(n, 3))
+    if srb:
+        prob["inertia"][:] = np.diag([40.0, 20.0, 10.0])
+        x0 = np.concatenate([c0, rng.uniform(-0.05, 0.05, size=(n, 3)), v0, rng.uniform(-0.1, 0.1, size=(n, 3))],
+                            axis=1)
+    else:
+        x0 = np.concatenate([c0, mass * v0, np.zeros((n, 3))], axis=1)
+    return prob, np.ascontiguousarray(x0)
+
+
+def srb_ori_ref(t):
+    """TestDdpSingleRigidBody.cpp:78-85 (the +1e-6 included): roll reference bump between 2.2 s and 2.4 s."""
+    t = t + 1e-6
+    return np.array([0.0, 0.0, 0.3]) if 2.2 < t < 2.4 else np.zeros(3)
+
+
+def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.005, end_time=3.0, P=4, M=16,
+                        disturb_time=1.0, ang_disturb=(0.05, 0.05, 0.0)):
+    """The control loops of TestDdpCentroidal.cpp:96-150 / TestDdpSingleRigidBody.cpp:103-170 around any
+    `plan(prob, x0 [1,S], u_init [1,N,M] | None, max_iter) -> u [1,N,M]`: first cycle cold start with the full
+    iteration budget, afterwards warm start (unshifted u_list, zeroed where the input dimension changed) with
+    max_iter = 1.  Returns per-cycle records for the reference's property assertions."""
+    inertia = np.array([40.0, 20.0, 10.0])
+    sim = CentroidalSim(mass, inertia, sim_dt)
+    sim.pos = reference_schedule(0.0)[1].copy()
+    rect_half = (0.1, 0.5) if srb else (0.1, 0.1)
+    u_prev, dims_prev = None, None
+    log, t, cycle = [], 0.0, 0
+    while t < end_time:
+        prob = reference_problem(t, N, dt, P, M, rect_half, srb, np.diag(inertia), srb_ori_ref if srb else None)
+        dims = prob["phase_dim"][0][prob["step_phase"][0]]
+        if srb:
+            x0 = np.concatenate([sim.pos, sim.ori[::-1], sim.vel, sim.ang_vel])[None]
+        else:
+            x0 = np.concatenate([sim.pos, mass * sim.vel, sim.ang_mom])[None]
+        u_init = None
+        if u_prev is not None:
+            u_init = u_prev.copy()
+            changed = dims != dims_prev
+            u_init[0, changed, :] = 0.0
+            for i in range(N):
+                u_init[0, i, dims[i]:] = 0.0
+        u = plan(prob, x0, u_init, 500 if cycle == 0 else 1)
+        u_prev, dims_prev = u, dims
+        ph = prob["step_phase"][0, 0]
+        m0 = prob["phase_dim"][0, ph]
+        moment, force = total_wrench(prob["phase_vertex"][0, ph], prob["phase_ridge"][0, ph], u[0, 0, :m0], sim.pos)
+        ref = prob["ref_pos"][0, 0]
+        log.append(dict(t=t, pos=sim.pos.copy(), ref=ref.copy(), vel=sim.vel.copy(), ang_mom=sim.ang_mom.copy(),
+                        ori=sim.ori.copy(), ang_vel=sim.ang_vel.copy(),
+                        ori_ref=(prob["ref_ori"][0, 0][::-1].copy() if srb else np.zeros(3)), force=force))
+        t += sim_dt
+        sim.update(force, moment)
+        if disturb_time <= t < disturb_time + sim_dt:
+            sim.addDisturb(np.zeros(3), ang_disturb)
+        cycle += 1
+    ref_end = reference_schedule(t)[1]
+    ori_end = srb_ori_ref(t)[::-1] if srb else np.zeros(3)
+    return log, dict(t=t, pos=sim.pos.copy(), ref=ref_end, vel=sim.vel.copy(), ang_mom=sim.ang_mom.copy(),
+                     ori=sim.ori.copy(), ori_ref=ori_end, ang_vel=sim.ang_vel.copy())

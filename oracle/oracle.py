@@ -150,3 +150,155 @@ class LinearMpcZmp:
         lib().oracle_zmp_plan_batch(self._h, n, _ptr(x0), _ptr(zlim), float(control_dt), _ptr(zmp), _ptr(jerk),
                                     _ptr(status, ctypes.c_int), _ptr(iters, ctypes.c_int), int(nthreads))
         return dict(zmp=zmp, jerk=jerk, status=status, iters=iters)
+
+
+# ===================================================================== DDP (ddp.c, ddp_models.c)
+class _DdpConfig(ctypes.Structure):
+    _fields_ = [("with_input_constraint", ctypes.c_int), ("max_iter", ctypes.c_int),
+                ("initial_lambda", ctypes.c_double), ("initial_dlambda", ctypes.c_double),
+                ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
+                ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double),
+                ("cost_update_ratio_thre", ctypes.c_double), ("cost_update_thre", ctypes.c_double),
+                ("alpha_list", ctypes.c_double * 11)]
+
+
+class _DdpModel(ctypes.Structure):
+    _fields_ = [("model", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("M", ctypes.c_int),
+                ("mass", ctypes.c_double), ("dt", ctypes.c_double),
+                ("w_run", ctypes.c_double * 12), ("w_term", ctypes.c_double * 12), ("w_force", ctypes.c_double),
+                ("force_lo", ctypes.c_double), ("force_hi", ctypes.c_double),
+                ("phase_dim", ctypes.c_void_p), ("phase_vertex", ctypes.c_void_p), ("phase_ridge", ctypes.c_void_p),
+                ("step_phase", ctypes.c_void_p), ("ref_pos", ctypes.c_void_p), ("ref_ori", ctypes.c_void_p),
+                ("inertia", ctypes.c_void_p)]
+
+
+class _DdpProblem(ctypes.Structure):
+    _fields_ = [("S", ctypes.c_int), ("N", ctypes.c_int), ("M", ctypes.c_int), ("user", ctypes.c_void_p)] + \
+               [(name, ctypes.c_void_p) for name in ("input_dim", "state_eq", "running_cost", "terminal_cost",
+                                                      "state_eq_deriv", "running_cost_deriv", "terminal_cost_deriv",
+                                                      "input_limits")]
+
+
+_ddp_bound = False
+
+
+def _bind_ddp():
+    global _ddp_bound
+    L = lib()
+    if _ddp_bound:
+        return L
+    L.oracle_ddp_default_config.argtypes = [ctypes.POINTER(_DdpConfig)]
+    L.oracle_ddp_default_config.restype = None
+    L.oracle_box_qp.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _ip]
+    L.oracle_box_qp.restype = ctypes.c_int
+    L.oracle_ddp_model_problem.argtypes = [ctypes.POINTER(_DdpModel), ctypes.POINTER(_DdpProblem)]
+    L.oracle_ddp_model_problem.restype = None
+    L.oracle_ddp_plan_batch.argtypes = [ctypes.POINTER(_DdpModel), ctypes.POINTER(_DdpConfig), ctypes.c_long,
+                                        _ip, _dp, _dp, _ip, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp,
+                                        ctypes.c_int]
+    L.oracle_ddp_plan_batch.restype = ctypes.c_int
+    L.oracle_ddp_model_eval.argtypes = [ctypes.POINTER(_DdpModel), ctypes.c_int] + [_dp] * 10
+    L.oracle_ddp_model_eval.restype = None
+    _ddp_bound = True
+    return L
+
+
+def box_qp(H, g, lo, hi, x0=None):
+    """Tassa's boxQP restated (oracle_box_qp). Returns (x, result, is_free, iters)."""
+    L = _bind_ddp()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    n = H.shape[0]
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
+    is_free = np.zeros(n, dtype=np.int32)
+    Lf = np.zeros((n, n))
+    nf = ctypes.c_int(0)
+    it = ctypes.c_int(0)
+    rc = L.oracle_box_qp(n, _ptr(H), _ptr(g), _ptr(lo), _ptr(hi), _ptr(x), _ptr(is_free, ctypes.c_int), _ptr(Lf),
+                         ctypes.byref(nf), ctypes.byref(it))
+    return x, rc, is_free.astype(bool), it.value
+
+
+class Ddp:
+    """CPU restatement of CCC::DdpCentroidal (model=0, S=9) / CCC::DdpSingleRigidBody (model=1, S=12) on
+    pre-sampled, flattened per-instance problem data (oracle/ddp.c + oracle/ddp_models.c).
+
+    weights: dict(run=[S], term=[S], force=float). Config overrides of the reference constructors
+    (src/DdpCentroidal.cpp:197-201): initial_lambda=1e-6, lambda_min=1e-8, lambda_thre=1e-7."""
+
+    def __init__(self, model, mass, horizon_dt, horizon_steps, weights, max_iter=500, P=4, M=16,
+                 force_limits=(0.0, 1e6)):
+        L = _bind_ddp()
+        self.model, self.S = int(model), (9 if model == 0 else 12)
+        self.N, self.P, self.M = int(horizon_steps), int(P), int(M)
+        self.cfg = _DdpConfig()
+        L.oracle_ddp_default_config(ctypes.byref(self.cfg))
+        self.cfg.initial_lambda = 1e-6
+        self.cfg.lambda_min = 1e-8
+        self.cfg.lambda_thre = 1e-7
+        self.cfg.max_iter = int(max_iter)
+        self.mdl = _DdpModel()
+        self.mdl.model, self.mdl.N, self.mdl.P, self.mdl.M = self.model, self.N, self.P, self.M
+        self.mdl.mass, self.mdl.dt = float(mass), float(horizon_dt)
+        for a in range(self.S):
+            self.mdl.w_run[a] = float(weights["run"][a])
+            self.mdl.w_term[a] = float(weights["term"][a])
+        self.mdl.w_force = float(weights["force"])
+        self.mdl.force_lo, self.mdl.force_hi = float(force_limits[0]), float(force_limits[1])
+
+    def plan_batch(self, prob, x0, u_init=None, nthreads=1):
+        """prob: dict(phase_dim [n,P] i32, phase_vertex [n,P,M,3], phase_ridge [n,P,M,3], step_phase [n,N] i32,
+        ref_pos [n,N+1,3], ref_ori [n,N+1,3] (SRB), inertia [n,3,3] (SRB)); x0 [n,S]; u_init [n,N,M] | None.
+        Returns dict(u [n,N,M], x [n,N+1,S], iters [n], status [n], cost [n])."""
+        L = _bind_ddp()
+        N, P, M, S = self.N, self.P, self.M, self.S
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = x0.shape[0]
+        pd = np.ascontiguousarray(prob["phase_dim"], dtype=np.int32)
+        pv = np.ascontiguousarray(prob["phase_vertex"], dtype=np.float64)
+        pr = np.ascontiguousarray(prob["phase_ridge"], dtype=np.float64)
+        sp = np.ascontiguousarray(prob["step_phase"], dtype=np.int32)
+        rp = np.ascontiguousarray(prob["ref_pos"], dtype=np.float64)
+        assert pd.shape == (n, P) and pv.shape == (n, P, M, 3) and pr.shape == (n, P, M, 3)
+        assert sp.shape == (n, N) and rp.shape == (n, N + 1, 3) and x0.shape == (n, S)
+        ro = ine = None
+        if self.model == 1:
+            ro = np.ascontiguousarray(prob["ref_ori"], dtype=np.float64)
+            ine = np.ascontiguousarray(prob["inertia"], dtype=np.float64)
+            assert ro.shape == (n, N + 1, 3) and ine.shape == (n, 3, 3)
+        ui = None if u_init is None else np.ascontiguousarray(u_init, dtype=np.float64)
+        u = np.zeros((n, N, M))
+        x = np.zeros((n, N + 1, S))
+        iters = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        cost = np.zeros(n)
+        L.oracle_ddp_plan_batch(ctypes.byref(self.mdl), ctypes.byref(self.cfg), n, _ptr(pd, ctypes.c_int), _ptr(pv),
+                                _ptr(pr), _ptr(sp, ctypes.c_int), _ptr(rp), _ptr(ro), _ptr(ine), _ptr(x0), _ptr(ui),
+                                _ptr(u), _ptr(x), _ptr(iters, ctypes.c_int), _ptr(status, ctypes.c_int), _ptr(cost),
+                                int(nthreads))
+        return dict(u=u, x=x, iters=iters, status=status, cost=cost)
+
+    def eval(self, prob, k, step, x, u):
+        """Problem callbacks of instance k at (step, x, u): dict(x_next, Fx [S,S], Fu [S,M], run_cost, term_cost,
+        Lx, Lu, Vx)."""
+        L = _bind_ddp()
+        S, M = self.S, self.M
+        arrs = {}
+        mdl = _DdpModel.from_buffer_copy(self.mdl)
+        for name, dtype in (("phase_dim", np.int32), ("phase_vertex", np.float64), ("phase_ridge", np.float64),
+                            ("step_phase", np.int32), ("ref_pos", np.float64), ("ref_ori", np.float64),
+                            ("inertia", np.float64)):
+            if name in prob and prob[name] is not None:
+                arrs[name] = np.ascontiguousarray(prob[name][k], dtype=dtype)
+                setattr(mdl, name, arrs[name].ctypes.data)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.ascontiguousarray(np.pad(np.asarray(u, dtype=np.float64), (0, M - len(u))))
+        xn, Fx, Fu = np.zeros(S), np.zeros((S, S)), np.zeros((S, M))
+        Lx, Lu, Vx = np.zeros(S), np.zeros(M), np.zeros(S)
+        rc, tc = ctypes.c_double(0), ctypes.c_double(0)
+        L.oracle_ddp_model_eval(ctypes.byref(mdl), int(step), _ptr(x), _ptr(u), _ptr(xn), _ptr(Fx), _ptr(Fu),
+                                ctypes.cast(ctypes.byref(rc), _dp), ctypes.cast(ctypes.byref(tc), _dp), _ptr(Lx),
+                                _ptr(Lu), _ptr(Vx))
+        return dict(x_next=xn, Fx=Fx, Fu=Fu, run_cost=rc.value, term_cost=tc.value, Lx=Lx, Lu=Lu, Vx=Vx)
