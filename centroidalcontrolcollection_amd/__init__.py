@@ -4,6 +4,7 @@ Drop-in for ONE hot path of isri-aist/CentroidalControlCollection: many independ
 instances solved at once by hand-written HIP kernels (gfx950) behind the C-ABI of include/ccc_amd.h.
 See DESIGN.md (scope, kernels, rooflines) and INTEGRATION.md (how the reference binds to it).
 """
+from .ddp import DdpCentroidal, DdpSingleRigidBody  # noqa: F401
 from .linear_mpc_zmp import InitialParam, LinearMpcZmp, RefData  # noqa: F401
 
-__all__ = ["LinearMpcZmp", "RefData", "InitialParam"]
+__all__ = ["LinearMpcZmp", "RefData", "InitialParam", "DdpCentroidal", "DdpSingleRigidBody"]

@@ -33,6 +33,13 @@ ABI_SYMBOLS = [
     "ccc_zmp_get_seq",
     "ccc_zmp_plan_batch_device",
     "ccc_zmp_plan_batch",
+    "ccc_ddp_default_config",
+    "ccc_ddp_create",
+    "ccc_ddp_destroy",
+    "ccc_ddp_set_config",
+    "ccc_ddp_state_dim",
+    "ccc_ddp_plan_batch_device",
+    "ccc_ddp_plan_batch",
 ]
 
 

@@ -1,0 +1,300 @@
+// ddp.hip -- batched CCC::DdpCentroidal / CCC::DdpSingleRigidBody planOnce() on MI355X: kernel + C-ABI.
+//
+// One problem instance per wavefront (one 64-thread workgroup), the whole solve -- forward rollouts, analytic
+// derivatives, backward Riccati sweep with box-QP, line search -- on the device (csrc/ddp_core.h).  The small
+// per-step matrices live in LDS (struct Mem, ~20 KB per wavefront); trajectories, candidate trajectories and the
+// feedback gains K (N x 16 x S doubles = 115 KB at N = 100) live in an HBM workspace owned by the handle, laid out
+// per instance so that a wavefront streams through contiguous memory.
+#include "common.h"
+#include "ddp_core.h"
+
+#include <cstring>
+#include <vector>
+
+namespace ccc_amd
+{
+struct DdpBatch
+{
+  const int * phase_dim;
+  const double * phase_vertex;
+  const double * phase_ridge;
+  const int * step_phase;
+  const double * ref_pos;
+  const double * ref_ori;
+  const double * inertia;
+  const double * x0;
+  const double * u_init;
+  double * u_out;
+  double * x_out; // may alias the workspace
+  double *xc, *uc, *ks, *Ks;
+  int * iters;
+  int * status;
+  double * cost;
+};
+
+template<int S, int M>
+__global__ __launch_bounds__(64) void ddp_plan_kernel(ddp::Params P, DdpBatch B, long n)
+{
+  __shared__ ddp::Mem<S, M> mem;
+  const int N = P.N;
+  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  {
+    ddp::Instance I;
+    I.phase_dim = B.phase_dim + b * P.P;
+    I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
+    I.phase_ridge = B.phase_ridge + b * P.P * M * 3;
+    I.step_phase = B.step_phase + b * N;
+    I.ref_pos = B.ref_pos + b * (N + 1) * 3;
+    I.ref_ori = B.ref_ori ? B.ref_ori + b * (N + 1) * 3 : nullptr;
+    I.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
+    I.x0 = B.x0 + b * S;
+    I.u_init = B.u_init ? B.u_init + b * N * M : nullptr;
+    I.xs = B.x_out + b * (N + 1) * S;
+    I.us = B.u_out + b * N * M;
+    I.xc = B.xc + b * (N + 1) * S;
+    I.uc = B.uc + b * N * M;
+    I.ks = B.ks + b * N * M;
+    I.Ks = B.Ks + b * N * M * S;
+    I.out_iters = B.iters ? B.iters + b : nullptr;
+    I.out_status = B.status ? B.status + b : nullptr;
+    I.out_cost = B.cost ? B.cost + b : nullptr;
+    ddp::Solver<S, M> solver(P, I, mem);
+    solver.solve();
+    __syncthreads();
+  }
+}
+} // namespace ccc_amd
+
+using namespace ccc_amd;
+
+struct ccc_ddp
+{
+  int device = 0;
+  ccc_ddp_params_t prm{};
+  ccc_ddp_config_t cfg{};
+  int S = 9;
+  int num_cu = 0;
+  // device workspace (grown on demand)
+  int64_t cap = 0;
+  double *ws_x = nullptr, *ws_xc = nullptr, *ws_uc = nullptr, *ws_k = nullptr, *ws_K = nullptr;
+  // staging for the host entry
+  int64_t hcap = 0;
+  void * d_stage = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+extern "C" void ccc_ddp_default_config(ccc_ddp_config_t * c)
+{
+  if(!c) return;
+  c->max_iter = 500;
+  c->initial_lambda = 1e-6; // src/DdpCentroidal.cpp:199
+  c->initial_dlambda = 1.0;
+  c->lambda_factor = 1.6;
+  c->lambda_min = 1e-8; // :200
+  c->lambda_max = 1e10;
+  c->k_rel_norm_thre = 1e-4;
+  c->lambda_thre = 1e-7; // :201
+  c->cost_update_ratio_thre = 0.0;
+  c->cost_update_thre = 1e-7;
+  for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
+}
+
+extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t ** out)
+{
+  if(!out || !p) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: NULL argument");
+  *out = nullptr;
+  if(p->model != CCC_DDP_CENTROIDAL && p->model != CCC_DDP_SINGLE_RIGID_BODY)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: unknown model %d", p->model);
+  if(!(p->mass > 0) || !(p->horizon_dt > 0) || p->horizon_steps <= 0 || p->max_phases <= 0)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: mass, horizon_dt, horizon_steps, max_phases must be > 0");
+  int rc = select_device(device);
+  if(rc != CCC_OK) return rc;
+  ccc_ddp * h = new ccc_ddp();
+  h->device = device;
+  h->prm = *p;
+  h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
+  ccc_ddp_default_config(&h->cfg);
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if(e != hipSuccess)
+  {
+    delete h;
+    return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  h->num_cu = prop.multiProcessorCount;
+  *out = h;
+  return CCC_OK;
+}
+
+static void free_ws(ccc_ddp * h)
+{
+  for(double ** p : {&h->ws_x, &h->ws_xc, &h->ws_uc, &h->ws_k, &h->ws_K})
+  {
+    if(*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  h->cap = 0;
+}
+
+extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
+{
+  if(!h) return;
+  (void)hipSetDevice(h->device);
+  free_ws(h);
+  if(h->d_stage) (void)hipFree(h->d_stage);
+  if(h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
+{
+  if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: NULL argument");
+  if(cfg->max_iter < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: max_iter < 0");
+  h->cfg = *cfg;
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_state_dim(const ccc_ddp_t * h)
+{
+  return h ? h->S : -1;
+}
+
+static int ensure_ws(ccc_ddp * h, int64_t n)
+{
+  if(n <= h->cap) return CCC_OK;
+  free_ws(h);
+  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES;
+  CCC_HIP_CHECK(hipMalloc(&h->ws_x, (size_t)n * (N + 1) * S * sizeof(double)));
+  CCC_HIP_CHECK(hipMalloc(&h->ws_xc, (size_t)n * (N + 1) * S * sizeof(double)));
+  CCC_HIP_CHECK(hipMalloc(&h->ws_uc, (size_t)n * N * M * sizeof(double)));
+  CCC_HIP_CHECK(hipMalloc(&h->ws_k, (size_t)n * N * M * sizeof(double)));
+  CCC_HIP_CHECK(hipMalloc(&h->ws_K, (size_t)n * N * M * S * sizeof(double)));
+  h->cap = n;
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim,
+                                         const double * phase_vertex, const double * phase_ridge,
+                                         const int32_t * step_phase, const double * ref_pos, const double * ref_ori,
+                                         const double * inertia, const double * x0, const double * u_init,
+                                         double * u_out, double * x_out, int32_t * iters, int32_t * status,
+                                         double * cost, void * stream)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: n < 0");
+  if(n == 0) return CCC_OK;
+  if(!phase_dim || !phase_vertex || !phase_ridge || !step_phase || !ref_pos || !x0 || !u_out)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: NULL required array");
+  if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  int rc = ensure_ws(h, n);
+  if(rc != CCC_OK) return rc;
+  ddp::Params P;
+  std::memset(&P, 0, sizeof(P));
+  P.model = h->prm.model;
+  P.N = h->prm.horizon_steps;
+  P.P = h->prm.max_phases;
+  P.mass = h->prm.mass;
+  P.dt = h->prm.horizon_dt;
+  for(int a = 0; a < 12; a++)
+  {
+    P.w_run[a] = h->prm.w_run[a];
+    P.w_term[a] = h->prm.w_term[a];
+  }
+  P.w_force = h->prm.w_force;
+  P.flo = h->prm.force_scale_limits[0];
+  P.fhi = h->prm.force_scale_limits[1];
+  P.max_iter = h->cfg.max_iter;
+  P.lambda0 = h->cfg.initial_lambda;
+  P.dlambda0 = h->cfg.initial_dlambda;
+  P.lambda_factor = h->cfg.lambda_factor;
+  P.lambda_min = h->cfg.lambda_min;
+  P.lambda_max = h->cfg.lambda_max;
+  P.k_rel_norm_thre = h->cfg.k_rel_norm_thre;
+  P.lambda_thre = h->cfg.lambda_thre;
+  P.ratio_thre = h->cfg.cost_update_ratio_thre;
+  P.cost_thre = h->cfg.cost_update_thre;
+  for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
+  DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
+             x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // the gains of the last horizon step are read as a box-QP warm start before they are first written
+  CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * CCC_DDP_MAX_RIDGES * sizeof(double), s));
+  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 32);
+  if(h->S == 9)
+    hipLaunchKernelGGL((ddp_plan_kernel<9, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
+  else
+    hipLaunchKernelGGL((ddp_plan_kernel<12, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
+  CCC_HIP_CHECK(hipGetLastError());
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, const double * phase_vertex,
+                                  const double * phase_ridge, const int32_t * step_phase, const double * ref_pos,
+                                  const double * ref_ori, const double * inertia, const double * x0,
+                                  const double * u_init, double * u_out, double * x_out, int32_t * iters,
+                                  int32_t * status, double * cost)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch: n < 0");
+  if(n == 0) return CCC_OK;
+  if(!phase_dim || !phase_vertex || !phase_ridge || !step_phase || !ref_pos || !x0 || !u_out)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch: NULL required array");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES, Pn = h->prm.max_phases;
+  if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // one staging allocation, carved into the arrays (all sizes are multiples of 4 bytes; doubles first)
+  struct Seg
+  {
+    const void * src;
+    void * dst_host;
+    size_t bytes;
+    size_t off;
+  };
+  std::vector<Seg> in = {{phase_vertex, nullptr, n * Pn * M * 3 * 8, 0}, {phase_ridge, nullptr, n * Pn * M * 3 * 8, 0},
+                         {ref_pos, nullptr, n * (N + 1) * 3 * 8, 0},     {ref_ori, nullptr, n * (N + 1) * 3 * 8, 0},
+                         {inertia, nullptr, (size_t)n * 9 * 8, 0},        {x0, nullptr, n * S * 8, 0},
+                         {u_init, nullptr, n * N * M * 8, 0},             {phase_dim, nullptr, n * Pn * 4, 0},
+                         {step_phase, nullptr, n * N * 4, 0}};
+  std::vector<Seg> outv = {{nullptr, u_out, n * N * M * 8, 0},
+                           {nullptr, x_out, n * (N + 1) * S * 8, 0},
+                           {nullptr, cost, (size_t)n * 8, 0},
+                           {nullptr, iters, (size_t)n * 4, 0},
+                           {nullptr, status, (size_t)n * 4, 0}};
+  size_t total = 0;
+  for(auto & s : in)
+  {
+    s.off = total;
+    total += (s.bytes + 255) / 256 * 256;
+  }
+  for(auto & s : outv)
+  {
+    s.off = total;
+    total += (s.bytes + 255) / 256 * 256;
+  }
+  if((int64_t)total > h->hcap)
+  {
+    if(h->d_stage) (void)hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->hcap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->d_stage, total));
+    h->hcap = (int64_t)total;
+  }
+  char * base = static_cast<char *>(h->d_stage);
+  for(auto & s : in)
+    if(s.src) CCC_HIP_CHECK(hipMemcpyAsync(base + s.off, s.src, s.bytes, hipMemcpyHostToDevice, h->stream));
+  auto dptr = [&](const Seg & s, const void * host) -> void * { return host ? base + s.off : nullptr; };
+  int rc = ccc_ddp_plan_batch_device(
+      h, n, (const int32_t *)dptr(in[7], phase_dim), (const double *)dptr(in[0], phase_vertex),
+      (const double *)dptr(in[1], phase_ridge), (const int32_t *)dptr(in[8], step_phase),
+      (const double *)dptr(in[2], ref_pos), (const double *)dptr(in[3], ref_ori), (const double *)dptr(in[4], inertia),
+      (const double *)dptr(in[5], x0), (const double *)dptr(in[6], u_init), (double *)(base + outv[0].off),
+      (double *)dptr(outv[1], x_out), (int32_t *)dptr(outv[3], iters), (int32_t *)dptr(outv[4], status),
+      (double *)dptr(outv[2], cost), h->stream);
+  if(rc != CCC_OK) return rc;
+  for(auto & s : outv)
+    if(s.dst_host) CCC_HIP_CHECK(hipMemcpyAsync(s.dst_host, base + s.off, s.bytes, hipMemcpyDeviceToHost, h->stream));
+  CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return CCC_OK;
+}

@@ -1,0 +1,1071 @@
+// ddp_core.h -- one wavefront = one control-limited DDP / iLQR problem instance (CCC::DdpCentroidal,
+// CCC::DdpSingleRigidBody), written as a sequence of PHASES.
+//
+// Replaces (reference file:line under /root/reference):
+//   src/DdpCentroidal.cpp:32-64, :66-83, :85-121, :123-177          problem callbacks (S = 9)
+//   src/DdpSingleRigidBody.cpp:26-38, :52-91, :93-112, :114-243     problem callbacks (S = 12)
+//   src/DdpCentroidal.cpp:229,233 / src/DdpSingleRigidBody.cpp:299,303   the external nmpc_ddp::DDPSolver::solve
+// The solver algorithm is the one frozen in SURVEY.md App. B.2 and spelled out in oracle/ddp.c (Tassa et al.,
+// control-limited DDP, box-QP by projected Newton); this file and the oracle implement the same specification
+// independently.
+//
+// Execution model: in a phase every lane runs the same body on its own elements of the small per-instance
+// matrices (all staged in LDS, struct Mem); phases are separated by a wavefront-wide barrier.  Per-lane
+// registers never carry state across phases -- uniform scalars are re-read from LDS -- which is also what
+// lets tests/emu compile this very file for the host (lanes run one after the other) and check the phase
+// logic on a machine without a GPU.  The host build is a TEST AID; the product only ever runs the HIP build.
+#pragma once
+
+#include <cmath>
+
+#if defined(__HIPCC__)
+#  include <hip/hip_runtime.h>
+#  define CCC_DDP_FN __device__ __forceinline__
+#else
+#  define CCC_DDP_FN inline
+#endif
+
+// No FMA contraction in this translation unit: every product and sum rounds separately, exactly as in the
+// oracle (oracle/ddp.c, gcc -std=c11 => -ffp-contract=off).  With IEEE sqrt and division on both sides the
+// centroidal model then reproduces the oracle's iterates bit for bit, so that the discrete decisions of the
+// algorithm (line-search acceptance, box-QP clamping, termination tests) cannot flip between the two.  The
+// kernel is bound by phase latency, not by VALU issue, so the extra v_mul/v_add pairs are not what limits it.
+#if defined(__clang__)
+#  pragma clang fp contract(off)
+#endif
+
+namespace ccc_amd
+{
+namespace ddp
+{
+constexpr int kWave = 64;
+constexpr double kGravity = 9.80665; // include/CCC/Constants.h:10
+
+template<class F>
+CCC_DDP_FN void phase(F && f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  f(static_cast<int>(threadIdx.x & 63));
+  __syncthreads(); // one wavefront per workgroup: an s_barrier that only orders this wave's LDS traffic
+#else
+  for(int lane = 0; lane < kWave; ++lane) f(lane);
+#endif
+}
+
+// Batch-constant parameters (by value to the kernel)
+struct Params
+{
+  int model; // 0 = DdpCentroidal (S = 9), 1 = DdpSingleRigidBody (S = 12)
+  int N, P;  // horizon steps, contact phases per instance
+  double mass, dt;
+  double w_run[12], w_term[12], w_force; // WeightParam
+  double flo, fhi;                       // force_scale_limits_
+  // nmpc_ddp configuration (SURVEY.md App. B.2 + overrides of src/DdpCentroidal.cpp:197-201)
+  int max_iter;
+  double lambda0, dlambda0, lambda_factor, lambda_min, lambda_max;
+  double k_rel_norm_thre, lambda_thre, ratio_thre, cost_thre;
+  double alpha[11];
+};
+
+// Per-instance problem data and workspace (global memory)
+struct Instance
+{
+  const int * phase_dim;       // [P]
+  const double * phase_vertex; // [P][M][3]
+  const double * phase_ridge;  // [P][M][3]
+  const int * step_phase;      // [N]
+  const double * ref_pos;      // [N+1][3]
+  const double * ref_ori;      // [N+1][3]  (SRB)
+  const double * inertia;      // [9]       (SRB)
+  const double * x0;           // [S]
+  const double * u_init;       // [N][M] or nullptr
+  double *xs, *us;             // current trajectory   [(N+1)][S], [N][M]   (us is the u_out of the C-ABI)
+  double *xc, *uc;             // line-search candidate
+  double *ks, *Ks;             // gains [N][M], [N][M][S]
+  int * out_iters;
+  int * out_status;
+  double * out_cost;
+};
+
+template<int S, int M>
+struct Mem
+{
+  double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
+  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * M], QuuF[M * M];
+  double T1[S * S], T2[S * M], Lf[M * M], K[M * S];
+  double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
+  double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
+  double sc[16]; // uniform scalars
+  int clamped[M], oldc[M];
+  int ic[8]; // uniform ints
+};
+
+// indices into Mem::sc / Mem::ic
+enum
+{
+  SC_VALUE = 0,
+  SC_OLDVALUE,
+  SC_SDOTG,
+  SC_STEP,
+  SC_VC,
+  SC_COST,
+  SC_COSTC,
+  SC_DV0,
+  SC_DV1,
+  SC_LAMBDA,
+  SC_DLAMBDA,
+  SC_G,
+  SC_GNORM
+};
+enum
+{
+  IC_RESULT = 0,
+  IC_CHANGED,
+  IC_ALLCL,
+  IC_OK,
+  IC_FLAG
+};
+
+CCC_DDP_FN void cross3(const double * a, const double * b, double * c)
+{
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+
+// Deterministic sin/cos (Cody-Waite reduction by pi/2 + the classic fdlibm minimax kernels), accurate to ~1 ulp for
+// |x| < 1e3.  The reference calls std::sin / std::cos (src/DdpSingleRigidBody.cpp:30-33,128-131); glibc and the GPU's
+// device libm differ from each other in the last ulp, and DDP's discrete decisions can amplify one ulp into a different
+// iterate.  Oracle and HIP kernel therefore both evaluate THIS restatement (same operations, no FMA contraction), which
+// keeps the single-rigid-body model bit-reproducible across the two; tests check it against libm to 2 ulp.
+CCC_DDP_FN void det_sincos(double x, double * s, double * c)
+{
+  const double fn = floor(x * 6.36619772367581382433e-01 + 0.5);
+  const int n = (int)fn;
+  double r = x - fn * 1.57079632673412561417e+00;
+  r = r - fn * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01
+                    + z * (8.33333333332248946124e-03
+                           + z * (-1.98412698298579493134e-04
+                                  + z * (2.75573137070700676789e-06
+                                         + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02
+                    + z * (-1.38888888888741095749e-03
+                           + z * (2.48015872894767294178e-05
+                                  + z * (-2.75573143513906633035e-07
+                                         + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double sn = r + r * z * ps;
+  const double cs = 1.0 - (0.5 * z - z * z * pc);
+  switch(n & 3)
+  {
+    case 0:
+      *s = sn;
+      *c = cs;
+      break;
+    case 1:
+      *s = cs;
+      *c = -sn;
+      break;
+    case 2:
+      *s = -sn;
+      *c = -cs;
+      break;
+    default:
+      *s = -cs;
+      *c = sn;
+      break;
+  }
+}
+
+// Eigen::LLT<Matrix3d>::solve (src/DdpSingleRigidBody.cpp:88,122-123)
+CCC_DDP_FN void llt3_solve(const double * I, const double * b, double * x)
+{
+  const double l00 = sqrt(I[0]);
+  const double l10 = I[3] / l00, l20 = I[6] / l00;
+  const double l11 = sqrt(I[4] - l10 * l10);
+  const double l21 = (I[7] - l20 * l10) / l11;
+  const double l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
+  const double y0 = b[0] / l00;
+  const double y1 = (b[1] - l10 * y0) / l11;
+  const double y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
+  x[2] = y2 / l22;
+  x[1] = (y1 - l21 * x[2]) / l11;
+  x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+}
+
+template<int S, int M>
+struct Solver
+{
+  const Params & P;
+  const Instance & I;
+  Mem<S, M> & mem;
+
+  CCC_DDP_FN Solver(const Params & p, const Instance & i, Mem<S, M> & m) : P(p), I(i), mem(m) {}
+
+  CCC_DDP_FN int dim_of(int step) const
+  {
+    return I.phase_dim[I.step_phase[step]];
+  }
+  CCC_DDP_FN const double * vert_of(int step) const
+  {
+    return I.phase_vertex + static_cast<long>(I.step_phase[step]) * M * 3;
+  }
+  CCC_DDP_FN const double * ridge_of(int step) const
+  {
+    return I.phase_ridge + static_cast<long>(I.step_phase[step]) * M * 3;
+  }
+
+  // reference of the weighted state entries at a step (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0])
+  CCC_DDP_FN double ref_entry(int step, int a) const
+  {
+    if(a < 3) return I.ref_pos[static_cast<long>(step) * 3 + a];
+    if(S == 12 && a < 6) return I.ref_ori[static_cast<long>(step) * 3 + a - 3];
+    return 0.0;
+  }
+
+  // ---- x_next = stateEq(step, x, u): src/DdpCentroidal.cpp:32-64 / src/DdpSingleRigidBody.cpp:52-91.
+  //      x, u, out are LDS arrays of mem (out != x).
+  CCC_DDP_FN void state_eq(int step, const double * x, const double * u, double * out)
+  {
+    const int dim = dim_of(step);
+    const double * V = vert_of(step);
+    const double * R = ridge_of(step);
+    if constexpr(S == 9)
+    {
+      phase([&](int lane) {
+        if(lane < 9)
+        {
+          const int a = lane;
+          double xd;
+          if(a < 3)
+            xd = x[3 + a] / P.mass;
+          else if(a < 6)
+          {
+            xd = (a == 5) ? -1 * P.mass * kGravity : 0.0;
+            for(int r = 0; r < dim; r++) xd += u[r] * R[r * 3 + a - 3];
+          }
+          else
+          {
+            xd = 0.0;
+            for(int r = 0; r < dim; r++)
+            {
+              const double d[3] = {V[r * 3] - x[0], V[r * 3 + 1] - x[1], V[r * 3 + 2] - x[2]};
+              double c[3];
+              cross3(d, R + r * 3, c);
+              xd += u[r] * c[a - 6];
+            }
+          }
+          out[a] = x[a] + P.dt * xd;
+        }
+      });
+    }
+    else
+    {
+      phase([&](int lane) {
+        if(lane < 9)
+        {
+          const int a = lane;
+          const double * w = x + 9;
+          double xd;
+          if(a < 3)
+            xd = x[6 + a];
+          else if(a < 6)
+          {
+            // matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72
+            double ca, sa, cb, sb;
+            det_sincos(x[3], &sa, &ca);
+            det_sincos(x[4], &sb, &cb);
+            const double K[9] = {(ca * sb) / cb, (sb * sa) / cb, 1.0, -1 * sa, ca, 0.0, ca / cb, sa / cb, 0.0};
+            const int b = a - 3;
+            xd = K[b * 3] * w[0] + K[b * 3 + 1] * w[1] + K[b * 3 + 2] * w[2];
+          }
+          else
+          {
+            xd = (a == 8) ? -1 * kGravity : 0.0;
+            for(int r = 0; r < dim; r++) xd += u[r] * R[r * 3 + a - 6] / P.mass;
+          }
+          mem.xd[a] = xd;
+        }
+        else if(lane < 12)
+        {
+          // -w x (I w) + sum_r u_r (p_r - c) x rho_r   (before the inertia solve)
+          const int a = lane - 9;
+          const double * w = x + 9;
+          const double * In = I.inertia;
+          double Iw[3], cw[3];
+          for(int b = 0; b < 3; b++) Iw[b] = In[b * 3] * w[0] + In[b * 3 + 1] * w[1] + In[b * 3 + 2] * w[2];
+          cross3(w, Iw, cw);
+          double wd = -1 * cw[a];
+          for(int r = 0; r < dim; r++)
+          {
+            const double d[3] = {V[r * 3] - x[0], V[r * 3 + 1] - x[1], V[r * 3 + 2] - x[2]};
+            double c[3];
+            cross3(d, R + r * 3, c);
+            wd += u[r] * c[a];
+          }
+          mem.wd[a] = wd;
+        }
+      });
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          double sol[3];
+          llt3_solve(I.inertia, mem.wd, sol);
+          for(int a = 0; a < 3; a++) mem.xd[9 + a] = sol[a];
+        }
+      });
+      phase([&](int lane) {
+        if(lane < 12) out[lane] = x[lane] + P.dt * mem.xd[lane];
+      });
+    }
+  }
+
+  // running cost of (step, x, u) -- evaluated by ONE lane inside a phase (sequential sums like the oracle)
+  CCC_DDP_FN double running_cost(int step, const double * x, const double * u) const
+  {
+    const int dim = dim_of(step);
+    double c = 0, un = 0;
+    for(int a = 0; a < S; a++)
+    {
+      const double e = x[a] - ref_entry(step, a);
+      c += 0.5 * P.w_run[a] * e * e;
+    }
+    for(int r = 0; r < dim; r++) un += u[r] * u[r];
+    return c + 0.5 * P.w_force * un;
+  }
+  CCC_DDP_FN double terminal_cost(const double * x) const
+  {
+    double c = 0;
+    for(int a = 0; a < S; a++)
+    {
+      const double e = x[a] - ref_entry(P.N, a);
+      c += 0.5 * P.w_term[a] * e * e;
+    }
+    return c;
+  }
+
+  // ---- Fx, Fu at (step, mem.x, mem.u): src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185
+  CCC_DDP_FN void state_eq_deriv(int step)
+  {
+    const int dim = dim_of(step);
+    const double * V = vert_of(step);
+    const double * R = ridge_of(step);
+    const double * x = mem.x;
+    const double * u = mem.u;
+    phase([&](int lane) {
+      for(int e = lane; e < S * S; e += kWave) mem.Fx[e] = 0.0;
+      for(int e = lane; e < S * M; e += kWave) mem.Fu[e] = 0.0;
+      if(lane < 3)
+      {
+        double tf = 0.0;
+        for(int r = 0; r < dim; r++) tf += u[r] * R[r * 3 + lane];
+        mem.tf[lane] = tf;
+      }
+    });
+    if constexpr(S == 9)
+    {
+      phase([&](int lane) {
+        if(lane < dim)
+        {
+          const int r = lane;
+          const double d[3] = {V[r * 3] - x[0], V[r * 3 + 1] - x[1], V[r * 3 + 2] - x[2]};
+          double c[3];
+          cross3(d, R + r * 3, c);
+          for(int a = 0; a < 3; a++)
+          {
+            mem.Fu[(3 + a) * M + r] = R[r * 3 + a];
+            mem.Fu[(6 + a) * M + r] = c[a];
+          }
+        }
+        if(lane == 32)
+        {
+          const double * tf = mem.tf;
+          for(int a = 0; a < 3; a++) mem.Fx[a * S + 3 + a] = 1 / P.mass;
+          mem.Fx[6 * S + 1] = -tf[2];
+          mem.Fx[6 * S + 2] = tf[1];
+          mem.Fx[7 * S + 0] = tf[2];
+          mem.Fx[7 * S + 2] = -tf[0];
+          mem.Fx[8 * S + 0] = -tf[1];
+          mem.Fx[8 * S + 1] = tf[0];
+        }
+      });
+    }
+    else
+    {
+      phase([&](int lane) {
+        const double * In = I.inertia;
+        if(lane < dim)
+        {
+          const int r = lane;
+          const double d[3] = {V[r * 3] - x[0], V[r * 3 + 1] - x[1], V[r * 3 + 2] - x[2]};
+          double c[3], sol[3];
+          cross3(d, R + r * 3, c);
+          llt3_solve(In, c, sol);
+          for(int a = 0; a < 3; a++)
+          {
+            mem.Fu[(6 + a) * M + r] = R[r * 3 + a] / P.mass;
+            mem.Fu[(9 + a) * M + r] = sol[a];
+          }
+        }
+        if(lane >= 32 && lane < 35)
+        {
+          // column b of I^-1 d(-w x I w)/dw  -> block (9, 9)
+          const int b = lane - 32;
+          const double w1 = x[9], w2 = x[10], w3 = x[11];
+          const double I11 = In[0], I12 = In[1], I13 = In[2], I22 = In[4], I23 = In[5], I33 = In[8];
+          const double D[9] = {I12 * w3 - I13 * w2,
+                               -I13 * w1 + I22 * w3 - 2 * I23 * w2 - I33 * w3,
+                               I12 * w1 + I22 * w2 + 2 * I23 * w3 - I33 * w2,
+                               -I11 * w3 + 2 * I13 * w1 + I23 * w2 + I33 * w3,
+                               -I12 * w3 + I23 * w1,
+                               -I11 * w1 - I12 * w2 - 2 * I13 * w3 + I33 * w1,
+                               I11 * w2 - 2 * I12 * w1 - I22 * w2 - I23 * w3,
+                               I11 * w1 + 2 * I12 * w2 + I13 * w3 - I22 * w1,
+                               I13 * w2 - I23 * w1};
+          const double col[3] = {D[b], D[3 + b], D[6 + b]};
+          double sol[3];
+          llt3_solve(In, col, sol);
+          for(int a = 0; a < 3; a++) mem.Fx[(9 + a) * S + 9 + b] = sol[a];
+        }
+        if(lane >= 35 && lane < 38)
+        {
+          // column b of I^-1 crossMat(totalForce) -> block (9, 0)
+          const int b = lane - 35;
+          const double * tf = mem.tf;
+          const double CM[9] = {0, -tf[2], tf[1], tf[2], 0, -tf[0], -tf[1], tf[0], 0};
+          const double col[3] = {CM[b], CM[3 + b], CM[6 + b]};
+          double sol[3];
+          llt3_solve(In, col, sol);
+          for(int a = 0; a < 3; a++) mem.Fx[(9 + a) * S + b] = sol[a];
+        }
+        if(lane == 38)
+        {
+          const double w1 = x[9], w2 = x[10];
+          double ca, sa, cb, sb;
+          det_sincos(x[3], &sa, &ca);
+          det_sincos(x[4], &sb, &cb);
+          const double cb2 = cb * cb, sb2 = sb * sb;
+          for(int a = 0; a < 3; a++) mem.Fx[a * S + 6 + a] = 1.0;
+          const double K[9] = {(ca * sb) / cb, (sb * sa) / cb, 1.0, -1 * sa, ca, 0.0, ca / cb, sa / cb, 0.0};
+          for(int a = 0; a < 3; a++)
+            for(int b = 0; b < 3; b++) mem.Fx[(3 + a) * S + 9 + b] = K[a * 3 + b];
+          mem.Fx[3 * S + 3] = -w1 * sa * sb / cb + w2 * sb * ca / cb;
+          mem.Fx[4 * S + 3] = -w1 * ca - w2 * sa;
+          mem.Fx[5 * S + 3] = -w1 * sa / cb + w2 * ca / cb;
+          mem.Fx[3 * S + 4] = w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa;
+          mem.Fx[4 * S + 4] = 0.0;
+          mem.Fx[5 * S + 4] = w1 * sb * ca / cb2 + w2 * sa * sb / cb2;
+        }
+      });
+    }
+    phase([&](int lane) {
+      for(int e = lane; e < S * S; e += kWave)
+      {
+        double v = mem.Fx[e] * P.dt;
+        if(e / S == e % S) v += 1.0;
+        mem.Fx[e] = v;
+      }
+      for(int e = lane; e < S * M; e += kWave) mem.Fu[e] *= P.dt;
+    });
+  }
+
+  // ---- box-QP: min 1/2 k'Hk + g'k, lo <= k <= hi with H = mem.QuuF (m x m, stride m), g = mem.Qu,
+  //      warm start in mem.kq; result in mem.kq / mem.clamped / mem.Lf (Cholesky of H with the clamped rows and
+  //      columns replaced by identity = the factor of H_ff embedded).  Tassa's boxQP.m; returns result >= 1 on success.
+  CCC_DDP_FN int box_qp(int m)
+  {
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    const int max_iter = 100;
+    const double * H = mem.QuuF;
+    const double * g = mem.Qu;
+    phase([&](int lane) {
+      if(lane < m)
+      {
+        mem.kq[lane] = fmin(fmax(mem.kq[lane], mem.lo[lane]), mem.hi[lane]);
+        mem.clamped[lane] = 0;
+      }
+      if(lane == 0) mem.ic[IC_RESULT] = 0;
+    });
+    auto value_of = [&](const double * x, int slot) {
+      // value = x'g + 1/2 x'Hx, rows in parallel then a sequential sum (same order as the oracle)
+      phase([&](int lane) {
+        if(lane < m)
+        {
+          double s = 0;
+          for(int j = 0; j < m; j++) s += H[lane * m + j] * x[j];
+          mem.tmp[lane] = x[lane] * g[lane] + 0.5 * x[lane] * s;
+        }
+      });
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          double v = 0;
+          for(int i = 0; i < m; i++) v += mem.tmp[i];
+          mem.sc[slot] = v;
+        }
+      });
+    };
+    value_of(mem.kq, SC_VALUE);
+    int iter;
+    for(iter = 1; iter <= max_iter; iter++)
+    {
+      if(mem.ic[IC_RESULT] != 0) break;
+      if(iter > 1 && (mem.sc[SC_OLDVALUE] - mem.sc[SC_VALUE]) < min_rel_improve * fabs(mem.sc[SC_OLDVALUE]))
+      {
+        phase([&](int lane) {
+          if(lane == 0) mem.ic[IC_RESULT] = 4;
+        });
+        break;
+      }
+      phase([&](int lane) {
+        if(lane == 0) mem.sc[SC_OLDVALUE] = mem.sc[SC_VALUE];
+        if(lane < m)
+        {
+          double s = g[lane];
+          for(int j = 0; j < m; j++) s += H[lane * m + j] * mem.kq[j];
+          mem.grad[lane] = s;
+          mem.oldc[lane] = mem.clamped[lane];
+          mem.clamped[lane] = ((mem.kq[lane] == mem.lo[lane] && s > 0) || (mem.kq[lane] == mem.hi[lane] && s < 0)) ? 1 : 0;
+        }
+      });
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          int changed = (iter == 1), all = 1;
+          for(int i = 0; i < m; i++)
+          {
+            if(mem.clamped[i] != mem.oldc[i]) changed = 1;
+            if(!mem.clamped[i]) all = 0;
+          }
+          mem.ic[IC_CHANGED] = changed;
+          mem.ic[IC_ALLCL] = all;
+          if(all) mem.ic[IC_RESULT] = 6;
+        }
+      });
+      if(mem.ic[IC_ALLCL]) break;
+      if(mem.ic[IC_CHANGED])
+      {
+        if(!cholesky_free(m))
+        {
+          phase([&](int lane) {
+            if(lane == 0) mem.ic[IC_RESULT] = -1;
+          });
+          break;
+        }
+      }
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          double gn = 0;
+          for(int i = 0; i < m; i++)
+            if(!mem.clamped[i]) gn += mem.grad[i] * mem.grad[i];
+          gn = sqrt(gn);
+          mem.sc[SC_GNORM] = gn;
+          if(gn < min_grad) mem.ic[IC_RESULT] = 5;
+        }
+        // grad_clamped = g + H (x .* clamped) on the free rows
+        if(lane < m)
+        {
+          double s = g[lane];
+          for(int j = 0; j < m; j++)
+            if(mem.clamped[j]) s += H[lane * m + j] * mem.kq[j];
+          mem.tmp[lane] = mem.clamped[lane] ? 0.0 : s;
+        }
+      });
+      if(mem.ic[IC_RESULT] != 0) break;
+      solve_free(m, mem.tmp); // tmp <- H_ff^-1 tmp on the free rows
+      phase([&](int lane) {
+        if(lane < m) mem.srch[lane] = mem.clamped[lane] ? 0.0 : -mem.tmp[lane] - mem.kq[lane];
+      });
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          double s = 0;
+          for(int i = 0; i < m; i++) s += mem.srch[i] * mem.grad[i];
+          mem.sc[SC_SDOTG] = s;
+          mem.sc[SC_STEP] = 1.0;
+        }
+      });
+      if(mem.sc[SC_SDOTG] >= 0) break; // no descent direction: result stays 0
+      for(;;)
+      {
+        phase([&](int lane) {
+          if(lane < m)
+            mem.xcand[lane] = fmin(fmax(mem.kq[lane] + mem.sc[SC_STEP] * mem.srch[lane], mem.lo[lane]), mem.hi[lane]);
+        });
+        value_of(mem.xcand, SC_VC);
+        if(!((mem.sc[SC_VC] - mem.sc[SC_OLDVALUE]) / (mem.sc[SC_STEP] * mem.sc[SC_SDOTG]) < armijo)) break;
+        bool stop = false;
+        phase([&](int lane) {
+          if(lane == 0)
+          {
+            mem.sc[SC_STEP] *= step_dec;
+            if(mem.sc[SC_STEP] < min_step) mem.ic[IC_RESULT] = 2;
+          }
+        });
+        stop = mem.ic[IC_RESULT] == 2;
+        if(stop) break;
+      }
+      phase([&](int lane) {
+        if(lane < m) mem.kq[lane] = mem.xcand[lane];
+        if(lane == 0) mem.sc[SC_VALUE] = mem.sc[SC_VC];
+      });
+    }
+    int result = mem.ic[IC_RESULT];
+    if(iter > max_iter && result == 0) result = 1;
+    return result;
+  }
+
+  // Cholesky of H~ (H with clamped rows/columns replaced by identity) into mem.Lf (lower, stride m).
+  CCC_DDP_FN bool cholesky_free(int m)
+  {
+    const double * H = mem.QuuF;
+    phase([&](int lane) {
+      for(int e = lane; e < m * m; e += kWave)
+      {
+        const int i = e / m, j = e % m;
+        const bool cl = mem.clamped[i] || mem.clamped[j];
+        mem.Lf[e] = cl ? (i == j ? 1.0 : 0.0) : H[e];
+      }
+      if(lane == 0) mem.ic[IC_OK] = 1;
+    });
+    // right-looking, column by column; the arithmetic per entry (subtract products in increasing k, then
+    // divide) matches the row-oriented loop of the oracle
+    for(int j = 0; j < m; j++)
+    {
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          const double s = mem.Lf[j * m + j];
+          if(!(s > 0.0))
+            mem.ic[IC_OK] = 0;
+          else
+            mem.Lf[j * m + j] = sqrt(s);
+        }
+      });
+      if(!mem.ic[IC_OK]) return false;
+      phase([&](int lane) {
+        const int i = j + 1 + lane;
+        if(i < m) mem.Lf[i * m + j] = mem.Lf[i * m + j] / mem.Lf[j * m + j];
+      });
+      phase([&](int lane) {
+        // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
+        const int cnt = m - j - 1;
+        for(int e = lane; e < cnt * cnt; e += kWave)
+        {
+          const int i = j + 1 + e / cnt, k = j + 1 + e % cnt;
+          if(k <= i) mem.Lf[i * m + k] -= mem.Lf[i * m + j] * mem.Lf[k * m + j];
+        }
+      });
+    }
+    return true;
+  }
+
+  // v <- H~^-1 v using mem.Lf (forward then backward substitution; v is an LDS vector of length m)
+  CCC_DDP_FN void solve_free(int m, double * v)
+  {
+    phase([&](int lane) {
+      if(lane == 0)
+      {
+        for(int a = 0; a < m; a++)
+        {
+          double s = v[a];
+          for(int k = 0; k < a; k++) s -= mem.Lf[a * m + k] * v[k];
+          v[a] = s / mem.Lf[a * m + a];
+        }
+        for(int a = m - 1; a >= 0; a--)
+        {
+          double s = v[a];
+          for(int k = a + 1; k < m; k++) s -= mem.Lf[k * m + a] * v[k];
+          v[a] = s / mem.Lf[a * m + a];
+        }
+      }
+    });
+  }
+
+  // ---- backward pass (oracle/ddp.c backward_pass); returns false when a box-QP / Cholesky fails
+  CCC_DDP_FN bool backward_pass()
+  {
+    const int N = P.N;
+    phase([&](int lane) {
+      // terminal value: src/DdpCentroidal.cpp:156-177 at x_N
+      for(int e = lane; e < S * S; e += kWave) mem.Vxx[e] = (e / S == e % S) ? P.w_term[e / S] : 0.0;
+      if(lane < S) mem.Vx[lane] = P.w_term[lane] * (I.xs[static_cast<long>(N) * S + lane] - ref_entry(N, lane));
+      if(lane == 0)
+      {
+        mem.sc[SC_DV0] = 0.0;
+        mem.sc[SC_DV1] = 0.0;
+      }
+    });
+    for(int i = N - 1; i >= 0; i--)
+    {
+      const int m = dim_of(i);
+      const double lambda = mem.sc[SC_LAMBDA];
+      phase([&](int lane) {
+        if(lane < S) mem.x[lane] = I.xs[static_cast<long>(i) * S + lane];
+        if(lane < M) mem.u[lane] = (lane < m) ? I.us[static_cast<long>(i) * M + lane] : 0.0;
+      });
+      state_eq_deriv(i);
+      phase([&](int lane) {
+        // Qx = Lx + Fx'Vx ; Qu = Lu + Fu'Vx
+        if(lane < S)
+        {
+          double s = P.w_run[lane] * (mem.x[lane] - ref_entry(i, lane));
+          for(int b = 0; b < S; b++) s += mem.Fx[b * S + lane] * mem.Vx[b];
+          mem.Qx[lane] = s;
+        }
+        else if(lane >= 32 && lane - 32 < m)
+        {
+          const int r = lane - 32;
+          double s = P.w_force * mem.u[r];
+          for(int b = 0; b < S; b++) s += mem.Fu[b * M + r] * mem.Vx[b];
+          mem.Qu[r] = s;
+        }
+        // T1 = Vxx Fx ; T2 = Vxx Fu
+        for(int e = lane; e < S * S; e += kWave)
+        {
+          const int a = e / S, b = e % S;
+          double s = 0;
+          for(int k = 0; k < S; k++) s += mem.Vxx[a * S + k] * mem.Fx[k * S + b];
+          mem.T1[e] = s;
+        }
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0;
+          for(int k = 0; k < S; k++) s += mem.Vxx[a * S + k] * mem.Fu[k * M + r];
+          mem.T2[a * M + r] = s;
+        }
+      });
+      phase([&](int lane) {
+        // Qxx = Lxx + Fx'T1 ; Qxu = Fx'T2 ; Quu = Luu + Fu'T2   (Lxu = 0, Lxx = diag(w_run), Luu = w_force I)
+        for(int e = lane; e < S * S; e += kWave)
+        {
+          const int a = e / S, b = e % S;
+          double s = (a == b) ? P.w_run[a] : 0.0;
+          for(int k = 0; k < S; k++) s += mem.Fx[k * S + a] * mem.T1[k * S + b];
+          mem.Qxx[e] = s;
+        }
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0.0;
+          for(int k = 0; k < S; k++) s += mem.Fx[k * S + a] * mem.T2[k * M + r];
+          mem.Qxu[a * M + r] = s;
+        }
+        for(int e = lane; e < m * m; e += kWave)
+        {
+          const int r = e / m, q = e % m;
+          double s = (r == q) ? P.w_force : 0.0;
+          for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
+          mem.Quu[e] = s;
+        }
+      });
+      phase([&](int lane) {
+        // regularised: T2 = (Vxx + lambda I) Fu
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0;
+          for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda : 0.0)) * mem.Fu[k * M + r];
+          mem.T2[a * M + r] = s;
+        }
+      });
+      phase([&](int lane) {
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0.0;
+          for(int k = 0; k < S; k++) s += mem.Fx[k * S + a] * mem.T2[k * M + r];
+          mem.Qxur[a * M + r] = s;
+        }
+        for(int e = lane; e < m * m; e += kWave)
+        {
+          const int r = e / m, q = e % m;
+          double s = (r == q) ? P.w_force : 0.0;
+          for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
+          mem.QuuF[e] = s;
+        }
+        // box limits on the input CHANGE and the warm start (gain of step i+1 of this pass, zeros on a dim change)
+        if(lane < M)
+        {
+          mem.lo[lane] = P.flo - mem.u[lane];
+          mem.hi[lane] = P.fhi - mem.u[lane];
+          const bool warm = (i + 1 < N) && (dim_of(i + 1) == m);
+          mem.kq[lane] = (warm && lane < m) ? I.ks[static_cast<long>(i + 1) * M + lane] : 0.0;
+          mem.k[lane] = 0.0;
+        }
+        for(int e = lane; e < M * S; e += kWave) mem.K[e] = 0.0;
+      });
+      if(m > 0)
+      {
+        const int rc = box_qp(m);
+        if(rc < 1) return false;
+        // K_f = -H_ff^-1 Qxur_f' : one right-hand side (state index a) per lane, clamped rows stay zero
+        phase([&](int lane) {
+          if(lane < m) mem.k[lane] = mem.kq[lane];
+          if(lane < S)
+          {
+            const int a = lane;
+            double * t3 = mem.T2 + a * M; // (Vxx + lambda I) Fu is consumed; its rows serve as scratch
+            for(int f = 0; f < m; f++)
+            {
+              double s = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
+              for(int kk = 0; kk < f; kk++) s -= mem.Lf[f * m + kk] * t3[kk];
+              t3[f] = s / mem.Lf[f * m + f];
+            }
+            for(int f = m - 1; f >= 0; f--)
+            {
+              double s = t3[f];
+              for(int kk = f + 1; kk < m; kk++) s -= mem.Lf[kk * m + f] * t3[kk];
+              t3[f] = s / mem.Lf[f * m + f];
+            }
+            for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
+          }
+        });
+      }
+      phase([&](int lane) {
+        // t4 = Quu k ; gains to global memory
+        if(lane < m)
+        {
+          double s = 0;
+          for(int q = 0; q < m; q++) s += mem.Quu[lane * m + q] * mem.k[q];
+          mem.t4[lane] = s;
+        }
+        if(lane < M) I.ks[static_cast<long>(i) * M + lane] = mem.k[lane];
+        for(int e = lane; e < M * S; e += kWave) I.Ks[static_cast<long>(i) * M * S + e] = mem.K[e];
+        // T2 (S x m) = K' Quu
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0;
+          for(int q = 0; q < m; q++) s += mem.K[q * S + a] * mem.Quu[q * m + r];
+          mem.T2[a * M + r] = s;
+        }
+      });
+      phase([&](int lane) {
+        if(lane == 63)
+        {
+          double s0 = 0, s1 = 0;
+          for(int r = 0; r < m; r++)
+          {
+            s0 += mem.k[r] * mem.Qu[r];
+            s1 += mem.k[r] * mem.t4[r];
+          }
+          mem.sc[SC_DV0] += s0;
+          mem.sc[SC_DV1] += 0.5 * s1;
+        }
+        if(lane < S)
+        {
+          const int a = lane;
+          double s = mem.Qx[a];
+          for(int r = 0; r < m; r++)
+            s += mem.K[r * S + a] * mem.t4[r] + mem.K[r * S + a] * mem.Qu[r] + mem.Qxu[a * M + r] * mem.k[r];
+          mem.Vx[a] = s;
+        }
+        for(int e = lane; e < S * S; e += kWave)
+        {
+          const int a = e / S, b = e % S;
+          double s = mem.Qxx[e];
+          for(int r = 0; r < m; r++)
+            s += mem.T2[a * M + r] * mem.K[r * S + b] + mem.K[r * S + a] * mem.Qxu[b * M + r]
+                 + mem.Qxu[a * M + r] * mem.K[r * S + b];
+          mem.T1[e] = s;
+        }
+      });
+      phase([&](int lane) {
+        for(int e = lane; e < S * S; e += kWave)
+        {
+          const int a = e / S, b = e % S;
+          mem.Vxx[e] = 0.5 * (mem.T1[a * S + b] + mem.T1[b * S + a]);
+        }
+      });
+    }
+    return true;
+  }
+
+  // ---- rollout of the initial inputs / line-search candidate.  alpha < 0: plain rollout of I.us into I.xs.
+  CCC_DDP_FN void rollout(double alpha)
+  {
+    const int N = P.N;
+    const bool initial = alpha < 0;
+    double * xo = initial ? I.xs : I.xc;
+    double * uo = initial ? I.us : I.uc;
+    phase([&](int lane) {
+      if(lane < S)
+      {
+        const double v = initial ? I.x0[lane] : I.xs[lane];
+        mem.x[lane] = v;
+        xo[lane] = v;
+      }
+      if(lane == 0) mem.sc[initial ? SC_COST : SC_COSTC] = 0.0;
+    });
+    for(int i = 0; i < N; i++)
+    {
+      const int m = dim_of(i);
+      phase([&](int lane) {
+        if(lane < M)
+        {
+          double s = 0.0;
+          if(lane < m)
+          {
+            if(initial)
+              s = I.u_init ? I.u_init[static_cast<long>(i) * M + lane] : 0.0;
+            else
+            {
+              s = I.us[static_cast<long>(i) * M + lane] + alpha * I.ks[static_cast<long>(i) * M + lane];
+              const double * Kr = I.Ks + (static_cast<long>(i) * M + lane) * S;
+              const double * xi = I.xs + static_cast<long>(i) * S;
+              for(int a = 0; a < S; a++) s += Kr[a] * (mem.x[a] - xi[a]);
+              s = fmin(fmax(s, P.flo), P.fhi);
+            }
+          }
+          mem.un[lane] = s;
+          uo[static_cast<long>(i) * M + lane] = s;
+        }
+      });
+      state_eq(i, mem.x, mem.un, mem.xn);
+      phase([&](int lane) {
+        if(lane == 32) mem.sc[initial ? SC_COST : SC_COSTC] += running_cost(i, mem.x, mem.un);
+        if(lane < S) xo[static_cast<long>(i + 1) * S + lane] = mem.xn[lane];
+      });
+      phase([&](int lane) {
+        if(lane < S) mem.x[lane] = mem.xn[lane];
+      });
+    }
+    phase([&](int lane) {
+      if(lane == 0) mem.sc[initial ? SC_COST : SC_COSTC] += terminal_cost(mem.x);
+    });
+  }
+
+  CCC_DDP_FN void increase_lambda()
+  {
+    phase([&](int lane) {
+      if(lane == 0)
+      {
+        mem.sc[SC_DLAMBDA] = fmax(mem.sc[SC_DLAMBDA] * P.lambda_factor, P.lambda_factor);
+        mem.sc[SC_LAMBDA] = fmax(mem.sc[SC_LAMBDA] * mem.sc[SC_DLAMBDA], P.lambda_min);
+      }
+    });
+  }
+  CCC_DDP_FN void decrease_lambda()
+  {
+    phase([&](int lane) {
+      if(lane == 0)
+      {
+        mem.sc[SC_DLAMBDA] = fmin(mem.sc[SC_DLAMBDA] / P.lambda_factor, 1.0 / P.lambda_factor);
+        mem.sc[SC_LAMBDA] = mem.sc[SC_LAMBDA] * mem.sc[SC_DLAMBDA] * (mem.sc[SC_LAMBDA] > P.lambda_min ? 1.0 : 0.0);
+      }
+    });
+  }
+
+  // ---- the whole solve (oracle/ddp.c oracle_ddp_solve)
+  CCC_DDP_FN void solve()
+  {
+    const int N = P.N;
+    phase([&](int lane) {
+      if(lane == 0)
+      {
+        mem.sc[SC_LAMBDA] = P.lambda0;
+        mem.sc[SC_DLAMBDA] = P.dlambda0;
+      }
+    });
+    rollout(-1.0);
+    int iter = 0, status = 0;
+    for(iter = 1; iter <= P.max_iter; iter++)
+    {
+      bool bp_ok = false;
+      for(;;)
+      {
+        if(backward_pass())
+        {
+          bp_ok = true;
+          break;
+        }
+        increase_lambda();
+        if(mem.sc[SC_LAMBDA] > P.lambda_max) break;
+      }
+      if(!bp_ok)
+      {
+        status = -1;
+        break;
+      }
+      phase([&](int lane) {
+        if(lane == 0)
+        {
+          double g = 0;
+          for(int i = 0; i < N; i++)
+          {
+            const int m = dim_of(i);
+            double mx = 0;
+            for(int r = 0; r < m; r++)
+            {
+              const double v =
+                  fabs(I.ks[static_cast<long>(i) * M + r]) / (fabs(I.us[static_cast<long>(i) * M + r]) + 1.0);
+              if(v > mx) mx = v;
+            }
+            g += mx;
+          }
+          mem.sc[SC_G] = g / N;
+        }
+      });
+      if(mem.sc[SC_G] < P.k_rel_norm_thre && mem.sc[SC_LAMBDA] < P.lambda_thre)
+      {
+        decrease_lambda();
+        status = 1;
+        break;
+      }
+      bool accepted = false;
+      double actual = 0;
+      for(int a = 0; a < 11; a++)
+      {
+        const double alpha = P.alpha[a];
+        rollout(alpha);
+        actual = mem.sc[SC_COST] - mem.sc[SC_COSTC];
+        const double expected = -alpha * (mem.sc[SC_DV0] + alpha * mem.sc[SC_DV1]);
+        const double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
+        if(ratio > P.ratio_thre)
+        {
+          accepted = true;
+          break;
+        }
+      }
+      if(accepted)
+      {
+        decrease_lambda();
+        phase([&](int lane) {
+          for(int e = lane; e < (N + 1) * S; e += kWave) I.xs[e] = I.xc[e];
+          for(int e = lane; e < N * M; e += kWave) I.us[e] = I.uc[e];
+          if(lane == 0) mem.sc[SC_COST] = mem.sc[SC_COSTC];
+        });
+        if(actual < P.cost_thre)
+        {
+          status = 2;
+          break;
+        }
+      }
+      else
+      {
+        increase_lambda();
+        if(mem.sc[SC_LAMBDA] > P.lambda_max)
+        {
+          status = -1;
+          break;
+        }
+      }
+    }
+    if(iter > P.max_iter) iter = P.max_iter;
+    phase([&](int lane) {
+      if(lane == 0)
+      {
+        if(I.out_iters) *I.out_iters = iter;
+        if(I.out_status) *I.out_status = status;
+        if(I.out_cost) *I.out_cost = mem.sc[SC_COST];
+      }
+    });
+  }
+};
+} // namespace ddp
+} // namespace ccc_amd

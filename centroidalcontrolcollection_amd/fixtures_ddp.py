@@ -176,11 +176,11 @@ def srb_ori_ref(t):
 
 
 def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.005, end_time=3.0, P=4, M=16,
-                        disturb_time=1.0, ang_disturb=(0.05, 0.05, 0.0)):
+                        disturb_time=1.0, ang_disturb=(0.05, 0.05, 0.0), warm_max_iter=1):
     """The control loops of TestDdpCentroidal.cpp:96-150 / TestDdpSingleRigidBody.cpp:103-170 around any
     `plan(prob, x0 [1,S], u_init [1,N,M] | None, max_iter) -> u [1,N,M]`: first cycle cold start with the full
     iteration budget, afterwards warm start (unshifted u_list, zeroed where the input dimension changed) with
-    max_iter = 1.  Returns per-cycle records for the reference's property assertions."""
+    max_iter = warm_max_iter (1 in the reference).  Returns per-cycle records for the reference's property assertions."""
     inertia = np.array([40.0, 20.0, 10.0])
     sim = CentroidalSim(mass, inertia, sim_dt)
     sim.pos = reference_schedule(0.0)[1].copy()
@@ -201,7 +201,7 @@ def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.00
             u_init[0, changed, :] = 0.0
             for i in range(N):
                 u_init[0, i, dims[i]:] = 0.0
-        u = plan(prob, x0, u_init, 500 if cycle == 0 else 1)
+        u = plan(prob, x0, u_init, 500 if cycle == 0 else warm_max_iter)
         u_prev, dims_prev = u, dims
         ph = prob["step_phase"][0, 0]
         m0 = prob["phase_dim"][0, ph]

@@ -80,6 +80,84 @@ int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double * x0, const
 int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, const double * zlim, double control_dt,
                        double * zmp, double * jerk, int32_t * status);
 
+/* =========================================================================================
+ * CCC::DdpCentroidal          /root/reference/include/CCC/DdpCentroidal.h:13-366
+ * CCC::DdpSingleRigidBody     /root/reference/include/CCC/DdpSingleRigidBody.h
+ * ========================================================================================= */
+typedef struct ccc_ddp ccc_ddp_t;
+
+#define CCC_DDP_CENTROIDAL 0        /* 9 states  [c, P, L]         src/DdpCentroidal.cpp:32-64 */
+#define CCC_DDP_SINGLE_RIGID_BODY 1 /* 12 states [c, alpha, v, w]  src/DdpSingleRigidBody.cpp:52-91 */
+#define CCC_DDP_MAX_RIDGES 16       /* ridges per contact phase the kernels are built for (one 4-vertex surface) */
+
+/* Constructor arguments of DdpCentroidal(mass, horizon_dt, horizon_steps, weight_param)
+ * (include/CCC/DdpCentroidal.h:342) / DdpSingleRigidBody (include/CCC/DdpSingleRigidBody.h:379-394), with the
+ * WeightParam flattened per state entry:
+ *   centroidal: w_run = [running_pos(3), running_linear_momentum(3), running_angular_momentum(3)]
+ *   SRB:        w_run = [running_pos(3), running_ori(3), running_linear_vel(3), running_angular_vel(3)]
+ * (w_term likewise), w_force = running_force, force_scale_limits = force_scale_limits_ (DdpCentroidal.h:364). */
+typedef struct
+{
+  int model;
+  double mass;
+  double horizon_dt;
+  int horizon_steps;
+  double w_run[12], w_term[12], w_force;
+  double force_scale_limits[2];
+  int max_phases; /* P: contact phases per instance (distinct contact lists inside one horizon) */
+} ccc_ddp_params_t;
+
+/* ddp_solver_->config() (nmpc_ddp::DDPSolver::Configuration, external).  ccc_ddp_default_config
+ * fills the nmpc_ddp defaults with the overrides of src/DdpCentroidal.cpp:197-201 (with_input_constraint = true,
+ * initial_lambda = 1e-6, lambda_min = 1e-8, lambda_thre = 1e-7). */
+typedef struct
+{
+  int max_iter;
+  double initial_lambda, initial_dlambda, lambda_factor, lambda_min, lambda_max;
+  double k_rel_norm_thre, lambda_thre, cost_update_ratio_thre, cost_update_thre;
+  double alpha_list[11];
+} ccc_ddp_config_t;
+
+void ccc_ddp_default_config(ccc_ddp_config_t * cfg);
+int ccc_ddp_create(const ccc_ddp_params_t * params, int device, ccc_ddp_t ** out);
+void ccc_ddp_destroy(ccc_ddp_t * h);
+/* ddp_solver_->config() = cfg   (e.g. max_iter = 1 after the first control cycle, TestDdpCentroidal.cpp:116) */
+int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg);
+int ccc_ddp_state_dim(const ccc_ddp_t * h);
+
+/* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,
+ * initial_param, current_time) (src/DdpCentroidal.cpp:213-237, src/DdpSingleRigidBody.cpp:283-307) including the
+ * external ddp_solver_->solve (:229,:233), with the callbacks already sampled at current_time + i*dt and the
+ * contact lists flattened in contact -> vertex -> ridge order (src/DdpCentroidal.cpp:49-60):
+ *
+ *   phase_dim    [n][P]            i32  ridges of contact phase p (0 = no contact)        inputDim(t)
+ *   phase_vertex [n][P][16][3]     f64  vertex of ridge r         (Contact::vertexWithRidgeList_[..].vertex)
+ *   phase_ridge  [n][P][16][3]     f64  ridge direction r         (..ridgeList[..])
+ *   step_phase   [n][N]            i32  contact phase of horizon step i
+ *   ref_pos      [n][N+1][3]       f64  RefData::pos at step i (i = N: terminal cost)
+ *   ref_ori      [n][N+1][3]       f64  RefData::ori            (SRB only, else NULL)
+ *   inertia      [n][3][3]         f64  MotionParam::inertia_mat (SRB only, else NULL; constant over the horizon)
+ *   x0           [n][S]            f64  InitialParam::toState()  (S = 9: [pos, mass*vel, angular_momentum];
+ *                                       S = 12: [pos, ori, linear_vel, angular_vel])
+ *   u_init       [n][N][16]        f64  InitialParam::u_list (warm start) or NULL (zeros, src/DdpCentroidal.cpp:221-229)
+ *   u_out        [n][N][16]        f64  controlData().u_list; planOnce returns u_out[k][0][0 : phase_dim of step 0]
+ *   x_out        [n][N+1][S]       f64  optional: controlData().x_list
+ *   iters        [n]               i32  optional: traceDataList().back().iter
+ *   status       [n]               i32  optional: 0 max_iter reached, 1 gradient small, 2 cost change small,
+ *                                       -1 regularisation exceeded lambda_max
+ *   cost         [n]               f64  optional: final cost
+ * All DEVICE pointers, asynchronous on `stream`. */
+int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, const double * phase_vertex,
+                              const double * phase_ridge, const int32_t * step_phase, const double * ref_pos,
+                              const double * ref_ori, const double * inertia, const double * x0,
+                              const double * u_init, double * u_out, double * x_out, int32_t * iters,
+                              int32_t * status, double * cost, void * stream);
+/* Same with HOST pointers (H2D, solve, D2H, synchronise). */
+int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, const double * phase_vertex,
+                       const double * phase_ridge, const int32_t * step_phase, const double * ref_pos,
+                       const double * ref_ori, const double * inertia, const double * x0, const double * u_init,
+                       double * u_out, double * x_out, int32_t * iters, int32_t * status, double * cost);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,10 +59,58 @@ static void mdl_limits(void * user, int step, double * lo, double * hi)
   }
 }
 
+
+/* Deterministic sin/cos (Cody-Waite reduction by pi/2 + the classic fdlibm minimax kernels), accurate to ~1 ulp for
+ * |x| < 1e3.  The reference calls std::sin / std::cos (src/DdpSingleRigidBody.cpp:30-33,128-131); glibc and the GPU's
+ * device libm differ from each other in the last ulp, and DDP's discrete decisions can amplify one ulp into a different
+ * iterate.  Oracle and HIP kernel therefore both evaluate THIS restatement (same operations, no FMA contraction), which
+ * keeps the single-rigid-body model bit-reproducible across the two; tests check it against libm to 2 ulp. */
+static void det_sincos(double x, double * s, double * c)
+{
+  const double fn = floor(x * 6.36619772367581382433e-01 + 0.5);
+  const int n = (int)fn;
+  double r = x - fn * 1.57079632673412561417e+00;
+  r = r - fn * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01
+                    + z * (8.33333333332248946124e-03
+                           + z * (-1.98412698298579493134e-04
+                                  + z * (2.75573137070700676789e-06
+                                         + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02
+                    + z * (-1.38888888888741095749e-03
+                           + z * (2.48015872894767294178e-05
+                                  + z * (-2.75573143513906633035e-07
+                                         + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double sn = r + r * z * ps;
+  const double cs = 1.0 - (0.5 * z - z * z * pc);
+  switch(n & 3)
+  {
+    case 0:
+      *s = sn;
+      *c = cs;
+      break;
+    case 1:
+      *s = cs;
+      *c = -sn;
+      break;
+    case 2:
+      *s = -sn;
+      *c = -cs;
+      break;
+    default:
+      *s = -cs;
+      *c = sn;
+      break;
+  }
+}
+
 /* matAngularVelToEulerDot, src/DdpSingleRigidBody.cpp:26-38 (row-major 3x3) */
 static void euler_trans(const double * ori, double * K)
 {
-  double ca = cos(ori[0]), sa = sin(ori[0]), cb = cos(ori[1]), sb = sin(ori[1]);
+  double ca, sa, cb, sb;
+  det_sincos(ori[0], &sa, &ca);
+  det_sincos(ori[1], &sb, &cb);
   K[0] = (ca * sb) / cb;
   K[1] = (sb * sa) / cb;
   K[2] = 1.0;
@@ -210,8 +258,10 @@ static void mdl_state_eq_deriv(void * user, int step, const double * x, const do
     for(int a = 0; a < 3; a++)
       for(int b = 0; b < 3; b++) Fx[(3 + a) * S + 9 + b] = K[a * 3 + b];
     double w1 = x[9], w2 = x[10], w3 = x[11];
-    double ca = cos(ori[0]), sa = sin(ori[0]), cb = cos(ori[1]), sb = sin(ori[1]);
-    double cb2 = pow(cb, 2), sb2 = pow(sb, 2);
+    double ca, sa, cb, sb;
+    det_sincos(ori[0], &sa, &ca);
+    det_sincos(ori[1], &sb, &cb);
+    double cb2 = cb * cb, sb2 = sb * sb;
     double I11 = I[0], I12 = I[1], I13 = I[2], I22 = I[4], I23 = I[5], I33 = I[8];
     /* block (3,3), column 0 and column 1 (column 2 stays zero) */
     Fx[3 * S + 3] = -w1 * sa * sb / cb + w2 * sb * ca / cb;
@@ -375,4 +425,9 @@ void oracle_ddp_model_eval(const oracle_ddp_model_t * mdl, int step, const doubl
     mdl_terminal_cost_deriv((void *)mdl, x, Vx, Vxx);
     free(Vxx);
   }
+}
+
+void oracle_det_sincos(double x, double * s, double * c)
+{
+  det_sincos(x, s, c);
 }

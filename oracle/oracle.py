@@ -199,8 +199,17 @@ def _bind_ddp():
     L.oracle_ddp_plan_batch.restype = ctypes.c_int
     L.oracle_ddp_model_eval.argtypes = [ctypes.POINTER(_DdpModel), ctypes.c_int] + [_dp] * 10
     L.oracle_ddp_model_eval.restype = None
+    L.oracle_det_sincos.argtypes = [ctypes.c_double, _dp, _dp]
+    L.oracle_det_sincos.restype = None
     _ddp_bound = True
     return L
+
+
+def det_sincos(x):
+    L = _bind_ddp()
+    s, c = ctypes.c_double(0), ctypes.c_double(0)
+    L.oracle_det_sincos(float(x), ctypes.cast(ctypes.byref(s), _dp), ctypes.cast(ctypes.byref(c), _dp))
+    return s.value, c.value
 
 
 def box_qp(H, g, lo, hi, x0=None):
