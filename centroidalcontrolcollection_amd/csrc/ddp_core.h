@@ -39,6 +39,8 @@ namespace ccc_amd
 namespace ddp
 {
 constexpr int kWave = 64;
+constexpr int kMaxSteps = 128; // horizon steps the per-instance LDS tables are sized for
+constexpr int kMaxPhases = 4;  // contact phases per instance
 constexpr double kGravity = 9.80665; // include/CCC/Constants.h:10
 
 template<class F>
@@ -95,9 +97,14 @@ struct Mem
   double T1[S * S], T2[S * M], Lf[M * M], K[M * S];
   double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
+  double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
   double sc[16]; // uniform scalars
   int clamped[M], oldc[M];
   int ic[8]; // uniform ints
+  // per-instance problem tables, staged once per solve (every model evaluation reads them)
+  double pV[kMaxPhases * M * 3], pR[kMaxPhases * M * 3];
+  int pdim[kMaxPhases];
+  unsigned char sphase[kMaxSteps];
 };
 
 // indices into Mem::sc / Mem::ic
@@ -206,15 +213,28 @@ struct Solver
 
   CCC_DDP_FN int dim_of(int step) const
   {
-    return I.phase_dim[I.step_phase[step]];
+    return mem.pdim[mem.sphase[step]];
   }
   CCC_DDP_FN const double * vert_of(int step) const
   {
-    return I.phase_vertex + static_cast<long>(I.step_phase[step]) * M * 3;
+    return mem.pV + static_cast<int>(mem.sphase[step]) * M * 3;
   }
   CCC_DDP_FN const double * ridge_of(int step) const
   {
-    return I.phase_ridge + static_cast<long>(I.step_phase[step]) * M * 3;
+    return mem.pR + static_cast<int>(mem.sphase[step]) * M * 3;
+  }
+  // stage the contact tables of this instance in LDS
+  CCC_DDP_FN void stage_problem()
+  {
+    phase([&](int lane) {
+      for(int e = lane; e < P.P * M * 3; e += kWave)
+      {
+        mem.pV[e] = I.phase_vertex[e];
+        mem.pR[e] = I.phase_ridge[e];
+      }
+      if(lane < P.P) mem.pdim[lane] = I.phase_dim[lane];
+      for(int e = lane; e < P.N; e += kWave) mem.sphase[e] = static_cast<unsigned char>(I.step_phase[e]);
+    });
   }
 
   // reference of the weighted state entries at a step (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0])
@@ -618,71 +638,193 @@ struct Solver
     return result;
   }
 
-  // Cholesky of H~ (H with clamped rows/columns replaced by identity) into mem.Lf (lower, stride m).
+  // Cholesky of H~ (H = mem.QuuF with the clamped rows/columns replaced by identity, i.e. the factor of H_ff
+  // embedded) into mem.Lf (lower, stride m) + reciprocal diagonal mem.rd.  Arithmetic per entry exactly as the
+  // oracle: subtract the products in increasing k, diagonal = sqrt, sub-diagonal = value * (1 / diagonal).
+  //
+  // Device: ONE phase, lane i (mod 16) keeps row i in registers; pivots and the scaled column travel by
+  // v_readlane (constant lane numbers after unrolling) -- no LDS round trips, no barriers inside.
   CCC_DDP_FN bool cholesky_free(int m)
   {
     const double * H = mem.QuuF;
+#if defined(__HIP_DEVICE_COMPILE__)
     phase([&](int lane) {
-      for(int e = lane; e < m * m; e += kWave)
+      const int i = lane & 15;
+      double a[16];
+#  pragma unroll
+      for(int k = 0; k < 16; ++k)
       {
-        const int i = e / m, j = e % m;
-        const bool cl = mem.clamped[i] || mem.clamped[j];
-        mem.Lf[e] = cl ? (i == j ? 1.0 : 0.0) : H[e];
+        const bool in = (i < m) && (k < m);
+        const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
+        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * m + k]) : (i == k ? 1.0 : 0.0);
       }
-      if(lane == 0) mem.ic[IC_OK] = 1;
+      bool ok = true;
+      double rdi = 1.0;
+#  pragma unroll
+      for(int j = 0; j < 16; ++j)
+      {
+        if(j < m)
+        {
+          const double d = __shfl(a[j], j);
+          ok = ok && (d > 0.0);
+          const double sq = sqrt(d);
+          const double r = 1.0 / sq;
+          if(i == j)
+          {
+            a[j] = sq;
+            rdi = r;
+          }
+          else if(i > j)
+            a[j] = a[j] * r;
+#  pragma unroll
+          for(int k = j + 1; k < 16; ++k)
+          {
+            if(k < m)
+            {
+              const double lkj = __shfl(a[j], k);
+              if(i >= k) a[k] -= a[j] * lkj;
+            }
+          }
+        }
+      }
+      if(lane < m)
+      {
+#  pragma unroll
+        for(int k = 0; k < 16; ++k)
+          if(k <= i) mem.Lf[i * m + k] = a[k];
+        mem.rd[i] = rdi;
+      }
+      if(lane == 0) mem.ic[IC_OK] = ok ? 1 : 0;
     });
-    // right-looking, column by column; the arithmetic per entry (subtract products in increasing k, then
-    // divide) matches the row-oriented loop of the oracle
+    return mem.ic[IC_OK] != 0;
+#else
+    bool ok = true;
+    for(int i = 0; i < m; i++)
+      for(int k = 0; k <= i; k++)
+      {
+        const bool cl = mem.clamped[i] || mem.clamped[k];
+        mem.Lf[i * m + k] = cl ? (i == k ? 1.0 : 0.0) : H[i * m + k];
+      }
     for(int j = 0; j < m; j++)
     {
-      phase([&](int lane) {
-        if(lane == 0)
-        {
-          const double s = mem.Lf[j * m + j];
-          if(!(s > 0.0))
-            mem.ic[IC_OK] = 0;
-          else
-            mem.Lf[j * m + j] = sqrt(s);
-        }
-      });
-      if(!mem.ic[IC_OK]) return false;
-      phase([&](int lane) {
-        const int i = j + 1 + lane;
-        if(i < m) mem.Lf[i * m + j] = mem.Lf[i * m + j] / mem.Lf[j * m + j];
-      });
-      phase([&](int lane) {
-        // trailing update of the lower triangle: A[i][k] -= L[i][j] L[k][j], j < k <= i
-        const int cnt = m - j - 1;
-        for(int e = lane; e < cnt * cnt; e += kWave)
-        {
-          const int i = j + 1 + e / cnt, k = j + 1 + e % cnt;
-          if(k <= i) mem.Lf[i * m + k] -= mem.Lf[i * m + j] * mem.Lf[k * m + j];
-        }
-      });
+      const double d = mem.Lf[j * m + j];
+      ok = ok && (d > 0.0);
+      const double sq = sqrt(d);
+      const double r = 1.0 / sq;
+      mem.Lf[j * m + j] = sq;
+      mem.rd[j] = r;
+      for(int i = j + 1; i < m; i++) mem.Lf[i * m + j] = mem.Lf[i * m + j] * r;
+      for(int k = j + 1; k < m; k++)
+        for(int i = k; i < m; i++) mem.Lf[i * m + k] -= mem.Lf[i * m + j] * mem.Lf[k * m + j];
     }
-    return true;
+    mem.ic[IC_OK] = ok ? 1 : 0;
+    return ok;
+#endif
   }
 
-  // v <- H~^-1 v using mem.Lf (forward then backward substitution; v is an LDS vector of length m)
+  // registers of lane i for the triangular solves: row i of L left of the diagonal, column i below it
+#if defined(__HIP_DEVICE_COMPILE__)
+  CCC_DDP_FN void load_factor_lane(int m, int i, double (&lr)[16], double (&lc)[16], double & rdi) const
+  {
+#  pragma unroll
+    for(int k = 0; k < 16; ++k)
+    {
+      lr[k] = (i < m && k < i) ? mem.Lf[i * m + k] : 0.0;
+      lc[k] = (i < m && k < m && k > i) ? mem.Lf[k * m + i] : 0.0;
+    }
+    rdi = (i < m) ? mem.rd[i] : 1.0;
+  }
+  // acc <- (L L')^-1 acc inside a 16-lane group (WIDTH = 16) or with every group redundant (WIDTH = 64)
+  template<int WIDTH>
+  static CCC_DDP_FN double solve_lane(int m, int i, double acc, const double (&lr)[16], const double (&lc)[16], double rdi)
+  {
+#  pragma unroll
+    for(int k = 0; k < 16; ++k)
+    {
+      if(k < m)
+      {
+        const double yk = __shfl(acc * rdi, k, WIDTH);
+        if(i == k)
+          acc = yk;
+        else if(i > k)
+          acc -= lr[k] * yk;
+      }
+    }
+#  pragma unroll
+    for(int k = 15; k >= 0; --k)
+    {
+      if(k < m)
+      {
+        const double zk = __shfl(acc * rdi, k, WIDTH);
+        if(i == k)
+          acc = zk;
+        else if(i < k)
+          acc -= lc[k] * zk;
+      }
+    }
+    return acc;
+  }
+#endif
+
+  // v <- H~^-1 v using mem.Lf / mem.rd: forward substitution in increasing, backward in DEcreasing column order,
+  // multiplying by the reciprocal diagonal (the oracle's order).  v is an LDS vector of length m.
   CCC_DDP_FN void solve_free(int m, double * v)
   {
+#if defined(__HIP_DEVICE_COMPILE__)
     phase([&](int lane) {
-      if(lane == 0)
-      {
-        for(int a = 0; a < m; a++)
-        {
-          double s = v[a];
-          for(int k = 0; k < a; k++) s -= mem.Lf[a * m + k] * v[k];
-          v[a] = s / mem.Lf[a * m + a];
-        }
-        for(int a = m - 1; a >= 0; a--)
-        {
-          double s = v[a];
-          for(int k = a + 1; k < m; k++) s -= mem.Lf[k * m + a] * v[k];
-          v[a] = s / mem.Lf[a * m + a];
-        }
-      }
+      const int i = lane & 15;
+      double lr[16], lc[16], rdi;
+      load_factor_lane(m, i, lr, lc, rdi);
+      const double acc = solve_lane<64>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi);
+      if(lane < m) v[i] = acc;
     });
+#else
+    for(int a = 0; a < m; a++)
+    {
+      double s = v[a];
+      for(int k = 0; k < a; k++) s -= mem.Lf[a * m + k] * v[k];
+      v[a] = s * mem.rd[a];
+    }
+    for(int a = m - 1; a >= 0; a--)
+    {
+      double s = v[a];
+      for(int k = m - 1; k > a; k--) s -= mem.Lf[k * m + a] * v[k];
+      v[a] = s * mem.rd[a];
+    }
+#endif
+  }
+
+  // K_f = -H_ff^-1 Qxur_f' (clamped rows of K stay zero), k <- kq.  Device: the four 16-lane groups of the
+  // wavefront each solve one right-hand side (state index) at a time.
+  CCC_DDP_FN void gains(int m)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    phase([&](int lane) {
+      const int i = lane & 15, grp = lane >> 4;
+      double lr[16], lc[16], rdi;
+      load_factor_lane(m, i, lr, lc, rdi);
+      const bool cl = (i < m) && mem.clamped[i];
+#  pragma unroll
+      for(int a0 = 0; a0 < S; a0 += 4)
+      {
+        const int a = a0 + grp;
+        const bool act = a < S;
+        double acc = (act && i < m && !cl) ? mem.Qxur[a * M + i] : 0.0;
+        acc = solve_lane<16>(m, i, acc, lr, lc, rdi);
+        if(act && i < m) mem.K[i * S + a] = cl ? 0.0 : -acc;
+      }
+      if(lane < m) mem.k[lane] = mem.kq[lane];
+    });
+#else
+    for(int a = 0; a < S; a++)
+    {
+      double t3[M];
+      for(int f = 0; f < m; f++) t3[f] = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
+      solve_free(m, t3);
+      for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
+    }
+    for(int r = 0; r < m; r++) mem.k[r] = mem.kq[r];
+#endif
   }
 
   // ---- backward pass (oracle/ddp.c backward_pass); returns false when a box-QP / Cholesky fails
@@ -803,28 +945,7 @@ struct Solver
       {
         const int rc = box_qp(m);
         if(rc < 1) return false;
-        // K_f = -H_ff^-1 Qxur_f' : one right-hand side (state index a) per lane, clamped rows stay zero
-        phase([&](int lane) {
-          if(lane < m) mem.k[lane] = mem.kq[lane];
-          if(lane < S)
-          {
-            const int a = lane;
-            double * t3 = mem.T2 + a * M; // (Vxx + lambda I) Fu is consumed; its rows serve as scratch
-            for(int f = 0; f < m; f++)
-            {
-              double s = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
-              for(int kk = 0; kk < f; kk++) s -= mem.Lf[f * m + kk] * t3[kk];
-              t3[f] = s / mem.Lf[f * m + f];
-            }
-            for(int f = m - 1; f >= 0; f--)
-            {
-              double s = t3[f];
-              for(int kk = f + 1; kk < m; kk++) s -= mem.Lf[kk * m + f] * t3[kk];
-              t3[f] = s / mem.Lf[f * m + f];
-            }
-            for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
-          }
-        });
+        gains(m);
       }
       phase([&](int lane) {
         // t4 = Quu k ; gains to global memory
@@ -965,6 +1086,7 @@ struct Solver
   CCC_DDP_FN void solve()
   {
     const int N = P.N;
+    stage_problem();
     phase([&](int lane) {
       if(lane == 0)
       {

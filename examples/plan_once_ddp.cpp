@@ -1,0 +1,94 @@
+// plan_once_ddp.cpp -- one planOnce() of CCC::DdpCentroidal and CCC::DdpSingleRigidBody through the drop-in
+// headers (host C++ -> header shim -> C-ABI -> HIP kernel), on the contact / reference schedule of
+// /root/reference/tests/src/TestDdpCentroidal.cpp:35-80.  Prints the planned force scales of the first horizon
+// step so that tests/test_ddp_gpu.py can compare them with the Python mirror (same kernels, same inputs).
+#include <CCC/DdpCentroidal.h>
+#include <CCC/DdpSingleRigidBody.h>
+
+#include <cstdio>
+
+int main()
+{
+  try
+  {
+    const double dt = 0.03, mass = 100.0;
+    const int N = 100;
+    auto c0 = CCC::makeContactFromRect({CCC::Vector2d(-0.1, -0.1), CCC::Vector2d(0.1, 0.1)});
+    auto c2 = CCC::makeContactFromRect({CCC::Vector2d(0.4, -0.1), CCC::Vector2d(0.6, 0.1)});
+    {
+      CCC::DdpCentroidal::WeightParam w;
+      w.running_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      w.terminal_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      CCC::DdpCentroidal ddp(mass, dt, N, w);
+      ddp.ddp_solver_->config().max_iter = 20;
+      auto motion = [&](double t) {
+        t += 1e-6;
+        CCC::DdpCentroidal::MotionParam mp;
+        if(t < 1.4)
+          mp.contact_list.push_back(c0);
+        else if(t >= 1.6)
+          mp.contact_list.push_back(c2);
+        return mp;
+      };
+      auto ref = [](double t) {
+        t += 1e-6;
+        CCC::DdpCentroidal::RefData r;
+        r.pos = t < 1.4 ? CCC::Vector3d(0.0, 0.0, 1.0) : (t < 1.6 ? CCC::Vector3d(0.25, 0.0, 1.2) : CCC::Vector3d(0.5, 0.0, 1.0));
+        return r;
+      };
+      CCC::DdpCentroidal::InitialParam ip;
+      ip.pos = CCC::Vector3d(0.01, -0.02, 1.0);
+      ip.vel = CCC::Vector3d(0.05, 0.0, 0.0);
+      CCC::VectorXd u = ddp.planOnce(motion, ref, ip, 0.0);
+      std::printf("centroidal iter=%d dim=%d inputDim(1.5)=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size(),
+                  ddp.ddp_problem_->inputDim(1.5));
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+      // warm start, one iteration (TestDdpCentroidal.cpp:102-116)
+      ip.u_list = ddp.ddp_solver_->controlData().u_list;
+      ddp.ddp_solver_->config().max_iter = 1;
+      u = ddp.planOnce(motion, ref, ip, 0.0);
+      std::printf("centroidal_warm iter=%d u0[0]=%.17g\n", ddp.ddp_solver_->traceDataList().back().iter, u[0]);
+    }
+    {
+      CCC::DdpSingleRigidBody::WeightParam w;
+      w.running_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      w.terminal_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      w.running_ori = CCC::Vector3d::Constant(0.5);
+      w.terminal_ori = CCC::Vector3d::Constant(0.5);
+      CCC::DdpSingleRigidBody ddp(mass, dt, N, w);
+      ddp.ddp_solver_->config().max_iter = 20;
+      auto motion = [&](double t) {
+        t += 1e-6;
+        CCC::DdpSingleRigidBody::MotionParam mp;
+        if(t < 1.4)
+          mp.contact_list.push_back(c0);
+        else if(t >= 1.6)
+          mp.contact_list.push_back(c2);
+        mp.inertia_mat(0, 0) = 40.0;
+        mp.inertia_mat(1, 1) = 20.0;
+        mp.inertia_mat(2, 2) = 10.0;
+        return mp;
+      };
+      auto ref = [](double t) {
+        t += 1e-6;
+        CCC::DdpSingleRigidBody::RefData r;
+        r.pos = t < 1.4 ? CCC::Vector3d(0.0, 0.0, 1.0) : (t < 1.6 ? CCC::Vector3d(0.25, 0.0, 1.2) : CCC::Vector3d(0.5, 0.0, 1.0));
+        return r;
+      };
+      CCC::DdpSingleRigidBody::InitialParam ip;
+      ip.pos = CCC::Vector3d(0.01, -0.02, 1.0);
+      ip.ori = CCC::Vector3d(0.02, -0.01, 0.03);
+      CCC::VectorXd u = ddp.planOnce(motion, ref, ip, 0.0);
+      std::printf("srb iter=%d dim=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size());
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+    }
+    return 0;
+  }
+  catch(const std::exception & e)
+  {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 2;
+  }
+}

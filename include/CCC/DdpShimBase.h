@@ -1,0 +1,175 @@
+/* DdpShimBase.h -- shared plumbing of the DdpCentroidal / DdpSingleRigidBody header shims: sampling the reference's
+ * std::function callbacks into the flattened per-instance arrays of include/ccc_amd.h (contact lists -> contact
+ * phases in contact -> vertex -> ridge order, /root/reference/src/DdpCentroidal.cpp:49-60) and the stand-ins for the
+ * nmpc_ddp::DDPSolver members the reference's tests touch (config().max_iter, controlData().u_list,
+ * traceDataList().back().iter: /root/reference/tests/src/TestDdpCentroidal.cpp:102-129).
+ */
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../ccc_amd.h"
+#include "EigenLite.h"
+
+namespace CCC
+{
+namespace ddp_shim
+{
+struct TraceData
+{
+  int iter = 0;
+};
+
+struct ControlData
+{
+  std::vector<VectorXd> u_list;
+  std::vector<std::vector<double>> x_list;
+};
+
+/** Stand-in for nmpc_ddp::DDPSolver<S, Dynamic>: the members the reference's callers use. */
+class Solver
+{
+public:
+  Solver()
+  {
+    ccc_ddp_default_config(&config_);
+  }
+  ccc_ddp_config_t & config()
+  {
+    return config_;
+  }
+  const ControlData & controlData() const
+  {
+    return control_data_;
+  }
+  const std::vector<TraceData> & traceDataList() const
+  {
+    return trace_data_list_;
+  }
+
+  ccc_ddp_config_t config_;
+  ControlData control_data_;
+  std::vector<TraceData> trace_data_list_;
+};
+
+/** Flattened problem of ONE instance (the n = 1 case of the C-ABI arrays). */
+struct Flat
+{
+  int N = 0, P = 0;
+  std::vector<int32_t> phase_dim, step_phase;
+  std::vector<double> phase_vertex, phase_ridge, ref_pos, ref_ori, inertia;
+  std::vector<int> dims; // input dimension per step
+
+  void init(int n_steps, int n_phases)
+  {
+    N = n_steps;
+    P = n_phases;
+    phase_dim.assign(static_cast<size_t>(P), 0);
+    step_phase.assign(static_cast<size_t>(N), 0);
+    phase_vertex.assign(static_cast<size_t>(P) * CCC_DDP_MAX_RIDGES * 3, 0.0);
+    phase_ridge.assign(static_cast<size_t>(P) * CCC_DDP_MAX_RIDGES * 3, 0.0);
+    ref_pos.assign(static_cast<size_t>(N + 1) * 3, 0.0);
+    ref_ori.assign(static_cast<size_t>(N + 1) * 3, 0.0);
+    inertia.assign(9, 0.0);
+    dims.assign(static_cast<size_t>(N), 0);
+    n_used_ = 0;
+  }
+
+  /** Register the contact list of step i (find or append its contact phase). */
+  void setStepContacts(int i, const std::vector<std::shared_ptr<Contact>> & contact_list)
+  {
+    std::vector<double> V, R;
+    for(const auto & contact : contact_list)
+      for(const auto & vr : contact->vertexWithRidgeList_)
+        for(const auto & ridge : vr.ridgeList)
+          for(int a = 0; a < 3; a++)
+          {
+            V.push_back(vr.vertex[a]);
+            R.push_back(ridge[a]);
+          }
+    const int m = static_cast<int>(V.size() / 3);
+    if(m > CCC_DDP_MAX_RIDGES)
+      throw std::runtime_error("[DDP shim] more than " + std::to_string(CCC_DDP_MAX_RIDGES) + " ridges in a contact list");
+    for(int k = 0; k < n_used_; k++)
+    {
+      if(phase_dim[static_cast<size_t>(k)] != m) continue;
+      bool same = true;
+      for(int e = 0; e < m * 3 && same; e++)
+        same = phase_vertex[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] == V[static_cast<size_t>(e)]
+               && phase_ridge[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] == R[static_cast<size_t>(e)];
+      if(same)
+      {
+        step_phase[static_cast<size_t>(i)] = k;
+        dims[static_cast<size_t>(i)] = m;
+        return;
+      }
+    }
+    if(n_used_ >= P) throw std::runtime_error("[DDP shim] more than max_phases distinct contact lists in the horizon");
+    const int k = n_used_++;
+    phase_dim[static_cast<size_t>(k)] = m;
+    for(int e = 0; e < m * 3; e++)
+    {
+      phase_vertex[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] = V[static_cast<size_t>(e)];
+      phase_ridge[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] = R[static_cast<size_t>(e)];
+    }
+    step_phase[static_cast<size_t>(i)] = k;
+    dims[static_cast<size_t>(i)] = m;
+  }
+
+private:
+  int n_used_ = 0;
+};
+
+inline void check(int rc, const char * who)
+{
+  if(rc != CCC_OK) throw std::runtime_error(std::string("[") + who + "] " + ccc_last_error_string());
+}
+
+/** Run one instance through ccc_ddp_plan_batch and fill the solver stand-in; returns u_list[0]. */
+inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool srb, const std::vector<double> & x0,
+                         const std::vector<VectorXd> & u_init_list, const char * who)
+{
+  const int N = f.N, M = CCC_DDP_MAX_RIDGES, S = static_cast<int>(x0.size());
+  std::vector<double> u_init, u(static_cast<size_t>(N) * M, 0.0), x(static_cast<size_t>(N + 1) * S, 0.0);
+  if(!u_init_list.empty())
+  {
+    if(static_cast<int>(u_init_list.size()) != N) throw std::runtime_error(std::string("[") + who + "] u_list length");
+    u_init.assign(static_cast<size_t>(N) * M, 0.0);
+    for(int i = 0; i < N; i++)
+    {
+      if(u_init_list[static_cast<size_t>(i)].size() != f.dims[static_cast<size_t>(i)])
+        throw std::runtime_error(std::string("[") + who + "] u_list[i] size differs from inputDim");
+      for(int r = 0; r < f.dims[static_cast<size_t>(i)]; r++)
+        u_init[static_cast<size_t>(i) * M + r] = u_init_list[static_cast<size_t>(i)][r];
+    }
+  }
+  int32_t iters = 0, status = 0;
+  double cost = 0;
+  check(ccc_ddp_set_config(h, &solver.config_), who);
+  check(ccc_ddp_plan_batch(h, 1, f.phase_dim.data(), f.phase_vertex.data(), f.phase_ridge.data(), f.step_phase.data(),
+                           f.ref_pos.data(), srb ? f.ref_ori.data() : nullptr, srb ? f.inertia.data() : nullptr,
+                           x0.data(), u_init.empty() ? nullptr : u_init.data(), u.data(), x.data(), &iters, &status,
+                           &cost),
+        who);
+  solver.control_data_.u_list.assign(static_cast<size_t>(N), VectorXd());
+  for(int i = 0; i < N; i++)
+  {
+    VectorXd ui(f.dims[static_cast<size_t>(i)]);
+    for(int r = 0; r < f.dims[static_cast<size_t>(i)]; r++) ui[r] = u[static_cast<size_t>(i) * M + r];
+    solver.control_data_.u_list[static_cast<size_t>(i)] = ui;
+  }
+  solver.control_data_.x_list.assign(static_cast<size_t>(N + 1), std::vector<double>(static_cast<size_t>(S)));
+  for(int i = 0; i <= N; i++)
+    for(int a = 0; a < S; a++) solver.control_data_.x_list[static_cast<size_t>(i)][static_cast<size_t>(a)] = x[static_cast<size_t>(i) * S + a];
+  TraceData td;
+  td.iter = iters;
+  solver.trace_data_list_.assign(1, td);
+  return solver.control_data_.u_list[0];
+}
+} // namespace ddp_shim
+} // namespace CCC

@@ -23,52 +23,7 @@
 
 #include "../ccc_amd.h"
 
-#if __has_include(<Eigen/Core>)
-#  include <Eigen/Core>
-namespace CCC
-{
-using Vector2d = Eigen::Vector2d;
-}
-#else
-namespace CCC
-{
-/** Minimal stand-in for Eigen::Vector2d (Eigen is not installed in the build image). */
-struct Vector2d
-{
-  double v[2] = {0.0, 0.0};
-  Vector2d() = default;
-  Vector2d(double x, double y) : v{x, y} {}
-  static Vector2d Zero()
-  {
-    return Vector2d();
-  }
-  double & x()
-  {
-    return v[0];
-  }
-  double & y()
-  {
-    return v[1];
-  }
-  double x() const
-  {
-    return v[0];
-  }
-  double y() const
-  {
-    return v[1];
-  }
-  double & operator[](int i)
-  {
-    return v[i];
-  }
-  double operator[](int i) const
-  {
-    return v[i];
-  }
-};
-} // namespace CCC
-#endif
+#include "EigenLite.h"
 
 namespace CCC
 {

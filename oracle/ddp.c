@@ -51,10 +51,12 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
 /* ------------------------------------------------------------------------------------------- box QP */
 
 /* min 1/2 x'Hx + g'x, lo <= x <= hi; x enters as the warm start.  H: n x n row-major.
- * Outputs: x, is_free[n], Lf (nf x nf lower Cholesky factor of H_ff, row-major with stride n).
+ * Outputs: x, is_free[n], Lf (nf x nf lower Cholesky factor of H_ff, row-major with stride n), rd (nf reciprocals
+ * of its diagonal: the triangular solves multiply by rd instead of dividing; the backward substitution subtracts
+ * in DEcreasing column order -- both choices are part of the frozen specification the HIP kernel shares).
  * Returns the boxQP.m result code (>= 1 success; -1 not positive definite; 0 no descent direction). */
 int oracle_box_qp(int n, const double * H, const double * g, const double * lo, const double * hi, double * x,
-                  int * is_free, double * Lf, int * n_free_out, int * iters_out)
+                  int * is_free, double * Lf, double * rd, int * n_free_out, int * iters_out)
 {
   const int max_iter = 100;
   const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
@@ -119,11 +121,12 @@ int oracle_box_qp(int n, const double * H, const double * g, const double * lo, 
           break;
         }
         Lf[a * n + a] = sqrt(s);
+        rd[a] = 1.0 / Lf[a * n + a];
         for(int b = a + 1; b < nf; b++)
         {
           double t = H[fidx[b] * n + fidx[a]];
           for(int k = 0; k < a; k++) t -= Lf[b * n + k] * Lf[a * n + k];
-          Lf[b * n + a] = t / Lf[a * n + a];
+          Lf[b * n + a] = t * rd[a];
         }
       }
       if(!ok)
@@ -152,13 +155,13 @@ int oracle_box_qp(int n, const double * H, const double * g, const double * lo, 
     {
       double s = tmp[a];
       for(int k = 0; k < a; k++) s -= Lf[a * n + k] * tmp[k];
-      tmp[a] = s / Lf[a * n + a];
+      tmp[a] = s * rd[a];
     }
     for(int a = nf - 1; a >= 0; a--)
     {
       double s = tmp[a];
-      for(int k = a + 1; k < nf; k++) s -= Lf[k * n + a] * tmp[k];
-      tmp[a] = s / Lf[a * n + a];
+      for(int k = nf - 1; k > a; k--) s -= Lf[k * n + a] * tmp[k];
+      tmp[a] = s * rd[a];
     }
     for(int i = 0; i < n; i++) search[i] = 0;
     for(int a = 0; a < nf; a++) search[fidx[a]] = -tmp[a] - x[fidx[a]];
@@ -240,7 +243,7 @@ static void decrease_lambda(ddp_t * d)
 static int backward_pass(ddp_t * d)
 {
   const int S = d->S, N = d->N, M = d->M;
-  double * Vx = (double *)malloc(sizeof(double) * (S + S * S * 4 + S * M * 3 + M * M * 3 + M * 6 + S * 2));
+  double * Vx = (double *)malloc(sizeof(double) * (S + S * S * 4 + S * M * 3 + M * M * 3 + M * 7 + S * 2));
   double * Vxx = Vx + S;
   double * Vxxr = Vxx + S * S;
   double * Qxx = Vxxr + S * S;
@@ -253,7 +256,8 @@ static int backward_pass(ddp_t * d)
   double * Lf = QuuF + M * M;
   double * Qu = Lf + M * M;
   double * lo = Qu + M, * hi = lo + M, * kq = hi + M, * t3 = kq + M, * t4 = t3 + M;
-  double * Qx = t4 + M, * vxn = Qx + S;
+  double * rd = t4 + M;
+  double * Qx = rd + M, * vxn = Qx + S;
   int * is_free = (int *)malloc(sizeof(int) * M);
   int ok = 1;
 
@@ -362,7 +366,7 @@ static int backward_pass(ddp_t * d)
           memcpy(kq, d->k + (size_t)(i + 1) * M, sizeof(double) * m);
         else
           memset(kq, 0, sizeof(double) * m);
-        int rc = oracle_box_qp(m, QuuF, Qu, lo, hi, kq, is_free, Lf, &nf, NULL);
+        int rc = oracle_box_qp(m, QuuF, Qu, lo, hi, kq, is_free, Lf, rd, &nf, NULL);
         if(rc < 1)
         {
           ok = 0;
@@ -377,7 +381,7 @@ static int backward_pass(ddp_t * d)
           hi[r] = INFINITY;
           kq[r] = 0;
         }
-        int rc = oracle_box_qp(m, QuuF, Qu, lo, hi, kq, is_free, Lf, &nf, NULL);
+        int rc = oracle_box_qp(m, QuuF, Qu, lo, hi, kq, is_free, Lf, rd, &nf, NULL);
         if(rc < 1)
         {
           ok = 0;
@@ -396,13 +400,13 @@ static int backward_pass(ddp_t * d)
         {
           double s = Qxur[a * M + fidx[f]];
           for(int k = 0; k < f; k++) s -= Lf[f * m + k] * t3[k];
-          t3[f] = s / Lf[f * m + f];
+          t3[f] = s * rd[f];
         }
         for(int f = cnt - 1; f >= 0; f--)
         {
           double s = t3[f];
-          for(int k = f + 1; k < cnt; k++) s -= Lf[k * m + f] * t3[k];
-          t3[f] = s / Lf[f * m + f];
+          for(int k = cnt - 1; k > f; k--) s -= Lf[k * m + f] * t3[k];
+          t3[f] = s * rd[f];
         }
         for(int f = 0; f < cnt; f++) Ki[fidx[f] * S + a] = -t3[f];
       }

@@ -189,7 +189,7 @@ def _bind_ddp():
         return L
     L.oracle_ddp_default_config.argtypes = [ctypes.POINTER(_DdpConfig)]
     L.oracle_ddp_default_config.restype = None
-    L.oracle_box_qp.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _ip, _ip]
+    L.oracle_box_qp.argtypes = [ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _ip, _ip]
     L.oracle_box_qp.restype = ctypes.c_int
     L.oracle_ddp_model_problem.argtypes = [ctypes.POINTER(_DdpModel), ctypes.POINTER(_DdpProblem)]
     L.oracle_ddp_model_problem.restype = None
@@ -223,10 +223,11 @@ def box_qp(H, g, lo, hi, x0=None):
     x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
     is_free = np.zeros(n, dtype=np.int32)
     Lf = np.zeros((n, n))
+    rd = np.zeros(n)
     nf = ctypes.c_int(0)
     it = ctypes.c_int(0)
     rc = L.oracle_box_qp(n, _ptr(H), _ptr(g), _ptr(lo), _ptr(hi), _ptr(x), _ptr(is_free, ctypes.c_int), _ptr(Lf),
-                         ctypes.byref(nf), ctypes.byref(it))
+                         _ptr(rd), ctypes.byref(nf), ctypes.byref(it))
     return x, rc, is_free.astype(bool), it.value
 
 

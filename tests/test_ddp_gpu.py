@@ -137,3 +137,47 @@ def test_device_entry_and_determinism():
     assert torch.equal(u1, u2)
     host = d.planOnceBatch(prob, x0)
     assert np.array_equal(host["u"], u1.cpu().numpy()) and np.array_equal(host["iters"], it.cpu().numpy())
+
+
+def test_cpp_header_shims_match_python_mirror():
+    """Host C++ against include/CCC/DdpCentroidal.h and DdpSingleRigidBody.h (examples/plan_once_ddp.cpp): same
+    kernels, same sampled inputs as the Python mirrors -> identical force scales; warm start path included."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "plan_once_ddp")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = {ln.split()[0]: ln for ln in out.stdout.strip().splitlines()}
+    N, dt = 100, 0.03
+    V0, R0 = fd.contact_from_rect((-0.1, -0.1), (0.1, 0.1))
+    V2, R2 = fd.contact_from_rect((0.4, -0.1), (0.6, 0.1))
+
+    def contacts(t):
+        ph, _ = fd.reference_schedule(t)
+        return [(V0, R0)] if ph == 0 else ([] if ph == 1 else [(V2, R2)])
+
+    d = _cen(N, dt, 20)
+    ip = DdpCentroidal.InitialParam((0.01, -0.02, 1.0), (0.05, 0.0, 0.0), (0, 0, 0))
+    u = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
+                   lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
+    cpp = np.array([float(v) for v in lines["centroidal"].split("u0=")[1].split()])
+    assert "dim=16" in lines["centroidal"] and "inputDim(1.5)=0" in lines["centroidal"]
+    assert np.array_equal(cpp, u)
+    assert "iter=%d" % d.ddp_solver_.last_iter in lines["centroidal"]
+    ip.u_list = d.ddp_solver_.controlData().u_list
+    d.ddp_solver_.config().max_iter = 1
+    u1 = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
+                    lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
+    assert float(lines["centroidal_warm"].split("u0[0]=")[1]) == u1[0]
+    s = _srb(N, dt, 20)
+    ips = DdpSingleRigidBody.InitialParam((0.01, -0.02, 1.0), (0.02, -0.01, 0.03))
+    us = s.planOnce(lambda t: DdpSingleRigidBody.MotionParam(contacts(t), np.diag([40.0, 20.0, 10.0])),
+                    lambda t: DdpSingleRigidBody.RefData(fd.reference_schedule(t)[1]), ips, 0.0)
+    cpps = np.array([float(v) for v in lines["srb"].split("u0=")[1].split()])
+    assert np.array_equal(cpps, us)
