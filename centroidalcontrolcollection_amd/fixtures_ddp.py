@@ -219,3 +219,49 @@ def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.00
     ori_end = srb_ori_ref(t)[::-1] if srb else np.zeros(3)
     return log, dict(t=t, pos=sim.pos.copy(), ref=ref_end, vel=sim.vel.copy(), ang_mom=sim.ang_mom.copy(),
                      ori=sim.ori.copy(), ori_ref=ori_end, ang_vel=sim.ang_vel.copy())
+
+
+# ===================================================================== LinearMpcXY fixtures
+def xy_reference_schedule(t):
+    """TestLinearMpcXY.cpp:29-80: (rect_min, rect_max, ref pos) at time t (no epsilon in this test)."""
+    if t < 3.0:
+        return (0.9, -0.15), (1.1, 0.15), (1.0, 0.0)
+    if t < 4.0:
+        return (0.9, 0.05), (1.1, 0.15), (1.0, 0.1)
+    if t < 5.0:
+        return (1.15, -0.15), (1.35, -0.05), (1.25, -0.1)
+    if t < 6.0:
+        return (1.4, 0.05), (1.6, 0.15), (1.5, 0.1)
+    return (1.4, -0.15), (1.6, 0.15), (1.5, 0.0)
+
+
+def xy_problem(current_time, N, dt, mass=100.0, M=16, schedule=xy_reference_schedule, com_z=1.0):
+    """One flattened LinearMpcXY instance sampled at current_time + i*dt (src/LinearMpcXY.cpp:102-110):
+    dict(dim [1,N], vertex [1,N,M,3], ridge [1,N,M,3], com_z [1,N], total_force_z [1,N], ref_out [1,N,6])."""
+    prob = dict(dim=np.zeros((1, N), dtype=np.int32), vertex=np.zeros((1, N, M, 3)), ridge=np.zeros((1, N, M, 3)),
+                com_z=np.full((1, N), com_z), total_force_z=np.full((1, N), mass * G), ref_out=np.zeros((1, N, 6)))
+    for i in range(N):
+        rmin, rmax, ref = schedule(current_time + i * dt)
+        V, R = contact_from_rect(rmin, rmax)
+        prob["dim"][0, i] = len(V)
+        prob["vertex"][0, i, :len(V)] = V
+        prob["ridge"][0, i, :len(V)] = R
+        # RefData::toOutput(mass): [m px, m vx, m py, m vy, Lx, Ly] with vel = L = 0
+        prob["ref_out"][0, i] = [mass * ref[0], 0.0, mass * ref[1], 0.0, 0.0, 0.0]
+    return prob
+
+
+def make_xy_batch(n, N=20, dt=0.1, mass=100.0, M=16, seed=20250928):
+    """Synthetic LinearMpcXY workload: the contact pattern of TestLinearMpcXY.cpp:29-57 with a
+    random phase (evaluation time U(0, 7) s) and a random lateral scale, x0 near the reference.
+    Returns (prob, x0 [n,6]) with x0 = InitialParam::toState(mass) = [m px, m vx, m py, m vy, Lx, Ly]."""
+    rng = np.random.default_rng(seed)
+    t0 = rng.uniform(0.0, 7.0, size=n)
+    probs = [xy_problem(t0[k], N, dt, mass, M) for k in range(n)]
+    prob = {k: np.concatenate([p[k] for p in probs]) for k in probs[0]}
+    ref0 = prob["ref_out"][:, 0, :]
+    pos = np.stack([ref0[:, 0] / mass, ref0[:, 2] / mass], axis=1) + rng.uniform(-0.03, 0.03, size=(n, 2))
+    vel = rng.uniform(-0.1, 0.1, size=(n, 2))
+    am = rng.uniform(-0.5, 0.5, size=(n, 2))
+    x0 = np.stack([mass * pos[:, 0], mass * vel[:, 0], mass * pos[:, 1], mass * vel[:, 1], am[:, 0], am[:, 1]], axis=1)
+    return prob, np.ascontiguousarray(x0)

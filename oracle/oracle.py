@@ -312,3 +312,50 @@ class Ddp:
                                 ctypes.cast(ctypes.byref(rc), _dp), ctypes.cast(ctypes.byref(tc), _dp), _ptr(Lx),
                                 _ptr(Lu), _ptr(Vx))
         return dict(x_next=xn, Fx=Fx, Fu=Fu, run_cost=rc.value, term_cost=tc.value, Lx=Lx, Lu=Lu, Vx=Vx)
+
+
+# ===================================================================== LinearMpcXY (linear_mpc_xy.c)
+class _XyParams(ctypes.Structure):
+    _fields_ = [("mass", ctypes.c_double), ("horizon_dt", ctypes.c_double), ("horizon_steps", ctypes.c_int),
+                ("M", ctypes.c_int), ("w_lmi", ctypes.c_double * 2), ("w_lm", ctypes.c_double * 2),
+                ("w_am", ctypes.c_double * 2), ("w_force", ctypes.c_double)]
+
+
+class LinearMpcXY:
+    """CPU restatement of CCC::LinearMpcXY on pre-sampled, flattened per-step data (oracle/linear_mpc_xy.c)."""
+
+    def __init__(self, mass, horizon_dt, horizon_steps, w_lmi=(1.0, 1.0), w_lm=(0.0, 0.0), w_am=(1.0, 1.0),
+                 w_force=1e-5, M=16):
+        L = lib()
+        L.oracle_xy_plan_batch.argtypes = [ctypes.POINTER(_XyParams), ctypes.c_long, _ip, _dp, _dp, _dp, _dp, _dp, _dp,
+                                           _dp, _dp, _ip, _ip, ctypes.c_int]
+        L.oracle_xy_plan_batch.restype = ctypes.c_int
+        self.p = _XyParams()
+        self.p.mass, self.p.horizon_dt, self.p.horizon_steps, self.p.M = float(mass), float(horizon_dt), int(horizon_steps), int(M)
+        for a in range(2):
+            self.p.w_lmi[a], self.p.w_lm[a], self.p.w_am[a] = float(w_lmi[a]), float(w_lm[a]), float(w_am[a])
+        self.p.w_force = float(w_force)
+        self.N, self.M, self.mass = int(horizon_steps), int(M), float(mass)
+
+    def plan_batch(self, prob, x0, nthreads=1, want_all=False):
+        """prob: dict(dim [n,N] i32, vertex [n,N,M,3], ridge [n,N,M,3], com_z [n,N], total_force_z [n,N],
+        ref_out [n,N,6]); x0 [n,6].  Returns dict(u0 [n,M], lam [n,N*M] (compact) | None, iters, status)."""
+        N, M = self.N, self.M
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = x0.shape[0]
+        dim = np.ascontiguousarray(prob["dim"], dtype=np.int32)
+        V = np.ascontiguousarray(prob["vertex"], dtype=np.float64)
+        R = np.ascontiguousarray(prob["ridge"], dtype=np.float64)
+        cz = np.ascontiguousarray(prob["com_z"], dtype=np.float64)
+        fz = np.ascontiguousarray(prob["total_force_z"], dtype=np.float64)
+        ref = np.ascontiguousarray(prob["ref_out"], dtype=np.float64)
+        assert dim.shape == (n, N) and V.shape == (n, N, M, 3) and R.shape == (n, N, M, 3)
+        assert cz.shape == (n, N) and fz.shape == (n, N) and ref.shape == (n, N, 6) and x0.shape == (n, 6)
+        u0 = np.zeros((n, M))
+        lam = np.zeros((n, N * M)) if want_all else None
+        iters = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        lib().oracle_xy_plan_batch(ctypes.byref(self.p), n, _ptr(dim, ctypes.c_int), _ptr(V), _ptr(R), _ptr(cz),
+                                   _ptr(fz), _ptr(ref), _ptr(x0), _ptr(u0), _ptr(lam), _ptr(iters, ctypes.c_int),
+                                   _ptr(status, ctypes.c_int), int(nthreads))
+        return dict(u0=u0, lam=lam, iters=iters, status=status)
