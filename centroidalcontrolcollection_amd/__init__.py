@@ -5,6 +5,7 @@ instances solved at once by hand-written HIP kernels (gfx950) behind the C-ABI o
 See DESIGN.md (scope, kernels, rooflines) and INTEGRATION.md (how the reference binds to it).
 """
 from .ddp import DdpCentroidal, DdpSingleRigidBody  # noqa: F401
+from .linear_mpc_xy import LinearMpcXY  # noqa: F401
 from .linear_mpc_zmp import InitialParam, LinearMpcZmp, RefData  # noqa: F401
 
-__all__ = ["LinearMpcZmp", "RefData", "InitialParam", "DdpCentroidal", "DdpSingleRigidBody"]
+__all__ = ["LinearMpcZmp", "RefData", "InitialParam", "DdpCentroidal", "DdpSingleRigidBody", "LinearMpcXY"]

@@ -40,6 +40,10 @@ ABI_SYMBOLS = [
     "ccc_ddp_state_dim",
     "ccc_ddp_plan_batch_device",
     "ccc_ddp_plan_batch",
+    "ccc_xy_create",
+    "ccc_xy_destroy",
+    "ccc_xy_plan_batch_device",
+    "ccc_xy_plan_batch",
 ]
 
 
@@ -52,7 +56,8 @@ class CccError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    # CCC_AMD_LIB selects another build of the SAME library (e.g. an instrumented one while profiling)
+    return os.environ.get("CCC_AMD_LIB", _build.LIB_PATH)
 
 
 def load():

@@ -158,6 +158,51 @@ int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, cons
                        const double * ref_ori, const double * inertia, const double * x0, const double * u_init,
                        double * u_out, double * x_out, int32_t * iters, int32_t * status, double * cost);
 
+/* =========================================================================================
+ * CCC::LinearMpcXY          /root/reference/include/CCC/LinearMpcXY.h:27-257
+ * ========================================================================================= */
+typedef struct ccc_xy ccc_xy_t;
+
+#define CCC_XY_MAX_STEPS 20 /* horizon steps the kernel is built for (BASELINE config 4: N = 20) */
+
+/* Constructor arguments of LinearMpcXY(mass, horizon_dt, horizon_steps, weight_param, qp_solver_type)
+ * (include/CCC/LinearMpcXY.h:211-215, src/LinearMpcXY.cpp:85-94); WeightParam (:104-142) flattened:
+ * w_lmi = linear_momentum_integral, w_lm = linear_momentum, w_am = angular_momentum, w_force = force.
+ * force_range_ = (3, 3 m g) is fixed as in src/LinearMpcXY.cpp:91. */
+typedef struct
+{
+  double mass;
+  double horizon_dt;
+  int horizon_steps;
+  double w_lmi[2], w_lm[2], w_am[2], w_force;
+} ccc_xy_params_t;
+
+int ccc_xy_create(const ccc_xy_params_t * params, int device, ccc_xy_t ** out);
+void ccc_xy_destroy(ccc_xy_t * h);
+
+/* Replaces n calls of LinearMpcXY::planOnce(motion_param_func, ref_data_func, initial_param, current_time)
+ * (include/CCC/LinearMpcXY.h:224-227, src/LinearMpcXY.cpp:96-182: per-step models :59-83 with their ZOH
+ * discretisation, VariantSequentialExtension, QP coefficients, the external QP solve :181), callbacks sampled at
+ * current_time + i*dt, contact lists flattened in contact -> vertex -> ridge order (:69-82):
+ *
+ *   dim            [n][N]          i32  ridges of step i (0: no contact -> no variables, no equality row, :126-133)
+ *   vertex, ridge  [n][N][16][3]   f64  per-ridge vertex / ridge direction of step i
+ *   com_z          [n][N]          f64  MotionParam::com_z
+ *   total_force_z  [n][N]          f64  MotionParam::total_force_z
+ *   ref_out        [n][N][6]       f64  RefData::toOutput(mass) = [m px, m vx, m py, m vy, Lx, Ly]   (:33-38)
+ *   x0             [n][6]          f64  InitialParam::toState(mass)                                  (:26-31)
+ *   u0             [n][16]         f64  planned force scales of step 0 (first dim[.][0] entries = the return value)
+ *   lambda_all     [n][N][16]      f64  optional: every QP variable, per step
+ *   status         [n]             i32  optional: CCC_STATUS_*
+ * All DEVICE pointers, asynchronous on `stream`. */
+int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t * dim, const double * vertex, const double * ridge,
+                             const double * com_z, const double * total_force_z, const double * ref_out,
+                             const double * x0, double * u0, double * lambda_all, int32_t * status, void * stream);
+/* Same with HOST pointers. */
+int ccc_xy_plan_batch(ccc_xy_t * h, int64_t n, const int32_t * dim, const double * vertex, const double * ridge,
+                      const double * com_z, const double * total_force_z, const double * ref_out, const double * x0,
+                      double * u0, double * lambda_all, int32_t * status);
+
 #ifdef __cplusplus
 }
 #endif
