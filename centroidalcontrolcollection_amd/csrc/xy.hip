@@ -1,20 +1,29 @@
-// xy.hip -- batched CCC::LinearMpcXY::planOnce() on MI355X (gfx950): kernel + C-ABI.  FIRST (dense) VERSION.
+// xy.hip -- batched CCC::LinearMpcXY::planOnce() on MI355X (gfx950): kernel + C-ABI.
 //
 // Path replaced (reference file:line under /root/reference):
 //   src/LinearMpcXY.cpp:59-83      Model::Model (continuous A, B from the flattened contact ridges)
 //   include/CCC/StateSpaceModel.h:170-180   ZOH discretisation -- closed form here: A^3 = 0, so
 //                                  Ad = I + A dt + A^2 dt^2/2,  Bd = B dt + A B dt^2/2 + A^2 B dt^3/6
-//   include/CCC/VariantSequentialExtension.h:110-208   A_seq x0 and B_seq (block lower-triangular)
+//   include/CCC/VariantSequentialExtension.h:110-208   A_seq x0 and B_seq -- never materialised (see below)
 //   src/LinearMpcXY.cpp:116-182    procOnce: H = B'WB + w I, g = -B'W(ref - A x0), one equality row per contact step,
 //                                  bounds [3, 3 m g], the external QP solve (:181), head(m0)
 //
-// One problem instance per 384-thread workgroup.  The QP (n <= 320 variables, <= 20 equalities, bounds) is solved
-// by the same Goldfarb-Idnani dual active-set / sweep-tableau iteration as LinearMpcZmp (csrc/zmp.hip): rows =
-// variables (range constraints lo <= lambda_j <= hi) and equality rows (range of width zero, never dropped);
-// G = C H^-1 C' comes from sweeping the KKT matrix [[H, A'],[A, 0]] on all variables.  Thread i owns row i of the
-// symmetric tableau, which lives in an HBM workspace ([j][i], i fastest: every access is coalesced).  This version
-// is bound by HBM traffic on the rank-1 updates (about 1.9 MB per pivot); exploiting H = w I + (rank 4N) is the
-// planned next step.
+// One problem instance per 320-thread workgroup (5 wavefronts), thread i = variable (step i/16, ridge i%16); nothing
+// but the inputs and outputs touches HBM.  The QP is solved by the Goldfarb-Idnani dual active-set iteration of the
+// oracle (most violated bound enters, blocking multipliers leave), but in "stage space":
+//   column i of B_seq is the response of the N six-dimensional states to the impulse b_i = Bd_s[:, r] applied at step
+//   s, i.e. c_i = R_s b_i with R = sqrt(W) Phi shared by the 16 ridges of a step.  With bt_i = (b_i, rho_z,i) and F the
+//   set of variables that are not clamped at a bound,
+//       M_F  = w diag(I, 0) + sum_{i in F} ct_i ct_i'      (state-residual multipliers theta and equality multipliers),
+//       Qt   = Rt' M_F^-1 Rt                              (7N x 7N, symmetric),
+//   every quantity the iteration needs is a 7-term product with Qt:  D_ip = bt_i' Qt[s_i, s_p] bt_p gives the primal
+//   direction z_i = (delta_ip - D_ip)/w of the free variables and the multiplier rates of the clamped ones, and a
+//   variable changing sides is the rank-1 update Qt -+ pi pi'/(1 +- bt' pi_s), pi = Qt[:, s] bt.
+// Qt lives in REGISTERS: thread t < N(N+1)/2 owns one 7x7 block (rb >= cb) of the lower triangle (98 VGPRs).
+// Set-up: Qt for F = {} is V_s Phi(s, s')/w (backward Gramian recursion, sparse Ad), the 16 N variables are added by
+// rank-1 updates, and the unit regularisation that keeps the equality rows non-singular meanwhile is removed again.
+// The start point (equality-constrained minimiser) and the closing iterative refinement use EXACT residuals from the
+// stage recursion x_{j+1} = Ad_j x_j + Bd_j lambda_j and its adjoint, with Qt as the approximate inverse.
 #include "common.h"
 #include "wave_group.h"
 
@@ -24,12 +33,12 @@
 
 namespace ccc_amd
 {
-constexpr int kXyS = 6;
 constexpr int kXyM = 16;
 constexpr int kXyMaxN = CCC_XY_MAX_STEPS;
-constexpr int kXyNP = 352; // >= 320 variables + 20 equality rows, multiple of 32
-constexpr int kXyNT = 384; // threads per workgroup (6 wavefronts)
+constexpr int kXyNT = kXyMaxN * kXyM; // 320 threads per workgroup (5 wavefronts), one per variable slot
 constexpr int kXyWaves = kXyNT / 64;
+constexpr int kXyNB = 7;                // stage block: 6 states + the step's equality row
+constexpr int kXyQ = kXyMaxN * kXyNB;   // 140
 constexpr double kXyG = 9.80665;
 constexpr double kXyInf = __builtin_huge_val();
 
@@ -48,8 +57,6 @@ struct XyBatch
   const double *vertex, *ridge, *com_z, *total_force_z, *ref_out, *x0;
   double *u0, *lambda_all;
   int * status;
-  double * ws_T;    // [blocks][NP][NP]
-  double * ws_Bhat; // [blocks][6 N][320]
 };
 
 struct XyRed
@@ -58,13 +65,61 @@ struct XyRed
   int idx[kXyWaves];
 };
 
-// (min over the block, lowest thread index attaining it; index kXyNT if every candidate is NaN)
+struct XyShared
+{
+  double bt[kXyNT][kXyNB];               // bt_i = (Bd_s[:, r], rho_z) of every variable
+  double pi[2][kXyQ];                    // Qt[:, s] bt (double buffered: one barrier per rank-1 update)
+  double part[kXyMaxN][kXyMaxN][kXyNB];  // partial products of the full Qt * gamma (refinement only)
+  double gam[kXyQ];
+  double c2[kXyMaxN], c3[kXyMaxN];       // sparse Ad_j: kappa dt, kappa dt^2/2 with kappa = f_z/m
+  double fz[kXyMaxN];
+  double ref[kXyMaxN][6];
+  double beta[kXyMaxN][6];               // Bd_j lambda_j
+  double adj[kXyMaxN][6];                // adjoint states
+  double r2[kXyMaxN];                    // equality residuals
+  double x0[6];
+  double e6[kXyNB];
+  double sg;
+  int dims[kXyMaxN];
+  XyRed red[2];
+};
+
+// y = Ad' x for the sparse Ad = I + {(0,1): c1, (2,3): c1, (4,2): -c2, (4,3): -c3, (5,0): c2, (5,1): c3}
+// (A: src/LinearMpcXY.cpp:63-66, A^3 = 0).  The same operation right-multiplies a row by Ad.
+__device__ __forceinline__ void xy_adT(double & x0, double & x1, double & x2, double & x3, double & x4, double & x5,
+                                       double c1, double c2, double c3)
+{
+  x1 = fma(c1, x0, fma(c3, x5, x1));
+  x3 = fma(c1, x2, fma(-c3, x4, x3));
+  x0 = fma(c2, x5, x0);
+  x2 = fma(-c2, x4, x2);
+}
+// y = Ad x
+__device__ __forceinline__ void xy_ad(double & x0, double & x1, double & x2, double & x3, double & x4, double & x5,
+                                      double c1, double c2, double c3)
+{
+  x4 = fma(-c2, x2, fma(-c3, x3, x4));
+  x5 = fma(c2, x0, fma(c3, x1, x5));
+  x0 = fma(c1, x1, x0);
+  x2 = fma(c1, x3, x2);
+}
+
+__device__ __forceinline__ double xy_row16_sum(double v)
+{
+  v += dpp_f64<kDppQuadXor1>(v);
+  v += dpp_f64<kDppQuadXor2>(v);
+  v += dpp_f64<kDppRowHalfMirror>(v);
+  v += dpp_f64<kDppRowMirror>(v);
+  return v;
+}
+
+// (min over the block, lowest thread index attaining it; index kXyNT if every candidate is +inf/NaN).  One barrier:
+// callers alternate the two reduction buffers.
 __device__ __forceinline__ void xy_block_argmin(double v, XyRed * red, double & vmin, int & imin)
 {
   const int tid = threadIdx.x, w = tid >> 6;
   const double wm = WaveGroup<64>::min(v);
-  const int wi = WaveGroup<64>::first(v == wm);
-  __syncthreads();
+  const int wi = WaveGroup<64>::first(v == wm && v < kXyInf);
   if((tid & 63) == 0)
   {
     red->val[w] = wm;
@@ -86,412 +141,425 @@ __device__ __forceinline__ void xy_block_argmin(double v, XyRed * red, double & 
   imin = bi;
 }
 
-__global__ __launch_bounds__(kXyNT) void xy_plan_kernel(XyParams P, XyBatch B, long n)
+struct XyBlock
 {
-  constexpr int S = kXyS, M = kXyM, NP = kXyNP;
-  __shared__ double Ad[kXyMaxN][S * S];
-  __shared__ double Bd[kXyMaxN][S * M];
-  __shared__ double res[kXyMaxN * S]; // ref - A_seq x0
-  __shared__ double cb[NP];           // staged pivot column / vectors
-  __shared__ double gvec[NP];         // QP gradient
-  __shared__ double Btile[kXyMaxN * S][32];
-  __shared__ int off[kXyMaxN + 1];
-  __shared__ int dims[kXyMaxN];
-  __shared__ int eqrow_of_step[kXyMaxN];
-  __shared__ XyRed red;
-  __shared__ int s_flag;
+  double q[kXyNB][kXyNB]; // Qt[7 rb + a][7 cb + c]
+};
+
+// pi = Qt[:, 7 s .. 7 s + 6] bv  (owners of the blocks in block-column s and block-row s write their 7 entries)
+__device__ __forceinline__ void xy_col(const XyBlock & Q, bool owner, int rb, int cb, int s, const double * bv,
+                                       double * pi)
+{
+  if(!owner) return;
+  if(cb == s)
+  {
+    double b[kXyNB];
+#pragma unroll
+    for(int c = 0; c < kXyNB; c++) b[c] = bv[c];
+#pragma unroll
+    for(int a = 0; a < kXyNB; a++)
+    {
+      double acc = 0.0;
+#pragma unroll
+      for(int c = 0; c < kXyNB; c++) acc = fma(Q.q[a][c], b[c], acc);
+      pi[kXyNB * rb + a] = acc;
+    }
+  }
+  else if(rb == s)
+  {
+    double b[kXyNB];
+#pragma unroll
+    for(int a = 0; a < kXyNB; a++) b[a] = bv[a];
+    // (accumulated row by row: a different instruction stream from the branch above keeps the optimiser from
+    //  merging the two into one body that indexes Q dynamically, which would push the block out of registers)
+    double acc[kXyNB];
+#pragma unroll
+    for(int c = 0; c < kXyNB; c++) acc[c] = Q.q[0][c] * b[0];
+#pragma unroll
+    for(int a = 1; a < kXyNB; a++)
+#pragma unroll
+      for(int c = 0; c < kXyNB; c++) acc[c] = fma(Q.q[a][c], b[a], acc[c]);
+#pragma unroll
+    for(int c = 0; c < kXyNB; c++) pi[kXyNB * cb + c] = acc[c];
+  }
+}
+
+// Qt -= sign * pi pi' / (1 + sign * bv' pi_s)   (sign = +1: the variable becomes free, -1: it is clamped).
+// Every thread runs the update on its block (threads without one keep a dummy; enable = false scales it to nothing):
+// unconditional arithmetic keeps the 49 block entries in place in their registers.
+__device__ __forceinline__ void xy_rank1(XyBlock & Q, bool enable, int rb, int cb, int s, const double * bv,
+                                         const double * pi, double sign)
+{
+  double den = 1.0;
+#pragma unroll
+  for(int c = 0; c < kXyNB; c++) den = fma(sign * bv[c], pi[kXyNB * s + c], den);
+  const double coef = enable ? -sign / den : 0.0;
+  double pr[kXyNB], pc[kXyNB];
+#pragma unroll
+  for(int a = 0; a < kXyNB; a++)
+  {
+    pr[a] = coef * pi[kXyNB * rb + a];
+    pc[a] = pi[kXyNB * cb + a];
+  }
+#pragma unroll
+  for(int a = 0; a < kXyNB; a++)
+#pragma unroll
+    for(int c = 0; c < kXyNB; c++) Q.q[a][c] = fma(pr[a], pc[c], Q.q[a][c]);
+}
+
+__global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B, long n)
+{
+  constexpr int M = kXyM, NB = kXyNB;
+  __shared__ XyShared sh;
 
   const int i = threadIdx.x;
   const int N = P.N;
-  double * T = B.ws_T + (size_t)blockIdx.x * NP * NP;
-  double * Bhat = B.ws_Bhat + (size_t)blockIdx.x * (kXyMaxN * S) * (kXyMaxN * M);
-  const int BW = kXyMaxN * M; // row stride of Bhat
+  const int s_i = i >> 4, r_i = i & 15;
+  // block ownership: thread t < N (N + 1)/2 holds block (rb, cb), cb <= rb
+  int rb = 0;
+  while((rb + 1) * (rb + 2) / 2 <= i) rb++;
+  int cb = i - rb * (rb + 1) / 2;
+  const bool owner = rb < N;
+  if(!owner) rb = cb = 0; // dummy block: same arithmetic, never stored
+  const double c1 = P.dt;
+  const double wf = P.w_force, iwf = 1.0 / P.w_force;
+  if(i < NB) sh.e6[i] = (i == NB - 1) ? 1.0 : 0.0;
 
   for(long b = blockIdx.x; b < n; b += gridDim.x)
   {
-    // ---------------- per-step models (src/LinearMpcXY.cpp:59-83) and their closed-form ZOH
-    if(i == 0)
-    {
-      int acc = 0, eq = 0;
-      for(int k = 0; k < N; k++)
-      {
-        const int d = B.dim[b * N + k];
-        dims[k] = d;
-        off[k] = acc;
-        acc += d;
-        eqrow_of_step[k] = d > 0 ? eq++ : -1;
-      }
-      off[N] = acc;
-      s_flag = eq;
-    }
     __syncthreads();
-    const int tot = off[N], me = s_flag, NR = tot + me;
+    // ---------------- per-step data and the variables' impulse vectors (src/LinearMpcXY.cpp:59-83, closed-form ZOH)
     if(i < N)
     {
-      const int k = i;
-      const double fz = B.total_force_z[b * N + k] / P.mass;
-      // A: (0,1)=1, (2,3)=1, (4,2)=-fz, (5,0)=fz ; A^2: (4,3)=-fz, (5,1)=fz ; A^3 = 0
-      double * a = Ad[k];
-      for(int e = 0; e < S * S; e++) a[e] = (e / S == e % S) ? 1.0 : 0.0;
-      a[0 * S + 1] += P.dt;
-      a[2 * S + 3] += P.dt;
-      a[4 * S + 2] += -fz * P.dt;
-      a[5 * S + 0] += fz * P.dt;
-      a[4 * S + 3] += -fz * P.dt * P.dt / 2;
-      a[5 * S + 1] += fz * P.dt * P.dt / 2;
+      const double fz = B.total_force_z[b * N + i];
+      const double kap = fz / P.mass;
+      sh.fz[i] = fz;
+      sh.c2[i] = kap * P.dt;
+      sh.c3[i] = kap * P.dt * P.dt / 2;
+      sh.dims[i] = B.dim[b * N + i];
     }
-    __syncthreads();
-    for(int e = i; e < N * M; e += kXyNT)
+    for(int e = i; e < N * 6; e += kXyNT) sh.ref[e / 6][e % 6] = B.ref_out[(size_t)b * N * 6 + e];
+    if(i < 6) sh.x0[i] = B.x0[b * 6 + i];
+    const bool valid = s_i < N && r_i < B.dim[b * N + (s_i < N ? s_i : 0)];
+    double bt[NB];
+#pragma unroll
+    for(int c = 0; c < NB; c++) bt[c] = 0.0;
+    if(valid)
     {
-      const int k = e / M, r = e % M;
-      if(r < dims[k])
+      const double * v = B.vertex + ((size_t)(b * N + s_i) * M + r_i) * 3;
+      const double * rd = B.ridge + ((size_t)(b * N + s_i) * M + r_i) * 3;
+      const double cz = B.com_z[b * N + s_i];
+      const double fz = B.total_force_z[b * N + s_i] / P.mass;
+      const double bc[6] = {0.0, rd[0], 0.0, rd[1], -1 * (v[2] - cz) * rd[1] + v[1] * rd[2],
+                            (v[2] - cz) * rd[0] + -1 * v[0] * rd[2]};
+      const double ab[6] = {bc[1], 0.0, bc[3], 0.0, -fz * bc[2], fz * bc[0]};
+      const double aab[6] = {0.0, 0.0, 0.0, 0.0, -fz * bc[3], fz * bc[1]};
+      const double dt = P.dt;
+#pragma unroll
+      for(int a = 0; a < 6; a++) bt[a] = bc[a] * dt + ab[a] * dt * dt / 2 + aab[a] * dt * dt * dt / 6;
+      bt[6] = rd[2];
+    }
+#pragma unroll
+    for(int c = 0; c < NB; c++) sh.bt[i][c] = bt[c];
+    __syncthreads();
+
+    // ---------------- Qt for F = {}: block (s, s') = V_s Phi(s, s')/w, V_s = W + Ad_{s+1}' V_{s+1} Ad_{s+1};
+    //                  equality part regularised by 1 (removed below)
+    XyBlock Q;
+#pragma unroll
+    for(int a = 0; a < NB; a++)
+#pragma unroll
+      for(int c = 0; c < NB; c++) Q.q[a][c] = 0.0;
+    {
+#pragma unroll
+      for(int a = 0; a < 6; a++) Q.q[a][a] = P.w[a];
+      for(int j = N - 1; j > rb; j--)
       {
-        const double * v = B.vertex + ((size_t)(b * N + k) * M + r) * 3;
-        const double * rd = B.ridge + ((size_t)(b * N + k) * M + r) * 3;
-        const double cz = B.com_z[b * N + k];
-        const double fz = B.total_force_z[b * N + k] / P.mass;
-        const double bc[6] = {0.0, rd[0], 0.0, rd[1], -1 * (v[2] - cz) * rd[1] + v[1] * rd[2],
-                              (v[2] - cz) * rd[0] + -1 * v[0] * rd[2]};
-        // A b and A^2 b for the sparse A above
-        const double ab[6] = {bc[1], 0.0, bc[3], 0.0, -fz * bc[2], fz * bc[0]};
-        const double aab[6] = {0.0, 0.0, 0.0, 0.0, -fz * bc[3], fz * bc[1]};
-        const double dt = P.dt;
-        for(int a = 0; a < S; a++) Bd[k][a * M + r] = bc[a] * dt + ab[a] * dt * dt / 2 + aab[a] * dt * dt * dt / 6;
+        const double c2 = sh.c2[j], c3 = sh.c3[j];
+#pragma unroll
+        for(int a = 0; a < 6; a++) xy_adT(Q.q[a][0], Q.q[a][1], Q.q[a][2], Q.q[a][3], Q.q[a][4], Q.q[a][5], c1, c2, c3);
+#pragma unroll
+        for(int c = 0; c < 6; c++) xy_adT(Q.q[0][c], Q.q[1][c], Q.q[2][c], Q.q[3][c], Q.q[4][c], Q.q[5][c], c1, c2, c3);
+#pragma unroll
+        for(int a = 0; a < 6; a++) Q.q[a][a] += P.w[a];
       }
-    }
-    __syncthreads();
-    // ---------------- B_seq (VariantSequentialExtension.h:145-186): column j = (step s, ridge r), rows of steps k >= s
-    if(i < tot)
-    {
-      int s = 0;
-      while(off[s + 1] <= i) s++;
-      const int r = i - off[s];
-      double v[6];
-      for(int a = 0; a < S; a++) v[a] = Bd[s][a * M + r];
-      for(int k = 0; k < N; k++)
+      for(int j = rb; j > cb; j--)
       {
-        if(k < s)
+        const double c2 = sh.c2[j], c3 = sh.c3[j];
+#pragma unroll
+        for(int a = 0; a < 6; a++) xy_adT(Q.q[a][0], Q.q[a][1], Q.q[a][2], Q.q[a][3], Q.q[a][4], Q.q[a][5], c1, c2, c3);
+      }
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+#pragma unroll
+        for(int c = 0; c < 6; c++) Q.q[a][c] *= iwf;
+      if(rb == cb) Q.q[6][6] = 1.0;
+    }
+    // ---------------- add every variable (F = all), then remove the regularisation of the contact steps' equality rows
+    int buf = 0;
+    for(int v = 0; v < N * M; v++)
+    {
+      const int sv = v >> 4;
+      if((v & 15) >= sh.dims[sv]) continue;
+      xy_col(Q, owner, rb, cb, sv, sh.bt[v], sh.pi[buf]);
+      __syncthreads();
+      xy_rank1(Q, true, rb, cb, sv, sh.bt[v], sh.pi[buf], 1.0);
+      buf ^= 1;
+    }
+    for(int sv = 0; sv < N; sv++)
+    {
+      if(sh.dims[sv] == 0) continue;
+      xy_col(Q, owner, rb, cb, sv, sh.e6, sh.pi[buf]);
+      __syncthreads();
+      xy_rank1(Q, true, rb, cb, sv, sh.e6, sh.pi[buf], -1.0);
+      buf ^= 1;
+    }
+
+    const double tl = 1e-12 * (1.0 + fabs(P.flo)), th = 1e-12 * (1.0 + fabs(P.fhi));
+    double lam = 0.0, mu = 0.0;
+    int stt = 0; // 0 free, -1 clamped at the lower bound, +1 at the upper bound
+    int st = CCC_STATUS_SOLVED, passes = 0, rbuf = 0;
+    const int maxpass = 20 * N * M + 100;
+
+    // lambda += (approximate inverse)(exact residuals): x_{j+1} = Ad_j x_j + Bd_j lambda_j, e_j = W (x_{j+1} - ref_j),
+    // adjoint p_j = e_j + Ad_{j+1}' p_{j+1}, gradient_i = w lambda_i + b_i' p_s, r2_s = f_z,s - sum rho_z lambda
+    auto refine = [&]() __attribute__((always_inline)) {
+      __syncthreads();
+      {
+        double t6[6];
+#pragma unroll
+        for(int a = 0; a < 6; a++) t6[a] = xy_row16_sum(bt[a] * lam);
+        const double sz = xy_row16_sum(bt[6] * lam);
+        if(r_i == 0 && s_i < N)
         {
-          for(int a = 0; a < S; a++) Bhat[(size_t)(k * S + a) * BW + i] = 0.0;
-          continue;
+#pragma unroll
+          for(int a = 0; a < 6; a++) sh.beta[s_i][a] = t6[a];
+          sh.r2[s_i] = sh.fz[s_i] - sz;
         }
-        if(k > s)
+      }
+      __syncthreads();
+      if(i == 0)
+      {
+        double x[6];
+#pragma unroll
+        for(int a = 0; a < 6; a++) x[a] = sh.x0[a];
+        for(int j = 0; j < N; j++)
         {
-          double nv[6];
-          for(int a = 0; a < S; a++)
+          xy_ad(x[0], x[1], x[2], x[3], x[4], x[5], c1, sh.c2[j], sh.c3[j]);
+#pragma unroll
+          for(int a = 0; a < 6; a++)
           {
-            double t = 0;
-            for(int c = 0; c < S; c++) t += Ad[k][a * S + c] * v[c];
-            nv[a] = t;
+            x[a] += sh.beta[j][a];
+            sh.adj[j][a] = P.w[a] * (x[a] - sh.ref[j][a]);
           }
-          for(int a = 0; a < S; a++) v[a] = nv[a];
         }
-        for(int a = 0; a < S; a++) Bhat[(size_t)(k * S + a) * BW + i] = v[a];
-      }
-    }
-    // ---------------- res = ref - A_seq x0 (free response, sequential over the horizon)
-    if(i == kXyNT - 1)
-    {
-      double x[6];
-      for(int a = 0; a < S; a++) x[a] = B.x0[b * S + a];
-      for(int k = 0; k < N; k++)
-      {
-        double nx[6];
-        for(int a = 0; a < S; a++)
+        double p[6] = {0, 0, 0, 0, 0, 0};
+        for(int j = N - 1; j >= 0; j--)
         {
-          double t = 0;
-          for(int c = 0; c < S; c++) t += Ad[k][a * S + c] * x[c];
-          nx[a] = t;
-        }
-        for(int a = 0; a < S; a++)
-        {
-          x[a] = nx[a];
-          res[k * S + a] = B.ref_out[(size_t)(b * N + k) * S + a] - x[a];
-        }
-      }
-    }
-    __syncthreads();
-    // ---------------- KKT matrix Q = [[H, A'],[A, 0]] into the tableau; H = B'WB + w I (src/LinearMpcXY.cpp:141-144)
-    const int K = N * S;
-    {
-      double gi = 0.0;
-      for(int q0 = 0; q0 < tot; q0 += 32)
-      {
-        __syncthreads();
-        for(int e = i; e < K * 32; e += kXyNT)
-        {
-          const int k = e / 32, qq = e % 32;
-          Btile[k][qq] = (q0 + qq < tot) ? Bhat[(size_t)k * BW + q0 + qq] : 0.0;
-        }
-        __syncthreads();
-        if(i < tot)
-        {
-          double acc[32];
+          if(j + 1 < N) xy_adT(p[0], p[1], p[2], p[3], p[4], p[5], c1, sh.c2[j + 1], sh.c3[j + 1]);
 #pragma unroll
-          for(int qq = 0; qq < 32; qq++) acc[qq] = 0.0;
-          for(int k = 0; k < K; k++)
+          for(int a = 0; a < 6; a++)
           {
-            const double wb = P.w[k % S] * Bhat[(size_t)k * BW + i];
-#pragma unroll
-            for(int qq = 0; qq < 32; qq++) acc[qq] = fma(wb, Btile[k][qq], acc[qq]);
+            p[a] += sh.adj[j][a];
+            sh.adj[j][a] = p[a];
           }
+        }
+      }
+      __syncthreads();
+      double r1 = 0.0;
+      {
+        double gr = wf * lam;
+        if(s_i < N)
+        {
 #pragma unroll
-          for(int qq = 0; qq < 32; qq++)
-            if(q0 + qq < tot) T[(size_t)(q0 + qq) * NP + i] = acc[qq] + ((q0 + qq == i) ? P.w_force : 0.0);
+          for(int a = 0; a < 6; a++) gr = fma(bt[a], sh.adj[s_i][a], gr);
         }
-      }
-      // g = -B'W res (:145-146)
-      if(i < tot)
-      {
-        for(int k = 0; k < K; k++) gi = fma(P.w[k % S] * Bhat[(size_t)k * BW + i], res[k], gi);
-        gvec[i] = -gi;
-      }
-    }
-    __syncthreads();
-    // equality rows (:149-176): row tot + e, columns of step k: ridge z
-    if(i < NR)
-    {
-      if(i < tot)
-      {
-        int s = 0;
-        while(off[s + 1] <= i) s++;
-        const int r = i - off[s];
-        const double rz = B.ridge[((size_t)(b * N + s) * M + r) * 3 + 2];
-        for(int e = 0; e < me; e++) T[(size_t)(tot + e) * NP + i] = (e == eqrow_of_step[s]) ? rz : 0.0;
-      }
-      else
-      {
-        const int e = i - tot;
-        int s = 0;
-        while(eqrow_of_step[s] != e) s++;
-        for(int j = 0; j < tot; j++)
-          T[(size_t)j * NP + i] =
-              (j >= off[s] && j < off[s + 1]) ? B.ridge[((size_t)(b * N + s) * M + (j - off[s])) * 3 + 2] : 0.0;
-        for(int e2 = 0; e2 < me; e2++) T[(size_t)(tot + e2) * NP + i] = 0.0;
-      }
-    }
-    __syncthreads();
-    // ---------------- sweep every variable: T <- sweep(Q) (T_vv = -H^-1, T_ev = A H^-1, T_ee = -A H^-1 A')
-    for(int kp = 0; kp < tot; kp++)
-    {
-      if(i < NR) cb[i] = T[(size_t)kp * NP + i];
-      __syncthreads();
-      if(i < NR)
-      {
-        const double rp = 1.0 / cb[kp];
-        if(i == kp)
+        // the gradient of a free variable is rho_z eta_s (equality multiplier) plus the residual: take the multiplier
+        // part out (least squares over the step's free ridges) -- left in, it would have to cancel inside
+        // r1 - bt' pi to 1e-12 relative, which the updated Qt cannot deliver
+        const bool fr = valid && stt == 0;
+        const double num = xy_row16_sum(fr ? bt[6] * gr : 0.0), dsq = xy_row16_sum(fr ? bt[6] * bt[6] : 0.0);
+        const double eta = dsq > 0.0 ? num / dsq : 0.0;
+        r1 = fr ? -(gr - bt[6] * eta) : 0.0;
+        double t7[NB];
+#pragma unroll
+        for(int c = 0; c < NB; c++) t7[c] = xy_row16_sum(bt[c] * r1);
+        if(r_i == 0 && s_i < N)
         {
-          for(int j = 0; j < NR; j++) T[(size_t)j * NP + i] = cb[j] * rp;
-          T[(size_t)kp * NP + i] = -rp;
-        }
-        else
-        {
-          const double g = cb[i] * rp;
-          for(int j = 0; j < NR; j++) T[(size_t)j * NP + i] = fma(-g, cb[j], T[(size_t)j * NP + i]);
-          T[(size_t)kp * NP + i] = g;
+          const bool has = sh.dims[s_i] > 0;
+#pragma unroll
+          for(int c = 0; c < NB; c++) sh.gam[NB * s_i + c] = has ? t7[c] : 0.0;
+          if(has) sh.gam[NB * s_i + 6] -= wf * sh.r2[s_i];
         }
       }
       __syncthreads();
-    }
-    // ---------------- G = D (-T) D, D = diag(I_var, -I_eq); lambda* = -H^-1 g; per-row ranges
-    const bool iseq = i >= tot && i < NR;
-    const bool isrow = i < NR;
-    double lam0 = 0.0;
-    if(isrow)
-    {
-      double acc = 0.0;
-      for(int j = 0; j < NR; j++)
+      if(owner)
       {
-        const bool jeq = j >= tot;
-        const double gij = (iseq == jeq) ? -T[(size_t)j * NP + i] : T[(size_t)j * NP + i];
-        T[(size_t)j * NP + i] = gij;
-        if(!jeq) acc = fma(gij, gvec[j], acc);
-      }
-      lam0 = -acc; // variable rows: lambda*_i ; equality rows: (A lambda*)_e
-      cb[i] = lam0;
-    }
-    __syncthreads();
-    double lo = -kXyInf, hi = kXyInf;
-    if(isrow)
-    {
-      if(!iseq)
-      {
-        lo = P.flo - lam0;
-        hi = P.fhi - lam0;
-      }
-      else
-      {
-        int s = 0;
-        while(eqrow_of_step[s] != i - tot) s++;
-        lo = hi = B.total_force_z[b * N + s] - lam0;
-      }
-    }
-    const double tl = isrow ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
-    const double th = isrow ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
-    // ---------------- dual active-set iteration (see csrc/zmp.hip)
-    double z = 0.0, mu = 0.0;
-    bool inW = false;
-    int p = 0, st = CCC_STATUS_SOLVED, passes = 0;
-    double psig = 0.0, pd = 0.0;
-    bool need_select = true;
-    const int maxpass = 20 * NR + 100;
-    for(;;)
-    {
-      if(need_select)
-      {
-        const double sl = (lo - z) - tl, sh = (z - hi) - th;
-        double score = (inW || !isrow) ? -kXyInf : fmax(sl, sh);
-        if(iseq && score > 0.0) score = 1e300; // equality rows enter first
-        double m;
-        int cand;
-        xy_block_argmin(-score, &red, m, cand);
-        m = -m;
-        if(!(m > 0.0)) break;
-        p = cand;
-        if(i == cand)
+        double g1[NB], g2[NB];
+#pragma unroll
+        for(int c = 0; c < NB; c++)
         {
-          psig = (sl >= sh) ? 1.0 : -1.0;
-          pd = (sl >= sh) ? lo : hi;
-          cb[NP - 1] = psig;
+          g1[c] = sh.gam[NB * cb + c];
+          g2[c] = sh.gam[NB * rb + c];
         }
-        __syncthreads();
-      }
-      else
-      {
-        if(i == p) cb[NP - 1] = psig;
-        __syncthreads();
-      }
-      const double sig = cb[NP - 1];
-      const double c = isrow ? T[(size_t)p * NP + i] : 0.0;
-      const double dm = -sig * c;
-      const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-      const bool isp = (i == p);
-      const double num = isp ? psig * (pd - z) : -mu;
-      const double den = isp ? c : dm;
-      const double ratio = (isp || blocking) ? num / den : kXyInf;
-      double t;
-      int kk;
-      xy_block_argmin(ratio, &red, t, kk);
-      if(kk >= kXyNT)
-      {
-        st = CCC_STATUS_MAX_ITER;
-        break;
-      }
-      const bool isadd = (kk == p);
-      const double s = isadd ? 1.0 : -1.0;
-      if(inW)
-        mu = fma(t, dm, mu);
-      else
-        z = fma(sig * t, c, z);
-      if(isp) mu += sig * t;
-      const double v = isrow ? T[(size_t)kk * NP + i] : 0.0;
-      __syncthreads();
-      if(isrow) cb[i] = v;
-      __syncthreads();
-      if(isrow)
-      {
-        const double rp = 1.0 / cb[kk];
-        if(i == kk)
+#pragma unroll
+        for(int a = 0; a < NB; a++)
         {
-          for(int j = 0; j < NR; j++) T[(size_t)j * NP + i] = s * cb[j] * rp;
-          T[(size_t)kk * NP + i] = -rp;
-        }
-        else
-        {
-          const double g = v * rp;
-          for(int j = 0; j < NR; j++) T[(size_t)j * NP + i] = fma(-g, cb[j], T[(size_t)j * NP + i]);
-          T[(size_t)kk * NP + i] = s * g;
-        }
-      }
-      __syncthreads();
-      if(isadd)
-      {
-        if(isp)
-        {
-          inW = true;
-          z = pd;
-        }
-        need_select = true;
-      }
-      else
-      {
-        if(i == kk)
-        {
-          inW = false;
-          mu = 0.0;
-        }
-        need_select = false;
-      }
-      if(++passes > maxpass)
-      {
-        st = CCC_STATUS_MAX_ITER;
-        break;
-      }
-    }
-    // ---------------- iterative refinement against the ORIGINAL data (removes the drift of the ~400 rank-1 updates):
-    //   r1 = -(H lambda + g) on the free variables, with H lambda = B'(W (B lambda)) + w lambda from B_seq itself,
-    //   r2 = f_z - sum rho_z lambda on the equality rows (exact residuals);
-    //   delta lambda_F = T_FF r1 + T_F,eq r2 : on the swept tableau T_FF is the inverse reduced Hessian (it annihilates
-    //   the constraint normals, so the equality multipliers are not needed) and T_iW = G_iW G_WW^-1.
-    {
-      double * wy = &Btile[0][0];        // [K]   W (B lambda)
-      double * rvec = &Btile[0][0] + 256; // [NR]  residuals
-      for(int rep = 0; rep < 2; rep++)
-      {
-        __syncthreads();
-        if(i < tot) cb[i] = lam0 + z;
-        __syncthreads();
-        for(int k = (i >> 6); k < K; k += kXyWaves)
-        {
-          double part = 0.0;
-          for(int j = (i & 63); j < tot; j += 64) part = fma(Bhat[(size_t)k * BW + j], cb[j], part);
-          part = WaveGroup<64>::sum(part);
-          if((i & 63) == 0) wy[k] = P.w[k % S] * part;
-        }
-        __syncthreads();
-        if(i < tot)
-        {
-          double hl = P.w_force * cb[i] + gvec[i];
-          for(int k = 0; k < K; k++) hl = fma(Bhat[(size_t)k * BW + i], wy[k], hl);
-          rvec[i] = inW ? 0.0 : -hl;
-        }
-        else if(iseq)
-        {
-          int sstep = 0;
-          while(eqrow_of_step[sstep] != i - tot) sstep++;
           double acc = 0.0;
-          for(int r = 0; r < dims[sstep]; r++)
-            acc = fma(B.ridge[((size_t)(b * N + sstep) * M + r) * 3 + 2], cb[off[sstep] + r], acc);
-          rvec[i] = B.total_force_z[b * N + sstep] - acc;
+#pragma unroll
+          for(int c = 0; c < NB; c++) acc = fma(Q.q[a][c], g1[c], acc);
+          sh.part[rb][cb][a] = acc;
         }
-        __syncthreads();
-        if(i < tot && !inW)
+        if(rb != cb)
         {
-          double dz = 0.0;
-          for(int j = 0; j < NR; j++) dz = fma(T[(size_t)j * NP + i], rvec[j], dz);
-          z += dz;
+#pragma unroll
+          for(int c = 0; c < NB; c++)
+          {
+            double acc = 0.0;
+#pragma unroll
+            for(int a = 0; a < NB; a++) acc = fma(Q.q[a][c], g2[a], acc);
+            sh.part[cb][rb][c] = acc;
+          }
         }
       }
-    }
-    // ---------------- outputs: lambda = lambda* + z on the variable rows (:181 head(m0))
-    __syncthreads();
-    if(i < M) B.u0[b * M + i] = 0.0;
-    if(B.lambda_all)
-      for(int e = i; e < N * M; e += kXyNT) B.lambda_all[(size_t)b * N * M + e] = 0.0;
-    __syncthreads();
-    if(i < tot)
-    {
-      const double lam = lam0 + z;
-      if(i < dims[0]) B.u0[b * M + i] = lam;
-      if(B.lambda_all)
+      __syncthreads();
+      if(i < N * NB)
       {
-        int s = 0;
-        while(off[s + 1] <= i) s++;
-        B.lambda_all[((size_t)b * N + s) * M + (i - off[s])] = lam;
+        double acc = 0.0;
+        for(int q = 0; q < N; q++) acc += sh.part[i / NB][q][i % NB];
+        sh.pi[buf][i] = acc;
       }
+      __syncthreads();
+      if(valid && stt == 0)
+      {
+        double d = 0.0;
+#pragma unroll
+        for(int c = 0; c < NB; c++) d = fma(bt[c], sh.pi[buf][NB * s_i + c], d);
+        lam += (r1 - d) * iwf;
+      }
+      buf ^= 1;
+    };
+
+    refine();
+    refine();
+
+    for(int round = 0; round < 3; round++)
+    {
+      // ---------------- dual active-set iteration (oracle/qp_gi.c; the equality rows are always active).
+      // One loop body = one column pi = Qt[:, s] bt of a "target" variable followed by at most one rank-1 update:
+      //   target = entering variable p: directions, step length; a full step clamps p (update with this pi),
+      //            a partial step only moves and makes the blocking variable kk the next target;
+      //   target = blocking variable kk: it becomes free (update), then p is the target again.
+      bool moved = false;
+      int p = 0, target = -1;
+      bool dropping = false; // uniform: the target is a blocking variable that leaves its bound
+      double sg = 0.0, bound = 0.0;
+      for(;;)
+      {
+        if(!dropping && target < 0)
+        {
+          const double sl = (P.flo - lam) - tl, sh_ = (lam - P.fhi) - th;
+          const double score = (valid && stt == 0) ? fmax(sl, sh_) : -kXyInf;
+          double m;
+          xy_block_argmin(score > 0.0 ? -score : kXyInf, &sh.red[rbuf], m, p);
+          rbuf ^= 1;
+          if(p >= kXyNT) break;
+          moved = true;
+          sg = (sl >= sh_) ? 1.0 : -1.0;
+          bound = (sl >= sh_) ? P.flo : P.fhi;
+          if(i == p) sh.sg = sg;
+          target = p;
+        }
+        const int stg = target >> 4;
+        const double * btg = sh.bt[target];
+        xy_col(Q, owner, rb, cb, stg, btg, sh.pi[buf]);
+        __syncthreads();
+        double coef_sign = 1.0; // +1: target becomes free
+        bool update = true;
+        if(!dropping)
+        {
+          const bool isp = (i == p);
+          const double sgp = sh.sg;
+          double D = 0.0;
+          if(s_i < N)
+          {
+#pragma unroll
+            for(int c = 0; c < NB; c++) D = fma(bt[c], sh.pi[buf][NB * s_i + c], D);
+          }
+          // primal direction of the free variables, multiplier rates of the clamped ones
+          const double zdir = isp ? sgp * (1.0 - D) * iwf : -sgp * D * iwf;
+          const double dmu = (stt < 0) ? sgp * D : -sgp * D;
+          double ratio = kXyInf;
+          if(isp)
+          {
+            const double curv = 1.0 - D;
+            ratio = (curv > 1e-15) ? fabs(bound - lam) * wf / curv : kXyInf;
+          }
+          else if(valid && stt != 0 && dmu < 0.0)
+            ratio = mu / -dmu;
+          double t;
+          int kk;
+          xy_block_argmin(ratio, &sh.red[rbuf], t, kk);
+          rbuf ^= 1;
+          if(kk >= kXyNT || ++passes > maxpass)
+          {
+            st = CCC_STATUS_MAX_ITER;
+            break;
+          }
+          const bool isadd = (kk == p);
+          if(valid && stt == 0)
+            lam = fma(t, zdir, lam);
+          else if(valid)
+            mu = fmax(fma(t, dmu, mu), 0.0);
+          if(isp) mu += t;
+          if(isadd)
+          {
+            if(isp)
+            {
+              stt = sg > 0.0 ? -1 : 1;
+              lam = bound;
+            }
+            coef_sign = -1.0; // p is clamped: Qt += pi pi'/(1 - bt' pi_s)
+            target = -1;      // select again
+          }
+          else
+          {
+            // the blocking variable kk leaves its bound (stays there, multiplier 0)
+            if(i == kk)
+            {
+              stt = 0;
+              mu = 0.0;
+            }
+            update = false;
+            dropping = true;
+            target = kk;
+          }
+        }
+        else
+        {
+          dropping = false;
+          target = p;
+        }
+        xy_rank1(Q, update, rb, cb, stg, btg, sh.pi[buf], coef_sign);
+        buf ^= 1;
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      if(round > 0 && !moved) break;
+      // ---------------- iterative refinement with exact residuals (removes the drift of the rank-1 updates);
+      //                  if it pushes a free variable across a bound, iterate again
+      refine();
+      refine();
     }
+
+    // ---------------- outputs (:181 head(m0)); slots beyond dim are zero
+    if(s_i < N)
+    {
+      const double out = valid ? lam : 0.0;
+      if(s_i == 0) B.u0[b * M + r_i] = out;
+      if(B.lambda_all) B.lambda_all[((size_t)b * N + s_i) * M + r_i] = out;
+    }
+    if(N * M < M && i < M) B.u0[b * M + i] = 0.0;
     if(i == 0 && B.status) B.status[b] = (passes << 8) | st;
-    __syncthreads();
   }
 }
 } // namespace ccc_amd
@@ -503,7 +571,6 @@ struct ccc_xy
   int device = 0;
   ccc_xy_params_t prm{};
   int num_cu = 0, blocks = 0;
-  double *ws_T = nullptr, *ws_B = nullptr;
   int64_t hcap = 0;
   void * d_stage = nullptr;
   hipStream_t stream = nullptr;
@@ -531,15 +598,7 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
     return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
   h->num_cu = prop.multiProcessorCount;
-  h->blocks = h->num_cu * 2;
-  e = hipMalloc(&h->ws_T, (size_t)h->blocks * kXyNP * kXyNP * sizeof(double));
-  if(e == hipSuccess)
-    e = hipMalloc(&h->ws_B, (size_t)h->blocks * (kXyMaxN * kXyS) * (kXyMaxN * kXyM) * sizeof(double));
-  if(e != hipSuccess)
-  {
-    ccc_xy_destroy(h);
-    return fail(CCC_ERR_HIP, "hipMalloc(workspace): %s", hipGetErrorString(e));
-  }
+  h->blocks = h->num_cu * 2; // two resident workgroups per CU (registers: 5 + 5 wavefronts of <= 168 VGPRs)
   *out = h;
   return CCC_OK;
 }
@@ -548,8 +607,6 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
 {
   if(!h) return;
   (void)hipSetDevice(h->device);
-  if(h->ws_T) (void)hipFree(h->ws_T);
-  if(h->ws_B) (void)hipFree(h->ws_B);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -580,7 +637,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   P.w_force = h->prm.w_force;
   P.flo = 3.0; // src/LinearMpcXY.cpp:91
   P.fhi = 3.0 * h->prm.mass * kXyG;
-  XyBatch B{dim, vertex, ridge, com_z, total_force_z, ref_out, x0, u0, lambda_all, status, h->ws_T, h->ws_B};
+  XyBatch B{dim, vertex, ridge, com_z, total_force_z, ref_out, x0, u0, lambda_all, status};
   const int grid = (int)std::min<int64_t>(n, h->blocks);
   hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
   CCC_HIP_CHECK(hipGetLastError());
