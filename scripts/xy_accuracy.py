@@ -1,6 +1,9 @@
-import sys, numpy as np
-sys.path.insert(0, "/root/repo/scratch"); sys.path.insert(0, "/root/repo")
-import xy_proto as P
+"""Offline: compare a kernel dump (scripts/xy_dump.py, run on the GPU box) with the oracle and with a long-double KKT
+solve on the same active set.  usage: xy_accuracy.py N seed"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import xy_stage_space_proto as P
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
 from oracle import oracle as orc
 N = int(sys.argv[1]); n = 96; seed = int(sys.argv[2])

@@ -1,6 +1,8 @@
-"""numpy prototype of the structured (stage-space) dual active-set for LinearMpcXY."""
-import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+"""numpy prototype of the stage-space dual active-set of csrc/xy.hip (same algorithm, dense 7N x 7N operator), plus a
+long-double KKT solve on a given active set (truth_ld) used to measure the accuracy of kernel and oracle offline."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
 from oracle import oracle as orc
 
