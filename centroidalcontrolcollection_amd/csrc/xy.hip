@@ -31,11 +31,17 @@
 #include <cstring>
 #include <vector>
 
+// profiling switches (scripts/xy_variants.sh): number of active-set/refinement rounds, skip the set-up updates
+#ifndef XY_ROUNDS
+#define XY_ROUNDS 3
+#endif
+
 namespace ccc_amd
 {
 constexpr int kXyM = 16;
 constexpr int kXyMaxN = CCC_XY_MAX_STEPS;
-constexpr int kXyNT = kXyMaxN * kXyM; // 320 threads per workgroup (5 wavefronts), one per variable slot
+constexpr int kXyNV = kXyMaxN * kXyM;   // 320 variable slots: thread i < 320 = (step i/16, ridge i%16)
+constexpr int kXyNT = 448;              // threads per workgroup (7 wavefronts): 2 x 210 half-blocks of Qt
 constexpr int kXyWaves = kXyNT / 64;
 constexpr int kXyNB = 7;                // stage block: 6 states + the step's equality row
 constexpr int kXyQ = kXyMaxN * kXyNB;   // 140
@@ -67,9 +73,10 @@ struct XyRed
 
 struct XyShared
 {
-  double bt[kXyNT][kXyNB];               // bt_i = (Bd_s[:, r], rho_z) of every variable
+  double bt[kXyNV][kXyNB];               // bt_i = (Bd_s[:, r], rho_z) of every variable
   double pi[2][kXyQ];                    // Qt[:, s] bt (double buffered: one barrier per rank-1 update)
   double part[kXyMaxN][kXyMaxN][kXyNB];  // partial products of the full Qt * gamma (refinement only)
+  double V[kXyMaxN][6][6];               // Gramians V_s (set-up only)
   double gam[kXyQ];
   double c2[kXyMaxN], c3[kXyMaxN];       // sparse Ad_j: kappa dt, kappa dt^2/2 with kappa = f_z/m
   double fz[kXyMaxN];
@@ -141,73 +148,81 @@ __device__ __forceinline__ void xy_block_argmin(double v, XyRed * red, double & 
   imin = bi;
 }
 
-struct XyBlock
+// Half of one 7x7 block of the lower block triangle of Qt: rows a0 .. a0+3 (a0 = 0: rows 0-3, a0 = 4: rows 4-6 plus
+// an unused one).  Lanes 2k and 2k+1 hold the two halves of block k.
+struct XyHalf
 {
-  double q[kXyNB][kXyNB]; // Qt[7 rb + a][7 cb + c]
+  double q[4][kXyNB];
 };
 
-// pi = Qt[:, 7 s .. 7 s + 6] bv  (owners of the blocks in block-column s and block-row s write their 7 entries)
-__device__ __forceinline__ void xy_col(const XyBlock & Q, bool owner, int rb, int cb, int s, const double * bv,
+// pi = Qt[:, 7 s .. 7 s + 6] bv: the halves of the blocks in block-column s produce their rows, the two halves of a
+// block in block-row s (left of the diagonal) add their partial column sums across the lane pair.
+__device__ __forceinline__ void xy_col(const XyHalf & Q, bool owner, int rb, int cb, int a0, int s, const double * bv,
                                        double * pi)
 {
-  if(!owner) return;
-  if(cb == s)
+  const bool colcase = owner && cb == s, rowcase = owner && rb == s && cb != s;
+  if(colcase)
   {
     double b[kXyNB];
 #pragma unroll
     for(int c = 0; c < kXyNB; c++) b[c] = bv[c];
 #pragma unroll
-    for(int a = 0; a < kXyNB; a++)
+    for(int r = 0; r < 4; r++)
     {
       double acc = 0.0;
 #pragma unroll
-      for(int c = 0; c < kXyNB; c++) acc = fma(Q.q[a][c], b[c], acc);
-      pi[kXyNB * rb + a] = acc;
+      for(int c = 0; c < kXyNB; c++) acc = fma(Q.q[r][c], b[c], acc);
+      if(a0 + r < kXyNB) pi[kXyNB * rb + a0 + r] = acc;
     }
   }
-  else if(rb == s)
+  // (accumulated row by row: a different instruction stream from the branch above, so that the optimiser does not
+  //  merge the two into one body that indexes Q dynamically and pushes it out of registers)
+  double acc[kXyNB];
   {
-    double b[kXyNB];
+    double b[4];
 #pragma unroll
-    for(int a = 0; a < kXyNB; a++) b[a] = bv[a];
-    // (accumulated row by row: a different instruction stream from the branch above keeps the optimiser from
-    //  merging the two into one body that indexes Q dynamically, which would push the block out of registers)
-    double acc[kXyNB];
+    for(int r = 0; r < 4; r++) b[r] = (rowcase && a0 + r < kXyNB) ? bv[a0 + r] : 0.0;
 #pragma unroll
     for(int c = 0; c < kXyNB; c++) acc[c] = Q.q[0][c] * b[0];
 #pragma unroll
-    for(int a = 1; a < kXyNB; a++)
+    for(int r = 1; r < 4; r++)
 #pragma unroll
-      for(int c = 0; c < kXyNB; c++) acc[c] = fma(Q.q[a][c], b[a], acc[c]);
+      for(int c = 0; c < kXyNB; c++) acc[c] = fma(Q.q[r][c], b[r], acc[c]);
+  }
+  if(__any(rowcase))
+  {
 #pragma unroll
-    for(int c = 0; c < kXyNB; c++) pi[kXyNB * cb + c] = acc[c];
+    for(int c = 0; c < kXyNB; c++) acc[c] += dpp_f64<kDppQuadXor1>(acc[c]);
+    if(rowcase && a0 == 0)
+    {
+#pragma unroll
+      for(int c = 0; c < kXyNB; c++) pi[kXyNB * cb + c] = acc[c];
+    }
   }
 }
 
 // Qt -= sign * pi pi' / (1 + sign * bv' pi_s)   (sign = +1: the variable becomes free, -1: it is clamped).
-// Every thread runs the update on its block (threads without one keep a dummy; enable = false scales it to nothing):
-// unconditional arithmetic keeps the 49 block entries in place in their registers.
-__device__ __forceinline__ void xy_rank1(XyBlock & Q, bool enable, int rb, int cb, int s, const double * bv,
+// Every thread runs the update on its half block (threads without one keep a dummy; enable = false scales it to
+// nothing): unconditional arithmetic keeps the entries in place in their registers.
+__device__ __forceinline__ void xy_rank1(XyHalf & Q, bool enable, int rb, int cb, int a0, int s, const double * bv,
                                          const double * pi, double sign)
 {
   double den = 1.0;
 #pragma unroll
   for(int c = 0; c < kXyNB; c++) den = fma(sign * bv[c], pi[kXyNB * s + c], den);
   const double coef = enable ? -sign / den : 0.0;
-  double pr[kXyNB], pc[kXyNB];
+  double pr[4], pc[kXyNB];
 #pragma unroll
-  for(int a = 0; a < kXyNB; a++)
-  {
-    pr[a] = coef * pi[kXyNB * rb + a];
-    pc[a] = pi[kXyNB * cb + a];
-  }
+  for(int r = 0; r < 4; r++) pr[r] = coef * pi[kXyNB * rb + (a0 + r < kXyNB ? a0 + r : 0)];
 #pragma unroll
-  for(int a = 0; a < kXyNB; a++)
+  for(int c = 0; c < kXyNB; c++) pc[c] = pi[kXyNB * cb + c];
 #pragma unroll
-    for(int c = 0; c < kXyNB; c++) Q.q[a][c] = fma(pr[a], pc[c], Q.q[a][c]);
+  for(int r = 0; r < 4; r++)
+#pragma unroll
+    for(int c = 0; c < kXyNB; c++) Q.q[r][c] = fma(pr[r], pc[c], Q.q[r][c]);
 }
 
-__global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B, long n)
+__global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B, long n)
 {
   constexpr int M = kXyM, NB = kXyNB;
   __shared__ XyShared sh;
@@ -215,10 +230,14 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
   const int i = threadIdx.x;
   const int N = P.N;
   const int s_i = i >> 4, r_i = i & 15;
-  // block ownership: thread t < N (N + 1)/2 holds block (rb, cb), cb <= rb
+  // half-block ownership: threads 2k, 2k+1 hold block k = (rb, cb), cb <= rb, of the lower block triangle
   int rb = 0;
-  while((rb + 1) * (rb + 2) / 2 <= i) rb++;
-  int cb = i - rb * (rb + 1) / 2;
+  {
+    const int k = i >> 1;
+    while((rb + 1) * (rb + 2) / 2 <= k) rb++;
+  }
+  int cb = (i >> 1) - rb * (rb + 1) / 2;
+  const int a0 = (i & 1) * 4;
   const bool owner = rb < N;
   if(!owner) rb = cb = 0; // dummy block: same arithmetic, never stored
   const double c1 = P.dt;
@@ -241,85 +260,104 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
     for(int e = i; e < N * 6; e += kXyNT) sh.ref[e / 6][e % 6] = B.ref_out[(size_t)b * N * 6 + e];
     if(i < 6) sh.x0[i] = B.x0[b * 6 + i];
     const bool valid = s_i < N && r_i < B.dim[b * N + (s_i < N ? s_i : 0)];
-    double bt[NB];
-#pragma unroll
-    for(int c = 0; c < NB; c++) bt[c] = 0.0;
-    if(valid)
+    if(i < kXyNV)
     {
-      const double * v = B.vertex + ((size_t)(b * N + s_i) * M + r_i) * 3;
-      const double * rd = B.ridge + ((size_t)(b * N + s_i) * M + r_i) * 3;
-      const double cz = B.com_z[b * N + s_i];
-      const double fz = B.total_force_z[b * N + s_i] / P.mass;
-      const double bc[6] = {0.0, rd[0], 0.0, rd[1], -1 * (v[2] - cz) * rd[1] + v[1] * rd[2],
-                            (v[2] - cz) * rd[0] + -1 * v[0] * rd[2]};
-      const double ab[6] = {bc[1], 0.0, bc[3], 0.0, -fz * bc[2], fz * bc[0]};
-      const double aab[6] = {0.0, 0.0, 0.0, 0.0, -fz * bc[3], fz * bc[1]};
-      const double dt = P.dt;
+      double btv[NB];
 #pragma unroll
-      for(int a = 0; a < 6; a++) bt[a] = bc[a] * dt + ab[a] * dt * dt / 2 + aab[a] * dt * dt * dt / 6;
-      bt[6] = rd[2];
-    }
-#pragma unroll
-    for(int c = 0; c < NB; c++) sh.bt[i][c] = bt[c];
-    __syncthreads();
-
-    // ---------------- Qt for F = {}: block (s, s') = V_s Phi(s, s')/w, V_s = W + Ad_{s+1}' V_{s+1} Ad_{s+1};
-    //                  equality part regularised by 1 (removed below)
-    XyBlock Q;
-#pragma unroll
-    for(int a = 0; a < NB; a++)
-#pragma unroll
-      for(int c = 0; c < NB; c++) Q.q[a][c] = 0.0;
-    {
-#pragma unroll
-      for(int a = 0; a < 6; a++) Q.q[a][a] = P.w[a];
-      for(int j = N - 1; j > rb; j--)
+      for(int c = 0; c < NB; c++) btv[c] = 0.0;
+      if(valid)
       {
-        const double c2 = sh.c2[j], c3 = sh.c3[j];
+        const double * v = B.vertex + ((size_t)(b * N + s_i) * M + r_i) * 3;
+        const double * rd = B.ridge + ((size_t)(b * N + s_i) * M + r_i) * 3;
+        const double cz = B.com_z[b * N + s_i];
+        const double fz = B.total_force_z[b * N + s_i] / P.mass;
+        const double bc[6] = {0.0, rd[0], 0.0, rd[1], -1 * (v[2] - cz) * rd[1] + v[1] * rd[2],
+                              (v[2] - cz) * rd[0] + -1 * v[0] * rd[2]};
+        const double ab[6] = {bc[1], 0.0, bc[3], 0.0, -fz * bc[2], fz * bc[0]};
+        const double aab[6] = {0.0, 0.0, 0.0, 0.0, -fz * bc[3], fz * bc[1]};
+        const double dt = P.dt;
 #pragma unroll
-        for(int a = 0; a < 6; a++) xy_adT(Q.q[a][0], Q.q[a][1], Q.q[a][2], Q.q[a][3], Q.q[a][4], Q.q[a][5], c1, c2, c3);
-#pragma unroll
-        for(int c = 0; c < 6; c++) xy_adT(Q.q[0][c], Q.q[1][c], Q.q[2][c], Q.q[3][c], Q.q[4][c], Q.q[5][c], c1, c2, c3);
-#pragma unroll
-        for(int a = 0; a < 6; a++) Q.q[a][a] += P.w[a];
+        for(int a = 0; a < 6; a++) btv[a] = bc[a] * dt + ab[a] * dt * dt / 2 + aab[a] * dt * dt * dt / 6;
+        btv[6] = rd[2];
       }
-      for(int j = rb; j > cb; j--)
+#pragma unroll
+      for(int c = 0; c < NB; c++) sh.bt[i][c] = btv[c];
+    }
+    __syncthreads();
+    // ---------------- Gramians V_s = W + Ad_{s+1}' V_{s+1} Ad_{s+1} (thread s runs its own recursion)
+    if(i < N)
+    {
+      double v[6][6];
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+#pragma unroll
+        for(int c = 0; c < 6; c++) v[a][c] = (a == c) ? P.w[a] : 0.0;
+      for(int j = N - 1; j > i; j--)
       {
         const double c2 = sh.c2[j], c3 = sh.c3[j];
 #pragma unroll
-        for(int a = 0; a < 6; a++) xy_adT(Q.q[a][0], Q.q[a][1], Q.q[a][2], Q.q[a][3], Q.q[a][4], Q.q[a][5], c1, c2, c3);
+        for(int a = 0; a < 6; a++) xy_adT(v[a][0], v[a][1], v[a][2], v[a][3], v[a][4], v[a][5], c1, c2, c3);
+#pragma unroll
+        for(int c = 0; c < 6; c++) xy_adT(v[0][c], v[1][c], v[2][c], v[3][c], v[4][c], v[5][c], c1, c2, c3);
+#pragma unroll
+        for(int a = 0; a < 6; a++) v[a][a] += P.w[a];
       }
 #pragma unroll
       for(int a = 0; a < 6; a++)
 #pragma unroll
-        for(int c = 0; c < 6; c++) Q.q[a][c] *= iwf;
-      if(rb == cb) Q.q[6][6] = 1.0;
+        for(int c = 0; c < 6; c++) sh.V[i][a][c] = v[a][c];
     }
+    __syncthreads();
+    // ---------------- Qt for F = {}: block (s, s') = V_s Phi(s, s')/w (rows of V_s right-multiplied by Ad_s .. Ad_{s'+1});
+    //                  the equality part is regularised by 1 (removed below)
+    XyHalf Q;
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+    {
+      const int a = a0 + r;
+#pragma unroll
+      for(int c = 0; c < 6; c++) Q.q[r][c] = (a < 6) ? sh.V[rb][a < 6 ? a : 0][c] : 0.0;
+      Q.q[r][6] = 0.0;
+    }
+    for(int j = rb; j > cb; j--)
+    {
+      const double c2 = sh.c2[j], c3 = sh.c3[j];
+#pragma unroll
+      for(int r = 0; r < 4; r++) xy_adT(Q.q[r][0], Q.q[r][1], Q.q[r][2], Q.q[r][3], Q.q[r][4], Q.q[r][5], c1, c2, c3);
+    }
+#pragma unroll
+    for(int r = 0; r < 4; r++)
+#pragma unroll
+      for(int c = 0; c < 6; c++) Q.q[r][c] *= iwf;
+    if(rb == cb && a0 == 4) Q.q[2][6] = 1.0;
     // ---------------- add every variable (F = all), then remove the regularisation of the contact steps' equality rows
     int buf = 0;
+#ifndef XY_PROF_NO_ADDS
     for(int v = 0; v < N * M; v++)
     {
       const int sv = v >> 4;
       if((v & 15) >= sh.dims[sv]) continue;
-      xy_col(Q, owner, rb, cb, sv, sh.bt[v], sh.pi[buf]);
+      xy_col(Q, owner, rb, cb, a0, sv, sh.bt[v], sh.pi[buf]);
       __syncthreads();
-      xy_rank1(Q, true, rb, cb, sv, sh.bt[v], sh.pi[buf], 1.0);
+      xy_rank1(Q, true, rb, cb, a0, sv, sh.bt[v], sh.pi[buf], 1.0);
       buf ^= 1;
     }
     for(int sv = 0; sv < N; sv++)
     {
       if(sh.dims[sv] == 0) continue;
-      xy_col(Q, owner, rb, cb, sv, sh.e6, sh.pi[buf]);
+      xy_col(Q, owner, rb, cb, a0, sv, sh.e6, sh.pi[buf]);
       __syncthreads();
-      xy_rank1(Q, true, rb, cb, sv, sh.e6, sh.pi[buf], -1.0);
+      xy_rank1(Q, true, rb, cb, a0, sv, sh.e6, sh.pi[buf], -1.0);
       buf ^= 1;
     }
+#endif
 
     const double tl = 1e-12 * (1.0 + fabs(P.flo)), th = 1e-12 * (1.0 + fabs(P.fhi));
     double lam = 0.0, mu = 0.0;
     int stt = 0; // 0 free, -1 clamped at the lower bound, +1 at the upper bound
     int st = CCC_STATUS_SOLVED, passes = 0, rbuf = 0;
     const int maxpass = 20 * N * M + 100;
+    const int ib = i < kXyNV ? i : 0; // row of sh.bt read by this thread (threads >= 320 hold no variable)
 
     // lambda += (approximate inverse)(exact residuals): x_{j+1} = Ad_j x_j + Bd_j lambda_j, e_j = W (x_{j+1} - ref_j),
     // adjoint p_j = e_j + Ad_{j+1}' p_{j+1}, gradient_i = w lambda_i + b_i' p_s, r2_s = f_z,s - sum rho_z lambda
@@ -328,8 +366,8 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
       {
         double t6[6];
 #pragma unroll
-        for(int a = 0; a < 6; a++) t6[a] = xy_row16_sum(bt[a] * lam);
-        const double sz = xy_row16_sum(bt[6] * lam);
+        for(int a = 0; a < 6; a++) t6[a] = xy_row16_sum(sh.bt[ib][a] * lam);
+        const double sz = xy_row16_sum(sh.bt[ib][6] * lam);
         if(r_i == 0 && s_i < N)
         {
 #pragma unroll
@@ -372,18 +410,19 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
         if(s_i < N)
         {
 #pragma unroll
-          for(int a = 0; a < 6; a++) gr = fma(bt[a], sh.adj[s_i][a], gr);
+          for(int a = 0; a < 6; a++) gr = fma(sh.bt[ib][a], sh.adj[s_i][a], gr);
         }
         // the gradient of a free variable is rho_z eta_s (equality multiplier) plus the residual: take the multiplier
         // part out (least squares over the step's free ridges) -- left in, it would have to cancel inside
         // r1 - bt' pi to 1e-12 relative, which the updated Qt cannot deliver
         const bool fr = valid && stt == 0;
-        const double num = xy_row16_sum(fr ? bt[6] * gr : 0.0), dsq = xy_row16_sum(fr ? bt[6] * bt[6] : 0.0);
+        const double rz = sh.bt[ib][6];
+        const double num = xy_row16_sum(fr ? rz * gr : 0.0), dsq = xy_row16_sum(fr ? rz * rz : 0.0);
         const double eta = dsq > 0.0 ? num / dsq : 0.0;
-        r1 = fr ? -(gr - bt[6] * eta) : 0.0;
+        r1 = fr ? -(gr - rz * eta) : 0.0;
         double t7[NB];
 #pragma unroll
-        for(int c = 0; c < NB; c++) t7[c] = xy_row16_sum(bt[c] * r1);
+        for(int c = 0; c < NB; c++) t7[c] = xy_row16_sum(sh.bt[ib][c] * r1);
         if(r_i == 0 && s_i < N)
         {
           const bool has = sh.dims[s_i] > 0;
@@ -393,33 +432,30 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
         }
       }
       __syncthreads();
-      if(owner)
       {
-        double g1[NB], g2[NB];
+        // full product Qt gamma from the half blocks: rows of the block times gamma_cb, and (left of the diagonal)
+        // the transposed product, halves added across the lane pair
+        double acc2[NB];
 #pragma unroll
-        for(int c = 0; c < NB; c++)
-        {
-          g1[c] = sh.gam[NB * cb + c];
-          g2[c] = sh.gam[NB * rb + c];
-        }
+        for(int c = 0; c < NB; c++) acc2[c] = 0.0;
 #pragma unroll
-        for(int a = 0; a < NB; a++)
+        for(int r = 0; r < 4; r++)
         {
+          const int a = a0 + r;
           double acc = 0.0;
 #pragma unroll
-          for(int c = 0; c < NB; c++) acc = fma(Q.q[a][c], g1[c], acc);
-          sh.part[rb][cb][a] = acc;
+          for(int c = 0; c < NB; c++) acc = fma(Q.q[r][c], sh.gam[NB * cb + c], acc);
+          if(owner && a < NB) sh.part[rb][cb][a] = acc;
+          const double g2 = (a < NB) ? sh.gam[NB * rb + (a < NB ? a : 0)] : 0.0;
+#pragma unroll
+          for(int c = 0; c < NB; c++) acc2[c] = fma(Q.q[r][c], g2, acc2[c]);
         }
-        if(rb != cb)
+#pragma unroll
+        for(int c = 0; c < NB; c++) acc2[c] += dpp_f64<kDppQuadXor1>(acc2[c]);
+        if(owner && rb != cb && a0 == 0)
         {
 #pragma unroll
-          for(int c = 0; c < NB; c++)
-          {
-            double acc = 0.0;
-#pragma unroll
-            for(int a = 0; a < NB; a++) acc = fma(Q.q[a][c], g2[a], acc);
-            sh.part[cb][rb][c] = acc;
-          }
+          for(int c = 0; c < NB; c++) sh.part[cb][rb][c] = acc2[c];
         }
       }
       __syncthreads();
@@ -434,7 +470,7 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
       {
         double d = 0.0;
 #pragma unroll
-        for(int c = 0; c < NB; c++) d = fma(bt[c], sh.pi[buf][NB * s_i + c], d);
+        for(int c = 0; c < NB; c++) d = fma(sh.bt[ib][c], sh.pi[buf][NB * s_i + c], d);
         lam += (r1 - d) * iwf;
       }
       buf ^= 1;
@@ -443,7 +479,7 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
     refine();
     refine();
 
-    for(int round = 0; round < 3; round++)
+    for(int round = 0; round < XY_ROUNDS; round++)
     {
       // ---------------- dual active-set iteration (oracle/qp_gi.c; the equality rows are always active).
       // One loop body = one column pi = Qt[:, s] bt of a "target" variable followed by at most one rank-1 update:
@@ -472,7 +508,7 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
         }
         const int stg = target >> 4;
         const double * btg = sh.bt[target];
-        xy_col(Q, owner, rb, cb, stg, btg, sh.pi[buf]);
+        xy_col(Q, owner, rb, cb, a0, stg, btg, sh.pi[buf]);
         __syncthreads();
         double coef_sign = 1.0; // +1: target becomes free
         bool update = true;
@@ -484,7 +520,7 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
           if(s_i < N)
           {
 #pragma unroll
-            for(int c = 0; c < NB; c++) D = fma(bt[c], sh.pi[buf][NB * s_i + c], D);
+            for(int c = 0; c < NB; c++) D = fma(sh.bt[ib][c], sh.pi[buf][NB * s_i + c], D);
           }
           // primal direction of the free variables, multiplier rates of the clamped ones
           const double zdir = isp ? sgp * (1.0 - D) * iwf : -sgp * D * iwf;
@@ -540,7 +576,7 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
           dropping = false;
           target = p;
         }
-        xy_rank1(Q, update, rb, cb, stg, btg, sh.pi[buf], coef_sign);
+        xy_rank1(Q, update, rb, cb, a0, stg, btg, sh.pi[buf], coef_sign);
         buf ^= 1;
       }
       if(st != CCC_STATUS_SOLVED) break;
@@ -558,7 +594,6 @@ __global__ __launch_bounds__(kXyNT, 3) void xy_plan_kernel(XyParams P, XyBatch B
       if(s_i == 0) B.u0[b * M + r_i] = out;
       if(B.lambda_all) B.lambda_all[((size_t)b * N + s_i) * M + r_i] = out;
     }
-    if(N * M < M && i < M) B.u0[b * M + i] = 0.0;
     if(i == 0 && B.status) B.status[b] = (passes << 8) | st;
   }
 }
@@ -598,7 +633,7 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
     return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
   h->num_cu = prop.multiProcessorCount;
-  h->blocks = h->num_cu * 2; // two resident workgroups per CU (registers: 5 + 5 wavefronts of <= 168 VGPRs)
+  h->blocks = h->num_cu * 2; // two resident workgroups per CU (7 + 7 wavefronts of <= 128 VGPRs)
   *out = h;
   return CCC_OK;
 }
