@@ -177,20 +177,20 @@ __device__ __forceinline__ void xy_col(const XyHalf & Q, bool owner, int rb, int
   }
   // (accumulated row by row: a different instruction stream from the branch above, so that the optimiser does not
   //  merge the two into one body that indexes Q dynamically and pushes it out of registers)
-  double acc[kXyNB];
+  if(__any(rowcase)) // wave-uniform: at most two wavefronts hold the blocks of block-row s
   {
-    double b[4];
+    double acc[kXyNB];
+    {
+      double b[4];
 #pragma unroll
-    for(int r = 0; r < 4; r++) b[r] = (rowcase && a0 + r < kXyNB) ? bv[a0 + r] : 0.0;
+      for(int r = 0; r < 4; r++) b[r] = (rowcase && a0 + r < kXyNB) ? bv[a0 + r] : 0.0;
 #pragma unroll
-    for(int c = 0; c < kXyNB; c++) acc[c] = Q.q[0][c] * b[0];
+      for(int c = 0; c < kXyNB; c++) acc[c] = Q.q[0][c] * b[0];
 #pragma unroll
-    for(int r = 1; r < 4; r++)
+      for(int r = 1; r < 4; r++)
 #pragma unroll
-      for(int c = 0; c < kXyNB; c++) acc[c] = fma(Q.q[r][c], b[r], acc[c]);
-  }
-  if(__any(rowcase))
-  {
+        for(int c = 0; c < kXyNB; c++) acc[c] = fma(Q.q[r][c], b[r], acc[c]);
+    }
 #pragma unroll
     for(int c = 0; c < kXyNB; c++) acc[c] += dpp_f64<kDppQuadXor1>(acc[c]);
     if(rowcase && a0 == 0)
@@ -210,7 +210,7 @@ __device__ __forceinline__ void xy_rank1(XyHalf & Q, bool enable, int rb, int cb
   double den = 1.0;
 #pragma unroll
   for(int c = 0; c < kXyNB; c++) den = fma(sign * bv[c], pi[kXyNB * s + c], den);
-  const double coef = enable ? -sign / den : 0.0;
+  const double coef = enable ? -sign * fast_rcp(den) : 0.0;
   double pr[4], pc[kXyNB];
 #pragma unroll
   for(int r = 0; r < 4; r++) pr[r] = coef * pi[kXyNB * rb + (a0 + r < kXyNB ? a0 + r : 0)];
@@ -476,11 +476,12 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
       buf ^= 1;
     };
 
-    refine();
-    refine();
-
-    for(int round = 0; round < XY_ROUNDS; round++)
+    // start point = equality-constrained minimiser (two refinement steps from 0), then rounds of
+    // [active-set iteration, refinement]; a later round that changes nothing ends the solve
+    for(int round = 0;; round++)
     {
+      for(int rep = 0; rep < 2; rep++) refine();
+      if(round >= XY_ROUNDS || st != CCC_STATUS_SOLVED) break;
       // ---------------- dual active-set iteration (oracle/qp_gi.c; the equality rows are always active).
       // One loop body = one column pi = Qt[:, s] bt of a "target" variable followed by at most one rank-1 update:
       //   target = entering variable p: directions, step length; a full step clamps p (update with this pi),
@@ -529,10 +530,10 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
           if(isp)
           {
             const double curv = 1.0 - D;
-            ratio = (curv > 1e-15) ? fabs(bound - lam) * wf / curv : kXyInf;
+            ratio = (curv > 1e-15) ? fabs(bound - lam) * wf * fast_rcp(curv) : kXyInf;
           }
           else if(valid && stt != 0 && dmu < 0.0)
-            ratio = mu / -dmu;
+            ratio = mu * fast_rcp(-dmu);
           double t;
           int kk;
           xy_block_argmin(ratio, &sh.red[rbuf], t, kk);
@@ -581,10 +582,8 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
       }
       if(st != CCC_STATUS_SOLVED) break;
       if(round > 0 && !moved) break;
-      // ---------------- iterative refinement with exact residuals (removes the drift of the rank-1 updates);
-      //                  if it pushes a free variable across a bound, iterate again
-      refine();
-      refine();
+      // (next: iterative refinement with exact residuals, which removes the drift of the rank-1 updates; if it pushes
+      //  a free variable across a bound, the next round picks that up)
     }
 
     // ---------------- outputs (:181 head(m0)); slots beyond dim are zero
