@@ -128,3 +128,38 @@ def test_device_entry_and_determinism():
     assert np.all((st.cpu().numpy() & 0xff) == 0)
     host = mpc.planOnceBatch(prob, x0)
     assert np.array_equal(host["u0"], u1.cpu().numpy())
+
+
+def test_cpp_header_shim_matches_python_mirror():
+    """Host C++ against include/CCC/LinearMpcXY.h (examples/plan_once_linear_mpc_xy.cpp): same kernel, same sampled
+    inputs as the Python mirror -> identical force scales, for planOnce and planOnceBatch."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "plan_once_linear_mpc_xy")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    N, dt, mass = 15, 0.1, 100.0
+    mpc = LinearMpcXY(mass, dt, N)
+
+    def motion(t):
+        rmin, rmax, _ = fd.xy_reference_schedule(t)
+        return LinearMpcXY.MotionParam(1.0, mass * fd.G, [fd.contact_from_rect(rmin, rmax)])
+
+    def ref(t):
+        return LinearMpcXY.RefData(fd.xy_reference_schedule(t)[2])
+
+    ip = LinearMpcXY.InitialParam((1.01, -0.02), (0.05, 0.0))
+    for ln, t in zip(lines[:3], (0.0, 2.45, 4.3)):
+        assert ln.startswith("t=%.2f dim=16" % t)
+        cpp = np.array([float(v) for v in ln.split("u0=")[1].split()])
+        u = mpc.planOnce(motion, ref, ip, t)
+        assert np.array_equal(cpp, u)
+        bl = [b for b in lines[3:] if b.startswith("batch[%d]" % (0.0, 2.45, 4.3).index(t))][0]
+        assert float(bl.split("u0[0]=")[1]) == u[0]
