@@ -172,7 +172,7 @@ def main():
             "pivots_per_solve": pivots_per_solve,
             "unsolved": n_bad,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle meanwhile)
             cb, ref_zmp, n_chk = cpu_baseline(batch)
             out["cpu_baseline"] = cb
             out["parity_max_abs_err"] = float(np.abs(zmp.cpu().numpy()[:n_chk] - ref_zmp).max())
