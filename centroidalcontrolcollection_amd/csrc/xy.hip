@@ -586,6 +586,16 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
       //  a free variable across a bound, the next round picks that up)
     }
 
+    // ---------------- certificate: bounds and equality rows hold at the returned point (also catches NaN).  An
+    //                  infeasible instance (f_z that the bounded ridges cannot produce) drives M_F singular instead
+    //                  of tripping the iteration limit; it must not be reported as solved.
+    {
+      const double sz = xy_row16_sum(valid ? sh.bt[ib][6] * lam : 0.0);
+      bool bad = false;
+      if(valid) bad = !(fmax(P.flo - lam, lam - P.fhi) <= 1e-7 * (1.0 + fabs(P.fhi)));
+      if(s_i < N && r_i == 0 && sh.dims[s_i] > 0) bad = bad || !(fabs(sh.fz[s_i] - sz) <= 1e-7 * (1.0 + fabs(sh.fz[s_i])));
+      if(__syncthreads_or(bad ? 1 : 0) && st == CCC_STATUS_SOLVED) st = CCC_STATUS_INFEASIBLE;
+    }
     // ---------------- outputs (:181 head(m0)); slots beyond dim are zero
     if(s_i < N)
     {

@@ -1,16 +1,28 @@
-"""Time the DdpCentroidal kernel on BASELINE config 3 (batch 4096, horizon 100, 20 iterations)."""
+"""Time the DDP kernel: BASELINE config 3 (DdpCentroidal, batch 4096, horizon 100, 20 iterations) by default, or the
+shape of config 5 with `srb` (DdpSingleRigidBody, horizon 50, batch 32768; fp64 -- the fp32 variant is not built).
+usage: ddp_bench.py [n] [reps] [cen|srb]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from centroidalcontrolcollection_amd import DdpCentroidal, fixtures_ddp as fd
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
+model = sys.argv[3] if len(sys.argv) > 3 else "cen"
+srb = model == "srb"
+n = int(sys.argv[1]) if len(sys.argv) > 1 else (32768 if srb else 4096)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-N, dt = 100, 0.03
-prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=1)
-d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)))
+N, dt = (50, 0.03) if srb else (100, 0.03)
+base = min(n, 4096)
+prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=1, srb=srb)
+k = (n + base - 1) // base
+prob = {a: np.concatenate([v] * k)[:n] for a, v in prob.items()}
+x0 = np.concatenate([x0] * k)[:n]
+if srb:
+    d = DdpSingleRigidBody(100.0, dt, N, DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3,
+                                                                         terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3))
+else:
+    d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)))
 d.ddp_solver_.config().max_iter = 20
 dev = torch.device("cuda:0")
-tp = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in prob.items()}
+tp = {a: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for a, v in prob.items()}
 tx0 = torch.from_numpy(x0).to(dev)
 u = torch.zeros((n, N, 16), dtype=torch.float64, device=dev)
 it = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -20,4 +32,4 @@ ts = []
 for _ in range(reps):
     t0 = time.perf_counter(); d.plan_batch_device(tp, tx0, u, iters=it); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = min(ts)
-print("DdpCentroidal n=%d N=%d max_iter=20: %.1f ms -> %.0f solves/s (mean iters %.2f)" % (n, N, t * 1e3, n / t, it.float().mean().item()))
+print("%s n=%d N=%d max_iter=20: %.1f ms -> %.0f solves/s (mean iters %.2f)" % (type(d).__name__, n, N, t * 1e3, n / t, it.float().mean().item()))

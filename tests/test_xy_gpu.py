@@ -79,6 +79,65 @@ def test_steps_without_contact_are_skipped():
     assert np.all(r["lam"][0, 3:5] == 0.0)
 
 
+def _random_geometry_batch(n, N, dt, mass, seed):
+    """Steps with 0 / 4 / 8 / 12 / 16 ridges (vertices dropped from the rect contact, i.e. point / line / partial
+    contacts and the two-contact case of two 2-vertex feet), random vertical force and CoM height per step."""
+    rng = np.random.default_rng(seed)
+    prob, x0 = fd.make_xy_batch(n, N, dt, mass, seed=seed)
+    for k in range(n):
+        for i in range(N):
+            nv = rng.choice([0, 1, 2, 3, 4, 4, 4])
+            prob["dim"][k, i] = 4 * nv
+            prob["vertex"][k, i, 4 * nv:] = 0.0
+            prob["ridge"][k, i, 4 * nv:] = 0.0
+        if prob["dim"][k, 0] == 0:  # keep an output to compare
+            prob["dim"][k, 0] = 16
+            V, R = fd.contact_from_rect((0.9, -0.15), (1.1, 0.15))
+            prob["vertex"][k, 0], prob["ridge"][k, 0] = V, R
+    prob["total_force_z"] *= rng.uniform(0.8, 1.2, size=prob["total_force_z"].shape)
+    prob["com_z"] *= rng.uniform(0.9, 1.1, size=prob["com_z"].shape)
+    return prob, x0
+
+
+def test_random_contact_dimensions_and_weights():
+    """Ragged inputs: per-step ridge counts in {0,4,8,12,16}, varying f_z and c_z, non-default weights (momentum
+    weights switched on: all 6N output rows carry weight)."""
+    N, dt, mass, n = 14, 0.08, 80.0, 64
+    prob, x0 = _random_geometry_batch(n, N, dt, mass, seed=11)
+    w = dict(w_lmi=(2.0, 0.5), w_lm=(0.1, 0.3), w_am=(0.7, 1.5), w_force=3e-5)
+    o = _oracle().LinearMpcXY(mass, dt, N, **w).plan_batch(prob, x0, nthreads=8, want_all=True)
+    wp = LinearMpcXY.WeightParam(w["w_lmi"], w["w_lm"], w["w_am"], w["w_force"])
+    r = LinearMpcXY(mass, dt, N, wp).planOnceBatch(prob, x0, want_all=True)
+    ok = o["status"] == 0
+    assert ok.sum() >= n // 2 and np.all(r["status"][ok] == 0)
+    # instances the oracle finds infeasible (f_z outside what the remaining ridges can carry) must not report success
+    assert np.all(r["status"][~ok] != 0)
+    sel = np.where(ok)[0]
+    sub = {k2: v[sel] for k2, v in prob.items()}
+    _compare(sub, {k2: (v[sel] if v is not None else None) for k2, v in r.items()},
+             {k2: (v[sel] if v is not None else None) for k2, v in o.items()}, N)
+    assert np.all(r["pivots"][sel] == o["iters"][sel])
+    for k in sel:
+        lam_o = o["lam"][k, :prob["dim"][k].sum()]
+        lam_g = np.concatenate([r["lam"][k, i, :prob["dim"][k, i]] for i in range(N)])
+        assert np.abs(lam_g - lam_o).max() <= LAM_RTOL * (1.0 + np.abs(lam_o).max())
+        assert np.all(r["lam"][k][prob["dim"][k][:, None] <= np.arange(16)[None, :]] == 0.0)
+
+
+def test_infeasible_instance_is_flagged():
+    """f_z below what the 3 N lower bounds already produce: no feasible point; status must be non-zero (never a
+    silently wrong plan), and the neighbouring instances of the batch are unaffected."""
+    N, dt, mass = 10, 0.1, 100.0
+    prob, x0 = fd.make_xy_batch(3, N, dt, mass, seed=2)
+    prob["total_force_z"][1, 4] = 1.0
+    o = _oracle().LinearMpcXY(mass, dt, N).plan_batch(prob, x0)
+    r = LinearMpcXY(mass, dt, N).planOnceBatch(prob, x0)
+    assert o["status"][1] != 0 and r["status"][1] != 0
+    assert r["status"][0] == 0 and r["status"][2] == 0
+    scale = np.abs(o["u0"][[0, 2]]).max() + 1.0
+    assert np.abs(r["u0"][[0, 2]] - o["u0"][[0, 2]]).max() <= LAM_RTOL * scale
+
+
 def test_reference_closed_loop_through_planonce():
     """TestLinearMpcXY.cpp:15-160 through planOnce(motion_param_func, ref_data_func, initial_param, t): per-cycle and
     final property assertions (:126-128, :140-142)."""
