@@ -44,6 +44,11 @@ ABI_SYMBOLS = [
     "ccc_xy_destroy",
     "ccc_xy_plan_batch_device",
     "ccc_xy_plan_batch",
+    "ccc_ism_create",
+    "ccc_ism_destroy",
+    "ccc_ism_horizon_steps",
+    "ccc_ism_plan_batch_device",
+    "ccc_ism_plan_batch",
 ]
 
 

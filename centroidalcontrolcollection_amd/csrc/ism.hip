@@ -1,0 +1,491 @@
+// ism.hip -- batched CCC::IntrinsicallyStableMpc::planOnce() on MI355X (gfx950): kernel + C-ABI.
+// (the first widening of the hot path; same dual active-set machinery as LinearMpcZmp.)
+//
+// Path replaced (reference file:line under /root/reference):
+//   src/IntrinsicallyStableMpc.cpp:8-45     IntrinsicallyStableMpc1d constructor: P (dt on and below the diagonal),
+//                                           H = w_vel I + w_zmp P'P, the stability equality row a (eq. 14), ZMP rows +-P
+//   src/IntrinsicallyStableMpc.cpp:63-104   procOnce: right-hand sides, the external QP solve (:93), ZMP update + clamp
+//   src/IntrinsicallyStableMpc.cpp:106-139  planOnce: x axis, then y axis
+//
+// Per axis:  min 1/2 u'Hu + g'u,  g = w_zmp P'(z0 1 - zref),  s.t.  a'u = cp - z0,  zmin - z0 <= P u <= zmax - z0.
+// With Ct = [P; a] ((N+1) x N) the constraint values are Ct u = Ct u* + G mu, G = Ct H^-1 Ct' batch-constant and
+// u* = -H^-1 g the unconstrained minimiser; because g = -w_zmp P'r (r = zref - z0 1) the offsets are
+// d = Ct u* = w_zmp G[:, :N] r -- G itself, no further matrix.  So this is LinearMpcZmp's range problem
+// lo <= G mu <= hi (csrc/zmp.hip) with N+1 rows, the last one of zero width (an equality: it enters first and is never
+// dropped), solved by the same sweep-tableau iteration: one QP per 128-thread workgroup, thread i = row i, tableau in
+// LDS.  u0 = H^-1[0, :] Ct' (mu + w_zmp [r; 0]) needs one more constant row (hc).
+#include "common.h"
+#include "wave_group.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace ccc_amd
+{
+constexpr int kIsmNP = 128; // rows per QP = threads per workgroup (N + 1 <= 128)
+constexpr double kIsmInf = __builtin_huge_val();
+
+struct IsmDev
+{
+  int N;             // horizon steps
+  const double * G;  // [NP][NP]  Ct H^-1 Ct', identity on the padding
+  const double * Wc; // [N][NP]   H^-1 Ct'  (row 0 = hc)
+  double w_zmp;
+  double dt;
+};
+
+struct IsmRed
+{
+  double val[2];
+  int idx[2];
+};
+
+// (min value over the 128-thread block, lowest thread index attaining it; index kIsmNP if no finite candidate)
+__device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double & vmin, int & imin)
+{
+  const int tid = threadIdx.x, w = tid >> 6;
+  const double wm = WaveGroup<64>::min(v);
+  const int wi = WaveGroup<64>::first(v == wm && v < kIsmInf);
+  __syncthreads(); // red may still be read by the previous reduction
+  if((tid & 63) == 0)
+  {
+    red->val[w] = wm;
+    red->idx[w] = wi < 64 ? wi + 64 * w : kIsmNP;
+  }
+  __syncthreads();
+  const double a = red->val[0], b = red->val[1];
+  const int ia = red->idx[0], ib = red->idx[1];
+  const bool first = (ia < kIsmNP) && (a <= b || ib >= kIsmNP);
+  vmin = first ? a : b;
+  imin = first ? ia : ib;
+}
+
+// init [nqp][2] (capture_point, planned_zmp), ref [nqp][3][N] (ref zmp, zmin, zmax), zmp [nqp], vel [nqp][N] | null,
+// status [nqp] | null.  A "qp" is one axis of one instance.
+__global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, const double * __restrict__ init,
+                                                          const double * __restrict__ ref, double control_dt,
+                                                          double * __restrict__ zmp, double * __restrict__ vel,
+                                                          int * __restrict__ status)
+{
+  constexpr int NP = kIsmNP;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double * T = smem;            // [NP][NP]
+  double * cb = smem + NP * NP; // [NP] staging of the pivot row / of mu / of rho
+  IsmRed * red = reinterpret_cast<IsmRed *>(cb + NP);
+  const int i = threadIdx.x;
+  const int N = P.N;
+  const int maxpass = 20 * (N + 1) + 100;
+
+  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  {
+    const bool rng = i < N, iseq = i == N, row = i <= N;
+    const double cp = init[qp * 2 + 0], z0 = init[qp * 2 + 1];
+    double zr = 0, zl = 0, zh = 0;
+    if(rng)
+    {
+      zr = ref[qp * 3 * N + i];
+      zl = ref[qp * 3 * N + N + i];
+      zh = ref[qp * 3 * N + 2 * N + i];
+    }
+    const double r = rng ? zr - z0 : 0.0;
+    __syncthreads();
+    cb[i] = r;
+    __syncthreads();
+    // tableau <- G, offsets d = w_zmp G[:, :N] r in the same pass (G symmetric: column i read as row i)
+    double d = 0.0;
+    for(int j = 0; j < NP; ++j)
+    {
+      const double g = P.G[j * NP + i];
+      T[j * NP + i] = g;
+      d = fma(g, cb[j], d); // cb[j] = 0 for j >= N
+    }
+    d *= P.w_zmp;
+    const double lo = rng ? (zl - z0) - d : (iseq ? (cp - z0) - d : -kIsmInf);
+    const double hi = rng ? (zh - z0) - d : (iseq ? (cp - z0) - d : kIsmInf);
+    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
+    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
+    int st = CCC_STATUS_SOLVED;
+    if(__syncthreads_or(rng && lo > hi)) st = CCC_STATUS_INFEASIBLE;
+
+    double z = 0.0, mu = 0.0, dact = 0.0;
+    bool inW = false;
+    int p = 0;
+    double psig = 0.0, pd = 0.0;
+    bool done = st != CCC_STATUS_SOLVED; // block uniform
+    bool need_select = true;
+    int passes = 0;
+
+    for(int round = 0; round < 3 && !done; ++round)
+    {
+      while(!done)
+      {
+        if(need_select)
+        {
+          const double sl = (lo - z) - tl, sh = (z - hi) - th;
+          double score = (inW || !row) ? -kIsmInf : fmax(sl, sh);
+          if(iseq && !inW) score = 1e300; // the equality row enters first (oracle/qp_gi.c) and stays
+          double m;
+          int cand;
+          ism_block_argmin(score > 0.0 ? -score : kIsmInf, red, m, cand);
+          if(cand >= NP) break;
+          p = cand;
+          if(i == cand)
+          {
+            psig = (sl >= sh) ? 1.0 : -1.0;
+            pd = (sl >= sh) ? lo : hi;
+            cb[0] = psig;
+          }
+          __syncthreads();
+        }
+        else
+        {
+          if(i == p) cb[0] = psig;
+          __syncthreads();
+        }
+        const double sig = cb[0];
+        const double c = T[p * NP + i]; // column p = row p (symmetric)
+        const double dm = -sig * c;
+        const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const bool isp = (i == p);
+        const double num = isp ? psig * (pd - z) : -mu;
+        const double den = isp ? c : dm;
+        double ratio = (isp || blocking) ? num / den : kIsmInf;
+        if(isp && !(c > 0.0)) ratio = kIsmInf; // no curvature left along row p: it cannot be satisfied
+        double t;
+        int kk;
+        ism_block_argmin(ratio, red, t, kk);
+        if(kk >= NP)
+        {
+          st = CCC_STATUS_INFEASIBLE;
+          done = true;
+          break;
+        }
+        const bool isadd = (kk == p);
+        const double s = isadd ? 1.0 : -1.0;
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, c, z);
+        if(isp) mu += sig * t;
+        // pivot on row/column kk
+        const double v = T[kk * NP + i];
+        cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+        if(i == kk)
+        {
+          for(int j = 0; j < NP; ++j) T[j * NP + i] = s * cb[j] * rp;
+        }
+        else
+        {
+          for(int j = 0; j < NP; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+        }
+        __syncthreads();
+        T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        __syncthreads();
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(++passes > maxpass)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+        }
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      // closing refinement against the untouched G (see csrc/zmp.hip): rho = d_W - (G mu)_W, mu_W -= T_WW rho,
+      // z = G mu recomputed; re-open if a row turns out violated
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      double acc = 0.0;
+      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      const double rho = inW ? dact - acc : 0.0;
+      __syncthreads();
+      cb[i] = rho;
+      __syncthreads();
+      double tr = 0.0;
+      for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
+      if(inW) mu -= tr;
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      acc = 0.0;
+      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      z = inW ? dact : acc;
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
+      need_select = true;
+      if(!reopen) break;
+    }
+
+    // certificate: every row of lo <= G mu <= hi holds at the returned multipliers (also catches NaN).  When the
+    // capture point cannot be caught inside the ZMP limits the tableau runs out of curvature instead of hitting the
+    // pass limit; such an instance must not be reported as solved.
+    if(st == CCC_STATUS_SOLVED)
+    {
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      double acc = 0.0;
+      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      const bool bad = row && !((lo - acc) <= 1e-9 * (1.0 + fabs(lo)) && (acc - hi) <= 1e-9 * (1.0 + fabs(hi)));
+      if(__syncthreads_or(bad ? 1 : 0)) st = CCC_STATUS_INFEASIBLE;
+    }
+    // outputs: u = H^-1 Ct'(mu + w_zmp [r; 0]); zmp = clamp(z0 + control_dt u0, zmin0, zmax0)  (:93-101)
+    __syncthreads();
+    cb[i] = row ? mu + P.w_zmp * r : 0.0;
+    __syncthreads();
+    if(i == 0)
+    {
+      double u0 = 0.0;
+      for(int k = 0; k <= N; ++k) u0 = fma(P.Wc[k], cb[k], u0);
+      const double cdt = control_dt < 0 ? P.dt : control_dt;
+      double zv = z0 + cdt * u0;
+      zv = zv < zl ? zl : (zh < zv ? zh : zv);
+      zmp[qp] = zv;
+      if(status) status[qp] = (passes << 8) | st;
+    }
+    if(vel && rng)
+    {
+      double uj = 0.0;
+      for(int k = 0; k <= N; ++k) uj = fma(P.Wc[(size_t)i * NP + k], cb[k], uj);
+      vel[qp * N + i] = uj;
+    }
+    __syncthreads();
+  }
+}
+} // namespace ccc_amd
+
+using namespace ccc_amd;
+
+struct ccc_ism
+{
+  int device = 0;
+  int N = 0;
+  double com_height = 0, horizon_duration = 0, horizon_dt = 0, w_zmp = 1.0, w_zmp_vel = 1e-3;
+  double *dG = nullptr, *dWc = nullptr;
+  int num_cu = 0;
+  // staging for the host-pointer entry point
+  int64_t cap = 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  int32_t * d_status = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+namespace
+{
+constexpr double kG = 9.80665; // include/CCC/Constants.h:10
+
+// Batch constants in long double: H = w_vel I + w_zmp P'P (src/IntrinsicallyStableMpc.cpp:29-32), Ct = [P; a] with the
+// stability row a (:35-39), Wc = H^-1 Ct' by Cholesky, G = Ct Wc.
+int upload_model(ccc_ism * h)
+{
+  typedef long double ld;
+  const int N = h->N, NP = kIsmNP, R = N + 1;
+  const ld dt = h->horizon_dt;
+  std::vector<ld> H((size_t)N * N), Ct((size_t)R * N, 0.0L), L((size_t)N * N, 0.0L), W((size_t)N * R);
+  // P'P[i][j] = dt^2 * #{k >= max(i, j)} = dt^2 (N - max(i, j))
+  for(int i = 0; i < N; i++)
+    for(int j = 0; j < N; j++)
+      H[(size_t)i * N + j] = (ld)h->w_zmp * dt * dt * (ld)(N - (i > j ? i : j)) + (i == j ? (ld)h->w_zmp_vel : 0.0L);
+  for(int i = 0; i < N; i++)
+    for(int j = 0; j <= i; j++) Ct[(size_t)i * N + j] = dt;
+  const double omega = std::sqrt(kG / h->com_height), lambda = std::exp(-1 * omega * h->horizon_dt); // :15 (double, as there)
+  {
+    double a = (1 - lambda) / (omega * (1 - std::pow(lambda, N)));
+    for(int j = 0; j < N; j++)
+    {
+      Ct[(size_t)N * N + j] = a;
+      a = lambda * a;
+    }
+  }
+  for(int j = 0; j < N; j++)
+  {
+    ld dgn = H[(size_t)j * N + j];
+    for(int k = 0; k < j; k++) dgn -= L[(size_t)j * N + k] * L[(size_t)j * N + k];
+    if(!(dgn > 0)) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_create: objective matrix is not positive definite");
+    const ld ljj = sqrtl(dgn);
+    L[(size_t)j * N + j] = ljj;
+    for(int i = j + 1; i < N; i++)
+    {
+      ld s = H[(size_t)i * N + j];
+      for(int k = 0; k < j; k++) s -= L[(size_t)i * N + k] * L[(size_t)j * N + k];
+      L[(size_t)i * N + j] = s / ljj;
+    }
+  }
+  for(int c = 0; c < R; c++)
+  {
+    std::vector<ld> y(N);
+    for(int i = 0; i < N; i++)
+    {
+      ld s = Ct[(size_t)c * N + i];
+      for(int k = 0; k < i; k++) s -= L[(size_t)i * N + k] * y[k];
+      y[i] = s / L[(size_t)i * N + i];
+    }
+    for(int i = N - 1; i >= 0; i--)
+    {
+      ld s = y[i];
+      for(int k = i + 1; k < N; k++) s -= L[(size_t)k * N + i] * y[k];
+      y[i] = s / L[(size_t)i * N + i];
+    }
+    for(int i = 0; i < N; i++) W[(size_t)i * R + c] = y[i];
+  }
+  std::vector<double> G((size_t)NP * NP, 0.0), Wc((size_t)N * NP, 0.0);
+  for(int a = 0; a < R; a++)
+    for(int b = 0; b < R; b++)
+    {
+      ld s = 0;
+      for(int k = 0; k < N; k++) s += Ct[(size_t)a * N + k] * W[(size_t)k * R + b];
+      G[(size_t)a * NP + b] = (double)s;
+    }
+  for(int a = 0; a < R; a++) // exact symmetry (the kernel reads column i as row i)
+    for(int b = 0; b < a; b++) G[(size_t)a * NP + b] = G[(size_t)b * NP + a] = 0.5 * (G[(size_t)a * NP + b] + G[(size_t)b * NP + a]);
+  for(int a = R; a < NP; a++) G[(size_t)a * NP + a] = 1.0;
+  for(int i = 0; i < N; i++)
+    for(int c = 0; c < R; c++) Wc[(size_t)i * NP + c] = (double)W[(size_t)i * R + c];
+  CCC_HIP_CHECK(hipMalloc(&h->dG, G.size() * sizeof(double)));
+  CCC_HIP_CHECK(hipMalloc(&h->dWc, Wc.size() * sizeof(double)));
+  CCC_HIP_CHECK(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
+  CCC_HIP_CHECK(hipMemcpy(h->dWc, Wc.data(), Wc.size() * sizeof(double), hipMemcpyHostToDevice));
+  return CCC_OK;
+}
+} // namespace
+
+extern "C" int ccc_ism_create(double com_height, double horizon_duration, double horizon_dt, double w_zmp,
+                              double w_zmp_vel, int device, ccc_ism_t ** out)
+{
+  if(!out) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_create: out is NULL");
+  *out = nullptr;
+  if(!(com_height > 0) || !(horizon_duration > 0) || !(horizon_dt > 0) || !(w_zmp >= 0) || !(w_zmp_vel > 0))
+    return fail(CCC_ERR_INVALID_ARGUMENT,
+                "ccc_ism_create: com_height, horizon_duration, horizon_dt, w_zmp_vel must be > 0 and w_zmp >= 0");
+  const int N = (int)std::ceil(horizon_duration / horizon_dt); // src/IntrinsicallyStableMpc.cpp:14
+  if(N + 1 > kIsmNP)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ism_create: horizon_steps %d > %d exceeds the LDS-resident tableau", N,
+                kIsmNP - 1);
+  int rc = select_device(device);
+  if(rc != CCC_OK) return rc;
+  ccc_ism * h = new ccc_ism();
+  h->device = device;
+  h->N = N;
+  h->com_height = com_height;
+  h->horizon_duration = horizon_duration;
+  h->horizon_dt = horizon_dt;
+  h->w_zmp = w_zmp;
+  h->w_zmp_vel = w_zmp_vel;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if(e != hipSuccess)
+  {
+    delete h;
+    return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  h->num_cu = prop.multiProcessorCount;
+  rc = upload_model(h);
+  if(rc != CCC_OK)
+  {
+    ccc_ism_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return CCC_OK;
+}
+
+extern "C" void ccc_ism_destroy(ccc_ism_t * h)
+{
+  if(!h) return;
+  (void)hipSetDevice(h->device);
+  if(h->dG) (void)hipFree(h->dG);
+  if(h->dWc) (void)hipFree(h->dWc);
+  if(h->d_in) (void)hipFree(h->d_in);
+  if(h->d_out) (void)hipFree(h->d_out);
+  if(h->d_status) (void)hipFree(h->d_status);
+  if(h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int ccc_ism_horizon_steps(const ccc_ism_t * h)
+{
+  return h ? h->N : -1;
+}
+
+extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double * init, const double * ref,
+                                         double control_dt, double * zmp, double * vel, int32_t * status, void * stream)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: n = %lld < 0", (long long)n);
+  if(n == 0) return CCC_OK;
+  if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t lds = ((size_t)kIsmNP * kIsmNP + kIsmNP) * sizeof(double) + sizeof(IsmRed);
+  static bool attr_set = false;
+  if(!attr_set)
+  {
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ism_plan_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t nqp = 2 * n;
+  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
+  IsmDev P{h->N, h->dG, h->dWc, h->w_zmp, h->horizon_dt};
+  hipLaunchKernelGGL(ism_plan_kernel, dim3(grid), dim3(kIsmNP), lds, reinterpret_cast<hipStream_t>(stream), P,
+                     (long)nqp, init, ref, control_dt, zmp, vel, status);
+  CCC_HIP_CHECK(hipGetLastError());
+  return CCC_OK;
+}
+
+extern "C" int ccc_ism_plan_batch(ccc_ism_t * h, int64_t n, const double * init, const double * ref, double control_dt,
+                                  double * zmp, double * vel, int32_t * status)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch: n = %lld < 0", (long long)n);
+  if(n == 0) return CCC_OK;
+  if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch: NULL init/ref/zmp");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t N = (size_t)h->N;
+  const size_t ni = (size_t)n * 4, nr = (size_t)n * 6 * N, nz = (size_t)n * 2, nv = (size_t)n * 2 * N;
+  if(n > h->cap)
+  {
+    if(h->d_in) (void)hipFree(h->d_in);
+    if(h->d_out) (void)hipFree(h->d_out);
+    if(h->d_status) (void)hipFree(h->d_status);
+    h->d_in = h->d_out = nullptr;
+    h->d_status = nullptr;
+    h->cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->d_in, (ni + nr) * sizeof(double)));
+    CCC_HIP_CHECK(hipMalloc(&h->d_out, (nz + nv) * sizeof(double)));
+    CCC_HIP_CHECK(hipMalloc(&h->d_status, (size_t)n * 2 * sizeof(int32_t)));
+    h->cap = n;
+  }
+  if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CCC_HIP_CHECK(hipMemcpyAsync(h->d_in, init, ni * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CCC_HIP_CHECK(hipMemcpyAsync(h->d_in + ni, ref, nr * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int rc = ccc_ism_plan_batch_device(h, n, h->d_in, h->d_in + ni, control_dt, h->d_out, vel ? h->d_out + nz : nullptr,
+                                     h->d_status, h->stream);
+  if(rc != CCC_OK) return rc;
+  CCC_HIP_CHECK(hipMemcpyAsync(zmp, h->d_out, nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if(vel) CCC_HIP_CHECK(hipMemcpyAsync(vel, h->d_out + nz, nv * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if(status)
+    CCC_HIP_CHECK(hipMemcpyAsync(status, h->d_status, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return CCC_OK;
+}

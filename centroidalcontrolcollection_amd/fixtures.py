@@ -73,33 +73,46 @@ class FootstepManager:
             self.footstep_list_.pop(0)
         # :162-206  (std::map::emplace keeps the FIRST value of a key)
         entries = {}
+        zmps = {}  # ref_zmp_list_
 
         def emplace(t, stance):
             if t not in entries:
                 entries[t] = {k: v.copy() for k, v in stance.items()}
 
+        def emplace_zmp(t, zmp):
+            if t not in zmps:
+                zmps[t] = np.array(zmp, dtype=np.float64)
+
         if not self.footstep_list_:
+            emplace_zmp(current_time, _mid_pos(self.footstance_))
+            emplace_zmp(current_time + self.horizon_duration_, _mid_pos(self.footstance_))
             emplace(current_time, self.footstance_)
             emplace(current_time + self.horizon_duration_, self.footstance_)
         else:
             if current_time < self.footstep_list_[0].transit_start_time:
+                emplace_zmp(current_time, _mid_pos(self.footstance_))
                 emplace(current_time, self.footstance_)
             tmp = {k: v.copy() for k, v in self.footstance_.items()}
-            last_zmp_key = -math.inf
             for fs in self.footstep_list_:
                 if not fs.transit_start_time <= current_time + self.horizon_duration_:
                     break
+                emplace_zmp(fs.transit_start_time, _mid_pos(tmp))
                 emplace(fs.transit_start_time, tmp)
                 tmp.pop(fs.foot, None)
+                emplace_zmp(fs.swing_start_time, tmp[opposite(fs.foot)])
                 emplace(fs.swing_start_time, tmp)
                 tmp.setdefault(fs.foot, fs.pos.copy())
+                emplace_zmp(fs.swing_end_time, tmp[opposite(fs.foot)])
                 emplace(fs.swing_end_time, tmp)
-                last_zmp_key = fs.transit_end_time
+                emplace_zmp(fs.transit_end_time, _mid_pos(tmp))
             # the reference compares against the last key of ref_zmp_list_ (:201)
-            if max(max(entries), last_zmp_key) < current_time + self.horizon_duration_:
+            if max(zmps) < current_time + self.horizon_duration_:
+                emplace_zmp(current_time + self.horizon_duration_, _mid_pos(tmp))
                 emplace(current_time + self.horizon_duration_, tmp)
         self._stance_times = sorted(entries)
         self._stances = [entries[t] for t in self._stance_times]
+        self._zmp_times = sorted(zmps)
+        self._zmps = [zmps[t] for t in self._zmp_times]
 
     def zmpLimits(self, t):
         # :242-254
@@ -107,6 +120,20 @@ class FootstepManager:
         k = bisect.bisect_right(self._stance_times, t) - 1
         region = _support_region(self._stances[k])
         return [region[0] - 0.5 * self.foot_size_, region[1] + 0.5 * self.foot_size_]
+
+    def refZmp(self, t):
+        # :228-237 (linear interpolation in ref_zmp_list_)
+        t = t + 1e-6
+        k = bisect.bisect_right(self._zmp_times, t)
+        t0, t1 = self._zmp_times[k - 1], self._zmp_times[k]
+        ratio = (t - t0) / (t1 - t0)
+        return (1 - ratio) * self._zmps[k - 1] + ratio * self._zmps[k]
+
+    def makeIntrinsicallyStableMpcRefData(self, t):
+        # :370-380 (its own +1e-6 on top of those of refZmp / zmpLimits): (ref zmp, zmin, zmax)
+        t = t + 1e-6
+        lim = self.zmpLimits(t)
+        return self.refZmp(t), lim[0], lim[1]
 
     def makeLinearMpcZmpRefData(self, t):
         # :356-365
@@ -245,3 +272,80 @@ def run_closed_loop(plan_once, com_height=1.0, sim_dt=0.005, end_time=10.0, dist
                 break
     lim = fm.zmpLimits(t)
     return log, dict(t=t, com=sim.pos(), zmp=planned, zmin=lim[0], zmax=lim[1])
+
+
+def run_closed_loop_ism(plan_once, com_height=1.0, sim_dt=0.005, end_time=10.0, disturb_times=(4.5, 8.5),
+                        disturb=(0.05, 0.05)):
+    """The control loop of TestIntrinsicallyStableMpc.cpp:55-100 around any
+    `plan_once(ref_func, capture_point [2], planned_zmp [2], t, sim_dt) -> zmp [2]` with
+    `ref_func(t) -> (ref zmp [2], zmin [2], zmax [2])`.  Returns per-cycle records and the final state for the property
+    assertions of :84-85,:103-106."""
+    fm = FootstepManager()
+    for fs in reference_scenario_footsteps():
+        fm.appendFootstep(fs)
+    sim = ComZmpSim2d(com_height, sim_dt)
+    planned = sim.pos()
+    t = 0.0
+    log = []
+    while t < end_time:
+        fm.update(t)
+        cp = sim.pos() + math.sqrt(com_height / G) * sim.vel()  # :67
+        planned = np.asarray(plan_once(fm.makeIntrinsicallyStableMpcRefData, cp, planned, t, sim_dt))
+        lim = fm.zmpLimits(t)
+        log.append(dict(t=t, com=sim.pos(), zmp=planned.copy(), zmin=lim[0], zmax=lim[1], cp=cp))
+        t += sim_dt
+        sim.update(planned)
+        for dtm in disturb_times:
+            if dtm <= t < dtm + sim_dt:
+                sim.addDisturb(disturb)
+                break
+    lim = fm.zmpLimits(t)
+    return log, dict(t=t, com=sim.pos(), zmp=planned, zmin=lim[0], zmax=lim[1])
+
+
+def sample_ism_refs(ref_func, t, N, dt):
+    """IntrinsicallyStableMpc::planOnce sampling (src/IntrinsicallyStableMpc.cpp:112-124): [2 axes][3][N] rows
+    (ref zmp, zmin, zmax)."""
+    out = np.zeros((2, 3, N))
+    for i in range(N):
+        z, lo, hi = ref_func(t + i * dt)
+        out[:, 0, i], out[:, 1, i], out[:, 2, i] = z, lo, hi
+    return out
+
+
+def make_ism_batch(n, horizon_steps=100, horizon_dt=0.02, com_height=1.0, seed=20250928):
+    """Synthetic IntrinsicallyStableMpc workload: random evaluation times / states along the reference scenario of
+    TestIntrinsicallyStableMpc.cpp:30-43 (capture point = stance reference + U(-0.04, 0.04), planned ZMP inside the
+    current limits).  Returns dict(init [n,2,2], ref [n,2,3,N])."""
+    rng = np.random.default_rng(seed)
+    init = np.zeros((n, 2, 2))
+    ref = np.zeros((n, 2, 3, horizon_steps))
+    cache = {}
+    for k in range(n):
+        t = round(float(rng.uniform(0.0, 9.0)) / 0.005) * 0.005
+        if t not in cache:
+            fm = FootstepManager()
+            for fs in reference_scenario_footsteps():
+                fm.appendFootstep(fs)
+            # replay update() up to t like the control loop does (it mutates the footstance)
+            tt = 0.0
+            while tt < t - 1e-12:
+                fm.update(tt)
+                tt += 0.05
+            fm.update(t)
+            cache[t] = sample_ism_refs(fm.makeIntrinsicallyStableMpcRefData, t, horizon_steps, horizon_dt)
+        ref[k] = cache[t]
+        lo, hi, z = ref[k, :, 1, 0], ref[k, :, 2, 0], ref[k, :, 0, 0]
+        init[k, :, 1] = np.clip(z + rng.uniform(-0.03, 0.03, size=2), lo, hi)
+        # capture point = the one a feasible ZMP trajectory implies through the stability constraint (eq. (14)):
+        # z_{i+1} = zmin_i + rho (zmax_i - zmin_i), u_i = (z_{i+1} - z_i)/dt, cp = z0 + a'u.  rho near 0 or 1 makes
+        # the limit rows of eq. (8) bind; an arbitrary capture point is usually infeasible.
+        om = math.sqrt(G / com_height)
+        lam = math.exp(-om * horizon_dt)
+        a = (1 - lam) / (om * (1 - lam ** horizon_steps)) * lam ** np.arange(horizon_steps)
+        for ax in range(2):
+            rho = rng.choice([rng.uniform(0.0, 1.0), rng.uniform(0.0, 0.03), rng.uniform(0.97, 1.0)])
+            traj = ref[k, ax, 1] + rho * (ref[k, ax, 2] - ref[k, ax, 1])
+            u = np.diff(np.concatenate([[init[k, ax, 1]], traj])) / horizon_dt
+            init[k, ax, 0] = init[k, ax, 1] + a @ u
+    return dict(init=np.ascontiguousarray(init), ref=np.ascontiguousarray(ref))

@@ -203,6 +203,37 @@ int ccc_xy_plan_batch(ccc_xy_t * h, int64_t n, const int32_t * dim, const double
                       const double * com_z, const double * total_force_z, const double * ref_out, const double * x0,
                       double * u0, double * lambda_all, int32_t * status);
 
+/* ============================================================================================
+ * CCC::IntrinsicallyStableMpc   (/root/reference/include/CCC/IntrinsicallyStableMpc.h:127-193)
+ * the first widening of the hot path (same range-QP kernel family as LinearMpcZmp).
+ * ============================================================================================ */
+typedef struct ccc_ism ccc_ism_t;
+
+/* Replaces IntrinsicallyStableMpc::IntrinsicallyStableMpc(com_height, horizon_duration, horizon_dt, qp_solver_type,
+ * weight_param) (IntrinsicallyStableMpc.h:162-169) -> IntrinsicallyStableMpc1d constructor
+ * (src/IntrinsicallyStableMpc.cpp:8-45).  WeightParam{zmp = 1, zmp_vel = 1e-3} (IntrinsicallyStableMpc.h:42-55).
+ * horizon_steps = ceil(horizon_duration / horizon_dt) must be <= 127. */
+int ccc_ism_create(double com_height, double horizon_duration, double horizon_dt, double w_zmp, double w_zmp_vel,
+                   int device, ccc_ism_t ** out);
+void ccc_ism_destroy(ccc_ism_t * h);
+int ccc_ism_horizon_steps(const ccc_ism_t * h);
+
+/* Replaces n calls of IntrinsicallyStableMpc::planOnce(ref_data_func, initial_param, current_time, control_dt)
+ * (IntrinsicallyStableMpc.h:178-181, src/IntrinsicallyStableMpc.cpp:106-139 incl. procOnce :63-104 and the QP solve
+ * :93), ref_data_func sampled at current_time + i*horizon_dt (:112-124):
+ *
+ *   init    [n][2 axes][2]     f64  (capture_point, planned_zmp) per axis           (InitialParam, .h:144-153)
+ *   ref     [n][2 axes][3][N]  f64  rows: RefData::zmp, zmp_limits[0], zmp_limits[1] of the axis
+ *   zmp     [n][2]             f64  planned ZMP (the return value)
+ *   vel     [n][2][N]          f64  optional: the planned ZMP-velocity sequence (the QP solution)
+ *   status  [n][2]             i32  optional, per axis: (pivots << 8) | CCC_STATUS_*
+ * control_dt < 0 means horizon_dt (:96-99).  All DEVICE pointers, asynchronous on `stream`. */
+int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double * init, const double * ref, double control_dt,
+                              double * zmp, double * vel, int32_t * status, void * stream);
+/* Same with HOST pointers. */
+int ccc_ism_plan_batch(ccc_ism_t * h, int64_t n, const double * init, const double * ref, double control_dt,
+                       double * zmp, double * vel, int32_t * status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -321,6 +321,49 @@ class _XyParams(ctypes.Structure):
                 ("w_am", ctypes.c_double * 2), ("w_force", ctypes.c_double)]
 
 
+class IntrinsicallyStableMpc:
+    """CPU restatement of CCC::IntrinsicallyStableMpc on pre-sampled reference sequences
+    (oracle/intrinsically_stable_mpc.c)."""
+
+    def __init__(self, com_height, horizon_duration, horizon_dt, w_zmp=1.0, w_zmp_vel=1e-3):
+        L = lib()
+        L.oracle_ism_create.restype = ctypes.c_void_p
+        L.oracle_ism_create.argtypes = [ctypes.c_double] * 5
+        L.oracle_ism_destroy.argtypes = [ctypes.c_void_p]
+        L.oracle_ism_horizon_steps.argtypes = [ctypes.c_void_p]
+        L.oracle_ism_plan_batch.restype = ctypes.c_int
+        L.oracle_ism_plan_batch.argtypes = [ctypes.c_void_p, ctypes.c_long, _dp, _dp, ctypes.c_double, _dp, _dp, _ip, _ip,
+                                            ctypes.c_int]
+        self._h = L.oracle_ism_create(float(com_height), float(horizon_duration), float(horizon_dt), float(w_zmp),
+                                      float(w_zmp_vel))
+        self.horizon_steps = L.oracle_ism_horizon_steps(self._h)
+        self.horizon_dt = float(horizon_dt)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().oracle_ism_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def plan_batch(self, init, ref, control_dt=-1.0, want_vel=True, nthreads=1):
+        """init [n,2,2] (capture_point, planned_zmp per axis), ref [n,2,3,N] (ref zmp, zmin, zmax rows per axis)
+        -> dict(zmp [n,2], vel [n,2,N], status [n], iters [n,2])."""
+        N = self.horizon_steps
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        n = init.shape[0]
+        assert init.shape == (n, 2, 2) and ref.shape == (n, 2, 3, N)
+        zmp = np.empty((n, 2))
+        vel = np.empty((n, 2, N)) if want_vel else None
+        status = np.empty(n, dtype=np.int32)
+        iters = np.empty((n, 2), dtype=np.int32)
+        lib().oracle_ism_plan_batch(self._h, n, _ptr(init), _ptr(ref), float(control_dt), _ptr(zmp), _ptr(vel),
+                                    _ptr(status, ctypes.c_int), _ptr(iters, ctypes.c_int), int(nthreads))
+        return dict(zmp=zmp, vel=vel, status=status, iters=iters)
+
+
 class LinearMpcXY:
     """CPU restatement of CCC::LinearMpcXY on pre-sampled, flattened per-step data (oracle/linear_mpc_xy.c)."""
 
