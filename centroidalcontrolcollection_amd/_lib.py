@@ -49,6 +49,10 @@ ABI_SYMBOLS = [
     "ccc_ism_horizon_steps",
     "ccc_ism_plan_batch_device",
     "ccc_ism_plan_batch",
+    "ccc_z_create",
+    "ccc_z_destroy",
+    "ccc_z_plan_batch_device",
+    "ccc_z_plan_batch",
 ]
 
 

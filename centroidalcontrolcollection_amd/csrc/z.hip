@@ -1,0 +1,408 @@
+// z.hip -- batched CCC::LinearMpcZ::planOnce() on MI355X (gfx950): kernel + C-ABI.
+// (the vertical companion of LinearMpcXY -- it plans the total_force_z that LinearMpcXY takes.)
+//
+// Path replaced (reference file:line under /root/reference):
+//   src/LinearMpcZ.cpp:10-29     ModelContactPhase / ModelNoncontactPhase: x = [m z, m zdot], A = [[0,1],[0,0]],
+//                                B = [0,1]' (contact only), C = [1/m, 0], E = [0, -m g]
+//   include/CCC/StateSpaceModel.h:164-216   ZOH with offset -- closed form here (A^2 = 0):
+//                                Ad = [[1,dt],[0,1]], Bd = [dt^2/2, dt]', Ed = -m g [dt^2/2, dt]'
+//   include/CCC/VariantSequentialExtension.h:110-208   setup(extend_for_output = true) -- closed form here:
+//                                output j (height after step j) responds to the force of contact step s <= j with
+//                                c (j - s + 1/2), c = dt^2/m; free response z0 + t v0 - g t^2/2, t = (j+1) dt
+//   src/LinearMpcZ.cpp:48-71     planOnce (zero force when there is no contact at current_time)
+//   src/LinearMpcZ.cpp:73-94     procOnce: H = w_pos B'B + w_force I, g = -w_pos B'(ref - free response),
+//                                bounds (10, 10 m g), the external QP solve (:93), [0]
+//
+// One instance per wavefront (64-thread workgroup), lane i = variable i (one per contact step, <= 64).  H is built in
+// closed form, inverted by sweeping every variable (LDS tableau, 32 KB), and the bound-constrained QP is solved by
+// the dual active-set / sweep-tableau iteration of LinearMpcZmp on G = H^-1; a closing primal refinement with the
+// untouched H removes the drift, a final certificate checks the bounds.
+#include "common.h"
+#include "wave_group.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace ccc_amd
+{
+constexpr int kZNP = 64; // horizon steps / variables per instance
+constexpr double kZG = 9.80665;
+constexpr double kZInf = __builtin_huge_val();
+
+struct ZParams
+{
+  int N;
+  double mass, dt, w_pos, w_force, fmin, fmax;
+};
+
+struct ZBatch
+{
+  const int * contact;  // [n][N]
+  const double * ref;   // [n][N]
+  const double * x0;    // [n][2]
+  double * force;       // [n]
+  double * force_all;   // [n][N] per step, or null
+  int * status;         // [n] or null
+};
+
+// (min over the wavefront, lowest lane attaining it; 64 if no finite candidate)
+__device__ __forceinline__ void z_wave_argmin(double v, double & vmin, int & imin)
+{
+  vmin = WaveGroup<64>::min(v);
+  imin = WaveGroup<64>::first(v == vmin && v < kZInf);
+}
+
+__global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n)
+{
+  constexpr int NP = kZNP;
+  __shared__ double T[NP * NP];  // sweep tableau, [j][i] (i fastest)
+  __shared__ double Hs[NP * NP]; // the untouched H
+  __shared__ double cb[NP];
+  __shared__ double res[NP];
+  __shared__ int svar[NP];
+  const int i = threadIdx.x;
+  const int N = P.N;
+  const double c = P.dt * P.dt / P.mass;
+
+  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  {
+    __syncthreads();
+    const bool ct = i < N && B.contact[b * N + i] != 0;
+    const unsigned long long mask = __ballot(ct);
+    const int nv = __popcll(mask);
+    if(!(mask & 1ull)) // src/LinearMpcZ.cpp:54-57
+    {
+      if(i == 0)
+      {
+        B.force[b] = 0.0;
+        if(B.status) B.status[b] = CCC_STATUS_SOLVED;
+      }
+      if(B.force_all && i < N) B.force_all[b * N + i] = 0.0;
+      continue;
+    }
+    const int myvar = __popcll(mask & ((1ull << i) - 1ull)); // variable index of step i (if in contact)
+    if(ct) svar[myvar] = i;
+    // free response and residual of output i (height after step i)
+    {
+      const double z0 = B.x0[b * 2 + 0], v0 = B.x0[b * 2 + 1];
+      const double t = (i + 1) * P.dt;
+      res[i] = (i < N) ? B.ref[b * N + i] - (z0 + t * v0 - 0.5 * kZG * t * t) : 0.0;
+    }
+    __syncthreads();
+    const bool row = i < nv;
+    const int si = row ? svar[i] : 0;
+    // H (closed form) and g
+    double gi = 0.0;
+    {
+      const double a = si - 0.5;
+      for(int l = 0; l < NP; l++)
+      {
+        double h = (l == i) ? 1.0 : 0.0; // identity on the padding
+        if(row && l < nv)
+        {
+          const int sl = svar[l];
+          const double bb = sl - 0.5;
+          const double J = si > sl ? si : sl;
+          // sum_{j=J}^{N-1} (j - a)(j - bb) with S1(m) = sum_{j<m} j, S2(m) = sum_{j<m} j^2
+          const double Nn = N;
+          const double s1 = 0.5 * (Nn * (Nn - 1.0) - J * (J - 1.0));
+          const double s2 = ((Nn - 1.0) * Nn * (2.0 * Nn - 1.0) - (J - 1.0) * J * (2.0 * J - 1.0)) / 6.0;
+          h = P.w_pos * (c * c) * (s2 - (a + bb) * s1 + a * bb * (Nn - J)) + ((l == i) ? P.w_force : 0.0);
+        }
+        T[l * NP + i] = h;
+        Hs[l * NP + i] = h;
+      }
+      if(row)
+      {
+        double s = 0.0;
+        for(int j = si; j < N; j++) s = fma(c * (j - a), res[j], s);
+        gi = -P.w_pos * s;
+      }
+    }
+    __syncthreads();
+    // T <- -H^-1 by sweeping every variable
+    for(int kp = 0; kp < nv; kp++)
+    {
+      cb[i] = T[kp * NP + i];
+      __syncthreads();
+      const double rp = 1.0 / cb[kp];
+      if(i == kp)
+      {
+        for(int j = 0; j < nv; j++) T[j * NP + i] = cb[j] * rp;
+        T[kp * NP + i] = -rp;
+      }
+      else if(row)
+      {
+        const double g = cb[i] * rp;
+        for(int j = 0; j < nv; j++) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+        T[kp * NP + i] = g;
+      }
+      __syncthreads();
+    }
+    // unconstrained minimiser lam0 = -H^-1 g, then G = H^-1 = -T
+    cb[i] = row ? gi : 0.0;
+    __syncthreads();
+    double lam0 = 0.0;
+    for(int j = 0; j < nv; j++)
+    {
+      const double t = T[j * NP + i];
+      lam0 = fma(t, cb[j], lam0);
+      T[j * NP + i] = -t;
+    }
+    __syncthreads();
+    const double lo = row ? P.fmin - lam0 : -kZInf;
+    const double hi = row ? P.fmax - lam0 : kZInf;
+    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
+    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
+    int st = CCC_STATUS_SOLVED;
+
+    double z = 0.0, mu = 0.0;
+    bool inW = false;
+    int p = 0;
+    double psig = 0.0, pd = 0.0;
+    bool done = false;
+    bool need_select = true;
+    int passes = 0;
+    const int maxpass = 20 * nv + 100;
+
+    for(int round = 0; round < 3 && !done; ++round)
+    {
+      while(!done)
+      {
+        if(need_select)
+        {
+          const double sl = (lo - z) - tl, sh = (z - hi) - th;
+          const double score = (inW || !row) ? -kZInf : fmax(sl, sh);
+          double m;
+          int cand;
+          z_wave_argmin(score > 0.0 ? -score : kZInf, m, cand);
+          if(cand >= NP) break;
+          p = cand;
+          if(i == cand)
+          {
+            psig = (sl >= sh) ? 1.0 : -1.0;
+            pd = (sl >= sh) ? lo : hi;
+          }
+        }
+        const double sig = __shfl(psig, p);
+        const double cc = T[p * NP + i]; // column p = row p (symmetric)
+        const double dm = -sig * cc;
+        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const bool isp = (i == p);
+        const double num = isp ? psig * (pd - z) : -mu;
+        const double den = isp ? cc : dm;
+        double ratio = (isp || blocking) ? num / den : kZInf;
+        if(isp && !(cc > 0.0)) ratio = kZInf;
+        double t;
+        int kk;
+        z_wave_argmin(ratio, t, kk);
+        if(kk >= NP)
+        {
+          st = CCC_STATUS_INFEASIBLE;
+          done = true;
+          break;
+        }
+        const bool isadd = (kk == p);
+        const double s = isadd ? 1.0 : -1.0;
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, cc, z);
+        if(isp) mu += sig * t;
+        // pivot on row/column kk
+        const double v = T[kk * NP + i];
+        __syncthreads();
+        cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+        if(i == kk)
+        {
+          for(int j = 0; j < nv; ++j) T[j * NP + i] = s * cb[j] * rp;
+        }
+        else if(row)
+        {
+          for(int j = 0; j < nv; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+        }
+        __syncthreads();
+        if(row) T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        __syncthreads();
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(++passes > maxpass)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+        }
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      // closing primal refinement with the untouched H: r = -(H lambda + g) on the free variables,
+      // lambda_F += (H_FF)^-1 r -- on the tableau swept on W the free-free block IS (H_FF)^-1
+      __syncthreads();
+      cb[i] = row ? lam0 + z : 0.0;
+      __syncthreads();
+      double hl = gi;
+      for(int j = 0; j < nv; ++j) hl = fma(Hs[j * NP + i], cb[j], hl);
+      const double r = (row && !inW) ? -hl : 0.0;
+      __syncthreads();
+      cb[i] = r;
+      __syncthreads();
+      if(row && !inW)
+      {
+        double dz = 0.0;
+        for(int j = 0; j < nv; ++j) dz = fma(T[j * NP + i], cb[j], dz);
+        z += dz;
+      }
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
+      need_select = true;
+      if(!reopen) break;
+    }
+    // certificate (also catches NaN): every force inside its bounds
+    {
+      const double lam = lam0 + z;
+      const bool bad = row && !((P.fmin - lam) <= 1e-9 * (1.0 + fabs(P.fmin)) && (lam - P.fmax) <= 1e-9 * (1.0 + fabs(P.fmax)));
+      if(__syncthreads_or(bad ? 1 : 0) && st == CCC_STATUS_SOLVED) st = CCC_STATUS_INFEASIBLE;
+    }
+    // outputs: variable 0 is the force of step 0 (src/LinearMpcZ.cpp:93)
+    if(i == 0)
+    {
+      B.force[b] = lam0 + z;
+      if(B.status) B.status[b] = (passes << 8) | st;
+    }
+    if(B.force_all)
+    {
+      if(i < N) B.force_all[b * N + i] = 0.0;
+      __syncthreads();
+      if(row) B.force_all[b * N + si] = lam0 + z;
+    }
+  }
+}
+} // namespace ccc_amd
+
+using namespace ccc_amd;
+
+struct ccc_z
+{
+  int device = 0;
+  int N = 0;
+  double mass = 0, dt = 0, w_pos = 1.0, w_force = 1e-7;
+  int num_cu = 0;
+  int64_t cap = 0;
+  char * d_stage = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, double w_pos, double w_force, int device,
+                            ccc_z_t ** out)
+{
+  if(!out) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_create: out is NULL");
+  *out = nullptr;
+  if(!(mass > 0) || !(horizon_dt > 0) || horizon_steps <= 0 || !(w_pos >= 0) || !(w_force > 0))
+    return fail(CCC_ERR_INVALID_ARGUMENT,
+                "ccc_z_create: mass, horizon_dt, horizon_steps, w_force must be > 0 and w_pos >= 0");
+  if(horizon_steps > kZNP)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_z_create: horizon_steps %d > %d is not built into this library",
+                horizon_steps, kZNP);
+  int rc = select_device(device);
+  if(rc != CCC_OK) return rc;
+  ccc_z * h = new ccc_z();
+  h->device = device;
+  h->N = horizon_steps;
+  h->mass = mass;
+  h->dt = horizon_dt;
+  h->w_pos = w_pos;
+  h->w_force = w_force;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if(e != hipSuccess)
+  {
+    delete h;
+    return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  }
+  h->num_cu = prop.multiProcessorCount;
+  *out = h;
+  return CCC_OK;
+}
+
+extern "C" void ccc_z_destroy(ccc_z_t * h)
+{
+  if(!h) return;
+  (void)hipSetDevice(h->device);
+  if(h->d_stage) (void)hipFree(h->d_stage);
+  if(h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * contact, const double * ref_pos,
+                                       const double * x0, double * force, double * force_all, int32_t * status,
+                                       void * stream)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch_device: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch_device: n = %lld < 0", (long long)n);
+  if(n == 0) return CCC_OK;
+  if(!contact || !ref_pos || !x0 || !force)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch_device: NULL contact/ref_pos/x0/force");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
+  ZBatch B{contact, ref_pos, x0, force, force_all, status};
+  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 16);
+  hipLaunchKernelGGL(z_plan_kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
+  CCC_HIP_CHECK(hipGetLastError());
+  return CCC_OK;
+}
+
+extern "C" int ccc_z_plan_batch(ccc_z_t * h, int64_t n, const int32_t * contact, const double * ref_pos,
+                                const double * x0, double * force, double * force_all, int32_t * status)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch: NULL handle");
+  if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch: n = %lld < 0", (long long)n);
+  if(n == 0) return CCC_OK;
+  if(!contact || !ref_pos || !x0 || !force)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch: NULL contact/ref_pos/x0/force");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t N = (size_t)h->N;
+  const size_t bc = (size_t)n * N * 4, br = (size_t)n * N * 8, bx = (size_t)n * 16, bf = (size_t)n * 8, bs = (size_t)n * 4;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t oc = 0, orf = oc + up(bc), ox = orf + up(br), of = ox + up(bx), ofa = of + up(bf), os = ofa + up(br),
+               total = os + up(bs);
+  if(n > h->cap)
+  {
+    if(h->d_stage) (void)hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->d_stage, total));
+    h->cap = n;
+  }
+  if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  char * d = h->d_stage;
+  CCC_HIP_CHECK(hipMemcpyAsync(d + oc, contact, bc, hipMemcpyHostToDevice, h->stream));
+  CCC_HIP_CHECK(hipMemcpyAsync(d + orf, ref_pos, br, hipMemcpyHostToDevice, h->stream));
+  CCC_HIP_CHECK(hipMemcpyAsync(d + ox, x0, bx, hipMemcpyHostToDevice, h->stream));
+  int rc = ccc_z_plan_batch_device(h, n, (const int32_t *)(d + oc), (const double *)(d + orf), (const double *)(d + ox),
+                                   (double *)(d + of), force_all ? (double *)(d + ofa) : nullptr, (int32_t *)(d + os),
+                                   h->stream);
+  if(rc != CCC_OK) return rc;
+  CCC_HIP_CHECK(hipMemcpyAsync(force, d + of, bf, hipMemcpyDeviceToHost, h->stream));
+  if(force_all) CCC_HIP_CHECK(hipMemcpyAsync(force_all, d + ofa, br, hipMemcpyDeviceToHost, h->stream));
+  if(status) CCC_HIP_CHECK(hipMemcpyAsync(status, d + os, bs, hipMemcpyDeviceToHost, h->stream));
+  CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return CCC_OK;
+}

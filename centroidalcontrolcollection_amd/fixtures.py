@@ -349,3 +349,58 @@ def make_ism_batch(n, horizon_steps=100, horizon_dt=0.02, com_height=1.0, seed=2
             u = np.diff(np.concatenate([[init[k, ax, 1]], traj])) / horizon_dt
             init[k, ax, 0] = init[k, ax, 1] + a @ u
     return dict(init=np.ascontiguousarray(init), ref=np.ascontiguousarray(ref))
+
+
+# ------------------------------------------------------------------------------------------------ LinearMpcZ
+def z_reference_contact(t):
+    """TestLinearMpcZ.cpp:26: two flight windows."""
+    return not ((5.0 < t < 5.25) or (6.0 < t < 6.5))
+
+
+def z_reference_height(t):
+    """TestLinearMpcZ.cpp:27."""
+    return 1.0 if t < 8.5 else 0.8
+
+
+class VerticalSim:
+    """SimModels.h:44-73: state [z, zdot], input force; exact ZOH of the double integrator with gravity."""
+
+    def __init__(self, mass, sim_dt):
+        self.Ad = np.array([[1.0, sim_dt], [0.0, 1.0]])
+        self.Bd = np.array([0.5 * sim_dt * sim_dt, sim_dt]) / mass
+        self.Ed = -G * np.array([0.5 * sim_dt * sim_dt, sim_dt])
+        self.state = np.zeros(2)
+
+    def update(self, force):
+        self.state = self.Ad @ self.state + self.Bd * force + self.Ed
+
+
+def run_closed_loop_z(plan_once, mass=100.0, sim_dt=0.04, end_time=10.0):
+    """The control loop of TestLinearMpcZ.cpp:41-72 around any `plan_once(contact_func, ref_pos_func, state [2], t)`.
+    Returns per-cycle records and the final (t, state)."""
+    sim = VerticalSim(mass, sim_dt)
+    sim.state = np.array([z_reference_height(0.0), 0.0])
+    t, log = 0.0, []
+    while t < end_time:
+        f = float(plan_once(z_reference_contact, z_reference_height, sim.state.copy(), t))
+        log.append(dict(t=t, state=sim.state.copy(), ref=z_reference_height(t), force=f, contact=z_reference_contact(t)))
+        t += sim_dt
+        sim.update(f)
+    return log, (t, sim.state.copy())
+
+
+def make_z_batch(n, horizon_steps=40, horizon_dt=0.05, seed=20250928):
+    """Synthetic LinearMpcZ workload: up to two random flight windows inside the horizon (never at step 0 for 7 of 8
+    instances), a reference height with one random step change, and initial heights / velocities far enough from the
+    reference that the force bounds (10 N, 10 m g) bind.  Returns dict(contact [n,N] i32, ref_pos [n,N], x0 [n,2])."""
+    rng = np.random.default_rng(seed)
+    N = horizon_steps
+    contact = np.ones((n, N), dtype=np.int32)
+    ref = np.ones((n, N))
+    for k in range(n):
+        for _ in range(rng.integers(0, 3)):
+            a = 0 if rng.random() < 0.125 else rng.integers(1, N)
+            contact[k, a:a + rng.integers(1, 9)] = 0
+        ref[k, rng.integers(0, N):] = rng.uniform(0.7, 1.2)
+    x0 = np.stack([1.0 + rng.uniform(-0.5, 0.5, size=n), rng.uniform(-3.0, 3.0, size=n)], axis=1)
+    return dict(contact=contact, ref_pos=ref, x0=np.ascontiguousarray(x0))

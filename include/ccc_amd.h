@@ -234,6 +234,35 @@ int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double * init, con
 int ccc_ism_plan_batch(ccc_ism_t * h, int64_t n, const double * init, const double * ref, double control_dt,
                        double * zmp, double * vel, int32_t * status);
 
+/* ============================================================================================
+ * CCC::LinearMpcZ   (/root/reference/include/CCC/LinearMpcZ.h:14-179)
+ * the vertical companion of LinearMpcXY (it plans the total_force_z LinearMpcXY consumes).
+ * ============================================================================================ */
+typedef struct ccc_z ccc_z_t;
+
+/* Replaces LinearMpcZ::LinearMpcZ(mass, horizon_dt, horizon_steps, weight_param, qp_solver_type)
+ * (LinearMpcZ.h:127-131, src/LinearMpcZ.cpp:31-46).  WeightParam{pos = 1, force = 1e-7} (LinearMpcZ.h:34-47);
+ * force_range_ = (10, 10 m g) (:37).  horizon_steps <= 64. */
+int ccc_z_create(double mass, double horizon_dt, int horizon_steps, double w_pos, double w_force, int device,
+                 ccc_z_t ** out);
+void ccc_z_destroy(ccc_z_t * h);
+
+/* Replaces n calls of LinearMpcZ::planOnce(contact_func, ref_pos_func, initial_param, current_time)
+ * (LinearMpcZ.h:140-143, src/LinearMpcZ.cpp:48-94 incl. the QP solve :93), callbacks sampled at current_time + i*dt:
+ *
+ *   contact    [n][N]  i32  contact_func(t_i) (0 / non-zero); step 0 without contact -> planned force 0 (:54-57)
+ *   ref_pos    [n][N]  f64  ref_pos_func(t_i)
+ *   x0         [n][2]  f64  InitialParam = (CoM height, vertical velocity)                    (LinearMpcZ.h:31)
+ *   force      [n]     f64  planned vertical force of step 0 (the return value)
+ *   force_all  [n][N]  f64  optional: planned force of every step (0 at steps without contact)
+ *   status     [n]     i32  optional: (pivots << 8) | CCC_STATUS_*
+ * All DEVICE pointers, asynchronous on `stream`. */
+int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * contact, const double * ref_pos, const double * x0,
+                            double * force, double * force_all, int32_t * status, void * stream);
+/* Same with HOST pointers. */
+int ccc_z_plan_batch(ccc_z_t * h, int64_t n, const int32_t * contact, const double * ref_pos, const double * x0,
+                     double * force, double * force_all, int32_t * status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -364,6 +364,45 @@ class IntrinsicallyStableMpc:
         return dict(zmp=zmp, vel=vel, status=status, iters=iters)
 
 
+class LinearMpcZ:
+    """CPU restatement of CCC::LinearMpcZ on pre-sampled contact flags / reference heights (oracle/linear_mpc_z.c)."""
+
+    def __init__(self, mass, horizon_dt, horizon_steps, w_pos=1.0, w_force=1e-7):
+        L = lib()
+        L.oracle_z_create.restype = ctypes.c_void_p
+        L.oracle_z_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+        L.oracle_z_destroy.argtypes = [ctypes.c_void_p]
+        L.oracle_z_plan_batch.restype = ctypes.c_int
+        L.oracle_z_plan_batch.argtypes = [ctypes.c_void_p, ctypes.c_long, _ip, _dp, _dp, _dp, _dp, _ip, _ip, ctypes.c_int]
+        self._h = L.oracle_z_create(float(mass), float(horizon_dt), int(horizon_steps), float(w_pos), float(w_force))
+        self.N, self.mass = int(horizon_steps), float(mass)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().oracle_z_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def plan_batch(self, contact, ref_pos, x0, nthreads=1, want_all=False):
+        """contact [n,N] (0/1), ref_pos [n,N], x0 [n,2] (pos, vel) -> dict(force [n], force_all [n,N] (compact) | None,
+        status [n], iters [n])."""
+        N = self.N
+        contact = np.ascontiguousarray(contact, dtype=np.int32)
+        ref_pos = np.ascontiguousarray(ref_pos, dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = x0.shape[0]
+        assert contact.shape == (n, N) and ref_pos.shape == (n, N) and x0.shape == (n, 2)
+        force = np.zeros(n)
+        fall = np.zeros((n, N)) if want_all else None
+        status = np.zeros(n, dtype=np.int32)
+        iters = np.zeros(n, dtype=np.int32)
+        lib().oracle_z_plan_batch(self._h, n, _ptr(contact, ctypes.c_int), _ptr(ref_pos), _ptr(x0), _ptr(force),
+                                  _ptr(fall), _ptr(status, ctypes.c_int), _ptr(iters, ctypes.c_int), int(nthreads))
+        return dict(force=force, force_all=fall, status=status, iters=iters)
+
+
 class LinearMpcXY:
     """CPU restatement of CCC::LinearMpcXY on pre-sampled, flattened per-step data (oracle/linear_mpc_xy.c)."""
 

@@ -1,0 +1,36 @@
+"""Time the LinearMpcZ kernel (reference test horizon: 40 steps @ 50 ms) and, with `cpu`, the oracle beside it.
+usage: z_bench.py [n] [reps] [cpu]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from centroidalcontrolcollection_amd import LinearMpcZ, fixtures as fx
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+N, dt = 40, 0.05
+base = min(n, 4096)
+b = fx.make_z_batch(base, N, dt, seed=7)
+k = (n + base - 1) // base
+b = {a: np.concatenate([v] * k)[:n] for a, v in b.items()}
+mpc = LinearMpcZ(100.0, dt, N)
+dev = torch.device("cuda:0")
+tc, tr, tx = (torch.from_numpy(np.ascontiguousarray(b[a])).to(dev) for a in ("contact", "ref_pos", "x0"))
+f = torch.zeros(n, dtype=torch.float64, device=dev)
+st = torch.zeros(n, dtype=torch.int32, device=dev)
+mpc.plan_batch_device(tc, tr, tx, f, status=st)
+torch.cuda.synchronize()
+ts = []
+for _ in range(reps):
+    t0 = time.perf_counter(); mpc.plan_batch_device(tc, tr, tx, f, status=st); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+t = min(ts)
+s = st.cpu().numpy()
+print("LinearMpcZ n=%d N=%d: %.2f ms -> %.0f solves/s (mean pivots %.2f, max %d, non-ok %d)"
+      % (n, N, t * 1e3, n / t, (s >> 8).mean(), (s >> 8).max(), int(((s & 0xff) != 0).sum())))
+if len(sys.argv) > 3 and sys.argv[3] == "cpu":
+    from oracle import oracle
+    o = oracle.LinearMpcZ(100.0, dt, N)
+    nc = min(n, 16384)
+    cores = os.cpu_count()
+    t0 = time.perf_counter(); r = o.plan_batch(b["contact"][:nc], b["ref_pos"][:nc], b["x0"][:nc], nthreads=cores); tcpu = time.perf_counter() - t0
+    t0 = time.perf_counter(); o.plan_batch(b["contact"][:256], b["ref_pos"][:256], b["x0"][:256], nthreads=1); t1 = time.perf_counter() - t0
+    print("oracle: %d threads %.0f solves/s, 1 thread %.0f solves/s; max rel |dF| vs GPU = %.2e"
+          % (cores, nc / tcpu, 256 / t1, (np.abs(r["force"] - f.cpu().numpy()[:nc]) / (np.abs(r["force"]) + 1)).max()))
