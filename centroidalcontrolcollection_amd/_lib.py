@@ -33,6 +33,9 @@ ABI_SYMBOLS = [
     "ccc_zmp_get_seq",
     "ccc_zmp_plan_batch_device",
     "ccc_zmp_plan_batch",
+    "ccc_zmp_get_model",
+    "ccc_zmp_sample_limits_device",
+    "ccc_zmp_closed_loop_device",
     "ccc_ddp_default_config",
     "ccc_ddp_create",
     "ccc_ddp_destroy",

@@ -800,6 +800,14 @@ extern "C" int ccc_zmp_horizon_steps(const ccc_zmp_t * h)
   return h ? h->N : -1;
 }
 
+extern "C" int ccc_zmp_get_model(const ccc_zmp_t * h, double * com_height, double * horizon_dt)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_get_model: NULL handle");
+  if(com_height) *com_height = h->com_height;
+  if(horizon_dt) *horizon_dt = h->horizon_dt;
+  return CCC_OK;
+}
+
 extern "C" int ccc_zmp_get_seq(const ccc_zmp_t * h, double * A_seq, double * B_seq)
 {
   if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_get_seq: NULL handle");

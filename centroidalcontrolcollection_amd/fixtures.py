@@ -404,3 +404,36 @@ def make_z_batch(n, horizon_steps=40, horizon_dt=0.05, seed=20250928):
         ref[k, rng.integers(0, N):] = rng.uniform(0.7, 1.2)
     x0 = np.stack([1.0 + rng.uniform(-0.5, 0.5, size=n), rng.uniform(-3.0, 3.0, size=n)], axis=1)
     return dict(contact=contact, ref_pos=ref, x0=np.ascontiguousarray(x0))
+
+
+def make_zmp_timelines(n, seed=20250928, num_footsteps=6):
+    """Random footstep timelines of the shape of TestLinearMpcZmp.cpp:30-43 (the ones make_zmp_batch draws), in the
+    device format of include/ccc_amd.h: dict(foot0 [n,2,2], foot_pos [n,K,2], foot_id [n,K] i32, swing_start [n,K],
+    swing_end [n,K])."""
+    rng = np.random.default_rng(seed)
+    K = num_footsteps
+    foot0 = np.empty((n, 2, 2))
+    foot0[:, LEFT] = [0.0, 0.1]
+    foot0[:, RIGHT] = [0.0, -0.1]
+    first_foot = rng.integers(0, 2, size=n)
+    foot_id = ((first_foot[:, None] + np.arange(K)[None, :]) % 2).astype(np.int32)
+    step_x = rng.uniform(-0.1, 0.3, size=(n, K))
+    lateral = 0.1 + rng.uniform(-0.02, 0.05, size=(n, K))
+    foot_pos = np.empty((n, K, 2))
+    foot_pos[:, :, 0] = np.cumsum(step_x, axis=1)
+    foot_pos[:, :, 1] = np.where(foot_id == LEFT, lateral, -lateral)
+    t_first = rng.uniform(0.3, 2.0, size=n)
+    transit_start = t_first[:, None] + 1.0 * np.arange(K)[None, :]
+    swing_start = transit_start + 0.1
+    swing_end = swing_start + 0.8
+    return dict(foot0=foot0, foot_pos=np.ascontiguousarray(foot_pos), foot_id=np.ascontiguousarray(foot_id),
+                swing_start=np.ascontiguousarray(swing_start), swing_end=np.ascontiguousarray(swing_end))
+
+
+def reference_scenario_timeline():
+    """The footsteps of TestLinearMpcZmp.cpp:30-43 as one timeline (n = 1)."""
+    steps = reference_scenario_footsteps()
+    return dict(foot0=np.array([[[0.0, 0.1], [0.0, -0.1]]]), foot_pos=np.array([[fs.pos for fs in steps]]),
+                foot_id=np.array([[fs.foot for fs in steps]], dtype=np.int32),
+                swing_start=np.array([[fs.swing_start_time for fs in steps]]),
+                swing_end=np.array([[fs.swing_end_time for fs in steps]]))

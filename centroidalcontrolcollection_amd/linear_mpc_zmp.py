@@ -123,3 +123,69 @@ class LinearMpcZmp:
             self._h, n, ctypes.c_void_p(x0.data_ptr()), ctypes.c_void_p(zlim.data_ptr()), float(control_dt),
             ctypes.c_void_p(zmp.data_ptr()), ctypes.c_void_p(jerk.data_ptr()) if jerk is not None else None,
             ctypes.c_void_p(status.data_ptr()) if status is not None else None, sp))
+
+    # ------------------------------------------------------------------ either side of the path, on the device
+    def _timeline_args(self, tl):
+        """tl: dict of contiguous CUDA tensors foot0 [n,2,2] f64, foot_pos [n,K,2] f64, foot_id [n,K] i32,
+        swing_start / swing_end [n,K] f64 (the footstep timeline format of include/ccc_amd.h)."""
+        import torch
+
+        n, K = tl["foot_id"].shape
+        for name, dt in (("foot0", torch.float64), ("foot_pos", torch.float64), ("foot_id", torch.int32),
+                         ("swing_start", torch.float64), ("swing_end", torch.float64)):
+            t = tl[name]
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous %s CUDA tensor" % (name, dt))
+        p = [ctypes.c_void_p(tl[k].data_ptr()) for k in ("foot0", "foot_pos", "foot_id", "swing_start", "swing_end")]
+        return n, K, p
+
+    def sample_limits_device(self, timeline, zlim, t_eval=None, t_common=0.0, foot_size=None, stream=None):
+        """ccc_zmp_sample_limits_device: zlim [n,2,2,N] <- the limits FootstepManager::makeLinearMpcZmpRefData returns at
+        t + i*horizon_dt, t = t_eval[k] (CUDA tensor) or t_common."""
+        import torch
+
+        L = self._L
+        L.ccc_zmp_sample_limits_device.restype = ctypes.c_int
+        L.ccc_zmp_sample_limits_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 7 + [
+            ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        n, K, p = self._timeline_args(timeline)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        fs = (ctypes.c_double * 2)(*foot_size) if foot_size is not None else None
+        _lib.check(L.ccc_zmp_sample_limits_device(self._h, n, K, *p, fs,
+                                                  ctypes.c_void_p(t_eval.data_ptr()) if t_eval is not None else None,
+                                                  float(t_common), ctypes.c_void_p(zlim.data_ptr()),
+                                                  ctypes.c_void_p(stream.cuda_stream)))
+
+    def closed_loop_device(self, timeline, com_state, planned_zmp, t0, sim_dt, cycles, disturb_times=(),
+                           disturb_impulse=0.0, violations=None, traj_com=None, traj_zmp=None, foot_size=None,
+                           stream=None):
+        """ccc_zmp_closed_loop_device: `cycles` control cycles of TestLinearMpcZmp.cpp:55-102 for every instance, on the
+        device.  com_state [n,2,2] and planned_zmp [n,2] are updated in place; returns the time after the last cycle."""
+        import torch
+
+        L = self._L
+        L.ccc_zmp_closed_loop_device.restype = ctypes.c_int
+        L.ccc_zmp_closed_loop_device.argtypes = ([ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 8
+                                                 + [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_void_p, ctypes.c_double] + [ctypes.c_void_p] * 7)
+        n, K, p = self._timeline_args(timeline)
+        N = self.horizon_steps_
+        dev = com_state.device
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        wx0 = torch.empty((n, 2, 3), dtype=torch.float64, device=dev)
+        wz = torch.empty((n, 2, 2, N), dtype=torch.float64, device=dev)
+        fs = (ctypes.c_double * 2)(*foot_size) if foot_size is not None else None
+        dts = (ctypes.c_double * max(1, len(disturb_times)))(*disturb_times)
+        t_end = ctypes.c_double(0.0)
+
+        def q(t):
+            return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+        _lib.check(L.ccc_zmp_closed_loop_device(self._h, n, K, *p, fs, q(com_state), q(planned_zmp), float(t0),
+                                                float(sim_dt), int(cycles), len(disturb_times), dts,
+                                                float(disturb_impulse), q(wx0), q(wz), q(violations), q(traj_com),
+                                                q(traj_zmp), ctypes.byref(t_end), ctypes.c_void_p(stream.cuda_stream)))
+        self._keep = (wx0, wz)  # the launches are asynchronous: keep the workspaces alive
+        return t_end.value

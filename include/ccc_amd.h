@@ -80,6 +80,44 @@ int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double * x0, const
 int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, const double * zlim, double control_dt,
                        double * zmp, double * jerk, int32_t * status);
 
+/* --------------------------------------------------------------------------------------------
+ * The steps either side of LinearMpcZmp::planOnce, on the device.
+ * A footstep timeline per instance replaces the reference test's FootstepManager
+ * (/root/reference/tests/src/FootstepManager.h:130-254): feet start at foot0; footstep j moves foot foot_id[j]
+ * (0 = left, 1 = right) to foot_pos[j]; the foot is off the ground during [swing_start[j], swing_end[j]) and sits at the
+ * new position from swing_end[j] on; ZMP limits = support region of the feet on the ground -+ half the foot size.
+ *   foot0 [n][2][2], foot_pos [n][K][2], foot_id [n][K] i32, swing_start / swing_end [n][K], foot_size [2] HOST
+ *   (NULL: (0.1, 0.05), FootstepManager.h:464).  All other pointers DEVICE.
+ * -------------------------------------------------------------------------------------------- */
+/* com_height / horizon_dt the handle was created with (either may be NULL). */
+int ccc_zmp_get_model(const ccc_zmp_t * h, double * com_height, double * horizon_dt);
+
+/* zlim [n][2][2][N] <- what N calls of FootstepManager::makeLinearMpcZmpRefData(t + i*horizon_dt) return
+ * (src/LinearMpcZmp.cpp:86-98, FootstepManager.h:356-365 incl. both +1e-6), t = t_eval[k] (DEVICE array) or t_common
+ * when t_eval is NULL.  Bit-identical to the host fixture (fixtures.zmp_limits_timeline). */
+int ccc_zmp_sample_limits_device(ccc_zmp_t * h, int64_t n, int K, const double * foot0, const double * foot_pos,
+                                 const int32_t * foot_id, const double * swing_start, const double * swing_end,
+                                 const double * foot_size, const double * t_eval, double t_common, double * zlim,
+                                 void * stream);
+
+/* `cycles` control cycles of /root/reference/tests/src/TestLinearMpcZmp.cpp:55-102 for n instances at once, without
+ * leaving the device: sample the limits at t, planOnce(control_dt = sim_dt), ComZmpSim2d::update(planned_zmp)
+ * (SimModels.h:76-137, exact ZOH), t += sim_dt, add disturb_impulse to both axes' velocity when a disturb_times[d]
+ * falls into [t, t + sim_dt) (SimModels.h:125-129 adds impulse.x() to both axes; disturb_times is a HOST array).
+ *   com_state    [n][2 axes][2]  in/out  (position, velocity)
+ *   planned_zmp  [n][2]          in/out  (in: the ZMP of the previous cycle, used for the first InitialParam, :52,69)
+ *   work_x0 [n][2][3], work_zlim [n][2][2][N]   workspaces
+ *   violations   [n] i32  optional, incremented for every cycle whose planned ZMP is outside zmpLimits(t) (:86-87)
+ *   traj_com / traj_zmp  [cycles][n][2]  optional: CoM position before, planned ZMP of, every cycle
+ *   t_end        HOST, optional: the time after the last cycle (accumulated like the reference's `t += sim_dt`)
+ * Asynchronous on `stream`. */
+int ccc_zmp_closed_loop_device(ccc_zmp_t * h, int64_t n, int K, const double * foot0, const double * foot_pos,
+                               const int32_t * foot_id, const double * swing_start, const double * swing_end,
+                               const double * foot_size, double * com_state, double * planned_zmp, double t0,
+                               double sim_dt, int cycles, int n_disturb, const double * disturb_times,
+                               double disturb_impulse, double * work_x0, double * work_zlim, int32_t * violations,
+                               double * traj_com, double * traj_zmp, double * t_end, void * stream);
+
 /* =========================================================================================
  * CCC::DdpCentroidal          /root/reference/include/CCC/DdpCentroidal.h:13-366
  * CCC::DdpSingleRigidBody     /root/reference/include/CCC/DdpSingleRigidBody.h
