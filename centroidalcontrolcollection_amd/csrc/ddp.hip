@@ -33,7 +33,7 @@ struct DdpBatch
 };
 
 template<int S, int M>
-__global__ __launch_bounds__(64) void ddp_plan_kernel(ddp::Params P, DdpBatch B, long n)
+__global__ __launch_bounds__(64, 2) void ddp_plan_kernel(ddp::Params P, DdpBatch B, long n)
 {
   __shared__ ddp::Mem<S, M> mem;
   const int N = P.N;

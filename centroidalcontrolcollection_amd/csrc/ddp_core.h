@@ -34,10 +34,58 @@
 #  pragma clang fp contract(off)
 #endif
 
+// Section profiler (development aid, off unless the library is built with -DCCC_DDP_PROF, see scripts/ddp_sections.py):
+// lane 0 accumulates shader-clock cycles per section in LDS; solve() then overwrites the first 16 planned inputs with
+// the totals, so a profiling build returns timings INSTEAD of a plan.
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#  define CCC_PROF_START() long long prof_t_ = (long long)__builtin_readcyclecounter()
+#  define CCC_PROF_RESTART() prof_t_ = (long long)__builtin_readcyclecounter()
+#  define CCC_PROF_ADD(k)                                                                   \
+    do                                                                                      \
+    {                                                                                       \
+      const long long prof_n_ = (long long)__builtin_readcyclecounter();                    \
+      if((threadIdx.x & 63) == 0) mem.prof[k] += (double)(prof_n_ - prof_t_);               \
+      prof_t_ = prof_n_;                                                                    \
+    } while(0)
+#else
+#  define CCC_PROF_START() \
+    do                     \
+    {                      \
+    } while(0)
+#  define CCC_PROF_RESTART() \
+    do                       \
+    {                        \
+    } while(0)
+#  define CCC_PROF_ADD(k) \
+    do                    \
+    {                     \
+    } while(0)
+#endif
+
 namespace ccc_amd
 {
 namespace ddp
 {
+// profiler sections
+enum
+{
+  PR_DERIV = 0,
+  PR_PRODUCTS,
+  PR_BOXQP_VALUE,
+  PR_BOXQP_GRAD,
+  PR_BOXQP_CHOL,
+  PR_BOXQP_SOLVE,
+  PR_BOXQP_LINESEARCH,
+  PR_GAINS,
+  PR_VALUE_UPDATE,
+  PR_ROLLOUT,
+  PR_OTHER,
+  PR_BOXQP_CALLS,
+  PR_BOXQP_ITERS,
+  PR_BOXQP_CHOLS,
+  PR_ROLLOUTS,
+  PR_TOTAL
+};
 constexpr int kWave = 64;
 constexpr int kMaxSteps = 128; // horizon steps the per-instance LDS tables are sized for
 constexpr int kMaxPhases = 4;  // contact phases per instance
@@ -99,6 +147,9 @@ struct Mem
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
   double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
   double sc[16]; // uniform scalars
+#if defined(CCC_DDP_PROF)
+  double prof[16];
+#endif
   int clamped[M], oldc[M];
   int ic[8]; // uniform ints
   // per-instance problem tables, staged once per solve (every model evaluation reads them)
@@ -201,6 +252,17 @@ CCC_DDP_FN void llt3_solve(const double * I, const double * b, double * x)
   x[1] = (y1 - l21 * x[2]) / l11;
   x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// value held by lane k of the wavefront, k uniform: two v_readlane_b32 into an SGPR pair (no LDS crossbar round trip,
+// which is what __shfl costs even for a constant lane)
+CCC_DDP_FN double lane_value(double v, int k)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+#endif
 
 template<int S, int M>
 struct Solver
@@ -527,11 +589,19 @@ struct Solver
         }
       });
     };
+    CCC_PROF_START();
     value_of(mem.kq, SC_VALUE);
+    CCC_PROF_ADD(PR_BOXQP_VALUE);
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if((threadIdx.x & 63) == 0) mem.prof[PR_BOXQP_CALLS] += 1.0;
+#endif
     int iter;
     for(iter = 1; iter <= max_iter; iter++)
     {
       if(mem.ic[IC_RESULT] != 0) break;
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+      if((threadIdx.x & 63) == 0) mem.prof[PR_BOXQP_ITERS] += 1.0;
+#endif
       if(iter > 1 && (mem.sc[SC_OLDVALUE] - mem.sc[SC_VALUE]) < min_rel_improve * fabs(mem.sc[SC_OLDVALUE]))
       {
         phase([&](int lane) {
@@ -564,9 +634,13 @@ struct Solver
           if(all) mem.ic[IC_RESULT] = 6;
         }
       });
+      CCC_PROF_ADD(PR_BOXQP_GRAD);
       if(mem.ic[IC_ALLCL]) break;
       if(mem.ic[IC_CHANGED])
       {
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        if((threadIdx.x & 63) == 0) mem.prof[PR_BOXQP_CHOLS] += 1.0;
+#endif
         if(!cholesky_free(m))
         {
           phase([&](int lane) {
@@ -575,6 +649,7 @@ struct Solver
           break;
         }
       }
+      CCC_PROF_ADD(PR_BOXQP_CHOL);
       phase([&](int lane) {
         if(lane == 0)
         {
@@ -594,8 +669,10 @@ struct Solver
           mem.tmp[lane] = mem.clamped[lane] ? 0.0 : s;
         }
       });
+      CCC_PROF_ADD(PR_BOXQP_GRAD);
       if(mem.ic[IC_RESULT] != 0) break;
       solve_free(m, mem.tmp); // tmp <- H_ff^-1 tmp on the free rows
+      CCC_PROF_ADD(PR_BOXQP_SOLVE);
       phase([&](int lane) {
         if(lane < m) mem.srch[lane] = mem.clamped[lane] ? 0.0 : -mem.tmp[lane] - mem.kq[lane];
       });
@@ -632,6 +709,7 @@ struct Solver
         if(lane < m) mem.kq[lane] = mem.xcand[lane];
         if(lane == 0) mem.sc[SC_VALUE] = mem.sc[SC_VC];
       });
+      CCC_PROF_ADD(PR_BOXQP_LINESEARCH);
     }
     int result = mem.ic[IC_RESULT];
     if(iter > max_iter && result == 0) result = 1;
@@ -648,54 +726,10 @@ struct Solver
   {
     const double * H = mem.QuuF;
 #if defined(__HIP_DEVICE_COMPILE__)
-    phase([&](int lane) {
-      const int i = lane & 15;
-      double a[16];
-#  pragma unroll
-      for(int k = 0; k < 16; ++k)
-      {
-        const bool in = (i < m) && (k < m);
-        const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
-        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * m + k]) : (i == k ? 1.0 : 0.0);
-      }
-      bool ok = true;
-      double rdi = 1.0;
-#  pragma unroll
-      for(int j = 0; j < 16; ++j)
-      {
-        if(j < m)
-        {
-          const double d = __shfl(a[j], j);
-          ok = ok && (d > 0.0);
-          const double sq = sqrt(d);
-          const double r = 1.0 / sq;
-          if(i == j)
-          {
-            a[j] = sq;
-            rdi = r;
-          }
-          else if(i > j)
-            a[j] = a[j] * r;
-#  pragma unroll
-          for(int k = j + 1; k < 16; ++k)
-          {
-            if(k < m)
-            {
-              const double lkj = __shfl(a[j], k);
-              if(i >= k) a[k] -= a[j] * lkj;
-            }
-          }
-        }
-      }
-      if(lane < m)
-      {
-#  pragma unroll
-        for(int k = 0; k < 16; ++k)
-          if(k <= i) mem.Lf[i * m + k] = a[k];
-        mem.rd[i] = rdi;
-      }
-      if(lane == 0) mem.ic[IC_OK] = ok ? 1 : 0;
-    });
+    if(m == 16)
+      cholesky_phase<16>(m);
+    else
+      cholesky_phase<0>(m);
     return mem.ic[IC_OK] != 0;
 #else
     bool ok = true;
@@ -722,10 +756,71 @@ struct Solver
 #endif
   }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // MM = 16: every step has the full 16 ridges (the usual case) -- all size tests fold away and the factorisation is
+  // straight-line code; MM = 0: size m at run time.
+  template<int MM>
+  CCC_DDP_FN void cholesky_phase(int m_rt)
+  {
+    const double * H = mem.QuuF;
+    const int m = MM ? MM : m_rt;
+    phase([&](int lane) {
+      const int i = lane & 15;
+      double a[16];
+#  pragma unroll
+      for(int k = 0; k < 16; ++k)
+      {
+        const bool in = (i < m) && (k < m);
+        const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
+        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * m + k]) : (i == k ? 1.0 : 0.0);
+      }
+      bool ok = true;
+      double rdi = 1.0;
+#  pragma unroll
+      for(int j = 0; j < 16; ++j)
+      {
+        if(j < m)
+        {
+          const double d = lane_value(a[j], j);
+          ok = ok && (d > 0.0);
+          const double sq = sqrt(d);
+          const double r = 1.0 / sq;
+          if(i == j)
+          {
+            a[j] = sq;
+            rdi = r;
+          }
+          else if(i > j)
+            a[j] = a[j] * r;
+#  pragma unroll
+          for(int k = j + 1; k < 16; ++k)
+          {
+            if(k < m)
+            {
+              const double lkj = lane_value(a[j], k);
+              if(i >= k) a[k] -= a[j] * lkj;
+            }
+          }
+        }
+      }
+      if(lane < m)
+      {
+#  pragma unroll
+        for(int k = 0; k < 16; ++k)
+          if(k <= i) mem.Lf[i * m + k] = a[k];
+        mem.rd[i] = rdi;
+      }
+      if(lane == 0) mem.ic[IC_OK] = ok ? 1 : 0;
+    });
+  }
+#endif
+
   // registers of lane i for the triangular solves: row i of L left of the diagonal, column i below it
 #if defined(__HIP_DEVICE_COMPILE__)
-  CCC_DDP_FN void load_factor_lane(int m, int i, double (&lr)[16], double (&lc)[16], double & rdi) const
+  template<int MM>
+  CCC_DDP_FN void load_factor_lane(int m_rt, int i, double (&lr)[16], double (&lc)[16], double & rdi) const
   {
+    const int m = MM ? MM : m_rt;
 #  pragma unroll
     for(int k = 0; k < 16; ++k)
     {
@@ -735,15 +830,16 @@ struct Solver
     rdi = (i < m) ? mem.rd[i] : 1.0;
   }
   // acc <- (L L')^-1 acc inside a 16-lane group (WIDTH = 16) or with every group redundant (WIDTH = 64)
-  template<int WIDTH>
-  static CCC_DDP_FN double solve_lane(int m, int i, double acc, const double (&lr)[16], const double (&lc)[16], double rdi)
+  template<int WIDTH, int MM>
+  static CCC_DDP_FN double solve_lane(int m_rt, int i, double acc, const double (&lr)[16], const double (&lc)[16], double rdi)
   {
+    const int m = MM ? MM : m_rt;
 #  pragma unroll
     for(int k = 0; k < 16; ++k)
     {
       if(k < m)
       {
-        const double yk = __shfl(acc * rdi, k, WIDTH);
+        const double yk = (WIDTH == 64) ? lane_value(acc * rdi, k) : __shfl(acc * rdi, k, WIDTH);
         if(i == k)
           acc = yk;
         else if(i > k)
@@ -755,7 +851,7 @@ struct Solver
     {
       if(k < m)
       {
-        const double zk = __shfl(acc * rdi, k, WIDTH);
+        const double zk = (WIDTH == 64) ? lane_value(acc * rdi, k) : __shfl(acc * rdi, k, WIDTH);
         if(i == k)
           acc = zk;
         else if(i < k)
@@ -771,13 +867,10 @@ struct Solver
   CCC_DDP_FN void solve_free(int m, double * v)
   {
 #if defined(__HIP_DEVICE_COMPILE__)
-    phase([&](int lane) {
-      const int i = lane & 15;
-      double lr[16], lc[16], rdi;
-      load_factor_lane(m, i, lr, lc, rdi);
-      const double acc = solve_lane<64>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi);
-      if(lane < m) v[i] = acc;
-    });
+    if(m == 16)
+      solve_free_phase<16>(m, v);
+    else
+      solve_free_phase<0>(m, v);
 #else
     for(int a = 0; a < m; a++)
     {
@@ -794,15 +887,28 @@ struct Solver
 #endif
   }
 
-  // K_f = -H_ff^-1 Qxur_f' (clamped rows of K stay zero), k <- kq.  Device: the four 16-lane groups of the
-  // wavefront each solve one right-hand side (state index) at a time.
-  CCC_DDP_FN void gains(int m)
-  {
 #if defined(__HIP_DEVICE_COMPILE__)
+  template<int MM>
+  CCC_DDP_FN void solve_free_phase(int m_rt, double * v)
+  {
+    const int m = MM ? MM : m_rt;
+    phase([&](int lane) {
+      const int i = lane & 15;
+      double lr[16], lc[16], rdi;
+      load_factor_lane<MM>(m, i, lr, lc, rdi);
+      const double acc = solve_lane<64, MM>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi);
+      if(lane < m) v[i] = acc;
+    });
+  }
+
+  template<int MM>
+  CCC_DDP_FN void gains_phase(int m_rt)
+  {
+    const int m = MM ? MM : m_rt;
     phase([&](int lane) {
       const int i = lane & 15, grp = lane >> 4;
       double lr[16], lc[16], rdi;
-      load_factor_lane(m, i, lr, lc, rdi);
+      load_factor_lane<MM>(m, i, lr, lc, rdi);
       const bool cl = (i < m) && mem.clamped[i];
 #  pragma unroll
       for(int a0 = 0; a0 < S; a0 += 4)
@@ -810,11 +916,23 @@ struct Solver
         const int a = a0 + grp;
         const bool act = a < S;
         double acc = (act && i < m && !cl) ? mem.Qxur[a * M + i] : 0.0;
-        acc = solve_lane<16>(m, i, acc, lr, lc, rdi);
+        acc = solve_lane<16, MM>(m, i, acc, lr, lc, rdi);
         if(act && i < m) mem.K[i * S + a] = cl ? 0.0 : -acc;
       }
       if(lane < m) mem.k[lane] = mem.kq[lane];
     });
+  }
+#endif
+
+  // K_f = -H_ff^-1 Qxur_f' (clamped rows of K stay zero), k <- kq.  Device: the four 16-lane groups of the
+  // wavefront each solve one right-hand side (state index) at a time.
+  CCC_DDP_FN void gains(int m)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if(m == 16)
+      gains_phase<16>(m);
+    else
+      gains_phase<0>(m);
 #else
     for(int a = 0; a < S; a++)
     {
@@ -849,7 +967,9 @@ struct Solver
         if(lane < S) mem.x[lane] = I.xs[static_cast<long>(i) * S + lane];
         if(lane < M) mem.u[lane] = (lane < m) ? I.us[static_cast<long>(i) * M + lane] : 0.0;
       });
+      CCC_PROF_START();
       state_eq_deriv(i);
+      CCC_PROF_ADD(PR_DERIV);
       phase([&](int lane) {
         // Qx = Lx + Fx'Vx ; Qu = Lu + Fu'Vx
         if(lane < S)
@@ -941,12 +1061,16 @@ struct Solver
         }
         for(int e = lane; e < M * S; e += kWave) mem.K[e] = 0.0;
       });
+      CCC_PROF_ADD(PR_PRODUCTS);
       if(m > 0)
       {
         const int rc = box_qp(m);
         if(rc < 1) return false;
+        CCC_PROF_RESTART();
         gains(m);
+        CCC_PROF_ADD(PR_GAINS);
       }
+      CCC_PROF_RESTART();
       phase([&](int lane) {
         // t4 = Quu k ; gains to global memory
         if(lane < m)
@@ -1003,6 +1127,7 @@ struct Solver
           mem.Vxx[e] = 0.5 * (mem.T1[a * S + b] + mem.T1[b * S + a]);
         }
       });
+      CCC_PROF_ADD(PR_VALUE_UPDATE);
     }
     return true;
   }
@@ -1093,7 +1218,13 @@ struct Solver
         mem.sc[SC_LAMBDA] = P.lambda0;
         mem.sc[SC_DLAMBDA] = P.dlambda0;
       }
+#if defined(CCC_DDP_PROF)
+      if(lane < 16) mem.prof[lane] = 0.0;
+#endif
     });
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const long long prof_begin_ = (long long)__builtin_readcyclecounter();
+#endif
     rollout(-1.0);
     int iter = 0, status = 0;
     for(iter = 1; iter <= P.max_iter; iter++)
@@ -1144,7 +1275,14 @@ struct Solver
       for(int a = 0; a < 11; a++)
       {
         const double alpha = P.alpha[a];
-        rollout(alpha);
+        {
+          CCC_PROF_START();
+          rollout(alpha);
+          CCC_PROF_ADD(PR_ROLLOUT);
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+          if((threadIdx.x & 63) == 0) mem.prof[PR_ROLLOUTS] += 1.0;
+#endif
+        }
         actual = mem.sc[SC_COST] - mem.sc[SC_COSTC];
         const double expected = -alpha * (mem.sc[SC_DV0] + alpha * mem.sc[SC_DV1]);
         const double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
@@ -1179,6 +1317,14 @@ struct Solver
       }
     }
     if(iter > P.max_iter) iter = P.max_iter;
+#if defined(CCC_DDP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    phase([&](int lane) {
+      if(lane == 0) mem.prof[PR_TOTAL] = (double)((long long)__builtin_readcyclecounter() - prof_begin_);
+    });
+    phase([&](int lane) {
+      if(lane < 16) I.us[lane] = mem.prof[lane]; // a profiling build returns timings instead of a plan
+    });
+#endif
     phase([&](int lane) {
       if(lane == 0)
       {
