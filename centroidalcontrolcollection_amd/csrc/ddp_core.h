@@ -556,6 +556,158 @@ struct Solver
   // ---- box-QP: min 1/2 k'Hk + g'k, lo <= k <= hi with H = mem.QuuF (m x m, stride m), g = mem.Qu,
   //      warm start in mem.kq; result in mem.kq / mem.clamped / mem.Lf (Cholesky of H with the clamped rows and
   //      columns replaced by identity = the factor of H_ff embedded).  Tassa's boxQP.m; returns result >= 1 on success.
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device box-QP: the whole projected-Newton iteration as ONE phase.  Lane i (mod 16) keeps row i of H, its
+  // entries of g / lo / hi / x / gradient and the clamped flag in registers; every vector entry another lane needs
+  // arrives by v_readlane, every reduction is the oracle's sequential sum run as a readlane chain (same order,
+  // same roundings), and all decisions are taken on values that are identical in every lane, so control flow
+  // stays uniform.  Only the Cholesky factor goes through LDS (cholesky_phase / load_factor_lane, when the clamped
+  // set changes).  Statement by statement the arithmetic is that of the phase version below, which the host
+  // emulation (tests/emu) keeps using.
+  CCC_DDP_FN int box_qp(int m)
+  {
+    return m == 16 ? box_qp_dev<16>(m) : box_qp_dev<0>(m);
+  }
+
+  template<int MM>
+  CCC_DDP_FN int box_qp_dev(int m_rt)
+  {
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    const int max_iter = 100;
+    const int m = MM ? MM : __builtin_amdgcn_readfirstlane(m_rt);
+    const int lane = static_cast<int>(threadIdx.x & 63), i = lane & 15;
+    const bool in = i < m;
+    CCC_PROF_START();
+#if defined(CCC_DDP_PROF)
+    if(lane == 0) mem.prof[PR_BOXQP_CALLS] += 1.0;
+#endif
+    double Hr[16];
+#  pragma unroll
+    for(int k = 0; k < 16; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * m + k] : 0.0;
+    const double gi = in ? mem.Qu[i] : 0.0;
+    const double lo = in ? mem.lo[i] : 0.0, hi = in ? mem.hi[i] : 0.0;
+    double x = in ? fmin(fmax(mem.kq[i], lo), hi) : 0.0;
+    bool cl = false;
+    // sum_{k<m} t_k in increasing k, starting from 0 (the oracle's loops)
+    auto seq_sum = [&](double t) {
+      double v = 0;
+#  pragma unroll
+      for(int k = 0; k < 16; ++k)
+        if(k < m) v += lane_value(t, k);
+      return v;
+    };
+    // s0 + sum_{j<m} H[i][j] y_j in increasing j
+    auto row_dot = [&](double s0, double y) {
+      double s = s0;
+#  pragma unroll
+      for(int j = 0; j < 16; ++j)
+        if(j < m) s += Hr[j] * lane_value(y, j);
+      return s;
+    };
+    auto value_of = [&](double y) {
+      const double s = row_dot(0.0, y);
+      return seq_sum(y * gi + 0.5 * y * s);
+    };
+    double value = value_of(x), oldvalue = 0.0;
+    CCC_PROF_ADD(PR_BOXQP_VALUE);
+    int result = 0, iter;
+    for(iter = 1; iter <= max_iter; iter++)
+    {
+      if(result != 0) break;
+#if defined(CCC_DDP_PROF)
+      if(lane == 0) mem.prof[PR_BOXQP_ITERS] += 1.0;
+#endif
+      if(iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
+      {
+        result = 4;
+        break;
+      }
+      oldvalue = value;
+      const double grad = row_dot(gi, x);
+      const bool oldc = cl;
+      cl = in && ((x == lo && grad > 0) || (x == hi && grad < 0));
+      const unsigned long long inmask = (m >= 16) ? 0xffffull : ((1ull << m) - 1ull);
+      const unsigned long long clmask = __ballot(cl) & inmask;
+      const bool changed = (iter == 1) || ((__ballot(cl != oldc) & inmask) != 0ull);
+      CCC_PROF_ADD(PR_BOXQP_GRAD);
+      if(clmask == inmask)
+      {
+        result = 6;
+        break;
+      }
+      if(changed)
+      {
+#if defined(CCC_DDP_PROF)
+        if(lane == 0) mem.prof[PR_BOXQP_CHOLS] += 1.0;
+#endif
+        __syncthreads();
+        if(lane < m) mem.clamped[lane] = cl ? 1 : 0;
+        __syncthreads();
+        cholesky_phase<MM>(m);
+        if(mem.ic[IC_OK] == 0)
+        {
+          result = -1;
+          break;
+        }
+        CCC_PROF_ADD(PR_BOXQP_CHOL);
+      }
+      double gn = 0;
+      {
+        const double g2 = grad * grad;
+#  pragma unroll
+        for(int k = 0; k < 16; ++k)
+          if(k < m && !((clmask >> k) & 1ull)) gn += lane_value(g2, k);
+      }
+      gn = sqrt(gn);
+      if(gn < min_grad) result = 5;
+      // grad_clamped = g + H (x .* clamped) on the free rows
+      double gc = gi;
+#  pragma unroll
+      for(int j = 0; j < 16; ++j)
+        if(j < m && ((clmask >> j) & 1ull)) gc += Hr[j] * lane_value(x, j);
+      CCC_PROF_ADD(PR_BOXQP_GRAD);
+      if(result != 0) break;
+      double sol;
+      {
+        // the factor is re-read from LDS for every solve: keeping its 32 entries live across the factorisation would
+        // not fit the register budget of two waves per SIMD
+        double lr[16], lc[16], rdi;
+        load_factor_lane<MM>(m, i, lr, lc, rdi);
+        sol = solve_lane<64, MM>(m, i, (in && !cl) ? gc : 0.0, lr, lc, rdi);
+      }
+      const double srch = (in && !cl) ? -sol - x : 0.0;
+      const double sdotg = seq_sum(srch * grad);
+      CCC_PROF_ADD(PR_BOXQP_SOLVE);
+      double step = 1.0;
+      if(sdotg >= 0) break; // no descent direction: result stays 0
+      double xc, vc;
+      for(;;)
+      {
+        xc = in ? fmin(fmax(x + step * srch, lo), hi) : 0.0;
+        vc = value_of(xc);
+        if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
+        step *= step_dec;
+        if(step < min_step)
+        {
+          result = 2;
+          break;
+        }
+      }
+      x = xc;
+      value = vc;
+      CCC_PROF_ADD(PR_BOXQP_LINESEARCH);
+    }
+    __syncthreads();
+    if(lane < m)
+    {
+      mem.kq[lane] = x;
+      mem.clamped[lane] = cl ? 1 : 0;
+    }
+    __syncthreads();
+    if(iter > max_iter && result == 0) result = 1;
+    return result;
+  }
+#else
   CCC_DDP_FN int box_qp(int m)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
@@ -715,6 +867,7 @@ struct Solver
     if(iter > max_iter && result == 0) result = 1;
     return result;
   }
+#endif
 
   // Cholesky of H~ (H = mem.QuuF with the clamped rows/columns replaced by identity, i.e. the factor of H_ff
   // embedded) into mem.Lf (lower, stride m) + reciprocal diagonal mem.rd.  Arithmetic per entry exactly as the
