@@ -1286,8 +1286,160 @@ struct Solver
   }
 
   // ---- rollout of the initial inputs / line-search candidate.  alpha < 0: plain rollout of I.us into I.xs.
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device rollout for the centroidal model (S = 9): ONE phase for the whole trajectory.  Lane a keeps state entry a,
+  // lane r the input of ridge r; the feedback, the dynamics and the cost reach across lanes with v_readlane in the
+  // oracle's summation order (no LDS staging, no barriers per step), and the gains / nominal trajectory of the next
+  // step are fetched from HBM while the current step computes.  Statement by statement the arithmetic is that of the
+  // phase version below (state_eq, running_cost, terminal_cost), which the host emulation keeps using.
+  CCC_DDP_FN void rollout_centroidal(double alpha)
+  {
+    const int N = P.N;
+    const bool initial = alpha < 0;
+    double * xo = initial ? I.xs : I.xc;
+    double * uo = initial ? I.us : I.uc;
+    const int lane = static_cast<int>(threadIdx.x & 63);
+    const bool st = lane < S;
+    double x = st ? (initial ? I.x0[lane] : I.xs[lane]) : 0.0;
+    if(st) xo[lane] = x;
+    const double wr = st ? P.w_run[lane < S ? lane : 0] : 0.0, wt = st ? P.w_term[lane < S ? lane : 0] : 0.0;
+    double cost = 0.0; // accumulated by lane kCostLane only
+    constexpr int kCostLane = 9, kTermLane = 10;
+    // per-step staging of the products whose ordered sums the dynamics and the cost need: rows 0-2 u_r rho_r,
+    // 3-5 u_r (p_r - c) x rho_r, 6 u_r^2 (columns = ridges), row 7 the state-cost terms.  The block of backward-pass
+    // matrices Qxx .. of Mem is idle during a rollout.
+    double * const pr = mem.Qxx;
+    static_assert(8 * 16 <= 2 * S * S + 3 * S * M, "staging area too small");
+    // operands of step 0 (the next step's are fetched from HBM while the current one computes)
+    double us_c = 0.0, ks_c = 0.0, Kr_c[S], xi_c[S], ref_c = 0.0;
+    auto fetch = [&](int i, double & us_v, double & ks_v, double (&Kr_v)[S], double (&xi_v)[S], double & ref_v) {
+      const int ln = lane < M ? lane : 0;
+      if(initial)
+        us_v = I.u_init ? I.u_init[static_cast<long>(i) * M + ln] : 0.0;
+      else
+      {
+        us_v = I.us[static_cast<long>(i) * M + ln];
+        ks_v = I.ks[static_cast<long>(i) * M + ln];
+        const double * Kr = I.Ks + (static_cast<long>(i) * M + ln) * S;
+        const double * xi = I.xs + static_cast<long>(i) * S;
+#  pragma unroll
+        for(int a = 0; a < S; a++)
+        {
+          Kr_v[a] = Kr[a];
+          xi_v[a] = xi[a];
+        }
+      }
+      ref_v = (lane < 3) ? I.ref_pos[static_cast<long>(i) * 3 + lane] : 0.0;
+    };
+#  pragma unroll
+    for(int a = 0; a < S; a++) Kr_c[a] = xi_c[a] = 0.0;
+    fetch(0, us_c, ks_c, Kr_c, xi_c, ref_c);
+    // which ordered sum this lane owns: lanes 3-8 the six force / moment sums, kCostLane sum u^2, kTermLane the state cost
+    const int myrow = (lane >= 3 && lane < 9) ? lane - 3 : (lane == kCostLane ? 6 : 7);
+    const bool sums = (lane >= 3 && lane <= kTermLane);
+    for(int i = 0; i < N; i++)
+    {
+      double us_n = 0.0, ks_n = 0.0, Kr_n[S], xi_n[S], ref_n = 0.0;
+#  pragma unroll
+      for(int a = 0; a < S; a++) Kr_n[a] = xi_n[a] = 0.0;
+      if(i + 1 < N)
+        fetch(i + 1, us_n, ks_n, Kr_n, xi_n, ref_n);
+      else
+        ref_n = (lane < 3) ? I.ref_pos[static_cast<long>(N) * 3 + lane] : 0.0; // terminal reference
+      const int m = __builtin_amdgcn_readfirstlane(dim_of(i));
+      const double * V = vert_of(i);
+      const double * R = ridge_of(i);
+      double xa[S];
+#  pragma unroll
+      for(int a = 0; a < S; a++) xa[a] = lane_value(x, a);
+      // input of ridge `lane`
+      double u = 0.0;
+      if(lane < m)
+      {
+        if(initial)
+          u = us_c;
+        else
+        {
+          double s = us_c + alpha * ks_c;
+#  pragma unroll
+          for(int a = 0; a < S; a++) s += Kr_c[a] * (xa[a] - xi_c[a]);
+          u = fmin(fmax(s, P.flo), P.fhi);
+        }
+      }
+      if(lane < M) uo[static_cast<long>(i) * M + lane] = u;
+      // dynamics, src/DdpCentroidal.cpp:32-64: lane r forms the products of its own ridge, lane a its state-cost term;
+      // after one LDS round trip lanes 3-10 each add up one row in increasing index -- the oracle's order
+      __syncthreads();
+      if(lane < m)
+      {
+        const double rr[3] = {R[lane * 3], R[lane * 3 + 1], R[lane * 3 + 2]};
+        const double d[3] = {V[lane * 3] - xa[0], V[lane * 3 + 1] - xa[1], V[lane * 3 + 2] - xa[2]};
+        double c[3];
+        cross3(d, rr, c);
+#  pragma unroll
+        for(int k = 0; k < 3; k++)
+        {
+          pr[k * 16 + lane] = u * rr[k];
+          pr[(3 + k) * 16 + lane] = u * c[k];
+        }
+        pr[6 * 16 + lane] = u * u;
+      }
+      if(st)
+      {
+        const double e = x - ref_c;
+        pr[7 * 16 + lane] = 0.5 * wr * e * e;
+      }
+      __syncthreads();
+      double acc = (lane == 5) ? -1 * P.mass * kGravity : 0.0;
+      if(sums)
+      {
+        const int cnt = (lane == kTermLane) ? S : m;
+        const double * row = pr + myrow * 16;
+        for(int r = 0; r < cnt; r++) acc += row[r];
+      }
+      const double cterm = lane_value(acc, kTermLane);
+      if(lane == kCostLane) cost += cterm + 0.5 * P.w_force * acc;
+      double xd = 0.0;
+      if(lane < 3)
+        xd = (lane == 0 ? xa[3] : (lane == 1 ? xa[4] : xa[5])) / P.mass;
+      else if(lane < 9)
+        xd = acc;
+      x = x + P.dt * xd;
+      if(st) xo[static_cast<long>(i + 1) * S + lane] = x;
+      us_c = us_n;
+      ks_c = ks_n;
+      ref_c = ref_n;
+#  pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        Kr_c[a] = Kr_n[a];
+        xi_c[a] = xi_n[a];
+      }
+    }
+    {
+      const double e = x - ref_c;
+      const double term = 0.5 * wt * e * e;
+      double c = 0;
+#  pragma unroll
+      for(int a = 0; a < S; a++) c += lane_value(term, a);
+      if(lane == kCostLane) cost += c;
+    }
+    __syncthreads();
+    if(st) mem.x[lane] = x;
+    if(lane == kCostLane) mem.sc[initial ? SC_COST : SC_COSTC] = cost;
+    __syncthreads();
+  }
+#endif
+
   CCC_DDP_FN void rollout(double alpha)
   {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr(S == 9)
+    {
+      rollout_centroidal(alpha);
+      return;
+    }
+#endif
     const int N = P.N;
     const bool initial = alpha < 0;
     double * xo = initial ? I.xs : I.xc;
