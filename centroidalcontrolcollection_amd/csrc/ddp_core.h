@@ -1115,6 +1115,20 @@ struct Solver
     for(int i = N - 1; i >= 0; i--)
     {
       const int m = dim_of(i);
+      // the usual case of a full 16-ridge contact gets its own instantiation: index arithmetic by constants, loops the
+      // compiler can unroll (same statements, same results)
+      const bool ok = (m == M) ? backward_step<M>(i, m) : backward_step<0>(i, m);
+      if(!ok) return false;
+    }
+    return true;
+  }
+
+  template<int MM>
+  CCC_DDP_FN bool backward_step(int i, int m_rt)
+  {
+    const int N = P.N;
+    {
+      const int m = MM ? MM : m_rt;
       const double lambda = mem.sc[SC_LAMBDA];
       phase([&](int lane) {
         if(lane < S) mem.x[lane] = I.xs[static_cast<long>(i) * S + lane];
