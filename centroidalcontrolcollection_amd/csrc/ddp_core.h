@@ -1054,23 +1054,47 @@ struct Solver
     });
   }
 
+  // Device gains: lane a (< S) runs the two triangular solves of ITS right-hand side (state index a) start to finish
+  // with the factor read from LDS (every lane reads the same entry: a broadcast) -- the host statement order, no
+  // cross-lane traffic and therefore no LDS-crossbar latency inside the 2 x 16-step recurrences.
   template<int MM>
   CCC_DDP_FN void gains_phase(int m_rt)
   {
     const int m = MM ? MM : m_rt;
     phase([&](int lane) {
-      const int i = lane & 15, grp = lane >> 4;
-      double lr[16], lc[16], rdi;
-      load_factor_lane<MM>(m, i, lr, lc, rdi);
-      const bool cl = (i < m) && mem.clamped[i];
-#  pragma unroll
-      for(int a0 = 0; a0 < S; a0 += 4)
+      if(lane < S)
       {
-        const int a = a0 + grp;
-        const bool act = a < S;
-        double acc = (act && i < m && !cl) ? mem.Qxur[a * M + i] : 0.0;
-        acc = solve_lane<16, MM>(m, i, acc, lr, lc, rdi);
-        if(act && i < m) mem.K[i * S + a] = cl ? 0.0 : -acc;
+        const int a = lane;
+        double t3[M];
+#  pragma unroll
+        for(int f = 0; f < M; f++) t3[f] = (f < m && !mem.clamped[f]) ? mem.Qxur[a * M + f] : 0.0;
+#  pragma unroll
+        for(int r = 0; r < M; r++)
+        {
+          if(r < m)
+          {
+            double sum = t3[r];
+#  pragma unroll
+            for(int k = 0; k < M; k++)
+              if(k < r) sum -= mem.Lf[r * m + k] * t3[k];
+            t3[r] = sum * mem.rd[r];
+          }
+        }
+#  pragma unroll
+        for(int r = M - 1; r >= 0; r--)
+        {
+          if(r < m)
+          {
+            double sum = t3[r];
+#  pragma unroll
+            for(int k = M - 1; k >= 0; k--)
+              if(k > r && k < m) sum -= mem.Lf[k * m + r] * t3[k];
+            t3[r] = sum * mem.rd[r];
+          }
+        }
+#  pragma unroll
+        for(int f = 0; f < M; f++)
+          if(f < m) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
       }
       if(lane < m) mem.k[lane] = mem.kq[lane];
     });
