@@ -1122,6 +1122,40 @@ struct Solver
 #endif
   }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device matrix product with one OUTPUT COLUMN per lane: lane (g, c) = (lane / 16, lane % 16) keeps column c of the
+  // right factor in registers and produces C(a, c) for the rows a = g, g + 4, ..; the left factor's entries are read
+  // from LDS as broadcasts (one address per 16-lane group).  The element-per-lane loops of the phase version read two
+  // LDS operands per multiply-add and are bound by LDS bandwidth (8 wavefronts per CU); this form reads half as many
+  // words, almost all of them broadcasts.  Sums run over k = 0 .. S-1 in increasing order from the same start value:
+  // identical results.   C(a,c) = [DIAG] + sum_k Aop(a,k) B(k,c),  Aop = A or A' (TRANS), optionally A + lam I (LAM);
+  //   DIAG 0: none, 1: w_run[a] on a == c, 2: w_force on a == c.
+  template<bool TRANS, int DIAG, bool LAM>
+  CCC_DDP_FN void colprod(int lane, int rows, int ncols, const double * A, int lda, const double * B, int ldb, double lam,
+                          double * C, int ldc) const
+  {
+    const int c = lane & 15, g = lane >> 4;
+    const bool act = c < ncols;
+    double Bc[S];
+#  pragma unroll
+    for(int k = 0; k < S; k++) Bc[k] = act ? B[k * ldb + c] : 0.0;
+    for(int a = g; a < rows; a += 4)
+    {
+      double sum = 0.0;
+      if(DIAG == 1) sum = (a == c) ? P.w_run[a] : 0.0;
+      if(DIAG == 2) sum = (a == c) ? P.w_force : 0.0;
+#  pragma unroll
+      for(int k = 0; k < S; k++)
+      {
+        double av = TRANS ? A[k * lda + a] : A[a * lda + k];
+        if(LAM) av = av + (a == k ? lam : 0.0);
+        sum += av * Bc[k];
+      }
+      if(act) C[a * ldc + c] = sum;
+    }
+  }
+#endif
+
   // ---- backward pass (oracle/ddp.c backward_pass); returns false when a box-QP / Cholesky fails
   CCC_DDP_FN bool backward_pass()
   {
@@ -1177,6 +1211,10 @@ struct Solver
           mem.Qu[r] = s;
         }
         // T1 = Vxx Fx ; T2 = Vxx Fu
+#if defined(__HIP_DEVICE_COMPILE__)
+        colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
+        colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
+#else
         for(int e = lane; e < S * S; e += kWave)
         {
           const int a = e / S, b = e % S;
@@ -1191,9 +1229,15 @@ struct Solver
           for(int k = 0; k < S; k++) s += mem.Vxx[a * S + k] * mem.Fu[k * M + r];
           mem.T2[a * M + r] = s;
         }
+#endif
       });
       phase([&](int lane) {
         // Qxx = Lxx + Fx'T1 ; Qxu = Fx'T2 ; Quu = Luu + Fu'T2   (Lxu = 0, Lxx = diag(w_run), Luu = w_force I)
+#if defined(__HIP_DEVICE_COMPILE__)
+        colprod<true, 1, false>(lane, S, S, mem.Fx, S, mem.T1, S, 0.0, mem.Qxx, S);
+        colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxu, M);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.Quu, m);
+#else
         for(int e = lane; e < S * S; e += kWave)
         {
           const int a = e / S, b = e % S;
@@ -1215,9 +1259,13 @@ struct Solver
           for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
           mem.Quu[e] = s;
         }
+#endif
       });
       phase([&](int lane) {
         // regularised: T2 = (Vxx + lambda I) Fu
+#if defined(__HIP_DEVICE_COMPILE__)
+        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda, mem.T2, M);
+#else
         for(int e = lane; e < S * m; e += kWave)
         {
           const int a = e / m, r = e % m;
@@ -1225,8 +1273,13 @@ struct Solver
           for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda : 0.0)) * mem.Fu[k * M + r];
           mem.T2[a * M + r] = s;
         }
+#endif
       });
       phase([&](int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxur, M);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.QuuF, m);
+#else
         for(int e = lane; e < S * m; e += kWave)
         {
           const int a = e / m, r = e % m;
@@ -1241,6 +1294,7 @@ struct Solver
           for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
           mem.QuuF[e] = s;
         }
+#endif
         // box limits on the input CHANGE and the warm start (gain of step i+1 of this pass, zeros on a dim change)
         if(lane < M)
         {
