@@ -1170,27 +1170,57 @@ struct Solver
         mem.sc[SC_DV1] = 0.0;
       }
     });
+    StepRegs sr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    fetch_step(N - 1, static_cast<int>(threadIdx.x & 63), sr);
+#endif
     for(int i = N - 1; i >= 0; i--)
     {
       const int m = dim_of(i);
       // the usual case of a full 16-ridge contact gets its own instantiation: index arithmetic by constants, loops the
       // compiler can unroll (same statements, same results)
-      const bool ok = (m == M) ? backward_step<M>(i, m) : backward_step<0>(i, m);
+      const bool ok = (m == M) ? backward_step<M>(i, m, sr) : backward_step<0>(i, m, sr);
       if(!ok) return false;
     }
     return true;
   }
 
+  // Device: the per-step operands that live in HBM (nominal x_i, u_i, the reference entry and the feed-forward term
+  // of step i+1 used as box-QP warm start) are carried in registers -- x/u/ref of step i-1 are requested while step i
+  // computes, k of step i+1 is simply kept -- so that no backward step starts with an HBM round trip.
+  struct StepRegs
+  {
+    double x = 0, u = 0, ref = 0, kprev = 0;
+  };
+  CCC_DDP_FN void fetch_step(int i, int lane, StepRegs & r) const
+  {
+    r.x = (lane < S) ? I.xs[static_cast<long>(i) * S + lane] : 0.0;
+    r.u = (lane < M) ? I.us[static_cast<long>(i) * M + lane] : 0.0;
+    r.ref = (lane < S) ? ref_entry(i, lane) : 0.0;
+  }
+
   template<int MM>
-  CCC_DDP_FN bool backward_step(int i, int m_rt)
+  CCC_DDP_FN bool backward_step(int i, int m_rt, StepRegs & sr)
   {
     const int N = P.N;
     {
       const int m = MM ? MM : m_rt;
       const double lambda = mem.sc[SC_LAMBDA];
+#if defined(__HIP_DEVICE_COMPILE__)
+      const StepRegs cur = sr;
+      {
+        const int lane = static_cast<int>(threadIdx.x & 63);
+        if(i > 0) fetch_step(i - 1, lane, sr); // sr.kprev is set further down
+      }
+#endif
       phase([&](int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if(lane < S) mem.x[lane] = cur.x;
+        if(lane < M) mem.u[lane] = (lane < m) ? cur.u : 0.0;
+#else
         if(lane < S) mem.x[lane] = I.xs[static_cast<long>(i) * S + lane];
         if(lane < M) mem.u[lane] = (lane < m) ? I.us[static_cast<long>(i) * M + lane] : 0.0;
+#endif
       });
       CCC_PROF_START();
       state_eq_deriv(i);
@@ -1199,7 +1229,11 @@ struct Solver
         // Qx = Lx + Fx'Vx ; Qu = Lu + Fu'Vx
         if(lane < S)
         {
+#if defined(__HIP_DEVICE_COMPILE__)
+          double s = P.w_run[lane] * (mem.x[lane] - cur.ref);
+#else
           double s = P.w_run[lane] * (mem.x[lane] - ref_entry(i, lane));
+#endif
           for(int b = 0; b < S; b++) s += mem.Fx[b * S + lane] * mem.Vx[b];
           mem.Qx[lane] = s;
         }
@@ -1301,7 +1335,11 @@ struct Solver
           mem.lo[lane] = P.flo - mem.u[lane];
           mem.hi[lane] = P.fhi - mem.u[lane];
           const bool warm = (i + 1 < N) && (dim_of(i + 1) == m);
+#if defined(__HIP_DEVICE_COMPILE__)
+          mem.kq[lane] = (warm && lane < m) ? cur.kprev : 0.0;
+#else
           mem.kq[lane] = (warm && lane < m) ? I.ks[static_cast<long>(i + 1) * M + lane] : 0.0;
+#endif
           mem.k[lane] = 0.0;
         }
         for(int e = lane; e < M * S; e += kWave) mem.K[e] = 0.0;
@@ -1324,7 +1362,13 @@ struct Solver
           for(int q = 0; q < m; q++) s += mem.Quu[lane * m + q] * mem.k[q];
           mem.t4[lane] = s;
         }
-        if(lane < M) I.ks[static_cast<long>(i) * M + lane] = mem.k[lane];
+        if(lane < M)
+        {
+          I.ks[static_cast<long>(i) * M + lane] = mem.k[lane];
+#if defined(__HIP_DEVICE_COMPILE__)
+          sr.kprev = mem.k[lane];
+#endif
+        }
         for(int e = lane; e < M * S; e += kWave) I.Ks[static_cast<long>(i) * M * S + e] = mem.K[e];
         // T2 (S x m) = K' Quu
         for(int e = lane; e < S * m; e += kWave)
