@@ -1244,11 +1244,21 @@ struct Solver
           for(int b = 0; b < S; b++) s += mem.Fu[b * M + r] * mem.Vx[b];
           mem.Qu[r] = s;
         }
-        // T1 = Vxx Fx ; T2 = Vxx Fu
+        // T1 = Vxx Fx ; T2 = Vxx Fu ; regularised T2r = (Vxx + lambda I) Fu, parked in mem.Lf (free until the box-QP
+        // factorises) so that everything built from T1 / T2 / T2r fits one more phase
+        double * const T2r = mem.Lf;
 #if defined(__HIP_DEVICE_COMPILE__)
         colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
         colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
+        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda, T2r, M);
 #else
+        for(int e = lane; e < S * m; e += kWave)
+        {
+          const int a = e / m, r = e % m;
+          double s = 0;
+          for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda : 0.0)) * mem.Fu[k * M + r];
+          T2r[a * M + r] = s;
+        }
         for(int e = lane; e < S * S; e += kWave)
         {
           const int a = e / S, b = e % S;
@@ -1294,38 +1304,24 @@ struct Solver
           mem.Quu[e] = s;
         }
 #endif
-      });
-      phase([&](int lane) {
-        // regularised: T2 = (Vxx + lambda I) Fu
+        // regularised versions from T2r
+        const double * const T2r = mem.Lf;
 #if defined(__HIP_DEVICE_COMPILE__)
-        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda, mem.T2, M);
-#else
-        for(int e = lane; e < S * m; e += kWave)
-        {
-          const int a = e / m, r = e % m;
-          double s = 0;
-          for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda : 0.0)) * mem.Fu[k * M + r];
-          mem.T2[a * M + r] = s;
-        }
-#endif
-      });
-      phase([&](int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxur, M);
-        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.QuuF, m);
+        colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, T2r, M, 0.0, mem.QuuF, m);
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
           const int a = e / m, r = e % m;
           double s = 0.0;
-          for(int k = 0; k < S; k++) s += mem.Fx[k * S + a] * mem.T2[k * M + r];
+          for(int k = 0; k < S; k++) s += mem.Fx[k * S + a] * T2r[k * M + r];
           mem.Qxur[a * M + r] = s;
         }
         for(int e = lane; e < m * m; e += kWave)
         {
           const int r = e / m, q = e % m;
           double s = (r == q) ? P.w_force : 0.0;
-          for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
+          for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * T2r[k * M + q];
           mem.QuuF[e] = s;
         }
 #endif
