@@ -141,8 +141,8 @@ template<int S, int M>
 struct Mem
 {
   double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
-  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * M], QuuF[M * M];
-  double T1[S * S], T2[S * M], Lf[M * M], K[M * S];
+  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * (M + 1)], QuuF[M * (M + 1)]; // rows padded to M + 1: bank-conflict free
+  double T1[S * S], T2[S * M], Lf[M * (M + 1)], K[M * S];
   double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
   double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
@@ -267,6 +267,8 @@ CCC_DDP_FN double lane_value(double v, int k)
 template<int S, int M>
 struct Solver
 {
+  static constexpr int LQ = M + 1; // row stride of the M x M matrices Quu, QuuF, Lf in LDS (padded)
+
   const Params & P;
   const Instance & I;
   Mem<S, M> & mem;
@@ -583,7 +585,7 @@ struct Solver
 #endif
     double Hr[16];
 #  pragma unroll
-    for(int k = 0; k < 16; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * m + k] : 0.0;
+    for(int k = 0; k < 16; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * LQ + k] : 0.0;
     const double gi = in ? mem.Qu[i] : 0.0;
     const double lo = in ? mem.lo[i] : 0.0, hi = in ? mem.hi[i] : 0.0;
     double x = in ? fmin(fmax(mem.kq[i], lo), hi) : 0.0;
@@ -728,7 +730,7 @@ struct Solver
         if(lane < m)
         {
           double s = 0;
-          for(int j = 0; j < m; j++) s += H[lane * m + j] * x[j];
+          for(int j = 0; j < m; j++) s += H[lane * LQ + j] * x[j];
           mem.tmp[lane] = x[lane] * g[lane] + 0.5 * x[lane] * s;
         }
       });
@@ -766,7 +768,7 @@ struct Solver
         if(lane < m)
         {
           double s = g[lane];
-          for(int j = 0; j < m; j++) s += H[lane * m + j] * mem.kq[j];
+          for(int j = 0; j < m; j++) s += H[lane * LQ + j] * mem.kq[j];
           mem.grad[lane] = s;
           mem.oldc[lane] = mem.clamped[lane];
           mem.clamped[lane] = ((mem.kq[lane] == mem.lo[lane] && s > 0) || (mem.kq[lane] == mem.hi[lane] && s < 0)) ? 1 : 0;
@@ -817,7 +819,7 @@ struct Solver
         {
           double s = g[lane];
           for(int j = 0; j < m; j++)
-            if(mem.clamped[j]) s += H[lane * m + j] * mem.kq[j];
+            if(mem.clamped[j]) s += H[lane * LQ + j] * mem.kq[j];
           mem.tmp[lane] = mem.clamped[lane] ? 0.0 : s;
         }
       });
@@ -890,19 +892,19 @@ struct Solver
       for(int k = 0; k <= i; k++)
       {
         const bool cl = mem.clamped[i] || mem.clamped[k];
-        mem.Lf[i * m + k] = cl ? (i == k ? 1.0 : 0.0) : H[i * m + k];
+        mem.Lf[i * LQ + k] = cl ? (i == k ? 1.0 : 0.0) : H[i * LQ + k];
       }
     for(int j = 0; j < m; j++)
     {
-      const double d = mem.Lf[j * m + j];
+      const double d = mem.Lf[j * LQ + j];
       ok = ok && (d > 0.0);
       const double sq = sqrt(d);
       const double r = 1.0 / sq;
-      mem.Lf[j * m + j] = sq;
+      mem.Lf[j * LQ + j] = sq;
       mem.rd[j] = r;
-      for(int i = j + 1; i < m; i++) mem.Lf[i * m + j] = mem.Lf[i * m + j] * r;
+      for(int i = j + 1; i < m; i++) mem.Lf[i * LQ + j] = mem.Lf[i * LQ + j] * r;
       for(int k = j + 1; k < m; k++)
-        for(int i = k; i < m; i++) mem.Lf[i * m + k] -= mem.Lf[i * m + j] * mem.Lf[k * m + j];
+        for(int i = k; i < m; i++) mem.Lf[i * LQ + k] -= mem.Lf[i * LQ + j] * mem.Lf[k * LQ + j];
     }
     mem.ic[IC_OK] = ok ? 1 : 0;
     return ok;
@@ -925,7 +927,7 @@ struct Solver
       {
         const bool in = (i < m) && (k < m);
         const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
-        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * m + k]) : (i == k ? 1.0 : 0.0);
+        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * LQ + k]) : (i == k ? 1.0 : 0.0);
       }
       bool ok = true;
       double rdi = 1.0;
@@ -960,7 +962,7 @@ struct Solver
       {
 #  pragma unroll
         for(int k = 0; k < 16; ++k)
-          if(k <= i) mem.Lf[i * m + k] = a[k];
+          if(k <= i) mem.Lf[i * LQ + k] = a[k];
         mem.rd[i] = rdi;
       }
       if(lane == 0) mem.ic[IC_OK] = ok ? 1 : 0;
@@ -977,8 +979,8 @@ struct Solver
 #  pragma unroll
     for(int k = 0; k < 16; ++k)
     {
-      lr[k] = (i < m && k < i) ? mem.Lf[i * m + k] : 0.0;
-      lc[k] = (i < m && k < m && k > i) ? mem.Lf[k * m + i] : 0.0;
+      lr[k] = (i < m && k < i) ? mem.Lf[i * LQ + k] : 0.0;
+      lc[k] = (i < m && k < m && k > i) ? mem.Lf[k * LQ + i] : 0.0;
     }
     rdi = (i < m) ? mem.rd[i] : 1.0;
   }
@@ -1028,13 +1030,13 @@ struct Solver
     for(int a = 0; a < m; a++)
     {
       double s = v[a];
-      for(int k = 0; k < a; k++) s -= mem.Lf[a * m + k] * v[k];
+      for(int k = 0; k < a; k++) s -= mem.Lf[a * LQ + k] * v[k];
       v[a] = s * mem.rd[a];
     }
     for(int a = m - 1; a >= 0; a--)
     {
       double s = v[a];
-      for(int k = m - 1; k > a; k--) s -= mem.Lf[k * m + a] * v[k];
+      for(int k = m - 1; k > a; k--) s -= mem.Lf[k * LQ + a] * v[k];
       v[a] = s * mem.rd[a];
     }
 #endif
@@ -1076,7 +1078,7 @@ struct Solver
             double sum = t3[r];
 #  pragma unroll
             for(int k = 0; k < M; k++)
-              if(k < r) sum -= mem.Lf[r * m + k] * t3[k];
+              if(k < r) sum -= mem.Lf[r * LQ + k] * t3[k];
             t3[r] = sum * mem.rd[r];
           }
         }
@@ -1088,7 +1090,7 @@ struct Solver
             double sum = t3[r];
 #  pragma unroll
             for(int k = M - 1; k >= 0; k--)
-              if(k > r && k < m) sum -= mem.Lf[k * m + r] * t3[k];
+              if(k > r && k < m) sum -= mem.Lf[k * LQ + r] * t3[k];
             t3[r] = sum * mem.rd[r];
           }
         }
@@ -1280,7 +1282,7 @@ struct Solver
 #if defined(__HIP_DEVICE_COMPILE__)
         colprod<true, 1, false>(lane, S, S, mem.Fx, S, mem.T1, S, 0.0, mem.Qxx, S);
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxu, M);
-        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.Quu, m);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.Quu, LQ);
 #else
         for(int e = lane; e < S * S; e += kWave)
         {
@@ -1301,14 +1303,14 @@ struct Solver
           const int r = e / m, q = e % m;
           double s = (r == q) ? P.w_force : 0.0;
           for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * mem.T2[k * M + q];
-          mem.Quu[e] = s;
+          mem.Quu[r * LQ + q] = s;
         }
 #endif
         // regularised versions from T2r
         const double * const T2r = mem.Lf;
 #if defined(__HIP_DEVICE_COMPILE__)
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
-        colprod<true, 2, false>(lane, m, m, mem.Fu, M, T2r, M, 0.0, mem.QuuF, m);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, T2r, M, 0.0, mem.QuuF, LQ);
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
@@ -1322,7 +1324,7 @@ struct Solver
           const int r = e / m, q = e % m;
           double s = (r == q) ? P.w_force : 0.0;
           for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * T2r[k * M + q];
-          mem.QuuF[e] = s;
+          mem.QuuF[r * LQ + q] = s;
         }
 #endif
         // box limits on the input CHANGE and the warm start (gain of step i+1 of this pass, zeros on a dim change)
@@ -1355,7 +1357,7 @@ struct Solver
         if(lane < m)
         {
           double s = 0;
-          for(int q = 0; q < m; q++) s += mem.Quu[lane * m + q] * mem.k[q];
+          for(int q = 0; q < m; q++) s += mem.Quu[lane * LQ + q] * mem.k[q];
           mem.t4[lane] = s;
         }
         if(lane < M)
@@ -1371,7 +1373,7 @@ struct Solver
         {
           const int a = e / m, r = e % m;
           double s = 0;
-          for(int q = 0; q < m; q++) s += mem.K[q * S + a] * mem.Quu[q * m + r];
+          for(int q = 0; q < m; q++) s += mem.K[q * S + a] * mem.Quu[q * LQ + r];
           mem.T2[a * M + r] = s;
         }
       });
