@@ -879,7 +879,6 @@ struct Solver
   // v_readlane (constant lane numbers after unrolling) -- no LDS round trips, no barriers inside.
   CCC_DDP_FN bool cholesky_free(int m)
   {
-    const double * H = mem.QuuF;
 #if defined(__HIP_DEVICE_COMPILE__)
     if(m == 16)
       cholesky_phase<16>(m);
@@ -887,6 +886,7 @@ struct Solver
       cholesky_phase<0>(m);
     return mem.ic[IC_OK] != 0;
 #else
+    const double * H = mem.QuuF;
     bool ok = true;
     for(int i = 0; i < m; i++)
       for(int k = 0; k <= i; k++)
