@@ -1,0 +1,216 @@
+"""Secondary workloads of bench.py (`--workload xy|ddp|srb|ism|z`): the other rows of SURVEY.md section 8, measured
+with the same protocol as the headline (W untimed warm-up steps, K timed steps bracketed by barrier + synchronize, max
+over ranks, ONE JSON line with `roofline` and `cpu_baseline`).  A step = one pass of the class's batched planOnce()
+over one batch of synthetic instances already resident in HBM; weak scaling (every rank its own batch)."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _dev(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _tile(d, n, base):
+    k = (n + base - 1) // base
+    return {a: np.concatenate([v] * k)[:n] for a, v in d.items()}
+
+
+def _xy(n, dev, rank):
+    from centroidalcontrolcollection_amd import LinearMpcXY, fixtures_ddp as fd
+    N, dt, base = 20, 0.1, min(n, 2048)
+    prob, x0 = fd.make_xy_batch(base, N, dt, seed=20250928 + rank)
+    prob = _tile(prob, n, base)
+    x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
+    mpc = LinearMpcXY(100.0, dt, N, device=dev.index)
+    tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
+    out = torch.zeros((n, 16), dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step(stream):
+        mpc.plan_batch_device(tp, tx0, out, status=st, stream=stream)
+
+    def cpu(cores):
+        from oracle import oracle
+        ns = min(n, 2048)
+        sub = {a: v[:ns] for a, v in prob.items()}
+        o = oracle.LinearMpcXY(100.0, dt, N)
+        t0 = time.perf_counter()
+        r = o.plan_batch(sub, x0[:ns], nthreads=cores)
+        t = time.perf_counter() - t0
+        err = np.abs(out.cpu().numpy()[:ns] - r["u0"]).max() / (np.abs(r["u0"]).max() + 1.0)
+        return ns / t, ns, float(err), "max |d force scale| / (1 + max force scale)"
+
+    return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
+                workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
+                algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, kernel="xy_plan_kernel", cpu=cpu, keep=(mpc, tp, tx0))
+
+
+def _ddp(n, dev, rank, srb):
+    from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
+    N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
+    prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
+    prob = _tile(prob, n, base)
+    x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
+    if srb:
+        w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0),
+                                           terminal_ori=(0.5,) * 3)
+        d = DdpSingleRigidBody(100.0, dt, N, w, device=dev.index)
+    else:
+        d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
+                          device=dev.index)
+    d.ddp_solver_.config().max_iter = 20
+    tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
+    out = torch.zeros((n, N, 16), dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step(stream):
+        d.plan_batch_device(tp, tx0, out, iters=it, status=st, stream=stream)
+
+    def cpu(cores):
+        from oracle import oracle
+        ns = min(n, 2048)
+        sub = {a: v[:ns] for a, v in prob.items()}
+        o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20)
+        t0 = time.perf_counter()
+        r = o.plan_batch(sub, x0[:ns], nthreads=cores)
+        t = time.perf_counter() - t0
+        same = bool(np.array_equal(out.cpu().numpy()[:ns], r["u"]))
+        return ns / t, ns, 0.0 if same else float(np.abs(out.cpu().numpy()[:ns] - r["u"]).max()), \
+            "max |d force scale| over the whole planned sequence (0.0 = bit-identical)"
+
+    S = 12 if srb else 9
+    return dict(name="%s planOnce() solves/sec (horizon %d, <= 20 DDP iterations, fp64, inputs resident in HBM)"
+                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N), step=step, out=out, status=st, iters=it,
+                workload="%s horizon=%d @ 30 ms, max_iter=20, batch=%d per GPU (BASELINE config %s)"
+                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, n, "5 shape, fp64" if srb else "3"),
+                algo_bytes=4 * 4 + 2 * 4 * 16 * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
+                + S * 8 + N * 16 * 8, kernel="ddp_plan_kernel<%d,16>" % S, cpu=cpu, keep=(d, tp, tx0))
+
+
+def _ism(n, dev, rank):
+    from centroidalcontrolcollection_amd import IntrinsicallyStableMpc, fixtures as fx
+    N, dt, base = 100, 0.02, min(n, 1024)
+    b = _tile(fx.make_ism_batch(base, N, dt, seed=20250928 + rank), n, base)
+    mpc = IntrinsicallyStableMpc(1.0, 2.0, dt, device=dev.index)
+    ti, tr = _dev(b["init"], dev), _dev(b["ref"], dev)
+    out = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    st = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+
+    def step(stream):
+        mpc.plan_batch_device(ti, tr, 0.005, out, status=st, stream=stream)
+
+    def cpu(cores):
+        from oracle import oracle
+        ns = min(n, 16384)
+        o = oracle.IntrinsicallyStableMpc(1.0, 2.0, dt)
+        t0 = time.perf_counter()
+        r = o.plan_batch(b["init"][:ns], b["ref"][:ns], 0.005, want_vel=False, nthreads=cores)
+        t = time.perf_counter() - t0
+        return ns / t, ns, float(np.abs(out.cpu().numpy()[:ns] - r["zmp"]).max()), "max |d ZMP| [m]"
+
+    return dict(name="IntrinsicallyStableMpc planOnce() solves/sec (N=100, fp64, inputs resident in HBM)", step=step, out=out,
+                status=st, workload="IntrinsicallyStableMpc N=100 (2 s horizon @ 20 ms), batch=%d per GPU" % n,
+                algo_bytes=2 * (16 + 3 * N * 8) + 16, kernel="ism_plan_kernel", cpu=cpu, keep=(mpc, ti, tr))
+
+
+def _z(n, dev, rank):
+    from centroidalcontrolcollection_amd import LinearMpcZ, fixtures as fx
+    N, dt, base = 40, 0.05, min(n, 4096)
+    b = _tile(fx.make_z_batch(base, N, dt, seed=20250928 + rank), n, base)
+    mpc = LinearMpcZ(100.0, dt, N, device=dev.index)
+    tc, tr, tx = _dev(b["contact"], dev), _dev(b["ref_pos"], dev), _dev(b["x0"], dev)
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+
+    def step(stream):
+        mpc.plan_batch_device(tc, tr, tx, out, status=st, stream=stream)
+
+    def cpu(cores):
+        from oracle import oracle
+        ns = min(n, 65536)
+        o = oracle.LinearMpcZ(100.0, dt, N)
+        t0 = time.perf_counter()
+        r = o.plan_batch(b["contact"][:ns], b["ref_pos"][:ns], b["x0"][:ns], nthreads=cores)
+        t = time.perf_counter() - t0
+        err = (np.abs(out.cpu().numpy()[:ns] - r["force"]) / (np.abs(r["force"]) + 1.0)).max()
+        return ns / t, ns, float(err), "max relative |d force|"
+
+    return dict(name="LinearMpcZ planOnce() solves/sec (N=40, fp64, inputs resident in HBM)", step=step, out=out, status=st,
+                workload="LinearMpcZ N=40 (2 s horizon @ 50 ms), batch=%d per GPU" % n, algo_bytes=N * 4 + N * 8 + 16 + 8,
+                kernel="z_plan_kernel", cpu=cpu, keep=(mpc, tc, tr, tx))
+
+
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=16384, z=65536)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(10, 2), z=(50, 5))
+
+
+def run(args, rank, world, local_rank, dist):
+    dev = torch.device("cuda", local_rank)
+    n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
+    steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
+    make = dict(xy=_xy, ism=_ism, z=_z, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True))
+    w = make[args.workload](n, dev, rank)
+    stream = torch.cuda.current_stream(dev)
+    gathered = torch.empty((world,) + tuple(w["out"].shape), dtype=w["out"].dtype, device=dev) if world > 1 else None
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        w["step"](stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, w["out"])
+
+    for _ in range(warmup):
+        step()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(evs[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = np.array([a.elapsed_time(b) for a, b in evs])
+    if rank != 0:
+        return
+    kavg = float(kern_ms.mean()) * 1e-3
+    achieved = w["algo_bytes"] * n / kavg / 1e9
+    st = w["status"].cpu().numpy()
+    out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
+           "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": w["workload"], "batch_per_gpu": n, "parallelism": "batch-sharded x%d" % world,
+                      "collective": "all_gather(planned outputs)" if world > 1 else "none"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": w["algo_bytes"] * n,
+                        "kernel": w["kernel"], "kernel_avg_ms": kavg * 1e3,
+                        "note": "algorithmic bytes = mandatory inputs + outputs per instance x batch; the kernel is bound "
+                                "by dependent-operation latency / LDS, not by HBM (DESIGN.md)"},
+           "unsolved": int((st < 0).sum()) if "iters" in w else int(((st & 0xff) != 0).sum())}  # DDP: status < 0 = failure,
+    #                                      0 = iteration limit, 1 / 2 = converged (oracle/ddp.c); QPs: low byte != 0
+    if "iters" in w:
+        out["mean_iterations"] = float(w["iters"].float().mean().item())
+    if not args.no_cpu_baseline and world == 1:
+        cores = os.cpu_count() or 1
+        rate, ns, err, what = w["cpu"](cores)
+        out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": cores, "kind": "port",
+                               "sample": "first %d instances of the rank-0 batch, OpenMP over instances, %d threads; C "
+                                         "restatement of the reference path (oracle/)" % (ns, cores)}
+        out["parity"] = {"value": err, "what": what}
+    print(json.dumps(out))
