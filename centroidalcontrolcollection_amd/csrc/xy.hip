@@ -125,12 +125,20 @@ __device__ __forceinline__ double xy_row16_sum(double v)
 __device__ __forceinline__ void xy_block_argmin(double v, XyRed * red, double & vmin, int & imin)
 {
   const int tid = threadIdx.x, w = tid >> 6;
-  const double wm = WaveGroup<64>::min(v);
-  const int wi = WaveGroup<64>::first(v == wm && v < kXyInf);
-  if((tid & 63) == 0)
+  if(tid < kXyNV) // wavefronts 5 and 6 hold blocks of Qt only, never a candidate
   {
-    red->val[w] = wm;
-    red->idx[w] = wi < 64 ? wi + 64 * w : kXyNT;
+    const double wm = WaveGroup<64>::min(v);
+    const int wi = WaveGroup<64>::first(v == wm && v < kXyInf);
+    if((tid & 63) == 0)
+    {
+      red->val[w] = wm;
+      red->idx[w] = wi < 64 ? wi + 64 * w : kXyNT;
+    }
+  }
+  else if((tid & 63) == 0)
+  {
+    red->val[w] = kXyInf;
+    red->idx[w] = kXyNT;
   }
   __syncthreads();
   double best = red->val[0];
@@ -495,8 +503,13 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
       {
         if(!dropping && target < 0)
         {
-          const double sl = (P.flo - lam) - tl, sh_ = (lam - P.fhi) - th;
-          const double score = (valid && stt == 0) ? fmax(sl, sh_) : -kXyInf;
+          double sl = 0.0, sh_ = 0.0, score = -kXyInf;
+          if(i < kXyNV)
+          {
+            sl = (P.flo - lam) - tl;
+            sh_ = (lam - P.fhi) - th;
+            score = (valid && stt == 0) ? fmax(sl, sh_) : -kXyInf;
+          }
           double m;
           xy_block_argmin(score > 0.0 ? -score : kXyInf, &sh.red[rbuf], m, p);
           rbuf ^= 1;
@@ -516,24 +529,27 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
         if(!dropping)
         {
           const bool isp = (i == p);
-          const double sgp = sh.sg;
-          double D = 0.0;
-          if(s_i < N)
+          double zdir = 0.0, dmu = 0.0, ratio = kXyInf;
+          if(i < kXyNV) // (wave-uniform) wavefronts 5 and 6 hold no variables
           {
+            const double sgp = sh.sg;
+            double D = 0.0;
+            if(s_i < N)
+            {
 #pragma unroll
-            for(int c = 0; c < NB; c++) D = fma(sh.bt[ib][c], sh.pi[buf][NB * s_i + c], D);
+              for(int c = 0; c < NB; c++) D = fma(sh.bt[ib][c], sh.pi[buf][NB * s_i + c], D);
+            }
+            // primal direction of the free variables, multiplier rates of the clamped ones
+            zdir = isp ? sgp * (1.0 - D) * iwf : -sgp * D * iwf;
+            dmu = (stt < 0) ? sgp * D : -sgp * D;
+            if(isp)
+            {
+              const double curv = 1.0 - D;
+              ratio = (curv > 1e-15) ? fabs(bound - lam) * wf * fast_rcp(curv) : kXyInf;
+            }
+            else if(valid && stt != 0 && dmu < 0.0)
+              ratio = mu * fast_rcp(-dmu);
           }
-          // primal direction of the free variables, multiplier rates of the clamped ones
-          const double zdir = isp ? sgp * (1.0 - D) * iwf : -sgp * D * iwf;
-          const double dmu = (stt < 0) ? sgp * D : -sgp * D;
-          double ratio = kXyInf;
-          if(isp)
-          {
-            const double curv = 1.0 - D;
-            ratio = (curv > 1e-15) ? fabs(bound - lam) * wf * fast_rcp(curv) : kXyInf;
-          }
-          else if(valid && stt != 0 && dmu < 0.0)
-            ratio = mu * fast_rcp(-dmu);
           double t;
           int kk;
           xy_block_argmin(ratio, &sh.red[rbuf], t, kk);
