@@ -398,7 +398,7 @@ def make_z_batch(n, horizon_steps=40, horizon_dt=0.05, seed=20250928):
     contact = np.ones((n, N), dtype=np.int32)
     ref = np.ones((n, N))
     for k in range(n):
-        for _ in range(rng.integers(0, 3)):
+        for _ in range(rng.integers(0, 3) if N > 1 else 0):
             a = 0 if rng.random() < 0.125 else rng.integers(1, N)
             contact[k, a:a + rng.integers(1, 9)] = 0
         ref[k, rng.integers(0, N):] = rng.uniform(0.7, 1.2)

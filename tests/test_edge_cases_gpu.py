@@ -1,0 +1,94 @@
+"""GPU edge cases across the kernels: smallest and largest supported horizons, empty problems, degenerate inputs --
+each against the CPU oracle."""
+import numpy as np
+import pytest
+
+from centroidalcontrolcollection_amd import IntrinsicallyStableMpc, LinearMpcXY, LinearMpcZ, LinearMpcZmp
+from centroidalcontrolcollection_amd._lib import CccError
+from centroidalcontrolcollection_amd import fixtures as fx
+from centroidalcontrolcollection_amd import fixtures_ddp as fd
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle
+
+    return oracle
+
+
+def test_xy_single_step_and_no_contact_at_all():
+    mass = 100.0
+    for N in (1, 2):
+        prob, x0 = fd.make_xy_batch(16, N, 0.1, mass, seed=N)
+        o = _oracle().LinearMpcXY(mass, 0.1, N).plan_batch(prob, x0)
+        r = LinearMpcXY(mass, 0.1, N).planOnceBatch(prob, x0)
+        assert np.all(r["status"] == 0) and np.all(o["status"] == 0)
+        assert np.abs(r["u0"] - o["u0"]).max() <= 1e-7 * (1.0 + np.abs(o["u0"]).max())
+    prob, x0 = fd.make_xy_batch(4, 6, 0.1, mass, seed=3)
+    prob["dim"][:] = 0
+    r = LinearMpcXY(mass, 0.1, 6).planOnceBatch(prob, x0, want_all=True)
+    assert np.all(r["status"] == 0) and np.all(r["u0"] == 0.0) and np.all(r["lam"] == 0.0) and np.all(r["pivots"] == 0)
+
+
+def test_xy_rejects_unsupported_sizes():
+    with pytest.raises(CccError):
+        LinearMpcXY(100.0, 0.1, 21)
+    with pytest.raises(CccError):
+        LinearMpcXY(-1.0, 0.1, 10)
+
+
+def test_ism_largest_and_smallest_horizon():
+    for T, dt in ((2.54, 0.02), (0.02, 0.02), (0.06, 0.02)):
+        o = _oracle().IntrinsicallyStableMpc(1.0, T, dt)
+        N = o.horizon_steps
+        assert N in (127, 1, 3)
+        b = fx.make_ism_batch(24, N, dt, seed=N)
+        ro = o.plan_batch(b["init"], b["ref"], 0.005, want_vel=False, nthreads=8)
+        r = IntrinsicallyStableMpc(1.0, T, dt).planOnceBatch(b["init"], b["ref"], 0.005)
+        ok = ro["status"] == 0
+        assert ok.sum() >= 12 and np.all(r["status"][ok] == 0)
+        assert np.abs(r["zmp"][ok] - ro["zmp"][ok]).max() <= 1e-9
+        assert np.all(r["status"][~ok].max(axis=1) != 0) if (~ok).any() else True
+    with pytest.raises(CccError):
+        IntrinsicallyStableMpc(1.0, 2.56, 0.02)  # 128 steps + the stability row exceed the LDS-resident tableau
+
+
+def test_z_single_step_and_all_flight():
+    mass = 100.0
+    b = fx.make_z_batch(32, 1, 0.05, seed=1)
+    o = _oracle().LinearMpcZ(mass, 0.05, 1).plan_batch(b["contact"], b["ref_pos"], b["x0"])
+    r = LinearMpcZ(mass, 0.05, 1).planOnceBatch(b["contact"], b["ref_pos"], b["x0"])
+    assert np.all(r["status"] == 0)
+    assert (np.abs(r["force"] - o["force"]) / (np.abs(o["force"]) + 1.0)).max() <= 1e-8
+    b = fx.make_z_batch(8, 40, 0.05, seed=2)
+    b["contact"][:] = 0
+    r = LinearMpcZ(mass, 0.05, 40).planOnceBatch(b["contact"], b["ref_pos"], b["x0"], want_all=True)
+    assert np.all(r["force"] == 0.0) and np.all(r["force_all"] == 0.0) and np.all(r["status"] == 0)
+    with pytest.raises(CccError):
+        LinearMpcZ(mass, 0.05, 65)
+
+
+def test_zmp_timeline_without_footsteps_and_single_instance_loop():
+    """K = 0 footsteps: constant double-support limits; the closed loop holds the CoM inside them."""
+    import torch
+
+    mpc = LinearMpcZmp(1.0, 2.0, 0.0625)
+    tl = dict(foot0=torch.tensor([[[0.0, 0.1], [0.0, -0.1]]], dtype=torch.float64, device="cuda:0"),
+              foot_pos=torch.zeros((1, 0, 2), dtype=torch.float64, device="cuda:0"),
+              foot_id=torch.zeros((1, 0), dtype=torch.int32, device="cuda:0"),
+              swing_start=torch.zeros((1, 0), dtype=torch.float64, device="cuda:0"),
+              swing_end=torch.zeros((1, 0), dtype=torch.float64, device="cuda:0"))
+    zl = torch.zeros((1, 2, 2, 32), dtype=torch.float64, device="cuda:0")
+    mpc.sample_limits_device(tl, zl, t_common=1.0)
+    torch.cuda.synchronize()
+    z = zl.cpu().numpy()[0]
+    assert np.all(z[0, 0] == -0.05) and np.all(z[0, 1] == 0.05) and np.all(z[1, 0] == -0.125) and np.all(z[1, 1] == 0.125)
+    com = torch.tensor([[[0.02, 0.05], [-0.05, 0.0]]], dtype=torch.float64, device="cuda:0")  # capture point inside
+    zmp = com[:, :, 0].clone().contiguous()
+    viol = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    mpc.closed_loop_device(tl, com, zmp, 0.0, 0.01, 300, violations=viol)
+    torch.cuda.synchronize()
+    assert viol.item() == 0
+    c = com.cpu().numpy()[0]
+    assert abs(c[0, 0]) < 0.05 and abs(c[1, 0]) < 0.125 and np.abs(c[:, 1]).max() < 0.05
