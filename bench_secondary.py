@@ -1,7 +1,8 @@
 """Secondary workloads of bench.py (`--workload xy|ddp|srb|ism|z`): the other rows of SURVEY.md section 8, measured
 with the same protocol as the headline (W untimed warm-up steps, K timed steps bracketed by barrier + synchronize, max
 over ranks, ONE JSON line with `roofline` and `cpu_baseline`).  A step = one pass of the class's batched planOnce()
-over one batch of synthetic instances already resident in HBM; weak scaling (every rank its own batch)."""
+over one batch of synthetic instances already resident in HBM; weak scaling (every rank its own batch).
+Part of bench.py: the `cpu` callbacks below are its cpu_baseline leg (the only place here that touches oracle/)."""
 import json
 import os
 import time

@@ -1,5 +1,5 @@
-"""Time the IntrinsicallyStableMpc kernel (reference test horizon: 2 s @ 20 ms = 100 steps) and, with `cpu`, the oracle
-on the host cores beside it.  usage: ism_bench.py [n] [reps] [cpu]"""
+"""Time the IntrinsicallyStableMpc kernel (reference test horizon: 2 s @ 20 ms = 100 steps).
+The CPU baseline and the parity check live in `python bench.py --workload ism`.  usage: ism_bench.py [n] [reps]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -25,12 +25,3 @@ t = min(ts)
 s = st.cpu().numpy()
 print("IntrinsicallyStableMpc n=%d N=100: %.1f ms -> %.0f solves/s (mean pivots/axis %.1f, max %d, non-ok %d)"
       % (n, t * 1e3, n / t, (s >> 8).mean(), (s >> 8).max(), int(((s & 0xff) != 0).sum())))
-if len(sys.argv) > 3 and sys.argv[3] == "cpu":
-    from oracle import oracle
-    o = oracle.IntrinsicallyStableMpc(1.0, 2.0, 0.02)
-    nc = min(n, 4096)
-    cores = os.cpu_count()
-    t0 = time.perf_counter(); r = o.plan_batch(init[:nc], ref[:nc], 0.005, want_vel=False, nthreads=cores); tc = time.perf_counter() - t0
-    t0 = time.perf_counter(); o.plan_batch(init[:64], ref[:64], 0.005, want_vel=False, nthreads=1); t1 = time.perf_counter() - t0
-    print("oracle: %d threads %.0f solves/s, 1 thread %.0f solves/s; max |dZMP| vs GPU = %.2e"
-          % (cores, nc / tc, 64 / t1, np.abs(r["zmp"] - z.cpu().numpy()[:nc]).max()))

@@ -1,5 +1,5 @@
-"""Time the LinearMpcZ kernel (reference test horizon: 40 steps @ 50 ms) and, with `cpu`, the oracle beside it.
-usage: z_bench.py [n] [reps] [cpu]"""
+"""Time the LinearMpcZ kernel (reference test horizon: 40 steps @ 50 ms).  The CPU baseline and the parity check
+live in `python bench.py --workload z`.  usage: z_bench.py [n] [reps]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -25,12 +25,3 @@ t = min(ts)
 s = st.cpu().numpy()
 print("LinearMpcZ n=%d N=%d: %.2f ms -> %.0f solves/s (mean pivots %.2f, max %d, non-ok %d)"
       % (n, N, t * 1e3, n / t, (s >> 8).mean(), (s >> 8).max(), int(((s & 0xff) != 0).sum())))
-if len(sys.argv) > 3 and sys.argv[3] == "cpu":
-    from oracle import oracle
-    o = oracle.LinearMpcZ(100.0, dt, N)
-    nc = min(n, 16384)
-    cores = os.cpu_count()
-    t0 = time.perf_counter(); r = o.plan_batch(b["contact"][:nc], b["ref_pos"][:nc], b["x0"][:nc], nthreads=cores); tcpu = time.perf_counter() - t0
-    t0 = time.perf_counter(); o.plan_batch(b["contact"][:256], b["ref_pos"][:256], b["x0"][:256], nthreads=1); t1 = time.perf_counter() - t0
-    print("oracle: %d threads %.0f solves/s, 1 thread %.0f solves/s; max rel |dF| vs GPU = %.2e"
-          % (cores, nc / tcpu, 256 / t1, (np.abs(r["force"] - f.cpu().numpy()[:nc]) / (np.abs(r["force"]) + 1)).max()))

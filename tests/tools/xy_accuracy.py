@@ -1,8 +1,9 @@
-"""Offline: compare a kernel dump (scripts/xy_dump.py, run on the GPU box) with the oracle and with a long-double KKT
+"""Offline: compare a kernel dump (scripts/xy_dump.py, run on the GPU box); lives under tests/ because it uses the oracle with the oracle and with a long-double KKT
 solve on the same active set.  usage: xy_accuracy.py N seed"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import xy_stage_space_proto as P
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
 from oracle import oracle as orc

@@ -2,7 +2,7 @@
 long-double KKT solve on a given active set (truth_ld) used to measure the accuracy of kernel and oracle offline."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
 from oracle import oracle as orc
 
