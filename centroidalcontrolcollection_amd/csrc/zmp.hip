@@ -392,15 +392,20 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 // active-set iteration and closing refinement as zmp_plan_kernel; built for coverage of the drop-in
 // surface, not for the headline throughput.
 // ---------------------------------------------------------------------------------------------
+// Horizons beyond 128 steps (e.g. 2 s @ 10 ms = 200, BASELINE configs[0] as worded) do not fit the 160 KB of LDS any
+// more: the same kernel with 256 threads keeps its tableau in an HBM workspace ([j][i], i fastest: coalesced).  Slow
+// (every pivot streams 2 x 512 KB through L2) -- there for completeness of the drop-in surface.
 constexpr int kBlkNP = 128;
+constexpr int kBigNP = 256;
 
 struct BlockRed
 {
-  double val[2];
-  int idx[2];
+  double val[4];
+  int idx[4];
 };
 
-// (min value over the 128-thread block, lowest thread index attaining it; index kBlkNP if every candidate is NaN)
+// (min value over the NP-thread block, lowest thread index attaining it; index NP if every candidate is NaN)
+template<int NP>
 __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & vmin, int & imin)
 {
   const int tid = threadIdx.x, w = tid >> 6;
@@ -410,26 +415,33 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
   if((tid & 63) == 0)
   {
     red->val[w] = wm;
-    red->idx[w] = wi < 64 ? wi + 64 * w : kBlkNP;
+    red->idx[w] = wi < 64 ? wi + 64 * w : NP;
   }
   __syncthreads();
-  const double a = red->val[0], b = red->val[1];
-  const int ia = red->idx[0], ib = red->idx[1];
-  const bool first = (ia < kBlkNP) && (a <= b || ib >= kBlkNP);
-  vmin = first ? a : b;
-  imin = first ? ia : ib;
+  double best = red->val[0];
+  int bi = red->idx[0];
+#pragma unroll
+  for(int k = 1; k < NP / 64; ++k)
+  {
+    const double a = red->val[k];
+    const int ia = red->idx[k];
+    const bool take = (ia < NP) && (bi >= NP || a < best);
+    best = take ? a : best;
+    bi = take ? ia : bi;
+  }
+  vmin = best;
+  imin = bi;
 }
 
-__global__ __launch_bounds__(kBlkNP) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
-                                                                const double * __restrict__ zlim,
-                                                                double control_dt, double * __restrict__ zmp,
-                                                                double * __restrict__ jerk,
-                                                                int * __restrict__ status)
+template<int NP, bool HBM>
+__global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                            const double * __restrict__ zlim, double control_dt,
+                                                            double * __restrict__ zmp, double * __restrict__ jerk,
+                                                            int * __restrict__ status, double * __restrict__ ws)
 {
-  constexpr int NP = kBlkNP;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double * T = smem;              // [NP][NP]
-  double * cb = smem + NP * NP;   // [NP] staging of the pivot row / of mu / of rho
+  double * T = HBM ? ws + (size_t)blockIdx.x * NP * NP : smem; // [NP][NP]
+  double * cb = HBM ? smem : smem + NP * NP;                   // [NP] staging of the pivot row / of mu / of rho
   BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
   const int i = threadIdx.x;
   const int N = P.N;
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(kBlkNP) void zmp_plan_block_kernel(ZmpDev P, long n
           const double score = (inW || !row) ? -kInf : fmax(sl, sh);
           double m;
           int cand;
-          block_argmin(-score, red, m, cand);
+          block_argmin<NP>(-score, red, m, cand);
           m = -m;
           if(!(m > 0.0)) break;
           p = cand;
@@ -503,7 +515,7 @@ __global__ __launch_bounds__(kBlkNP) void zmp_plan_block_kernel(ZmpDev P, long n
         const double ratio = (isp || blocking) ? num / den : kInf;
         double t;
         int kk;
-        block_argmin(ratio, red, t, kk);
+        block_argmin<NP>(ratio, red, t, kk);
         if(kk >= NP)
         {
           st = CCC_STATUS_MAX_ITER;
@@ -627,6 +639,7 @@ struct ccc_zmp
   double com_height = 0, horizon_duration = 0, horizon_dt = 0, c2 = 0;
   std::vector<double> A_seq, B_seq; // host copies, N x 3 and N x N
   double *dG = nullptr, *dA = nullptr, *db = nullptr;
+  double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
   int num_cu = 0;
   // staging for the host-pointer entry point
   int64_t cap = 0;
@@ -722,19 +735,30 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
 int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
                  double * jerk, int32_t * status, hipStream_t stream)
 {
+  const int64_t nqp = 2 * n;
+  ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  if(h->NP == kBigNP)
+  {
+    const int blocks = h->num_cu * 2;
+    if(!h->ws_big) CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
+    const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed);
+    const int grid = (int)std::min<int64_t>(nqp, blocks);
+    hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true>), dim3(grid), dim3(kBigNP), lds, stream, P, (long)nqp, x0,
+                       zlim, control_dt, zmp, jerk, status, h->ws_big);
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  }
   const size_t lds = ((size_t)kBlkNP * kBlkNP + kBlkNP) * sizeof(double) + sizeof(BlockRed);
   static bool attr_set = false;
   if(!attr_set)
   {
-    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel),
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel<kBlkNP, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int64_t nqp = 2 * n;
   const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
-  ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
-  hipLaunchKernelGGL(zmp_plan_block_kernel, dim3(grid), dim3(kBlkNP), lds, stream, P, (long)nqp, x0, zlim, control_dt,
-                     zmp, jerk, status);
+  hipLaunchKernelGGL((zmp_plan_block_kernel<kBlkNP, false>), dim3(grid), dim3(kBlkNP), lds, stream, P, (long)nqp, x0,
+                     zlim, control_dt, zmp, jerk, status, (double *)nullptr);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
@@ -748,14 +772,14 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(!(com_height > 0) || !(horizon_duration > 0) || !(horizon_dt > 0))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_create: com_height, horizon_duration, horizon_dt must be > 0");
   const int N = (int)std::ceil(horizon_duration / horizon_dt); // src/LinearMpcZmp.cpp:13
-  if(N > 128)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > 128 exceeds the LDS-resident tableau", N);
+  if(N > kBigNP)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > %d is not built into this library", N, kBigNP);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   ccc_zmp * h = new ccc_zmp();
   h->device = device;
   h->N = N;
-  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : 128);
+  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : kBigNP));
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
   h->horizon_dt = horizon_dt;
@@ -785,6 +809,7 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);
+  if(h->ws_big) (void)hipFree(h->ws_big);
   if(h->d_in) (void)hipFree(h->d_in);
   if(h->d_out) (void)hipFree(h->d_out);
   if(h->d_status) (void)hipFree(h->d_status);

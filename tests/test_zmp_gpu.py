@@ -183,6 +183,24 @@ def test_golden_vectors_n100_block_kernel(golden_zmp):
     assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
 
 
+def test_n200_hbm_tableau_kernel():
+    """128 < N <= 256: BASELINE.json configs[0] as worded (2 s horizon @ dt = 10 ms = 200 steps) -- the tableau no longer
+    fits LDS and lives in an HBM workspace.  Parity with the oracle, and a short stretch of the reference closed loop."""
+    mpc = LinearMpcZmp(1.0, 2.0, 0.01)
+    assert mpc.horizon_steps_ == 200
+    b = fx.make_zmp_batch(40, 200, 0.01, seed=31)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.01).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+    log, fin = fx.run_closed_loop(mpc.planOnce, end_time=3.0)
+    for rec in log:
+        assert np.all(rec["zmp"] - rec["zmin"] >= 0) and np.all(rec["zmax"] - rec["zmp"] >= 0)
+    with pytest.raises(_lib.CccError):
+        LinearMpcZmp(1.0, 2.0, 0.005)  # 400 steps: not built
+
+
 def test_reference_scenario_n100_closed_loop():
     """BASELINE.json configs[0]: TestLinearMpcZmp.cpp:15-126 exactly (2 s horizon @ 20 ms, sim_dt 5 ms, 10 s, two
     kicks) through planOnce(callback, ...): the reference's per-cycle and final property assertions, and the
