@@ -152,6 +152,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])  # HIP events on the launch stream
+    # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
+    # ccc_zmp_plan_batch (pinned staging, H2D, kernel, D2H); PCIe-inclusive, never the `value` above
+    h2h = []
+    if rank == 0:
+        for _ in range(12):
+            t1 = time.perf_counter()
+            mpc.planOnceBatch(batch["x0"], batch["zlim"], 0.005)
+            h2h.append(1e3 * (time.perf_counter() - t1))
+        h2h = h2h[2:]
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -167,6 +176,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "p50_ms": float(np.median(kern_ms)) if world == 1 else ms_per_step,
+            "p50_host_to_host_ms": float(np.median(h2h)),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
