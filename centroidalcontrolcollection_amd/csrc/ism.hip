@@ -94,11 +94,19 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
     __syncthreads();
     // tableau <- G, offsets d = w_zmp G[:, :N] r in the same pass (G symmetric: column i read as row i)
     double d = 0.0;
-    for(int j = 0; j < NP; ++j)
+    for(int j0 = 0; j0 < NP; j0 += 8)
     {
-      const double g = P.G[j * NP + i];
-      T[j * NP + i] = g;
-      d = fma(g, cb[j], d); // cb[j] = 0 for j >= N
+      double gv[8], cv[8];
+#pragma unroll
+      for(int q = 0; q < 8; ++q) gv[q] = P.G[(j0 + q) * NP + i];
+#pragma unroll
+      for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q]; // 0 for j >= N
+#pragma unroll
+      for(int q = 0; q < 8; ++q)
+      {
+        T[(j0 + q) * NP + i] = gv[q];
+        d = fma(gv[q], cv[q], d);
+      }
     }
     d *= P.w_zmp;
     const double lo = rng ? (zl - z0) - d : (iseq ? (cp - z0) - d : -kIsmInf);
@@ -174,13 +182,19 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        if(i == kk)
+        // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and cb
+        // are both LDS, so the compiler must assume they alias and would otherwise serialise load - store - load ...)
+        for(int j0 = 0; j0 < NP; j0 += 16)
         {
-          for(int j = 0; j < NP; ++j) T[j * NP + i] = s * cb[j] * rp;
-        }
-        else
-        {
-          for(int j = 0; j < NP; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+          double tv[16], cv[16];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * NP + i];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+#pragma unroll
+          for(int q = 0; q < 16; ++q) T[(j0 + q) * NP + i] = tv[q];
         }
         __syncthreads();
         T[kk * NP + i] = (i == kk) ? -rp : s * g;

@@ -127,16 +127,23 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       cb[i] = T[kp * NP + i];
       __syncthreads();
       const double rp = 1.0 / cb[kp];
-      if(i == kp)
-      {
-        for(int j = 0; j < nv; j++) T[j * NP + i] = cb[j] * rp;
-        T[kp * NP + i] = -rp;
-      }
-      else if(row)
+      if(row)
       {
         const double g = cb[i] * rp;
-        for(int j = 0; j < nv; j++) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
-        T[kp * NP + i] = g;
+        for(int j0 = 0; j0 < nv; j0 += 8)
+        {
+          double tv[8], cv[8];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) tv[q] = (i == kp) ? cv[q] * rp : fma(-g, cv[q], tv[q]);
+#pragma unroll
+          for(int q = 0; q < 8; ++q)
+            if(j0 + q < nv) T[(j0 + q) * NP + i] = tv[q];
+        }
+        T[kp * NP + i] = (i == kp) ? -rp : g;
       }
       __syncthreads();
     }
@@ -217,14 +224,21 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        if(i == kk)
-        {
-          for(int j = 0; j < nv; ++j) T[j * NP + i] = s * cb[j] * rp;
-        }
-        else if(row)
-        {
-          for(int j = 0; j < nv; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
-        }
+        // (chunks of 8: loads before stores -- T and cb are both LDS and would otherwise be assumed to alias)
+        if(row)
+          for(int j0 = 0; j0 < nv; j0 += 8)
+          {
+            double tv[8], cv[8];
+#pragma unroll
+            for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+#pragma unroll
+            for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+            for(int q = 0; q < 8; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+#pragma unroll
+            for(int q = 0; q < 8; ++q)
+              if(j0 + q < nv) T[(j0 + q) * NP + i] = tv[q];
+          }
         __syncthreads();
         if(row) T[kk * NP + i] = (i == kk) ? -rp : s * g;
         __syncthreads();

@@ -535,13 +535,20 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        if(i == kk)
+        // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and
+        // cb may both be LDS, so the compiler must assume they alias and would otherwise serialise load - store - load);
+        // thread kk writes row kk, stored as column i = kk of [j][i]
+        for(int j0 = 0; j0 < NP; j0 += 16)
         {
-          for(int j = 0; j < NP; ++j) T[j * NP + i] = s * cb[j] * rp; // row kk, stored as column i = kk of [j][i]
-        }
-        else
-        {
-          for(int j = 0; j < NP; ++j) T[j * NP + i] = fma(-g, cb[j], T[j * NP + i]);
+          double tv[16], cv[16];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * NP + i];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+          for(int q = 0; q < 16; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+#pragma unroll
+          for(int q = 0; q < 16; ++q) T[(j0 + q) * NP + i] = tv[q];
         }
         __syncthreads();
         // column kk (entries [kk][i]) and the pivot itself
