@@ -23,7 +23,9 @@
 
 namespace ccc_amd
 {
-constexpr int kIsmNP = 128; // rows per QP = threads per workgroup (N + 1 <= 128)
+constexpr int kIsmNP = 128;   // rows per QP (N + 1 <= 128)
+constexpr int kIsmParts = 4;  // threads per row: thread (part, i) updates a quarter of column i of the tableau
+constexpr int kIsmNT = kIsmNP * kIsmParts; // 512 threads = 8 wavefronts: the LDS latency of the rank-1 update is hidden
 constexpr double kIsmInf = __builtin_huge_val();
 
 struct IsmDev
@@ -48,7 +50,7 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm && v < kIsmInf);
   __syncthreads(); // red may still be read by the previous reduction
-  if((tid & 63) == 0)
+  if((tid & 63) == 0 && w < 2) // rows live in the first two wavefronts (part 0)
   {
     red->val[w] = wm;
     red->idx[w] = wi < 64 ? wi + 64 * w : kIsmNP;
@@ -63,7 +65,7 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
 
 // init [nqp][2] (capture_point, planned_zmp), ref [nqp][3][N] (ref zmp, zmin, zmax), zmp [nqp], vel [nqp][N] | null,
 // status [nqp] | null.  A "qp" is one axis of one instance.
-__global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, const double * __restrict__ init,
+__global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, const double * __restrict__ init,
                                                           const double * __restrict__ ref, double control_dt,
                                                           double * __restrict__ zmp, double * __restrict__ vel,
                                                           int * __restrict__ status)
@@ -72,14 +74,17 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double * T = smem;            // [NP][NP]
   double * cb = smem + NP * NP; // [NP] staging of the pivot row / of mu / of rho
-  IsmRed * red = reinterpret_cast<IsmRed *>(cb + NP);
-  const int i = threadIdx.x;
+  double * dp = cb + NP;        // [kIsmParts][NP] partial offsets
+  IsmRed * red = reinterpret_cast<IsmRed *>(dp + kIsmParts * NP);
+  const int i = threadIdx.x & (NP - 1), part = threadIdx.x / NP;
+  const bool lead = part == 0; // thread (0, i) owns row i: bounds, multiplier, flags
+  constexpr int JQ = NP / kIsmParts;
   const int N = P.N;
   const int maxpass = 20 * (N + 1) + 100;
 
   for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
   {
-    const bool rng = i < N, iseq = i == N, row = i <= N;
+    const bool rng = lead && i < N, iseq = lead && i == N, row = lead && i <= N;
     const double cp = init[qp * 2 + 0], z0 = init[qp * 2 + 1];
     double zr = 0, zl = 0, zh = 0;
     if(rng)
@@ -90,11 +95,12 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
     }
     const double r = rng ? zr - z0 : 0.0;
     __syncthreads();
-    cb[i] = r;
+    if(lead) cb[i] = r;
     __syncthreads();
-    // tableau <- G, offsets d = w_zmp G[:, :N] r in the same pass (G symmetric: column i read as row i)
+    // tableau <- G, offsets d = w_zmp G[:, :N] r in the same pass (G symmetric: column i read as row i); every part
+    // copies its quarter and contributes a partial sum
     double d = 0.0;
-    for(int j0 = 0; j0 < NP; j0 += 8)
+    for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 8)
     {
       double gv[8], cv[8];
 #pragma unroll
@@ -108,7 +114,9 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
         d = fma(gv[q], cv[q], d);
       }
     }
-    d *= P.w_zmp;
+    dp[part * NP + i] = d;
+    __syncthreads();
+    d = ((dp[i] + dp[NP + i]) + (dp[2 * NP + i] + dp[3 * NP + i])) * P.w_zmp;
     const double lo = rng ? (zl - z0) - d : (iseq ? (cp - z0) - d : -kIsmInf);
     const double hi = rng ? (zh - z0) - d : (iseq ? (cp - z0) - d : kIsmInf);
     const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
           ism_block_argmin(score > 0.0 ? -score : kIsmInf, red, m, cand);
           if(cand >= NP) break;
           p = cand;
-          if(i == cand)
+          if(lead && i == cand)
           {
             psig = (sl >= sh) ? 1.0 : -1.0;
             pd = (sl >= sh) ? lo : hi;
@@ -148,14 +156,14 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
         }
         else
         {
-          if(i == p) cb[0] = psig;
+          if(lead && i == p) cb[0] = psig;
           __syncthreads();
         }
         const double sig = cb[0];
         const double c = T[p * NP + i]; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-        const bool isp = (i == p);
+        const bool isp = lead && (i == p);
         const double num = isp ? psig * (pd - z) : -mu;
         const double den = isp ? c : dm;
         double ratio = (isp || blocking) ? num / den : kIsmInf;
@@ -178,13 +186,13 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
         if(isp) mu += sig * t;
         // pivot on row/column kk
         const double v = T[kk * NP + i];
-        cb[i] = v;
+        if(lead) cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
         // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and cb
         // are both LDS, so the compiler must assume they alias and would otherwise serialise load - store - load ...)
-        for(int j0 = 0; j0 < NP; j0 += 16)
+        for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 16)
         {
           double tv[16], cv[16];
 #pragma unroll
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
           for(int q = 0; q < 16; ++q) T[(j0 + q) * NP + i] = tv[q];
         }
         __syncthreads();
-        T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        if(lead) T[kk * NP + i] = (i == kk) ? -rp : s * g;
         __syncthreads();
         if(isadd)
         {
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
         }
         else
         {
-          if(i == kk)
+          if(lead && i == kk)
           {
             inW = false;
             mu = 0.0;
@@ -228,19 +236,19 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
       // closing refinement against the untouched G (see csrc/zmp.hip): rho = d_W - (G mu)_W, mu_W -= T_WW rho,
       // z = G mu recomputed; re-open if a row turns out violated
       __syncthreads();
-      cb[i] = inW ? mu : 0.0;
+      if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       double acc = 0.0;
       for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
       const double rho = inW ? dact - acc : 0.0;
       __syncthreads();
-      cb[i] = rho;
+      if(lead) cb[i] = rho;
       __syncthreads();
       double tr = 0.0;
       for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
       if(inW) mu -= tr;
       __syncthreads();
-      cb[i] = inW ? mu : 0.0;
+      if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       acc = 0.0;
       for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
     if(st == CCC_STATUS_SOLVED)
     {
       __syncthreads();
-      cb[i] = inW ? mu : 0.0;
+      if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       double acc = 0.0;
       for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
@@ -266,9 +274,9 @@ __global__ __launch_bounds__(kIsmNP) void ism_plan_kernel(IsmDev P, long nqp, co
     }
     // outputs: u = H^-1 Ct'(mu + w_zmp [r; 0]); zmp = clamp(z0 + control_dt u0, zmin0, zmax0)  (:93-101)
     __syncthreads();
-    cb[i] = row ? mu + P.w_zmp * r : 0.0;
+    if(lead) cb[i] = row ? mu + P.w_zmp * r : 0.0;
     __syncthreads();
-    if(i == 0)
+    if(lead && i == 0)
     {
       double u0 = 0.0;
       for(int k = 0; k <= N; ++k) u0 = fma(P.Wc[k], cb[k], u0);
@@ -450,7 +458,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(n == 0) return CCC_OK;
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
   CCC_HIP_CHECK(hipSetDevice(h->device));
-  const size_t lds = ((size_t)kIsmNP * kIsmNP + kIsmNP) * sizeof(double) + sizeof(IsmRed);
+  const size_t lds = ((size_t)kIsmNP * kIsmNP + kIsmNP + kIsmParts * kIsmNP) * sizeof(double) + sizeof(IsmRed);
   static bool attr_set = false;
   if(!attr_set)
   {
@@ -461,7 +469,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   const int64_t nqp = 2 * n;
   const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
   IsmDev P{h->N, h->dG, h->dWc, h->w_zmp, h->horizon_dt};
-  hipLaunchKernelGGL(ism_plan_kernel, dim3(grid), dim3(kIsmNP), lds, reinterpret_cast<hipStream_t>(stream), P,
+  hipLaunchKernelGGL(ism_plan_kernel, dim3(grid), dim3(kIsmNT), lds, reinterpret_cast<hipStream_t>(stream), P,
                      (long)nqp, init, ref, control_dt, zmp, vel, status);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
