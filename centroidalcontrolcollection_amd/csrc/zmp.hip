@@ -412,7 +412,7 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm);
   __syncthreads(); // red may still be read by the previous reduction
-  if((tid & 63) == 0)
+  if((tid & 63) == 0 && w < NP / 64) // rows live in the first NP / 64 wavefronts (part 0)
   {
     red->val[w] = wm;
     red->idx[w] = wi < 64 ? wi + 64 * w : NP;
@@ -433,8 +433,10 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
   imin = bi;
 }
 
-template<int NP, bool HBM>
-__global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+// PARTS threads per row: thread (part, i) updates its share of column i in the rank-1 update (more wavefronts in flight
+// hide the LDS latency); thread (0, i) owns row i (bounds, multiplier, flags).
+template<int NP, bool HBM, int PARTS>
+__global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                             const double * __restrict__ zlim, double control_dt,
                                                             double * __restrict__ zmp, double * __restrict__ jerk,
                                                             int * __restrict__ status, double * __restrict__ ws)
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
   double * T = HBM ? ws + (size_t)blockIdx.x * NP * NP : smem; // [NP][NP]
   double * cb = HBM ? smem : smem + NP * NP;                   // [NP] staging of the pivot row / of mu / of rho
   BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
-  const int i = threadIdx.x;
+  const int i = threadIdx.x % NP, part = threadIdx.x / NP;
+  const bool lead = part == 0;
+  constexpr int JQ = NP / PARTS;
   const int N = P.N;
   const double a0 = P.A[i * 3 + 0], a1 = P.A[i * 3 + 1], a2 = P.A[i * 3 + 2];
   const double bi = P.b[i];
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
 
   for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
   {
-    const bool row = i < N;
+    const bool row = lead && i < N;
     const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
     double zl = 0, zh = 0;
     if(row)
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
     int st = CCC_STATUS_SOLVED;
     if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
 
-    for(int j = 0; j < NP; ++j) T[j * NP + i] = P.G[j * NP + i];
+    for(int j = part * JQ; j < (part + 1) * JQ; ++j) T[j * NP + i] = P.G[j * NP + i];
     __syncthreads();
 
     double z = 0.0, mu = 0.0, dact = 0.0;
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
           m = -m;
           if(!(m > 0.0)) break;
           p = cand;
-          if(i == cand)
+          if(lead && i == cand)
           {
             psig = (sl >= sh) ? 1.0 : -1.0;
             pd = (sl >= sh) ? lo : hi;
@@ -502,14 +506,14 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
         }
         else
         {
-          if(i == p) cb[0] = psig;
+          if(lead && i == p) cb[0] = psig;
           __syncthreads();
         }
         const double sig = cb[0];
         const double c = T[p * NP + i]; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-        const bool isp = (i == p);
+        const bool isp = lead && (i == p);
         const double num = isp ? psig * (pd - z) : -mu;
         const double den = isp ? c : dm;
         const double ratio = (isp || blocking) ? num / den : kInf;
@@ -531,14 +535,14 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
         if(isp) mu += sig * t;
         // pivot on row/column kk
         const double v = T[kk * NP + i];
-        cb[i] = v;
+        if(lead) cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
         // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and
         // cb may both be LDS, so the compiler must assume they alias and would otherwise serialise load - store - load);
         // thread kk writes row kk, stored as column i = kk of [j][i]
-        for(int j0 = 0; j0 < NP; j0 += 16)
+        for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 16)
         {
           double tv[16], cv[16];
 #pragma unroll
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
         }
         __syncthreads();
         // column kk (entries [kk][i]) and the pivot itself
-        T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        if(lead) T[kk * NP + i] = (i == kk) ? -rp : s * g;
         __syncthreads();
         if(isadd)
         {
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
         }
         else
         {
-          if(i == kk)
+          if(lead && i == kk)
           {
             inW = false;
             mu = 0.0;
@@ -582,19 +586,19 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
       if(st != CCC_STATUS_SOLVED) break;
       // closing refinement (see zmp_plan_kernel)
       __syncthreads();
-      cb[i] = inW ? mu : 0.0;
+      if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       double acc = 0.0;
       for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
       const double rho = inW ? dact - acc : 0.0;
       __syncthreads();
-      cb[i] = rho;
+      if(lead) cb[i] = rho;
       __syncthreads();
       double tr = 0.0;
       for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
       if(inW) mu -= tr;
       __syncthreads();
-      cb[i] = inW ? mu : 0.0;
+      if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       acc = 0.0;
       for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
@@ -607,9 +611,9 @@ __global__ __launch_bounds__(NP) void zmp_plan_block_kernel(ZmpDev P, long nqp, 
 
     // outputs
     __syncthreads();
-    cb[i] = row ? mu : 0.0;
+    if(lead) cb[i] = row ? mu : 0.0;
     __syncthreads();
-    if(i == 0)
+    if(lead && i == 0)
     {
       double u0 = 0.0;
       for(int r = 0; r < N; ++r) u0 = fma(P.b[r], cb[r], u0);
@@ -750,8 +754,8 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     if(!h->ws_big) CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
     const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed);
     const int grid = (int)std::min<int64_t>(nqp, blocks);
-    hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true>), dim3(grid), dim3(kBigNP), lds, stream, P, (long)nqp, x0,
-                       zlim, control_dt, zmp, jerk, status, h->ws_big);
+    hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
+                       x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
@@ -759,13 +763,13 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   static bool attr_set = false;
   if(!attr_set)
   {
-    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel<kBlkNP, false>),
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel<kBlkNP, false, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
-  hipLaunchKernelGGL((zmp_plan_block_kernel<kBlkNP, false>), dim3(grid), dim3(kBlkNP), lds, stream, P, (long)nqp, x0,
-                     zlim, control_dt, zmp, jerk, status, (double *)nullptr);
+  hipLaunchKernelGGL((zmp_plan_block_kernel<kBlkNP, false, 4>), dim3(grid), dim3(kBlkNP * 4), lds, stream, P, (long)nqp,
+                     x0, zlim, control_dt, zmp, jerk, status, (double *)nullptr);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
