@@ -57,7 +57,6 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
 {
   constexpr int NP = kZNP;
   __shared__ double T[NP * NP];  // sweep tableau, [j][i] (i fastest)
-  __shared__ double Hs[NP * NP]; // the untouched H
   __shared__ double cb[NP];
   __shared__ double res[NP];
   __shared__ int svar[NP];
@@ -94,24 +93,25 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     const int si = row ? svar[i] : 0;
     // H (closed form) and g
     double gi = 0.0;
+    // H(l, i) in closed form: w_pos c^2 sum_{j=J}^{N-1} (j - a)(j - bb) + w_force delta, J = max(s_l, s_i), with
+    // S1(m) = sum_{j<m} j, S2(m) = sum_{j<m} j^2.  Cheap enough that the closing refinement re-evaluates it instead of
+    // keeping an untouched copy of H in LDS (32 KB: the difference between two and four workgroups per CU).
+    auto h_entry = [&](int l, int sl) {
+      const double a = si - 0.5, bb = sl - 0.5;
+      const double J = si > sl ? si : sl;
+      const double Nn = N;
+      const double s1 = 0.5 * (Nn * (Nn - 1.0) - J * (J - 1.0));
+      const double s2 = ((Nn - 1.0) * Nn * (2.0 * Nn - 1.0) - (J - 1.0) * J * (2.0 * J - 1.0)) / 6.0;
+      return P.w_pos * (c * c) * (s2 - (a + bb) * s1 + a * bb * (Nn - J)) + ((l == i) ? P.w_force : 0.0);
+    };
     {
       const double a = si - 0.5;
       for(int l = 0; l < NP; l++)
       {
-        double h = (l == i) ? 1.0 : 0.0; // identity on the padding
-        if(row && l < nv)
-        {
-          const int sl = svar[l];
-          const double bb = sl - 0.5;
-          const double J = si > sl ? si : sl;
-          // sum_{j=J}^{N-1} (j - a)(j - bb) with S1(m) = sum_{j<m} j, S2(m) = sum_{j<m} j^2
-          const double Nn = N;
-          const double s1 = 0.5 * (Nn * (Nn - 1.0) - J * (J - 1.0));
-          const double s2 = ((Nn - 1.0) * Nn * (2.0 * Nn - 1.0) - (J - 1.0) * J * (2.0 * J - 1.0)) / 6.0;
-          h = P.w_pos * (c * c) * (s2 - (a + bb) * s1 + a * bb * (Nn - J)) + ((l == i) ? P.w_force : 0.0);
-        }
-        T[l * NP + i] = h;
-        Hs[l * NP + i] = h;
+        // step of variable l = what lane l holds in si (a v_readlane: an LDS load of svar[l] here would have to wait for
+        // the stores of the previous trip, which the compiler must assume to alias)
+        const int sl = __builtin_amdgcn_readlane(si, l);
+        T[l * NP + i] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
       }
       if(row)
       {
@@ -151,11 +151,20 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     cb[i] = row ? gi : 0.0;
     __syncthreads();
     double lam0 = 0.0;
-    for(int j = 0; j < nv; j++)
+    for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores (LDS aliasing, see the pivot loop)
     {
-      const double t = T[j * NP + i];
-      lam0 = fma(t, cb[j], lam0);
-      T[j * NP + i] = -t;
+      double tv[8], cv[8];
+#pragma unroll
+      for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+#pragma unroll
+      for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+      for(int q = 0; q < 8; ++q)
+        if(j0 + q < nv)
+        {
+          lam0 = fma(tv[q], cv[q], lam0);
+          T[(j0 + q) * NP + i] = -tv[q];
+        }
     }
     __syncthreads();
     const double lo = row ? P.fmin - lam0 : -kZInf;
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       cb[i] = row ? lam0 + z : 0.0;
       __syncthreads();
       double hl = gi;
-      for(int j = 0; j < nv; ++j) hl = fma(Hs[j * NP + i], cb[j], hl);
+      for(int j = 0; j < nv; ++j) hl = fma(h_entry(j, __builtin_amdgcn_readlane(si, j)), cb[j], hl);
       const double r = (row && !inW) ? -hl : 0.0;
       __syncthreads();
       cb[i] = r;
@@ -377,7 +386,7 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   CCC_HIP_CHECK(hipSetDevice(h->device));
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
-  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 16);
+  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 32);
   hipLaunchKernelGGL(z_plan_kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
