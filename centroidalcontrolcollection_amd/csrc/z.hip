@@ -56,10 +56,15 @@ __device__ __forceinline__ void z_wave_argmin(double v, double & vmin, int & imi
 __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n)
 {
   constexpr int NP = kZNP;
-  __shared__ double T[NP * NP];  // sweep tableau, [j][i] (i fastest)
-  __shared__ double cb[NP];
-  __shared__ double res[NP];
-  __shared__ int svar[NP];
+  // sweep tableau [j][i] (i fastest) with the odd row stride NS = N | 1 (bank-conflict free, no padding to 64: at N = 40
+  // 13 KB instead of 32 KB, i.e. eleven resident workgroups per CU instead of four); lanes >= N never write it, and
+  // their (ignored) reads stay inside the NP doubles of slack behind it
+  extern __shared__ __attribute__((aligned(16))) double zsm[];
+  const int NS = P.N | 1;
+  double * T = zsm;
+  double * cb = zsm + (P.N + 8) * NS + NP; // 8 rows + NP doubles of slack: chunked loops read (and discard) past row N - 1
+  double * res = cb + NP;
+  int * svar = reinterpret_cast<int *>(res + NP);
   const int i = threadIdx.x;
   const int N = P.N;
   const double c = P.dt * P.dt / P.mass;
@@ -106,12 +111,12 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     };
     {
       const double a = si - 0.5;
-      for(int l = 0; l < NP; l++)
+      for(int l = 0; l < N; l++)
       {
         // step of variable l = what lane l holds in si (a v_readlane: an LDS load of svar[l] here would have to wait for
         // the stores of the previous trip, which the compiler must assume to alias)
         const int sl = __builtin_amdgcn_readlane(si, l);
-        T[l * NP + i] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
+        if(i < N) T[l * NS + i] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
       }
       if(row)
       {
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     // T <- -H^-1 by sweeping every variable
     for(int kp = 0; kp < nv; kp++)
     {
-      cb[i] = T[kp * NP + i];
+      cb[i] = T[kp * NS + i];
       __syncthreads();
       const double rp = 1.0 / cb[kp];
       if(row)
@@ -134,16 +139,16 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
         {
           double tv[8], cv[8];
 #pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+          for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
 #pragma unroll
           for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
           for(int q = 0; q < 8; ++q) tv[q] = (i == kp) ? cv[q] * rp : fma(-g, cv[q], tv[q]);
 #pragma unroll
           for(int q = 0; q < 8; ++q)
-            if(j0 + q < nv) T[(j0 + q) * NP + i] = tv[q];
+            if(j0 + q < nv) T[(j0 + q) * NS + i] = tv[q];
         }
-        T[kp * NP + i] = (i == kp) ? -rp : g;
+        T[kp * NS + i] = (i == kp) ? -rp : g;
       }
       __syncthreads();
     }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     {
       double tv[8], cv[8];
 #pragma unroll
-      for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+      for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
 #pragma unroll
       for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
         if(j0 + q < nv)
         {
           lam0 = fma(tv[q], cv[q], lam0);
-          T[(j0 + q) * NP + i] = -tv[q];
+          if(row) T[(j0 + q) * NS + i] = -tv[q];
         }
     }
     __syncthreads();
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           }
         }
         const double sig = __shfl(psig, p);
-        const double cc = T[p * NP + i]; // column p = row p (symmetric)
+        const double cc = T[p * NS + i]; // column p = row p (symmetric)
         const double dm = -sig * cc;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = (i == p);
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           z = fma(sig * t, cc, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = T[kk * NP + i];
+        const double v = T[kk * NS + i];
         __syncthreads();
         cb[i] = v;
         __syncthreads();
@@ -239,17 +244,17 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           {
             double tv[8], cv[8];
 #pragma unroll
-            for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NP + i];
+            for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
 #pragma unroll
             for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
             for(int q = 0; q < 8; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
 #pragma unroll
             for(int q = 0; q < 8; ++q)
-              if(j0 + q < nv) T[(j0 + q) * NP + i] = tv[q];
+              if(j0 + q < nv) T[(j0 + q) * NS + i] = tv[q];
           }
         __syncthreads();
-        if(row) T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        if(row) T[kk * NS + i] = (i == kk) ? -rp : s * g;
         __syncthreads();
         if(isadd)
         {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       if(row && !inW)
       {
         double dz = 0.0;
-        for(int j = 0; j < nv; ++j) dz = fma(T[j * NP + i], cb[j], dz);
+        for(int j = 0; j < nv; ++j) dz = fma(T[j * NS + i], cb[j], dz);
         z += dz;
       }
       const double sl = (lo - z) - tl, sh = (z - hi) - th;
@@ -386,8 +391,9 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   CCC_HIP_CHECK(hipSetDevice(h->device));
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
-  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 32);
-  hipLaunchKernelGGL(z_plan_kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
+  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 64);
+  const size_t lds = ((size_t)(h->N + 8) * (h->N | 1) + 3 * kZNP) * sizeof(double) + kZNP * sizeof(int);
+  hipLaunchKernelGGL(z_plan_kernel, dim3(grid), dim3(kZNP), lds, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
