@@ -89,13 +89,20 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # (the modulo and the backend override exist to exercise the multi-rank path on a single-GPU box:
+    #  CCC_BENCH_BACKEND=gloo with two ranks sharing cuda:0; on the 8-GPU node both are no-ops)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CCC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload != "zmp":
         import bench_secondary
@@ -113,19 +120,34 @@ def main():
     batch = fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + rank)
     x0 = torch.from_numpy(batch["x0"]).to(dev)
     zlim = torch.from_numpy(batch["zlim"]).to(dev)
-    zmp = torch.empty((n, 2), dtype=torch.float64, device=dev)
+    # two output buffers: the all-gather of step k (RCCL's own stream) overlaps the kernel of step k + 1
+    zbuf = [torch.empty((n, 2), dtype=torch.float64, device=dev) for _ in range(2)]
+    zmp = zbuf[0]
     status = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    gathered = torch.empty((world * n, 2), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = [torch.empty((world * n, 2), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
     stream = torch.cuda.current_stream(dev)
+    counter = [0]
 
     def step(ev=None):
+        k = counter[0] & 1
+        counter[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()  # the stream waits until the gather that still reads zbuf[k] is done
+            pending[k] = None
         if ev is not None:
             ev[0].record(stream)
-        mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, None, stream)
+        mpc.plan_batch_device(x0, zlim, 0.005, zbuf[k], None, None, stream)
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, zmp)
+            pending[k] = dist.all_gather_into_tensor(gathered[k], zbuf[k], async_op=True)
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     # one untimed launch with the status array for pivot statistics / status check
     mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, status, stream)
@@ -136,6 +158,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
@@ -143,6 +166,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(evs[k])
+    drain()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

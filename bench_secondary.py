@@ -159,7 +159,8 @@ def run(args, rank, world, local_rank, dist):
     make = dict(xy=_xy, ism=_ism, z=_z, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
-    gathered = torch.empty((world,) + tuple(w["out"].shape), dtype=w["out"].dtype, device=dev) if world > 1 else None
+    gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)
+                if world > 1 else None)
 
     def step(ev=None):
         if ev is not None:

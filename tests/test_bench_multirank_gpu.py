@@ -1,0 +1,38 @@
+"""The multi-rank path of bench.py on a single-GPU box: two ranks share cuda:0 and exchange through gloo
+(CCC_BENCH_BACKEND=gloo; on the 8-GPU node the driver uses the default RCCL backend, one rank per GPU).  Guards the
+launch protocol, the double-buffered all-gather and the JSON contract for the headline and one secondary workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(port, extra):
+    env = dict(os.environ, CCC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_headline_two_ranks():
+    d = _run(29611, ["--steps", "6", "--warmup", "2", "--batch", "4096"])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["collective"] == "all_gather(zmp)" and d["unsolved"] == 0
+    assert d["value"] > 0 and abs(d["value"] - 2 * 4096 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(d["roofline"])
+
+
+def test_secondary_workload_two_ranks():
+    d = _run(29612, ["--workload", "z", "--steps", "4", "--warmup", "1", "--batch", "2048"])
+    assert d["n_gpus"] == 2 and d["unsolved"] == 0 and d["value"] > 0
+    assert d["config"]["collective"].startswith("all_gather")
