@@ -141,8 +141,8 @@ template<int S, int M>
 struct Mem
 {
   double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
-  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * (M + 1)], QuuF[M * (M + 1)]; // rows padded to M + 1: bank-conflict free
-  double T1[S * S], T2[S * M], Lf[M * (M + 1)], K[M * S];
+  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * M], QuuF[M * M];
+  double T1[S * S], T2[S * M], Lf[M * M], K[M * S];
   double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
   double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
@@ -267,7 +267,9 @@ CCC_DDP_FN double lane_value(double v, int k)
 template<int S, int M>
 struct Solver
 {
-  static constexpr int LQ = M + 1; // row stride of the M x M matrices Quu, QuuF, Lf in LDS (padded)
+  // row stride of the M x M matrices Quu, QuuF, Lf in LDS.  (Padding it to M + 1 removes their bank conflicts but
+  // costs 384 B, which is the difference between eight and seven resident workgroups per CU -- not worth it.)
+  static constexpr int LQ = M;
 
   const Params & P;
   const Instance & I;
