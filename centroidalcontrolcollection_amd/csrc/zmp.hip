@@ -412,7 +412,7 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm);
   __syncthreads(); // red may still be read by the previous reduction
-  if((tid & 63) == 0 && w < NP / 64) // rows live in the first NP / 64 wavefronts (part 0)
+  if((tid & 63) == 0 && w < (NP + 63) / 64) // rows live in the first wavefronts (part 0)
   {
     red->val[w] = wm;
     red->idx[w] = wi < 64 ? wi + 64 * w : NP;
@@ -421,7 +421,7 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
   double best = red->val[0];
   int bi = red->idx[0];
 #pragma unroll
-  for(int k = 1; k < NP / 64; ++k)
+  for(int k = 1; k < (NP + 63) / 64; ++k)
   {
     const double a = red->val[k];
     const int ia = red->idx[k];
@@ -542,17 +542,19 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
         // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and
         // cb may both be LDS, so the compiler must assume they alias and would otherwise serialise load - store - load);
         // thread kk writes row kk, stored as column i = kk of [j][i]
-        for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 16)
+        constexpr int CH = (JQ % 16 == 0) ? 16 : 8;
+        static_assert(JQ % CH == 0, "a part's share of a column must be whole chunks");
+        for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += CH)
         {
-          double tv[16], cv[16];
+          double tv[CH], cv[CH];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * NP + i];
+          for(int q = 0; q < CH; ++q) tv[q] = T[(j0 + q) * NP + i];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) cv[q] = cb[j0 + q];
+          for(int q = 0; q < CH; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+          for(int q = 0; q < CH; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
 #pragma unroll
-          for(int q = 0; q < 16; ++q) T[(j0 + q) * NP + i] = tv[q];
+          for(int q = 0; q < CH; ++q) T[(j0 + q) * NP + i] = tv[q];
         }
         __syncthreads();
         // column kk (entries [kk][i]) and the pivot itself
@@ -759,17 +761,23 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
-  const size_t lds = ((size_t)kBlkNP * kBlkNP + kBlkNP) * sizeof(double) + sizeof(BlockRed);
-  static bool attr_set = false;
-  if(!attr_set)
-  {
-    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_block_kernel<kBlkNP, false, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
-  hipLaunchKernelGGL((zmp_plan_block_kernel<kBlkNP, false, 4>), dim3(grid), dim3(kBlkNP * 4), lds, stream, P, (long)nqp,
-                     x0, zlim, control_dt, zmp, jerk, status, (double *)nullptr);
+  // LDS-resident tableau sized to the horizon: 96 x 96 (74 KB, two workgroups per CU) or 128 x 128 (one).  (A 64 x 64
+  // instantiation for 33..64 steps was measured too: the register kernel K1' is 20 % faster there.)
+  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 16);
+  auto go = [&](auto kernel, int np) -> int {
+    const size_t lds = ((size_t)np * np + np) * sizeof(double) + sizeof(BlockRed);
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(np * 4), lds, stream, P, (long)nqp, x0, zlim, control_dt, zmp, jerk, status,
+                       (double *)nullptr);
+    return CCC_OK;
+  };
+  int rc;
+  if(h->NP == 96)
+    rc = go(&zmp_plan_block_kernel<96, false, 4>, 96);
+  else
+    rc = go(&zmp_plan_block_kernel<kBlkNP, false, 4>, kBlkNP);
+  if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
@@ -790,7 +798,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   ccc_zmp * h = new ccc_zmp();
   h->device = device;
   h->N = N;
-  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : kBigNP));
+  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 96 ? 96 : (N <= 128 ? 128 : kBigNP)));
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
   h->horizon_dt = horizon_dt;
