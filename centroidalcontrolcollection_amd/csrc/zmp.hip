@@ -637,6 +637,220 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     (void)bi;
   }
 }
+// ---------------------------------------------------------------------------------------------
+// K1w.  Mid-size horizons (32 < N <= 64): one QP (axis) per WAVEFRONT, lane i = column i of the sweep tableau, which
+// lives in LDS as NR x NR doubles (NR = N rounded up to 8) with the odd row stride NR + 1.  NR is a template parameter:
+// every tableau access is then `ds_read/write_b64 base, offset:imm` off ONE address register, the update loop is
+// straight-line (read 8 rows, 8 FMAs, write 8 rows), and the padding rows/columns are zero and stay zero under the
+// update, so nothing in the loop is predicated.  The pivot row and column are written afterwards (lane j writes
+// (kk, j) and (j, kk): the stride is odd, so the column write is bank-conflict free).  Same iteration as the kernels
+// above; replaces the register kernel K1' (64-double rows: 220 VGPRs and spills).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_argmin64(double v, double & vmin, int & imin)
+{
+  vmin = WaveGroup<64>::min(v);
+  imin = WaveGroup<64>::first(v == vmin && v < kInf);
+}
+
+template<int NR>
+__global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, long nqp, const double * __restrict__ x0,
+                                                           const double * __restrict__ zlim, double control_dt,
+                                                           double * __restrict__ zmp, double * __restrict__ jerk,
+                                                           int * __restrict__ status)
+{
+  constexpr int NS = NR + 1;
+  __shared__ __attribute__((aligned(16))) double cb[64];
+  __shared__ double Tm[NR * NS + 64]; // + slack: lanes >= NR address (and never use) up to 63 - NR doubles past the end
+  const int N = P.N;
+  const int i = threadIdx.x;
+  const bool row = i < N;
+  const bool col = i < NR; // lanes NR..63 (NR < 64) own no column
+  double * Tc = Tm + i;    // column i
+  const double a0 = row ? P.A[i * 3 + 0] : 0.0, a1 = row ? P.A[i * 3 + 1] : 0.0, a2 = row ? P.A[i * 3 + 2] : 0.0;
+  const int maxpass = 20 * N + 100;
+
+  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  {
+    const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
+    double zl = 0, zh = 0;
+    if(row)
+    {
+      zl = zlim[qp * 2 * N + i];
+      zh = zlim[qp * 2 * N + N + i];
+    }
+    const double fr = a0 * px + a1 * vx + a2 * ax;
+    const double lo = row ? zl - fr : -kInf;
+    const double hi = row ? zh - fr : kInf;
+    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
+    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
+    int st = CCC_STATUS_SOLVED;
+    if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
+#pragma unroll
+    for(int j = 0; j < NR; ++j)
+      if(col) Tc[j * NS] = (row && j < N) ? P.G[j * GS + i] : 0.0;
+    __syncthreads();
+
+    double z = 0.0, mu = 0.0, dact = 0.0;
+    bool inW = false;
+    int p = 0;
+    double psig = 0.0, pd = 0.0;
+    bool done = st != CCC_STATUS_SOLVED;
+    bool need_select = true;
+    int passes = 0;
+    for(int round = 0; round < 3 && !done; ++round)
+    {
+      while(!done)
+      {
+        if(need_select)
+        {
+          const double sl = (lo - z) - tl, sh = (z - hi) - th;
+          const double score = (inW || !row) ? -kInf : fmax(sl, sh);
+          double m;
+          int cand;
+          wave_argmin64(score > 0.0 ? -score : kInf, m, cand);
+          if(cand >= 64) break;
+          p = cand;
+          if(i == cand)
+          {
+            psig = (sl >= sh) ? 1.0 : -1.0;
+            pd = (sl >= sh) ? lo : hi;
+          }
+        }
+        const double sig = __shfl(psig, p);
+        const double c = col ? Tm[p * NS + i] : 0.0; // row p = column p (symmetric)
+        const double dm = -sig * c;
+        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const bool isp = (i == p);
+        const double num = isp ? psig * (pd - z) : -mu;
+        const double den = isp ? c : dm;
+        const double ratio = (isp || blocking) ? num / den : kInf;
+        double t;
+        int kk;
+        wave_argmin64(ratio, t, kk);
+        if(kk >= 64)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+          break;
+        }
+        const bool isadd = (kk == p);
+        const double s = isadd ? 1.0 : -1.0;
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, c, z);
+        if(isp) mu += sig * t;
+        // pivot on row/column kk
+        const double v = col ? Tm[kk * NS + i] : 0.0;
+        cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+        if(col)
+#pragma unroll
+        for(int j0 = 0; j0 < NR; j0 += 8) // chunks: loads before stores (T and cb are both LDS: assumed to alias)
+        {
+          double tv[8], cv[8];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
+#pragma unroll
+          for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
+#pragma unroll
+          for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
+        }
+        __syncthreads();
+        {
+          const double e = (i == kk) ? -rp : s * g;
+          if(col)
+          {
+            Tm[kk * NS + i] = e;
+            Tm[i * NS + kk] = e;
+          }
+        }
+        __syncthreads();
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(++passes > maxpass)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+        }
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      // closing refinement (see zmp_plan_kernel)
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      double acc = 0.0;
+#pragma unroll 8
+      for(int j = 0; j < NR; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
+      const double rho = inW ? dact - acc : 0.0;
+      __syncthreads();
+      cb[i] = rho;
+      __syncthreads();
+      double tr = 0.0;
+#pragma unroll
+      for(int j = 0; j < NR; ++j) tr = fma(Tc[j * NS], cb[j], tr); // lanes >= NR: unused
+      if(inW) mu -= tr;
+      __syncthreads();
+      cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      acc = 0.0;
+#pragma unroll 8
+      for(int j = 0; j < NR; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
+      z = inW ? dact : acc;
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
+      need_select = true;
+      if(!reopen) break;
+    }
+    // outputs
+    __syncthreads();
+    cb[i] = row ? mu : 0.0;
+    __syncthreads();
+    if(i == 0)
+    {
+      double u0 = 0.0;
+      for(int r = 0; r < N; ++r) u0 = fma(P.b[r], cb[r], u0);
+      const double cdt = control_dt < 0 ? P.dt : control_dt;
+      const double com_acc = ax + cdt * u0;
+      const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
+      double zv = com_pos + P.c2 * com_acc;
+      zv = zv < zl ? zl : (zh < zv ? zh : zv);
+      zmp[qp] = zv;
+      if(status) status[qp] = (passes << 8) | st;
+    }
+    if(jerk && row)
+    {
+      double uj = 0.0;
+      for(int r = i; r < N; ++r) uj = fma(P.b[r - i], cb[r], uj);
+      jerk[qp * N + i] = uj;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kZmpWaveMaxN = 64; // above: the tableau leaves one wavefront per SIMD and K1' is faster
+
 } // namespace ccc_amd
 
 // =============================================================================================
@@ -871,6 +1085,25 @@ extern "C" int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double 
   CCC_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if(h->NP == 32) return launch<32, 4>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
+  if(h->NP == 64 && h->N <= kZmpWaveMaxN)
+  {
+    const int64_t nqp = 2 * n;
+    const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 64);
+    ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+    auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, P, 64, (long)nqp, x0, zlim, control_dt, zmp, jerk, status);
+    };
+    if(h->N <= 40)
+      go(zmp_plan_wave_kernel<40>);
+    else if(h->N <= 48)
+      go(zmp_plan_wave_kernel<48>);
+    else if(h->N <= 56)
+      go(zmp_plan_wave_kernel<56>);
+    else
+      go(zmp_plan_wave_kernel<64>);
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  }
   if(h->NP == 64) return launch<64, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
   return launch_block(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
 }
