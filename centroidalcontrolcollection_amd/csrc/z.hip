@@ -53,20 +53,24 @@ __device__ __forceinline__ void z_wave_argmin(double v, double & vmin, int & imi
   imin = WaveGroup<64>::first(v == vmin && v < kZInf);
 }
 
+template<int NR>
 __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n)
 {
   constexpr int NP = kZNP;
-  // sweep tableau [j][i] (i fastest) with the odd row stride NS = N | 1 (bank-conflict free, no padding to 64: at N = 40
-  // 13 KB instead of 32 KB, i.e. eleven resident workgroups per CU instead of four); lanes >= N never write it, and
-  // their (ignored) reads stay inside the NP doubles of slack behind it
-  extern __shared__ __attribute__((aligned(16))) double zsm[];
-  const int NS = P.N | 1;
-  double * T = zsm;
-  double * cb = zsm + (P.N + 8) * NS + NP; // 8 rows + NP doubles of slack: chunked loops read (and discard) past row N - 1
-  double * res = cb + NP;
-  int * svar = reinterpret_cast<int *>(res + NP);
+  // sweep tableau [j][i] (i fastest), NR x NR doubles (NR = N rounded up to 8; a template parameter, so that every
+  // access is `ds_read/write_b64 base, offset:imm` off one address register) with the odd row stride NR + 1: row AND
+  // column accesses are bank-conflict free, and at N = 40 the tableau takes 13 KB instead of 32 KB (eleven resident
+  // workgroups per CU instead of four).  Padding rows/columns hold the identity and stay so under the sweeps; lanes
+  // >= NR own no column.
+  constexpr int NS = NR + 1;
+  __shared__ __attribute__((aligned(16))) double cb[NP];
+  __shared__ double res[NP];
+  __shared__ int svar[NP];
+  __shared__ double T[NR * NS];
   const int i = threadIdx.x;
   const int N = P.N;
+  const bool col = i < NR;
+  double * Tc = T + i; // column i
   const double c = P.dt * P.dt / P.mass;
 
   for(long b = blockIdx.x; b < n; b += gridDim.x)
@@ -111,12 +115,12 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     };
     {
       const double a = si - 0.5;
-      for(int l = 0; l < N; l++)
+      for(int l = 0; l < NR; l++)
       {
         // step of variable l = what lane l holds in si (a v_readlane: an LDS load of svar[l] here would have to wait for
         // the stores of the previous trip, which the compiler must assume to alias)
         const int sl = __builtin_amdgcn_readlane(si, l);
-        if(i < N) T[l * NS + i] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
+        if(col) Tc[l * NS] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
       }
       if(row)
       {
@@ -129,26 +133,30 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     // T <- -H^-1 by sweeping every variable
     for(int kp = 0; kp < nv; kp++)
     {
-      cb[i] = T[kp * NS + i];
+      const double v = col ? T[kp * NS + i] : 0.0;
+      cb[i] = v;
       __syncthreads();
       const double rp = 1.0 / cb[kp];
+      const double g = v * rp;
       if(row)
-      {
-        const double g = cb[i] * rp;
-        for(int j0 = 0; j0 < nv; j0 += 8)
+        for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores (T and cb are both LDS: assumed to alias)
         {
           double tv[8], cv[8];
 #pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
+          for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
 #pragma unroll
           for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = (i == kp) ? cv[q] * rp : fma(-g, cv[q], tv[q]);
+          for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
 #pragma unroll
-          for(int q = 0; q < 8; ++q)
-            if(j0 + q < nv) T[(j0 + q) * NS + i] = tv[q];
+          for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
         }
-        T[kp * NS + i] = (i == kp) ? -rp : g;
+      __syncthreads();
+      if(row) // row and column kp (lane kp's column came out of the loop as rounding noise) and the pivot itself
+      {
+        const double e = (i == kp) ? -rp : g;
+        T[kp * NS + i] = e;
+        T[i * NS + kp] = e;
       }
       __syncthreads();
     }
@@ -156,21 +164,19 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     cb[i] = row ? gi : 0.0;
     __syncthreads();
     double lam0 = 0.0;
-    for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores (LDS aliasing, see the pivot loop)
-    {
-      double tv[8], cv[8];
+    if(row)
+      for(int j0 = 0; j0 < nv; j0 += 8) // (the padding rows of the last chunk are zero in column i < nv)
+      {
+        double tv[8], cv[8];
 #pragma unroll
-      for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
+        for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
 #pragma unroll
-      for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
+        for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-      for(int q = 0; q < 8; ++q)
-        if(j0 + q < nv)
-        {
-          lam0 = fma(tv[q], cv[q], lam0);
-          if(row) T[(j0 + q) * NS + i] = -tv[q];
-        }
-    }
+        for(int q = 0; q < 8; ++q) lam0 = fma(tv[q], cv[q], lam0);
+#pragma unroll
+        for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = -tv[q];
+      }
     __syncthreads();
     const double lo = row ? P.fmin - lam0 : -kZInf;
     const double hi = row ? P.fmax - lam0 : kZInf;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           }
         }
         const double sig = __shfl(psig, p);
-        const double cc = T[p * NS + i]; // column p = row p (symmetric)
+        const double cc = col ? T[p * NS + i] : 0.0; // column p = row p (symmetric)
         const double dm = -sig * cc;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = (i == p);
@@ -232,29 +238,32 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           z = fma(sig * t, cc, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = T[kk * NS + i];
+        const double v = col ? T[kk * NS + i] : 0.0;
         __syncthreads();
         cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        // (chunks of 8: loads before stores -- T and cb are both LDS and would otherwise be assumed to alias)
         if(row)
-          for(int j0 = 0; j0 < nv; j0 += 8)
+          for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores
           {
             double tv[8], cv[8];
 #pragma unroll
-            for(int q = 0; q < 8; ++q) tv[q] = T[(j0 + q) * NS + i];
+            for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
 #pragma unroll
             for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-            for(int q = 0; q < 8; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+            for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
 #pragma unroll
-            for(int q = 0; q < 8; ++q)
-              if(j0 + q < nv) T[(j0 + q) * NS + i] = tv[q];
+            for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
           }
         __syncthreads();
-        if(row) T[kk * NS + i] = (i == kk) ? -rp : s * g;
+        if(row)
+        {
+          const double e = (i == kk) ? -rp : s * g;
+          T[kk * NS + i] = e;
+          T[i * NS + kk] = e;
+        }
         __syncthreads();
         if(isadd)
         {
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       if(row && !inW)
       {
         double dz = 0.0;
-        for(int j = 0; j < nv; ++j) dz = fma(T[j * NS + i], cb[j], dz);
+        for(int j = 0; j < nv; ++j) dz = fma(Tc[j * NS], cb[j], dz);
         z += dz;
       }
       const double sl = (lo - z) - tl, sh = (z - hi) - th;
@@ -392,8 +401,19 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
   const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 64);
-  const size_t lds = ((size_t)(h->N + 8) * (h->N | 1) + 3 * kZNP) * sizeof(double) + kZNP * sizeof(int);
-  hipLaunchKernelGGL(z_plan_kernel, dim3(grid), dim3(kZNP), lds, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
+  };
+  switch((h->N + 7) / 8)
+  {
+    case 1: case 2: go(z_plan_kernel<16>); break;
+    case 3: go(z_plan_kernel<24>); break;
+    case 4: go(z_plan_kernel<32>); break;
+    case 5: go(z_plan_kernel<40>); break;
+    case 6: go(z_plan_kernel<48>); break;
+    case 7: go(z_plan_kernel<56>); break;
+    default: go(z_plan_kernel<64>); break;
+  }
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }

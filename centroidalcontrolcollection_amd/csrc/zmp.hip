@@ -442,8 +442,9 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
                                                             int * __restrict__ status, double * __restrict__ ws)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double * T = HBM ? ws + (size_t)blockIdx.x * NP * NP : smem; // [NP][NP]
-  double * cb = HBM ? smem : smem + NP * NP;                   // [NP] staging of the pivot row / of mu / of rho
+  constexpr int TS = HBM ? NP : NP + 1; // row stride of T; odd in LDS, so that column writes are bank-conflict free
+  double * T = HBM ? ws + (size_t)blockIdx.x * NP * NP : smem; // [NP][TS]
+  double * cb = HBM ? smem : smem + NP * TS;                   // [NP] staging of the pivot row / of mu / of rho
   BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
   const int i = threadIdx.x % NP, part = threadIdx.x / NP;
   const bool lead = part == 0;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     int st = CCC_STATUS_SOLVED;
     if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
 
-    for(int j = part * JQ; j < (part + 1) * JQ; ++j) T[j * NP + i] = P.G[j * NP + i];
+    for(int j = part * JQ; j < (part + 1) * JQ; ++j) T[j * TS + i] = P.G[j * NP + i];
     __syncthreads();
 
     double z = 0.0, mu = 0.0, dact = 0.0;
@@ -481,11 +482,20 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     bool done = st != CCC_STATUS_SOLVED; // block uniform
     bool need_select = true;
     int passes = 0;
+#ifdef CCC_ZMP_PROF
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter(), pn;
+#undef ZPROF
+#define ZPROF(k) pn = __builtin_readcyclecounter(); pc[k] += pn - pt; pt = pn;
+#else
+#undef ZPROF
+#define ZPROF(k)
+#endif
 
     for(int round = 0; round < 3 && !done; ++round)
     {
       while(!done)
       {
+        ZPROF(5)
         if(need_select)
         {
           const double sl = (lo - z) - tl, sh = (z - hi) - th;
@@ -509,8 +519,9 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
           if(lead && i == p) cb[0] = psig;
           __syncthreads();
         }
+        ZPROF(0)
         const double sig = cb[0];
-        const double c = T[p * NP + i]; // column p = row p (symmetric)
+        const double c = T[p * TS + i]; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = lead && (i == p);
@@ -526,6 +537,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
           done = true;
           break;
         }
+        ZPROF(1)
         const bool isadd = (kk == p);
         const double s = isadd ? 1.0 : -1.0;
         if(inW)
@@ -534,31 +546,37 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
           z = fma(sig * t, c, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = T[kk * NP + i];
+        const double v = T[kk * TS + i];
         if(lead) cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
+        ZPROF(2)
         // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and
-        // cb may both be LDS, so the compiler must assume they alias and would otherwise serialise load - store - load);
-        // thread kk writes row kk, stored as column i = kk of [j][i]
+        // cb may both be LDS, so the compiler must assume they alias and would otherwise serialise load - store - load)
         constexpr int CH = (JQ % 16 == 0) ? 16 : 8;
         static_assert(JQ % CH == 0, "a part's share of a column must be whole chunks");
         for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += CH)
         {
           double tv[CH], cv[CH];
 #pragma unroll
-          for(int q = 0; q < CH; ++q) tv[q] = T[(j0 + q) * NP + i];
+          for(int q = 0; q < CH; ++q) tv[q] = T[(j0 + q) * TS + i];
 #pragma unroll
           for(int q = 0; q < CH; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-          for(int q = 0; q < CH; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+          for(int q = 0; q < CH; ++q) tv[q] = fma(-g, cv[q], tv[q]);
 #pragma unroll
-          for(int q = 0; q < CH; ++q) T[(j0 + q) * NP + i] = tv[q];
+          for(int q = 0; q < CH; ++q) T[(j0 + q) * TS + i] = tv[q];
         }
         __syncthreads();
-        // column kk (entries [kk][i]) and the pivot itself
-        if(lead) T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        ZPROF(3)
+        // row and column kk (thread kk's column came out of the loop as rounding noise) and the pivot itself
+        if(lead)
+        {
+          const double e = (i == kk) ? -rp : s * g;
+          T[kk * TS + i] = e;
+          T[i * TS + kk] = e;
+        }
         __syncthreads();
         if(isadd)
         {
@@ -579,6 +597,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
           }
           need_select = false;
         }
+        ZPROF(4)
         if(++passes > maxpass)
         {
           st = CCC_STATUS_MAX_ITER;
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
       if(lead) cb[i] = rho;
       __syncthreads();
       double tr = 0.0;
-      for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
+      for(int j = 0; j < NP; ++j) tr = fma(T[j * TS + i], cb[j], tr);
       if(inW) mu -= tr;
       __syncthreads();
       if(lead) cb[i] = inW ? mu : 0.0;
@@ -611,6 +630,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
       if(!reopen) break;
     }
 
+    ZPROF(5)
     // outputs
     __syncthreads();
     if(lead) cb[i] = row ? mu : 0.0;
@@ -634,6 +654,10 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
       jerk[qp * N + i] = uj;
     }
     __syncthreads();
+#ifdef CCC_ZMP_PROF
+    if(jerk && qp == 0 && threadIdx.x == 0)
+      for(int q = 0; q < 6; ++q) jerk[q] = (double)pc[q];
+#endif
     (void)bi;
   }
 }
@@ -697,10 +721,19 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
     bool done = st != CCC_STATUS_SOLVED;
     bool need_select = true;
     int passes = 0;
+#ifdef CCC_ZMP_PROF
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter(), pn;
+#undef ZPROF
+#define ZPROF(k) pn = __builtin_readcyclecounter(); pc[k] += pn - pt; pt = pn;
+#else
+#undef ZPROF
+#define ZPROF(k)
+#endif
     for(int round = 0; round < 3 && !done; ++round)
     {
       while(!done)
       {
+        ZPROF(5)
         if(need_select)
         {
           const double sl = (lo - z) - tl, sh = (z - hi) - th;
@@ -716,6 +749,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
             pd = (sl >= sh) ? lo : hi;
           }
         }
+        ZPROF(0)
         const double sig = __shfl(psig, p);
         const double c = col ? Tm[p * NS + i] : 0.0; // row p = column p (symmetric)
         const double dm = -sig * c;
@@ -733,6 +767,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
           done = true;
           break;
         }
+        ZPROF(1)
         const bool isadd = (kk == p);
         const double s = isadd ? 1.0 : -1.0;
         if(inW)
@@ -746,6 +781,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
+        ZPROF(2)
         if(col)
 #pragma unroll
         for(int j0 = 0; j0 < NR; j0 += 8) // chunks: loads before stores (T and cb are both LDS: assumed to alias)
@@ -761,6 +797,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
           for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
         }
         __syncthreads();
+        ZPROF(3)
         {
           const double e = (i == kk) ? -rp : s * g;
           if(col)
@@ -789,6 +826,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
           }
           need_select = false;
         }
+        ZPROF(4)
         if(++passes > maxpass)
         {
           st = CCC_STATUS_MAX_ITER;
@@ -823,6 +861,7 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
       need_select = true;
       if(!reopen) break;
     }
+    ZPROF(5)
     // outputs
     __syncthreads();
     cb[i] = row ? mu : 0.0;
@@ -846,6 +885,10 @@ __global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, lon
       jerk[qp * N + i] = uj;
     }
     __syncthreads();
+#ifdef CCC_ZMP_PROF
+    if(jerk && qp == 0 && i == 0)
+      for(int q = 0; q < 6; ++q) jerk[q] = (double)pc[q];
+#endif
   }
 }
 
@@ -979,7 +1022,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   // instantiation for 33..64 steps was measured too: the register kernel K1' is 20 % faster there.)
   const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 16);
   auto go = [&](auto kernel, int np) -> int {
-    const size_t lds = ((size_t)np * np + np) * sizeof(double) + sizeof(BlockRed);
+    const size_t lds = ((size_t)np * (np + 1) + np) * sizeof(double) + sizeof(BlockRed);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(np * 4), lds, stream, P, (long)nqp, x0, zlim, control_dt, zmp, jerk, status,
