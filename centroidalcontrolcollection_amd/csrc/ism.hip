@@ -72,8 +72,9 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
 {
   constexpr int NP = kIsmNP;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double * T = smem;            // [NP][NP]
-  double * cb = smem + NP * NP; // [NP] staging of the pivot row / of mu / of rho
+  constexpr int TS = NP + 1;    // odd row stride: column writes are bank-conflict free
+  double * T = smem;            // [NP][TS]
+  double * cb = smem + NP * TS; // [NP] staging of the pivot row / of mu / of rho
   double * dp = cb + NP;        // [kIsmParts][NP] partial offsets
   IsmRed * red = reinterpret_cast<IsmRed *>(dp + kIsmParts * NP);
   const int i = threadIdx.x & (NP - 1), part = threadIdx.x / NP;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
 #pragma unroll
       for(int q = 0; q < 8; ++q)
       {
-        T[(j0 + q) * NP + i] = gv[q];
+        T[(j0 + q) * TS + i] = gv[q];
         d = fma(gv[q], cv[q], d);
       }
     }
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
           __syncthreads();
         }
         const double sig = cb[0];
-        const double c = T[p * NP + i]; // column p = row p (symmetric)
+        const double c = T[p * TS + i]; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = lead && (i == p);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
           z = fma(sig * t, c, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = T[kk * NP + i];
+        const double v = T[kk * TS + i];
         if(lead) cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
@@ -196,16 +197,21 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
         {
           double tv[16], cv[16];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * NP + i];
+          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * TS + i];
 #pragma unroll
           for(int q = 0; q < 16; ++q) cv[q] = cb[j0 + q];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = (i == kk) ? s * cv[q] * rp : fma(-g, cv[q], tv[q]);
+          for(int q = 0; q < 16; ++q) tv[q] = fma(-g, cv[q], tv[q]);
 #pragma unroll
-          for(int q = 0; q < 16; ++q) T[(j0 + q) * NP + i] = tv[q];
+          for(int q = 0; q < 16; ++q) T[(j0 + q) * TS + i] = tv[q];
         }
         __syncthreads();
-        if(lead) T[kk * NP + i] = (i == kk) ? -rp : s * g;
+        if(lead) // row and column kk (thread kk's column came out of the loop as rounding noise), the pivot itself
+        {
+          const double e = (i == kk) ? -rp : s * g;
+          T[kk * TS + i] = e;
+          T[i * TS + kk] = e;
+        }
         __syncthreads();
         if(isadd)
         {
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
       if(lead) cb[i] = rho;
       __syncthreads();
       double tr = 0.0;
-      for(int j = 0; j < NP; ++j) tr = fma(T[j * NP + i], cb[j], tr);
+      for(int j = 0; j < NP; ++j) tr = fma(T[j * TS + i], cb[j], tr);
       if(inW) mu -= tr;
       __syncthreads();
       if(lead) cb[i] = inW ? mu : 0.0;
@@ -458,7 +464,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(n == 0) return CCC_OK;
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
   CCC_HIP_CHECK(hipSetDevice(h->device));
-  const size_t lds = ((size_t)kIsmNP * kIsmNP + kIsmNP + kIsmParts * kIsmNP) * sizeof(double) + sizeof(IsmRed);
+  const size_t lds = ((size_t)kIsmNP * (kIsmNP + 1) + kIsmNP + kIsmParts * kIsmNP) * sizeof(double) + sizeof(IsmRed);
   static bool attr_set = false;
   if(!attr_set)
   {

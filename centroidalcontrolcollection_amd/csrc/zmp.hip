@@ -404,14 +404,27 @@ struct BlockRed
   int idx[4];
 };
 
+struct SelRed
+{
+  double val[4], sig[4];
+  int idx[4];
+};
+
+__device__ __forceinline__ double wave_lane_value(double v, int k) // k uniform: two v_readlane_b32, no LDS round trip
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
 // (min value over the NP-thread block, lowest thread index attaining it; index NP if every candidate is NaN)
-template<int NP>
+template<int NP, bool GUARD = true>
 __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & vmin, int & imin)
 {
   const int tid = threadIdx.x, w = tid >> 6;
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm);
-  __syncthreads(); // red may still be read by the previous reduction
+  if(GUARD) __syncthreads(); // red may still be read by the previous reduction
   if((tid & 63) == 0 && w < (NP + 63) / 64) // rows live in the first wavefronts (part 0)
   {
     red->val[w] = wm;
@@ -446,6 +459,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
   double * T = HBM ? ws + (size_t)blockIdx.x * NP * NP : smem; // [NP][TS]
   double * cb = HBM ? smem : smem + NP * TS;                   // [NP] staging of the pivot row / of mu / of rho
   BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
+  SelRed * sel = reinterpret_cast<SelRed *>(red + 1);
   const int i = threadIdx.x % NP, part = threadIdx.x / NP;
   const bool lead = part == 0;
   constexpr int JQ = NP / PARTS;
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     double z = 0.0, mu = 0.0, dact = 0.0;
     bool inW = false;
     int p = 0;
-    double psig = 0.0, pd = 0.0;
+    double psig = 0.0, pd = 0.0, sig = 0.0;
     bool done = st != CCC_STATUS_SOLVED; // block uniform
     bool need_select = true;
     int passes = 0;
@@ -491,36 +505,52 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
 #define ZPROF(k)
 #endif
 
+    // per wavefront: the most violated bound among the rows outside the working set, and its side
+    auto post_select = [&]() {
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const double key = (inW || !row) ? kInf : -fmax(sl, sh);
+      const double wm = WaveGroup<64>::min(key);
+      const int wi = WaveGroup<64>::first(key == wm);
+      const double wsig = wave_lane_value((sl >= sh) ? 1.0 : -1.0, wi & 63);
+      const int w = threadIdx.x >> 6;
+      if((threadIdx.x & 63) == 0 && w < (NP + 63) / 64)
+      {
+        sel->val[w] = wm;
+        sel->sig[w] = wsig;
+        sel->idx[w] = wi < 64 ? wi + 64 * w : NP;
+      }
+    };
     for(int round = 0; round < 3 && !done; ++round)
     {
+      post_select();
+      __syncthreads();
       while(!done)
       {
         ZPROF(5)
-        if(need_select)
+        if(need_select) // the candidates were posted before the previous barrier (post_select)
         {
-          const double sl = (lo - z) - tl, sh = (z - hi) - th;
-          const double score = (inW || !row) ? -kInf : fmax(sl, sh);
-          double m;
-          int cand;
-          block_argmin<NP>(-score, red, m, cand);
-          m = -m;
-          if(!(m > 0.0)) break;
+          double best = sel->val[0], sg = sel->sig[0];
+          int cand = sel->idx[0];
+#pragma unroll
+          for(int k = 1; k < (NP + 63) / 64; ++k)
+          {
+            const double a = sel->val[k];
+            const int ia = sel->idx[k];
+            const bool take = (ia < NP) && (cand >= NP || a < best);
+            best = take ? a : best;
+            sg = take ? sel->sig[k] : sg;
+            cand = take ? ia : cand;
+          }
+          if(!(-best > 0.0)) break;
           p = cand;
+          sig = sg;
           if(lead && i == cand)
           {
-            psig = (sl >= sh) ? 1.0 : -1.0;
-            pd = (sl >= sh) ? lo : hi;
-            cb[0] = psig;
+            psig = sg;
+            pd = (sg > 0.0) ? lo : hi;
           }
-          __syncthreads();
-        }
-        else
-        {
-          if(lead && i == p) cb[0] = psig;
-          __syncthreads();
         }
         ZPROF(0)
-        const double sig = cb[0];
         const double c = T[p * TS + i]; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
@@ -530,7 +560,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
         const double ratio = (isp || blocking) ? num / den : kInf;
         double t;
         int kk;
-        block_argmin<NP>(ratio, red, t, kk);
+        block_argmin<NP, false>(ratio, red, t, kk); // (red was last read three barriers ago)
         if(kk >= NP)
         {
           st = CCC_STATUS_MAX_ITER;
@@ -545,6 +575,28 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
         else
           z = fma(sig * t, c, z);
         if(isp) mu += sig * t;
+        // bookkeeping of the step, and the candidates of the next selection (they do not depend on the tableau
+        // update: posting them here lets the selection ride on the barriers of the update)
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(lead && i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(need_select) post_select();
         // pivot on row/column kk
         const double v = T[kk * TS + i];
         if(lead) cb[i] = v;
@@ -578,25 +630,6 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
           T[i * TS + kk] = e;
         }
         __syncthreads();
-        if(isadd)
-        {
-          if(isp)
-          {
-            inW = true;
-            z = pd;
-            dact = pd;
-          }
-          need_select = true;
-        }
-        else
-        {
-          if(lead && i == kk)
-          {
-            inW = false;
-            mu = 0.0;
-          }
-          need_select = false;
-        }
         ZPROF(4)
         if(++passes > maxpass)
         {
@@ -1011,7 +1044,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   {
     const int blocks = h->num_cu * 2;
     if(!h->ws_big) CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
-    const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed);
+    const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     const int grid = (int)std::min<int64_t>(nqp, blocks);
     hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
                        x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
@@ -1022,7 +1055,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   // instantiation for 33..64 steps was measured too: the register kernel K1' is 20 % faster there.)
   const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 16);
   auto go = [&](auto kernel, int np) -> int {
-    const size_t lds = ((size_t)np * (np + 1) + np) * sizeof(double) + sizeof(BlockRed);
+    const size_t lds = ((size_t)np * (np + 1) + np) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(np * 4), lds, stream, P, (long)nqp, x0, zlim, control_dt, zmp, jerk, status,
