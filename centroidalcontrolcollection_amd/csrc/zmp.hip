@@ -22,9 +22,12 @@
 // Mapping: N <= 32: the two axes of one instance are the two 32-lane halves of ONE wavefront (one
 // planOnce() per wavefront); 32 < N <= 64: one axis per wavefront.
 #include "common.h"
+#include "sym_tableau.h"
 #include "wave_group.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -395,7 +398,6 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 // Horizons beyond 128 steps (e.g. 2 s @ 10 ms = 200, BASELINE configs[0] as worded) do not fit the 160 KB of LDS any
 // more: the same kernel with 256 threads keeps its tableau in an HBM workspace ([j][i], i fastest: coalesced).  Slow
 // (every pivot streams 2 x 512 KB through L2) -- there for completeness of the drop-in surface.
-constexpr int kBlkNP = 128;
 constexpr int kBigNP = 256;
 
 struct BlockRed
@@ -692,6 +694,253 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
       for(int q = 0; q < 6; ++q) jerk[q] = (double)pc[q];
 #endif
     (void)bi;
+  }
+}
+// K2.  64 < N <= 128: one QP per workgroup, the sweep tableau PACKED (lower triangle in 4 x 4 tiles, sym_tableau.h) in
+// LDS; thread t updates the tiles t, t + NT, thread i < NP owns row i (bounds, multiplier, flags).  GS = row stride of P.G.
+template<int NP>
+__global__ __launch_bounds__(SymTab<NP>::NT, (SymTab<NP>::NT > 256 ? 4 : 3)) void zmp_plan_sym_kernel(ZmpDev P, int GS, long nqp,
+                                                                      const double * __restrict__ x0,
+                                                                      const double * __restrict__ zlim, double control_dt,
+                                                                      double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                      int * __restrict__ status)
+{
+  using ST = SymTab<NP>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double * T = smem;                 // packed tableau
+  double * cb = smem + ST::kDoubles; // [NP] staging of the pivot row / of mu / of rho
+  BlockRed * red = reinterpret_cast<BlockRed *>(cb + NP);
+  SelRed * sel = reinterpret_cast<SelRed *>(red + 1);
+  const int i = threadIdx.x;
+  const bool lead = i < NP;
+  int ta[ST::TPT], tb[ST::TPT]; // this thread's tiles: i, i + NT, ...
+#pragma unroll
+  for(int k = 0; k < ST::TPT; ++k) ST::tile_of(i + k * ST::NT < ST::NTILE ? i + k * ST::NT : 0, ta[k], tb[k]);
+  const int N = P.N;
+  const double a0 = lead ? P.A[i * 3 + 0] : 0.0, a1 = lead ? P.A[i * 3 + 1] : 0.0, a2 = lead ? P.A[i * 3 + 2] : 0.0;
+  const int maxpass = 20 * N + 100;
+
+  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  {
+#ifdef CCC_ZMP_PROF
+    const long long rtq = wall_clock64();
+#endif
+    const bool row = lead && i < N;
+    const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
+    double zl = 0, zh = 0;
+    if(row)
+    {
+      zl = zlim[qp * 2 * N + i];
+      zh = zlim[qp * 2 * N + N + i];
+    }
+    const double fr = a0 * px + a1 * vx + a2 * ax;
+    const double lo = row ? zl - fr : -kInf;
+    const double hi = row ? zh - fr : kInf;
+    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
+    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
+    int st = CCC_STATUS_SOLVED;
+    if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
+
+#pragma unroll
+    for(int k = 0; k < ST::TPT; ++k)
+      if(i + k * ST::NT < ST::NTILE) ST::load_tile(T, P.G, GS, i + k * ST::NT, ta[k], tb[k]);
+    __syncthreads();
+
+    double z = 0.0, mu = 0.0, dact = 0.0;
+    bool inW = false;
+    int p = 0;
+    double psig = 0.0, pd = 0.0, sig = 0.0;
+    bool done = st != CCC_STATUS_SOLVED; // block uniform
+    bool need_select = true;
+    int passes = 0;
+#ifdef CCC_ZMP_PROF
+    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter(), pn;
+    const long long rt0 = wall_clock64(), ct0 = pt;
+#undef ZPROF
+#define ZPROF(k) pn = __builtin_readcyclecounter(); pc[k] += pn - pt; pt = pn;
+#else
+#undef ZPROF
+#define ZPROF(k)
+#endif
+
+    // per wavefront: the most violated bound among the rows outside the working set, and its side
+    auto post_select = [&]() {
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const double key = (inW || !row) ? kInf : -fmax(sl, sh);
+      const double wm = WaveGroup<64>::min(key);
+      const int wi = WaveGroup<64>::first(key == wm);
+      const double wsig = wave_lane_value((sl >= sh) ? 1.0 : -1.0, wi & 63);
+      const int w = threadIdx.x >> 6;
+      if((threadIdx.x & 63) == 0 && w < (NP + 63) / 64)
+      {
+        sel->val[w] = wm;
+        sel->sig[w] = wsig;
+        sel->idx[w] = wi < 64 ? wi + 64 * w : NP;
+      }
+    };
+    for(int round = 0; round < 3 && !done; ++round)
+    {
+      post_select();
+      __syncthreads();
+      while(!done)
+      {
+        ZPROF(5)
+        if(need_select) // the candidates were posted before the previous barrier (post_select)
+        {
+          double best = sel->val[0], sg = sel->sig[0];
+          int cand = sel->idx[0];
+#pragma unroll
+          for(int k = 1; k < (NP + 63) / 64; ++k)
+          {
+            const double a = sel->val[k];
+            const int ia = sel->idx[k];
+            const bool take = (ia < NP) && (cand >= NP || a < best);
+            best = take ? a : best;
+            sg = take ? sel->sig[k] : sg;
+            cand = take ? ia : cand;
+          }
+          if(!(-best > 0.0)) break;
+          p = cand;
+          sig = sg;
+          if(lead && i == cand)
+          {
+            psig = sg;
+            pd = (sg > 0.0) ? lo : hi;
+          }
+        }
+        ZPROF(0)
+        const double c = lead ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
+        const double dm = -sig * c;
+        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const bool isp = lead && (i == p);
+        const double num = isp ? psig * (pd - z) : -mu;
+        const double den = isp ? c : dm;
+        const double ratio = (isp || blocking) ? num / den : kInf;
+        double t;
+        int kk;
+        block_argmin<NP, false>(ratio, red, t, kk); // (red was last read three barriers ago)
+        if(kk >= NP)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+          break;
+        }
+        ZPROF(1)
+        const bool isadd = (kk == p);
+        const double s = isadd ? 1.0 : -1.0;
+        if(inW)
+          mu = fma(t, dm, mu);
+        else
+          z = fma(sig * t, c, z);
+        if(isp) mu += sig * t;
+        // bookkeeping of the step, and the candidates of the next selection (they do not depend on the tableau
+        // update: posting them here lets the selection ride on the barriers of the update)
+        if(isadd)
+        {
+          if(isp)
+          {
+            inW = true;
+            z = pd;
+            dact = pd;
+          }
+          need_select = true;
+        }
+        else
+        {
+          if(lead && i == kk)
+          {
+            inW = false;
+            mu = 0.0;
+          }
+          need_select = false;
+        }
+        if(need_select) post_select();
+        // pivot on row/column kk
+        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
+        if(lead) cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+        ZPROF(2)
+#pragma unroll
+        for(int k = 0; k < ST::TPT; ++k)
+          if(i + k * ST::NT < ST::NTILE) ST::update_tile(T, cb, rp, i + k * ST::NT, ta[k], tb[k]);
+        __syncthreads();
+        ZPROF(3)
+        // row/column kk (the update left rounding noise there) and the pivot itself
+        if(lead)
+        {
+          T[ST::entry(kk, i)] = (i == kk) ? -rp : s * g;
+        }
+        __syncthreads();
+        ZPROF(4)
+        if(++passes > maxpass)
+        {
+          st = CCC_STATUS_MAX_ITER;
+          done = true;
+        }
+      }
+      if(st != CCC_STATUS_SOLVED) break;
+      // closing refinement (see zmp_plan_kernel)
+      __syncthreads();
+      if(lead) cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      double acc = 0.0;
+      if(lead)
+        for(int j = 0; j < NP; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
+      const double rho = inW ? dact - acc : 0.0;
+      __syncthreads();
+      if(lead) cb[i] = rho;
+      __syncthreads();
+      const double tr = lead ? ST::matvec_row(T, cb, i) : 0.0;
+      if(inW) mu -= tr;
+      __syncthreads();
+      if(lead) cb[i] = inW ? mu : 0.0;
+      __syncthreads();
+      acc = 0.0;
+      if(lead)
+        for(int j = 0; j < NP; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
+      z = inW ? dact : acc;
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
+      need_select = true;
+      if(!reopen) break;
+    }
+
+    ZPROF(5)
+    // outputs
+    __syncthreads();
+    if(lead) cb[i] = row ? mu : 0.0;
+    __syncthreads();
+    if(lead && i == 0)
+    {
+      double u0 = 0.0;
+      for(int r = 0; r < N; ++r) u0 = fma(P.b[r], cb[r], u0);
+      const double cdt = control_dt < 0 ? P.dt : control_dt;
+      const double com_acc = ax + cdt * u0;
+      const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
+      double zv = com_pos + P.c2 * com_acc;
+      zv = zv < zl ? zl : (zh < zv ? zh : zv);
+      zmp[qp] = zv;
+      if(status) status[qp] = (passes << 8) | st;
+    }
+    if(jerk && row)
+    {
+      double uj = 0.0;
+      for(int r = i; r < N; ++r) uj = fma(P.b[r - i], cb[r], uj);
+      jerk[qp * N + i] = uj;
+    }
+    __syncthreads();
+#ifdef CCC_ZMP_PROF
+    if(jerk && threadIdx.x == 0)
+    {
+      for(int q = 0; q < 6; ++q) jerk[qp * N + q] = (double)pc[q];
+      jerk[qp * N + 6] = (double)(wall_clock64() - rt0);
+      jerk[qp * N + 7] = (double)(__builtin_readcyclecounter() - ct0);
+      jerk[qp * N + 8] = (double)rtq;
+      jerk[qp * N + 9] = (double)(rt0 - rtq);
+    }
+#endif
   }
 }
 // ---------------------------------------------------------------------------------------------
@@ -1051,22 +1300,39 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
-  // LDS-resident tableau sized to the horizon: 96 x 96 (74 KB, two workgroups per CU) or 128 x 128 (one).  (A 64 x 64
-  // instantiation for 33..64 steps was measured too: the register kernel K1' is 20 % faster there.)
-  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 16);
-  auto go = [&](auto kernel, int np) -> int {
-    const size_t lds = ((size_t)np * (np + 1) + np) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
+  // packed LDS tableau sized to the horizon (rows rounded up to a tile boundary the instantiations cover)
+  auto go = [&](auto kernel, auto st) -> int {
+    using ST = decltype(st);
+    const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
+    // one workgroup per QP: the pivot count varies severalfold between QPs, so the balancing is left to the hardware
+    // dispatcher (a QP takes ~100 us, the launch of a workgroup ~1 us)
+    const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(np * 4), lds, stream, P, (long)nqp, x0, zlim, control_dt, zmp, jerk, status,
-                       (double *)nullptr);
+    if(std::getenv("CCC_ZMP_DEBUG"))
+    {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, ST::NT, lds);
+      std::fprintf(stderr, "zmp sym kernel: rows %d threads %d lds %zu B -> %d workgroups per CU (grid %d)\n", ST::NB * 4, ST::NT,
+                   lds, nb, grid);
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, stream, P, h->NP, (long)nqp, x0, zlim, control_dt, zmp, jerk,
+                       status);
     return CCC_OK;
   };
   int rc;
-  if(h->NP == 96)
-    rc = go(&zmp_plan_block_kernel<96, false, 4>, 96);
+  if(h->N <= 72)
+    rc = go(&zmp_plan_sym_kernel<72>, SymTab<72>{});
+  else if(h->N <= 80)
+    rc = go(&zmp_plan_sym_kernel<80>, SymTab<80>{});
+  else if(h->N <= 96)
+    rc = go(&zmp_plan_sym_kernel<96>, SymTab<96>{});
+  else if(h->N <= 104)
+    rc = go(&zmp_plan_sym_kernel<104>, SymTab<104>{});
+  else if(h->N <= 112)
+    rc = go(&zmp_plan_sym_kernel<112>, SymTab<112>{});
   else
-    rc = go(&zmp_plan_block_kernel<kBlkNP, false, 4>, kBlkNP);
+    rc = go(&zmp_plan_sym_kernel<128>, SymTab<128>{});
   if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
