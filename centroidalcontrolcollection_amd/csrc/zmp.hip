@@ -19,8 +19,10 @@
 // its own element plus the broadcast of the whole row; adding / dropping a row is then one rank-1
 // update T -= g v' of register-resident data (N FMAs per lane, no data-dependent loop bounds).
 //
-// Mapping: N <= 32: the two axes of one instance are the two 32-lane halves of ONE wavefront (one
-// planOnce() per wavefront); 32 < N <= 64: one axis per wavefront.
+// Mapping: N <= 32 (K1, zmp_plan_kernel): the two axes of one instance are the two 32-lane halves of ONE wavefront
+// (one planOnce() per wavefront), the tableau in registers.  32 < N <= 200 (K2, zmp_plan_sym_kernel): one QP per
+// workgroup, the tableau packed (lower triangle, sym_tableau.h) in LDS.  200 < N <= 256 (K3, zmp_plan_block_kernel):
+// the full tableau in an HBM workspace.
 #include "common.h"
 #include "sym_tableau.h"
 #include "wave_group.h"
@@ -389,15 +391,11 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 }
 
 // ---------------------------------------------------------------------------------------------
-// Long horizons (64 < N <= 128, e.g. the reference test's 2 s @ 20 ms = 100 steps): one QP per
-// 128-thread workgroup, thread i = row i, the whole sweep tableau resident in LDS ([j][i], i fastest:
-// own-row accesses are conflict free, the pivot row is broadcast from a staging copy).  Same dual
-// active-set iteration and closing refinement as zmp_plan_kernel; built for coverage of the drop-in
-// surface, not for the headline throughput.
+// K3.  Horizons beyond 200 steps do not fit the 160 KB of LDS even packed: one QP per 512-thread workgroup, thread
+// (part, i) updates its share of column i of the FULL tableau, which lives in an HBM workspace ([j][i], i fastest:
+// coalesced).  Slow (every pivot streams 2 x 512 KB through L2) -- there for completeness of the drop-in surface.
+// Same dual active-set iteration and closing refinement as zmp_plan_kernel.
 // ---------------------------------------------------------------------------------------------
-// Horizons beyond 128 steps (e.g. 2 s @ 10 ms = 200, BASELINE configs[0] as worded) do not fit the 160 KB of LDS any
-// more: the same kernel with 256 threads keeps its tableau in an HBM workspace ([j][i], i fastest: coalesced).  Slow
-// (every pivot streams 2 x 512 KB through L2) -- there for completeness of the drop-in surface.
 constexpr int kBigNP = 256;
 
 struct BlockRed
@@ -696,16 +694,19 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     (void)bi;
   }
 }
-// K2.  64 < N <= 128: one QP per workgroup, the sweep tableau PACKED (lower triangle in 4 x 4 tiles, sym_tableau.h) in
-// LDS; thread t updates the tiles t, t + NT, thread i < NP owns row i (bounds, multiplier, flags).  GS = row stride of P.G.
-template<int NP>
-__global__ __launch_bounds__(SymTab<NP>::NT, (SymTab<NP>::NT > 256 ? 4 : 3)) void zmp_plan_sym_kernel(ZmpDev P, int GS, long nqp,
+// K2.  32 < N <= 200 (the reference test's 2 s @ 20 ms = 100 steps; BASELINE configs[0] as worded, 2 s @ 10 ms = 200):
+// one QP per workgroup, the sweep tableau PACKED (lower triangle in 4 x 4 tiles -- 2 x 2 at 200 rows --, sym_tableau.h)
+// in LDS; thread t updates the tiles t, t + NT, ..., thread i < NP owns row i (bounds, multiplier, flags).  One to
+// twelve workgroups share a CU (7 KB at 40 rows ... 160 KB at 200), one workgroup is one to sixteen wavefronts.
+// GS = row stride of P.G.
+template<int NP, int TS, int TPT>
+__global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kMinWaves)) void zmp_plan_sym_kernel(ZmpDev P, int GS, long nqp,
                                                                       const double * __restrict__ x0,
                                                                       const double * __restrict__ zlim, double control_dt,
                                                                       double * __restrict__ zmp, double * __restrict__ jerk,
                                                                       int * __restrict__ status)
 {
-  using ST = SymTab<NP>;
+  using ST = SymTab<NP, TS, TPT>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double * T = smem;                 // packed tableau
   double * cb = smem + ST::kDoubles; // [NP] staging of the pivot row / of mu / of rho
@@ -943,238 +944,6 @@ __global__ __launch_bounds__(SymTab<NP>::NT, (SymTab<NP>::NT > 256 ? 4 : 3)) voi
 #endif
   }
 }
-// ---------------------------------------------------------------------------------------------
-// K1w.  Mid-size horizons (32 < N <= 64): one QP (axis) per WAVEFRONT, lane i = column i of the sweep tableau, which
-// lives in LDS as NR x NR doubles (NR = N rounded up to 8) with the odd row stride NR + 1.  NR is a template parameter:
-// every tableau access is then `ds_read/write_b64 base, offset:imm` off ONE address register, the update loop is
-// straight-line (read 8 rows, 8 FMAs, write 8 rows), and the padding rows/columns are zero and stay zero under the
-// update, so nothing in the loop is predicated.  The pivot row and column are written afterwards (lane j writes
-// (kk, j) and (j, kk): the stride is odd, so the column write is bank-conflict free).  Same iteration as the kernels
-// above; replaces the register kernel K1' (64-double rows: 220 VGPRs and spills).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_argmin64(double v, double & vmin, int & imin)
-{
-  vmin = WaveGroup<64>::min(v);
-  imin = WaveGroup<64>::first(v == vmin && v < kInf);
-}
-
-template<int NR>
-__global__ __launch_bounds__(64) void zmp_plan_wave_kernel(ZmpDev P, int GS, long nqp, const double * __restrict__ x0,
-                                                           const double * __restrict__ zlim, double control_dt,
-                                                           double * __restrict__ zmp, double * __restrict__ jerk,
-                                                           int * __restrict__ status)
-{
-  constexpr int NS = NR + 1;
-  __shared__ __attribute__((aligned(16))) double cb[64];
-  __shared__ double Tm[NR * NS + 64]; // + slack: lanes >= NR address (and never use) up to 63 - NR doubles past the end
-  const int N = P.N;
-  const int i = threadIdx.x;
-  const bool row = i < N;
-  const bool col = i < NR; // lanes NR..63 (NR < 64) own no column
-  double * Tc = Tm + i;    // column i
-  const double a0 = row ? P.A[i * 3 + 0] : 0.0, a1 = row ? P.A[i * 3 + 1] : 0.0, a2 = row ? P.A[i * 3 + 2] : 0.0;
-  const int maxpass = 20 * N + 100;
-
-  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
-  {
-    const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
-    double zl = 0, zh = 0;
-    if(row)
-    {
-      zl = zlim[qp * 2 * N + i];
-      zh = zlim[qp * 2 * N + N + i];
-    }
-    const double fr = a0 * px + a1 * vx + a2 * ax;
-    const double lo = row ? zl - fr : -kInf;
-    const double hi = row ? zh - fr : kInf;
-    const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
-    const double th = row ? 1e-12 * (1.0 + fabs(hi)) : 0.0;
-    int st = CCC_STATUS_SOLVED;
-    if(__syncthreads_or(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
-#pragma unroll
-    for(int j = 0; j < NR; ++j)
-      if(col) Tc[j * NS] = (row && j < N) ? P.G[j * GS + i] : 0.0;
-    __syncthreads();
-
-    double z = 0.0, mu = 0.0, dact = 0.0;
-    bool inW = false;
-    int p = 0;
-    double psig = 0.0, pd = 0.0;
-    bool done = st != CCC_STATUS_SOLVED;
-    bool need_select = true;
-    int passes = 0;
-#ifdef CCC_ZMP_PROF
-    long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = __builtin_readcyclecounter(), pn;
-#undef ZPROF
-#define ZPROF(k) pn = __builtin_readcyclecounter(); pc[k] += pn - pt; pt = pn;
-#else
-#undef ZPROF
-#define ZPROF(k)
-#endif
-    for(int round = 0; round < 3 && !done; ++round)
-    {
-      while(!done)
-      {
-        ZPROF(5)
-        if(need_select)
-        {
-          const double sl = (lo - z) - tl, sh = (z - hi) - th;
-          const double score = (inW || !row) ? -kInf : fmax(sl, sh);
-          double m;
-          int cand;
-          wave_argmin64(score > 0.0 ? -score : kInf, m, cand);
-          if(cand >= 64) break;
-          p = cand;
-          if(i == cand)
-          {
-            psig = (sl >= sh) ? 1.0 : -1.0;
-            pd = (sl >= sh) ? lo : hi;
-          }
-        }
-        ZPROF(0)
-        const double sig = __shfl(psig, p);
-        const double c = col ? Tm[p * NS + i] : 0.0; // row p = column p (symmetric)
-        const double dm = -sig * c;
-        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-        const bool isp = (i == p);
-        const double num = isp ? psig * (pd - z) : -mu;
-        const double den = isp ? c : dm;
-        const double ratio = (isp || blocking) ? num / den : kInf;
-        double t;
-        int kk;
-        wave_argmin64(ratio, t, kk);
-        if(kk >= 64)
-        {
-          st = CCC_STATUS_MAX_ITER;
-          done = true;
-          break;
-        }
-        ZPROF(1)
-        const bool isadd = (kk == p);
-        const double s = isadd ? 1.0 : -1.0;
-        if(inW)
-          mu = fma(t, dm, mu);
-        else
-          z = fma(sig * t, c, z);
-        if(isp) mu += sig * t;
-        // pivot on row/column kk
-        const double v = col ? Tm[kk * NS + i] : 0.0;
-        cb[i] = v;
-        __syncthreads();
-        const double rp = 1.0 / cb[kk];
-        const double g = v * rp;
-        ZPROF(2)
-        if(col)
-#pragma unroll
-        for(int j0 = 0; j0 < NR; j0 += 8) // chunks: loads before stores (T and cb are both LDS: assumed to alias)
-        {
-          double tv[8], cv[8];
-#pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
-#pragma unroll
-          for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
-#pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
-#pragma unroll
-          for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
-        }
-        __syncthreads();
-        ZPROF(3)
-        {
-          const double e = (i == kk) ? -rp : s * g;
-          if(col)
-          {
-            Tm[kk * NS + i] = e;
-            Tm[i * NS + kk] = e;
-          }
-        }
-        __syncthreads();
-        if(isadd)
-        {
-          if(isp)
-          {
-            inW = true;
-            z = pd;
-            dact = pd;
-          }
-          need_select = true;
-        }
-        else
-        {
-          if(i == kk)
-          {
-            inW = false;
-            mu = 0.0;
-          }
-          need_select = false;
-        }
-        ZPROF(4)
-        if(++passes > maxpass)
-        {
-          st = CCC_STATUS_MAX_ITER;
-          done = true;
-        }
-      }
-      if(st != CCC_STATUS_SOLVED) break;
-      // closing refinement (see zmp_plan_kernel)
-      __syncthreads();
-      cb[i] = inW ? mu : 0.0;
-      __syncthreads();
-      double acc = 0.0;
-#pragma unroll 8
-      for(int j = 0; j < NR; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
-      const double rho = inW ? dact - acc : 0.0;
-      __syncthreads();
-      cb[i] = rho;
-      __syncthreads();
-      double tr = 0.0;
-#pragma unroll
-      for(int j = 0; j < NR; ++j) tr = fma(Tc[j * NS], cb[j], tr); // lanes >= NR: unused
-      if(inW) mu -= tr;
-      __syncthreads();
-      cb[i] = inW ? mu : 0.0;
-      __syncthreads();
-      acc = 0.0;
-#pragma unroll 8
-      for(int j = 0; j < NR; ++j) acc = fma(P.G[j * GS + i], cb[j], acc);
-      z = inW ? dact : acc;
-      const double sl = (lo - z) - tl, sh = (z - hi) - th;
-      const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
-      need_select = true;
-      if(!reopen) break;
-    }
-    ZPROF(5)
-    // outputs
-    __syncthreads();
-    cb[i] = row ? mu : 0.0;
-    __syncthreads();
-    if(i == 0)
-    {
-      double u0 = 0.0;
-      for(int r = 0; r < N; ++r) u0 = fma(P.b[r], cb[r], u0);
-      const double cdt = control_dt < 0 ? P.dt : control_dt;
-      const double com_acc = ax + cdt * u0;
-      const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
-      double zv = com_pos + P.c2 * com_acc;
-      zv = zv < zl ? zl : (zh < zv ? zh : zv);
-      zmp[qp] = zv;
-      if(status) status[qp] = (passes << 8) | st;
-    }
-    if(jerk && row)
-    {
-      double uj = 0.0;
-      for(int r = i; r < N; ++r) uj = fma(P.b[r - i], cb[r], uj);
-      jerk[qp * N + i] = uj;
-    }
-    __syncthreads();
-#ifdef CCC_ZMP_PROF
-    if(jerk && qp == 0 && i == 0)
-      for(int q = 0; q < 6; ++q) jerk[q] = (double)pc[q];
-#endif
-  }
-}
-
-constexpr int kZmpWaveMaxN = 64; // above: the tableau leaves one wavefront per SIMD and K1' is faster
 
 } // namespace ccc_amd
 
@@ -1289,7 +1058,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 {
   const int64_t nqp = 2 * n;
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
-  if(h->NP == kBigNP)
+  if(h->N > 200) // beyond the LDS: the tableau in HBM
   {
     const int blocks = h->num_cu * 2;
     if(!h->ws_big) CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
@@ -1303,7 +1072,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   // packed LDS tableau sized to the horizon (rows rounded up to a tile boundary the instantiations cover)
   auto go = [&](auto kernel, auto st) -> int {
     using ST = decltype(st);
-    const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
+    const size_t lds = ((size_t)ST::kDoubles + ST::NB * ST::TS_) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     // one workgroup per QP: the pivot count varies severalfold between QPs, so the balancing is left to the hardware
     // dispatcher (a QP takes ~100 us, the launch of a workgroup ~1 us)
     const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
@@ -1313,7 +1082,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, ST::NT, lds);
-      std::fprintf(stderr, "zmp sym kernel: rows %d threads %d lds %zu B -> %d workgroups per CU (grid %d)\n", ST::NB * 4, ST::NT,
+      std::fprintf(stderr, "zmp sym kernel: rows %d threads %d lds %zu B -> %d workgroups per CU (grid %d)\n", ST::NB * ST::TS_, ST::NT,
                    lds, nb, grid);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, stream, P, h->NP, (long)nqp, x0, zlim, control_dt, zmp, jerk,
@@ -1321,18 +1090,22 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     return CCC_OK;
   };
   int rc;
-  if(h->N <= 72)
-    rc = go(&zmp_plan_sym_kernel<72>, SymTab<72>{});
-  else if(h->N <= 80)
-    rc = go(&zmp_plan_sym_kernel<80>, SymTab<80>{});
-  else if(h->N <= 96)
-    rc = go(&zmp_plan_sym_kernel<96>, SymTab<96>{});
-  else if(h->N <= 104)
-    rc = go(&zmp_plan_sym_kernel<104>, SymTab<104>{});
-  else if(h->N <= 112)
-    rc = go(&zmp_plan_sym_kernel<112>, SymTab<112>{});
-  else
-    rc = go(&zmp_plan_sym_kernel<128>, SymTab<128>{});
+#define CCC_ZMP_SYM(NR, TS, TPT) rc = go(&zmp_plan_sym_kernel<NR, TS, TPT>, SymTab<NR, TS, TPT>{})
+  const int N = h->N;
+  if(N <= 40) CCC_ZMP_SYM(40, 4, 2);
+  else if(N <= 48) CCC_ZMP_SYM(48, 4, 2);
+  else if(N <= 56) CCC_ZMP_SYM(56, 4, 2);
+  else if(N <= 64) CCC_ZMP_SYM(64, 4, 2);
+  else if(N <= 72) CCC_ZMP_SYM(72, 4, 2);
+  else if(N <= 80) CCC_ZMP_SYM(80, 4, 2);
+  else if(N <= 96) CCC_ZMP_SYM(96, 4, 2);
+  else if(N <= 104) CCC_ZMP_SYM(104, 4, 2);
+  else if(N <= 112) CCC_ZMP_SYM(112, 4, 2);
+  else if(N <= 128) CCC_ZMP_SYM(128, 4, 3);
+  else if(N <= 160) CCC_ZMP_SYM(160, 4, 2);
+  else if(N <= 192) CCC_ZMP_SYM(192, 4, 3);
+  else CCC_ZMP_SYM(200, 2, 5); // 2 x 2 tiles: 158 KB, the last size that fits the 160 KB of LDS
+#undef CCC_ZMP_SYM
   if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
@@ -1427,26 +1200,6 @@ extern "C" int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double 
   CCC_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if(h->NP == 32) return launch<32, 4>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
-  if(h->NP == 64 && h->N <= kZmpWaveMaxN)
-  {
-    const int64_t nqp = 2 * n;
-    const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 64);
-    ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
-    auto go = [&](auto kernel) {
-      hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), 0, s, P, 64, (long)nqp, x0, zlim, control_dt, zmp, jerk, status);
-    };
-    if(h->N <= 40)
-      go(zmp_plan_wave_kernel<40>);
-    else if(h->N <= 48)
-      go(zmp_plan_wave_kernel<48>);
-    else if(h->N <= 56)
-      go(zmp_plan_wave_kernel<56>);
-    else
-      go(zmp_plan_wave_kernel<64>);
-    CCC_HIP_CHECK(hipGetLastError());
-    return CCC_OK;
-  }
-  if(h->NP == 64) return launch<64, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
   return launch_block(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
 }
 

@@ -183,9 +183,10 @@ def test_golden_vectors_n100_block_kernel(golden_zmp):
     assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
 
 
-def test_n200_hbm_tableau_kernel():
-    """128 < N <= 256: BASELINE.json configs[0] as worded (2 s horizon @ dt = 10 ms = 200 steps) -- the tableau no longer
-    fits LDS and lives in an HBM workspace.  Parity with the oracle, and a short stretch of the reference closed loop."""
+def test_n200_packed_lds_tableau():
+    """BASELINE.json configs[0] as worded (2 s horizon @ dt = 10 ms = 200 steps): the largest horizon whose packed
+    symmetric tableau (2 x 2 tiles) fits the 160 KB of LDS.  Parity with the oracle, and a short stretch of the reference
+    closed loop."""
     mpc = LinearMpcZmp(1.0, 2.0, 0.01)
     assert mpc.horizon_steps_ == 200
     b = fx.make_zmp_batch(40, 200, 0.01, seed=31)
@@ -199,6 +200,21 @@ def test_n200_hbm_tableau_kernel():
         assert np.all(rec["zmp"] - rec["zmin"] >= 0) and np.all(rec["zmax"] - rec["zmp"] >= 0)
     with pytest.raises(_lib.CccError):
         LinearMpcZmp(1.0, 2.0, 0.005)  # 400 steps: not built
+
+
+@pytest.mark.parametrize("N", [36, 47, 64, 72, 90, 112, 128, 150, 180, 230])
+def test_horizon_sizes_against_oracle(N):
+    """One parity case per kernel instantiation: packed LDS tableau with 4 x 4 tiles (40..192 rows), and the HBM-resident
+    tableau beyond 200 steps."""
+    dt = 2.0 / N
+    mpc = LinearMpcZmp(1.0, 2.0, dt)
+    assert mpc.horizon_steps_ == N
+    b = fx.make_zmp_batch(24, N, dt, seed=100 + N)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
 
 
 def test_reference_scenario_n100_closed_loop():
