@@ -12,9 +12,9 @@
 // u* = -H^-1 g the unconstrained minimiser; because g = -w_zmp P'r (r = zref - z0 1) the offsets are
 // d = Ct u* = w_zmp G[:, :N] r -- G itself, no further matrix.  So this is LinearMpcZmp's range problem
 // lo <= G mu <= hi (csrc/zmp.hip) with N+1 rows, the last one of zero width (an equality: it enters first and is never
-// dropped), solved by the same sweep-tableau iteration: one QP per 128-thread workgroup, thread i = row i, tableau in
-// LDS.  u0 = H^-1[0, :] Ct' (mu + w_zmp [r; 0]) needs one more constant row (hc).
+// dropped), solved by the same sweep-tableau iteration: one QP per workgroup, the tableau packed in LDS (sym_tableau.h).  u0 = H^-1[0, :] Ct' (mu + w_zmp [r; 0]) needs one more constant row (hc).
 #include "common.h"
+#include "sym_tableau.h"
 #include "wave_group.h"
 
 #include <cmath>
@@ -24,8 +24,6 @@
 namespace ccc_amd
 {
 constexpr int kIsmNP = 128;   // rows per QP (N + 1 <= 128)
-constexpr int kIsmParts = 4;  // threads per row: thread (part, i) updates a quarter of column i of the tableau
-constexpr int kIsmNT = kIsmNP * kIsmParts; // 512 threads = 8 wavefronts: the LDS latency of the rank-1 update is hidden
 constexpr double kIsmInf = __builtin_huge_val();
 
 struct IsmDev
@@ -43,21 +41,23 @@ struct IsmRed
   int idx[2];
 };
 
-// (min value over the 128-thread block, lowest thread index attaining it; index kIsmNP if no finite candidate)
+// (min value over the rows -- the first WR wavefronts of the block --, lowest thread index attaining it; index kIsmNP
+// if no finite candidate)
+template<int WR>
 __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double & vmin, int & imin)
 {
   const int tid = threadIdx.x, w = tid >> 6;
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm && v < kIsmInf);
   __syncthreads(); // red may still be read by the previous reduction
-  if((tid & 63) == 0 && w < 2) // rows live in the first two wavefronts (part 0)
+  if((tid & 63) == 0 && w < WR)
   {
     red->val[w] = wm;
     red->idx[w] = wi < 64 ? wi + 64 * w : kIsmNP;
   }
   __syncthreads();
-  const double a = red->val[0], b = red->val[1];
-  const int ia = red->idx[0], ib = red->idx[1];
+  const double a = red->val[0], b = WR > 1 ? red->val[1] : kIsmInf;
+  const int ia = red->idx[0], ib = WR > 1 ? red->idx[1] : kIsmNP;
   const bool first = (ia < kIsmNP) && (a <= b || ib >= kIsmNP);
   vmin = first ? a : b;
   imin = first ? ia : ib;
@@ -65,21 +65,25 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
 
 // init [nqp][2] (capture_point, planned_zmp), ref [nqp][3][N] (ref zmp, zmin, zmax), zmp [nqp], vel [nqp][N] | null,
 // status [nqp] | null.  A "qp" is one axis of one instance.
-__global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, const double * __restrict__ init,
-                                                          const double * __restrict__ ref, double control_dt,
-                                                          double * __restrict__ zmp, double * __restrict__ vel,
-                                                          int * __restrict__ status)
+// One QP per workgroup, the sweep tableau packed (lower triangle in 4 x 4 tiles, sym_tableau.h) in LDS: thread t updates
+// the tiles t, t + NT, ..., thread i < NR owns row i (bounds, multiplier, flags).  NR >= N + 1 rows.
+template<int NR, int TPT>
+__global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMinWaves)) void ism_plan_kernel(
+    IsmDev P, long nqp, const double * __restrict__ init, const double * __restrict__ ref, double control_dt,
+    double * __restrict__ zmp, double * __restrict__ vel, int * __restrict__ status)
 {
-  constexpr int NP = kIsmNP;
+  using ST = SymTab<NR, 4, TPT>;
+  constexpr int NP = kIsmNP; // row stride of P.G / P.Wc, and the "no candidate" index
+  constexpr int WR = (NR + 63) / 64;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int TS = NP + 1;    // odd row stride: column writes are bank-conflict free
-  double * T = smem;            // [NP][TS]
-  double * cb = smem + NP * TS; // [NP] staging of the pivot row / of mu / of rho
-  double * dp = cb + NP;        // [kIsmParts][NP] partial offsets
-  IsmRed * red = reinterpret_cast<IsmRed *>(dp + kIsmParts * NP);
-  const int i = threadIdx.x & (NP - 1), part = threadIdx.x / NP;
-  const bool lead = part == 0; // thread (0, i) owns row i: bounds, multiplier, flags
-  constexpr int JQ = NP / kIsmParts;
+  double * T = smem;                 // packed tableau
+  double * cb = smem + ST::kDoubles; // [NR] staging of the pivot row / of mu / of rho
+  IsmRed * red = reinterpret_cast<IsmRed *>(cb + NR);
+  const int i = threadIdx.x;
+  const bool lead = i < NR; // thread i owns row i: bounds, multiplier, flags
+  int ta[TPT], tb[TPT];     // this thread's tiles: i, i + NT, ...
+#pragma unroll
+  for(int k = 0; k < TPT; ++k) ST::tile_of(i + k * ST::NT < ST::NTILE ? i + k * ST::NT : 0, ta[k], tb[k]);
   const int N = P.N;
   const int maxpass = 20 * (N + 1) + 100;
 
@@ -98,26 +102,12 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
     __syncthreads();
     if(lead) cb[i] = r;
     __syncthreads();
-    // tableau <- G, offsets d = w_zmp G[:, :N] r in the same pass (G symmetric: column i read as row i); every part
-    // copies its quarter and contributes a partial sum
-    double d = 0.0;
-    for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 8)
-    {
-      double gv[8], cv[8];
+    // tableau <- G, then the offsets d = w_zmp G[:, :N] r off the LDS copy
 #pragma unroll
-      for(int q = 0; q < 8; ++q) gv[q] = P.G[(j0 + q) * NP + i];
-#pragma unroll
-      for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q]; // 0 for j >= N
-#pragma unroll
-      for(int q = 0; q < 8; ++q)
-      {
-        T[(j0 + q) * TS + i] = gv[q];
-        d = fma(gv[q], cv[q], d);
-      }
-    }
-    dp[part * NP + i] = d;
+    for(int k = 0; k < TPT; ++k)
+      if(i + k * ST::NT < ST::NTILE) ST::load_tile(T, P.G, NP, i + k * ST::NT, ta[k], tb[k]);
     __syncthreads();
-    d = ((dp[i] + dp[NP + i]) + (dp[2 * NP + i] + dp[3 * NP + i])) * P.w_zmp;
+    const double d = lead ? ST::matvec_row(T, cb, i) * P.w_zmp : 0.0;
     const double lo = rng ? (zl - z0) - d : (iseq ? (cp - z0) - d : -kIsmInf);
     const double hi = rng ? (zh - z0) - d : (iseq ? (cp - z0) - d : kIsmInf);
     const double tl = row ? 1e-12 * (1.0 + fabs(lo)) : 0.0;
@@ -144,7 +134,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
           if(iseq && !inW) score = 1e300; // the equality row enters first (oracle/qp_gi.c) and stays
           double m;
           int cand;
-          ism_block_argmin(score > 0.0 ? -score : kIsmInf, red, m, cand);
+          ism_block_argmin<WR>(score > 0.0 ? -score : kIsmInf, red, m, cand);
           if(cand >= NP) break;
           p = cand;
           if(lead && i == cand)
@@ -161,7 +151,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
           __syncthreads();
         }
         const double sig = cb[0];
-        const double c = T[p * TS + i]; // column p = row p (symmetric)
+        const double c = lead ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = lead && (i == p);
@@ -171,7 +161,7 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
         if(isp && !(c > 0.0)) ratio = kIsmInf; // no curvature left along row p: it cannot be satisfied
         double t;
         int kk;
-        ism_block_argmin(ratio, red, t, kk);
+        ism_block_argmin<WR>(ratio, red, t, kk);
         if(kk >= NP)
         {
           st = CCC_STATUS_INFEASIBLE;
@@ -186,32 +176,16 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
           z = fma(sig * t, c, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = T[kk * TS + i];
+        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
         if(lead) cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        // column i of the tableau, sixteen entries at a time: all loads of a chunk are issued before its stores (T and cb
-        // are both LDS, so the compiler must assume they alias and would otherwise serialise load - store - load ...)
-        for(int j0 = part * JQ; j0 < (part + 1) * JQ; j0 += 16)
-        {
-          double tv[16], cv[16];
 #pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = T[(j0 + q) * TS + i];
-#pragma unroll
-          for(int q = 0; q < 16; ++q) cv[q] = cb[j0 + q];
-#pragma unroll
-          for(int q = 0; q < 16; ++q) tv[q] = fma(-g, cv[q], tv[q]);
-#pragma unroll
-          for(int q = 0; q < 16; ++q) T[(j0 + q) * TS + i] = tv[q];
-        }
+        for(int k = 0; k < TPT; ++k)
+          if(i + k * ST::NT < ST::NTILE) ST::update_tile(T, cb, rp, i + k * ST::NT, ta[k], tb[k]);
         __syncthreads();
-        if(lead) // row and column kk (thread kk's column came out of the loop as rounding noise), the pivot itself
-        {
-          const double e = (i == kk) ? -rp : s * g;
-          T[kk * TS + i] = e;
-          T[i * TS + kk] = e;
-        }
+        if(lead) T[ST::entry(kk, i)] = (i == kk) ? -rp : s * g; // row/column kk (the update left noise there), the pivot
         __syncthreads();
         if(isadd)
         {
@@ -245,19 +219,20 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
       if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       double acc = 0.0;
-      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      if(lead)
+        for(int j = 0; j < NR; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
       const double rho = inW ? dact - acc : 0.0;
       __syncthreads();
       if(lead) cb[i] = rho;
       __syncthreads();
-      double tr = 0.0;
-      for(int j = 0; j < NP; ++j) tr = fma(T[j * TS + i], cb[j], tr);
+      const double tr = lead ? ST::matvec_row(T, cb, i) : 0.0;
       if(inW) mu -= tr;
       __syncthreads();
       if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       acc = 0.0;
-      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      if(lead)
+        for(int j = 0; j < NR; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
       z = inW ? dact : acc;
       const double sl = (lo - z) - tl, sh = (z - hi) - th;
       const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
@@ -274,7 +249,8 @@ __global__ __launch_bounds__(kIsmNT) void ism_plan_kernel(IsmDev P, long nqp, co
       if(lead) cb[i] = inW ? mu : 0.0;
       __syncthreads();
       double acc = 0.0;
-      for(int j = 0; j < NP; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
+      if(lead)
+        for(int j = 0; j < NR; ++j) acc = fma(P.G[j * NP + i], cb[j], acc);
       const bool bad = row && !((lo - acc) <= 1e-9 * (1.0 + fabs(lo)) && (acc - hi) <= 1e-9 * (1.0 + fabs(hi)));
       if(__syncthreads_or(bad ? 1 : 0)) st = CCC_STATUS_INFEASIBLE;
     }
@@ -464,19 +440,32 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(n == 0) return CCC_OK;
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
   CCC_HIP_CHECK(hipSetDevice(h->device));
-  const size_t lds = ((size_t)kIsmNP * (kIsmNP + 1) + kIsmNP + kIsmParts * kIsmNP) * sizeof(double) + sizeof(IsmRed);
-  static bool attr_set = false;
-  if(!attr_set)
-  {
-    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&ism_plan_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   const int64_t nqp = 2 * n;
-  const int grid = (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 8);
+  // one workgroup per QP: the pivot count varies severalfold between QPs, the hardware dispatcher evens it out
+  const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
   IsmDev P{h->N, h->dG, h->dWc, h->w_zmp, h->horizon_dt};
-  hipLaunchKernelGGL(ism_plan_kernel, dim3(grid), dim3(kIsmNT), lds, reinterpret_cast<hipStream_t>(stream), P,
-                     (long)nqp, init, ref, control_dt, zmp, vel, status);
+  auto go = [&](auto kernel, auto st) -> int {
+    using ST = decltype(st);
+    const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(IsmRed);
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, reinterpret_cast<hipStream_t>(stream), P, (long)nqp, init, ref,
+                       control_dt, zmp, vel, status);
+    return CCC_OK;
+  };
+  const int R = h->N + 1; // rows: the ZMP limits of every step and the capture-point equality
+  int rc;
+  if(R <= 32)
+    rc = go(&ism_plan_kernel<32, 2>, SymTab<32, 4, 2>{});
+  else if(R <= 56)
+    rc = go(&ism_plan_kernel<56, 2>, SymTab<56, 4, 2>{});
+  else if(R <= 80)
+    rc = go(&ism_plan_kernel<80, 2>, SymTab<80, 4, 2>{});
+  else if(R <= 104)
+    rc = go(&ism_plan_kernel<104, 2>, SymTab<104, 4, 2>{});
+  else
+    rc = go(&ism_plan_kernel<128, 3>, SymTab<128, 4, 3>{});
+  if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }
