@@ -18,6 +18,7 @@
 // the dual active-set / sweep-tableau iteration of LinearMpcZmp on G = H^-1; a closing primal refinement with the
 // untouched H removes the drift, a final certificate checks the bounds.
 #include "common.h"
+#include "sym_tableau.h"
 #include "wave_group.h"
 
 #include <cmath>
@@ -53,24 +54,25 @@ __device__ __forceinline__ void z_wave_argmin(double v, double & vmin, int & imi
   imin = WaveGroup<64>::first(v == vmin && v < kZInf);
 }
 
-template<int NR>
+template<int NR, int TPT>
 __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n)
 {
   constexpr int NP = kZNP;
-  // sweep tableau [j][i] (i fastest), NR x NR doubles (NR = N rounded up to 8; a template parameter, so that every
-  // access is `ds_read/write_b64 base, offset:imm` off one address register) with the odd row stride NR + 1: row AND
-  // column accesses are bank-conflict free, and at N = 40 the tableau takes 13 KB instead of 32 KB (eleven resident
-  // workgroups per CU instead of four).  Padding rows/columns hold the identity and stay so under the sweeps; lanes
-  // >= NR own no column.
-  constexpr int NS = NR + 1;
+  // sweep tableau: symmetric, packed in LDS as the 4 x 4 tiles of its lower triangle (sym_tableau.h), NR = N rounded up
+  // to 8 rows: lane t updates the tiles t, t + 64, ...; at N = 40 the tableau takes 7 KB (full storage: 13 KB; padded
+  // to 64 x 64: 32 KB).  Padding rows/columns hold the identity and stay so under the sweeps.
+  using ST = SymTab<NR, 4, TPT>;
+  static_assert(ST::NT == kZNP, "one wavefront per instance");
   __shared__ __attribute__((aligned(16))) double cb[NP];
   __shared__ double res[NP];
   __shared__ int svar[NP];
-  __shared__ double T[NR * NS];
+  __shared__ __attribute__((aligned(16))) double T[ST::kDoubles];
   const int i = threadIdx.x;
   const int N = P.N;
   const bool col = i < NR;
-  double * Tc = T + i; // column i
+  int ta[TPT], tb[TPT]; // this lane's tiles: i, i + 64, ...
+#pragma unroll
+  for(int k = 0; k < TPT; ++k) ST::tile_of(i + k * 64 < ST::NTILE ? i + k * 64 : 0, ta[k], tb[k]);
   const double c = P.dt * P.dt / P.mass;
 
   for(long b = blockIdx.x; b < n; b += gridDim.x)
@@ -105,22 +107,33 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     // H(l, i) in closed form: w_pos c^2 sum_{j=J}^{N-1} (j - a)(j - bb) + w_force delta, J = max(s_l, s_i), with
     // S1(m) = sum_{j<m} j, S2(m) = sum_{j<m} j^2.  Cheap enough that the closing refinement re-evaluates it instead of
     // keeping an untouched copy of H in LDS (32 KB: the difference between two and four workgroups per CU).
-    auto h_entry = [&](int l, int sl) {
-      const double a = si - 0.5, bb = sl - 0.5;
-      const double J = si > sl ? si : sl;
+    auto h_steps = [&](int sa, int sb, bool diag) { // entry of H between the variables of steps sa and sb
+      const double a = sa - 0.5, bb = sb - 0.5;
+      const double J = sa > sb ? sa : sb;
       const double Nn = N;
       const double s1 = 0.5 * (Nn * (Nn - 1.0) - J * (J - 1.0));
       const double s2 = ((Nn - 1.0) * Nn * (2.0 * Nn - 1.0) - (J - 1.0) * J * (2.0 * J - 1.0)) / 6.0;
-      return P.w_pos * (c * c) * (s2 - (a + bb) * s1 + a * bb * (Nn - J)) + ((l == i) ? P.w_force : 0.0);
+      return P.w_pos * (c * c) * (s2 - (a + bb) * s1 + a * bb * (Nn - J)) + (diag ? P.w_force : 0.0);
     };
+    auto h_entry = [&](int l, int sl) { return h_steps(si, sl, l == i); };
     {
       const double a = si - 0.5;
-      for(int l = 0; l < NR; l++)
+      // tile (ta, tb) <- H[4 ta + r][4 tb + cc] (steps of the two variables from svar), identity on the padding
+#pragma unroll
+      for(int k = 0; k < TPT; ++k)
       {
-        // step of variable l = what lane l holds in si (a v_readlane: an LDS load of svar[l] here would have to wait for
-        // the stores of the previous trip, which the compiler must assume to alias)
-        const int sl = __builtin_amdgcn_readlane(si, l);
-        if(col) Tc[l * NS] = (row && l < nv) ? h_entry(l, sl) : ((l == i) ? 1.0 : 0.0); // identity on the padding
+        const int t = i + k * 64;
+        if(t < ST::NTILE)
+#pragma unroll
+          for(int r = 0; r < 4; ++r)
+#pragma unroll
+            for(int cc = 0; cc < 4; ++cc)
+            {
+              const int vr = 4 * ta[k] + r, vc = 4 * tb[k] + cc;
+              const bool in = vr < nv && vc < nv;
+              T[ST::slot_index(t, r * 4 + cc)] =
+                  in ? h_steps(svar[vr < nv ? vr : 0], svar[vc < nv ? vc : 0], vr == vc) : (vr == vc ? 1.0 : 0.0);
+            }
       }
       if(row)
       {
@@ -130,53 +143,39 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       }
     }
     __syncthreads();
-    // T <- -H^-1 by sweeping every variable
+    // T <- -H^-1 by sweeping every variable (only the tiles of the first ceil(nv / 4) tile rows take part)
+    const int nbv = (nv + 3) >> 2, nta = (nbv * (nbv + 1)) >> 1;
     for(int kp = 0; kp < nv; kp++)
     {
-      const double v = col ? T[kp * NS + i] : 0.0;
+      const double v = col ? T[ST::entry(kp, i)] : 0.0;
       cb[i] = v;
       __syncthreads();
       const double rp = 1.0 / cb[kp];
       const double g = v * rp;
-      if(row)
-        for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores (T and cb are both LDS: assumed to alias)
-        {
-          double tv[8], cv[8];
 #pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
-#pragma unroll
-          for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
-#pragma unroll
-          for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
-#pragma unroll
-          for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
-        }
+      for(int k = 0; k < TPT; ++k)
+        if(i + k * 64 < nta) ST::update_tile(T, cb, rp, i + k * 64, ta[k], tb[k]);
       __syncthreads();
-      if(row) // row and column kp (lane kp's column came out of the loop as rounding noise) and the pivot itself
-      {
-        const double e = (i == kp) ? -rp : g;
-        T[kp * NS + i] = e;
-        T[i * NS + kp] = e;
-      }
+      if(row) T[ST::entry(kp, i)] = (i == kp) ? -rp : g; // row/column kp (the update left noise there), the pivot
       __syncthreads();
     }
     // unconstrained minimiser lam0 = -H^-1 g, then G = H^-1 = -T
     cb[i] = row ? gi : 0.0;
     __syncthreads();
-    double lam0 = 0.0;
-    if(row)
-      for(int j0 = 0; j0 < nv; j0 += 8) // (the padding rows of the last chunk are zero in column i < nv)
-      {
-        double tv[8], cv[8];
+    const double lam0 = row ? ST::matvec_row(T, cb, i) : 0.0;
+    __syncthreads();
+    {
+      double2 * T2 = reinterpret_cast<double2 *>(T);
 #pragma unroll
-        for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
+      for(int k = 0; k < TPT; ++k)
+        if(i + k * 64 < ST::NTILE)
 #pragma unroll
-        for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
-#pragma unroll
-        for(int q = 0; q < 8; ++q) lam0 = fma(tv[q], cv[q], lam0);
-#pragma unroll
-        for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = -tv[q];
-      }
+          for(int sl = 0; sl < ST::SL; ++sl)
+          {
+            const double2 x = T2[sl * ST::NTP + i + k * 64];
+            T2[sl * ST::NTP + i + k * 64] = make_double2(-x.x, -x.y);
+          }
+    }
     __syncthreads();
     const double lo = row ? P.fmin - lam0 : -kZInf;
     const double hi = row ? P.fmax - lam0 : kZInf;
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           }
         }
         const double sig = __shfl(psig, p);
-        const double cc = col ? T[p * NS + i] : 0.0; // column p = row p (symmetric)
+        const double cc = col ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
         const double dm = -sig * cc;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = (i == p);
@@ -238,32 +237,17 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
           z = fma(sig * t, cc, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = col ? T[kk * NS + i] : 0.0;
+        const double v = col ? T[ST::entry(kk, i)] : 0.0;
         __syncthreads();
         cb[i] = v;
         __syncthreads();
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
-        if(row)
-          for(int j0 = 0; j0 < nv; j0 += 8) // chunks: loads before stores
-          {
-            double tv[8], cv[8];
 #pragma unroll
-            for(int q = 0; q < 8; ++q) tv[q] = Tc[(j0 + q) * NS];
-#pragma unroll
-            for(int q = 0; q < 8; ++q) cv[q] = cb[j0 + q];
-#pragma unroll
-            for(int q = 0; q < 8; ++q) tv[q] = fma(-g, cv[q], tv[q]);
-#pragma unroll
-            for(int q = 0; q < 8; ++q) Tc[(j0 + q) * NS] = tv[q];
-          }
+        for(int k = 0; k < TPT; ++k)
+          if(i + k * 64 < nta) ST::update_tile(T, cb, rp, i + k * 64, ta[k], tb[k]);
         __syncthreads();
-        if(row)
-        {
-          const double e = (i == kk) ? -rp : s * g;
-          T[kk * NS + i] = e;
-          T[i * NS + kk] = e;
-        }
+        if(row) T[ST::entry(kk, i)] = (i == kk) ? -rp : s * g;
         __syncthreads();
         if(isadd)
         {
@@ -301,12 +285,7 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
       __syncthreads();
       cb[i] = r;
       __syncthreads();
-      if(row && !inW)
-      {
-        double dz = 0.0;
-        for(int j = 0; j < nv; ++j) dz = fma(Tc[j * NS], cb[j], dz);
-        z += dz;
-      }
+      if(row && !inW) z += ST::matvec_row(T, cb, i);
       const double sl = (lo - z) - tl, sh = (z - hi) - th;
       const int reopen = __syncthreads_or(row && !inW && fmax(sl, sh) > 0.0);
       need_select = true;
@@ -400,19 +379,19 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   CCC_HIP_CHECK(hipSetDevice(h->device));
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
-  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 64);
+  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances
   auto go = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
   };
   switch((h->N + 7) / 8)
   {
-    case 1: case 2: go(z_plan_kernel<16>); break;
-    case 3: go(z_plan_kernel<24>); break;
-    case 4: go(z_plan_kernel<32>); break;
-    case 5: go(z_plan_kernel<40>); break;
-    case 6: go(z_plan_kernel<48>); break;
-    case 7: go(z_plan_kernel<56>); break;
-    default: go(z_plan_kernel<64>); break;
+    case 1: case 2: go(z_plan_kernel<16, 1>); break;
+    case 3: go(z_plan_kernel<24, 1>); break;
+    case 4: go(z_plan_kernel<32, 1>); break;
+    case 5: go(z_plan_kernel<40, 1>); break;
+    case 6: go(z_plan_kernel<48, 2>); break;
+    case 7: go(z_plan_kernel<56, 2>); break;
+    default: go(z_plan_kernel<64, 3>); break;
   }
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
