@@ -221,7 +221,7 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the gains of the last horizon step are read as a box-QP warm start before they are first written
   CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * CCC_DDP_MAX_RIDGES * sizeof(double), s));
-  const int grid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 32);
+  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances
   if(h->S == 9)
     hipLaunchKernelGGL((ddp_plan_kernel<9, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
   else

@@ -698,7 +698,8 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   P.flo = 3.0; // src/LinearMpcXY.cpp:91
   P.fhi = 3.0 * h->prm.mass * kXyG;
   XyBatch B{dim, vertex, ridge, com_z, total_force_z, ref_out, x0, u0, lambda_all, status};
-  const int grid = (int)std::min<int64_t>(n, h->blocks);
+  // one workgroup per instance: the pivot count varies severalfold, the hardware dispatcher evens it out
+  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
   hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
