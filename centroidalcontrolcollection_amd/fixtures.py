@@ -437,3 +437,108 @@ def reference_scenario_timeline():
                 foot_id=np.array([[fs.foot for fs in steps]], dtype=np.int32),
                 swing_start=np.array([[fs.swing_start_time for fs in steps]]),
                 swing_end=np.array([[fs.swing_end_time for fs in steps]]))
+
+
+# ------------------------------------------------------------------------------------------------ DdpZmp
+class ComZmpSim3d:
+    """SimModels.h:140-222: the 1-D CoM-ZMP model per horizontal axis, rebuilt every cycle with the current CoM height
+    (:196), and the vertical double integrator under gravity (VerticalSimModel)."""
+
+    def __init__(self, mass, sim_dt):
+        self.sim_dt = sim_dt
+        self.x = np.zeros(2)
+        self.y = np.zeros(2)
+        self.zsim = VerticalSim(mass, sim_dt)
+
+    @property
+    def z(self):
+        return self.zsim.state
+
+    def pos(self):
+        return np.array([self.x[0], self.y[0], self.z[0]])
+
+    def vel(self):
+        return np.array([self.x[1], self.y[1], self.z[1]])
+
+    def update(self, zmp, force_z):
+        w = math.sqrt(G / self.z[0])
+        ch, sh = math.cosh(w * self.sim_dt), math.sinh(w * self.sim_dt)
+        Ad = np.array([[ch, sh / w], [w * sh, ch]])
+        Bd = np.array([1 - ch, -w * sh])
+        self.x = Ad @ self.x + Bd * zmp[0]
+        self.y = Ad @ self.y + Bd * zmp[1]
+        self.zsim.update(force_z)
+
+    def addDisturb(self, impulse_per_mass):
+        # SimModels.h:206-210 adds impulse.x() to BOTH axes (reference quirk, kept)
+        self.x[1] += impulse_per_mass[0]
+        self.y[1] += impulse_per_mass[0]
+
+
+def sample_ddpzmp_refs(fm, t, N, dt, com_height=1.0):
+    """RefData of TestDdpZmp.cpp:45-51 at t + i dt, i = 0..N: [N+1, 4] = (ref zmp x, y, 0, ref_com_height)."""
+    ref = np.zeros((N + 1, 4))
+    for i in range(N + 1):
+        ref[i, :2] = fm.refZmp(t + i * dt)
+        ref[i, 3] = com_height
+    return ref
+
+
+def run_closed_loop_ddpzmp(plan_once, mass=100.0, com_height=1.0, horizon_steps=100, horizon_dt=0.02, sim_dt=0.005,
+                           end_time=10.0, disturb_times=(4.5, 8.5), disturb=(0.05, 0.05)):
+    """The control loop of TestDdpZmp.cpp:70-125 around any
+    `plan_once(ref [N+1,4], x0 [6], u_init [N,3]) -> u [N,3]` (the planned input sequence, warm start of the next
+    cycle, :88-91).  Returns per-cycle records and the final state for the assertions of :108-109,:131-134."""
+    fm = FootstepManager()
+    for fs in reference_scenario_footsteps():
+        fm.appendFootstep(fs)
+    sim = ComZmpSim3d(mass, sim_dt)
+    sim.z[0] = com_height
+    t, log, u_list = 0.0, [], None
+    while t < end_time:
+        fm.update(t)
+        p, v = sim.pos(), sim.vel()
+        if u_list is None:
+            u_list = np.tile(np.array([p[0], p[1], mass * G]), (horizon_steps, 1))
+        x0 = np.array([p[0], v[0], p[1], v[1], p[2], v[2]])
+        u_list = np.asarray(plan_once(sample_ddpzmp_refs(fm, t, horizon_steps, horizon_dt, com_height), x0, u_list))
+        zmp, fz = u_list[0, :2].copy(), float(u_list[0, 2])
+        log.append(dict(t=t, com=p, zmp=zmp, force_z=fz, ref_zmp=fm.refZmp(t)))
+        t += sim_dt
+        sim.update(zmp, fz)
+        for dtm in disturb_times:
+            if dtm <= t < dtm + sim_dt:
+                sim.addDisturb(disturb)
+                break
+    return log, dict(t=t, com=sim.pos(), vel=sim.vel(), zmp=zmp, ref_zmp=fm.refZmp(t))
+
+
+def make_ddpzmp_batch(n, horizon_steps=100, horizon_dt=0.02, mass=100.0, com_height=1.0, seed=20250928):
+    """Synthetic DdpZmp workload: random evaluation times along the reference scenario of TestDdpZmp.cpp:32-44, CoM
+    near the reference ZMP (+- 5 cm, +- 0.2 m/s, height +- 2 cm), warm start = (CoM xy, m g) as in :84-86.
+    Returns dict(ref [n,N+1,4], x0 [n,6], u_init [n,N,3])."""
+    rng = np.random.default_rng(seed)
+    N = horizon_steps
+    ref = np.zeros((n, N + 1, 4))
+    x0 = np.zeros((n, 6))
+    u_init = np.zeros((n, N, 3))
+    cache = {}
+    for k in range(n):
+        t = round(float(rng.uniform(0.0, 9.0)) / 0.005) * 0.005
+        if t not in cache:
+            fm = FootstepManager()
+            for fs in reference_scenario_footsteps():
+                fm.appendFootstep(fs)
+            tt = 0.0
+            while tt < t - 1e-12:
+                fm.update(tt)
+                tt += 0.05
+            fm.update(t)
+            cache[t] = sample_ddpzmp_refs(fm, t, N, horizon_dt, com_height)
+        ref[k] = cache[t]
+        x0[k, 0] = ref[k, 0, 0] + rng.uniform(-0.05, 0.05)
+        x0[k, 2] = ref[k, 0, 1] + rng.uniform(-0.05, 0.05)
+        x0[k, 4] = com_height + rng.uniform(-0.02, 0.02)
+        x0[k, 1], x0[k, 3], x0[k, 5] = rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2), rng.uniform(-0.05, 0.05)
+        u_init[k, :, 0], u_init[k, :, 1], u_init[k, :, 2] = x0[k, 0], x0[k, 2], mass * G
+    return dict(ref=ref, x0=x0, u_init=u_init)

@@ -182,6 +182,13 @@ class _DdpProblem(ctypes.Structure):
 _ddp_bound = False
 
 
+class _DdpZmpParams(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int), ("mass", ctypes.c_double), ("dt", ctypes.c_double),
+                ("w_run_com_z", ctypes.c_double), ("w_run_zmp", ctypes.c_double), ("w_run_force_z", ctypes.c_double),
+                ("w_term_com_xy", ctypes.c_double), ("w_term_com_z", ctypes.c_double),
+                ("w_term_com_vel", ctypes.c_double)]
+
+
 def _bind_ddp():
     global _ddp_bound
     L = lib()
@@ -201,6 +208,13 @@ def _bind_ddp():
     L.oracle_ddp_model_eval.restype = None
     L.oracle_det_sincos.argtypes = [ctypes.c_double, _dp, _dp]
     L.oracle_det_sincos.restype = None
+    L.oracle_ddpzmp_default_config.argtypes = [ctypes.POINTER(_DdpConfig)]
+    L.oracle_ddpzmp_default_config.restype = None
+    L.oracle_ddpzmp_plan_batch.argtypes = [ctypes.POINTER(_DdpZmpParams), ctypes.POINTER(_DdpConfig), ctypes.c_long,
+                                           _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, ctypes.c_int]
+    L.oracle_ddpzmp_plan_batch.restype = ctypes.c_int
+    L.oracle_ddpzmp_eval.argtypes = [ctypes.POINTER(_DdpZmpParams), _dp, ctypes.c_int] + [_dp] * 10
+    L.oracle_ddpzmp_eval.restype = None
     _ddp_bound = True
     return L
 
@@ -441,3 +455,52 @@ class LinearMpcXY:
                                    _ptr(fz), _ptr(ref), _ptr(x0), _ptr(u0), _ptr(lam), _ptr(iters, ctypes.c_int),
                                    _ptr(status, ctypes.c_int), int(nthreads))
         return dict(u0=u0, lam=lam, iters=iters, status=status)
+
+
+class DdpZmp:
+    """CPU restatement of CCC::DdpZmp (oracle/ddp_zmp.c + oracle/ddp.c) on pre-sampled RefData.
+
+    weights = (running_com_pos_z, running_zmp, running_force_z, terminal_com_pos_xy, terminal_com_pos_z,
+    terminal_com_vel), defaults of include/CCC/DdpZmp.h:72-77."""
+
+    def __init__(self, mass, horizon_dt, horizon_steps, weights=(1e2, 1e-1, 1e-4, 1.0, 1e2, 1.0), max_iter=500):
+        L = _bind_ddp()
+        self.N = int(horizon_steps)
+        self.cfg = _DdpConfig()
+        L.oracle_ddpzmp_default_config(ctypes.byref(self.cfg))
+        self.cfg.max_iter = int(max_iter)
+        self.prm = _DdpZmpParams(self.N, float(mass), float(horizon_dt), *[float(w) for w in weights])
+
+    def plan_batch(self, ref, x0, u_init=None, nthreads=1):
+        """ref [n,N+1,4] (zmp x, y, z, com_z at t + i dt), x0 [n,6] ([cx,vx,cy,vy,cz,vz]), u_init [n,N,3] | None.
+        Returns dict(u [n,N,3], x [n,N+1,6], iters, status, cost); planned zmp = u[:,0,:2], force_z = u[:,0,2]."""
+        L = _bind_ddp()
+        N = self.N
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        n = x0.shape[0]
+        assert ref.shape == (n, N + 1, 4) and x0.shape == (n, 6)
+        ui = None if u_init is None else np.ascontiguousarray(u_init, dtype=np.float64)
+        assert ui is None or ui.shape == (n, N, 3)
+        u = np.zeros((n, N, 3))
+        x = np.zeros((n, N + 1, 6))
+        iters = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        cost = np.zeros(n)
+        L.oracle_ddpzmp_plan_batch(ctypes.byref(self.prm), ctypes.byref(self.cfg), n, _ptr(ref), _ptr(x0), _ptr(ui),
+                                   _ptr(u), _ptr(x), _ptr(iters, ctypes.c_int), _ptr(status, ctypes.c_int), _ptr(cost),
+                                   int(nthreads))
+        return dict(u=u, x=x, iters=iters, status=status, cost=cost)
+
+    def eval(self, ref, step, x, u):
+        """Problem callbacks at (step, x, u) for one instance: ref [N+1,4]."""
+        L = _bind_ddp()
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        xn, Fx, Fu = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 3))
+        rc, tc = np.zeros(1), np.zeros(1)
+        Lx, Lu, Vx = np.zeros(6), np.zeros(3), np.zeros(6)
+        L.oracle_ddpzmp_eval(ctypes.byref(self.prm), _ptr(ref), int(step), _ptr(x), _ptr(u), _ptr(xn), _ptr(Fx), _ptr(Fu),
+                             _ptr(rc), _ptr(tc), _ptr(Lx), _ptr(Lu), _ptr(Vx))
+        return dict(x_next=xn, Fx=Fx, Fu=Fu, run_cost=rc[0], term_cost=tc[0], Lx=Lx, Lu=Lu, Vx=Vx)
