@@ -8,7 +8,8 @@ from .ddp import DdpCentroidal, DdpSingleRigidBody  # noqa: F401
 from .linear_mpc_xy import LinearMpcXY  # noqa: F401
 from .intrinsically_stable_mpc import IntrinsicallyStableMpc  # noqa: F401
 from .linear_mpc_z import LinearMpcZ  # noqa: F401
+from .ddp_zmp import DdpZmp  # noqa: F401
 from .linear_mpc_zmp import InitialParam, LinearMpcZmp, RefData  # noqa: F401
 
 __all__ = ["LinearMpcZmp", "RefData", "InitialParam", "DdpCentroidal", "DdpSingleRigidBody", "LinearMpcXY",
-           "IntrinsicallyStableMpc", "LinearMpcZ"]
+           "IntrinsicallyStableMpc", "LinearMpcZ", "DdpZmp"]

@@ -56,6 +56,13 @@ ABI_SYMBOLS = [
     "ccc_z_destroy",
     "ccc_z_plan_batch_device",
     "ccc_z_plan_batch",
+    "ccc_ddpzmp_default_config",
+    "ccc_ddpzmp_create",
+    "ccc_ddpzmp_destroy",
+    "ccc_ddpzmp_set_config",
+    "ccc_ddpzmp_workspace_bytes",
+    "ccc_ddpzmp_plan_batch_device",
+    "ccc_ddpzmp_plan_batch",
 ]
 
 

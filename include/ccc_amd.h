@@ -302,6 +302,44 @@ int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * contact, con
 int ccc_z_plan_batch(ccc_z_t * h, int64_t n, const int32_t * contact, const double * ref_pos, const double * x0,
                      double * force, double * force_all, int32_t * status);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * CCC::DdpZmp -- csrc/ddpzmp.hip, one instance per lane, trajectories and gains streamed
+ * through an HBM workspace laid out [step][field][instance].
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct ccc_ddpzmp ccc_ddpzmp_t;
+
+/* nmpc_ddp::DDPSolver::Configuration defaults (no input constraint; CCC::DdpZmp overrides nothing,
+ * include/CCC/DdpZmp.h:277-282): max_iter 500, initial_lambda 1e-4, lambda_min 1e-6, lambda_thre 1e-5, ... */
+void ccc_ddpzmp_default_config(ccc_ddp_config_t * cfg);
+/* Replaces CCC::DdpZmp::DdpZmp(mass, horizon_dt, horizon_steps, weight_param) (include/CCC/DdpZmp.h:277-282).
+ * weights [6] = WeightParam (running_com_pos_z, running_zmp, running_force_z, terminal_com_pos_xy, terminal_com_pos_z,
+ * terminal_com_vel), NULL = the defaults of include/CCC/DdpZmp.h:72-77. */
+int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_steps, const double * weights, int device,
+                      ccc_ddpzmp_t ** out);
+void ccc_ddpzmp_destroy(ccc_ddpzmp_t * h);
+/* ddp_solver_->config() = cfg   (e.g. max_iter = 3, tests/src/TestDdpZmp.cpp:29) */
+int ccc_ddpzmp_set_config(ccc_ddpzmp_t * h, const ccc_ddp_config_t * cfg);
+/* bytes of device workspace a batch of n instances takes (allocated by the library, grown to the largest batch seen) */
+int64_t ccc_ddpzmp_workspace_bytes(const ccc_ddpzmp_t * h, int64_t n);
+
+/* Replaces n calls of CCC::DdpZmp::planOnce(ref_data_func, initial_param, current_time) (src/DdpZmp.cpp:156-174)
+ * including the external ddp_solver_->solve (:162-169), with ref_data_func already sampled at current_time + i*dt:
+ *
+ *   ref     [n][N+1][4]  f64  RefData (zmp x, y, z, com_z) at step i (i = N: terminal cost)   include/CCC/DdpZmp.h:19-28
+ *   x0      [n][6]       f64  InitialParam::toState() = [pos_x, vel_x, pos_y, vel_y, pos_z, vel_z]   src/DdpZmp.cpp:149-154
+ *   u_init  [n][N][3]    f64  InitialParam::u_list (warm start) or NULL (zeros, src/DdpZmp.cpp:161-166)
+ *   u_out   [n][N][3]    f64  controlData().u_list; PlannedData::zmp = u_out[.][0][0:2], force_z = u_out[.][0][2] (:171-172)
+ *   x_out   [n][N+1][6]  f64  controlData().x_list, or NULL
+ *   iters   [n]          i32  iterations executed (traceDataList().back().iter), or NULL
+ *   status  [n]          i32  0 max_iter reached, 1 gradient small, 2 cost change small, -1 regularisation exhausted; or NULL
+ *   cost    [n]          f64  final cost, or NULL
+ * _device: device pointers + a HIP stream (asynchronous); the other entry stages host arrays through the device. */
+int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const double * ref, const double * x0,
+                                 const double * u_init, double * u_out, double * x_out, int32_t * iters,
+                                 int32_t * status, double * cost, void * stream);
+int ccc_ddpzmp_plan_batch(ccc_ddpzmp_t * h, int64_t n, const double * ref, const double * x0, const double * u_init,
+                          double * u_out, double * x_out, int32_t * iters, int32_t * status, double * cost);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""GPU parity tests of the DdpZmp HIP path (csrc/ddpzmp.hip) -- all calls go through the C-ABI.
+
+The kernel runs the oracle's arithmetic operation by operation (products with structural zeros left out), so the bar
+is the same as for the other DDP classes: identical iteration counts / exit codes and bit-identical trajectories."""
+import numpy as np
+import pytest
+
+from centroidalcontrolcollection_amd import DdpZmp, _lib
+from centroidalcontrolcollection_amd import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.mark.parametrize("N,max_iter,n", [(100, 3, 300), (100, 50, 200), (30, 200, 200), (7, 20, 65)])
+def test_parity_with_oracle(N, max_iter, n):
+    dt = 0.02
+    b = fx.make_ddpzmp_batch(n, N, dt, seed=40 + N)
+    ref = _oracle().DdpZmp(100.0, dt, N, max_iter=max_iter).plan_batch(b["ref"], b["x0"], b["u_init"], nthreads=8)
+    d = DdpZmp(100.0, dt, N)
+    d.ddp_solver_.config().max_iter = max_iter
+    r = d.planOnceBatch(b["ref"], b["x0"], b["u_init"], want_x=True)
+    assert np.array_equal(r["iters"], ref["iters"]) and np.array_equal(r["status"], ref["status"])
+    assert np.array_equal(r["u"], ref["u"]) and np.array_equal(r["x"], ref["x"])
+    assert np.array_equal(r["cost"], ref["cost"])
+
+
+def test_cold_start_and_weights():
+    """u_list empty -> zeros (src/DdpZmp.cpp:161-166): f_z = 0 makes the first Quu singular in the horizontal inputs,
+    the regularisation schedule has to work; non-default weights."""
+    N, dt = 40, 0.02
+    b = fx.make_ddpzmp_batch(64, N, dt, seed=5)
+    w = (50.0, 0.2, 1e-3, 2.0, 80.0, 0.5)
+    ref = _oracle().DdpZmp(100.0, dt, N, weights=w, max_iter=60).plan_batch(b["ref"], b["x0"], None, nthreads=8)
+    d = DdpZmp(100.0, dt, N, DdpZmp.WeightParam(*w))
+    d.ddp_solver_.config().max_iter = 60
+    r = d.planOnceBatch(b["ref"], b["x0"], None)
+    assert np.array_equal(r["iters"], ref["iters"]) and np.array_equal(r["status"], ref["status"])
+    assert np.array_equal(r["u"], ref["u"])
+
+
+def test_ragged_batches_and_empty():
+    N, dt = 20, 0.02
+    b = fx.make_ddpzmp_batch(131, N, dt, seed=9)
+    d = DdpZmp(100.0, dt, N)
+    d.ddp_solver_.config().max_iter = 10
+    full = d.planOnceBatch(b["ref"], b["x0"], b["u_init"])["u"]
+    for n in (1, 63, 64, 65, 131):
+        part = d.planOnceBatch(b["ref"][:n], b["x0"][:n], b["u_init"][:n])["u"]
+        assert np.array_equal(part, full[:n])
+    e = d.planOnceBatch(np.zeros((0, N + 1, 4)), np.zeros((0, 6)), None)
+    assert e["u"].shape == (0, N, 3)
+    with pytest.raises(ValueError):
+        d.planOnceBatch(b["ref"][:, :-1], b["x0"], None)
+    with pytest.raises(_lib.CccError):
+        DdpZmp(-1.0, dt, N)
+
+
+def test_reference_closed_loop_through_plan_once():
+    """tests/src/TestDdpZmp.cpp:12-135 through planOnce(ref_data_func, initial_param, t) on the GPU, every cycle compared
+    with the oracle run on the same inputs."""
+    N, dt, mass = 100, 0.02, 100.0
+    d = DdpZmp(mass, dt, N)
+    d.ddp_solver_.config().max_iter = 3  # :29
+    o = _oracle().DdpZmp(mass, dt, N, max_iter=3)
+    worst = [0.0]
+
+    def plan_once(ref, x0, u_init):
+        ip = DdpZmp.InitialParam((x0[0], x0[2], x0[4]), (x0[1], x0[3], x0[5]), [u for u in u_init])
+        t0 = 0.0  # the callback below ignores the time origin: ref is already sampled at t + i dt
+        pd = d.planOnce(lambda t: DdpZmp.RefData(ref[int(round((t - t0) / dt)), :3], ref[int(round((t - t0) / dt)), 3]),
+                        ip, t0)
+        u = np.asarray(d.ddp_solver_.controlData().u_list)
+        assert np.array_equal(pd.zmp, u[0, :2]) and pd.force_z == u[0, 2]
+        uo = o.plan_batch(ref[None], x0[None], u_init[None])["u"][0]
+        worst[0] = max(worst[0], np.abs(u - uo).max())
+        return u
+
+    log, fin = fx.run_closed_loop_ddpzmp(plan_once, end_time=6.0)
+    assert worst[0] == 0.0
+    for rec in log:  # :108-109
+        assert np.linalg.norm(rec["zmp"] - rec["ref_zmp"]) < 0.1 and abs(rec["com"][2] - 1.0) < 0.1
+
+
+def test_device_entry_full_size_properties():
+    """Bench size (batch 65536, N = 100, max_iter = 3) through the device-pointer entry: determinism, cost decrease,
+    planned first input near the reference, oracle parity on a strided sample."""
+    import torch
+
+    n, N, dt = 65536, 100, 0.02
+    base = fx.make_ddpzmp_batch(2048, N, dt, seed=77)
+    rep = n // 2048
+    dev = torch.device("cuda:0")
+    ref = torch.from_numpy(np.tile(base["ref"], (rep, 1, 1))).to(dev)
+    x0 = torch.from_numpy(np.tile(base["x0"], (rep, 1))).to(dev)
+    ui = torch.from_numpy(np.tile(base["u_init"], (rep, 1, 1))).to(dev)
+    d = DdpZmp(100.0, dt, N)
+    d.ddp_solver_.config().max_iter = 3
+    u = torch.zeros((n, N, 3), dtype=torch.float64, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    c = torch.zeros(n, dtype=torch.float64, device=dev)
+    d.plan_batch_device(ref, x0, ui, u, None, it, st, c)
+    torch.cuda.synchronize()
+    u2 = torch.zeros_like(u)
+    d.plan_batch_device(ref, x0, ui, u2)
+    torch.cuda.synchronize()
+    assert torch.equal(u, u2)
+    uh = u.cpu().numpy()
+    assert np.all(st.cpu().numpy() >= 0)
+    assert np.array_equal(uh[:2048], uh[2048:4096])  # tiled inputs, identical outputs
+    o = _oracle().DdpZmp(100.0, dt, N, max_iter=3).plan_batch(base["ref"][::8], base["x0"][::8], base["u_init"][::8],
+                                                              nthreads=8)
+    assert np.array_equal(uh[:2048:8], o["u"])
+    assert np.array_equal(c.cpu().numpy()[:2048:8], o["cost"])
