@@ -7,7 +7,7 @@ one launch of the dual active-set kernel (csrc/zmp.hip) through the C-ABI (ccc_z
 plus -- for N > 1 GPUs -- the RCCL all-gather of the planned ZMPs (north_star).  Weak scaling: every rank
 solves its own batch of 65536 instances (seed = 20250928 + rank); value = all ranks' solves / max-over-ranks time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--workload zmp|xy|ddp|srb|ism|z]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--workload zmp|xy|ddp|srb|ism|z|ddpzmp]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line.
@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "ism", "z"], default="zmp",
+    ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
     args = ap.parse_args()

@@ -148,15 +148,52 @@ def _z(n, dev, rank):
                 kernel="z_plan_kernel", cpu=cpu, keep=(mpc, tc, tr, tx))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=16384, z=65536)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(10, 2), z=(50, 5))
+def _ddpzmp(n, dev, rank):
+    from centroidalcontrolcollection_amd import DdpZmp, fixtures as fx
+    N, dt, base, max_iter = 100, 0.02, min(n, 2048), 3
+    b = _tile(fx.make_ddpzmp_batch(base, N, dt, seed=20250928 + rank), n, base)
+    d = DdpZmp(100.0, dt, N, device=dev.index)
+    d.ddp_solver_.config().max_iter = max_iter  # tests/src/TestDdpZmp.cpp:29
+    tr, tx, tu = _dev(b["ref"], dev), _dev(b["x0"], dev), _dev(b["u_init"], dev)
+    u = torch.zeros((n, N, 3), dtype=torch.float64, device=dev)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    out = torch.zeros((n, 3), dtype=torch.float64, device=dev)  # PlannedData (zmp, force_z) = the first input
+
+    def step(stream):
+        d.plan_batch_device(tr, tx, tu, u, None, it, st, None, stream=stream)
+        out.copy_(u[:, 0, :])
+
+    def cpu(cores):
+        from oracle import oracle
+        ns = min(n, 65536)
+        o = oracle.DdpZmp(100.0, dt, N, max_iter=max_iter)
+        t0 = time.perf_counter()
+        r = o.plan_batch(b["ref"][:ns], b["x0"][:ns], b["u_init"][:ns], nthreads=cores)
+        t = time.perf_counter() - t0
+        err = np.abs(u.cpu().numpy()[:ns] - r["u"]).max()
+        return ns / t, ns, float(err), "max |d u| over the whole planned input sequence (0 = bit-identical)"
+
+    # bytes a lane must move: RefData + warm start in, per iteration one backward (13 in, 21 out) and one forward (34 in,
+    # 9 out) per horizon step through the workspace, the planned inputs out
+    algo = 8 * ((N + 1) * 4 + N * 3 + 6 + max_iter * N * (13 + 21 + 34 + 9) + N * 3)
+    return dict(name="DdpZmp planOnce() solves/sec (horizon 100, 3 DDP iterations, fp64, inputs resident in HBM)", step=step,
+                out=out, status=st, iters=it,
+                workload="DdpZmp horizon=100 @ 20 ms, max_iter=3, warm start (TestDdpZmp.cpp:17-29), batch=%d per GPU" % n,
+                algo_bytes=algo, kernel="ddpzmp_plan_kernel", cpu=cpu, keep=(d, tr, tx, tu, u),
+                note="algorithmic bytes = inputs + outputs + the trajectories and gains each DDP iteration streams through "
+                     "the HBM workspace (one instance per lane, DESIGN.md 7f)")
+
+
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=16384, z=65536, ddpzmp=65536)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(10, 2), z=(50, 5), ddpzmp=(20, 3))
 
 
 def run(args, rank, world, local_rank, dist):
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
-    make = dict(xy=_xy, ism=_ism, z=_z, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True))
+    make = dict(xy=_xy, ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)
@@ -202,8 +239,9 @@ def run(args, rank, world, local_rank, dist):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": w["algo_bytes"] * n,
                         "kernel": w["kernel"], "kernel_avg_ms": kavg * 1e3,
-                        "note": "algorithmic bytes = mandatory inputs + outputs per instance x batch; the kernel is bound "
-                                "by dependent-operation latency / LDS, not by HBM (DESIGN.md)"},
+                        "note": w.get("note", "algorithmic bytes = mandatory inputs + outputs per instance x batch; the "
+                                              "kernel is bound by dependent-operation latency / LDS, not by HBM "
+                                              "(DESIGN.md)")},
            "unsolved": int((st < 0).sum()) if "iters" in w else int(((st & 0xff) != 0).sum())}  # DDP: status < 0 = failure,
     #                                      0 = iteration limit, 1 / 2 = converged (oracle/ddp.c); QPs: low byte != 0
     if "iters" in w:

@@ -118,3 +118,36 @@ def test_device_entry_full_size_properties():
                                                               nthreads=8)
     assert np.array_equal(uh[:2048:8], o["u"])
     assert np.array_equal(c.cpu().numpy()[:2048:8], o["cost"])
+
+
+def test_cpp_header_shim_matches_python_mirror():
+    """Host C++ against include/CCC/DdpZmp.h (examples/plan_once_ddp_zmp.cpp): same kernel, same sampled inputs as the
+    Python mirror -> identical planned data."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "plan_once_ddp_zmp")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    mass, dt, N = 100.0, 0.02, 100
+    d = DdpZmp(mass, dt, N)
+    d.ddp_solver_.config().max_iter = 3
+
+    def ref(t):
+        s = 0.0 if t < 2.0 else ((t - 2.0) / 0.5 if t < 2.5 else 1.0)
+        return DdpZmp.RefData((0.2 * s, 0.1 * s, 0.0), 1.0)
+
+    for k, t in enumerate((0.0, 1.2, 1.9)):
+        ip = DdpZmp.InitialParam((0.01, -0.02, 1.0), (0.05, 0.0, 0.0), [np.array([0.01, -0.02, mass * fx.G])] * N)
+        pd = d.planOnce(ref, ip, t)
+        for line in (lines[k], lines[3 + k]):
+            z = line.split("zmp=")[1].split("force_z=")
+            zx, zy = (float(v) for v in z[0].split())
+            assert zx == pd.zmp[0] and zy == pd.zmp[1] and float(z[1].split()[0]) == pd.force_z
+        assert int(lines[k].split("iter=")[1]) == d.ddp_solver_.last_iter
