@@ -36,3 +36,9 @@ def test_secondary_workload_two_ranks():
     d = _run(29612, ["--workload", "z", "--steps", "4", "--warmup", "1", "--batch", "2048"])
     assert d["n_gpus"] == 2 and d["unsolved"] == 0 and d["value"] > 0
     assert d["config"]["collective"].startswith("all_gather")
+
+
+def test_ddpzmp_workload_two_ranks():
+    d = _run(29613, ["--workload", "ddpzmp", "--steps", "3", "--warmup", "1", "--batch", "1024"])
+    assert d["n_gpus"] == 2 and d["unsolved"] == 0 and d["value"] > 0 and d["mean_iterations"] == 3.0
+    assert d["config"]["collective"].startswith("all_gather")
