@@ -41,6 +41,19 @@ struct IsmRed
   int idx[2];
 };
 
+struct IsmSel
+{
+  double val[2], sig[2];
+  int idx[2];
+};
+
+__device__ __forceinline__ double ism_lane_value(double v, int k) // k uniform: two v_readlane_b32
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
 // (min value over the rows -- the first WR wavefronts of the block --, lowest thread index attaining it; index kIsmNP
 // if no finite candidate)
 template<int WR>
@@ -79,6 +92,7 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
   double * T = smem;                 // packed tableau
   double * cb = smem + ST::kDoubles; // [NR] staging of the pivot row / of mu / of rho
   IsmRed * red = reinterpret_cast<IsmRed *>(cb + NR);
+  IsmSel * sel = reinterpret_cast<IsmSel *>(red + 1);
   const int i = threadIdx.x;
   const bool lead = i < NR; // thread i owns row i: bounds, multiplier, flags
   int ta[TPT], tb[TPT];     // this thread's tiles: i, i + NT, ...
@@ -118,39 +132,56 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
     double z = 0.0, mu = 0.0, dact = 0.0;
     bool inW = false;
     int p = 0;
-    double psig = 0.0, pd = 0.0;
+    double psig = 0.0, pd = 0.0, sig = 0.0;
     bool done = st != CCC_STATUS_SOLVED; // block uniform
     bool need_select = true;
     int passes = 0;
 
+    // per wavefront: the most violated row outside the working set and its side (the equality row first)
+    auto post_select = [&]() {
+      const double sl = (lo - z) - tl, sh = (z - hi) - th;
+      double score = (inW || !row) ? -kIsmInf : fmax(sl, sh);
+      if(iseq && !inW) score = 1e300; // the equality row enters first (oracle/qp_gi.c) and stays
+      const double key = score > 0.0 ? -score : kIsmInf;
+      const double wm = WaveGroup<64>::min(key);
+      const int wi = WaveGroup<64>::first(key == wm && key < kIsmInf);
+      const double wsig = ism_lane_value((sl >= sh) ? 1.0 : -1.0, wi & 63);
+      const int w = threadIdx.x >> 6;
+      if((threadIdx.x & 63) == 0 && w < WR)
+      {
+        sel->val[w] = wm;
+        sel->sig[w] = wsig;
+        sel->idx[w] = wi < 64 ? wi + 64 * w : NP;
+      }
+    };
     for(int round = 0; round < 3 && !done; ++round)
     {
+      post_select();
+      __syncthreads();
       while(!done)
       {
-        if(need_select)
+        if(need_select) // the candidates were posted before the previous barrier (post_select)
         {
-          const double sl = (lo - z) - tl, sh = (z - hi) - th;
-          double score = (inW || !row) ? -kIsmInf : fmax(sl, sh);
-          if(iseq && !inW) score = 1e300; // the equality row enters first (oracle/qp_gi.c) and stays
-          double m;
-          int cand;
-          ism_block_argmin<WR>(score > 0.0 ? -score : kIsmInf, red, m, cand);
+          double best = sel->val[0], sg = sel->sig[0];
+          int cand = sel->idx[0];
+          if(WR > 1)
+          {
+            const double a2 = sel->val[1];
+            const int i2 = sel->idx[1];
+            const bool take = (i2 < NP) && (cand >= NP || a2 < best);
+            best = take ? a2 : best;
+            sg = take ? sel->sig[1] : sg;
+            cand = take ? i2 : cand;
+          }
           if(cand >= NP) break;
           p = cand;
+          sig = sg;
           if(lead && i == cand)
           {
-            psig = (sl >= sh) ? 1.0 : -1.0;
-            pd = (sl >= sh) ? lo : hi;
-            cb[0] = psig;
+            psig = sg;
+            pd = (sg > 0.0) ? lo : hi;
           }
-          __syncthreads();
         }
-        else
-        {
-          if(lead && i == p) cb[0] = psig;
-          __syncthreads();
-        }
-        const double sig = cb[0];
         const double c = lead ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
         const double dm = -sig * c;
         const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
@@ -176,17 +207,8 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
           z = fma(sig * t, c, z);
         if(isp) mu += sig * t;
         // pivot on row/column kk
-        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
-        if(lead) cb[i] = v;
-        __syncthreads();
-        const double rp = 1.0 / cb[kk];
-        const double g = v * rp;
-#pragma unroll
-        for(int k = 0; k < TPT; ++k)
-          if(i + k * ST::NT < ST::NTILE) ST::update_tile(T, cb, rp, i + k * ST::NT, ta[k], tb[k]);
-        __syncthreads();
-        if(lead) T[ST::entry(kk, i)] = (i == kk) ? -rp : s * g; // row/column kk (the update left noise there), the pivot
-        __syncthreads();
+        // bookkeeping of the step, then the candidates of the next selection: they do not depend on the tableau update,
+        // so posting them here lets the selection ride on the barriers of the update
         if(isadd)
         {
           if(isp)
@@ -206,6 +228,18 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
           }
           need_select = false;
         }
+        if(need_select) post_select();
+        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
+        if(lead) cb[i] = v;
+        __syncthreads();
+        const double rp = 1.0 / cb[kk];
+        const double g = v * rp;
+#pragma unroll
+        for(int k = 0; k < TPT; ++k)
+          if(i + k * ST::NT < ST::NTILE) ST::update_tile(T, cb, rp, i + k * ST::NT, ta[k], tb[k]);
+        __syncthreads();
+        if(lead) T[ST::entry(kk, i)] = (i == kk) ? -rp : s * g; // row/column kk (the update left noise there), the pivot
+        __syncthreads();
         if(++passes > maxpass)
         {
           st = CCC_STATUS_MAX_ITER;
@@ -446,7 +480,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   IsmDev P{h->N, h->dG, h->dWc, h->w_zmp, h->horizon_dt};
   auto go = [&](auto kernel, auto st) -> int {
     using ST = decltype(st);
-    const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(IsmRed);
+    const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(IsmRed) + sizeof(IsmSel);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, reinterpret_cast<hipStream_t>(stream), P, (long)nqp, init, ref,
