@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from centroidalcontrolcollection_amd import IntrinsicallyStableMpc, LinearMpcXY, LinearMpcZ, LinearMpcZmp
+from centroidalcontrolcollection_amd import _lib
 from centroidalcontrolcollection_amd._lib import CccError
 from centroidalcontrolcollection_amd import fixtures as fx
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
@@ -92,3 +93,34 @@ def test_zmp_timeline_without_footsteps_and_single_instance_loop():
     assert viol.item() == 0
     c = com.cpu().numpy()[0]
     assert abs(c[0, 0]) < 0.05 and abs(c[1, 0]) < 0.125 and np.abs(c[:, 1]).max() < 0.05
+
+
+@pytest.mark.parametrize("N", [40, 100, 128, 200])
+def test_zmp_packed_tableau_edge_instances(N):
+    """The packed-tableau kernel (32 < N <= 200) on the instances the N = 32 tests cover: nothing active (zero pivots,
+    zero jerk), every row active (N pivots), an infeasible axis (flagged, the other instances untouched), ragged batch
+    sizes, determinism."""
+    dt = 2.0 / N
+    mpc = LinearMpcZmp(1.0, 2.0, dt)
+    o = _oracle().LinearMpcZmp(1.0, 2.0, dt)
+    x0 = np.zeros((2, 2, 3))
+    zlim = np.empty((2, 2, 2, N))
+    zlim[0, :, 0], zlim[0, :, 1] = -10.0, 10.0
+    zlim[1, :, 0], zlim[1, :, 1] = 0.02, 0.02 + 1e-9
+    r = mpc.planOnceBatch(x0, zlim, 0.005, want_jerk=True)
+    ref = o.plan_batch(x0, zlim, 0.005)
+    assert np.all(r["status"] == 0) and np.all(r["jerk"][0] == 0.0) and np.all(r["pivots"][0] == 0)
+    assert np.all(r["pivots"][1] >= N)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= 1e-9
+    b = fx.make_zmp_batch(67, N, dt, seed=N)
+    full = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005)
+    for n in (1, 2, 63, 67):
+        part = mpc.planOnceBatch(b["x0"][:n], b["zlim"][:n], 0.005)
+        assert np.array_equal(part["zmp"], full["zmp"][:n])
+    bad = b["zlim"].copy()
+    bad[5, 0, 0, N // 2] = bad[5, 0, 1, N // 2] + 0.3
+    rb = mpc.planOnceBatch(b["x0"], bad, 0.005)
+    assert rb["status"][5, 0] == _lib.CCC_STATUS_INFEASIBLE and rb["status"].sum() == _lib.CCC_STATUS_INFEASIBLE
+    keep = np.ones((67, 2), bool)
+    keep[5, 0] = False
+    assert np.array_equal(rb["zmp"][keep], full["zmp"][keep])
