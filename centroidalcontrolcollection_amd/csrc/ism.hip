@@ -62,7 +62,8 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
   const int tid = threadIdx.x, w = tid >> 6;
   const double wm = WaveGroup<64>::min(v);
   const int wi = WaveGroup<64>::first(v == wm && v < kIsmInf);
-  __syncthreads(); // red may still be read by the previous reduction
+  // (no barrier before the write: the only caller is the ratio test, whose previous read of red lies at least two
+  // barriers back -- the update's and the row rewrite's)
   if((tid & 63) == 0 && w < WR)
   {
     red->val[w] = wm;
@@ -183,6 +184,8 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
           }
         }
         const double c = lead ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
+        if(lead) cb[i] = c; // staged as the pivot column already: most pivots add row p itself (published by the
+                            // barriers of the ratio test below)
         const double dm = -sig * c;
         const bool blocking = inW && !iseq && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = lead && (i == p);
@@ -229,9 +232,13 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
           need_select = false;
         }
         if(need_select) post_select();
-        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
-        if(lead) cb[i] = v;
-        __syncthreads();
+        double v = c;
+        if(!isadd) // a row leaves: stage its column instead
+        {
+          v = lead ? T[ST::entry(kk, i)] : 0.0;
+          if(lead) cb[i] = v;
+          __syncthreads();
+        }
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
 #pragma unroll

@@ -811,6 +811,8 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
         }
         ZPROF(0)
         const double c = lead ? T[ST::entry(p, i)] : 0.0; // column p = row p (symmetric)
+        if(lead) cb[i] = c; // staged as the pivot column already: most pivots add row p itself (published by the
+                            // barrier of the ratio test below)
         const double dm = -sig * c;
         const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
         const bool isp = lead && (i == p);
@@ -857,9 +859,13 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
         }
         if(need_select) post_select();
         // pivot on row/column kk
-        const double v = lead ? T[ST::entry(kk, i)] : 0.0;
-        if(lead) cb[i] = v;
-        __syncthreads();
+        double v = c;
+        if(!isadd) // a row leaves: stage its column instead
+        {
+          v = lead ? T[ST::entry(kk, i)] : 0.0;
+          if(lead) cb[i] = v;
+          __syncthreads();
+        }
         const double rp = 1.0 / cb[kk];
         const double g = v * rp;
         ZPROF(2)
