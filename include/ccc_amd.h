@@ -340,6 +340,23 @@ int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const double * ref
 int ccc_ddpzmp_plan_batch(ccc_ddpzmp_t * h, int64_t n, const double * ref, const double * x0, const double * u_init,
                           double * u_out, double * x_out, int32_t * iters, int32_t * status, double * cost);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The step after planOnce of the force-scale planners -- csrc/wrench.hip.
+ * Replaces n calls of ForceColl::calcTotalWrench(contact_list, force_scales, moment_origin) (external dependency; call
+ * sites tests/src/TestLinearMpcXY.cpp:119-120, TestDdpCentroidal.cpp:125-126, TestDdpSingleRigidBody.cpp:141-142) on
+ * the flattened contact lists the planners take:
+ *   dim     [n]                  i32  ridges of the instance's current contact list
+ *   vertex  [n][max_ridges][3]   f64  vertex of ridge r          ridge [n][max_ridges][3]  ridge direction r
+ *   scales  [n][scale_stride]    f64  planned force scales (first dim entries used; e.g. u0 of ccc_xy_plan_batch_device
+ *                                     with scale_stride = 16, or step 0 of ccc_ddp_plan_batch_device's u with N * 16)
+ *   origin  [n][3]               f64  moment origin (the CoM position in the reference tests)
+ *   wrench  [n][6]               f64  [moment; force]  (sva::ForceVecd::vector() order)
+ * Device pointers + a HIP stream (asynchronous).
+ * ------------------------------------------------------------------------------------------------------------- */
+int ccc_total_wrench_device(int64_t n, int max_ridges, const int32_t * dim, const double * vertex, const double * ridge,
+                            const double * scales, int scale_stride, const double * origin, double * wrench,
+                            void * stream);
+
 #ifdef __cplusplus
 }
 #endif
