@@ -398,6 +398,10 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 // ---------------------------------------------------------------------------------------------
 constexpr int kBigNP = 256;
 
+// -DCCC_ZMP_PROF (development builds only, scripts/zprof.py): the LDS-tableau kernels time the phases of a pivot with
+// s_memtime (ZPROF(k) closes phase k: 0 selection, 1 ratio test, 2 pivot-column staging, 3 tile update, 4 row rewrite +
+// bookkeeping, 5 refinement) and OVERWRITE the first entries of each QP's jerk output with the totals (K2 adds the
+// wall-clock span and start time of the QP: that is how the idle tail of grid-stride scheduling was found).
 struct BlockRed
 {
   double val[4];
