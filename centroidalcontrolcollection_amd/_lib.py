@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "ccc_ddpzmp_workspace_bytes",
     "ccc_ddpzmp_plan_batch_device",
     "ccc_ddpzmp_plan_batch",
+    "ccc_ddpzmp_closed_loop_device",
     "ccc_total_wrench_device",
 ]
 

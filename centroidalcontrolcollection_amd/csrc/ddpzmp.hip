@@ -644,23 +644,22 @@ struct Solver
   }
 };
 
-__global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long n)
+// oracle_ddp_solve on the workspace: RefData in W.R, the initial input sequence in W.U(0, ...); leaves the planned
+// trajectory in buffer sv.cur.  Returns the iterations executed, status in `status`.
+__device__ __forceinline__ int solve(const Params & P, const Ws & W, long inst, const double (&x0)[6], Solver & sv,
+                                     int & status)
 {
-  const long inst = (long)blockIdx.x * 64 + threadIdx.x;
-  if(inst >= n) return;
   const int N = P.N;
-  Ws W{B.ws, n, N};
-  // ---- inputs into the workspace layout; initial rollout and its cost (oracle_ddp_solve)
-  for(int i = 0; i <= N; i++)
-#pragma unroll
-    for(int a = 0; a < 4; a++) *W.R(i, a, inst) = B.ref[((size_t)inst * (N + 1) + i) * 4 + a];
-  Solver sv(P, W, inst);
+  // ---- initial rollout and its cost
+  sv.cur = 0;
+  sv.lambda = P.cfg.initial_lambda;
+  sv.dlambda = P.cfg.initial_dlambda;
   {
     double x[6];
 #pragma unroll
     for(int a = 0; a < 6; a++)
     {
-      x[a] = B.x0[inst * 6 + a];
+      x[a] = x0[a];
       *W.X(0, 0, a, inst) = x[a];
     }
     double c = 0;
@@ -668,11 +667,7 @@ __global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long
     {
       double u[3], r[4], xn[6];
 #pragma unroll
-      for(int q = 0; q < 3; q++)
-      {
-        u[q] = B.u_init ? B.u_init[((size_t)inst * N + i) * 3 + q] : 0.0;
-        *W.U(0, i, q, inst) = u[q];
-      }
+      for(int q = 0; q < 3; q++) u[q] = *W.U(0, i, q, inst);
 #pragma unroll
       for(int a = 0; a < 4; a++) r[a] = *W.R(i, a, inst);
       c += running_cost(P, x, u, r);
@@ -692,7 +687,8 @@ __global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long
   }
   // ---- iterations
   const ccc_ddp_config_t & C = P.cfg;
-  int iter = 0, status = 0;
+  int iter = 0;
+  status = 0;
   for(iter = 1; iter <= C.max_iter; iter++)
   {
     bool bp_ok = false;
@@ -755,6 +751,28 @@ __global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long
     }
   }
   if(iter > C.max_iter) iter = C.max_iter;
+  return iter;
+}
+
+__global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long n)
+{
+  const long inst = (long)blockIdx.x * 64 + threadIdx.x;
+  if(inst >= n) return;
+  const int N = P.N;
+  Ws W{B.ws, n, N};
+  // ---- inputs into the workspace layout
+  for(int i = 0; i <= N; i++)
+#pragma unroll
+    for(int a = 0; a < 4; a++) *W.R(i, a, inst) = B.ref[((size_t)inst * (N + 1) + i) * 4 + a];
+  for(int i = 0; i < N; i++)
+#pragma unroll
+    for(int q = 0; q < 3; q++) *W.U(0, i, q, inst) = B.u_init ? B.u_init[((size_t)inst * N + i) * 3 + q] : 0.0;
+  double x0[6];
+#pragma unroll
+  for(int a = 0; a < 6; a++) x0[a] = B.x0[inst * 6 + a];
+  Solver sv(P, W, inst);
+  int status = 0;
+  const int iter = solve(P, W, inst, x0, sv, status);
   // ---- outputs
   for(int i = 0; i < N; i++)
 #pragma unroll
@@ -766,6 +784,138 @@ __global__ __launch_bounds__(64) void ddpzmp_plan_kernel(Params P, Batch B, long
   if(B.iters) B.iters[inst] = iter;
   if(B.status) B.status[inst] = status;
   if(B.cost) B.cost[inst] = sv.cost;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The control loop of tests/src/TestDdpZmp.cpp:70-125 for n instances, entirely on the device (SURVEY.md 8(f) rank 4:
+// plan -> simulate -> plan ...): per cycle the RefData of the horizon is sampled from the instance's reference-ZMP
+// polyline (FootstepManager::refZmp, tests/src/FootstepManager.h:228-237: linear interpolation between the knots of
+// ref_zmp_list_, evaluated at t + 1e-6), the planner runs warm-started with its previous input sequence (:88-91; first
+// cycle (CoM xy, m g), :84-86), ComZmpSim3d advances by sim_dt (tests/src/SimModels.h:194-201: the horizontal model is
+// rebuilt with the current CoM height every cycle) and the kicks of :118-125 are added.
+// ---------------------------------------------------------------------------------------------------------------
+struct Loop
+{
+  int K;                  // knots per instance
+  const double * knot_t;  // [K][n]
+  const double * knot_z;  // [K][2][n]
+  double com_height;      // RefData::com_z (and zmp z = 0)
+  double * state;         // [6][n] in/out: [cx, vx, cy, vy, cz, vz]
+  double t0, sim_dt;
+  int cycles, n_disturb;
+  double disturb_t[8], disturb_v; // impulse per mass, added to BOTH horizontal velocities (SimModels.h:206-210)
+  double * stats;         // [4][n]: max |planned zmp - ref zmp|, max |cz - com_height|, final |planned zmp - ref zmp|,
+                          //         DDP iterations in total
+  double * log;           // [cycles][3][n] planned (zmp x, zmp y, f_z) per cycle, or null
+};
+
+__global__ __launch_bounds__(64) void ddpzmp_closed_loop_kernel(Params P, Loop L, double * ws, long n)
+{
+  const long inst = (long)blockIdx.x * 64 + threadIdx.x;
+  if(inst >= n) return;
+  const int N = P.N, K = L.K;
+  Ws W{ws, n, N};
+  double st[6];
+#pragma unroll
+  for(int a = 0; a < 6; a++) st[a] = L.state[(size_t)a * n + inst];
+  Solver sv(P, W, inst);
+  auto knot_time = [&](int k) { return L.knot_t[(size_t)k * n + inst]; };
+  // reference ZMP at time t (FootstepManager::refZmp): segment search forward from `k` (t never decreases)
+  auto ref_zmp = [&](double t, int & k, double & zx, double & zy) {
+    t = t + 1e-6;
+    while(k + 1 < K && knot_time(k + 1) <= t) ++k; // k = last knot with time <= t (0 if t lies before the first)
+    const double ta = knot_time(k);
+    if(k + 1 >= K || t < ta)
+    {
+      zx = L.knot_z[((size_t)k * 2 + 0) * n + inst];
+      zy = L.knot_z[((size_t)k * 2 + 1) * n + inst];
+      return;
+    }
+    const double tb = knot_time(k + 1);
+    const double ratio = (t - ta) / (tb - ta);
+    zx = (1 - ratio) * L.knot_z[((size_t)k * 2 + 0) * n + inst] + ratio * L.knot_z[((size_t)(k + 1) * 2 + 0) * n + inst];
+    zy = (1 - ratio) * L.knot_z[((size_t)k * 2 + 1) * n + inst] + ratio * L.knot_z[((size_t)(k + 1) * 2 + 1) * n + inst];
+  };
+  double t = L.t0, worst_zmp = 0, worst_z = 0, last_zmp = 0, iters_total = 0;
+  int k0 = 0;
+  for(int c = 0; c < L.cycles; c++)
+  {
+    // ---- RefData of the horizon (TestDdpZmp.cpp:45-51)
+    double rz0x = 0, rz0y = 0;
+    {
+      int k = k0;
+      for(int i = 0; i <= N; i++)
+      {
+        double zx, zy;
+        ref_zmp(t + i * P.dt, k, zx, zy);
+        if(i == 0)
+        {
+          k0 = k;
+          rz0x = zx;
+          rz0y = zy;
+        }
+        *W.R(i, 0, inst) = zx;
+        *W.R(i, 1, inst) = zy;
+        *W.R(i, 2, inst) = 0.0;
+        *W.R(i, 3, inst) = L.com_height;
+      }
+    }
+    // ---- warm start: the previous plan as it is (no shift), first cycle (CoM xy, m g)
+    const int prev = sv.cur;
+    for(int i = 0; i < N; i++)
+#pragma unroll
+      for(int q = 0; q < 3; q++)
+      {
+        const double v = (c == 0) ? (q == 0 ? st[0] : (q == 1 ? st[2] : P.mass * kG)) : *W.U(prev, i, q, inst);
+        if(c == 0 || prev != 0) *W.U(0, i, q, inst) = v;
+      }
+    int status = 0;
+    iters_total += solve(P, W, inst, st, sv, status);
+    const double zx = *W.U(sv.cur, 0, 0, inst), zy = *W.U(sv.cur, 0, 1, inst), fz = *W.U(sv.cur, 0, 2, inst);
+    if(L.log)
+    {
+      L.log[((size_t)c * 3 + 0) * n + inst] = zx;
+      L.log[((size_t)c * 3 + 1) * n + inst] = zy;
+      L.log[((size_t)c * 3 + 2) * n + inst] = fz;
+    }
+    {
+      const double ex = zx - rz0x, ey = zy - rz0y;
+      last_zmp = sqrt(ex * ex + ey * ey);
+      worst_zmp = fmax(worst_zmp, last_zmp);
+      worst_z = fmax(worst_z, fabs(st[4] - L.com_height));
+    }
+    // ---- simulate (SimModels.h:11-41,44-73,194-201): exact ZOH of x'' = w^2 (x - zmp) at the current height, and of
+    //      the vertical double integrator under gravity
+    t += L.sim_dt;
+    {
+      const double w = sqrt(kG / st[4]);
+      const double ch = cosh(w * L.sim_dt), sh = sinh(w * L.sim_dt);
+      const double x = st[0], vx = st[1], y = st[2], vy = st[3];
+      st[0] = ch * x + sh / w * vx + (1 - ch) * zx;
+      st[1] = w * sh * x + ch * vx + -w * sh * zx;
+      st[2] = ch * y + sh / w * vy + (1 - ch) * zy;
+      st[3] = w * sh * y + ch * vy + -w * sh * zy;
+      const double z = st[4], vz = st[5], h = L.sim_dt;
+      st[4] = z + h * vz + 0.5 * h * h / P.mass * fz + -kG * (0.5 * h * h);
+      st[5] = vz + h / P.mass * fz + -kG * h;
+    }
+    for(int d = 0; d < L.n_disturb; d++)
+      if(L.disturb_t[d] <= t && t < L.disturb_t[d] + L.sim_dt)
+      {
+        st[1] += L.disturb_v;
+        st[3] += L.disturb_v;
+        break;
+      }
+  }
+#pragma unroll
+  for(int a = 0; a < 6; a++) L.state[(size_t)a * n + inst] = st[a];
+  if(L.stats)
+  {
+    L.stats[(size_t)0 * n + inst] = worst_zmp;
+    L.stats[(size_t)1 * n + inst] = worst_z;
+    L.stats[(size_t)2 * n + inst] = last_zmp;
+    L.stats[(size_t)3 * n + inst] = iters_total;
+  }
 }
 } // namespace dz
 } // namespace ccc_amd
@@ -919,5 +1069,47 @@ extern "C" int ccc_ddpzmp_plan_batch(ccc_ddpzmp_t * h, int64_t n, const double *
   if(status) CCC_HIP_CHECK(hipMemcpyAsync(status, d + o_st, b_i, hipMemcpyDeviceToHost, h->stream));
   if(cost) CCC_HIP_CHECK(hipMemcpyAsync(cost, d + o_co, b_c, hipMemcpyDeviceToHost, h->stream));
   CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K, const double * knot_t,
+                                             const double * knot_zmp, double com_height, double * state, double t0,
+                                             double sim_dt, int cycles, int n_disturb, const double * disturb_times,
+                                             double disturb_impulse, double * stats, double * log, void * stream)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: NULL handle");
+  if(n < 0 || K < 1 || cycles < 0 || !(sim_dt > 0))
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: need n >= 0, K >= 1, cycles >= 0, sim_dt > 0");
+  if(n == 0 || cycles == 0) return CCC_OK;
+  if(!knot_t || !knot_zmp || !state) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: NULL argument");
+  if(n_disturb < 0 || n_disturb > 8 || (n_disturb > 0 && !disturb_times))
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: 0 <= n_disturb <= 8 (HOST array of times)");
+  CCC_HIP_CHECK(hipSetDevice(h->device));
+  if(n > h->ws_cap)
+  {
+    if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->ws, dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * (size_t)n));
+    h->ws_cap = n;
+  }
+  dz::Loop L{};
+  L.K = K;
+  L.knot_t = knot_t;
+  L.knot_z = knot_zmp;
+  L.com_height = com_height;
+  L.state = state;
+  L.t0 = t0;
+  L.sim_dt = sim_dt;
+  L.cycles = cycles;
+  L.n_disturb = n_disturb;
+  for(int d = 0; d < n_disturb; d++) L.disturb_t[d] = disturb_times[d];
+  L.disturb_v = disturb_impulse;
+  L.stats = stats;
+  L.log = log;
+  const int grid = (int)((n + 63) / 64);
+  hipLaunchKernelGGL(dz::ddpzmp_closed_loop_kernel, dim3(grid), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), h->P, L,
+                     h->ws, (long)n);
+  CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }

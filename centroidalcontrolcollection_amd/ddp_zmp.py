@@ -31,6 +31,9 @@ def _bind(L):
     L.ccc_ddpzmp_plan_batch_device.argtypes = [vp, ctypes.c_int64] + [vp] * 9
     L.ccc_ddpzmp_plan_batch.restype = ctypes.c_int
     L.ccc_ddpzmp_plan_batch.argtypes = [vp, ctypes.c_int64] + [vp] * 8
+    L.ccc_ddpzmp_closed_loop_device.restype = ctypes.c_int
+    L.ccc_ddpzmp_closed_loop_device.argtypes = [vp, ctypes.c_int64, ctypes.c_int, vp, vp, d, vp, d, d, ctypes.c_int,
+                                                ctypes.c_int, vp, d, vp, vp, vp]
     L._ddpzmp_bound = True
 
 
@@ -143,6 +146,26 @@ class DdpZmp:
         _lib.check(self._L.ccc_ddpzmp_plan_batch_device(self._h, x0.shape[0], p(ref), p(x0), p(u_init), p(u_out), p(x_out),
                                                         p(iters), p(status), p(cost),
                                                         ctypes.c_void_p(stream.cuda_stream)))
+
+    def closed_loop_device(self, knot_t, knot_zmp, com_height, state, t0, sim_dt, cycles, disturb_times=(), disturb_impulse=0.0,
+                           stats=None, log=None, stream=None):
+        """The control loop of TestDdpZmp.cpp:70-125 for n instances in one launch (ccc_ddpzmp_closed_loop_device).
+        Device tensors, instance-fastest: knot_t [K,n], knot_zmp [K,2,n], state [6,n] (in / out), stats [4,n] | None,
+        log [cycles,3,n] | None; disturb_times: host sequence (<= 8)."""
+        import torch
+
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+
+        def p(t):
+            return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+        dt_ = np.ascontiguousarray(disturb_times, dtype=np.float64)
+        self._push_config()
+        _lib.check(self._L.ccc_ddpzmp_closed_loop_device(
+            self._h, state.shape[1], knot_t.shape[0], p(knot_t), p(knot_zmp), float(com_height), p(state), float(t0),
+            float(sim_dt), int(cycles), int(dt_.size), ctypes.c_void_p(dt_.ctypes.data) if dt_.size else None,
+            float(disturb_impulse), p(stats), p(log), ctypes.c_void_p(stream.cuda_stream)))
 
     # ------------------------------------------------------------------ the reference's call
     def planOnce(self, ref_data_func, initial_param, current_time):

@@ -340,6 +340,27 @@ int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const double * ref
 int ccc_ddpzmp_plan_batch(ccc_ddpzmp_t * h, int64_t n, const double * ref, const double * x0, const double * u_init,
                           double * u_out, double * x_out, int32_t * iters, int32_t * status, double * cost);
 
+/* The control loop of tests/src/TestDdpZmp.cpp:70-125 for n instances in ONE launch (plan ->
+ * simulate -> plan ... on the device): per cycle the RefData of the horizon is sampled from the instance's reference-ZMP
+ * polyline (FootstepManager::refZmp, tests/src/FootstepManager.h:228-237), the planner runs warm-started with its
+ * previous input sequence (:88-91; first cycle (CoM xy, m g), :84-86), ComZmpSim3d (tests/src/SimModels.h:140-222)
+ * advances by sim_dt, and the kicks of :118-125 are added.  All arrays are instance-fastest ("SoA"):
+ *   knot_t    [K][n]      f64  knot times of the polyline (ascending; it is constant before the first / after the last)
+ *   knot_zmp  [K][2][n]   f64  reference ZMP at the knots
+ *   com_height            RefData::com_z (RefData::zmp z = 0)
+ *   state     [6][n]      f64  in / out: simulator state [cx, vx, cy, vy, cz, vz]
+ *   t0, sim_dt, cycles         time of the first cycle, simulator step, number of cycles
+ *   disturb_times [n_disturb <= 8]  HOST: at the first t with times[d] <= t < times[d] + sim_dt (t after the step) the
+ *                             impulse per mass `disturb_impulse` is added to BOTH horizontal velocities (reference quirk)
+ *   stats     [4][n]      f64  max |planned zmp - ref zmp| over the cycles, max |cz - com_height|, |planned zmp - ref
+ *                              zmp| of the last cycle, DDP iterations in total; or NULL
+ *   log       [cycles][3][n] f64  planned (zmp x, zmp y, f_z) of every cycle; or NULL
+ * Asynchronous on `stream`. */
+int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K, const double * knot_t, const double * knot_zmp,
+                                  double com_height, double * state, double t0, double sim_dt, int cycles, int n_disturb,
+                                  const double * disturb_times, double disturb_impulse, double * stats, double * log,
+                                  void * stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * The step after planOnce of the force-scale planners -- csrc/wrench.hip.
  * Replaces n calls of ForceColl::calcTotalWrench(contact_list, force_scales, moment_origin) (external dependency; call

@@ -151,3 +151,48 @@ def test_cpp_header_shim_matches_python_mirror():
             zx, zy = (float(v) for v in z[0].split())
             assert zx == pd.zmp[0] and zy == pd.zmp[1] and float(z[1].split()[0]) == pd.force_z
         assert int(lines[k].split("iter=")[1]) == d.ddp_solver_.last_iter
+
+
+def test_closed_loop_on_the_device_matches_the_host_driven_loop():
+    """ccc_ddpzmp_closed_loop_device (plan -> ComZmpSim3d -> plan ..., one launch) against the same loop driven from the
+    host through planOnceBatch: the planner is bit-identical given identical inputs, the simulators differ in the last
+    bits of cosh / sinh, so the trajectories agree to ~1e-10 over the 6.5 s that contain four footsteps and a kick; the
+    reference's per-cycle assertions (TestDdpZmp.cpp:108-109) hold for every instance of a batch of perturbed starts."""
+    import torch
+
+    N, dt, mass, h, sim_dt, cycles = 100, 0.02, 100.0, 1.0, 0.005, 1300
+    fm = fx.FootstepManager()
+    for fs in fx.reference_scenario_footsteps():
+        fm.appendFootstep(fs)
+    fm.update(0.0)
+    kt, kz = np.array(fm._zmp_times), np.array(fm._zmps)  # the whole polyline (horizon_duration_ = 10 s covers all steps)
+    K, n = len(kt), 70
+    rng = np.random.default_rng(2)
+    state = np.zeros((6, n))
+    state[4] = h
+    state[0, 1:] = rng.uniform(-0.01, 0.01, n - 1)
+    state[2, 1:] = rng.uniform(-0.01, 0.01, n - 1)
+    dev = torch.device("cuda:0")
+    d = DdpZmp(mass, dt, N)
+    d.ddp_solver_.config().max_iter = 3
+    tk = torch.from_numpy(np.repeat(kt[:, None], n, axis=1).copy()).to(dev)
+    tz = torch.from_numpy(np.repeat(kz[:, :, None], n, axis=2).copy()).to(dev)
+    ts = torch.from_numpy(state.copy()).to(dev)
+    stats = torch.zeros((4, n), dtype=torch.float64, device=dev)
+    log = torch.zeros((cycles, 3, n), dtype=torch.float64, device=dev)
+    d.closed_loop_device(tk, tz, h, ts, 0.0, sim_dt, cycles, (4.5, 8.5), 0.05, stats, log)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    assert st[0].max() < 0.1 and st[1].max() < 0.1  # :108-109 on every instance
+    assert np.all(st[3] >= cycles) and np.all(st[3] <= 3 * cycles)  # 1..3 iterations per cycle (it converges when quiet)
+    # instance 0 = the reference scenario: the host-driven loop (GPU planner, host simulator)
+    def plan_once(ref, x0, u_init):
+        return d.planOnceBatch(ref[None], x0[None], u_init[None])["u"][0]
+
+    hlog, fin = fx.run_closed_loop_ddpzmp(plan_once, end_time=cycles * sim_dt - 1e-9)
+    assert len(hlog) == cycles
+    dl = log.cpu().numpy()[:, :, 0]
+    hz = np.array([np.concatenate([r["zmp"], [r["force_z"]]]) for r in hlog])
+    assert np.abs(dl[:, :2] - hz[:, :2]).max() < 1e-8 and np.abs(dl[:, 2] - hz[:, 2]).max() < 1e-5
+    fs_ = ts.cpu().numpy()[:, 0]
+    assert np.abs(fs_[[0, 2, 4]] - fin["com"]).max() < 1e-8 and np.abs(fs_[[1, 3, 5]] - fin["vel"]).max() < 1e-7
