@@ -146,7 +146,7 @@ def test_device_entry_full_size_properties(mpc32):
 
 
 def test_n50_one_axis_per_wavefront_path():
-    """32 < N <= 64 runs one QP per wavefront (LG = 64 instantiation)."""
+    """32 < N <= 200 runs the packed-tableau kernel (one QP per workgroup; at N = 50 a workgroup is one wavefront)."""
     dt = 0.04
     mpc = LinearMpcZmp(1.0, 2.0, dt)
     assert mpc.horizon_steps_ == 50
@@ -168,7 +168,7 @@ def test_short_horizon_n5():
 
 
 def test_golden_vectors_n100_block_kernel(golden_zmp):
-    """64 < N <= 128 runs the workgroup-per-QP kernel; the reference test's horizon (2 s @ 20 ms = 100 steps)."""
+    """The reference test's horizon (2 s @ 20 ms = 100 steps): packed-tableau kernel, 104 rows, three workgroups per CU."""
     mpc = LinearMpcZmp(1.0, 2.0, 0.02)
     assert mpc.horizon_steps_ == 100
     r = mpc.planOnceBatch(golden_zmp["n100_x0"], golden_zmp["n100_zlim"], 0.005, want_jerk=True)
