@@ -22,6 +22,7 @@
 #include "wave_group.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -55,7 +56,8 @@ __device__ __forceinline__ void z_wave_argmin(double v, double & vmin, int & imi
 }
 
 template<int NR, int TPT>
-__global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n)
+__global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long n, const int * __restrict__ redo_list,
+                                                      const int * __restrict__ redo_count)
 {
   constexpr int NP = kZNP;
   // sweep tableau: symmetric, packed in LDS as the 4 x 4 tiles of its lower triangle (sym_tableau.h), NR = N rounded up
@@ -75,8 +77,11 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
   for(int k = 0; k < TPT; ++k) ST::tile_of(i + k * 64 < ST::NTILE ? i + k * 64 : 0, ta[k], tb[k]);
   const double c = P.dt * P.dt / P.mass;
 
-  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  // redo_list: the instances the streaming kernel below could not finish (normally none); otherwise the whole batch
+  const long nwork = redo_list ? (long)*redo_count : n;
+  for(long q = blockIdx.x; q < nwork; q += gridDim.x)
   {
+    const long b = redo_list ? (long)redo_list[q] : q;
     __syncthreads();
     const bool ct = i < N && B.contact[b * N + i] != 0;
     const unsigned long long mask = __ballot(ct);
@@ -311,6 +316,247 @@ __global__ __launch_bounds__(kZNP) void z_plan_kernel(ZParams P, ZBatch B, long 
     }
   }
 }
+// ---------------------------------------------------------------------------------------------------------------
+// The same QP in O(N) per iteration, ONE INSTANCE PER LANE.  With the state x = [z, zdot] the problem is a box-constrained
+// linear-quadratic tracking problem,
+//     min  sum_j  w_pos/2 (z_{j+1} - ref_j)^2 + w_force/2 f_j^2 ,   x_{j+1} = A x_j + B f_j + e  (f_j = 0 without contact),
+//     fmin <= f_j <= fmax                                             (H = w_pos B^'B^ + w_force I of src/LinearMpcZ.cpp:84-86)
+// so a Newton step on the free variables is a Riccati sweep, not a dense factorisation.  Projected Newton (the scheme of
+// the box-QP inside the DDP solver, with the Riccati recursion in place of the Cholesky factor):
+//   backward sweep  -- costate -> gradient -> clamped set {f at a bound, gradient pushing outward}; Riccati with the
+//                      clamped / contact-free steps as known inputs -> gains (K_j, k_j); the state trajectory is walked
+//                      BACKWARDS with the inverse dynamics (A is unimodular), nothing of it is stored;
+//   forward sweep   -- Newton candidate f+ = K x + k, projected step f(a) = clamp(f + a (f+ - f)) simulated alongside,
+//                      accepted when the cost does not increase (a = 1 almost always);
+//   converged       -- when a full step left the clamped set unchanged: f is then the exact minimiser on that set and
+//                      the set is consistent with the multiplier signs.
+// Two or three iterations on the bench workload (the tableau kernel above: N sweeps of an N x N tableau).  Per step the
+// lane keeps f (two buffers), the gains and a flag in a workspace laid out [step][instance] (coalesced); the inputs are
+// transposed into it once.  Instances that do not converge in kZMaxNewton iterations (none in any test) are appended to
+// a list that the tableau kernel then works off.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kZMaxNewton = 40;
+
+struct ZWork
+{
+  double * f;         // [2][N][n]
+  double * gain;      // [3][N][n]  K0, K1, k
+  double * ref;       // [N][n]
+  unsigned char * fl; // [N][n]  1 = free
+  int * redo_list;    // [n]
+  int * redo_count;   // [1]
+};
+
+__global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B, ZWork W, long n, int max_newton)
+{
+  const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if(b >= n) return;
+  const int N = P.N;
+  const size_t sn = (size_t)n;
+  const double dt = P.dt, im = 1.0 / P.mass;
+  const double B0 = 0.5 * dt * dt * im, B1 = dt * im;    // B
+  const double e0 = -kZG * (0.5 * dt * dt), e1 = -kZG * dt; // e
+  unsigned long long cmask = 0;
+  for(int jc = 0; jc < N; jc += 8) // (eight strided loads in flight)
+  {
+    int cc[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++) cc[u] = jc + u < N ? B.contact[b * N + jc + u] : 0;
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+      if(cc[u] != 0) cmask |= 1ull << (jc + u);
+  }
+  if(!(cmask & 1ull)) // src/LinearMpcZ.cpp:54-57
+  {
+    B.force[b] = 0.0;
+    if(B.status) B.status[b] = CCC_STATUS_SOLVED;
+    if(B.force_all)
+      for(int j = 0; j < N; j++) B.force_all[b * N + j] = 0.0;
+    return;
+  }
+  const double z0 = B.x0[b * 2 + 0], v0 = B.x0[b * 2 + 1];
+  int cur = 0;
+  double * fc = W.f;           // current forces  [N][n]
+  double * fo = W.f + N * sn;  // the other buffer
+  // start: the weight wherever there is contact; its cost and final state; the reference goes into the workspace layout
+  const double fstart = fmin(fmax(P.mass * kZG, P.fmin), P.fmax);
+  double J = 0, zN = z0, vN = v0;
+  for(int jc = 0; jc < N; jc += 8)
+  {
+    double rr[8];
+#pragma unroll
+    for(int u = 0; u < 8; u++) rr[u] = jc + u < N ? B.ref[b * N + jc + u] : 0.0;
+#pragma unroll
+    for(int u = 0; u < 8; u++)
+    {
+      const int j = jc + u;
+      if(j >= N) break;
+      W.ref[(size_t)j * sn + b] = rr[u];
+      const double f = ((cmask >> j) & 1ull) ? fstart : 0.0;
+      fc[(size_t)j * sn + b] = f;
+      const double zn = zN + dt * vN + B0 * f + e0;
+      vN = vN + B1 * f + e1;
+      zN = zn;
+      const double r = zN - rr[u];
+      J += 0.5 * P.w_pos * (r * r) + 0.5 * P.w_force * (f * f);
+    }
+  }
+  int st = CCC_STATUS_MAX_ITER, it = 0;
+  double alpha = 1.0;
+  for(it = 0; it < max_newton; it++)
+  {
+    // ---- backward: costate, gradient, clamped set, Riccati; the state runs backwards from x_N
+    double l0 = 0, l1 = 0;            // costate d cost / d x_{j+1}
+    double P00 = 0, P01 = 0, P11 = 0; // value function 1/2 x'Px + p'x at step j + 1
+    double p0 = 0, p1 = 0;
+    double z = zN, v = vN;
+    bool changed = false;
+    for(int jc = N - 1; jc >= 0; jc -= 8) // eight steps at a time: their operands are loaded before the dependent chain
+    {
+      double rr[8], ff[8];
+      unsigned char of[8];
+#pragma unroll
+      for(int u = 0; u < 8; u++)
+      {
+        const int j = jc - u;
+        rr[u] = j >= 0 ? W.ref[(size_t)j * sn + b] : 0.0;
+        ff[u] = j >= 0 ? fc[(size_t)j * sn + b] : 0.0;
+        of[u] = (j >= 0 && it > 0) ? W.fl[(size_t)j * sn + b] : 0;
+      }
+#pragma unroll
+      for(int u = 0; u < 8; u++)
+      {
+        const int j = jc - u;
+        if(j < 0) break;
+        const double rj = rr[u];
+        const bool ct = (cmask >> j) & 1ull;
+        const double f = ff[u];
+      l0 += P.w_pos * (z - rj);
+      const double T00 = P00 + P.w_pos, T01 = P01, T11 = P11; // P~ = P + w_pos e1 e1'
+      const double t0 = p0 - P.w_pos * rj, t1 = p1;            // p~
+      bool fr = false;
+      if(ct)
+      {
+        const double grad = P.w_force * f + (B0 * l0 + B1 * l1);
+        fr = !((f <= P.fmin && grad > 0.0) || (f >= P.fmax && grad < 0.0));
+        if(it > 0 && (of[u] != 0) != fr) changed = true;
+        W.fl[(size_t)j * sn + b] = fr ? 1 : 0;
+      }
+      // P~ A, A'P~A  (A = [[1, dt], [0, 1]])
+      const double M00 = T00, M01 = T00 * dt + T01, M11 = T01 * dt + T11; // P~ A (M10 = T01)
+      const double N00 = M00, N01 = M01, N11 = dt * M01 + M11;                       // A'(P~ A), symmetric
+      if(fr)
+      {
+        const double pb0 = T00 * B0 + T01 * B1, pb1 = T01 * B0 + T11 * B1; // P~ B
+        const double quu = P.w_force + (B0 * pb0 + B1 * pb1);
+        const double qx0 = pb0, qx1 = pb0 * dt + pb1;                      // B'P~A
+        const double pe0 = T00 * e0 + T01 * e1 + t0, pe1 = T01 * e0 + T11 * e1 + t1; // P~ e + p~
+        const double qu = B0 * pe0 + B1 * pe1;
+        const double iq = 1.0 / quu;
+        const double K0 = -qx0 * iq, K1 = -qx1 * iq, kk = -qu * iq;
+        W.gain[(size_t)j * sn + b] = K0;
+        W.gain[(size_t)(N + j) * sn + b] = K1;
+        W.gain[(size_t)(2 * N + j) * sn + b] = kk;
+        P00 = N00 + qx0 * K0;
+        P01 = N01 + qx0 * K1;
+        P11 = N11 + qx1 * K1;
+        p0 = pe0 + qx0 * kk;
+        p1 = dt * pe0 + pe1 + qx1 * kk;
+      }
+      else
+      {
+        const double c0 = B0 * f + e0, c1 = B1 * f + e1; // known input (a bound, or no contact: f = 0)
+        const double pe0 = T00 * c0 + T01 * c1 + t0, pe1 = T01 * c0 + T11 * c1 + t1;
+        P00 = N00;
+        P01 = N01;
+        P11 = N11;
+        p0 = pe0;
+        p1 = dt * pe0 + pe1;
+      }
+      // costate and state one step back: lambda_j = A' lambda_{j+1};  x_j = A^-1 (x_{j+1} - B f - e)
+      l1 = dt * l0 + l1;
+      const double vp = v - (B1 * f + e1);
+      z = z - (B0 * f + e0) - dt * vp;
+      v = vp;
+      }
+    }
+    if(it > 0 && !changed && alpha == 1.0)
+    {
+      st = CCC_STATUS_SOLVED;
+      break;
+    }
+    // ---- forward: Newton candidate and projected step, simulated together
+    alpha = 1.0;
+    for(;;)
+    {
+      double zn_ = z0, vn_ = v0; // state under the Newton candidate
+      double zc = z0, vc = v0;   // state under the projected step
+      double Jc = 0;
+      for(int jc = 0; jc < N; jc += 8)
+      {
+        double ff[8], rr[8], g0[8], g1[8], g2[8];
+        unsigned char fl[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+        {
+          const int j = jc + u;
+          const bool in = j < N;
+          ff[u] = in ? fc[(size_t)j * sn + b] : 0.0;
+          rr[u] = in ? W.ref[(size_t)j * sn + b] : 0.0;
+          fl[u] = in ? W.fl[(size_t)j * sn + b] : 0;
+          g0[u] = in ? W.gain[(size_t)j * sn + b] : 0.0;
+          g1[u] = in ? W.gain[(size_t)(N + j) * sn + b] : 0.0;
+          g2[u] = in ? W.gain[(size_t)(2 * N + j) * sn + b] : 0.0;
+        }
+#pragma unroll
+        for(int u = 0; u < 8; u++)
+        {
+          const int j = jc + u;
+          if(j >= N) break;
+          const double f = ff[u];
+          double fn = f, fp = f;
+          if((cmask >> j) & 1ull)
+          {
+            if(fl[u]) fn = g0[u] * zn_ + g1[u] * vn_ + g2[u];
+            fp = fmin(fmax(f + alpha * (fn - f), P.fmin), P.fmax);
+          }
+          fo[(size_t)j * sn + b] = fp;
+          const double zq = zn_ + dt * vn_ + B0 * fn + e0;
+          vn_ = vn_ + B1 * fn + e1;
+          zn_ = zq;
+          const double zr = zc + dt * vc + B0 * fp + e0;
+          vc = vc + B1 * fp + e1;
+          zc = zr;
+          const double r = zc - rr[u];
+          Jc += 0.5 * P.w_pos * (r * r) + 0.5 * P.w_force * (fp * fp);
+        }
+      }
+      if(Jc <= J + 1e-12 * fabs(J) || alpha < 1e-6)
+      {
+        J = Jc;
+        zN = zc;
+        vN = vc;
+        double * t = fc;
+        fc = fo;
+        fo = t;
+        cur ^= 1;
+        break;
+      }
+      alpha *= 0.5;
+    }
+  }
+  if(st != CCC_STATUS_SOLVED)
+  {
+    const int q = atomicAdd(W.redo_count, 1);
+    W.redo_list[q] = (int)b;
+    return; // the tableau kernel writes this instance's outputs
+  }
+  B.force[b] = fc[b]; // step 0 (src/LinearMpcZ.cpp:93)
+  if(B.status) B.status[b] = (it << 8) | st;
+  if(B.force_all)
+    for(int j = 0; j < N; j++) B.force_all[b * N + j] = fc[(size_t)j * sn + b];
+  (void)cur;
+}
 } // namespace ccc_amd
 
 using namespace ccc_amd;
@@ -324,6 +570,9 @@ struct ccc_z
   int64_t cap = 0;
   char * d_stage = nullptr;
   hipStream_t stream = nullptr;
+  // workspace of the streaming kernel, grown to the largest batch seen
+  char * ws = nullptr;
+  int64_t ws_cap = 0;
 };
 
 extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, double w_pos, double w_force, int device,
@@ -363,6 +612,7 @@ extern "C" void ccc_z_destroy(ccc_z_t * h)
   if(!h) return;
   (void)hipSetDevice(h->device);
   if(h->d_stage) (void)hipFree(h->d_stage);
+  if(h->ws) (void)hipFree(h->ws);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -379,10 +629,36 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   CCC_HIP_CHECK(hipSetDevice(h->device));
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
-  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances
-  auto go = [&](auto kernel) {
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kZNP), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
-  };
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t N = (size_t)h->N;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t o_f = 0, o_g = o_f + up(2 * N * n * 8), o_r = o_g + up(3 * N * n * 8), o_fl = o_r + up(N * n * 8),
+               o_li = o_fl + up(N * n), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
+  if(n > h->ws_cap) // (synchronous: not inside a captured stream)
+  {
+    if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->ws, total));
+    h->ws_cap = n;
+  }
+  ZWork W{reinterpret_cast<double *>(h->ws + o_f),       reinterpret_cast<double *>(h->ws + o_g),
+          reinterpret_cast<double *>(h->ws + o_r),       reinterpret_cast<unsigned char *>(h->ws + o_fl),
+          reinterpret_cast<int *>(h->ws + o_li),         reinterpret_cast<int *>(h->ws + o_cn)};
+  const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr; // (development switch: the LDS-tableau kernel alone)
+  if(!tableau_only)
+  {
+    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, sizeof(int), s));
+    const char * mi = std::getenv("CCC_Z_NEWTON_ITERS"); // (development switch: starve the iteration to exercise the fallback)
+    hipLaunchKernelGGL(z_plan_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, B, W, (long)n,
+                       mi ? std::atoi(mi) : kZMaxNewton);
+    CCC_HIP_CHECK(hipGetLastError());
+  }
+  // the LDS-tableau kernel: works off the (normally empty) list of instances the streaming kernel gave up on
+  const int grid = tableau_only ? (int)std::min<int64_t>(n, (int64_t)1 << 22) : (int)std::min<int64_t>(n, (int64_t)h->num_cu * 4);
+  const int * rl = tableau_only ? nullptr : W.redo_list;
+  const int * rc_ = tableau_only ? nullptr : W.redo_count;
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kZNP), 0, s, P, B, (long)n, rl, rc_); };
   switch((h->N + 7) / 8)
   {
     case 1: case 2: go(z_plan_kernel<16, 1>); break;
