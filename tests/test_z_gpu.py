@@ -110,11 +110,11 @@ def test_cpp_header_shim_matches_python_mirror():
     assert float(lines[2].split("force=")[1]) == 0.0
 
 
-@pytest.mark.parametrize("env", [{"CCC_Z_TABLEAU": "1"}, {"CCC_Z_NEWTON_ITERS": "1"}, {"CCC_Z_NEWTON_ITERS": "2"}])
+@pytest.mark.parametrize("env", [{"CCC_Z_TABLEAU": "1"}, {"CCC_Z_SWEEPS": "2"}, {"CCC_Z_SWEEPS": "4"}, {"CCC_Z_SWEEPS": "40"}])
 def test_tableau_kernel_and_fallback_list(env):
     """The streaming (Riccati / projected Newton) kernel is the default; the LDS-tableau kernel stays as its fallback.
     In a subprocess with the development switches: the tableau kernel alone, and the streaming kernel starved of
-    iterations so that (nearly) every instance goes through the fallback list -- same answers as the oracle."""
+    sweeps so that (nearly) every instance goes through the fallback list, or given a budget nobody exceeds -- same answers as the oracle."""
     import os
     import subprocess
     import sys
