@@ -390,6 +390,401 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
   }
 }
 
+// K1 with a work queue per 32-lane group ("dyn").  In zmp_plan_kernel the two axes of an instance run in lock-step: a
+// wavefront spends max(pivots_x, pivots_y) trips on a pair (measured: 24.7 against a mean of 17.9 per QP).  Here every group
+// takes its QPs from a global queue on its own: when one group finishes (refinement, outputs) it fetches and sets up the
+// next QP while the other keeps pivoting -- the set-up / refinement code runs under divergence, once per QP, the pivot trip
+// stays the same straight-line code.  The arithmetic of a QP is unchanged.
+constexpr int kQueues = 64;      // ticket counters of zmp_plan_kernel_dyn
+constexpr int kQueueStride = 16; // in counters: one 128-byte line each
+
+template<int LG, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                                 const double * __restrict__ zlim, double control_dt,
+                                                                 double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                 int * __restrict__ status,
+                                                                 unsigned long long * __restrict__ queue)
+{
+  using Grp = WaveGroup<LG>;
+  using Scr = ZmpScratch<LG>;
+  constexpr int NP = LG;
+  constexpr int QPW = 64 / LG; // QPs per wavefront
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double * Gs = smem;           // [NP][NP]
+  double * bs = smem + NP * NP; // [NP]
+  double * As = bs + NP;        // [NP][3]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & (LG - 1), grp = lane / LG;
+  double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
+  const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
+
+  for(int k = tid; k < NP * NP; k += WAVES * 64) Gs[k] = P.G[k];
+  for(int k = tid; k < NP; k += WAVES * 64) bs[k] = P.b[k];
+  for(int k = tid; k < 3 * NP; k += WAVES * 64) As[k] = P.A[k];
+  __syncthreads();
+
+  const int N = P.N;
+  const int maxpass = 20 * N + 100;
+
+  // group state (uniform inside a group)
+  enum { kNeed = 0, kActive = 1, kIdle = 2 };
+#ifndef CCC_ZMP_BATCH
+#define CCC_ZMP_BATCH 1
+#endif
+  constexpr int kBatch = CCC_ZMP_BATCH;
+  int phase = kNeed, left = 0;
+  long qp = 0, next = 0;
+  int myq = (int)((blockIdx.x * (WAVES * QPW) + wave * QPW + grp) % kQueues);
+  bool valid = false, row = false;
+  double lo = -kInf, hi = kInf;
+  int st = CCC_STATUS_SOLVED;
+  RowRegs<NP> T;
+#pragma unroll
+  for(int j = 0; j < NP; ++j) T.t[j / 16][j % 16] = 0.0;
+  double dg = 1.0, dgm = 1.0;
+  double z = 0.0, mu = 0.0;
+  bool inW = false, side = false;
+  int p = 0;
+  double sig = 0.0;
+  bool done = true, need_select = false;
+  int passes = 0, round = 0;
+
+    // -- Goldfarb-Idnani step 1: the most violated row enters (group-uniform result in p / sig / done)
+    auto select_entering = [&]() {
+      // Any violated row is a valid entering row; "most violated" is only a heuristic, so the argmax runs on
+      // fp32 keys (one v_max_f32 + DPP per butterfly step) while the violated / not-violated decision stays exact.
+      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
+      const double score = fmax(sl, sh);
+      const bool violated = row && !inW && score > 0.0;
+      const float key = violated ? fmaxf((float)score, 1.17549435e-38f) : -1.0f;
+      const float m = Grp::max(key);
+      const int cand = Grp::first(key == m);
+      const bool cand_lower = Grp::bit(sl >= sh, cand);
+      if(need_select && !done)
+      {
+        if(m > 0.0f)
+        {
+          p = cand;
+          sig = cand_lower ? 1.0 : -1.0;
+        }
+        else
+          done = true;
+      }
+    };
+
+
+  for(;;)
+  {
+    // ---- groups without a QP: take the next one from the queue and set it up
+    if(__ballot(phase == kNeed) != 0ull)
+    {
+      // kQueues ticket counters (one atomic per QP on a SINGLE address serialises in L2: 131072 of them take as long as
+      // the whole kernel), each serving a contiguous share of the QPs; a group starts at its own queue and moves on to
+      // the next ones when that is exhausted
+      if(__ballot(phase == kNeed && left == 0) != 0ull)
+      {
+        const long share = (nqp + kQueues - 1) / kQueues;
+        for(int tries = 0; tries < kQueues; ++tries) // (wave-uniform trip count; groups that found work idle along)
+        {
+          const bool want = phase == kNeed && left == 0;
+          if(__ballot(want) == 0ull) break;
+          long q = -1;
+          if(want && li == 0)
+          {
+            const long t = (long)atomicAdd(queue + (size_t)myq * kQueueStride, (unsigned long long)kBatch);
+            q = (t < share && myq * share + t < nqp) ? myq * share + t : -1;
+          }
+          q = __shfl(q, lane & ~(LG - 1)); // the group leader's ticket
+          if(want)
+          {
+            if(q >= 0)
+            {
+              next = q;
+              const long end = (myq + 1) * share < nqp ? (myq + 1) * share : nqp;
+              left = (int)(end - q < kBatch ? end - q : kBatch);
+            }
+            else
+              myq = (myq + 1) % kQueues;
+          }
+        }
+      }
+      bool fresh = false;
+      if(phase == kNeed)
+      {
+        valid = left > 0;
+        qp = valid ? next : 0;
+        if(valid)
+        {
+          ++next;
+          --left;
+        }
+        if(!valid)
+        {
+          phase = kIdle;
+          row = false;
+          done = true;
+          need_select = false;
+        }
+        else
+        {
+          fresh = true;
+          row = li < N;
+          // ---- src/LinearMpcZmp.cpp:54-66: lo/hi of the box on B u
+          lo = -kInf;
+          hi = kInf;
+          if(row)
+          {
+            const double fr = As[li * 3 + 0] * x0[qp * 3 + 0] + As[li * 3 + 1] * x0[qp * 3 + 1]
+                              + As[li * 3 + 2] * x0[qp * 3 + 2]; // (A_seq x0)_i
+            lo = zlim[qp * 2 * N + li] - fr;
+            hi = zlim[qp * 2 * N + N + li] - fr;
+          }
+          // ---- tableau T = G (W empty), see zmp_plan_kernel
+#pragma unroll
+          for(int j = 0; j < NP; ++j)
+          {
+            if(j % 8 == 0) asm volatile("" ::: "memory");
+            T.t[j / 16][j % 16] = Gs[j * NP + li];
+          }
+          dg = Gs[li * NP + li];
+          dgm = dg;
+          z = 0.0;
+          mu = 0.0;
+          inW = false;
+          side = false;
+          p = 0;
+          sig = 0.0;
+          passes = 0;
+          round = 0;
+          need_select = true;
+          phase = kActive;
+        }
+      }
+      // (group collectives outside the divergent region)
+      const bool infeasible = Grp::any(fresh && row && lo > hi);
+      if(fresh)
+      {
+        st = infeasible ? CCC_STATUS_INFEASIBLE : CCC_STATUS_SOLVED;
+        done = infeasible;
+      }
+      select_entering();
+    }
+    if(__ballot(phase != kIdle) == 0ull) break;
+
+    // ---- one pivot for every group that is iterating
+    if(__ballot(phase == kActive && !done) != 0ull)
+    {
+        // -- column p of T = {T[i][p]}: search direction on W, Schur complement elsewhere
+        const bool isp = (li == p);
+        double c = row_at_group_uniform<LG, NP>(T, p);
+        c = isp ? dg : c;
+
+        // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
+        const double dm = -sig * c;
+        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
+        const double pd = sig > 0.0 ? lo : hi;
+        const double num = isp ? sig * (pd - z) : -mu;
+        const double den = isp ? dg : dm;
+        const double ratio = (!done && (isp || blocking)) ? num * fast_rcp(den) : kInf;
+        const double t = Grp::min(ratio);
+        int kk = Grp::first(ratio == t);
+        if(!done && kk >= LG)
+        { // NaN step: numerical breakdown, report instead of spinning
+          done = true;
+          st = CCC_STATUS_MAX_ITER;
+        }
+        kk = kk >= LG ? 0 : kk;
+        const bool isadd = (kk == p);
+        const bool isk = (li == kk);
+        const double s = isadd ? 1.0 : -1.0;
+        if(!done)
+        {
+          if(inW)
+            mu = fma(t, dm, mu);
+          else
+            z = fma(sig * t, c, z);
+          if(isp) mu += sig * t;
+        }
+
+        // -- pivot row kk (add: p itself; drop: the blocking row).  Every lane publishes its element of
+        //    column kk; lane kk publishes (pivot - s) instead, which makes the generic update write column kk:
+        //    T'_ij = T_ij - (v_i rp) v_j ;  column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ;  row kk: g = 1 - s rp
+        double v = c;
+        if(__ballot(!done && !isadd) != 0ull)
+        {
+          const double vk = row_at_group_uniform<LG, NP>(T, kk);
+          v = isadd ? c : vk;
+        }
+        v = isk ? dg - s : v;
+        scr[li] = v;
+        if(isk) scr[Scr::kRp] = fast_rcp(dg);
+        __builtin_amdgcn_wave_barrier();
+        const double rp = scr[Scr::kRp];
+        double g = isk ? (1.0 - s * rp) : v * rp;
+        g = done ? 0.0 : g;
+        const double ng = -g;
+        {
+          // rank-1 update of the register-resident row, in place.  Software pipeline: two chunks of 8
+          // broadcast values in flight (32 VGPRs) so that row + state fit the VGPR budget; the empty asm
+          // statements pin the issue order, the tied operands keep the FMAs in place.
+          constexpr int CH = 8, NCH = NP / CH;
+          double2 buf[2][CH / 2];
+#pragma unroll
+          for(int ch = 0; ch < 2 && ch < NCH; ++ch)
+#pragma unroll
+            for(int q = 0; q < CH / 2; ++q) buf[ch][q] = scr2[ch * (CH / 2) + q];
+#pragma unroll
+          for(int ch = 0; ch < NCH; ++ch)
+          {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for(int q = 0; q < CH / 2; ++q)
+            {
+              const int j = ch * CH + 2 * q;
+              double t0 = T.t[j / 16][j % 16], t1 = T.t[(j + 1) / 16][(j + 1) % 16];
+              asm("v_fma_f64 %0, %2, %3, %0\n\tv_fma_f64 %1, %2, %4, %1"
+                  : "+v"(t0), "+v"(t1)
+                  : "v"(ng), "v"(buf[ch & 1][q].x), "v"(buf[ch & 1][q].y));
+              T.t[j / 16][j % 16] = t0;
+              T.t[(j + 1) / 16][(j + 1) % 16] = t1;
+            }
+            if(ch + 2 < NCH)
+            {
+#pragma unroll
+              for(int q = 0; q < CH / 2; ++q) buf[ch & 1][q] = scr2[(ch + 2) * (CH / 2) + q];
+            }
+          }
+        }
+        if(!done)
+        {
+          dg = isk ? -rp : fma(ng, v, dg);
+          dgm = fma(ng, v, dgm);
+          if(isadd)
+          {
+            if(isp)
+            {
+              inW = true;
+              side = sig > 0.0;
+              z = pd;
+            }
+            need_select = true;
+          }
+          else
+          {
+            if(isk)
+            {
+              inW = false;
+              mu = 0.0;
+            }
+            need_select = false;
+          }
+          if(++passes > maxpass)
+          {
+            done = true;
+            st = CCC_STATUS_MAX_ITER;
+          }
+        }
+      __builtin_amdgcn_wave_barrier();
+      if(__ballot(need_select && !done) != 0ull) select_entering();
+    }
+
+    // ---- groups whose iteration stopped: closing refinement, then either re-open or emit and ask for the next QP
+    if(__ballot(phase == kActive && done) != 0ull)
+    {
+      const bool fin = phase == kActive && done;
+      const bool ok = fin && valid && st == CCC_STATUS_SOLVED;
+      const bool act = inW && ok;
+      const double dact = side ? lo : hi;
+      scr[li] = act ? mu : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      double acc = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
+        const double2 mb = scr2[j / 2];
+        acc = fma(Gs[j * NP + li], mb.x, acc);
+        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
+      }
+      const double rho = act ? dact - acc : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      scr[li] = rho;
+      __builtin_amdgcn_wave_barrier();
+      double tr = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        if(j % 8 == 0) asm volatile("" ::: "memory");
+        const double2 rb = scr2[j / 2];
+        tr = fma(T.t[j / 16][j % 16], rb.x, tr);
+        tr = fma(T.t[(j + 1) / 16][(j + 1) % 16], rb.y, tr);
+      }
+      tr = fma(dg - dgm, rho, tr); // replace the stale in-row diagonal by the true one
+      if(act) mu -= tr;
+      __builtin_amdgcn_wave_barrier();
+      scr[li] = act ? mu : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      acc = 0.0;
+#pragma unroll
+      for(int j = 0; j < NP; j += 2)
+      {
+        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
+        const double2 mb = scr2[j / 2];
+        acc = fma(Gs[j * NP + li], mb.x, acc);
+        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
+      }
+      if(ok) z = inW ? dact : acc;
+      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
+      const bool reopen = Grp::any(ok && row && !inW && fmax(sl, sh) > 0.0);
+      const bool again = fin && reopen && round + 1 < 3;
+      if(fin)
+      {
+        ++round;
+        done = !again;
+        need_select = again;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if(__ballot(again) != 0ull) select_entering();
+      const bool emit = fin && !again;
+      if(__ballot(emit) != 0ull)
+      {
+        // ---- outputs: jerk[0] = (B' mu)_0, then src/LinearMpcZmp.cpp:72-78
+        const double u0 = Grp::sum((emit && row) ? bs[li] * mu : 0.0);
+        if(emit && valid && li == 0)
+        {
+          const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
+          const double zl = zlim[qp * 2 * N], zh = zlim[qp * 2 * N + N];
+          const double cdt = control_dt < 0 ? P.dt : control_dt;
+          const double com_acc = ax + cdt * u0;
+          const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
+          double zv = com_pos + P.c2 * com_acc;
+          zv = zv < zl ? zl : (zh < zv ? zh : zv);
+          zmp[qp] = zv;
+          if(status) status[qp] = (passes << 8) | st;
+        }
+        if(jerk)
+        {
+          // u_j = sum_{i >= j} b[i - j] mu_i   (mu is zero outside W)
+          scr[li] = (emit && row) ? mu : 0.0;
+          __builtin_amdgcn_wave_barrier();
+          double uj = 0.0;
+#pragma unroll 4
+          for(int i = 0; i < NP; ++i)
+          {
+            const double m = scr[i];
+            const int dlt = i - li;
+            const double bv = bs[dlt >= 0 ? dlt : 0];
+            uj = (dlt >= 0) ? fma(bv, m, uj) : uj;
+          }
+          if(emit && row) jerk[qp * N + li] = uj;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if(emit) phase = kNeed;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3.  Horizons beyond 200 steps do not fit the 160 KB of LDS even packed: one QP per 512-thread workgroup, thread
 // (part, i) updates its share of column i of the FULL tableau, which lives in an HBM workspace ([j][i], i fastest:
@@ -970,6 +1365,7 @@ struct ccc_zmp
   double com_height = 0, horizon_duration = 0, horizon_dt = 0, c2 = 0;
   std::vector<double> A_seq, B_seq; // host copies, N x 3 and N x N
   double *dG = nullptr, *dA = nullptr, *db = nullptr;
+  unsigned long long * queue = nullptr; // work-queue ticket counter of zmp_plan_kernel_dyn
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
   int num_cu = 0;
   // staging for the host-pointer entry point
@@ -1058,6 +1454,35 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   const int64_t resident = (int64_t)h->num_cu * (16 / WAVES);
   const int grid = (int)std::min<int64_t>(want, resident * 8);
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~6 QPs per resident group the queue cannot
+  // balance anything and the static pairing (one instance per wavefront, more workgroups than fit) is faster
+  const bool use_queue = !std::getenv("CCC_ZMP_STATIC") && nqp >= (int64_t)6 * h->num_cu * 12 * QPW;
+  if(use_queue)
+  {
+    static bool attr_dyn = false;
+    if(!attr_dyn)
+    {
+      CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_kernel_dyn<LG, WAVES>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_dyn = true;
+    }
+    const size_t qbytes = (size_t)kQueues * kQueueStride * sizeof(unsigned long long);
+    if(!h->queue) CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
+    CCC_HIP_CHECK(hipMemsetAsync(h->queue, 0, qbytes, stream));
+    static int per_cu = 0; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
+    if(per_cu == 0)
+    {
+      int nb = 0;
+      if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, zmp_plan_kernel_dyn<LG, WAVES>, WAVES * 64, lds) != hipSuccess || nb < 1)
+        nb = 16 / WAVES;
+      per_cu = nb;
+    }
+    const int gdyn = (int)std::min<int64_t>(want, (int64_t)h->num_cu * per_cu);
+    hipLaunchKernelGGL((zmp_plan_kernel_dyn<LG, WAVES>), dim3(gdyn), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
+                       control_dt, zmp, jerk, status, h->queue);
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  }
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
   CCC_HIP_CHECK(hipGetLastError());
@@ -1164,6 +1589,7 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
 {
   if(!h) return;
   (void)hipSetDevice(h->device);
+  if(h->queue) (void)hipFree(h->queue);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);
