@@ -266,3 +266,18 @@ def test_cpp_header_shim_reference_scenario():
     # same closed loop through the Python mirror: final CoM agrees (same kernels, same inputs)
     fin_cpp = [float(v) for v in subprocess.run([exe, "0.02"], capture_output=True, text=True).stdout.split("final_com=")[1].split()[:2]]
     assert np.abs(np.array(fin_cpp) - np.array([0.64215196, -0.05244137])).max() < 1e-6
+
+
+def test_work_queue_kernel_equals_static_pairing(mpc32):
+    """Large batches run zmp_plan_kernel_dyn (a work queue per 32-lane group), small ones the static pairing: the
+    arithmetic of a QP is the same, so an odd-sized large batch must reproduce, bit for bit, what chunks of 4096 give
+    (ZMP, jerk and pivot counts), and the queue must hand out every QP exactly once."""
+    n = 20001  # 40002 QPs: above the dispatch threshold, not a multiple of anything
+    b = fx.make_zmp_batch(n, 32, 0.0625, seed=77)
+    full = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(full["status"] == 0)
+    for a in range(0, n, 4096):
+        part = mpc32.planOnceBatch(b["x0"][a:a + 4096], b["zlim"][a:a + 4096], 0.005, want_jerk=True)
+        assert np.array_equal(part["zmp"], full["zmp"][a:a + 4096])
+        assert np.array_equal(part["jerk"], full["jerk"][a:a + 4096])
+        assert np.array_equal(part["pivots"], full["pivots"][a:a + 4096])
