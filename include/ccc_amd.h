@@ -12,6 +12,8 @@
  * take pointers to memory resident on the handle's GPU and enqueue asynchronously on the given
  * hipStream_t (passed as void*; NULL = the default stream); the others take host pointers and
  * return when the results are in the host buffers.
+ * A handle owns device scratch (work-queue counters, workspaces): launches of ONE handle must not overlap on the
+ * device -- enqueue them on one stream (or order the streams); use one handle per concurrent stream.
  */
 #ifndef CCC_AMD_H
 #define CCC_AMD_H
