@@ -281,3 +281,22 @@ def test_work_queue_kernel_equals_static_pairing(mpc32):
         assert np.array_equal(part["zmp"], full["zmp"][a:a + 4096])
         assert np.array_equal(part["jerk"], full["jerk"][a:a + 4096])
         assert np.array_equal(part["pivots"], full["pivots"][a:a + 4096])
+
+
+def test_random_horizons_sweep():
+    """Thirty random (horizon, com_height, seed) combinations across the packed-tableau range: ZMP and jerk parity
+    with the oracle (guards the tile bookkeeping at row counts that are not multiples of the tile size)."""
+    rng = np.random.default_rng(12345)
+    for _ in range(30):
+        N = int(rng.integers(33, 201))
+        h = float(rng.uniform(0.6, 1.2))
+        dt = 2.0 / N
+        mpc = LinearMpcZmp(h, 2.0, dt)
+        if mpc.horizon_steps_ != N:  # ceil(2 / (2 / N)) can round up
+            N = mpc.horizon_steps_
+        b = fx.make_zmp_batch(6, N, dt, com_height=h, seed=int(rng.integers(1, 10**6)))
+        ref = _oracle().LinearMpcZmp(h, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=4)
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+        assert np.all(r["status"] == 0), N
+        assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL, N
+        assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL, N
