@@ -18,6 +18,7 @@
 #include "wave_group.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -84,7 +85,8 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
 template<int NR, int TPT>
 __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMinWaves)) void ism_plan_kernel(
     IsmDev P, long nqp, const double * __restrict__ init, const double * __restrict__ ref, double control_dt,
-    double * __restrict__ zmp, double * __restrict__ vel, int * __restrict__ status)
+    double * __restrict__ zmp, double * __restrict__ vel, int * __restrict__ status, const int * __restrict__ redo_list,
+    const int * __restrict__ redo_count)
 {
   using ST = SymTab<NR, 4, TPT>;
   constexpr int NP = kIsmNP; // row stride of P.G / P.Wc, and the "no candidate" index
@@ -102,8 +104,11 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
   const int N = P.N;
   const int maxpass = 20 * (N + 1) + 100;
 
-  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  // redo_list: the QPs the tridiagonal kernel below handed over (normally few); otherwise all of them
+  const long nwork = redo_list ? (long)*redo_count : nqp;
+  for(long wq = blockIdx.x; wq < nwork; wq += gridDim.x)
   {
+    const long qp = redo_list ? (long)redo_list[wq] : wq;
     const bool rng = lead && i < N, iseq = lead && i == N, row = lead && i <= N;
     const double cp = init[qp * 2 + 0], z0 = init[qp * 2 + 1];
     double zr = 0, zl = 0, zh = 0;
@@ -318,6 +323,237 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
     __syncthreads();
   }
 }
+// ---------------------------------------------------------------------------------------------------------------
+// The same QP in the space of the ZMP positions, ONE QP PER WAVEFRONT (default path).
+// With y_i = z_{i+1} = z0 + dt (u_0 + .. + u_i) the objective of src/IntrinsicallyStableMpc.cpp:29-32,66-70 is
+//     w_vel/2 sum ((y_i - y_{i-1}) / dt)^2 + w_zmp/2 sum (y_i - zref_i)^2 ,      y_{-1} = z0,
+// a TRIDIAGONAL, strictly diagonally dominant Hessian (condition number ~ 1 + 4 w_vel / (w_zmp dt^2) = 11 with the
+// defaults), the ZMP limits are a box on y, and the stability row a'u = cp - z0 (:35-39,72) is one linear equality
+// at'y = c.  So:
+//   * the equality is dualised: for a multiplier nu the rest is a box QP  min 1/2 y'Hy + (q + nu at)'y, lo <= y <= hi,
+//     and phi(nu) = at'y(nu) - c is monotone and piecewise linear -- a safeguarded Newton iteration on nu (slope
+//     -at_F' H_FF^-1 at_F, a by-product of the inner solve) finds its root in 5-7 steps;
+//   * the box QP is solved by projected Newton; the Newton step is a tridiagonal solve on the free rows (clamped rows
+//     become identity rows), done by PARALLEL CYCLIC REDUCTION across the wavefront: 7 steps for 128 rows, two rows per
+//     lane, both right-hand sides (the step and at) in one pass; strictly diagonally dominant => no pivoting needed;
+//   * warm starts all the way (y and the clamped set carry over between values of nu): ~3 inner iterations per outer one.
+// ~20 tridiagonal solves of ~500 instructions per QP instead of ~42 pivots of a 104 x 104 tableau.  QPs that do not
+// converge within the iteration budget (an uncatchable capture point, i.e. an infeasible QP, drives nu to infinity) are
+// handed to the tableau kernel above through a work list; it classifies them.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kPcrNP = 128;
+constexpr int kPcrOuter = 40, kPcrInner = 30;
+
+struct IsmPcrDev
+{
+  int N;
+  const double * at; // [N]  (a_i - a_{i+1}) / dt, a_N = 0: the stability row in y
+  double a0_dt;      // a_0 / dt
+  double w_zmp, w_vel, dt;
+};
+
+__global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp, const double * __restrict__ init,
+                                                           const double * __restrict__ ref, double control_dt,
+                                                           double * __restrict__ zmp, double * __restrict__ vel,
+                                                           int * __restrict__ status, int * __restrict__ redo_list,
+                                                           int * __restrict__ redo_count)
+{
+  __shared__ double sh[4][6][kPcrNP];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long qp = (long)blockIdx.x * 4 + wave;
+  if(qp >= nqp) return; // (whole wavefront; the kernel uses no workgroup barrier)
+  double * Sy = sh[wave][0];
+  double * Sa = sh[wave][1];
+  double * Sr = sh[wave][2];
+  double * Sc = sh[wave][3];
+  double * Sd = sh[wave][4];
+  double * Se = sh[wave][5];
+  const int N = P.N;
+  const double kk = P.w_vel / (P.dt * P.dt), e = -kk;
+  const double cp = init[qp * 2 + 0], z0 = init[qp * 2 + 1];
+  const double c_eq = cp - z0 + P.a0_dt * z0;
+  int idx[2] = {lane, lane + 64};
+  bool in[2];
+  double lo[2], hi[2], q[2], at[2], dgn[2], y[2];
+  bool bad = false;
+#pragma unroll
+  for(int u = 0; u < 2; u++)
+  {
+    const int i = idx[u];
+    in[u] = i < N;
+    const double zr = in[u] ? ref[qp * 3 * N + i] : 0.0;
+    lo[u] = in[u] ? ref[qp * 3 * N + N + i] : 0.0;
+    hi[u] = in[u] ? ref[qp * 3 * N + 2 * N + i] : 0.0;
+    at[u] = in[u] ? P.at[i] : 0.0;
+    q[u] = -P.w_zmp * zr - (i == 0 ? kk * z0 : 0.0);
+    dgn[u] = P.w_zmp + (i == N - 1 ? kk : 2.0 * kk);
+    y[u] = fmin(fmax(z0, lo[u]), hi[u]);
+    bad = bad || (in[u] && lo[u] > hi[u]);
+  }
+  auto wsum = [&](double a, double b) { return WaveGroup<64>::sum(a + b); };
+  // (H v)_i for the rows of this lane, v staged in Sy
+  auto hmul = [&](const double (&v)[2], double (&hv)[2]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int u = 0; u < 2; u++) Sy[idx[u]] = in[u] ? v[u] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for(int u = 0; u < 2; u++)
+    {
+      const int i = idx[u];
+      const double vm = (i > 0) ? Sy[i - 1] : 0.0, vp = (i + 1 < N) ? Sy[i + 1] : 0.0;
+      hv[u] = in[u] ? dgn[u] * v[u] + e * (vm + vp) : 0.0;
+    }
+  };
+  double nu = 0.0, nu_lo = -kIsmInf, nu_hi = kIsmInf;
+  bool cl[2] = {false, false};
+  double sdir[2] = {0.0, 0.0}; // H_FF^-1 at of the last solve
+  int st = CCC_STATUS_MAX_ITER, solves = 0;
+  if(__any(bad)) st = CCC_STATUS_INFEASIBLE;
+  for(int outer = 0; outer < kPcrOuter && st == CCC_STATUS_MAX_ITER; outer++)
+  {
+    bool first = true, full = true, inner_ok = false;
+    for(int inner = 0; inner < kPcrInner; inner++)
+    {
+      double hv[2], qq[2], g[2];
+      hmul(y, hv);
+      bool ncl[2];
+      bool changed = false;
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+      {
+        qq[u] = q[u] + nu * at[u];
+        g[u] = hv[u] + qq[u];
+        ncl[u] = in[u] && ((y[u] <= lo[u] && g[u] > 0.0) || (y[u] >= hi[u] && g[u] < 0.0));
+        changed = changed || (ncl[u] != cl[u]);
+      }
+      if(!first && !__any(changed) && full)
+      {
+        inner_ok = true;
+        break;
+      }
+      first = false;
+      const double J0 = wsum(in[0] ? y[0] * (0.5 * hv[0] + qq[0]) : 0.0, in[1] ? y[1] * (0.5 * hv[1] + qq[1]) : 0.0);
+      // ---- Newton step: tridiagonal system on the free rows, identity on the clamped / padding rows; PCR
+      double a_[2], b_[2], c_[2], d_[2], f_[2], r_[2];
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+      {
+        cl[u] = ncl[u];
+        const bool fr = in[u] && !cl[u];
+        a_[u] = (fr && idx[u] > 0) ? e : 0.0;
+        c_[u] = (fr && idx[u] + 1 < N) ? e : 0.0;
+        b_[u] = fr ? dgn[u] : 1.0;
+        d_[u] = fr ? -qq[u] : (in[u] ? y[u] : 0.0);
+        f_[u] = fr ? at[u] : 0.0;
+        r_[u] = 1.0 / b_[u];
+      }
+      for(int s = 1; s < N; s <<= 1)
+      {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for(int u = 0; u < 2; u++)
+        {
+          Sa[idx[u]] = a_[u];
+          Sr[idx[u]] = r_[u];
+          Sc[idx[u]] = c_[u];
+          Sd[idx[u]] = d_[u];
+          Se[idx[u]] = f_[u];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for(int u = 0; u < 2; u++)
+        {
+          const int im = idx[u] - s, ip = idx[u] + s;
+          const bool hm = im >= 0, hp = ip < kPcrNP;
+          const double k1 = hm ? a_[u] * Sr[im] : 0.0, k2 = hp ? c_[u] * Sr[ip] : 0.0;
+          const double am = hm ? Sa[im] : 0.0, cm = hm ? Sc[im] : 0.0, dm = hm ? Sd[im] : 0.0, fm = hm ? Se[im] : 0.0;
+          const double ap = hp ? Sa[ip] : 0.0, cq = hp ? Sc[ip] : 0.0, dp = hp ? Sd[ip] : 0.0, fp = hp ? Se[ip] : 0.0;
+          b_[u] = b_[u] - cm * k1 - ap * k2;
+          d_[u] = d_[u] - dm * k1 - dp * k2;
+          f_[u] = f_[u] - fm * k1 - fp * k2;
+          a_[u] = -am * k1;
+          c_[u] = -cq * k2;
+          r_[u] = 1.0 / b_[u];
+        }
+      }
+      ++solves;
+      double xn[2];
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+      {
+        xn[u] = d_[u] * r_[u];
+        sdir[u] = f_[u] * r_[u];
+      }
+      // ---- projected step, halved until the objective does not increase
+      double alpha = 1.0;
+      for(;;)
+      {
+        double yt[2], ht[2];
+#pragma unroll
+        for(int u = 0; u < 2; u++) yt[u] = in[u] ? fmin(fmax(y[u] + alpha * (xn[u] - y[u]), lo[u]), hi[u]) : 0.0;
+        hmul(yt, ht);
+        const double Jt = wsum(in[0] ? yt[0] * (0.5 * ht[0] + qq[0]) : 0.0, in[1] ? yt[1] * (0.5 * ht[1] + qq[1]) : 0.0);
+        if(Jt <= J0 + 1e-14 * fabs(J0) || alpha < 1e-8)
+        {
+          y[0] = yt[0];
+          y[1] = yt[1];
+          break;
+        }
+        alpha *= 0.5;
+      }
+      full = alpha == 1.0;
+    }
+    if(!inner_ok) break; // inner iteration out of budget: hand the QP over
+    const double phi = wsum(at[0] * y[0], at[1] * y[1]) - c_eq;
+    if(fabs(phi) <= 1e-13 * (1.0 + fabs(c_eq)))
+    {
+      st = CCC_STATUS_SOLVED;
+      break;
+    }
+    if(phi > 0.0)
+      nu_lo = nu;
+    else
+      nu_hi = nu;
+    const double slope = wsum(at[0] * sdir[0], at[1] * sdir[1]); // > 0;  d phi / d nu = -slope
+    double nn = slope > 1e-300 ? nu + phi / slope : (phi > 0.0 ? nu + 1.0 : nu - 1.0);
+    if(!(nu_lo < nn && nn < nu_hi))
+    {
+      const bool both = nu_lo > -kIsmInf && nu_hi < kIsmInf;
+      nn = both ? 0.5 * (nu_lo + nu_hi) : nu + (2.0 * fabs(nu) + 1.0) * (phi > 0.0 ? 1.0 : -1.0);
+    }
+    nu = nn;
+  }
+  if(st != CCC_STATUS_SOLVED)
+  {
+    if(lane == 0)
+    {
+      const int w = atomicAdd(redo_count, 1);
+      redo_list[w] = (int)qp;
+    }
+    return; // the tableau kernel writes this QP's outputs
+  }
+  // ---- outputs: u_i = (y_i - y_{i-1}) / dt; zmp = clamp(z0 + control_dt u_0, zmin_0, zmax_0)  (:93-101)
+  __builtin_amdgcn_wave_barrier();
+  Sy[idx[0]] = y[0];
+  Sy[idx[1]] = in[1] ? y[1] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  if(lane == 0)
+  {
+    const double u0 = (y[0] - z0) / P.dt;
+    const double cdt = control_dt < 0 ? P.dt : control_dt;
+    double zv = z0 + cdt * u0;
+    zv = zv < lo[0] ? lo[0] : (hi[0] < zv ? hi[0] : zv);
+    zmp[qp] = zv;
+    if(status) status[qp] = (solves << 8) | st;
+  }
+  if(vel)
+  {
+#pragma unroll
+    for(int u = 0; u < 2; u++)
+      if(in[u]) vel[qp * N + idx[u]] = (y[u] - (idx[u] > 0 ? Sy[idx[u] - 1] : z0)) / P.dt;
+  }
+}
 } // namespace ccc_amd
 
 using namespace ccc_amd;
@@ -328,6 +564,10 @@ struct ccc_ism
   int N = 0;
   double com_height = 0, horizon_duration = 0, horizon_dt = 0, w_zmp = 1.0, w_zmp_vel = 1e-3;
   double *dG = nullptr, *dWc = nullptr;
+  double * dAt = nullptr; // [N] stability row in ZMP-position variables (ism_plan_pcr_kernel)
+  double a0_dt = 0;
+  int * redo = nullptr;   // [1 + 2 n]: count, list of QPs handed to the tableau kernel
+  int64_t redo_cap = 0;
   int num_cu = 0;
   // staging for the host-pointer entry point
   int64_t cap = 0;
@@ -411,6 +651,20 @@ int upload_model(ccc_ism * h)
   CCC_HIP_CHECK(hipMalloc(&h->dWc, Wc.size() * sizeof(double)));
   CCC_HIP_CHECK(hipMemcpy(h->dG, G.data(), G.size() * sizeof(double), hipMemcpyHostToDevice));
   CCC_HIP_CHECK(hipMemcpy(h->dWc, Wc.data(), Wc.size() * sizeof(double), hipMemcpyHostToDevice));
+  {
+    // stability row in the ZMP-position variables y_i = z_{i+1}: a'u = sum a_i (y_i - y_{i-1}) / dt = at'y - a_0 z0 / dt
+    std::vector<double> av(N + 1, 0.0), atv(N);
+    double a = (1 - lambda) / (omega * (1 - std::pow(lambda, N)));
+    for(int j = 0; j < N; j++)
+    {
+      av[j] = a;
+      a = lambda * a;
+    }
+    for(int j = 0; j < N; j++) atv[j] = (av[j] - av[j + 1]) / h->horizon_dt;
+    h->a0_dt = av[0] / h->horizon_dt;
+    CCC_HIP_CHECK(hipMalloc(&h->dAt, atv.size() * sizeof(double)));
+    CCC_HIP_CHECK(hipMemcpy(h->dAt, atv.data(), atv.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   return CCC_OK;
 }
 } // namespace
@@ -461,6 +715,8 @@ extern "C" void ccc_ism_destroy(ccc_ism_t * h)
   (void)hipSetDevice(h->device);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dWc) (void)hipFree(h->dWc);
+  if(h->dAt) (void)hipFree(h->dAt);
+  if(h->redo) (void)hipFree(h->redo);
   if(h->d_in) (void)hipFree(h->d_in);
   if(h->d_out) (void)hipFree(h->d_out);
   if(h->d_status) (void)hipFree(h->d_status);
@@ -482,16 +738,37 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
   CCC_HIP_CHECK(hipSetDevice(h->device));
   const int64_t nqp = 2 * n;
-  // one workgroup per QP: the pivot count varies severalfold between QPs, the hardware dispatcher evens it out
-  const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if(nqp > h->redo_cap) // (synchronous: not inside a captured stream)
+  {
+    if(h->redo) CCC_HIP_CHECK(hipFree(h->redo));
+    h->redo = nullptr;
+    h->redo_cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->redo, (size_t)(nqp + 1) * sizeof(int)));
+    h->redo_cap = nqp;
+  }
+  const bool tableau_only = std::getenv("CCC_ISM_TABLEAU") != nullptr || h->N > kPcrNP; // (development switch)
+  if(!tableau_only)
+  {
+    // default path: tridiagonal projected Newton, one QP per wavefront; what it cannot finish goes onto the list
+    CCC_HIP_CHECK(hipMemsetAsync(h->redo, 0, sizeof(int), s));
+    IsmPcrDev Q{h->N, h->dAt, h->a0_dt, h->w_zmp, h->w_zmp_vel, h->horizon_dt};
+    hipLaunchKernelGGL(ism_plan_pcr_kernel, dim3((unsigned)((nqp + 3) / 4)), dim3(256), 0, s, Q, (long)nqp, init, ref,
+                       control_dt, zmp, vel, status, h->redo + 1, h->redo);
+    CCC_HIP_CHECK(hipGetLastError());
+  }
+  const int * rl = tableau_only ? nullptr : h->redo + 1;
+  const int * rc_ = tableau_only ? nullptr : h->redo;
+  // tableau kernel: one workgroup per QP (all of them, or the list); the hardware dispatcher evens out the pivot counts
+  const int grid = tableau_only ? (int)std::min<int64_t>(nqp, (int64_t)1 << 22) : (int)std::min<int64_t>(nqp, (int64_t)h->num_cu * 6);
   IsmDev P{h->N, h->dG, h->dWc, h->w_zmp, h->horizon_dt};
   auto go = [&](auto kernel, auto st) -> int {
     using ST = decltype(st);
     const size_t lds = ((size_t)ST::kDoubles + ST::NB * 4) * sizeof(double) + sizeof(IsmRed) + sizeof(IsmSel);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, reinterpret_cast<hipStream_t>(stream), P, (long)nqp, init, ref,
-                       control_dt, zmp, vel, status);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(ST::NT), lds, s, P, (long)nqp, init, ref, control_dt, zmp, vel, status, rl,
+                       rc_);
     return CCC_OK;
   };
   const int R = h->N + 1; // rows: the ZMP limits of every step and the capture-point equality
