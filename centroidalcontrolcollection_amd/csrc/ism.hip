@@ -408,6 +408,8 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
   double nu = 0.0, nu_lo = -kIsmInf, nu_hi = kIsmInf;
   bool cl[2] = {false, false};
   double sdir[2] = {0.0, 0.0}; // H_FF^-1 at of the last solve
+  double hv[2] = {0.0, 0.0};   // H y, carried from the line search into the next iteration
+  bool have_hv = false;
   int st = CCC_STATUS_MAX_ITER, solves = 0;
   if(__any(bad)) st = CCC_STATUS_INFEASIBLE;
   for(int outer = 0; outer < kPcrOuter && st == CCC_STATUS_MAX_ITER; outer++)
@@ -415,8 +417,9 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
     bool first = true, full = true, inner_ok = false;
     for(int inner = 0; inner < kPcrInner; inner++)
     {
-      double hv[2], qq[2], g[2];
-      hmul(y, hv);
+      double qq[2], g[2];
+      if(!have_hv) hmul(y, hv);
+      have_hv = true;
       bool ncl[2];
       bool changed = false;
 #pragma unroll
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
         b_[u] = fr ? dgn[u] : 1.0;
         d_[u] = fr ? -qq[u] : (in[u] ? y[u] : 0.0);
         f_[u] = fr ? at[u] : 0.0;
-        r_[u] = 1.0 / b_[u];
+        r_[u] = fast_rcp(b_[u]);
       }
       for(int s = 1; s < N; s <<= 1)
       {
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
           f_[u] = f_[u] - fm * k1 - fp * k2;
           a_[u] = -am * k1;
           c_[u] = -cq * k2;
-          r_[u] = 1.0 / b_[u];
+          r_[u] = fast_rcp(b_[u]); // (v_rcp_f64 + two Newton steps: relative error ~1e-16, the pivots are >= w_zmp)
         }
       }
       ++solves;
@@ -498,6 +501,8 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
         {
           y[0] = yt[0];
           y[1] = yt[1];
+          hv[0] = ht[0]; // H y of the accepted point: the gradient of the next iteration
+          hv[1] = ht[1];
           break;
         }
         alpha *= 0.5;
