@@ -118,7 +118,7 @@ def _ism(n, dev, rank):
 
     return dict(name="IntrinsicallyStableMpc planOnce() solves/sec (N=100, fp64, inputs resident in HBM)", step=step, out=out,
                 status=st, workload="IntrinsicallyStableMpc N=100 (2 s horizon @ 20 ms), batch=%d per GPU" % n,
-                algo_bytes=2 * (16 + 3 * N * 8) + 16, kernel="ism_plan_kernel", cpu=cpu, keep=(mpc, ti, tr))
+                algo_bytes=2 * (16 + 3 * N * 8) + 16, kernel="ism_plan_pcr_kernel", cpu=cpu, keep=(mpc, ti, tr))
 
 
 def _z(n, dev, rank):
@@ -194,8 +194,8 @@ def _ddpzmp(n, dev, rank):
                      "the HBM workspace (one instance per lane, DESIGN.md 7f)")
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=16384, z=65536, ddpzmp=65536)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(10, 2), z=(50, 5), ddpzmp=(20, 3))
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3))
 
 
 def run(args, rank, world, local_rank, dist):

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
                                                            const double * __restrict__ ref, double control_dt,
                                                            double * __restrict__ zmp, double * __restrict__ vel,
                                                            int * __restrict__ status, int * __restrict__ redo_list,
-                                                           int * __restrict__ redo_count)
+                                                           int * __restrict__ redo_count, int max_outer)
 {
   __shared__ double sh[4][6][kPcrNP];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
   bool have_hv = false;
   int st = CCC_STATUS_MAX_ITER, solves = 0;
   if(__any(bad)) st = CCC_STATUS_INFEASIBLE;
-  for(int outer = 0; outer < kPcrOuter && st == CCC_STATUS_MAX_ITER; outer++)
+  for(int outer = 0; outer < max_outer && st == CCC_STATUS_MAX_ITER; outer++)
   {
     bool first = true, full = true, inner_ok = false;
     for(int inner = 0; inner < kPcrInner; inner++)
@@ -758,8 +758,9 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
     // default path: tridiagonal projected Newton, one QP per wavefront; what it cannot finish goes onto the list
     CCC_HIP_CHECK(hipMemsetAsync(h->redo, 0, sizeof(int), s));
     IsmPcrDev Q{h->N, h->dAt, h->a0_dt, h->w_zmp, h->w_zmp_vel, h->horizon_dt};
+    const char * mo = std::getenv("CCC_ISM_PCR_OUTER"); // (development switch: the outer budget; small values exercise the list)
     hipLaunchKernelGGL(ism_plan_pcr_kernel, dim3((unsigned)((nqp + 3) / 4)), dim3(256), 0, s, Q, (long)nqp, init, ref,
-                       control_dt, zmp, vel, status, h->redo + 1, h->redo);
+                       control_dt, zmp, vel, status, h->redo + 1, h->redo, mo ? std::atoi(mo) : kPcrOuter);
     CCC_HIP_CHECK(hipGetLastError());
   }
   const int * rl = tableau_only ? nullptr : h->redo + 1;

@@ -125,3 +125,29 @@ def test_cpp_header_shim_matches_python_mirror():
         cpp = np.array([float(v) for v in lines[k].split("zmp=")[1].split()])
         cppb = np.array([float(v) for v in lines[3 + k].split("zmp=")[1].split()])
         assert np.array_equal(cpp, z) and np.array_equal(cppb, z)
+
+
+@pytest.mark.parametrize("env", [{"CCC_ISM_TABLEAU": "1"}, {"CCC_ISM_PCR_OUTER": "1"}, {"CCC_ISM_PCR_OUTER": "3"}])
+def test_tableau_kernel_and_fallback_list(env):
+    """The tridiagonal (PCR) kernel is the default; the packed-tableau kernel stays as its fallback.  In a subprocess with
+    the development switches: the tableau kernel alone, and the PCR kernel starved of outer iterations so that most QPs
+    go through the work list -- same answers as the oracle either way."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from centroidalcontrolcollection_amd import IntrinsicallyStableMpc, fixtures as fx\n"
+        "from oracle import oracle\n"
+        "b = fx.make_ism_batch(300, 100, 0.02, seed=11)\n"
+        "o = oracle.IntrinsicallyStableMpc(1.0, 2.0, 0.02).plan_batch(b['init'], b['ref'], 0.005, nthreads=8)\n"
+        "r = IntrinsicallyStableMpc(1.0, 2.0, 0.02).planOnceBatch(b['init'], b['ref'], 0.005, want_vel=True)\n"
+        "assert np.all(r['status'] == 0) and np.all(o['status'] == 0)\n"
+        "print(np.abs(r['zmp'] - o['zmp']).max(), np.abs(r['vel'] - o['vel']).max() / (1 + np.abs(o['vel']).max()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root, **env))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    dz, dv = (float(v) for v in out.stdout.strip().splitlines()[-1].split())
+    assert dz <= TOL and dv <= 1e-7
