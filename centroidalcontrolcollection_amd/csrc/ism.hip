@@ -405,12 +405,68 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
       hv[u] = in[u] ? dgn[u] * v[u] + e * (vm + vp) : 0.0;
     }
   };
+  // parallel cyclic reduction of the tridiagonal system (a, b, c) with the right-hand sides d and f; r = 1 / b on entry
+  // and on exit the solutions are d * r and f * r
+  auto pcr = [&](double (&a_)[2], double (&b_)[2], double (&c_)[2], double (&d_)[2], double (&f_)[2], double (&r_)[2]) {
+    for(int s = 1; s < N; s <<= 1)
+    {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+      {
+        Sa[idx[u]] = a_[u];
+        Sr[idx[u]] = r_[u];
+        Sc[idx[u]] = c_[u];
+        Sd[idx[u]] = d_[u];
+        Se[idx[u]] = f_[u];
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+      {
+        const int im = idx[u] - s, ip = idx[u] + s;
+        const bool hm = im >= 0, hp = ip < kPcrNP;
+        const double k1 = hm ? a_[u] * Sr[im] : 0.0, k2 = hp ? c_[u] * Sr[ip] : 0.0;
+        const double am = hm ? Sa[im] : 0.0, cm = hm ? Sc[im] : 0.0, dm = hm ? Sd[im] : 0.0, fm = hm ? Se[im] : 0.0;
+        const double ap = hp ? Sa[ip] : 0.0, cq = hp ? Sc[ip] : 0.0, dp = hp ? Sd[ip] : 0.0, fp = hp ? Se[ip] : 0.0;
+        b_[u] = b_[u] - cm * k1 - ap * k2;
+        d_[u] = d_[u] - dm * k1 - dp * k2;
+        f_[u] = f_[u] - fm * k1 - fp * k2;
+        a_[u] = -am * k1;
+        c_[u] = -cq * k2;
+        r_[u] = fast_rcp(b_[u]); // (v_rcp_f64 + two Newton steps: relative error ~1e-16, the pivots are >= w_zmp)
+      }
+    }
+  };
   double nu = 0.0, nu_lo = -kIsmInf, nu_hi = kIsmInf;
+  int solves = 0;
+  {
+    // first guess: the equality-constrained minimiser without the box, y = H^-1(-q) - nu H^-1 at with nu from at'y = c,
+    // clamped -- the multiplier the outer iteration starts from is then usually within a step or two of the root
+    double a_[2], b_[2], c_[2], d_[2], f_[2], r_[2];
+#pragma unroll
+    for(int u = 0; u < 2; u++)
+    {
+      a_[u] = (in[u] && idx[u] > 0) ? e : 0.0;
+      c_[u] = (in[u] && idx[u] + 1 < N) ? e : 0.0;
+      b_[u] = in[u] ? dgn[u] : 1.0;
+      d_[u] = in[u] ? -q[u] : 0.0;
+      f_[u] = in[u] ? at[u] : 0.0;
+      r_[u] = fast_rcp(b_[u]);
+    }
+    pcr(a_, b_, c_, d_, f_, r_);
+    ++solves;
+    const double s0[2] = {d_[0] * r_[0], d_[1] * r_[1]}, s1[2] = {f_[0] * r_[0], f_[1] * r_[1]};
+    const double num = wsum(at[0] * s0[0], at[1] * s0[1]) - c_eq, den = wsum(at[0] * s1[0], at[1] * s1[1]);
+    if(den > 1e-300) nu = num / den;
+#pragma unroll
+    for(int u = 0; u < 2; u++) y[u] = in[u] ? fmin(fmax(s0[u] - nu * s1[u], lo[u]), hi[u]) : 0.0;
+  }
   bool cl[2] = {false, false};
   double sdir[2] = {0.0, 0.0}; // H_FF^-1 at of the last solve
   double hv[2] = {0.0, 0.0};   // H y, carried from the line search into the next iteration
   bool have_hv = false;
-  int st = CCC_STATUS_MAX_ITER, solves = 0;
+  int st = CCC_STATUS_MAX_ITER;
   if(__any(bad)) st = CCC_STATUS_INFEASIBLE;
   for(int outer = 0; outer < max_outer && st == CCC_STATUS_MAX_ITER; outer++)
   {
@@ -451,35 +507,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
         f_[u] = fr ? at[u] : 0.0;
         r_[u] = fast_rcp(b_[u]);
       }
-      for(int s = 1; s < N; s <<= 1)
-      {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for(int u = 0; u < 2; u++)
-        {
-          Sa[idx[u]] = a_[u];
-          Sr[idx[u]] = r_[u];
-          Sc[idx[u]] = c_[u];
-          Sd[idx[u]] = d_[u];
-          Se[idx[u]] = f_[u];
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for(int u = 0; u < 2; u++)
-        {
-          const int im = idx[u] - s, ip = idx[u] + s;
-          const bool hm = im >= 0, hp = ip < kPcrNP;
-          const double k1 = hm ? a_[u] * Sr[im] : 0.0, k2 = hp ? c_[u] * Sr[ip] : 0.0;
-          const double am = hm ? Sa[im] : 0.0, cm = hm ? Sc[im] : 0.0, dm = hm ? Sd[im] : 0.0, fm = hm ? Se[im] : 0.0;
-          const double ap = hp ? Sa[ip] : 0.0, cq = hp ? Sc[ip] : 0.0, dp = hp ? Sd[ip] : 0.0, fp = hp ? Se[ip] : 0.0;
-          b_[u] = b_[u] - cm * k1 - ap * k2;
-          d_[u] = d_[u] - dm * k1 - dp * k2;
-          f_[u] = f_[u] - fm * k1 - fp * k2;
-          a_[u] = -am * k1;
-          c_[u] = -cq * k2;
-          r_[u] = fast_rcp(b_[u]); // (v_rcp_f64 + two Newton steps: relative error ~1e-16, the pivots are >= w_zmp)
-        }
-      }
+      pcr(a_, b_, c_, d_, f_, r_);
       ++solves;
       double xn[2];
 #pragma unroll
