@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
   double sdir[2] = {0.0, 0.0}; // H_FF^-1 at of the last solve
   double hv[2] = {0.0, 0.0};   // H y, carried from the line search into the next iteration
   bool have_hv = false;
+  bool exact_move = false;     // the last change of y was the affine move along the multiplier, unclipped
   int st = CCC_STATUS_MAX_ITER;
   if(__any(bad)) st = CCC_STATUS_INFEASIBLE;
   for(int outer = 0; outer < max_outer && st == CCC_STATUS_MAX_ITER; outer++)
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
         ncl[u] = in[u] && ((y[u] <= lo[u] && g[u] > 0.0) || (y[u] >= hi[u] && g[u] < 0.0));
         changed = changed || (ncl[u] != cl[u]);
       }
-      if(!first && !__any(changed) && full)
+      if((!first || exact_move) && !__any(changed) && full)
       {
         inner_ok = true;
         break;
@@ -554,6 +555,24 @@ __global__ __launch_bounds__(256) void ism_plan_pcr_kernel(IsmPcrDev P, long nqp
     {
       const bool both = nu_lo > -kIsmInf && nu_hi < kIsmInf;
       nn = both ? 0.5 * (nu_lo + nu_hi) : nu + (2.0 * fabs(nu) + 1.0) * (phi > 0.0 ? 1.0 : -1.0);
+    }
+    // on the current free set y is affine in the multiplier: y(nn) = y - (nn - nu) H_FF^-1 at.  If that move stays inside
+    // the box, the next inner loop finds the clamped set unchanged and stops without a solve (and phi is then zero up
+    // to rounding); otherwise it is the warm start
+    {
+      const double dn = nn - nu;
+      bool clipped = false;
+#pragma unroll
+      for(int u = 0; u < 2; u++)
+        if(in[u] && !cl[u])
+        {
+          const double t = y[u] - dn * sdir[u];
+          const double tc = fmin(fmax(t, lo[u]), hi[u]);
+          clipped = clipped || (tc != t);
+          y[u] = tc;
+        }
+      exact_move = !__any(clipped);
+      have_hv = false;
     }
     nu = nn;
   }
