@@ -28,6 +28,7 @@
 #include "wave_group.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -230,7 +231,8 @@ __device__ __forceinline__ void xy_rank1(XyHalf & Q, bool enable, int rb, int cb
     for(int c = 0; c < kXyNB; c++) Q.q[r][c] = fma(pr[r], pc[c], Q.q[r][c]);
 }
 
-__global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B, long n)
+__global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B, long n, const int * __restrict__ redo_list,
+                                                           const int * __restrict__ redo_count)
 {
   constexpr int M = kXyM, NB = kXyNB;
   __shared__ XyShared sh;
@@ -252,8 +254,11 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
   const double wf = P.w_force, iwf = 1.0 / P.w_force;
   if(i < NB) sh.e6[i] = (i == NB - 1) ? 1.0 : 0.0;
 
-  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  // redo_list: the instances the stage-recursion kernel below handed over (normally few); otherwise the whole batch
+  const long nwork = redo_list ? (long)*redo_count : n;
+  for(long wq = blockIdx.x; wq < nwork; wq += gridDim.x)
   {
+    const long b = redo_list ? (long)redo_list[wq] : wq;
     __syncthreads();
     // ---------------- per-step data and the variables' impulse vectors (src/LinearMpcXY.cpp:59-83, closed-form ZOH)
     if(i < N)
@@ -622,6 +627,420 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
     if(i == 0 && B.status) B.status[b] = (passes << 8) | st;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same QP by a primal-dual active set whose equality-constrained solves are STAGE RECURSIONS, one instance per lane
+// (default path; prototypes: tests/tools/xy_pdas_proto.py, xy_pdas_riccati_proto.py).
+// In the states x_s the problem of src/LinearMpcXY.cpp:116-182 is an LQ tracking problem with box-bounded inputs (the
+// force scales), input cost w_f I and one equality per contact step.  For a guess of the clamped set:
+//   * stage s, next value 1/2 y'Py + p'y: with Pt = P + W, pt = p - W ref_s, S = sum_free b b', t = sum_free rho_z b,
+//     alpha = sum_free rho_z^2, c = sum_clamped b lambda, d' = f_z - sum_clamped rho_z lambda, the inputs and the stage
+//     multiplier eliminate in closed form (input cost w_f I => only 6 x 6 algebra):
+//         lambda_F = -(B_F' pi + nu rho_F) / w_f,   nu = -(w_f d' + t'pi) / alpha,   pi = Pt y + pt,
+//         (I + S'Pt / w_f) y = Ad x + c' - S'pt / w_f,   S' = S - t t'/alpha,  c' = c + t d'/alpha
+//     => y = E x + f (6 x 6 solve with partial pivoting), P_s = Ad'Pt E, p_s = Ad'(Pt f + pt);
+//   * forward pass: states, costates, stage multipliers, force scales of the free variables, bound multipliers
+//     w_f lambda + b'pi + nu rho_z of the clamped ones -> new clamped set (out-of-bounds free variables are clamped, clamped
+//     ones whose multiplier has the wrong sign are released; a contact step keeps at least one free variable);
+//   * converged when the set repeats: then the iterate is the KKT point.  ~7 iterations on the bench data, where the dual
+//     active set above needs 340 set-up updates + ~94 pivots of a 140 x 140 operator.
+// E, f, Pt, pt, t, alpha, d' and the clamped set live in an HBM workspace laid out [stage][field][instance] (coalesced).
+// Instances that do not settle within kXsMaxIt iterations (the iteration can cycle; none of the reference scenarios
+// does) go onto a work list for the dual active-set kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kXsMaxIt = 16;
+constexpr int kXsFields = 36 + 6 + 36 + 6 + 6 + 2; // E, f, Pt, pt, t, alpha, d'
+
+struct XyWork
+{
+  double * ws;         // [N][kXsFields][n]
+  double * rb;         // [N][16][7][n]: impulse vector (6) and rho_z of every ridge
+  unsigned * st;       // [N][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
+  int * redo_list;     // [n]
+  int * redo_count;    // [1]
+};
+
+// y = Ad x and v -> Ad'v for the closed-form ZOH of src/LinearMpcXY.cpp:59-83 (k2 = f_z/m dt, k3 = f_z/m dt^2/2)
+__device__ __forceinline__ void xs_ad(double dt, double k2, double k3, const double (&x)[6], double (&y)[6])
+{
+  y[0] = x[0] + dt * x[1];
+  y[1] = x[1];
+  y[2] = x[2] + dt * x[3];
+  y[3] = x[3];
+  y[4] = x[4] - k2 * x[2] - k3 * x[3];
+  y[5] = x[5] + k2 * x[0] + k3 * x[1];
+}
+__device__ __forceinline__ void xs_adT(double dt, double k2, double k3, const double (&v)[6], double (&o)[6])
+{
+  o[0] = v[0] + k2 * v[5];
+  o[1] = dt * v[0] + v[1] + k3 * v[5];
+  o[2] = v[2] - k2 * v[4];
+  o[3] = dt * v[2] + v[3] - k3 * v[4];
+  o[4] = v[4];
+  o[5] = v[5];
+}
+// impulse vector of ridge r of a step (column of Bd) and its rho_z
+__device__ __forceinline__ void xs_ridge(const XyParams & P, const double * __restrict__ v, const double * __restrict__ rd,
+                                         double cz, double kap, double (&b)[6], double & az)
+{
+  const double bc4 = -1 * (v[2] - cz) * rd[1] + v[1] * rd[2], bc5 = (v[2] - cz) * rd[0] + -1 * v[0] * rd[2];
+  const double dt = P.dt;
+  b[0] = rd[0] * dt * dt / 2;
+  b[1] = rd[0] * dt;
+  b[2] = rd[1] * dt * dt / 2;
+  b[3] = rd[1] * dt;
+  b[4] = bc4 * dt + -kap * rd[1] * dt * dt * dt / 6;
+  b[5] = bc5 * dt + kap * rd[0] * dt * dt * dt / 6;
+  az = rd[2];
+}
+
+__global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
+{
+  constexpr int M = kXyM;
+  const long b = (long)blockIdx.x * 64 + threadIdx.x;
+  if(b >= n) return;
+  const int N = P.N;
+  const size_t sn = (size_t)n;
+  const double wf = P.w_force, iwf = 1.0 / P.w_force, dt = P.dt;
+  auto WS = [&](int s, int f) -> double & { return W.ws[((size_t)s * kXsFields + f) * sn + b]; };
+  auto RB = [&](int s, int r, int f) -> double & { return W.rb[(((size_t)s * M + r) * 7 + f) * sn + b]; };
+  // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
+  for(int s = 0; s < N; s++)
+  {
+    W.st[(size_t)s * sn + b] = 0u;
+    const int m = B.dim[b * N + s];
+    const double cz = B.com_z[b * N + s], kap = B.total_force_z[b * N + s] / P.mass;
+    for(int r = 0; r < m; r++)
+    {
+      double bb[6], az;
+      xs_ridge(P, B.vertex + ((size_t)(b * N + s) * M + r) * 3, B.ridge + ((size_t)(b * N + s) * M + r) * 3, cz, kap, bb, az);
+#pragma unroll
+      for(int a = 0; a < 6; a++) RB(s, r, a) = bb[a];
+      RB(s, r, 6) = az;
+    }
+  }
+  double x0[6];
+#pragma unroll
+  for(int a = 0; a < 6; a++) x0[a] = B.x0[b * 6 + a];
+  int it = 0;
+  bool converged = false, cycling = false;
+  unsigned long long h1 = 0, h2 = 0; // hashes of the clamped sets of the last two iterations
+  for(it = 0; it < max_it && !converged && !cycling; it++)
+  {
+    // ---- backward recursion on the current clamped set
+    double Pm[6][6], pv[6];
+#pragma unroll
+    for(int a = 0; a < 6; a++)
+    {
+      pv[a] = 0.0;
+#pragma unroll
+      for(int c = 0; c < 6; c++) Pm[a][c] = 0.0;
+    }
+    for(int s = N - 1; s >= 0; s--)
+    {
+      const int m = B.dim[b * N + s];
+      const double fz = B.total_force_z[b * N + s];
+      const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
+      const unsigned bits = W.st[(size_t)s * sn + b];
+      double Pt[6][6], pt[6];
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        pt[a] = pv[a] - P.w[a] * B.ref_out[((size_t)b * N + s) * 6 + a];
+#pragma unroll
+        for(int c = 0; c < 6; c++) Pt[a][c] = Pm[a][c] + (a == c ? P.w[a] : 0.0);
+      }
+      double S[6][6], t[6], cc[6], alpha = 0.0, dprime = fz;
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        t[a] = 0.0;
+        cc[a] = 0.0;
+#pragma unroll
+        for(int c = 0; c < 6; c++) S[a][c] = 0.0;
+      }
+      for(int r = 0; r < m; r++)
+      {
+        double bb[6];
+#pragma unroll
+        for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
+        const double az = RB(s, r, 6);
+        const unsigned stt = (bits >> (2 * r)) & 3u;
+        if(stt == 0u)
+        {
+#pragma unroll
+          for(int a = 0; a < 6; a++)
+          {
+            t[a] += bb[a] * az;
+#pragma unroll
+            for(int c = 0; c < 6; c++) S[a][c] += bb[a] * bb[c];
+          }
+          alpha += az * az;
+        }
+        else
+        {
+          const double val = stt == 1u ? P.flo : P.fhi;
+#pragma unroll
+          for(int a = 0; a < 6; a++) cc[a] += bb[a] * val;
+          dprime -= az * val;
+        }
+      }
+      if(m > 0 && alpha > 0.0)
+      {
+        const double ia = 1.0 / alpha;
+#pragma unroll
+        for(int a = 0; a < 6; a++)
+        {
+          cc[a] += t[a] * dprime * ia;
+#pragma unroll
+          for(int c = 0; c < 6; c++) S[a][c] -= t[a] * t[c] * ia;
+        }
+      }
+      // augmented system [I + S Pt / w_f | Ad | c' - S pt / w_f]
+      double A_[6][13];
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        double sp = 0.0;
+#pragma unroll
+        for(int c = 0; c < 6; c++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for(int k = 0; k < 6; k++) acc += S[a][k] * Pt[k][c];
+          A_[a][c] = (a == c ? 1.0 : 0.0) + acc * iwf;
+          sp += S[a][c] * pt[c];
+        }
+        A_[a][12] = cc[a] - sp * iwf;
+      }
+      {
+        // Ad column by column: Ad e_c
+#pragma unroll
+        for(int c = 0; c < 6; c++)
+        {
+          double ec[6] = {0, 0, 0, 0, 0, 0}, col[6];
+          ec[c] = 1.0;
+          xs_ad(dt, k2, k3, ec, col);
+#pragma unroll
+          for(int a = 0; a < 6; a++) A_[a][6 + c] = col[a];
+        }
+      }
+      // Gaussian elimination with partial pivoting; the row exchange is a chain of selects (no dynamic register index)
+#pragma unroll
+      for(int k = 0; k < 6; k++)
+      {
+        int pr = k;
+        double best = fabs(A_[k][k]);
+#pragma unroll
+        for(int i = k + 1; i < 6; i++)
+        {
+          const double v = fabs(A_[i][k]);
+          const bool tk = v > best;
+          best = tk ? v : best;
+          pr = tk ? i : pr;
+        }
+#pragma unroll
+        for(int j = k; j < 13; j++)
+        {
+          const double ak = A_[k][j];
+          double ap = ak;
+#pragma unroll
+          for(int i = k + 1; i < 6; i++) ap = (pr == i) ? A_[i][j] : ap;
+#pragma unroll
+          for(int i = k + 1; i < 6; i++) A_[i][j] = (pr == i) ? ak : A_[i][j];
+          A_[k][j] = ap;
+        }
+        const double inv = 1.0 / A_[k][k];
+#pragma unroll
+        for(int i = k + 1; i < 6; i++)
+        {
+          const double f = A_[i][k] * inv;
+#pragma unroll
+          for(int j = k + 1; j < 13; j++) A_[i][j] -= f * A_[k][j];
+        }
+      }
+      double E[6][6], fv[6];
+#pragma unroll
+      for(int c = 0; c < 7; c++)
+      {
+        double xs[6];
+#pragma unroll
+        for(int i = 5; i >= 0; i--)
+        {
+          double acc = A_[i][6 + c];
+#pragma unroll
+          for(int j = i + 1; j < 6; j++) acc -= A_[i][j] * xs[j];
+          xs[i] = acc / A_[i][i];
+        }
+#pragma unroll
+        for(int i = 0; i < 6; i++)
+        {
+          if(c < 6)
+            E[i][c] = xs[i];
+          else
+            fv[i] = xs[i];
+        }
+      }
+      // store the stage, then the value function one step back: P = Ad'(Pt E) symmetrised, p = Ad'(Pt f + pt)
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+#pragma unroll
+        for(int c = 0; c < 6; c++)
+        {
+          WS(s, a * 6 + c) = E[a][c];
+          WS(s, 42 + a * 6 + c) = Pt[a][c];
+        }
+        WS(s, 36 + a) = fv[a];
+        WS(s, 78 + a) = pt[a];
+        WS(s, 84 + a) = t[a];
+      }
+      WS(s, 90) = alpha;
+      WS(s, 91) = dprime;
+      double Gm[6][6], gv[6];
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        double acc2 = pt[a];
+#pragma unroll
+        for(int k = 0; k < 6; k++) acc2 += Pt[a][k] * fv[k];
+        gv[a] = acc2;
+#pragma unroll
+        for(int c = 0; c < 6; c++)
+        {
+          double acc = 0.0;
+#pragma unroll
+          for(int k = 0; k < 6; k++) acc += Pt[a][k] * E[k][c];
+          Gm[a][c] = acc;
+        }
+      }
+      double Pn[6][6];
+#pragma unroll
+      for(int c = 0; c < 6; c++)
+      {
+        double colv[6], o[6];
+#pragma unroll
+        for(int a = 0; a < 6; a++) colv[a] = Gm[a][c];
+        xs_adT(dt, k2, k3, colv, o);
+#pragma unroll
+        for(int a = 0; a < 6; a++) Pn[a][c] = o[a];
+      }
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+#pragma unroll
+        for(int c = 0; c < 6; c++) Pm[a][c] = 0.5 * (Pn[a][c] + Pn[c][a]);
+      xs_adT(dt, k2, k3, gv, pv);
+    }
+    // ---- forward pass: new clamped set (and, once it repeats, the outputs)
+    for(int pass = 0; pass < 2; pass++)
+    {
+      const bool emit = pass == 1;
+      if(emit && !converged) break;
+      bool changed = false;
+      unsigned long long hh = 1469598103934665603ull;
+      double x[6];
+#pragma unroll
+      for(int a = 0; a < 6; a++) x[a] = x0[a];
+      for(int s = 0; s < N; s++)
+      {
+        const int m = B.dim[b * N + s];
+        double y[6], pi[6], tv[6];
+#pragma unroll
+        for(int a = 0; a < 6; a++)
+        {
+          double acc = WS(s, 36 + a);
+#pragma unroll
+          for(int c = 0; c < 6; c++) acc += WS(s, a * 6 + c) * x[c];
+          y[a] = acc;
+        }
+        double tpi = 0.0;
+#pragma unroll
+        for(int a = 0; a < 6; a++)
+        {
+          double acc = WS(s, 78 + a);
+#pragma unroll
+          for(int c = 0; c < 6; c++) acc += WS(s, 42 + a * 6 + c) * y[c];
+          pi[a] = acc;
+          tv[a] = WS(s, 84 + a);
+          tpi += tv[a] * acc;
+        }
+        const double alpha = WS(s, 90), dprime = WS(s, 91);
+        const double nu = alpha > 0.0 ? -(wf * dprime + tpi) / alpha : 0.0;
+        const unsigned bits = W.st[(size_t)s * sn + b];
+        unsigned nb = bits;
+        bool anyfree = false;
+        double bestm = kXyInf;
+        int besti = 0;
+        for(int r = 0; r < m; r++)
+        {
+          double bb[6];
+#pragma unroll
+          for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
+          const double az = RB(s, r, 6);
+          double bpi = nu * az;
+#pragma unroll
+          for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
+          const unsigned stt = (bits >> (2 * r)) & 3u;
+          double lam;
+          if(stt == 0u)
+          {
+            lam = -bpi * iwf;
+            unsigned ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
+            nb = (nb & ~(3u << (2 * r))) | (ns << (2 * r));
+            anyfree = anyfree || ns == 0u;
+          }
+          else
+          {
+            lam = stt == 1u ? P.flo : P.fhi;
+            const double mult = wf * lam + bpi;
+            const bool release = (stt == 1u && mult < 0.0) || (stt == 2u && mult > 0.0);
+            if(release) nb &= ~(3u << (2 * r));
+            anyfree = anyfree || release;
+            if(fabs(mult) < bestm)
+            {
+              bestm = fabs(mult);
+              besti = r;
+            }
+          }
+          if(emit)
+          {
+            if(s == 0) B.u0[b * M + r] = lam;
+            if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
+          }
+        }
+        if(emit)
+          for(int r = m; r < M; r++)
+          {
+            if(s == 0) B.u0[b * M + r] = 0.0;
+            if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = 0.0;
+          }
+        if(m > 0 && !anyfree) nb &= ~(3u << (2 * besti)); // the stage equality needs a free variable
+        if(!emit)
+        {
+          changed = changed || nb != bits;
+          W.st[(size_t)s * sn + b] = nb;
+          hh = (hh ^ nb) * 1099511628211ull;
+        }
+#pragma unroll
+        for(int a = 0; a < 6; a++) x[a] = y[a];
+      }
+      if(!emit)
+      {
+        converged = !changed;
+        cycling = !converged && hh == h2; // back at the set of two iterations ago: a 2-cycle, hand the instance over
+        h2 = h1;
+        h1 = hh;
+      }
+    }
+  }
+  if(!converged)
+  {
+    const int q = atomicAdd(W.redo_count, 1);
+    W.redo_list[q] = (int)b;
+    return; // the dual active-set kernel writes this instance's outputs
+  }
+  if(B.status) B.status[b] = ((it - 1) << 8) | CCC_STATUS_SOLVED; // changes of the clamped set before it repeated
+}
 } // namespace ccc_amd
 
 using namespace ccc_amd;
@@ -634,6 +1053,9 @@ struct ccc_xy
   int64_t hcap = 0;
   void * d_stage = nullptr;
   hipStream_t stream = nullptr;
+  // workspace of the stage-recursion kernel, grown to the largest batch seen
+  char * ws = nullptr;
+  int64_t ws_cap = 0;
 };
 
 extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** out)
@@ -667,6 +1089,7 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
 {
   if(!h) return;
   (void)hipSetDevice(h->device);
+  if(h->ws) (void)hipFree(h->ws);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -698,9 +1121,35 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   P.flo = 3.0; // src/LinearMpcXY.cpp:91
   P.fhi = 3.0 * h->prm.mass * kXyG;
   XyBatch B{dim, vertex, ridge, com_z, total_force_z, ref_out, x0, u0, lambda_all, status};
-  // one workgroup per instance: the pivot count varies severalfold, the hardware dispatcher evens it out
-  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
-  hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, reinterpret_cast<hipStream_t>(stream), P, B, (long)n);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t N = (size_t)P.N;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t o_ws = 0, o_rb = o_ws + up(N * kXsFields * (size_t)n * 8), o_st = o_rb + up(N * kXyM * 7 * (size_t)n * 8),
+               o_li = o_st + up(N * (size_t)n * 4), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
+  if(n > h->ws_cap) // (synchronous: not inside a captured stream)
+  {
+    if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
+    h->ws = nullptr;
+    h->ws_cap = 0;
+    CCC_HIP_CHECK(hipMalloc(&h->ws, total));
+    h->ws_cap = n;
+  }
+  XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
+           reinterpret_cast<unsigned *>(h->ws + o_st),
+           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn)};
+  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr; // (development switch: the dual active-set kernel alone)
+  if(!dual_only)
+  {
+    const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
+    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, sizeof(int), s));
+    hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, B, W, (long)n,
+                       mi ? std::atoi(mi) : kXsMaxIt);
+    CCC_HIP_CHECK(hipGetLastError());
+  }
+  // dual active-set kernel: one workgroup per instance (the whole batch, or the list the stage-recursion kernel left)
+  const int grid = dual_only ? (int)std::min<int64_t>(n, (int64_t)1 << 22) : (int)std::min<int64_t>(n, (int64_t)h->num_cu * 2);
+  hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, s, P, B, (long)n, dual_only ? nullptr : W.redo_list,
+                     dual_only ? nullptr : W.redo_count);
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }

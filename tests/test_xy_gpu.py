@@ -116,7 +116,10 @@ def test_random_contact_dimensions_and_weights():
     sub = {k2: v[sel] for k2, v in prob.items()}
     _compare(sub, {k2: (v[sel] if v is not None else None) for k2, v in r.items()},
              {k2: (v[sel] if v is not None else None) for k2, v in o.items()}, N)
-    assert np.all(r["pivots"][sel] == o["iters"][sel])
+    import os
+
+    if os.environ.get("CCC_XY_DUAL"):  # the dual active-set kernel follows the oracle pivot by pivot
+        assert np.all(r["pivots"][sel] == o["iters"][sel])
     for k in sel:
         lam_o = o["lam"][k, :prob["dim"][k].sum()]
         lam_g = np.concatenate([r["lam"][k, i, :prob["dim"][k, i]] for i in range(N)])
@@ -222,3 +225,28 @@ def test_cpp_header_shim_matches_python_mirror():
         assert np.array_equal(cpp, u)
         bl = [b for b in lines[3:] if b.startswith("batch[%d]" % (0.0, 2.45, 4.3).index(t))][0]
         assert float(bl.split("u0[0]=")[1]) == u[0]
+
+
+@pytest.mark.parametrize("env", [{"CCC_XY_DUAL": "1"}, {"CCC_XY_PDAS_ITERS": "1"}, {"CCC_XY_PDAS_ITERS": "3"}])
+def test_dual_kernel_and_fallback_list(env):
+    """The stage-recursion (primal-dual active set) kernel is the default; the dual active-set kernel stays as its
+    fallback.  In a subprocess with the development switches: the dual kernel alone, and the stage-recursion kernel starved
+    of iterations so that most instances go through the work list -- same answers as the oracle either way."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from centroidalcontrolcollection_amd import LinearMpcXY, fixtures_ddp as fd\n"
+        "from oracle import oracle\n"
+        "prob, x0 = fd.make_xy_batch(200, 20, 0.1, seed=9)\n"
+        "o = oracle.LinearMpcXY(100.0, 0.1, 20).plan_batch(prob, x0, nthreads=8)\n"
+        "r = LinearMpcXY(100.0, 0.1, 20).planOnceBatch(prob, x0)\n"
+        "assert np.all(r['status'] == 0) and np.all(o['status'] == 0)\n"
+        "print(np.abs(r['u0'] - o['u0']).max() / (1.0 + np.abs(o['u0']).max()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
+                         env=dict(os.environ, PYTHONPATH=root, **env))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert float(out.stdout.strip().splitlines()[-1]) <= 1e-7
