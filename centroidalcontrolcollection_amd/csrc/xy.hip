@@ -1137,7 +1137,9 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned *>(h->ws + o_st),
            reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn)};
-  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr; // (development switch: the dual active-set kernel alone)
+  // one instance per lane needs a large batch to fill the device (below ~24 k instances the dual active-set kernel, one
+  // 448-thread workgroup per instance, is faster); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
+  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 24576 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
   if(!dual_only)
   {
     const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)

@@ -13,6 +13,14 @@ from centroidalcontrolcollection_amd import fixtures_ddp as fd
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["stream", "dual"])
+def _xy_path(request, monkeypatch):
+    """Every test of this module runs on both kernels: the stage-recursion (primal-dual active set) kernel that large
+    batches take by default, and the dual active-set kernel that small batches (and the fallback list) take."""
+    monkeypatch.setenv("CCC_XY_STREAM" if request.param == "stream" else "CCC_XY_DUAL", "1")
+    yield
+
 LAM_RTOL = 1e-7
 WRENCH_RTOL = 1e-8
 
