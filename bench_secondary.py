@@ -22,6 +22,15 @@ def _tile(d, n, base):
     return {a: np.concatenate([v] * k)[:n] for a, v in d.items()}
 
 
+def _xy_algo(status):
+    """Bytes a lane must move (csrc/xy.hip, stage-recursion kernel): inputs and outputs once, the ridge vectors into the
+    workspace once (7 doubles per ridge), then per iteration and stage 92 doubles written and read back plus the ridge
+    vectors read in both sweeps (16 ridges); iterations = set changes + 1 of the instances that kernel finished."""
+    it = (status >> 8).astype(np.float64)
+    it = np.where(it <= 16, it + 1.0, 17.0).mean()
+    return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (2 * 92 + 2 * 16 * 7) * 8
+
+
 def _xy(n, dev, rank):
     from centroidalcontrolcollection_amd import LinearMpcXY, fixtures_ddp as fd
     N, dt, base = 20, 0.1, min(n, 2048)
@@ -49,7 +58,9 @@ def _xy(n, dev, rank):
 
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
-                algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, kernel="xy_plan_kernel", cpu=cpu, keep=(mpc, tp, tx0))
+                algo_bytes=_xy_algo, kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0),
+                note="algorithmic bytes = inputs + outputs + the stage data the primal-dual active-set iteration streams "
+                     "through the HBM workspace per iteration (one instance per lane, DESIGN.md 7b)")
 
 
 def _ddp(n, dev, rank, srb):
