@@ -694,7 +694,7 @@ __device__ __forceinline__ void xs_ridge(const XyParams & P, const double * __re
   az = rd[2];
 }
 
-__global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
+__global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
 {
   constexpr int M = kXyM;
   const long b = (long)blockIdx.x * 64 + threadIdx.x;
