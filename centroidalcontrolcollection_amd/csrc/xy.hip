@@ -694,20 +694,23 @@ __device__ __forceinline__ void xs_ridge(const XyParams & P, const double * __re
   az = rd[2];
 }
 
-__global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
+__global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
 {
   constexpr int M = kXyM;
   const long b = (long)blockIdx.x * 64 + threadIdx.x;
   if(b >= n) return;
   const int N = P.N;
-  const size_t sn = (size_t)n;
   const double wf = P.w_force, iwf = 1.0 / P.w_force, dt = P.dt;
-  auto WS = [&](int s, int f) -> double & { return W.ws[((size_t)s * kXsFields + f) * sn + b]; };
-  auto RB = [&](int s, int r, int f) -> double & { return W.rb[(((size_t)s * M + r) * 7 + f) * sn + b]; };
+  // workspace layout [wavefront][stage][field][lane]: everything a wavefront touches in a stage is one contiguous 47 KB
+  // (+ 57 KB of ridge vectors) run of memory, stage after stage -- with [stage][field][instance] every 512-byte access
+  // of a wavefront opened a DRAM page of its own
+  const size_t blk = (size_t)blockIdx.x, ln = threadIdx.x;
+  auto WS = [&](int s, int f) -> double & { return W.ws[((blk * N + s) * kXsFields + f) * 64 + ln]; };
+  auto RB = [&](int s, int r, int f) -> double & { return W.rb[(((blk * N + s) * M + r) * 7 + f) * 64 + ln]; };
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    W.st[(size_t)s * sn + b] = 0u;
+    W.st[(blk * N + s) * 64 + ln] = 0u;
     const int m = B.dim[b * N + s];
     const double cz = B.com_z[b * N + s], kap = B.total_force_z[b * N + s] / P.mass;
     for(int r = 0; r < m; r++)
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBat
       const int m = B.dim[b * N + s];
       const double fz = B.total_force_z[b * N + s];
       const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
-      const unsigned bits = W.st[(size_t)s * sn + b];
+      const unsigned bits = W.st[(blk * N + s) * 64 + ln];
       double Pt[6][6], pt[6];
 #pragma unroll
       for(int a = 0; a < 6; a++)
@@ -759,30 +762,41 @@ __global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBat
 #pragma unroll
         for(int c = 0; c < 6; c++) S[a][c] = 0.0;
       }
-      for(int r = 0; r < m; r++)
+      for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
       {
-        double bb[6];
+        double rbv[8][7];
 #pragma unroll
-        for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
-        const double az = RB(s, r, 6);
-        const unsigned stt = (bits >> (2 * r)) & 3u;
-        if(stt == 0u)
+        for(int u = 0; u < 8; u++)
+#pragma unroll
+          for(int a = 0; a < 7; a++) rbv[u][a] = (r0 + u < m) ? RB(s, r0 + u, a) : 0.0;
+#pragma unroll
+        for(int u = 0; u < 8; u++)
         {
+          const int r = r0 + u;
+          if(r >= m) break;
+          double bb[6];
 #pragma unroll
-          for(int a = 0; a < 6; a++)
+          for(int a = 0; a < 6; a++) bb[a] = rbv[u][a];
+          const double az = rbv[u][6];
+          const unsigned stt = (bits >> (2 * r)) & 3u;
+          if(stt == 0u)
           {
-            t[a] += bb[a] * az;
 #pragma unroll
-            for(int c = 0; c < 6; c++) S[a][c] += bb[a] * bb[c];
+            for(int a = 0; a < 6; a++)
+            {
+              t[a] += bb[a] * az;
+#pragma unroll
+              for(int c = 0; c < 6; c++) S[a][c] += bb[a] * bb[c];
+            }
+            alpha += az * az;
           }
-          alpha += az * az;
-        }
-        else
-        {
-          const double val = stt == 1u ? P.flo : P.fhi;
+          else
+          {
+            const double val = stt == 1u ? P.flo : P.fhi;
 #pragma unroll
-          for(int a = 0; a < 6; a++) cc[a] += bb[a] * val;
-          dprime -= az * val;
+            for(int a = 0; a < 6; a++) cc[a] += bb[a] * val;
+            dprime -= az * val;
+          }
         }
       }
       if(m > 0 && alpha > 0.0)
@@ -966,46 +980,57 @@ __global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBat
         }
         const double alpha = WS(s, 90), dprime = WS(s, 91);
         const double nu = alpha > 0.0 ? -(wf * dprime + tpi) / alpha : 0.0;
-        const unsigned bits = W.st[(size_t)s * sn + b];
+        const unsigned bits = W.st[(blk * N + s) * 64 + ln];
         unsigned nb = bits;
         bool anyfree = false;
         double bestm = kXyInf;
         int besti = 0;
-        for(int r = 0; r < m; r++)
+        for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
         {
-          double bb[6];
+          double rbv[8][7];
 #pragma unroll
-          for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
-          const double az = RB(s, r, 6);
-          double bpi = nu * az;
+          for(int u = 0; u < 8; u++)
 #pragma unroll
-          for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
-          const unsigned stt = (bits >> (2 * r)) & 3u;
-          double lam;
-          if(stt == 0u)
+            for(int a = 0; a < 7; a++) rbv[u][a] = (r0 + u < m) ? RB(s, r0 + u, a) : 0.0;
+#pragma unroll
+          for(int u = 0; u < 8; u++)
           {
-            lam = -bpi * iwf;
-            unsigned ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
-            nb = (nb & ~(3u << (2 * r))) | (ns << (2 * r));
-            anyfree = anyfree || ns == 0u;
-          }
-          else
-          {
-            lam = stt == 1u ? P.flo : P.fhi;
-            const double mult = wf * lam + bpi;
-            const bool release = (stt == 1u && mult < 0.0) || (stt == 2u && mult > 0.0);
-            if(release) nb &= ~(3u << (2 * r));
-            anyfree = anyfree || release;
-            if(fabs(mult) < bestm)
+            const int r = r0 + u;
+            if(r >= m) break;
+            double bb[6];
+#pragma unroll
+            for(int a = 0; a < 6; a++) bb[a] = rbv[u][a];
+            const double az = rbv[u][6];
+            double bpi = nu * az;
+#pragma unroll
+            for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
+            const unsigned stt = (bits >> (2 * r)) & 3u;
+            double lam;
+            if(stt == 0u)
             {
-              bestm = fabs(mult);
-              besti = r;
+              lam = -bpi * iwf;
+              unsigned ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
+              nb = (nb & ~(3u << (2 * r))) | (ns << (2 * r));
+              anyfree = anyfree || ns == 0u;
             }
-          }
-          if(emit)
-          {
-            if(s == 0) B.u0[b * M + r] = lam;
-            if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
+            else
+            {
+              lam = stt == 1u ? P.flo : P.fhi;
+              const double mult = wf * lam + bpi;
+              const bool release = (stt == 1u && mult < 0.0) || (stt == 2u && mult > 0.0);
+              if(release) nb &= ~(3u << (2 * r));
+              anyfree = anyfree || release;
+              if(fabs(mult) < bestm)
+              {
+                bestm = fabs(mult);
+                besti = r;
+              }
+            }
+            if(emit)
+            {
+              if(s == 0) B.u0[b * M + r] = lam;
+              if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
+            }
           }
         }
         if(emit)
@@ -1018,7 +1043,7 @@ __global__ __launch_bounds__(64, 2) void xy_plan_stream_kernel(XyParams P, XyBat
         if(!emit)
         {
           changed = changed || nb != bits;
-          W.st[(size_t)s * sn + b] = nb;
+          W.st[(blk * N + s) * 64 + ln] = nb;
           hh = (hh ^ nb) * 1099511628211ull;
         }
 #pragma unroll
@@ -1124,8 +1149,9 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t N = (size_t)P.N;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t o_ws = 0, o_rb = o_ws + up(N * kXsFields * (size_t)n * 8), o_st = o_rb + up(N * kXyM * 7 * (size_t)n * 8),
-               o_li = o_st + up(N * (size_t)n * 4), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
+  const size_t n64 = ((size_t)n + 63) / 64 * 64; // whole wavefronts
+  const size_t o_ws = 0, o_rb = o_ws + up(N * kXsFields * n64 * 8), o_st = o_rb + up(N * kXyM * 7 * n64 * 8),
+               o_li = o_st + up(N * n64 * 4), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
