@@ -341,10 +341,8 @@ constexpr int kZMaxSweeps = 12; // backward + forward sweeps a lane may spend be
 
 struct ZWork
 {
-  double * f;         // [2][N][n]
-  double * gain;      // [3][N][n]  K0, K1, k
-  double * ref;       // [N][n]
-  unsigned char * fl; // [N][n]  1 = free
+  double * f;         // [wavefront][N][6][64]: f (two buffers), K0, K1, k, ref
+  unsigned char * fl; // [wavefront][N][64]  1 = free
   int * redo_list;    // [n]
   int * redo_count;   // [1]
 };
@@ -354,7 +352,11 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= n) return;
   const int N = P.N;
-  const size_t sn = (size_t)n;
+  // workspace layout [wavefront][step][field][lane] (six doubles per step: f x 2, K0, K1, k, ref): what a wavefront
+  // touches in a sweep is one linear run of memory
+  const size_t blk = (size_t)(b >> 6), ln = (size_t)(b & 63);
+  auto WZ = [&](int j, int f) -> double & { return W.f[((blk * N + j) * 6 + f) * 64 + ln]; };
+  auto WF = [&](int j) -> unsigned char & { return W.fl[(blk * N + j) * 64 + ln]; };
   const double dt = P.dt, im = 1.0 / P.mass;
   const double B0 = 0.5 * dt * dt * im, B1 = dt * im;    // B
   const double e0 = -kZG * (0.5 * dt * dt), e1 = -kZG * dt; // e
@@ -378,8 +380,6 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
   }
   const double z0 = B.x0[b * 2 + 0], v0 = B.x0[b * 2 + 1];
   int cur = 0;
-  double * fc = W.f;           // current forces  [N][n]
-  double * fo = W.f + N * sn;  // the other buffer
   // start: the weight wherever there is contact; its cost and final state; the reference goes into the workspace layout
   const double fstart = fmin(fmax(P.mass * kZG, P.fmin), P.fmax);
   double J = 0, zN = z0, vN = v0;
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
     {
       const int j = jc + u;
       if(j >= N) break;
-      W.ref[(size_t)j * sn + b] = rr[u];
+      WZ(j, 5) = rr[u];
       const double f = ((cmask >> j) & 1ull) ? fstart : 0.0;
-      fc[(size_t)j * sn + b] = f;
+      WZ(j, cur) = f;
       const double zn = zN + dt * vN + B0 * f + e0;
       vN = vN + B1 * f + e1;
       zN = zn;
@@ -422,9 +422,9 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
       for(int u = 0; u < 8; u++)
       {
         const int j = jc - u;
-        rr[u] = j >= 0 ? W.ref[(size_t)j * sn + b] : 0.0;
-        ff[u] = j >= 0 ? fc[(size_t)j * sn + b] : 0.0;
-        of[u] = (j >= 0 && it > 0) ? W.fl[(size_t)j * sn + b] : 0;
+        rr[u] = j >= 0 ? WZ(j, 5) : 0.0;
+        ff[u] = j >= 0 ? WZ(j, cur) : 0.0;
+        of[u] = (j >= 0 && it > 0) ? WF(j) : 0;
       }
 #pragma unroll
       for(int u = 0; u < 8; u++)
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         const double grad = P.w_force * f + (B0 * l0 + B1 * l1);
         fr = !((f <= P.fmin && grad > 0.0) || (f >= P.fmax && grad < 0.0));
         if(it > 0 && (of[u] != 0) != fr) changed = true;
-        W.fl[(size_t)j * sn + b] = fr ? 1 : 0;
+        WF(j) = fr ? 1 : 0;
       }
       // P~ A, A'P~A  (A = [[1, dt], [0, 1]])
       const double M00 = T00, M01 = T00 * dt + T01, M11 = T01 * dt + T11; // P~ A (M10 = T01)
@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         const double qu = B0 * pe0 + B1 * pe1;
         const double iq = 1.0 / quu;
         const double K0 = -qx0 * iq, K1 = -qx1 * iq, kk = -qu * iq;
-        W.gain[(size_t)j * sn + b] = K0;
-        W.gain[(size_t)(N + j) * sn + b] = K1;
-        W.gain[(size_t)(2 * N + j) * sn + b] = kk;
+        WZ(j, 2) = K0;
+        WZ(j, 3) = K1;
+        WZ(j, 4) = kk;
         P00 = N00 + qx0 * K0;
         P01 = N01 + qx0 * K1;
         P11 = N11 + qx1 * K1;
@@ -511,12 +511,12 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         {
           const int j = jc + u;
           const bool in = j < N;
-          ff[u] = in ? fc[(size_t)j * sn + b] : 0.0;
-          rr[u] = in ? W.ref[(size_t)j * sn + b] : 0.0;
-          fl[u] = in ? W.fl[(size_t)j * sn + b] : 0;
-          g0[u] = in ? W.gain[(size_t)j * sn + b] : 0.0;
-          g1[u] = in ? W.gain[(size_t)(N + j) * sn + b] : 0.0;
-          g2[u] = in ? W.gain[(size_t)(2 * N + j) * sn + b] : 0.0;
+          ff[u] = in ? WZ(j, cur) : 0.0;
+          rr[u] = in ? WZ(j, 5) : 0.0;
+          fl[u] = in ? WF(j) : 0;
+          g0[u] = in ? WZ(j, 2) : 0.0;
+          g1[u] = in ? WZ(j, 3) : 0.0;
+          g2[u] = in ? WZ(j, 4) : 0.0;
         }
 #pragma unroll
         for(int u = 0; u < 8; u++)
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
             if(fl[u]) fn = g0[u] * zn_ + g1[u] * vn_ + g2[u];
             fp = fmin(fmax(f + alpha * (fn - f), P.fmin), P.fmax);
           }
-          fo[(size_t)j * sn + b] = fp;
+          WZ(j, cur ^ 1) = fp;
           const double zq = zn_ + dt * vn_ + B0 * fn + e0;
           vn_ = vn_ + B1 * fn + e1;
           zn_ = zq;
@@ -546,9 +546,6 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         J = Jc;
         zN = zc;
         vN = vc;
-        double * t = fc;
-        fc = fo;
-        fo = t;
         cur ^= 1;
         break;
       }
@@ -562,11 +559,10 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
     W.redo_list[q] = (int)b;
     return; // the tableau kernel writes this instance's outputs
   }
-  B.force[b] = fc[b]; // step 0 (src/LinearMpcZ.cpp:93)
+  B.force[b] = WZ(0, cur); // step 0 (src/LinearMpcZ.cpp:93)
   if(B.status) B.status[b] = (it << 8) | st;
   if(B.force_all)
-    for(int j = 0; j < N; j++) B.force_all[b * N + j] = fc[(size_t)j * sn + b];
-  (void)cur;
+    for(int j = 0; j < N; j++) B.force_all[b * N + j] = WZ(j, cur);
 }
 } // namespace ccc_amd
 
@@ -643,8 +639,9 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t N = (size_t)h->N;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t o_f = 0, o_g = o_f + up(2 * N * n * 8), o_r = o_g + up(3 * N * n * 8), o_fl = o_r + up(N * n * 8),
-               o_li = o_fl + up(N * n), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
+  const size_t n64 = ((size_t)n + 63) / 64 * 64; // whole wavefronts
+  const size_t o_f = 0, o_fl = o_f + up(6 * N * n64 * 8), o_li = o_fl + up(N * n64), o_cn = o_li + up((size_t)n * 4),
+               total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
@@ -653,9 +650,8 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
     CCC_HIP_CHECK(hipMalloc(&h->ws, total));
     h->ws_cap = n;
   }
-  ZWork W{reinterpret_cast<double *>(h->ws + o_f),       reinterpret_cast<double *>(h->ws + o_g),
-          reinterpret_cast<double *>(h->ws + o_r),       reinterpret_cast<unsigned char *>(h->ws + o_fl),
-          reinterpret_cast<int *>(h->ws + o_li),         reinterpret_cast<int *>(h->ws + o_cn)};
+  ZWork W{reinterpret_cast<double *>(h->ws + o_f), reinterpret_cast<unsigned char *>(h->ws + o_fl),
+          reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn)};
   const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr; // (development switch: the LDS-tableau kernel alone)
   if(!tableau_only)
   {
