@@ -1175,7 +1175,9 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
     CCC_HIP_CHECK(hipGetLastError());
   }
   // dual active-set kernel: one workgroup per instance (the whole batch, or the list the stage-recursion kernel left)
-  const int grid = dual_only ? (int)std::min<int64_t>(n, (int64_t)1 << 22) : (int)std::min<int64_t>(n, (int64_t)h->num_cu * 2);
+  // (one workgroup per instance or list entry: workgroups beyond the list's length find nothing and leave; the hardware
+  //  dispatcher evens out the pivot counts, which a strided loop over a short list would not)
+  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
   hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, s, P, B, (long)n, dual_only ? nullptr : W.redo_list,
                      dual_only ? nullptr : W.redo_count);
   CCC_HIP_CHECK(hipGetLastError());
