@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 // does) go onto a work list for the dual active-set kernel above.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kXsMaxIt = 16;
-constexpr int kXsFields = 36 + 6 + 36 + 6 + 6 + 2; // E, f, Pt, pt, t, alpha, d'
+constexpr int kXsFields = 36 + 6 + 36 + 6 + 6 + 2 + 8; // E, f, Pt, pt, t, alpha, d'; the step's dim, f_z, ref (6)
 
 struct XyWork
 {
@@ -712,7 +712,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   {
     W.st[(blk * N + s) * 64 + ln] = 0u;
     const int m = B.dim[b * N + s];
-    const double cz = B.com_z[b * N + s], kap = B.total_force_z[b * N + s] / P.mass;
+    const double fz0 = B.total_force_z[b * N + s];
+    const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
+    WS(s, 92) = (double)m; // the step's scalars, so that the sweeps read nothing instance-major
+    WS(s, 93) = fz0;
+#pragma unroll
+    for(int a = 0; a < 6; a++) WS(s, 94 + a) = B.ref_out[((size_t)b * N + s) * 6 + a];
     for(int r = 0; r < m; r++)
     {
       double bb[6], az;
@@ -741,15 +746,15 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     }
     for(int s = N - 1; s >= 0; s--)
     {
-      const int m = B.dim[b * N + s];
-      const double fz = B.total_force_z[b * N + s];
+      const int m = (int)WS(s, 92);
+      const double fz = WS(s, 93);
       const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
       const unsigned bits = W.st[(blk * N + s) * 64 + ln];
       double Pt[6][6], pt[6];
 #pragma unroll
       for(int a = 0; a < 6; a++)
       {
-        pt[a] = pv[a] - P.w[a] * B.ref_out[((size_t)b * N + s) * 6 + a];
+        pt[a] = pv[a] - P.w[a] * WS(s, 94 + a);
 #pragma unroll
         for(int c = 0; c < 6; c++) Pt[a][c] = Pm[a][c] + (a == c ? P.w[a] : 0.0);
       }
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       for(int a = 0; a < 6; a++) x[a] = x0[a];
       for(int s = 0; s < N; s++)
       {
-        const int m = B.dim[b * N + s];
+        const int m = (int)WS(s, 92);
         double y[6], pi[6], tv[6];
 #pragma unroll
         for(int a = 0; a < 6; a++)
