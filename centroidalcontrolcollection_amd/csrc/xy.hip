@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   for(int s = 0; s < N; s++)
   {
     W.st[(blk * N + s) * 64 + ln] = 0u;
-    const int m = B.dim[b * N + s];
+    const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..16: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
     const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
     WS(s, 92) = (double)m; // the step's scalars, so that the sweeps read nothing instance-major
