@@ -660,6 +660,12 @@ struct XyWork
   int * redo_count;    // [1]
 };
 
+// index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
+__device__ __forceinline__ constexpr int xs_tri(int a, int c)
+{
+  return a * 6 - a * (a - 1) / 2 + (c - a);
+}
+
 // y = Ad x and v -> Ad'v for the closed-form ZOH of src/LinearMpcXY.cpp:59-83 (k2 = f_z/m dt, k3 = f_z/m dt^2/2)
 __device__ __forceinline__ void xs_ad(double dt, double k2, double k3, const double (&x)[6], double (&y)[6])
 {
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         for(int c = 0; c < 6; c++)
         {
           WS(s, a * 6 + c) = E[a][c];
-          WS(s, 42 + a * 6 + c) = Pt[a][c];
+          if(c >= a) WS(s, 42 + xs_tri(a, c)) = Pt[a][c]; // (symmetric: the upper triangle)
         }
         WS(s, 36 + a) = fv[a];
         WS(s, 78 + a) = pt[a];
@@ -978,7 +984,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         {
           double acc = WS(s, 78 + a);
 #pragma unroll
-          for(int c = 0; c < 6; c++) acc += WS(s, 42 + a * 6 + c) * y[c];
+          for(int c = 0; c < 6; c++) acc += WS(s, 42 + (c >= a ? xs_tri(a, c) : xs_tri(c, a))) * y[c];
           pi[a] = acc;
           tv[a] = WS(s, 84 + a);
           tpi += tv[a] * acc;
