@@ -649,7 +649,11 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 // does) go onto a work list for the dual active-set kernel above.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kXsMaxIt = 16;
-constexpr int kXsFields = 36 + 6 + 36 + 6 + 6 + 2 + 8; // E, f, Pt, pt, t, alpha, d'; the step's dim, f_z, ref (6)
+// fields of a stage in the workspace: feedback E (36), f (6), P~ (upper triangle, 21), p~ (6); the clamped set's sums
+// t (6), alpha, d', S (upper triangle, 21), c (6); the step's ridge count, f_z and reference (6); the clamped set
+// (2 bits per ridge: 0 free, 1 at the lower bound, 2 at the upper bound)
+constexpr int kXsE = 0, kXsF = 36, kXsPt = 42, kXsPv = 63, kXsT = 69, kXsAl = 75, kXsDp = 76, kXsDim = 77, kXsFz = 78,
+              kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsFields = 120; // (120 + 16 x 7 fields x 512 B: stages start on 4 KB boundaries)
 
 struct XyWork
 {
@@ -658,6 +662,7 @@ struct XyWork
   unsigned * st;       // [N][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
   int * redo_list;     // [n]
   int * redo_count;    // [1]
+  size_t ws_stride, rb_stride; // doubles from one wavefront's region to the next
 };
 
 // index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
@@ -700,10 +705,34 @@ __device__ __forceinline__ void xs_ridge(const XyParams & P, const double * __re
   az = rd[2];
 }
 
+// one ridge's contribution to the sums over a clamped set: free (state 0) into S, t, alpha; clamped at `val` into c, d'
+__device__ __forceinline__ void xs_accumulate(unsigned state, double val, const double (&bb)[6], double az, double (&S)[21],
+                                              double (&t)[6], double (&c)[6], double & alpha, double & dprime)
+{
+  if(state == 0u)
+  {
+#pragma unroll
+    for(int a = 0; a < 6; a++)
+    {
+      t[a] += bb[a] * az;
+#pragma unroll
+      for(int k = a; k < 6; k++) S[xs_tri(a, k)] += bb[a] * bb[k];
+    }
+    alpha += az * az;
+  }
+  else
+  {
+#pragma unroll
+    for(int a = 0; a < 6; a++) c[a] += bb[a] * val;
+    dprime -= az * val;
+  }
+}
+
+constexpr int kXsLanes = 64; // instances per wavefront
 __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
 {
   constexpr int M = kXyM;
-  const long b = (long)blockIdx.x * 64 + threadIdx.x;
+  const long b = (long)blockIdx.x * kXsLanes + threadIdx.x;
   if(b >= n) return;
   const int N = P.N;
   const double wf = P.w_force, iwf = 1.0 / P.w_force, dt = P.dt;
@@ -711,19 +740,27 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // (+ 57 KB of ridge vectors) run of memory, stage after stage -- with [stage][field][instance] every 512-byte access
   // of a wavefront opened a DRAM page of its own
   const size_t blk = (size_t)blockIdx.x, ln = threadIdx.x;
-  auto WS = [&](int s, int f) -> double & { return W.ws[((blk * N + s) * kXsFields + f) * 64 + ln]; };
-  auto RB = [&](int s, int r, int f) -> double & { return W.rb[(((blk * N + s) * M + r) * 7 + f) * 64 + ln]; };
+  auto WS = [&](int s, int f) -> double & { return W.ws[blk * W.ws_stride + (size_t)((s * (kXsFields + M * 7) + f) * kXsLanes) + ln]; };
+  auto RB = [&](int s, int r, int f) -> double & { return W.rb[blk * W.rb_stride + (size_t)((s * (kXsFields + M * 7) + r * 7 + f) * kXsLanes) + ln]; };
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    W.st[(blk * N + s) * 64 + ln] = 0u;
+    WS(s, kXsSt) = 0.0;
     const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..16: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
     const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
-    WS(s, 92) = (double)m; // the step's scalars, so that the sweeps read nothing instance-major
-    WS(s, 93) = fz0;
+    WS(s, kXsDim) = (double)m; // the step's scalars, so that the sweeps read nothing instance-major
+    WS(s, kXsFz) = fz0;
 #pragma unroll
-    for(int a = 0; a < 6; a++) WS(s, 94 + a) = B.ref_out[((size_t)b * N + s) * 6 + a];
+    for(int a = 0; a < 6; a++) WS(s, kXsRef + a) = B.ref_out[((size_t)b * N + s) * 6 + a];
+    // ... and the sums over the clamped set the backward recursion starts from (nothing clamped: S = sum b b', t =
+    // sum b a_z, alpha = sum a_z^2, c = 0, d' = f_z); from then on the forward pass, which visits every ridge anyway,
+    // leaves the sums of the set it chooses
+    double S[21], t[6], alpha = 0.0;
+#pragma unroll
+    for(int a = 0; a < 21; a++) S[a] = 0.0;
+#pragma unroll
+    for(int a = 0; a < 6; a++) t[a] = 0.0;
     for(int r = 0; r < m; r++)
     {
       double bb[6], az;
@@ -731,7 +768,25 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
       for(int a = 0; a < 6; a++) RB(s, r, a) = bb[a];
       RB(s, r, 6) = az;
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        t[a] += bb[a] * az;
+#pragma unroll
+        for(int c = a; c < 6; c++) S[xs_tri(a, c)] += bb[a] * bb[c];
+      }
+      alpha += az * az;
     }
+#pragma unroll
+    for(int a = 0; a < 21; a++) WS(s, kXsS + a) = S[a];
+#pragma unroll
+    for(int a = 0; a < 6; a++)
+    {
+      WS(s, kXsT + a) = t[a];
+      WS(s, kXsC + a) = 0.0;
+    }
+    WS(s, kXsAl) = alpha;
+    WS(s, kXsDp) = fz0;
   }
   double x0[6];
 #pragma unroll
@@ -752,63 +807,27 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     }
     for(int s = N - 1; s >= 0; s--)
     {
-      const int m = (int)WS(s, 92);
-      const double fz = WS(s, 93);
+      const int m = (int)WS(s, kXsDim);
+      const double fz = WS(s, kXsFz);
       const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
-      const unsigned bits = W.st[(blk * N + s) * 64 + ln];
       double Pt[6][6], pt[6];
 #pragma unroll
       for(int a = 0; a < 6; a++)
       {
-        pt[a] = pv[a] - P.w[a] * WS(s, 94 + a);
+        pt[a] = pv[a] - P.w[a] * WS(s, kXsRef + a);
 #pragma unroll
         for(int c = 0; c < 6; c++) Pt[a][c] = Pm[a][c] + (a == c ? P.w[a] : 0.0);
       }
-      double S[6][6], t[6], cc[6], alpha = 0.0, dprime = fz;
+      // the clamped set's sums, as the setup / the last forward pass left them
+      double S[6][6], t[6], cc[6];
+      const double alpha = WS(s, kXsAl), dprime = WS(s, kXsDp);
 #pragma unroll
       for(int a = 0; a < 6; a++)
       {
-        t[a] = 0.0;
-        cc[a] = 0.0;
+        t[a] = WS(s, kXsT + a);
+        cc[a] = WS(s, kXsC + a);
 #pragma unroll
-        for(int c = 0; c < 6; c++) S[a][c] = 0.0;
-      }
-      for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
-      {
-        double rbv[8][7];
-#pragma unroll
-        for(int u = 0; u < 8; u++)
-#pragma unroll
-          for(int a = 0; a < 7; a++) rbv[u][a] = (r0 + u < m) ? RB(s, r0 + u, a) : 0.0;
-#pragma unroll
-        for(int u = 0; u < 8; u++)
-        {
-          const int r = r0 + u;
-          if(r >= m) break;
-          double bb[6];
-#pragma unroll
-          for(int a = 0; a < 6; a++) bb[a] = rbv[u][a];
-          const double az = rbv[u][6];
-          const unsigned stt = (bits >> (2 * r)) & 3u;
-          if(stt == 0u)
-          {
-#pragma unroll
-            for(int a = 0; a < 6; a++)
-            {
-              t[a] += bb[a] * az;
-#pragma unroll
-              for(int c = 0; c < 6; c++) S[a][c] += bb[a] * bb[c];
-            }
-            alpha += az * az;
-          }
-          else
-          {
-            const double val = stt == 1u ? P.flo : P.fhi;
-#pragma unroll
-            for(int a = 0; a < 6; a++) cc[a] += bb[a] * val;
-            dprime -= az * val;
-          }
-        }
+        for(int c = 0; c < 6; c++) S[a][c] = WS(s, kXsS + (c >= a ? xs_tri(a, c) : xs_tri(c, a)));
       }
       if(m > 0 && alpha > 0.0)
       {
@@ -913,15 +932,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
         for(int c = 0; c < 6; c++)
         {
-          WS(s, a * 6 + c) = E[a][c];
-          if(c >= a) WS(s, 42 + xs_tri(a, c)) = Pt[a][c]; // (symmetric: the upper triangle)
+          WS(s, kXsE + a * 6 + c) = E[a][c];
+          if(c >= a) WS(s, kXsPt + xs_tri(a, c)) = Pt[a][c]; // (symmetric: the upper triangle)
         }
-        WS(s, 36 + a) = fv[a];
-        WS(s, 78 + a) = pt[a];
-        WS(s, 84 + a) = t[a];
+        WS(s, kXsF + a) = fv[a];
+        WS(s, kXsPv + a) = pt[a];
       }
-      WS(s, 90) = alpha;
-      WS(s, 91) = dprime;
       double Gm[6][6], gv[6];
 #pragma unroll
       for(int a = 0; a < 6; a++)
@@ -968,32 +984,38 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       for(int a = 0; a < 6; a++) x[a] = x0[a];
       for(int s = 0; s < N; s++)
       {
-        const int m = (int)WS(s, 92);
+        const int m = (int)WS(s, kXsDim);
         double y[6], pi[6], tv[6];
 #pragma unroll
         for(int a = 0; a < 6; a++)
         {
-          double acc = WS(s, 36 + a);
+          double acc = WS(s, kXsF + a);
 #pragma unroll
-          for(int c = 0; c < 6; c++) acc += WS(s, a * 6 + c) * x[c];
+          for(int c = 0; c < 6; c++) acc += WS(s, kXsE + a * 6 + c) * x[c];
           y[a] = acc;
         }
         double tpi = 0.0;
 #pragma unroll
         for(int a = 0; a < 6; a++)
         {
-          double acc = WS(s, 78 + a);
+          double acc = WS(s, kXsPv + a);
 #pragma unroll
-          for(int c = 0; c < 6; c++) acc += WS(s, 42 + (c >= a ? xs_tri(a, c) : xs_tri(c, a))) * y[c];
+          for(int c = 0; c < 6; c++) acc += WS(s, kXsPt + (c >= a ? xs_tri(a, c) : xs_tri(c, a))) * y[c];
           pi[a] = acc;
-          tv[a] = WS(s, 84 + a);
+          tv[a] = WS(s, kXsT + a);
           tpi += tv[a] * acc;
         }
-        const double alpha = WS(s, 90), dprime = WS(s, 91);
+        const double alpha = WS(s, kXsAl), dprime = WS(s, kXsDp);
         const double nu = alpha > 0.0 ? -(wf * dprime + tpi) / alpha : 0.0;
-        const unsigned bits = W.st[(blk * N + s) * 64 + ln];
+        const unsigned bits = (unsigned)WS(s, kXsSt); // (2 bits per ridge, exact in a double)
         unsigned nb = bits;
         bool anyfree = false;
+        const double fz = WS(s, kXsFz);
+        double nS[21], nt[6], nc[6], nal = 0.0, ndp = fz; // the sums over the set this pass chooses
+#pragma unroll
+        for(int a = 0; a < 21; a++) nS[a] = 0.0;
+#pragma unroll
+        for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
         double bestm = kXyInf;
         int besti = 0;
         for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
@@ -1002,7 +1024,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
           for(int u = 0; u < 8; u++)
 #pragma unroll
-            for(int a = 0; a < 7; a++) rbv[u][a] = (r0 + u < m) ? RB(s, r0 + u, a) : 0.0;
+            for(int a = 0; a < 7; a++) rbv[u][a] = RB(s, r0 + u, a); // (all 16 slots exist; those past m are not used)
 #pragma unroll
           for(int u = 0; u < 8; u++)
           {
@@ -1017,10 +1039,11 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
             const unsigned stt = (bits >> (2 * r)) & 3u;
             double lam;
+            unsigned ns;
             if(stt == 0u)
             {
               lam = -bpi * iwf;
-              unsigned ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
+              ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
               nb = (nb & ~(3u << (2 * r))) | (ns << (2 * r));
               anyfree = anyfree || ns == 0u;
             }
@@ -1030,6 +1053,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
               const double mult = wf * lam + bpi;
               const bool release = (stt == 1u && mult < 0.0) || (stt == 2u && mult > 0.0);
               if(release) nb &= ~(3u << (2 * r));
+              ns = release ? 0u : stt;
               anyfree = anyfree || release;
               if(fabs(mult) < bestm)
               {
@@ -1042,6 +1066,8 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
               if(s == 0) B.u0[b * M + r] = lam;
               if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
             }
+            else
+              xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, az, nS, nt, nc, nal, ndp);
           }
         }
         if(emit)
@@ -1050,11 +1076,39 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             if(s == 0) B.u0[b * M + r] = 0.0;
             if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = 0.0;
           }
-        if(m > 0 && !anyfree) nb &= ~(3u << (2 * besti)); // the stage equality needs a free variable
+        const bool forced = m > 0 && !anyfree;
+        if(forced) nb &= ~(3u << (2 * besti)); // the stage equality needs a free variable
         if(!emit)
         {
+          if(forced) // (rare) the sums again, in ridge order, for the set with the forced release
+          {
+#pragma unroll
+            for(int a = 0; a < 21; a++) nS[a] = 0.0;
+#pragma unroll
+            for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
+            nal = 0.0;
+            ndp = fz;
+            for(int r = 0; r < m; r++)
+            {
+              double bb[6];
+#pragma unroll
+              for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
+              const unsigned ns = (nb >> (2 * r)) & 3u;
+              xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
+            }
+          }
+#pragma unroll
+          for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
+#pragma unroll
+          for(int a = 0; a < 6; a++)
+          {
+            WS(s, kXsT + a) = nt[a];
+            WS(s, kXsC + a) = nc[a];
+          }
+          WS(s, kXsAl) = nal;
+          WS(s, kXsDp) = ndp;
           changed = changed || nb != bits;
-          W.st[(blk * N + s) * 64 + ln] = nb;
+          WS(s, kXsSt) = (double)nb;
           hh = (hh ^ nb) * 1099511628211ull;
         }
 #pragma unroll
@@ -1160,8 +1214,10 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t N = (size_t)P.N;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t n64 = ((size_t)n + 63) / 64 * 64; // whole wavefronts
-  const size_t o_ws = 0, o_rb = o_ws + up(N * kXsFields * n64 * 8), o_st = o_rb + up(N * kXyM * 7 * n64 * 8),
+  const size_t n64 = ((size_t)n + kXsLanes - 1) / kXsLanes * kXsLanes; // whole wavefronts
+  // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
+  const size_t nwave = n64 / kXsLanes, ws_stride = N * (kXsFields + kXyM * 7) * kXsLanes, rb_stride = ws_stride;
+  const size_t o_ws = 0, o_rb = o_ws + (size_t)kXsFields * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
                o_li = o_st + up(N * n64 * 4), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
@@ -1173,7 +1229,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   }
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned *>(h->ws + o_st),
-           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn)};
+           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), ws_stride, rb_stride};
   // one instance per lane needs a large batch to fill the device (below ~24 k instances the dual active-set kernel, one
   // 448-thread workgroup per instance, is faster); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
   const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 24576 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
@@ -1181,7 +1237,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   {
     const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
     CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, sizeof(int), s));
-    hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, P, B, W, (long)n,
+    hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + kXsLanes - 1) / kXsLanes)), dim3(kXsLanes), 0, s, P, B, W, (long)n,
                        mi ? std::atoi(mi) : kXsMaxIt);
     CCC_HIP_CHECK(hipGetLastError());
   }
