@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 // profiling switches (scripts/xy_variants.sh): number of active-set/refinement rounds, skip the set-up updates
@@ -74,6 +75,7 @@ struct XyRed
 
 struct XyShared
 {
+  int ticket;                            // the list entry this workgroup took
   double bt[kXyNV][kXyNB];               // bt_i = (Bd_s[:, r], rho_z) of every variable
   double pi[2][kXyQ];                    // Qt[:, s] bt (double buffered: one barrier per rank-1 update)
   double part[kXyMaxN][kXyMaxN][kXyNB];  // partial products of the full Qt * gamma (refinement only)
@@ -232,7 +234,7 @@ __device__ __forceinline__ void xy_rank1(XyHalf & Q, bool enable, int rb, int cb
 }
 
 __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B, long n, const int * __restrict__ redo_list,
-                                                           const int * __restrict__ redo_count)
+                                                           const int * __restrict__ redo_count, int * ticket)
 {
   constexpr int M = kXyM, NB = kXyNB;
   __shared__ XyShared sh;
@@ -256,10 +258,19 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 
   // redo_list: the instances the stage-recursion kernel below handed over (normally few); otherwise the whole batch
   const long nwork = redo_list ? (long)*redo_count : n;
-  for(long wq = blockIdx.x; wq < nwork; wq += gridDim.x)
+  // (a list is worked off through a ticket counter by a grid the size of what is resident: its entries need 150-250
+  //  pivots each, and 65536 workgroups that find nothing cost 2 ms on their own)
+  for(long wq = blockIdx.x;; wq += gridDim.x)
   {
-    const long b = redo_list ? (long)redo_list[wq] : wq;
     __syncthreads();
+    if(ticket)
+    {
+      if(i == 0) sh.ticket = atomicAdd(ticket, 1);
+      __syncthreads();
+      wq = sh.ticket;
+    }
+    if(wq >= nwork) break;
+    const long b = redo_list ? (long)redo_list[wq] : wq;
     // ---------------- per-step data and the variables' impulse vectors (src/LinearMpcXY.cpp:59-83, closed-form ZOH)
     if(i < N)
     {
@@ -663,6 +674,13 @@ struct XyWork
   int * redo_list;     // [n]
   int * redo_count;    // [1]
   size_t ws_stride, rb_stride; // doubles from one wavefront's region to the next
+  size_t st_stride;            // instances per stage in st
+  // the kernel runs in rounds: the instances still changing their clamped set when a round's iterations are used up
+  // are listed (their sets saved in st) and the next round takes them up again packed into whole wavefronts
+  const int * in_list;
+  const int * in_count;
+  int * out_list;
+  int * out_count;
 };
 
 // index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
@@ -728,12 +746,15 @@ __device__ __forceinline__ void xs_accumulate(unsigned state, double val, const 
   }
 }
 
+constexpr int kXsRounds = 4;
+constexpr const char * kXsRoundsDefault = "6,10";
 constexpr int kXsLanes = 64; // instances per wavefront
-__global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int max_it)
+__global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int it_begin, int max_it)
 {
   constexpr int M = kXyM;
-  const long b = (long)blockIdx.x * kXsLanes + threadIdx.x;
-  if(b >= n) return;
+  const long slot = (long)blockIdx.x * kXsLanes + threadIdx.x;
+  if(slot >= (W.in_list ? (long)*W.in_count : n)) return;
+  const long b = W.in_list ? (long)W.in_list[slot] : slot;
   const int N = P.N;
   const double wf = P.w_force, iwf = 1.0 / P.w_force, dt = P.dt;
   // workspace layout [wavefront][stage][field][lane]: everything a wavefront touches in a stage is one contiguous 47 KB
@@ -745,7 +766,8 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    WS(s, kXsSt) = 0.0;
+    const unsigned bits0 = W.in_list ? W.st[(size_t)s * W.st_stride + b] : 0u; // (a resumed instance: the set it had)
+    WS(s, kXsSt) = (double)bits0;
     const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..16: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
     const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
@@ -756,11 +778,11 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     // ... and the sums over the clamped set the backward recursion starts from (nothing clamped: S = sum b b', t =
     // sum b a_z, alpha = sum a_z^2, c = 0, d' = f_z); from then on the forward pass, which visits every ridge anyway,
     // leaves the sums of the set it chooses
-    double S[21], t[6], alpha = 0.0;
+    double S[21], t[6], cc[6], alpha = 0.0, dprime = fz0;
 #pragma unroll
     for(int a = 0; a < 21; a++) S[a] = 0.0;
 #pragma unroll
-    for(int a = 0; a < 6; a++) t[a] = 0.0;
+    for(int a = 0; a < 6; a++) t[a] = cc[a] = 0.0;
     for(int r = 0; r < m; r++)
     {
       double bb[6], az;
@@ -768,14 +790,8 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
       for(int a = 0; a < 6; a++) RB(s, r, a) = bb[a];
       RB(s, r, 6) = az;
-#pragma unroll
-      for(int a = 0; a < 6; a++)
-      {
-        t[a] += bb[a] * az;
-#pragma unroll
-        for(int c = a; c < 6; c++) S[xs_tri(a, c)] += bb[a] * bb[c];
-      }
-      alpha += az * az;
+      const unsigned st0 = (bits0 >> (2 * r)) & 3u;
+      xs_accumulate(st0, st0 == 1u ? P.flo : P.fhi, bb, az, S, t, cc, alpha, dprime);
     }
 #pragma unroll
     for(int a = 0; a < 21; a++) WS(s, kXsS + a) = S[a];
@@ -783,10 +799,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     for(int a = 0; a < 6; a++)
     {
       WS(s, kXsT + a) = t[a];
-      WS(s, kXsC + a) = 0.0;
+      WS(s, kXsC + a) = cc[a];
     }
     WS(s, kXsAl) = alpha;
-    WS(s, kXsDp) = fz0;
+    WS(s, kXsDp) = dprime;
   }
   double x0[6];
 #pragma unroll
@@ -794,7 +810,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   int it = 0;
   bool converged = false, cycling = false;
   unsigned long long h1 = 0, h2 = 0; // hashes of the clamped sets of the last two iterations
-  for(it = 0; it < max_it && !converged && !cycling; it++)
+  for(it = it_begin; it < max_it && !converged && !cycling; it++)
   {
     // ---- backward recursion on the current clamped set
     double Pm[6][6], pv[6];
@@ -1117,11 +1133,20 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       if(!emit)
       {
         converged = !changed;
-        cycling = !converged && hh == h2; // back at the set of two iterations ago: a 2-cycle, hand the instance over
+        // back at the set of two iterations ago: a 2-cycle, hand the instance over (longer periods were looked for and
+        // do not occur: the instances that never settle wander)
+        cycling = !converged && hh == h2;
         h2 = h1;
         h1 = hh;
       }
     }
+  }
+  if(!converged && !cycling && W.out_list)
+  {
+    for(int s = 0; s < N; s++) W.st[(size_t)s * W.st_stride + b] = (unsigned)WS(s, kXsSt);
+    const int q = atomicAdd(W.out_count, 1);
+    W.out_list[q] = (int)b;
+    return; // the next round goes on from this set
   }
   if(!converged)
   {
@@ -1146,6 +1171,9 @@ struct ccc_xy
   // workspace of the stage-recursion kernel, grown to the largest batch seen
   char * ws = nullptr;
   int64_t ws_cap = 0;
+  // the dual active-set kernel works off the first round's hand-overs beside the later rounds, on a stream of its own
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** out)
@@ -1170,6 +1198,9 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
     return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
   h->num_cu = prop.multiProcessorCount;
+  CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  CCC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+  CCC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   h->blocks = h->num_cu * 2; // two resident workgroups per CU (7 + 7 wavefronts of <= 128 VGPRs)
   *out = h;
   return CCC_OK;
@@ -1182,6 +1213,9 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
   if(h->ws) (void)hipFree(h->ws);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
+  if(h->side) (void)hipStreamDestroy(h->side);
+  if(h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if(h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -1218,7 +1252,8 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
   const size_t nwave = n64 / kXsLanes, ws_stride = N * (kXsFields + kXyM * 7) * kXsLanes, rb_stride = ws_stride;
   const size_t o_ws = 0, o_rb = o_ws + (size_t)kXsFields * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
-               o_li = o_st + up(N * n64 * 4), o_cn = o_li + up((size_t)n * 4), total = o_cn + 256;
+               o_li = o_st + up(N * n64 * 4), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
+               o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
@@ -1229,24 +1264,76 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   }
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned *>(h->ws + o_st),
-           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), ws_stride, rb_stride};
+           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), ws_stride, rb_stride, n64,
+           nullptr, nullptr, nullptr, nullptr};
+  int * const round_list[2] = {reinterpret_cast<int *>(h->ws + o_l1), reinterpret_cast<int *>(h->ws + o_l2)};
+  int * const round_count = reinterpret_cast<int *>(h->ws + o_cn) + 1; // [kXsRounds], after the redo count
+  // hand-overs to the dual kernel: a list per round (the first round's is W.redo_list)
+  auto redo_list_of = [&](int k) { return k ? reinterpret_cast<int *>(h->ws + o_l3 + (size_t)(k - 1) * up((size_t)n * 4)) : W.redo_list; };
+  auto redo_count_of = [&](int k) { return k ? round_count + kXsRounds + (k - 1) : W.redo_count; };
+  auto ticket_of = [&](int k) { return W.redo_count + 2 * kXsRounds + k; };
+  const int lgrid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 4); // (two workgroups are resident per CU)
   // one instance per lane needs a large batch to fill the device (below ~24 k instances the dual active-set kernel, one
   // 448-thread workgroup per instance, is faster); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
+  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
   const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 24576 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
   if(!dual_only)
   {
     const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
-    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, sizeof(int), s));
-    hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + kXsLanes - 1) / kXsLanes)), dim3(kXsLanes), 0, s, P, B, W, (long)n,
-                       mi ? std::atoi(mi) : kXsMaxIt);
+    const int cap = mi ? std::atoi(mi) : kXsMaxIt;
+    // rounds of iterations (development switch CCC_XY_ROUNDS="a,b": the iteration counts at which the instances still
+    // going are repacked; the instances of a wavefront need very different numbers of iterations, and a wavefront is as
+    // slow as its slowest lane)
+    int ends[kXsRounds], nr = 0;
+    {
+      const char * rs = std::getenv("CCC_XY_ROUNDS");
+      std::string spec = rs ? rs : kXsRoundsDefault;
+      size_t pos = 0;
+      while(pos < spec.size() && nr < kXsRounds - 1)
+      {
+        const int v = std::atoi(spec.c_str() + pos);
+        if(v > (nr ? ends[nr - 1] : 0) && v < cap) ends[nr++] = v;
+        pos = spec.find(',', pos);
+        if(pos == std::string::npos) break;
+        pos++;
+      }
+      ends[nr++] = cap;
+    }
+    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, 3 * kXsRounds * sizeof(int), s));
+    for(int k = 0; k < nr; k++)
+    {
+      XyWork Wk = W;
+      Wk.in_list = k ? round_list[(k - 1) & 1] : nullptr;
+      Wk.in_count = k ? round_count + (k - 1) : nullptr;
+      Wk.out_list = k + 1 < nr ? round_list[k & 1] : nullptr;
+      Wk.out_count = k + 1 < nr ? round_count + k : nullptr;
+      Wk.redo_list = redo_list_of(k);
+      Wk.redo_count = redo_count_of(k);
+      hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + kXsLanes - 1) / kXsLanes)), dim3(kXsLanes), 0, s, P,
+                         B, Wk, (long)n, k ? ends[k - 1] : 0, ends[k]);
+      if(k + 1 < nr)
+      {
+        // this round's hand-overs (the instances found cycling) start on the dual kernel now, beside the next round:
+        // the later rounds run few wavefronts and leave most of the device idle
+        CCC_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+        CCC_HIP_CHECK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        hipLaunchKernelGGL(xy_plan_kernel, dim3(lgrid), dim3(kXyNT), 0, h->side, P, B, (long)n, Wk.redo_list, Wk.redo_count,
+                           ticket_of(k));
+      }
+    }
     CCC_HIP_CHECK(hipGetLastError());
+    if(nr > 1)
+    {
+      CCC_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
+      hipLaunchKernelGGL(xy_plan_kernel, dim3(lgrid), dim3(kXyNT), 0, s, P, B, (long)n, redo_list_of(nr - 1), redo_count_of(nr - 1),
+                         ticket_of(nr - 1));
+      CCC_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join, 0));
+      CCC_HIP_CHECK(hipGetLastError());
+      return CCC_OK;
+    }
   }
-  // dual active-set kernel: one workgroup per instance (the whole batch, or the list the stage-recursion kernel left)
-  // (one workgroup per instance or list entry: workgroups beyond the list's length find nothing and leave; the hardware
-  //  dispatcher evens out the pivot counts, which a strided loop over a short list would not)
-  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
-  hipLaunchKernelGGL(xy_plan_kernel, dim3(grid), dim3(kXyNT), 0, s, P, B, (long)n, dual_only ? nullptr : W.redo_list,
-                     dual_only ? nullptr : W.redo_count);
+  hipLaunchKernelGGL(xy_plan_kernel, dim3(dual_only ? grid : lgrid), dim3(kXyNT), 0, s, P, B, (long)n,
+                     dual_only ? nullptr : W.redo_list, dual_only ? nullptr : W.redo_count, dual_only ? nullptr : ticket_of(0));
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;
 }

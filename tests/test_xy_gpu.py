@@ -235,7 +235,26 @@ def test_cpp_header_shim_matches_python_mirror():
         assert float(bl.split("u0[0]=")[1]) == u[0]
 
 
-@pytest.mark.parametrize("env", [{"CCC_XY_DUAL": "1"}, {"CCC_XY_PDAS_ITERS": "1"}, {"CCC_XY_PDAS_ITERS": "3"}])
+def test_rounds_of_the_stage_recursion_kernel_are_bit_identical(monkeypatch):
+    """The stage-recursion kernel runs in rounds: the instances still changing their clamped set when a round ends are
+    repacked into whole wavefronts and go on from the set they had.  The iteration is a function of the set alone, so any
+    split into rounds gives the same answers, bit for bit, and the same iteration counts."""
+    monkeypatch.delenv("CCC_XY_DUAL", raising=False)
+    monkeypatch.setenv("CCC_XY_STREAM", "1")
+    prob, x0 = fd.make_xy_batch(700, 20, 0.1, seed=21)
+    mpc = LinearMpcXY(100.0, 0.1, 20)
+    res = []
+    for rounds in ("99", "6,10", "2,4,6", "1", "3,4,5"):
+        monkeypatch.setenv("CCC_XY_ROUNDS", rounds)
+        res.append(mpc.planOnceBatch(prob, x0, want_all=True))
+    assert np.all(res[0]["status"] == 0)
+    for r in res[1:]:
+        assert np.array_equal(r["u0"], res[0]["u0"]) and np.array_equal(r["lam"], res[0]["lam"])
+        assert np.array_equal(r["pivots"], res[0]["pivots"])
+
+
+@pytest.mark.parametrize("env", [{"CCC_XY_DUAL": "1"}, {"CCC_XY_PDAS_ITERS": "1"}, {"CCC_XY_PDAS_ITERS": "3"},
+                                 {"CCC_XY_STREAM": "1", "CCC_XY_ROUNDS": "2,5,9"}])
 def test_dual_kernel_and_fallback_list(env):
     """The stage-recursion (primal-dual active set) kernel is the default; the dual active-set kernel stays as its
     fallback.  In a subprocess with the development switches: the dual kernel alone, and the stage-recursion kernel starved
