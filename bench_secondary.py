@@ -24,11 +24,13 @@ def _tile(d, n, base):
 
 def _xy_algo(status):
     """Bytes a lane must move (csrc/xy.hip, stage-recursion kernel): inputs and outputs once, the ridge vectors into the
-    workspace once (7 doubles per ridge), then per iteration and stage 92 doubles written and read back plus the ridge
-    vectors read in both sweeps (16 ridges); iterations = set changes + 1 of the instances that kernel finished."""
+    workspace once (7 doubles per ridge), then per iteration and stage: the backward sweep reads 43 doubles (the clamped
+    set's sums, the step's scalars) and writes 69 (feedback, value function), the forward sweep reads 80 + the 16 ridge
+    vectors (112) and writes 36 (the next set and its sums); iterations = set changes + 1 of the instances that kernel
+    finished."""
     it = (status >> 8).astype(np.float64)
     it = np.where(it <= 16, it + 1.0, 17.0).mean()
-    return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (2 * 92 + 2 * 16 * 7) * 8
+    return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (43 + 69 + 80 + 16 * 7 + 36) * 8
 
 
 def _xy(n, dev, rank):
