@@ -28,6 +28,11 @@ inline int fail(int code, const char * fmt, ...)
 // Select `device` after checking that it exists and is a gfx950 part: the product path has no CPU
 // (or other-arch) fallback and must fail loudly instead.
 int select_device(int device);
+
+// Zero `words` 32-bit words at `p` on `stream` with a kernel of the library's own.  The per-launch counters (work-list
+// lengths, tickets) are reset with this rather than hipMemsetAsync: captured in a hipGraph, a 4-byte memset node
+// followed a foreign kernel with a memory access fault on replay (ROCm 7.2; tests/test_graph_capture_gpu.py).
+int zero_words(void * p, int words, void * stream);
 } // namespace ccc_amd
 
 #define CCC_HIP_CHECK(expr)                                                                              \

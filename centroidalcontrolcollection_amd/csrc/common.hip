@@ -11,6 +11,21 @@ std::string & last_error()
   return err;
 }
 
+__global__ void zero_words_kernel(unsigned * p, int words)
+{
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+int zero_words(void * p, int words, void * stream)
+{
+  if(words <= 0) return CCC_OK;
+  const int blocks = words < 256 * 64 ? (words + 255) / 256 : 64;
+  hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     static_cast<unsigned *>(p), words);
+  CCC_HIP_CHECK(hipGetLastError());
+  return CCC_OK;
+}
+
 int select_device(int device)
 {
   int count = 0;

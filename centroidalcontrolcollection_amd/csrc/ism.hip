@@ -803,7 +803,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(!tableau_only)
   {
     // default path: tridiagonal projected Newton, one QP per wavefront; what it cannot finish goes onto the list
-    CCC_HIP_CHECK(hipMemsetAsync(h->redo, 0, sizeof(int), s));
+    if(int zrc = zero_words(h->redo, 1, s)) return zrc;
     IsmPcrDev Q{h->N, h->dAt, h->a0_dt, h->w_zmp, h->w_zmp_vel, h->horizon_dt};
     const char * mo = std::getenv("CCC_ISM_PCR_OUTER"); // (development switch: the outer budget; small values exercise the list)
     hipLaunchKernelGGL(ism_plan_pcr_kernel, dim3((unsigned)((nqp + 3) / 4)), dim3(256), 0, s, Q, (long)nqp, init, ref,

@@ -1299,7 +1299,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       }
       ends[nr++] = cap;
     }
-    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, 3 * kXsRounds * sizeof(int), s));
+    if(int zrc = zero_words(W.redo_count, 3 * kXsRounds, s)) return zrc;
     for(int k = 0; k < nr; k++)
     {
       XyWork Wk = W;

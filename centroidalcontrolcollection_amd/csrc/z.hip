@@ -655,7 +655,7 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr; // (development switch: the LDS-tableau kernel alone)
   if(!tableau_only)
   {
-    CCC_HIP_CHECK(hipMemsetAsync(W.redo_count, 0, sizeof(int), s));
+    if(int zrc = zero_words(W.redo_count, 1, s)) return zrc;
     const char * mi = std::getenv("CCC_Z_SWEEPS"); // (development switch: the sweep budget; small values exercise the fallback)
     hipLaunchKernelGGL(z_plan_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, B, W, (long)n,
                        mi ? std::atoi(mi) : kZMaxSweeps);

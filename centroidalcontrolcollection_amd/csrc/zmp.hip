@@ -1468,7 +1468,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     }
     const size_t qbytes = (size_t)kQueues * kQueueStride * sizeof(unsigned long long);
     if(!h->queue) CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
-    CCC_HIP_CHECK(hipMemsetAsync(h->queue, 0, qbytes, stream));
+    if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream)) return zrc;
     static int per_cu = 0; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
     if(per_cu == 0)
     {

@@ -14,6 +14,9 @@
  * return when the results are in the host buffers.
  * A handle owns device scratch (work-queue counters, workspaces): launches of ONE handle must not overlap on the
  * device -- enqueue them on one stream (or order the streams); use one handle per concurrent stream.
+ * hipGraph: every "_device" call may be captured (hipStreamBeginCapture on the stream it is given) once the handle has
+ * run one call of at least that batch size eagerly -- workspaces are allocated, synchronously, when a batch size is
+ * first seen; a call enqueues only kernels (and, LinearMpcXY, an event fork/join with a stream the handle owns).
  */
 #ifndef CCC_AMD_H
 #define CCC_AMD_H
