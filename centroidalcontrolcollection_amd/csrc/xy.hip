@@ -746,6 +746,7 @@ __device__ __forceinline__ void xs_accumulate(unsigned state, double val, const 
   }
 }
 
+constexpr int kXsStage = kXsFields + kXyM * 8; // fields of a stage + 16 ridges x (7 + 1 pad)
 constexpr int kXsRounds = 4;
 constexpr const char * kXsRoundsDefault = "6,10";
 constexpr int kXsLanes = 64; // instances per wavefront
@@ -761,8 +762,13 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // (+ 57 KB of ridge vectors) run of memory, stage after stage -- with [stage][field][instance] every 512-byte access
   // of a wavefront opened a DRAM page of its own
   const size_t blk = (size_t)blockIdx.x, ln = threadIdx.x;
-  auto WS = [&](int s, int f) -> double & { return W.ws[blk * W.ws_stride + (size_t)((s * (kXsFields + M * 7) + f) * kXsLanes) + ln]; };
-  auto RB = [&](int s, int r, int f) -> double & { return W.rb[blk * W.rb_stride + (size_t)((s * (kXsFields + M * 7) + r * 7 + f) * kXsLanes) + ln]; };
+  // (fields in pairs, [pair][lane][2]: two neighbouring fields of a lane are 16 contiguous bytes, one dwordx4 access --
+  //  half the memory instructions and twice the bytes in flight per wavefront for the same vmcnt budget)
+  auto FLD = [&](int s, int g) -> double & {
+    return W.ws[blk * W.ws_stride + (size_t)((s * kXsStage + (g & ~1)) * kXsLanes) + ln * 2 + (g & 1)];
+  };
+  auto WS = [&](int s, int f) -> double & { return FLD(s, f); };
+  auto RB = [&](int s, int r, int f) -> double & { return FLD(s, kXsFields + r * 8 + f); };
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
@@ -1250,7 +1256,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t n64 = ((size_t)n + kXsLanes - 1) / kXsLanes * kXsLanes; // whole wavefronts
   // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
-  const size_t nwave = n64 / kXsLanes, ws_stride = N * (kXsFields + kXyM * 7) * kXsLanes, rb_stride = ws_stride;
+  const size_t nwave = n64 / kXsLanes, ws_stride = N * kXsStage * kXsLanes, rb_stride = ws_stride;
   const size_t o_ws = 0, o_rb = o_ws + (size_t)kXsFields * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
                o_li = o_st + up(N * n64 * 4), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
                o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
