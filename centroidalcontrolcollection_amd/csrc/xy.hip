@@ -1279,10 +1279,12 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   auto redo_count_of = [&](int k) { return k ? round_count + kXsRounds + (k - 1) : W.redo_count; };
   auto ticket_of = [&](int k) { return W.redo_count + 2 * kXsRounds + k; };
   const int lgrid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 4); // (two workgroups are resident per CU)
-  // one instance per lane needs a large batch to fill the device (below ~24 k instances the dual active-set kernel, one
-  // 448-thread workgroup per instance, is faster); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
+  // one instance per lane needs a batch to fill the device and has a latency floor of ~7 ms (16 dependent iterations, then
+  // the dual kernel on what is left): below 4096 instances the dual active-set kernel alone, one 448-thread workgroup
+  // per instance, is faster (measured: 4.2 against 7.3 ms at 2048, 7.6 / 7.3 at 4096, 14.5 / 8.1 at 8192, 28 / 9.4 at
+  // 16384); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
-  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 24576 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
+  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 4096 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
   if(!dual_only)
   {
     const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
