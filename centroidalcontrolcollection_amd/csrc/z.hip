@@ -652,7 +652,12 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   }
   ZWork W{reinterpret_cast<double *>(h->ws + o_f), reinterpret_cast<unsigned char *>(h->ws + o_fl),
           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn)};
-  const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr; // (development switch: the LDS-tableau kernel alone)
+  // the streaming kernel has a latency floor (sweeps x steps x memory round trips: 0.3 ms at N = 40) and wants the device
+  // full; below ~24 k instances at N = 40 the LDS-tableau kernel, one wavefront per instance, is faster (measured 0.05
+  // against 0.31 ms at 512, 0.17 / 0.36 at 8192, 0.41 / 0.45 at 24576, 0.53 / 0.45 at 32768); its cost per instance grows
+  // faster with N than the floor does, hence n N.  CCC_Z_TABLEAU / CCC_Z_STREAM force either path (development switches)
+  const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr ||
+                            (n * (int64_t)h->N < (int64_t)24576 * 40 && !std::getenv("CCC_Z_STREAM") && !std::getenv("CCC_Z_SWEEPS"));
   if(!tableau_only)
   {
     if(int zrc = zero_words(W.redo_count, 1, s)) return zrc;

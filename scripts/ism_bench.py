@@ -23,5 +23,5 @@ for _ in range(reps):
     t0 = time.perf_counter(); mpc.plan_batch_device(ti, tr, 0.005, z, status=st); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = min(ts)
 s = st.cpu().numpy()
-print("IntrinsicallyStableMpc n=%d N=100: %.1f ms -> %.0f solves/s (mean pivots/axis %.1f, max %d, non-ok %d)"
+print("IntrinsicallyStableMpc n=%d N=100: %.3f ms -> %.0f solves/s (mean pivots/axis %.1f, max %d, non-ok %d)"
       % (n, t * 1e3, n / t, (s >> 8).mean(), (s >> 8).max(), int(((s & 0xff) != 0).sum())))

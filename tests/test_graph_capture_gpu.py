@@ -73,9 +73,11 @@ def test_xy_graph_replay_with_rounds_and_second_stream(monkeypatch):
         assert np.all((st.cpu().numpy() & 0xff) == 0) and (st.cpu().numpy() >> 8).max() > 16  # some went to the dual kernel
 
 
-def test_z_graph_replay():
+@pytest.mark.parametrize("path", ["CCC_Z_STREAM", "CCC_Z_TABLEAU"])
+def test_z_graph_replay(monkeypatch, path):
     import torch
 
+    monkeypatch.setenv(path, "1")
     dev = torch.device("cuda:0")
     n = 3000
     z = LinearMpcZ(100.0, 0.05, 40)

@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-8
 
 
+@pytest.fixture(autouse=True, params=["stream", "tableau"])
+def _z_path(request, monkeypatch):
+    """Every test of this module runs on both kernels: the streaming (projected Newton, Riccati sweeps) kernel that large
+    batches take by default, and the LDS-tableau kernel that small batches (and the fallback list) take."""
+    monkeypatch.setenv("CCC_Z_STREAM" if request.param == "stream" else "CCC_Z_TABLEAU", "1")
+    yield
+
+
 def _oracle():
     from oracle import oracle
 
@@ -110,7 +118,7 @@ def test_cpp_header_shim_matches_python_mirror():
     assert float(lines[2].split("force=")[1]) == 0.0
 
 
-@pytest.mark.parametrize("env", [{"CCC_Z_TABLEAU": "1"}, {"CCC_Z_SWEEPS": "2"}, {"CCC_Z_SWEEPS": "4"}, {"CCC_Z_SWEEPS": "40"}])
+@pytest.mark.parametrize("env", [{"CCC_Z_TABLEAU": "1"}, {"CCC_Z_SWEEPS": "2"}, {"CCC_Z_SWEEPS": "4"}, {"CCC_Z_SWEEPS": "40"}, {}])
 def test_tableau_kernel_and_fallback_list(env):
     """The streaming (Riccati / projected Newton) kernel is the default; the LDS-tableau kernel stays as its fallback.
     In a subprocess with the development switches: the tableau kernel alone, and the streaming kernel starved of
@@ -130,6 +138,6 @@ def test_tableau_kernel_and_fallback_list(env):
         "print((np.abs(r['force'] - o['force']) / (np.abs(o['force']) + 1.0)).max())\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root,
-                         env=dict(os.environ, PYTHONPATH=root, **env))
+                         env=dict({k: v for k, v in os.environ.items() if not k.startswith("CCC_Z_")}, PYTHONPATH=root, **env))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert float(out.stdout.strip().splitlines()[-1]) <= RTOL
