@@ -213,7 +213,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
-                         "kernel": "zmp_plan_kernel_dyn<32,4>" if 2 * n >= 6 * 256 * 12 * 2 else "zmp_plan_kernel<32,4>",
+                         "kernel": "zmp_plan_kernel_dyn<32,2>" if 2 * n >= 6 * 256 * 12 * 2 else "zmp_plan_kernel<32,2>",
                          "kernel_avg_ms": kavg * 1e3,
                          "note": "algorithmic bytes = 1088 B/solve x batch; the kernel is fp64-VALU/LDS-latency "
                                  "bound (iterative active set), see DESIGN.md"},

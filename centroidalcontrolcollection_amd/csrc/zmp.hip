@@ -1635,7 +1635,7 @@ extern "C" int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double 
   if(!x0 || !zlim || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_plan_batch_device: NULL x0/zlim/zmp");
   CCC_HIP_CHECK(hipSetDevice(h->device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if(h->NP == 32) return launch<32, 4>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
+  if(h->NP == 32) return launch<32, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
   return launch_block(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
 }
 
