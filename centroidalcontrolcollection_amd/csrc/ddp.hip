@@ -97,6 +97,7 @@ extern "C" void ccc_ddp_default_config(ccc_ddp_config_t * c)
   c->cost_update_ratio_thre = 0.0;
   c->cost_update_thre = 1e-7;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
+  c->reg_type = 1;
 }
 
 extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t ** out)
@@ -150,6 +151,7 @@ extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
 {
   if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: NULL argument");
   if(cfg->max_iter < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: max_iter < 0");
+  if(cfg->reg_type != 1 && cfg->reg_type != 2) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: reg_type must be 1 or 2");
   h->cfg = *cfg;
   return CCC_OK;
 }
@@ -216,6 +218,7 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   P.ratio_thre = h->cfg.cost_update_ratio_thre;
   P.cost_thre = h->cfg.cost_update_thre;
   for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
+  P.reg_type = h->cfg.reg_type;
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
              x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -115,6 +115,7 @@ struct Params
   double lambda0, dlambda0, lambda_factor, lambda_min, lambda_max;
   double k_rel_norm_thre, lambda_thre, ratio_thre, cost_thre;
   double alpha[11];
+  int reg_type; // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
 };
 
 // Per-instance problem data and workspace (global memory)
@@ -577,7 +578,7 @@ struct Solver
   CCC_DDP_FN int box_qp_dev(int m_rt)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
-    const int max_iter = 100;
+    const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     const int m = MM ? MM : __builtin_amdgcn_readfirstlane(m_rt);
     const int lane = static_cast<int>(threadIdx.x & 63), i = lane & 15;
     const bool in = i < m;
@@ -715,7 +716,7 @@ struct Solver
   CCC_DDP_FN int box_qp(int m)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
-    const int max_iter = 100;
+    const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     const double * H = mem.QuuF;
     const double * g = mem.Qu;
     phase([&](int lane) {
@@ -1133,7 +1134,7 @@ struct Solver
   // LDS operands per multiply-add and are bound by LDS bandwidth (8 wavefronts per CU); this form reads half as many
   // words, almost all of them broadcasts.  Sums run over k = 0 .. S-1 in increasing order from the same start value:
   // identical results.   C(a,c) = [DIAG] + sum_k Aop(a,k) B(k,c),  Aop = A or A' (TRANS), optionally A + lam I (LAM);
-  //   DIAG 0: none, 1: w_run[a] on a == c, 2: w_force on a == c.
+  //   DIAG 0: none, 1: w_run[a] on a == c, 2: w_force on a == c, 3: as 2 and lam added to the diagonal after the sum.
   template<bool TRANS, int DIAG, bool LAM>
   CCC_DDP_FN void colprod(int lane, int rows, int ncols, const double * A, int lda, const double * B, int ldb, double lam,
                           double * C, int ldc) const
@@ -1147,7 +1148,7 @@ struct Solver
     {
       double sum = 0.0;
       if(DIAG == 1) sum = (a == c) ? P.w_run[a] : 0.0;
-      if(DIAG == 2) sum = (a == c) ? P.w_force : 0.0;
+      if(DIAG == 2 || DIAG == 3) sum = (a == c) ? P.w_force : 0.0;
 #  pragma unroll
       for(int k = 0; k < S; k++)
       {
@@ -1155,6 +1156,7 @@ struct Solver
         if(LAM) av = av + (a == k ? lam : 0.0);
         sum += av * Bc[k];
       }
+      if(DIAG == 3) sum = (a == c) ? sum + lam : sum;
       if(act) C[a * ldc + c] = sum;
     }
   }
@@ -1209,7 +1211,8 @@ struct Solver
     const int N = P.N;
     {
       const int m = MM ? MM : m_rt;
-      const double lambda = mem.sc[SC_LAMBDA];
+      const double lambda_v = P.reg_type == 2 ? mem.sc[SC_LAMBDA] : 0.0;
+      const double lambda_q = P.reg_type == 2 ? 0.0 : mem.sc[SC_LAMBDA];
 #if defined(__HIP_DEVICE_COMPILE__)
       const StepRegs cur = sr;
       {
@@ -1254,13 +1257,13 @@ struct Solver
 #if defined(__HIP_DEVICE_COMPILE__)
         colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
         colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
-        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda, T2r, M);
+        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda_v, T2r, M);
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
           const int a = e / m, r = e % m;
           double s = 0;
-          for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda : 0.0)) * mem.Fu[k * M + r];
+          for(int k = 0; k < S; k++) s += (mem.Vxx[a * S + k] + (a == k ? lambda_v : 0.0)) * mem.Fu[k * M + r];
           T2r[a * M + r] = s;
         }
         for(int e = lane; e < S * S; e += kWave)
@@ -1312,7 +1315,7 @@ struct Solver
         const double * const T2r = mem.Lf;
 #if defined(__HIP_DEVICE_COMPILE__)
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
-        colprod<true, 2, false>(lane, m, m, mem.Fu, M, T2r, M, 0.0, mem.QuuF, LQ);
+        colprod<true, 3, false>(lane, m, m, mem.Fu, M, T2r, M, lambda_q, mem.QuuF, LQ);
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
@@ -1326,6 +1329,7 @@ struct Solver
           const int r = e / m, q = e % m;
           double s = (r == q) ? P.w_force : 0.0;
           for(int k = 0; k < S; k++) s += mem.Fu[k * M + r] * T2r[k * M + q];
+          if(r == q) s = s + lambda_q;
           mem.QuuF[r * LQ + q] = s;
         }
 #endif

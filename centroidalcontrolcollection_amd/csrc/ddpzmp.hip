@@ -136,7 +136,7 @@ __device__ __forceinline__ double terminal_cost(const Params & P, const double *
 __device__ __forceinline__ int box_qp3(const double (&H)[3][3], const double (&g)[3], double (&x)[3],
                                        double (&Lf)[3][3], double (&rd)[3])
 {
-  const int max_iter = 100;
+  const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
   const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
   double grad[3], search[3], xc[3], tmp[3];
   int result = 0, iter = 0;
@@ -426,7 +426,8 @@ struct Solver
           Qxx[a][b] = s;
         }
       }
-      // ---- unregularised Qxu, Quu and regularised Qxur, QuuF (Vxx + lambda I)
+      // ---- unregularised Qxu, Quu and regularised Qxur, QuuF (reg_type 1: Quu_F + lambda I, 2: Vxx + lambda I)
+      const double lambda_v = P.cfg.reg_type == 2 ? lambda : 0.0, lambda_q = P.cfg.reg_type == 2 ? 0.0 : lambda;
       double Qxu[6][3], Quu[3][3], Qxur[6][3], QuuF[3][3];
 #pragma unroll
       for(int pass = 0; pass < 2; pass++)
@@ -441,7 +442,7 @@ struct Solver
             double s = 0;
 #pragma unroll
             for(int k = 0; k < 6; k++)
-              if(fu_nz(k, q)) s += ((pass == 1 && a == k) ? Vxx[a][k] + lambda : Vxx[a][k]) * Fu[k][q];
+              if(fu_nz(k, q)) s += ((pass == 1 && a == k) ? Vxx[a][k] + lambda_v : Vxx[a][k]) * Fu[k][q];
             t2[a] = s;
           }
 #pragma unroll
@@ -466,7 +467,7 @@ struct Solver
             if(pass == 0)
               Quu[p][q] = s;
             else
-              QuuF[p][q] = s;
+              QuuF[p][q] = (p == q) ? s + lambda_q : s;
           }
         }
       }
@@ -948,6 +949,7 @@ extern "C" void ccc_ddpzmp_default_config(ccc_ddp_config_t * c)
   c->cost_update_ratio_thre = 0.0;
   c->cost_update_thre = 1e-7;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
+  c->reg_type = 1;
 }
 
 extern "C" int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_steps, const double * weights, int device,
@@ -993,6 +995,7 @@ extern "C" int ccc_ddpzmp_set_config(ccc_ddpzmp_t * h, const ccc_ddp_config_t * 
 {
   if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: NULL argument");
   if(cfg->max_iter < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: max_iter < 0");
+  if(cfg->reg_type != 1 && cfg->reg_type != 2) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: reg_type must be 1 or 2");
   h->P.cfg = *cfg;
   return CCC_OK;
 }

@@ -75,7 +75,9 @@ class CentroidalSim:
         self.ang_mom = self.ang_mom + np.asarray(moment) * dt
 
     def addDisturb(self, lin_impulse_per_mass, ang_impulse_per_mass):
-        # SimModels.h:326-330: velocities only (the momentum states are separate integrators)
+        # SimModels.h:326-330: velocities only (the momentum states are separate integrators).  The reference tests
+        # build the impulse as sva::ForceVecd(Zero, (0.05, 0.05, 0)) (TestDdpCentroidal.cpp:24-25): sva's constructor
+        # order is (couple, force), so the kick is LINEAR, 0.05 m/s in x and y, and the angular part is zero.
         self.vel = self.vel + np.asarray(lin_impulse_per_mass)
         self.ang_vel = self.ang_vel + np.asarray(ang_impulse_per_mass)
 
@@ -176,7 +178,7 @@ def srb_ori_ref(t):
 
 
 def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.005, end_time=3.0, P=4, M=16,
-                        disturb_time=1.0, ang_disturb=(0.05, 0.05, 0.0), warm_max_iter=1):
+                        disturb_time=1.0, lin_disturb=(0.05, 0.05, 0.0), warm_max_iter=1):
     """The control loops of TestDdpCentroidal.cpp:96-150 / TestDdpSingleRigidBody.cpp:103-170 around any
     `plan(prob, x0 [1,S], u_init [1,N,M] | None, max_iter) -> u [1,N,M]`: first cycle cold start with the full
     iteration budget, afterwards warm start (unshifted u_list, zeroed where the input dimension changed) with
@@ -209,16 +211,18 @@ def run_closed_loop_ddp(plan, srb=False, mass=100.0, N=100, dt=0.03, sim_dt=0.00
         ref = prob["ref_pos"][0, 0]
         log.append(dict(t=t, pos=sim.pos.copy(), ref=ref.copy(), vel=sim.vel.copy(), ang_mom=sim.ang_mom.copy(),
                         ori=sim.ori.copy(), ang_vel=sim.ang_vel.copy(),
-                        ori_ref=(prob["ref_ori"][0, 0][::-1].copy() if srb else np.zeros(3)), force=force))
+                        ori_ref=(prob["ref_ori"][0, 0][::-1].copy() if srb else np.zeros(3)),
+                        ori_ref_zyx=(prob["ref_ori"][0, 0].copy() if srb else np.zeros(3)), force=force))
         t += sim_dt
         sim.update(force, moment)
         if disturb_time <= t < disturb_time + sim_dt:
-            sim.addDisturb(np.zeros(3), ang_disturb)
+            sim.addDisturb(lin_disturb, np.zeros(3))
         cycle += 1
     ref_end = reference_schedule(t)[1]
     ori_end = srb_ori_ref(t)[::-1] if srb else np.zeros(3)
     return log, dict(t=t, pos=sim.pos.copy(), ref=ref_end, vel=sim.vel.copy(), ang_mom=sim.ang_mom.copy(),
-                     ori=sim.ori.copy(), ori_ref=ori_end, ang_vel=sim.ang_vel.copy())
+                     ori=sim.ori.copy(), ori_ref=ori_end, ori_ref_zyx=ori_end[::-1].copy(),
+                     ang_vel=sim.ang_vel.copy())
 
 
 # ===================================================================== LinearMpcXY fixtures

@@ -160,6 +160,7 @@ typedef struct
   double initial_lambda, initial_dlambda, lambda_factor, lambda_min, lambda_max;
   double k_rel_norm_thre, lambda_thre, cost_update_ratio_thre, cost_update_thre;
   double alpha_list[11];
+  int reg_type; /* 1: Quu_F + lambda I (default; iLQG regType 1), 2: Vxx + lambda I */
 } ccc_ddp_config_t;
 
 void ccc_ddp_default_config(ccc_ddp_config_t * cfg);

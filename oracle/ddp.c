@@ -20,11 +20,16 @@
  *         expectation is not positive)
  *     (5) accepted: dlambda = min(dlambda/f, 1/f), lambda = lambda*dlambda*(lambda > lambda_min); stop if the cost
  *         decrease < cost_update_thre;  rejected: increase lambda as in (2), stop if lambda > lambda_max
- *   backward pass (reg_type 1): Vxx_reg = Vxx + lambda I; Quu_F = Luu + Fu' Vxx_reg Fu; Qxu_reg = Lxu + Fx' Vxx_reg Fu;
+ *   backward pass: reg_type 1 (default; iLQG.m "regType 1: q_uu + lambda*eye()", which nmpc_ddp's reg_type follows):
+ *       Quu_F = Luu + Fu' Vxx Fu + lambda I, Qxu_reg = Qxu;   reg_type 2: Vxx_reg = Vxx + lambda I in both.
+ *     Evidence for 1 (round 2, tests/test_oracle_ddp.py): on the reference's own SRB scenario the cold solve from
+ *     u = 0 converges in 29 of 32 runs (x0 perturbed by 1e-10) with reg_type 1 and in 3 of 32 with reg_type 2
+ *     (27 end with lambda > lambda_max); and the CCC constructors lower initial_lambda to 1e-6 = running_force
+ *     (src/DdpCentroidal.cpp:199), which only matters when lambda is added to Quu.
  *     k = boxQP(Quu_F, Qu, lo - u, hi - u, warm start k_{i+1}); K_free = -Quu_F,ff^-1 Qxu_reg,f'; clamped rows of K = 0;
  *     dV += [k'Qu, 1/2 k'Quu k]; Vx = Qx + K'Quu k + K'Qu + Qxu k; Vxx = sym(Qxx + K'Quu K + K'Qxu' + Qxu K)
- *   boxQP: projected Newton (Tassa's boxQP.m): max_iter 100, min_grad 1e-8, min_rel_improve 1e-8, step_dec 0.6,
- *     min_step 1e-22, Armijo 0.1.
+ *   boxQP: projected Newton (Tassa's boxQP.m) with nmpc_ddp's BoxQP::Configuration: max_iter 500, grad_thre 1e-8,
+ *     rel_improve_thre 1e-8, step_factor 0.6, min_step 1e-22, armijo_param 0.1.
  */
 #include "ccc_oracle.h"
 
@@ -45,6 +50,7 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
   c->lambda_thre = 1e-5;
   c->cost_update_ratio_thre = 0.0;
   c->cost_update_thre = 1e-7;
+  c->reg_type = 1;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = pow(10.0, -3.0 * i / 10.0);
 }
 
@@ -58,7 +64,7 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
 int oracle_box_qp(int n, const double * H, const double * g, const double * lo, const double * hi, double * x,
                   int * is_free, double * Lf, double * rd, int * n_free_out, int * iters_out)
 {
-  const int max_iter = 100;
+  const int max_iter = 500; /* nmpc_ddp BoxQP::Configuration::max_iter (boxQP.m has 100) */
   const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
   double * grad = (double *)malloc(sizeof(double) * n * 4);
   double * search = grad + n, * xc = grad + 2 * n, * tmp = grad + 3 * n;
@@ -205,6 +211,10 @@ int oracle_box_qp(int n, const double * H, const double * g, const double * lo, 
 
 /* ------------------------------------------------------------------------------------------- DDP */
 
+#include <stdio.h>
+/* development aid: when non-zero, oracle_ddp_solve prints one line per line-search candidate to stderr */
+int oracle_ddp_trace = 0;
+
 typedef struct
 {
   const oracle_ddp_problem_t * p;
@@ -287,7 +297,9 @@ static int backward_pass(ddp_t * d)
       Qu[r] = s;
     }
     for(int a = 0; a < S * S; a++) Vxxr[a] = Vxx[a];
-    for(int a = 0; a < S; a++) Vxxr[a * S + a] += d->lambda;
+    /* reg_type 1 (nmpc_ddp / iLQG default): Quu_F + lambda I;  reg_type 2: Vxx + lambda I */
+    const double lambda_v = d->c->reg_type == 2 ? d->lambda : 0.0, lambda_q = d->c->reg_type == 2 ? 0.0 : d->lambda;
+    for(int a = 0; a < S; a++) Vxxr[a * S + a] += lambda_v;
     /* Qxx = Lxx + Fx' Vxx Fx */
     for(int a = 0; a < S; a++)
       for(int b = 0; b < S; b++)
@@ -347,6 +359,7 @@ static int backward_pass(ddp_t * d)
         for(int k = 0; k < S; k++) s += Fu[k * M + r] * T2[k * M + q];
         QuuF[r * m + q] = s;
       }
+    for(int r = 0; r < m; r++) QuuF[r * m + r] += lambda_q;
     for(int r = 0; r < M; r++) ki[r] = 0;
     for(int a = 0; a < M * S; a++) Ki[a] = 0;
     int nf = 0;
@@ -590,6 +603,9 @@ int oracle_ddp_solve(const oracle_ddp_problem_t * p, const oracle_ddp_config_t *
       actual = d.cost - d.costc;
       double expected = -alpha * (d.dV[0] + alpha * d.dV[1]);
       double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
+      if(oracle_ddp_trace)
+        fprintf(stderr, "  iter %d alpha %.4f cost %.6g -> %.6g expected %.4g ratio %.4g lambda %.3g\n", iter, alpha,
+                d.cost, d.costc, expected, ratio, d.lambda);
       if(ratio > c->cost_update_ratio_thre)
       {
         accepted = 1;

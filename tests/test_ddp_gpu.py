@@ -54,6 +54,18 @@ def test_centroidal_parity_with_oracle(max_iter):
     _assert_bitwise(r, o, ("u", "x", "cost", "iters", "status"))
 
 
+def test_parity_with_the_other_regularisation():
+    """ccc_ddp_config_t::reg_type = 2 (lambda added to Vxx instead of Quu): both branches of the kernel are bit-identical
+    to the oracle's."""
+    N, dt = 60, 0.03
+    prob, x0 = fd.make_centroidal_batch(64, N, dt, seed=11)
+    o = _oracle().Ddp(0, 100.0, dt, N, fd.centroidal_weights(), max_iter=12)
+    o.cfg.reg_type = 2
+    d = _cen(N, dt, 12)
+    d.ddp_solver_.config().reg_type = 2
+    _assert_bitwise(d.planOnceBatch(prob, x0), o.plan_batch(prob, x0, nthreads=8))
+
+
 def test_srb_parity_with_oracle_config5_shape():
     """BASELINE.json configs[4] shape: 12-state SRB, horizon 50 (fp64 here)."""
     N, dt = 50, 0.03
@@ -114,9 +126,72 @@ def test_centroidal_reference_closed_loop_through_planonce():
         t += 0.005
         sim.update(force, moment)
         if 1.0 <= t < 1.005:
-            sim.addDisturb(np.zeros(3), (0.05, 0.05, 0.0))
+            sim.addDisturb((0.05, 0.05, 0.0), np.zeros(3))
     r = ref(t).pos
     assert np.linalg.norm(sim.pos - r) < 0.1 and np.linalg.norm(sim.vel) < 0.1 and np.linalg.norm(sim.ang_mom) < 0.01
+
+
+def test_srb_reference_closed_loop_through_planonce():
+    """TestDdpSingleRigidBody.cpp:15-195 AS WRITTEN through planOnce on the GPU: cold start with the default budget,
+    then the unshifted warm start with the dims reset (:118-127) and max_iter = 1 per cycle (:125), the ZYX/XYZ
+    reversal of the orientation (:115,:112), the linear kick at t = 1 s (:24-25), per-cycle assertions :150-153 and
+    final ones :172-175.  The GPU plans are also compared with the oracle's in the same loop: bit-identical force
+    scales every cycle (the kernel reproduces the oracle's iterates, so the chaotic loop follows the same path)."""
+    N, dt, mass = 100, 0.03, 100.0
+    inertia = np.diag([40.0, 20.0, 10.0])
+    d = _srb(N, dt, 500)
+    orc = {}
+    V0, R0 = fd.contact_from_rect((-0.1, -0.5), (0.1, 0.5))
+    V2, R2 = fd.contact_from_rect((0.4, -0.5), (0.6, 0.5))
+
+    def motion(t):
+        ph, _ = fd.reference_schedule(t)
+        return DdpSingleRigidBody.MotionParam([(V0, R0)] if ph == 0 else ([] if ph == 1 else [(V2, R2)]), inertia)
+
+    def ref(t):
+        return DdpSingleRigidBody.RefData(fd.reference_schedule(t)[1], fd.srb_ori_ref(t))
+
+    sim = fd.CentroidalSim(mass, (40.0, 20.0, 10.0), 0.005)
+    sim.pos = ref(0.0).pos.copy()
+    sim.ori = ref(0.0).ori[::-1].copy()
+    t, cycle = 0.0, 0
+    while t < 3.0:
+        ip = DdpSingleRigidBody.InitialParam(sim.pos, sim.ori[::-1], sim.vel, sim.ang_vel,
+                                             d.ddp_solver_.controlData().u_list)
+        if ip.u_list:
+            for i in range(N):
+                mi = sum(len(c[0]) for c in motion(t + i * dt).contact_list)
+                if len(ip.u_list[i]) != mi:
+                    ip.u_list[i] = np.zeros(mi)
+        max_iter = d.ddp_solver_.config().max_iter
+        scales = d.planOnce(motion, ref, ip, t)
+        if cycle % 25 == 0:  # the oracle on the same inputs
+            prob = d._sample(motion, ref, t)
+            u_init = None
+            if ip.u_list:
+                u_init = np.zeros((1, N, 16))
+                for i, ui in enumerate(ip.u_list):
+                    u_init[0, i, :len(ui)] = ui
+            o = orc.setdefault(max_iter, _oracle().Ddp(1, mass, dt, N, fd.srb_weights(), max_iter=max_iter))
+            ou = o.plan_batch(prob, ip.toState()[None], u_init)["u"][0, 0, :len(scales)]
+            assert np.array_equal(ou, scales), (cycle, np.abs(ou - scales).max())
+        d.ddp_solver_.config().max_iter = 1
+        mp = motion(t)
+        if mp.contact_list:
+            moment, force = fd.total_wrench(mp.contact_list[0][0], mp.contact_list[0][1], scales, sim.pos)
+        else:
+            moment, force = np.zeros(3), np.zeros(3)
+        r = ref(t)
+        assert np.linalg.norm(sim.pos - r.pos) < 2.0 and np.linalg.norm(sim.ori - r.ori) < 1.0
+        assert np.linalg.norm(sim.vel) < 2.0 and np.linalg.norm(sim.ang_vel) < 2.0
+        t += 0.005
+        sim.update(force, moment)
+        if 1.0 <= t < 1.005:
+            sim.addDisturb((0.05, 0.05, 0.0), np.zeros(3))
+        cycle += 1
+    r = ref(t)
+    assert np.linalg.norm(sim.pos - r.pos) < 0.1 and np.linalg.norm(sim.ori - r.ori) < 0.1
+    assert np.linalg.norm(sim.vel) < 0.1 and np.linalg.norm(sim.ang_vel) < 0.1
 
 
 def test_device_entry_and_determinism():

@@ -128,24 +128,71 @@ def test_centroidal_reference_closed_loop_properties():
     assert np.linalg.norm(fin["vel"]) < 0.1 and np.linalg.norm(fin["ang_mom"]) < 0.01
 
 
-def test_srb_reference_closed_loop_properties():
-    """TestDdpSingleRigidBody.cpp:15-195 on the oracle: per cycle pos < 2, ori < 1, v < 2, w < 2; final all < 0.1.
-
-    One deviation from the reference protocol: 2 DDP iterations per warm-started control cycle instead of 1
-    (TestDdpSingleRigidBody.cpp:125).  nmpc_ddp's exact iterates are not reproducible here (parity unpinned); with the
-    algorithm frozen in oracle/ddp.c a single iteration per cycle sits on the edge of stability when the flight phase
-    enters the horizon (the open-loop rollout of the unshifted warm start diverges) -- a last-ulp change in sin/cos
-    flips the outcome -- whereas 2 iterations meet every assertion with a wide margin (final errors < 0.03)."""
+def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1):
     N, dt = 100, 0.03
     solvers = {}
+    rng = np.random.default_rng(perturb_seed)
 
     def plan(prob, x0, u_init, max_iter):
-        d = solvers.setdefault(max_iter, oracle.Ddp(1, 100.0, dt, N, fd.srb_weights(), max_iter=max_iter))
+        d = solvers.get(max_iter)
+        if d is None:
+            d = solvers[max_iter] = oracle.Ddp(1, 100.0, dt, N, fd.srb_weights(), max_iter=max_iter)
+            d.cfg.reg_type = reg_type
+        if perturb_seed:
+            x0 = x0 + 1e-10 * rng.standard_normal(x0.shape)
         return d.plan_batch(prob, x0, u_init)["u"]
 
-    log, fin = fd.run_closed_loop_ddp(plan, srb=True, warm_max_iter=2)
-    for rec in log:
-        assert np.linalg.norm(rec["pos"] - rec["ref"]) < 2.0 and np.linalg.norm(rec["ori"] - rec["ori_ref"]) < 1.0
-        assert np.linalg.norm(rec["vel"]) < 2.0 and np.linalg.norm(rec["ang_vel"]) < 2.0
-    assert np.linalg.norm(fin["pos"] - fin["ref"]) < 0.1 and np.linalg.norm(fin["ori"] - fin["ori_ref"]) < 0.1
-    assert np.linalg.norm(fin["vel"]) < 0.1 and np.linalg.norm(fin["ang_vel"]) < 0.1
+    return fd.run_closed_loop_ddp(plan, srb=True, warm_max_iter=warm_max_iter)
+
+
+def _srb_assertions_hold(log, fin):
+    ok = True
+    for rec in log:  # TestDdpSingleRigidBody.cpp:150-153 (the orientation check compares unreversed vectors, as there)
+        ok &= np.linalg.norm(rec["pos"] - rec["ref"]) < 2.0 and np.linalg.norm(rec["ori"] - rec["ori_ref_zyx"]) < 1.0
+        ok &= np.linalg.norm(rec["vel"]) < 2.0 and np.linalg.norm(rec["ang_vel"]) < 2.0
+    ok &= np.linalg.norm(fin["pos"] - fin["ref"]) < 0.1 and np.linalg.norm(fin["ori"] - fin["ori_ref_zyx"]) < 0.1
+    ok &= np.linalg.norm(fin["vel"]) < 0.1 and np.linalg.norm(fin["ang_vel"]) < 0.1
+    return bool(ok)
+
+
+def test_srb_reference_closed_loop_properties():
+    """TestDdpSingleRigidBody.cpp:15-195 on the oracle AS WRITTEN: cold start with the default iteration budget, then
+    unshifted warm start (dims reset :118-127) and max_iter = 1 per control cycle (:125), linear kick of 0.05 m/s in x
+    and y at t = 1 s (:24-25, sva::ForceVecd(couple, force)), per-cycle assertions :150-153, final ones :172-175."""
+    log, fin = _srb_closed_loop()
+    assert len(log) in (600, 601)
+    assert _srb_assertions_hold(log, fin)
+    assert np.linalg.norm(fin["pos"] - fin["ref"]) < 0.01 and np.linalg.norm(fin["vel"]) < 0.02  # measured 0.003 / 0.008
+
+
+def test_srb_cold_solve_needs_the_quu_regularisation():
+    """The solver-internal the reference scenario discriminates: the cold solve of cycle 0 (u = 0: the nominal
+    trajectory is a 3 s free fall) over 16 starts that differ by 1e-10.  With lambda added to Quu (reg_type 1) a
+    failed line search shrinks the step towards plain gradient descent and the solve converges to the optimum
+    (cost 4.756); with lambda added to Vxx (reg_type 2, what round 1 had frozen) it makes the feedback stiffer, the
+    clamped rollouts keep diverging and lambda runs into lambda_max (status -1, cost > 1000)."""
+    N, dt, n = 100, 0.03, 16
+    prob = fd.reference_problem(0.0, N, dt, 4, 16, (0.1, 0.5), True, np.diag([40.0, 20.0, 10.0]), fd.srb_ori_ref)
+    probs = {k: np.repeat(v, n, axis=0) for k, v in prob.items()}
+    x0 = np.tile(np.array([0, 0, 1.0] + [0.0] * 9), (n, 1))
+    x0[1:] += 1e-10 * np.random.default_rng(1).standard_normal((n - 1, 12))
+    conv = {}
+    for reg in (1, 2):
+        d = oracle.Ddp(1, 100.0, dt, N, fd.srb_weights(), max_iter=500)
+        d.cfg.reg_type = reg
+        r = d.plan_batch(probs, x0, nthreads=8)
+        conv[reg] = int(np.sum((r["status"] >= 1) & (r["cost"] < 4.76)))
+    assert conv[1] >= 13 and conv[2] <= 5, conv  # measured 15 / 2 of 16 (29 / 3 of 32)
+
+
+def test_srb_closed_loop_margin_under_perturbation():
+    """How much margin the protocol of test_srb_reference_closed_loop_properties has: the same loop with every planner
+    input x0 perturbed by 1e-10.  One iteration per cycle on an UNSHIFTED warm start has to re-plan the 0.2 s flight as
+    6 or 7 horizon steps every few cycles; the open-loop rollout of the stale plan tumbles in pitch (through the
+    Euler-angle singularity of src/DdpSingleRigidBody.cpp:26-38), the near-deadbeat gains (force weight 1e-6) along it
+    are of order 1e4..1e6, the clamped line-search candidates overflow and only alpha <= 0.06 is accepted -- the loop
+    is chaotic under ANY of the solver variants tried (regularisation form, box-QP iteration limit and warm start,
+    1 / 2 / 3 iterations per cycle: 17..29 of 32 perturbed runs meet every assertion, never all).
+    Pinned here: the unperturbed run passes (above) and at least half of the perturbed ones do."""
+    passed = sum(_srb_assertions_hold(*_srb_closed_loop(seed)) for seed in range(1, 9))
+    assert passed >= 4, passed  # measured 5 of 8 (20 of 32)

@@ -73,7 +73,8 @@ def test_converged_solution_is_stationary():
             up[i, j] += h
             um[i, j] -= h
             g = (total(k, up) - total(k, um)) / (2 * h)
-            assert abs(g) < (2e-4 if j < 2 else 2e-6), (k, i, j, g)
+            # termination test: max |k| / (|u| + 1) < 1e-4 (k_rel_norm_thre) with u_z ~ 1e3 and Quu_zz ~ 1e-4..1e-3
+            assert abs(g) < (2e-4 if j < 2 else 1e-4), (k, i, j, g)
 
 
 def test_reference_closed_loop():
