@@ -91,6 +91,14 @@ def load():
         raise ImportError(
             "libccc_amd.so not found at %s: build it with `python -m centroidalcontrolcollection_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    if "CCC_AMD_LIB" not in os.environ and _build.is_stale():
+        # a library built from other sources than the tree's would be tested silently: rebuild it (hipcc cross-compiles
+        # anywhere this image runs) or fail loudly
+        try:
+            _build.build_lib(force=True)
+        except Exception as e:
+            raise ImportError("libccc_amd.so at %s was not built from the sources in this tree and rebuilding it "
+                              "failed (%s); run `python -m centroidalcontrolcollection_amd.build`" % (path, e))
     try:
         # torch bundles its own libamdhip64.so.7; importing it first makes both share one HIP runtime
         import torch  # noqa: F401

@@ -15,17 +15,37 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
+HASH_PATH = LIB_PATH + ".srchash"
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
+def source_hash():
+    """sha256 over everything the library is compiled from (file names + contents) and the compiler flags."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(
+        glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def is_stale():
+    """True when libccc_amd.so is missing or was not built from the sources in the tree (content hash recorded by
+    build_lib next to the library; mtimes do not survive the copy to the GPU box)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
-        os.path.join(_HERE, "..", "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(HASH_PATH) as f:
+        return f.read().strip() != source_hash()
+
+
+_stale = is_stale
 
 
 def build_lib(force=False, verbose=False):
@@ -37,6 +57,8 @@ def build_lib(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(HASH_PATH, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB_PATH
 
 

@@ -25,15 +25,49 @@ inline int fail(int code, const char * fmt, ...)
   return code;
 }
 
-// Select `device` after checking that it exists and is a gfx950 part: the product path has no CPU
-// (or other-arch) fallback and must fail loudly instead.
+// Check that `device` exists and is a gfx950 part: the product path has no CPU (or other-arch) fallback and must fail
+// loudly instead.  Does NOT change the calling thread's current device (see DeviceGuard).
 int select_device(int device);
+
+// Every C-ABI entry point works on its handle's device and restores the caller's current HIP device on return (a host
+// that drives several GPUs from one thread -- or torch, which reads the runtime's current device -- must not find it
+// switched behind its back).
+struct DeviceGuard
+{
+  int prev = -1, target = -1;
+  bool ok = false;
+  explicit DeviceGuard(int device) : target(device)
+  {
+    ok = hipGetDevice(&prev) == hipSuccess && (prev == device || hipSetDevice(device) == hipSuccess);
+  }
+  ~DeviceGuard()
+  {
+    if(prev >= 0 && prev != target) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard & operator=(const DeviceGuard &) = delete;
+};
 
 // Zero `words` 32-bit words at `p` on `stream` with a kernel of the library's own.  The per-launch counters (work-list
 // lengths, tickets) are reset with this rather than hipMemsetAsync: captured in a hipGraph, a 4-byte memset node
 // followed a foreign kernel with a memory access fault on replay (ROCm 7.2; tests/test_graph_capture_gpu.py).
 int zero_words(void * p, int words, void * stream);
+
+// The `_device` entry points are asynchronous and graph-capturable EXCEPT when a handle's workspace has to grow (a batch
+// larger than any seen before): hipMalloc / hipFree synchronise the device and invalidate an active capture.  Growth
+// during a capture is refused with CCC_ERR_INVALID_ARGUMENT instead (call once eagerly with the largest batch first).
+int refuse_growth_in_capture(void * stream, const char * who);
 } // namespace ccc_amd
+
+#define CCC_DEVICE_GUARD(device)                                                                   \
+  ccc_amd::DeviceGuard ccc_device_guard__(device);                                                 \
+  if(!ccc_device_guard__.ok) return ccc_amd::fail(CCC_ERR_HIP, "cannot select HIP device %d", (int)(device))
+
+#define CCC_NO_CAPTURE(stream, who)                                                      \
+  do                                                                                     \
+  {                                                                                      \
+    if(int rc__ = ccc_amd::refuse_growth_in_capture((void *)(stream), who)) return rc__; \
+  } while(0)
 
 #define CCC_HIP_CHECK(expr)                                                                              \
   do                                                                                                     \

@@ -26,6 +26,18 @@ int zero_words(void * p, int words, void * stream)
   return CCC_OK;
 }
 
+int refuse_growth_in_capture(void * stream, const char * who)
+{
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if(stream && hipStreamIsCapturing(reinterpret_cast<hipStream_t>(stream), &st) == hipSuccess &&
+     st != hipStreamCaptureStatusNone)
+    return fail(CCC_ERR_INVALID_ARGUMENT,
+                "%s: the workspace has to grow for this batch size, which cannot happen inside a stream capture; "
+                "call once eagerly with the largest batch before capturing",
+                who);
+  return CCC_OK;
+}
+
 int select_device(int device)
 {
   int count = 0;
@@ -40,7 +52,6 @@ int select_device(int device)
   if(std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(CCC_ERR_NO_DEVICE, "device %d is %s; libccc_amd is built for gfx950 (MI355X) only", device,
                 prop.gcnArchName);
-  CCC_HIP_CHECK(hipSetDevice(device));
   return CCC_OK;
 }
 } // namespace ccc_amd

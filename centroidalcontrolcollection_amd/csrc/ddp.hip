@@ -110,6 +110,7 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: mass, horizon_dt, horizon_steps, max_phases must be > 0");
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_ddp * h = new ccc_ddp();
   h->device = device;
   h->prm = *p;
@@ -140,7 +141,7 @@ static void free_ws(ccc_ddp * h)
 extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   free_ws(h);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -161,9 +162,10 @@ extern "C" int ccc_ddp_state_dim(const ccc_ddp_t * h)
   return h ? h->S : -1;
 }
 
-static int ensure_ws(ccc_ddp * h, int64_t n)
+static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
 {
   if(n <= h->cap) return CCC_OK;
+  CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
   free_ws(h);
   const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES;
   CCC_HIP_CHECK(hipMalloc(&h->ws_x, (size_t)n * (N + 1) * S * sizeof(double)));
@@ -189,8 +191,8 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: NULL required array");
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
-  int rc = ensure_ws(h, n);
+  CCC_DEVICE_GUARD(h->device);
+  int rc = ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp::Params P;
   std::memset(&P, 0, sizeof(P));
@@ -244,7 +246,7 @@ extern "C" int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phas
   if(n == 0) return CCC_OK;
   if(!phase_dim || !phase_vertex || !phase_ridge || !step_phase || !ref_pos || !x0 || !u_out)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch: NULL required array");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES, Pn = h->prm.max_phases;
   if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // one staging allocation, carved into the arrays (all sizes are multiples of 4 bytes; doubles first)

@@ -963,6 +963,7 @@ extern "C" int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_ste
     return fail(CCC_ERR_UNSUPPORTED, "ccc_ddpzmp_create: horizon_steps %d > 4096", horizon_steps);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_ddpzmp * h = new ccc_ddpzmp();
   h->device = device;
   h->P.N = horizon_steps;
@@ -984,7 +985,7 @@ extern "C" int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_ste
 extern "C" void ccc_ddpzmp_destroy(ccc_ddpzmp_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->ws) (void)hipFree(h->ws);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -1014,9 +1015,10 @@ extern "C" int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const d
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_plan_batch_device: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!ref || !x0 || !u_out) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_plan_batch_device: NULL ref/x0/u_out");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   if(n > h->ws_cap) // the workspace grows to the largest batch seen (synchronously: not inside a captured stream)
   {
+    CCC_NO_CAPTURE(stream, "ccc_ddpzmp device entry");
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;
@@ -1039,7 +1041,7 @@ extern "C" int ccc_ddpzmp_plan_batch(ccc_ddpzmp_t * h, int64_t n, const double *
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_plan_batch: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!ref || !x0 || !u_out) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_plan_batch: NULL ref/x0/u_out");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   const size_t N = (size_t)h->P.N;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t b_ref = (size_t)n * (N + 1) * 4 * 8, b_x0 = (size_t)n * 6 * 8, b_u = (size_t)n * N * 3 * 8,
@@ -1087,9 +1089,10 @@ extern "C" int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K,
   if(!knot_t || !knot_zmp || !state) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: NULL argument");
   if(n_disturb < 0 || n_disturb > 8 || (n_disturb > 0 && !disturb_times))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_closed_loop_device: 0 <= n_disturb <= 8 (HOST array of times)");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   if(n > h->ws_cap)
   {
+    CCC_NO_CAPTURE(stream, "ccc_ddpzmp device entry");
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;

@@ -735,6 +735,7 @@ extern "C" int ccc_ism_create(double com_height, double horizon_duration, double
                 kIsmNP - 1);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_ism * h = new ccc_ism();
   h->device = device;
   h->N = N;
@@ -764,7 +765,7 @@ extern "C" int ccc_ism_create(double com_height, double horizon_duration, double
 extern "C" void ccc_ism_destroy(ccc_ism_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dWc) (void)hipFree(h->dWc);
   if(h->dAt) (void)hipFree(h->dAt);
@@ -788,11 +789,12 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch_device: NULL init/ref/zmp");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   const int64_t nqp = 2 * n;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if(nqp > h->redo_cap) // (synchronous: not inside a captured stream)
   {
+    CCC_NO_CAPTURE(stream, "ccc_ism_plan_batch_device");
     if(h->redo) CCC_HIP_CHECK(hipFree(h->redo));
     h->redo = nullptr;
     h->redo_cap = 0;
@@ -848,7 +850,7 @@ extern "C" int ccc_ism_plan_batch(ccc_ism_t * h, int64_t n, const double * init,
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!init || !ref || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ism_plan_batch: NULL init/ref/zmp");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   const size_t N = (size_t)h->N;
   const size_t ni = (size_t)n * 4, nr = (size_t)n * 6 * N, nz = (size_t)n * 2, nv = (size_t)n * 2 * N;
   if(n > h->cap)

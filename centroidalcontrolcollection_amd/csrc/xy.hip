@@ -1193,6 +1193,7 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
                 p->horizon_steps, CCC_XY_MAX_STEPS);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_xy * h = new ccc_xy();
   h->device = device;
   h->prm = *p;
@@ -1204,9 +1205,14 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
     return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
   h->num_cu = prop.multiProcessorCount;
-  CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  CCC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-  CCC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if(e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+  if(e != hipSuccess)
+  {
+    ccc_xy_destroy(h); // frees whatever was created
+    return fail(CCC_ERR_HIP, "ccc_xy_create: stream / event creation failed: %s", hipGetErrorString(e));
+  }
   h->blocks = h->num_cu * 2; // two resident workgroups per CU (7 + 7 wavefronts of <= 128 VGPRs)
   *out = h;
   return CCC_OK;
@@ -1215,7 +1221,7 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
 extern "C" void ccc_xy_destroy(ccc_xy_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->ws) (void)hipFree(h->ws);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -1235,7 +1241,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   if(n == 0) return CCC_OK;
   if(!dim || !vertex || !ridge || !com_z || !total_force_z || !ref_out || !x0 || !u0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_plan_batch_device: NULL required array");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   XyParams P;
   P.N = h->prm.horizon_steps;
   P.mass = h->prm.mass;
@@ -1262,6 +1268,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
                o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
+    CCC_NO_CAPTURE(stream, "ccc_xy_plan_batch_device");
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;
@@ -1356,7 +1363,7 @@ extern "C" int ccc_xy_plan_batch(ccc_xy_t * h, int64_t n, const int32_t * dim, c
   if(n == 0) return CCC_OK;
   if(!dim || !vertex || !ridge || !com_z || !total_force_z || !ref_out || !x0 || !u0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_plan_batch: NULL required array");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t N = h->prm.horizon_steps, M = kXyM;
   struct Seg

@@ -595,6 +595,7 @@ extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, d
                 horizon_steps, kZNP);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_z * h = new ccc_z();
   h->device = device;
   h->N = horizon_steps;
@@ -617,7 +618,7 @@ extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, d
 extern "C" void ccc_z_destroy(ccc_z_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->ws) (void)hipFree(h->ws);
   if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -633,7 +634,7 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   if(n == 0) return CCC_OK;
   if(!contact || !ref_pos || !x0 || !force)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch_device: NULL contact/ref_pos/x0/force");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   ZParams P{h->N, h->mass, h->dt, h->w_pos, h->w_force, 10.0, 10.0 * h->mass * kZG}; // src/LinearMpcZ.cpp:37
   ZBatch B{contact, ref_pos, x0, force, force_all, status};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -644,6 +645,7 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
                total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
+    CCC_NO_CAPTURE(stream, "ccc_z_plan_batch_device");
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;
@@ -693,7 +695,7 @@ extern "C" int ccc_z_plan_batch(ccc_z_t * h, int64_t n, const int32_t * contact,
   if(n == 0) return CCC_OK;
   if(!contact || !ref_pos || !x0 || !force)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_z_plan_batch: NULL contact/ref_pos/x0/force");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   const size_t N = (size_t)h->N;
   const size_t bc = (size_t)n * N * 4, br = (size_t)n * N * 8, bx = (size_t)n * 16, bf = (size_t)n * 8, bs = (size_t)n * 4;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };

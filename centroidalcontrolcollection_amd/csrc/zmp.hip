@@ -1368,6 +1368,9 @@ struct ccc_zmp
   unsigned long long * queue = nullptr; // work-queue ticket counter of zmp_plan_kernel_dyn
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
   int num_cu = 0;
+  // per-handle (= per-device) launch state: function attributes set, resident workgroups per CU of the queue kernel
+  bool attr_set = false, attr_dyn = false;
+  int per_cu = 0;
   // staging for the host-pointer entry point
   int64_t cap = 0;
   double *h_in = nullptr, *h_out = nullptr; // pinned
@@ -1440,12 +1443,11 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
 {
   constexpr int QPW = 64 / LG;
   const size_t lds = ((size_t)LG * LG + 4 * LG + (size_t)WAVES * QPW * ZmpScratch<LG>::kSize) * sizeof(double);
-  static bool attr_set = false;
-  if(!attr_set)
+  if(!h->attr_set)
   {
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_kernel<LG, WAVES>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    h->attr_set = true;
   }
   const int64_t nqp = 2 * n;
   const int64_t ntask = (nqp + QPW - 1) / QPW;
@@ -1459,17 +1461,20 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   const bool use_queue = !std::getenv("CCC_ZMP_STATIC") && nqp >= (int64_t)6 * h->num_cu * 12 * QPW;
   if(use_queue)
   {
-    static bool attr_dyn = false;
-    if(!attr_dyn)
+    if(!h->attr_dyn)
     {
       CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&zmp_plan_kernel_dyn<LG, WAVES>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_dyn = true;
+      h->attr_dyn = true;
     }
     const size_t qbytes = (size_t)kQueues * kQueueStride * sizeof(unsigned long long);
-    if(!h->queue) CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
+    if(!h->queue)
+    {
+      CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
+      CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
+    }
     if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream)) return zrc;
-    static int per_cu = 0; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
+    int & per_cu = h->per_cu; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
     if(per_cu == 0)
     {
       int nb = 0;
@@ -1496,7 +1501,11 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   if(h->N > 200) // beyond the LDS: the tableau in HBM
   {
     const int blocks = h->num_cu * 2;
-    if(!h->ws_big) CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
+    if(!h->ws_big)
+    {
+      CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
+      CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
+    }
     const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     const int grid = (int)std::min<int64_t>(nqp, blocks);
     hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
@@ -1559,6 +1568,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
     return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > %d is not built into this library", N, kBigNP);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
+  CCC_DEVICE_GUARD(device);
   ccc_zmp * h = new ccc_zmp();
   h->device = device;
   h->N = N;
@@ -1588,7 +1598,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
 extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
 {
   if(!h) return;
-  (void)hipSetDevice(h->device);
+  ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->queue) (void)hipFree(h->queue);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
@@ -1633,7 +1643,7 @@ extern "C" int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double 
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_plan_batch_device: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!x0 || !zlim || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_plan_batch_device: NULL x0/zlim/zmp");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if(h->NP == 32) return launch<32, 2>(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
   return launch_block(h, n, x0, zlim, control_dt, zmp, jerk, status, s);
@@ -1671,7 +1681,7 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
   if(n < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_plan_batch: n = %lld < 0", (long long)n);
   if(n == 0) return CCC_OK;
   if(!x0 || !zlim || !zmp) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_plan_batch: NULL x0/zlim/zmp");
-  CCC_HIP_CHECK(hipSetDevice(h->device));
+  CCC_DEVICE_GUARD(h->device);
   int rc = ensure_staging(h, n);
   if(rc != CCC_OK) return rc;
   const int N = h->N;

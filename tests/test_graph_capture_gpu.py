@@ -152,3 +152,26 @@ def test_ddp_classes_graph_replay():
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), c.planOnceBatch(prob, x)["u"])
+
+
+def test_workspace_growth_inside_a_capture_is_refused():
+    """A batch larger than any the handle has seen needs hipMalloc / hipFree, which would invalidate the capture: the
+    entry point returns CCC_ERR_INVALID_ARGUMENT instead (and the capture itself survives)."""
+    import torch
+
+    from centroidalcontrolcollection_amd import _lib
+
+    dev = torch.device("cuda:0")
+    n, N = 300, 40
+    mpc = LinearMpcZ(100.0, 0.05, N)
+    b = fx.make_z_batch(n, N, 0.05, seed=9)
+    contact = torch.from_numpy(b["contact"]).to(dev)
+    ref = torch.from_numpy(b["ref_pos"]).to(dev)
+    x0 = torch.from_numpy(b["x0"]).to(dev)
+    force = torch.zeros(n, dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.CccError) as err:
+        with torch.cuda.graph(g, stream=s):
+            mpc.plan_batch_device(contact, ref, x0, force, stream=torch.cuda.current_stream())
+    assert err.value.code == _lib.CCC_ERR_INVALID_ARGUMENT and "capture" in str(err.value)
