@@ -106,7 +106,21 @@ int main(int argc, char ** argv)
                         && sy[0] >= lim.zmp_limits[0].y() && sy[0] <= lim.zmp_limits[1].y();
     std::printf("horizon_steps=%d cycles=%d violations=%d final_com=%.9f %.9f com_inside=%d\n", mpc.horizonSteps(),
                 cycles, violations, sx[0], sy[0], (int)com_ok);
-    return (violations == 0 && com_ok) ? 0 : 1;
+    // CCC::LinearMpcZmp1d (LinearMpcZmp.h:20-90) with an explicit QP solver type: the x axis of a 2-d plan
+    CCC::LinearMpcZmp1d mpc1d(com_height, horizon_duration, horizon_dt, QpSolverCollection::QpSolverType::QLD);
+    auto ref1d = [&](double tt) {
+      CCC::LinearMpcZmp1d::RefData rd;
+      const auto r2 = ref_func(tt);
+      rd.zmp_limits = {r2.zmp_limits[0].x(), r2.zmp_limits[1].x()};
+      return rd;
+    };
+    CCC::LinearMpcZmp::InitialParam ip2;
+    ip2.pos = CCC::Vector2d(0.01, -0.02);
+    ip2.vel = CCC::Vector2d(0.03, 0.01);
+    const CCC::Vector2d z2 = mpc.planOnce(ref_func, ip2, 2.3, sim_dt);
+    const double z1 = mpc1d.planOnce(ref1d, CCC::Vector3d(0.01, 0.03, 0.0), 2.3, sim_dt);
+    std::printf("1d_matches_2d=%d\n", (int)(z1 == z2.x()));
+    return (violations == 0 && com_ok && z1 == z2.x()) ? 0 : 1;
   }
   catch(const std::exception & e)
   {

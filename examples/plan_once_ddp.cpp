@@ -21,6 +21,7 @@ int main()
       w.terminal_pos = CCC::Vector3d(1.0, 1.0, 10.0);
       CCC::DdpCentroidal ddp(mass, dt, N, w);
       ddp.ddp_solver_->config().max_iter = 20;
+      if(ddp.ddp_solver_->config().horizon_steps != N || !ddp.ddp_solver_->config().with_input_constraint) return 3;
       auto motion = [&](double t) {
         t += 1e-6;
         CCC::DdpCentroidal::MotionParam mp;

@@ -32,6 +32,20 @@ int main()
     const auto all = mpc.planOnceBatch(rf, ips, {times[0], times[1], times[2]}, 0.005);
     for(size_t k = 0; k < all.size(); k++) std::printf("batch[%zu] zmp= %.17g %.17g\n", k, all[k].x(), all[k].y());
     std::printf("horizon_steps=%d\n", mpc.horizonSteps());
+    // the one-dimensional class of the reference (IntrinsicallyStableMpc.h:17-120) with an explicit QP solver type, as
+    // reference code writes it: the x axis of the plan above
+    CCC::IntrinsicallyStableMpc1d mpc1d(1.0, 2.0, 0.02, QpSolverCollection::QpSolverType::QLD);
+    auto ref1d = [&](double t) {
+      CCC::IntrinsicallyStableMpc1d::RefData rd;
+      const auto r2 = ref(t);
+      rd.zmp = r2.zmp.x();
+      rd.zmp_limits = {r2.zmp_limits[0].x(), r2.zmp_limits[1].x()};
+      return rd;
+    };
+    CCC::IntrinsicallyStableMpc1d::InitialParam ip1d;
+    ip1d.capture_point = ip.capture_point.x();
+    ip1d.planned_zmp = ip.planned_zmp.x();
+    std::printf("1d zmp= %.17g status=%d\n", mpc1d.planOnce(ref1d, ip1d, 0.0, 0.005), (int)CCC_STATUS_CODE(mpc1d.lastStatus()));
     return 0;
   }
   catch(const std::exception & e)

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -23,6 +24,16 @@ namespace ddp_shim
 struct TraceData
 {
   int iter = 0;
+  int status = 0; //!< 0 max_iter reached, 1 gradient small, 2 cost change small, -1 lambda exceeded lambda_max (new)
+};
+
+/** nmpc_ddp::DDPSolver::Configuration as the reference's callers see it: the solver parameters of ccc_ddp_config_t plus
+    the two fields the CCC constructors set / the tests read (src/DdpCentroidal.cpp:197-198,
+    tests/src/TestDdpCentroidal.cpp:105).  with_input_constraint is always true for these planners. */
+struct Configuration : public ccc_ddp_config_t
+{
+  int horizon_steps = 0;
+  bool with_input_constraint = true;
 };
 
 struct ControlData
@@ -39,7 +50,7 @@ public:
   {
     ccc_ddp_default_config(&config_);
   }
-  ccc_ddp_config_t & config()
+  Configuration & config()
   {
     return config_;
   }
@@ -52,7 +63,7 @@ public:
     return trace_data_list_;
   }
 
-  ccc_ddp_config_t config_;
+  Configuration config_;
   ControlData control_data_;
   std::vector<TraceData> trace_data_list_;
 };
@@ -168,7 +179,15 @@ inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool sr
     for(int a = 0; a < S; a++) solver.control_data_.x_list[static_cast<size_t>(i)][static_cast<size_t>(a)] = x[static_cast<size_t>(i) * S + a];
   TraceData td;
   td.iter = iters;
+  td.status = status;
   solver.trace_data_list_.assign(1, td);
+  if(status < 0)
+  {
+    // nmpc_ddp prints "[DDP] Failure: lambda is too large" and keeps the last accepted sequence; same here
+    std::fprintf(stderr, "[%s] DDP did not converge: regularisation exceeded lambda_max after %d iteration(s); the "
+                         "returned plan is the last accepted input sequence.\n",
+                 who, iters);
+  }
   return solver.control_data_.u_list[0];
 }
 } // namespace ddp_shim

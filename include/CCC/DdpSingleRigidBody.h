@@ -124,6 +124,7 @@ public:
     ccc_ddp_t * h = nullptr;
     ddp_shim::check(ccc_ddp_create(&p, device, &h), "DdpSingleRigidBody");
     handle_.reset(h, ccc_ddp_destroy);
+    ddp_solver_->config().horizon_steps = horizon_steps; // src/DdpCentroidal.cpp:198
     ddp_solver_->config().max_iter = 500;
   }
 

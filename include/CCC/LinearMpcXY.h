@@ -18,6 +18,7 @@
 #include "../ccc_amd.h"
 
 #include "EigenLite.h"
+#include "ShimCommon.h"
 
 namespace CCC
 {
@@ -100,7 +101,7 @@ public:
               double horizon_dt,
               int horizon_steps,
               const WeightParam & weight_param = WeightParam(),
-              int qp_solver_type = 0,
+              QpSolverCollection::QpSolverType qp_solver_type = QpSolverCollection::QpSolverType::Any,
               int device = 0)
   : mass_(mass), horizon_dt_(horizon_dt), horizon_steps_(horizon_steps), weight_param_(weight_param)
   {
@@ -136,8 +137,11 @@ public:
     Flat f(1, horizon_steps_);
     const int m0 = sample(f, 0, motion_param_func, ref_data_func, initial_param, current_time);
     std::vector<double> u0(CCC_DDP_MAX_RIDGES);
+    last_status_.assign(1, 0);
     check(ccc_xy_plan_batch(handle_.get(), 1, f.dim.data(), f.vertex.data(), f.ridge.data(), f.com_z.data(),
-                            f.total_force_z.data(), f.ref_out.data(), f.x0.data(), u0.data(), nullptr, nullptr));
+                            f.total_force_z.data(), f.ref_out.data(), f.x0.data(), u0.data(), nullptr,
+                            last_status_.data()));
+    shim::reportStatus("LinearMpcXY", last_status_);
     VectorXd out(m0);
     for(int r = 0; r < m0; r++) out[r] = u0[static_cast<size_t>(r)];
     return out;
@@ -160,9 +164,11 @@ public:
     for(size_t k = 0; k < n; k++)
       m0[k] = sample(f, k, motion_param_funcs[k], ref_data_funcs[k], initial_params[k], current_times[k]);
     std::vector<double> u0(n * CCC_DDP_MAX_RIDGES);
+    last_status_.assign(n, 0);
     check(ccc_xy_plan_batch(handle_.get(), static_cast<int64_t>(n), f.dim.data(), f.vertex.data(), f.ridge.data(),
                             f.com_z.data(), f.total_force_z.data(), f.ref_out.data(), f.x0.data(), u0.data(), nullptr,
-                            nullptr));
+                            last_status_.data()));
+    shim::reportStatus("LinearMpcXY", last_status_);
     std::vector<VectorXd> out(n);
     for(size_t k = 0; k < n; k++)
     {
@@ -178,6 +184,12 @@ public:
     return handle_.get();
   }
 
+  /** \brief Solver status of the last call, one per instance: (pivots << 8) | CCC_STATUS_* (new). */
+  const std::vector<int32_t> & lastStatuses() const
+  {
+    return last_status_;
+  }
+
 public:
   //! Robot mass [kg]
   const double mass_ = 0;
@@ -190,6 +202,9 @@ public:
 
   //! Min/max scale of ridge force (src/LinearMpcXY.cpp:91)
   std::array<double, 2> force_range_ = {3.0, 0.0}; // upper = 3 m g, set in the constructor
+
+protected:
+  std::vector<int32_t> last_status_;
 
 protected:
   /** Flat arrays of ccc_xy_plan_batch for n instances. */

@@ -16,6 +16,7 @@
 #include "../ccc_amd.h"
 
 #include "EigenLite.h"
+#include "ShimCommon.h"
 
 namespace CCC
 {
@@ -50,7 +51,7 @@ public:
              double horizon_dt,
              int horizon_steps,
              const WeightParam & weight_param = WeightParam(),
-             int qp_solver_type = 0,
+             QpSolverCollection::QpSolverType qp_solver_type = QpSolverCollection::QpSolverType::Any,
              int device = 0)
   : mass_(mass), horizon_dt_(horizon_dt), horizon_steps_(horizon_steps), weight_param_(weight_param),
     force_range_(10.0, 10.0 * mass * 9.80665)
@@ -78,7 +79,9 @@ public:
     sample(contact_func, ref_pos_func, current_time, contact.data(), ref.data());
     const double x0[2] = {initial_param[0], initial_param[1]};
     double force = 0;
-    check(ccc_z_plan_batch(handle_.get(), 1, contact.data(), ref.data(), x0, &force, nullptr, nullptr));
+    last_status_.assign(1, 0);
+    check(ccc_z_plan_batch(handle_.get(), 1, contact.data(), ref.data(), x0, &force, nullptr, last_status_.data()));
+    shim::reportStatus("LinearMpcZ", last_status_);
     return force;
   }
 
@@ -101,8 +104,10 @@ public:
       x0[2 * k] = initial_params[k][0];
       x0[2 * k + 1] = initial_params[k][1];
     }
+    last_status_.assign(n, 0);
     check(ccc_z_plan_batch(handle_.get(), static_cast<int64_t>(n), contact.data(), ref.data(), x0.data(), force.data(),
-                           nullptr, nullptr));
+                           nullptr, last_status_.data()));
+    shim::reportStatus("LinearMpcZ", last_status_);
     return force;
   }
 
@@ -110,6 +115,12 @@ public:
   ccc_z_t * handle() const
   {
     return handle_.get();
+  }
+
+  /** \brief Solver status of the last call, one per instance: (pivots << 8) | CCC_STATUS_* (new). */
+  const std::vector<int32_t> & lastStatuses() const
+  {
+    return last_status_;
   }
 
 public:
@@ -145,5 +156,6 @@ protected:
 
 protected:
   std::shared_ptr<ccc_z_t> handle_;
+  std::vector<int32_t> last_status_;
 };
 } // namespace CCC

@@ -112,7 +112,10 @@ def test_cpp_header_shim_matches_python_mirror():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[-1] == "horizon_steps=100"
+    assert lines[-2] == "horizon_steps=100"
+    # CCC::IntrinsicallyStableMpc1d (QpSolverType::QLD passed as reference code does): the x axis of the first plan
+    assert lines[-1].startswith("1d zmp=") and lines[-1].endswith("status=0")
+    assert float(lines[-1].split()[2]) == float(lines[0].split("zmp=")[1].split()[0])
     mpc = IntrinsicallyStableMpc(1.0, 2.0, 0.02)
 
     def ref(t):

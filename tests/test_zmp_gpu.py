@@ -263,6 +263,7 @@ def test_cpp_header_shim_reference_scenario():
         out = subprocess.run([exe, dt], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         assert "horizon_steps=%d" % steps in out.stdout and "violations=0" in out.stdout and "com_inside=1" in out.stdout
+        assert "1d_matches_2d=1" in out.stdout  # CCC::LinearMpcZmp1d = one axis of CCC::LinearMpcZmp, bit for bit
     # same closed loop through the Python mirror: final CoM agrees (same kernels, same inputs)
     fin_cpp = [float(v) for v in subprocess.run([exe, "0.02"], capture_output=True, text=True).stdout.split("final_com=")[1].split()[:2]]
     assert np.abs(np.array(fin_cpp) - np.array([0.64215196, -0.05244137])).max() < 1e-6
