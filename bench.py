@@ -27,6 +27,10 @@ import torch  # noqa: E402
 
 ALGO_BYTES_PER_SOLVE = 1088  # 48 B state + 1024 B limits in, 16 B ZMP out
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector fp64 (256 CUs x 64 lanes x 2 flop x 2.4 GHz)
+# algorithmic fp64 work of one pivot of one QP: the symmetric rank-1 update of the 32 x 32 sweep
+# tableau = 32 x 32 FMAs = 2048 flop; the ratio test, reciprocal and selection are O(32) and not counted
+FLOP_PER_PIVOT = 2048
 
 
 def measured_traffic(n):
@@ -37,6 +41,19 @@ def measured_traffic(n):
         d = json.load(open(path))
         if d.get("algorithmic_bytes_per_launch") == ALGO_BYTES_PER_SOLVE * n:
             return d["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def valu_counters(n):
+    """VALU-issue share of the kernel from the PMC pass of the same launch (profiles/zmp_valu_counters.json, written by
+    scripts/summarize_prof.py from rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES ...); None if not collected for this batch."""
+    path = os.path.join(ROOT, "profiles", "zmp_valu_counters.json")
+    try:
+        d = json.load(open(path))
+        if d.get("batch") == n:
+            return d
     except Exception:
         pass
     return None
@@ -74,6 +91,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
+                         "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
     ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
@@ -117,7 +137,18 @@ def main():
 
     N, dt, n = 32, 0.0625, args.batch
     mpc = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
-    batch = fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + rank)
+    if args.scaling == "strong" and world > 1:
+        # one workload of --batch instances in total (seed of rank 0), contiguous shards (sharding.shard_bounds)
+        from centroidalcontrolcollection_amd import sharding
+
+        lo, hi = sharding.shard_bounds(args.batch, world)[rank]
+        full = fx.make_zmp_batch(args.batch, N, dt, 1.0, seed=20250928)
+        batch = {k: np.ascontiguousarray(v[lo:hi]) for k, v in full.items()}
+        n = hi - lo
+        if args.batch % world:
+            raise SystemExit("--scaling strong needs --batch divisible by the number of GPUs (all_gather_into_tensor)")
+    else:
+        batch = fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + rank)
     x0 = torch.from_numpy(batch["x0"]).to(dev)
     zlim = torch.from_numpy(batch["zlim"]).to(dev)
     # two output buffers: the all-gather of step k (RCCL's own stream) overlaps the kernel of step k + 1
@@ -178,19 +209,85 @@ def main():
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])  # HIP events on the launch stream
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
     # ccc_zmp_plan_batch (pinned staging, H2D, kernel, D2H); PCIe-inclusive, never the `value` above
-    h2h = []
+    # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the DMA engines read the inputs
+    # and write the ZMPs in place, chunked beside the kernel) and from pageable numpy arrays (one more host copy each way)
+    h2h, h2h_pageable = [], []
+    px0 = torch.from_numpy(batch["x0"]).pin_memory()
+    pzl = torch.from_numpy(batch["zlim"]).pin_memory()
+    pz = torch.empty((n, 2), dtype=torch.float64).pin_memory()
+    pgath = torch.empty((world * n, 2), dtype=torch.float64).pin_memory() if world > 1 else None
+    for _ in range(20):
+        mpc.plan_batch_pinned(px0, pzl, 0.005, pz)
+    if world > 1:
+        dist.barrier()
+    for _ in range(200):
+        t1 = time.perf_counter()
+        mpc.plan_batch_pinned(px0, pzl, 0.005, pz)
+        if world > 1:  # "outputs gathered on every rank": through the device buffers RCCL works on
+            zbuf[0].copy_(pz, non_blocking=True)
+            dist.all_gather_into_tensor(gathered[0], zbuf[0])
+            pgath.copy_(gathered[0], non_blocking=True)
+            torch.cuda.synchronize(dev)
+        h2h.append(1e3 * (time.perf_counter() - t1))
+    assert np.array_equal(pz.numpy(), zbuf[(counter[0] - 1) & 1].cpu().numpy()), "pinned path differs from the device path"
     if rank == 0:
-        for _ in range(12):
+        for _ in range(8):
             t1 = time.perf_counter()
             mpc.planOnceBatch(batch["x0"], batch["zlim"], 0.005)
-            h2h.append(1e3 * (time.perf_counter() - t1))
-        h2h = h2h[2:]
+            h2h_pageable.append(1e3 * (time.perf_counter() - t1))
+        h2h_pageable = h2h_pageable[2:]
+    p50_h2h = float(np.median(h2h))
+    if world > 1:
+        t = torch.tensor([p50_h2h], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        p50_h2h = float(t.item())
 
+    # weak-scaling runs on N > 1 GPUs also time BASELINE's literal configuration -- 65536 instances in TOTAL, contiguous
+    # shards of batch / N per GPU -- so that one launch of the driver's command yields both curves
+    strong = None
+    if world > 1 and args.scaling == "weak" and args.batch % world == 0:
+        ns = args.batch // world
+        sx0, szl = x0[:ns].contiguous(), zlim[:ns].contiguous()
+        sz = [torch.empty((ns, 2), dtype=torch.float64, device=dev) for _ in range(2)]
+        sg = [torch.empty((world * ns, 2), dtype=torch.float64, device=dev) for _ in range(2)]
+        works = [None, None]
+
+        def sstep(i):
+            k = i & 1
+            if works[k] is not None:
+                works[k].wait()
+            mpc.plan_batch_device(sx0, szl, 0.005, sz[k], None, None, stream)
+            works[k] = dist.all_gather_into_tensor(sg[k], sz[k], async_op=True)
+
+        for i in range(args.warmup):
+            sstep(i)
+        for w in works:
+            if w is not None:
+                w.wait()
+        works = [None, None]
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for i in range(args.steps):
+            sstep(i)
+        for w in works:
+            if w is not None:
+                w.wait()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        es = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        dist.all_reduce(es, op=dist.ReduceOp.MAX)
+        es = float(es.item())
+        strong = {"total_batch": args.batch, "batch_per_gpu": ns, "value": args.batch * args.steps / es,
+                  "unit": "solves/s", "ms_per_step": 1e3 * es / args.steps,
+                  "what": "strong scaling: the same kernel + all-gather on shards of batch/N (BASELINE's 65536 total)"}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * n * args.steps / elapsed
         kavg = float(kern_ms.mean()) * 1e-3
         achieved = ALGO_BYTES_PER_SOLVE * n / kavg / 1e9
+        tflops = pivots_per_solve * FLOP_PER_PIVOT * n / kavg / 1e12
+        vc = valu_counters(n)
         out = {
             "metric": "LinearMpcZmp planOnce() solves/sec (N=32, fp64, inputs resident in HBM)",
             "value": value,
@@ -199,27 +296,44 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
-            "p50_ms": float(np.median(kern_ms)) if world == 1 else ms_per_step,
-            "p50_host_to_host_ms": float(np.median(h2h)),
+            # median wall time from "inputs resident in pinned host memory" to "planned ZMPs back in pinned
+            # host memory on every rank" (max over ranks); PCIe-inclusive, never the `value` above
+            "p50_ms": p50_h2h,
+            "p50_kernel_ms": float(np.median(kern_ms)),
+            "p50_pageable_host_ms": float(np.median(h2h_pageable)),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "LinearMpcZmp N=32 (2 s horizon @ 62.5 ms), batch=%d per GPU, random 6-step "
-                                   "footstep sequences (SURVEY.md 8d)" % n,
+            "config": {"workload": "LinearMpcZmp N=32 (2 s horizon @ 62.5 ms), batch=%d per GPU (%s), random 6-step "
+                                   "footstep sequences (SURVEY.md 8d)" % (
+                                       n, "%d in total, contiguous shards" % (world * n)
+                                       if args.scaling == "strong" and world > 1 else "weak scaling"),
                        "batch_per_gpu": n, "horizon_steps": N, "parallelism": "batch-sharded x%d" % world,
                        "collective": "all_gather(zmp)" if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # the bound that binds is VALU issue (fp64 vector pipe), not HBM and not MFMA: `achieved/peak/frac` are the
+            # HBM figures the contract asks for, `valu` the ones that say how far the kernel is from ITS roofline
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
                          "kernel": "zmp_plan_kernel_dyn<32,2>" if 2 * n >= 6 * 256 * 12 * 2 else "zmp_plan_kernel<32,2>",
                          "kernel_avg_ms": kavg * 1e3,
-                         "note": "algorithmic bytes = 1088 B/solve x batch; the kernel is fp64-VALU/LDS-latency "
-                                 "bound (iterative active set), see DESIGN.md"},
+                         "valu": {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
+                                  "flop_per_solve": pivots_per_solve * FLOP_PER_PIVOT,
+                                  "issue_frac": vc["valu_issue_frac"] if vc else None,
+                                  "insts_per_pivot_trip": vc["valu_insts_per_trip"] if vc else None,
+                                  "what": "useful fp64 flop = pivots x 2048 (rank-1 update of the 32 x 32 tableau) over "
+                                          "the kernel time, against the vector-fp64 peak; issue_frac = VALU wave-"
+                                          "instructions x 4 clk / (SIMDs x clk) from the PMC pass in profiles/"},
+                         "note": "algorithmic bytes = 1088 B/solve x batch: 1 % of HBM, the path is not memory-bound "
+                                 "(DESIGN.md section 4)"},
             "pivots_per_solve": pivots_per_solve,
             "unsolved": n_bad,
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle meanwhile)
             cb, ref_zmp, n_chk = cpu_baseline(batch)
             out["cpu_baseline"] = cb

@@ -1376,7 +1376,7 @@ struct ccc_zmp
   double *h_in = nullptr, *h_out = nullptr; // pinned
   double *d_in = nullptr, *d_out = nullptr;
   int32_t *h_status = nullptr, *d_status = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr;
 };
 
 namespace
@@ -1611,6 +1611,7 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->h_out) (void)hipHostFree(h->h_out);
   if(h->h_status) (void)hipHostFree(h->h_status);
   if(h->stream) (void)hipStreamDestroy(h->stream);
+  if(h->stream2) (void)hipStreamDestroy(h->stream2);
   delete h;
 }
 
@@ -1670,10 +1671,28 @@ static int ensure_staging(ccc_zmp * h, int64_t n)
   CCC_HIP_CHECK(hipHostMalloc(&h->h_out, out_elems * sizeof(double), hipHostMallocDefault));
   CCC_HIP_CHECK(hipHostMalloc(&h->h_status, (size_t)n * 2 * sizeof(int32_t), hipHostMallocDefault));
   if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  if(!h->stream2) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   h->cap = n;
   return CCC_OK;
 }
 
+// true when `p` is page-locked host memory the DMA engines can read / write directly (hipHostMalloc'ed or
+// hipHostRegister'ed by the caller)
+static bool is_pinned_host(const void * p)
+{
+  hipPointerAttribute_t attr;
+  if(hipPointerGetAttributes(&attr, p) != hipSuccess)
+  {
+    (void)hipGetLastError(); // plain malloc'ed memory: not an error for us
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+// Host-pointer entry: a chunked pipeline on two streams -- the H2D copy of chunk c + 1 runs on the copy engine while the
+// kernel of chunk c runs, results return per chunk.  Pinned caller buffers ("inputs resident in pinned
+// host memory") are read and written by DMA directly; pageable ones go through the handle's pinned staging, copied
+// chunk by chunk so that the host memcpy of chunk c + 1 overlaps the DMA of chunk c.
 extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, const double * zlim, double control_dt,
                                   double * zmp, double * jerk, int32_t * status)
 {
@@ -1684,21 +1703,49 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
   CCC_DEVICE_GUARD(h->device);
   int rc = ensure_staging(h, n);
   if(rc != CCC_OK) return rc;
-  const int N = h->N;
+  const size_t N = (size_t)h->N;
   const size_t nx = (size_t)n * 6, nl = (size_t)n * 4 * N, nz = (size_t)n * 2, nj = (size_t)n * 2 * N;
-  std::memcpy(h->h_in, x0, nx * sizeof(double));
-  std::memcpy(h->h_in + nx, zlim, nl * sizeof(double));
-  CCC_HIP_CHECK(hipMemcpyAsync(h->d_in, h->h_in, (nx + nl) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  rc = ccc_zmp_plan_batch_device(h, n, h->d_in, h->d_in + nx, control_dt, h->d_out, jerk ? h->d_out + nz : nullptr,
-                                 h->d_status, h->stream);
-  if(rc != CCC_OK) return rc;
-  CCC_HIP_CHECK(hipMemcpyAsync(h->h_out, h->d_out, (nz + (jerk ? nj : 0)) * sizeof(double), hipMemcpyDeviceToHost,
-                               h->stream));
-  CCC_HIP_CHECK(hipMemcpyAsync(h->h_status, h->d_status, (size_t)n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost,
-                               h->stream));
+  const bool in_pinned = is_pinned_host(x0) && is_pinned_host(zlim);
+  const bool out_pinned = is_pinned_host(zmp) && (!jerk || is_pinned_host(jerk)) && (!status || is_pinned_host(status));
+  // chunks small enough for the static-pairing kernel (the work-queue kernel keeps per-handle counters: two launches of
+  // it must not overlap); the kernels of N > 32 use per-handle workspaces as well: one chunk, one stream
+  const int64_t chunk = h->NP == 32 ? 8192 : n;
+  double * d_x0 = h->d_in, * d_zl = h->d_in + nx, * d_z = h->d_out, * d_j = h->d_out + nz;
+  double * s_x0 = h->h_in, * s_zl = h->h_in + nx, * s_z = h->h_out, * s_j = h->h_out + nz;
+  int c = 0;
+  for(int64_t b = 0; b < n; b += chunk, c++)
+  {
+    const size_t m = (size_t)std::min<int64_t>(chunk, n - b), o = (size_t)b;
+    hipStream_t st = (c & 1) ? h->stream2 : h->stream;
+    const double * src_x0 = x0 + o * 6, * src_zl = zlim + o * 4 * N;
+    if(!in_pinned)
+    {
+      std::memcpy(s_x0 + o * 6, src_x0, m * 6 * sizeof(double));
+      std::memcpy(s_zl + o * 4 * N, src_zl, m * 4 * N * sizeof(double));
+      src_x0 = s_x0 + o * 6;
+      src_zl = s_zl + o * 4 * N;
+    }
+    CCC_HIP_CHECK(hipMemcpyAsync(d_x0 + o * 6, src_x0, m * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    CCC_HIP_CHECK(hipMemcpyAsync(d_zl + o * 4 * N, src_zl, m * 4 * N * sizeof(double), hipMemcpyHostToDevice, st));
+    rc = ccc_zmp_plan_batch_device(h, (int64_t)m, d_x0 + o * 6, d_zl + o * 4 * N, control_dt, d_z + o * 2,
+                                   jerk ? d_j + o * 2 * N : nullptr, h->d_status + o * 2, st);
+    if(rc != CCC_OK) return rc;
+    CCC_HIP_CHECK(hipMemcpyAsync((out_pinned ? zmp : s_z) + o * 2, d_z + o * 2, m * 2 * sizeof(double),
+                                 hipMemcpyDeviceToHost, st));
+    if(jerk)
+      CCC_HIP_CHECK(hipMemcpyAsync((out_pinned ? jerk : s_j) + o * 2 * N, d_j + o * 2 * N, m * 2 * N * sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+    if(status)
+      CCC_HIP_CHECK(hipMemcpyAsync((out_pinned ? status : h->h_status) + o * 2, h->d_status + o * 2,
+                                   m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
   CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
-  std::memcpy(zmp, h->h_out, nz * sizeof(double));
-  if(jerk) std::memcpy(jerk, h->h_out + nz, nj * sizeof(double));
-  if(status) std::memcpy(status, h->h_status, (size_t)n * 2 * sizeof(int32_t));
+  if(c > 1) CCC_HIP_CHECK(hipStreamSynchronize(h->stream2));
+  if(!out_pinned)
+  {
+    std::memcpy(zmp, s_z, nz * sizeof(double));
+    if(jerk) std::memcpy(jerk, s_j, nj * sizeof(double));
+    if(status) std::memcpy(status, h->h_status, (size_t)n * 2 * sizeof(int32_t));
+  }
   return CCC_OK;
 }

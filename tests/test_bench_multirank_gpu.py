@@ -29,7 +29,19 @@ def test_headline_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["collective"] == "all_gather(zmp)" and d["unsolved"] == 0
     assert d["value"] > 0 and abs(d["value"] - 2 * 4096 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]
-    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic"]) <= set(d["roofline"])
+    assert set(["bound", "achieved", "peak", "unit", "frac", "traffic", "valu"]) <= set(d["roofline"])
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["valu"]["frac"] < 1
+    # p50 = pinned host -> planned ZMPs gathered on every rank; the kernel-only median beside it
+    assert d["p50_ms"] > d["p50_kernel_ms"] > 0
+    # BASELINE's literal configuration (the batch in TOTAL, shards of batch / N) is timed in the same run
+    ss = d["strong_scaling"]
+    assert ss["total_batch"] == 4096 and ss["batch_per_gpu"] == 2048 and ss["value"] > 0
+
+
+def test_headline_two_ranks_strong_scaling_flag():
+    d = _run(29614, ["--steps", "4", "--warmup", "1", "--batch", "4096", "--scaling", "strong"])
+    assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 2048 and d["unsolved"] == 0
+    assert abs(d["value"] - 4096 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
 
 
 def test_secondary_workload_two_ranks():
