@@ -323,7 +323,7 @@ def main():
                                   "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                                   "flop_per_solve": pivots_per_solve * FLOP_PER_PIVOT,
                                   "issue_frac": vc["valu_issue_frac"] if vc else None,
-                                  "insts_per_pivot_trip": vc["valu_insts_per_trip"] if vc else None,
+                                  "insts_per_pivot_trip": vc["valu_insts_per_solve"] / (0.5 * pivots_per_solve) if vc else None,
                                   "what": "useful fp64 flop = pivots x 2048 (rank-1 update of the 32 x 32 tableau) over "
                                           "the kernel time, against the vector-fp64 peak; issue_frac = VALU wave-"
                                           "instructions x 4 clk / (SIMDs x clk) from the PMC pass in profiles/"},

@@ -22,8 +22,8 @@ for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     meta = {}
     path = os.path.join(src, "%s_%s" % (tag, d), "zmp_counter_collection.csv")
     for r in csv.DictReader(open(path)):
-        if "zmp_plan" not in r["Kernel_Name"]:
-            continue
+        if "zmp_plan_kernel_dyn" not in r["Kernel_Name"]:  # the headline launches (the pinned-host p50 loop of bench.py
+            continue                                         # also runs the static kernel on 8192-instance chunks)
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta = dict(kernel=r["Kernel_Name"].split("(")[0], grid=r["Grid_Size"], wg=r["Workgroup_Size"],
                     lds=r["LDS_Block_Size"], vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], scratch=r["Scratch_Size"])
@@ -45,5 +45,19 @@ out = dict(tag=tag, workload="LinearMpcZmp N=32 batch=65536", kernel=rows[0]["ke
            note="FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); separate --pmc passes")
 json.dump(out, open(os.path.join(dst, "zmp_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+# VALU-issue share (bench.py roofline.valu): a wave64 VALU instruction occupies its SIMD's 16-lane pipe for 4 clocks
+# (fp64 FMA at full rate); 256 CUs x 4 SIMDs; clock from the kernel trace's average duration at 2.4 GHz
+dur_ns = None
+for r in csv.DictReader(open(os.path.join(dst, tag + "_zmp_kernel_stats.csv"))):
+    if "zmp_plan_kernel_dyn" in r["Name"]:
+        dur_ns = float(r["AverageNs"])
+        break
+valu = dict(tag=tag, batch=65536, kernel=rows[0]["kernel"], kernel_avg_ns=dur_ns, sq_insts_valu=c["SQ_INSTS_VALU"],
+            sq_insts_salu=c.get("SQ_INSTS_SALU"), sq_insts_lds=c.get("SQ_INSTS_LDS"),
+            valu_insts_per_solve=c["SQ_INSTS_VALU"] / 65536.0,
+            valu_issue_frac=c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * dur_ns * 2.4),
+            note="SQ_INSTS_VALU (wave-instructions per launch) x 4 clk / (1024 SIMDs x kernel clocks at 2.4 GHz)")
+json.dump(valu, open(os.path.join(dst, "zmp_valu_counters.json"), "w"), indent=1)
+print(json.dumps(valu, indent=1))
 for r in rows:
     print("%-24s %16.1f" % (r["counter"], r["avg_per_dispatch"]))
