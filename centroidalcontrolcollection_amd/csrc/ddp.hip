@@ -7,7 +7,9 @@
 // per instance so that a wavefront streams through contiguous memory.
 #include "common.h"
 #include "ddp_core.h"
+#include "ddp_group.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -77,6 +79,9 @@ struct ccc_ddp
   // device workspace (grown on demand)
   int64_t cap = 0;
   double *ws_x = nullptr, *ws_xc = nullptr, *ws_uc = nullptr, *ws_k = nullptr, *ws_K = nullptr;
+  // workspace of the group kernel (csrc/ddp_group.h): one allocation, carved per array
+  int64_t gcap = 0;
+  double * ws_g = nullptr;
   // staging for the host entry
   int64_t hcap = 0;
   void * d_stage = nullptr;
@@ -143,6 +148,7 @@ extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   free_ws(h);
+  if(h->ws_g) (void)hipFree(h->ws_g);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -177,6 +183,26 @@ static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
   return CCC_OK;
 }
 
+// doubles per instance of the group kernel's workspace: X [2][N+1][S], U [2][N][16], TF [2][N][3], ks [N][16],
+// Ks [N][16][S], gm [N]
+static size_t group_ws_doubles(const ccc_ddp * h)
+{
+  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES;
+  return 2 * (N + 1) * S + 2 * N * M + 2 * N * 3 + N * M + N * M * S + N;
+}
+
+static int ensure_group_ws(ccc_ddp * h, int64_t n, void * stream)
+{
+  if(n <= h->gcap) return CCC_OK;
+  CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
+  if(h->ws_g) (void)hipFree(h->ws_g);
+  h->ws_g = nullptr;
+  h->gcap = 0;
+  CCC_HIP_CHECK(hipMalloc(&h->ws_g, (size_t)n * group_ws_doubles(h) * sizeof(double)));
+  h->gcap = n;
+  return CCC_OK;
+}
+
 extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim,
                                          const double * phase_vertex, const double * phase_ridge,
                                          const int32_t * step_phase, const double * ref_pos, const double * ref_ori,
@@ -192,7 +218,10 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
-  int rc = ensure_ws(h, n, stream);
+  // reg_type 1 (the default): four instances per wavefront (csrc/ddp_group.h); reg_type 2 and the development switch
+  // CCC_DDP_WAVE keep the one-instance-per-wavefront kernel (csrc/ddp_core.h)
+  const bool group = h->cfg.reg_type == 1 && !std::getenv("CCC_DDP_WAVE");
+  int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp::Params P;
   std::memset(&P, 0, sizeof(P));
@@ -221,6 +250,45 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   P.cost_thre = h->cfg.cost_update_thre;
   for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
   P.reg_type = h->cfg.reg_type;
+  if(group)
+  {
+    const size_t N = P.N, S = h->S, M = CCC_DDP_MAX_RIDGES, nn = (size_t)n;
+    ddpg::Batch G{};
+    G.phase_dim = phase_dim;
+    G.phase_vertex = phase_vertex;
+    G.phase_ridge = phase_ridge;
+    G.step_phase = step_phase;
+    G.ref_pos = ref_pos;
+    G.ref_ori = ref_ori;
+    G.inertia = inertia;
+    G.x0 = x0;
+    G.u_init = u_init;
+    G.u_out = u_out;
+    G.x_out = x_out;
+    G.iters = iters;
+    G.status = status;
+    G.cost = cost;
+    double * w = h->ws_g;
+    G.X = w;
+    w += nn * 2 * (N + 1) * S;
+    G.U = w;
+    w += nn * 2 * N * M;
+    G.TF = w;
+    w += nn * 2 * N * 3;
+    G.ks = w;
+    w += nn * N * M;
+    G.Ks = w;
+    w += nn * N * M * S;
+    G.gm = w;
+    hipStream_t gs = reinterpret_cast<hipStream_t>(stream);
+    const int64_t blocks = (n + 3) / 4;
+    if(h->S == 9)
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+    else
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  }
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
              x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

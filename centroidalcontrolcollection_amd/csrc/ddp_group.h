@@ -1,0 +1,1095 @@
+// ddp_group.h -- control-limited DDP / iLQR for CCC::DdpCentroidal (S = 9) and CCC::DdpSingleRigidBody (S = 12) with
+// ONE PROBLEM INSTANCE PER 16-LANE GROUP: four instances per wavefront, lane l of a group = ridge l (= row l of the
+// 16 x 16 input-space matrices, column l of the S x 16 ones, column l of the S x S ones for l < S).
+//
+// Replaces (reference file:line under /root/reference), as csrc/ddp_core.h does:
+//   src/DdpCentroidal.cpp:32-64, :66-83, :85-121, :123-177          problem callbacks (S = 9)
+//   src/DdpSingleRigidBody.cpp:26-38, :52-91, :93-112, :114-243     problem callbacks (S = 12)
+//   src/DdpCentroidal.cpp:229,233 / src/DdpSingleRigidBody.cpp:299,303   the external nmpc_ddp::DDPSolver::solve
+// and implements the specification frozen in oracle/ddp.c (reg_type 1) operation by operation: every product and sum of
+// the oracle appears here with the same operands in the same order (terms that are structurally zero are skipped, which
+// is exact), no FMA contraction, IEEE sqrt and division, the shared deterministic sin/cos -- the results are
+// bit-identical to the oracle's (tests/test_ddp_gpu.py).
+//
+// Why this shape: the per-step matrices are 9..16 wide, so a wavefront per instance left 3/4 of
+// the lanes idle and needed 20 KB of LDS and 852 B of scratch per lane.  Here
+//   * everything a lane owns lives in its registers: row l of Quu / of the Cholesky factor, column l of Fu, T2 = Vxx Fu,
+//     Qxu, T2' = K'Quu; column l of T1 = Vxx Fx, Qxx and of the new Vxx (l < S); right-hand side l of the gain solve;
+//   * what every lane needs from every other one goes through a small per-instance LDS block (5.6 KB at S = 9, 6.9 KB
+//     at S = 12) as ONE write + broadcast reads (all 16 lanes read the same address: conflict-free): Vxx, the rows of T2
+//     that Fu's zero pattern keeps, the Cholesky factor, K, Qxu, T2' and 16-entry vectors;
+//   * ordered reductions (the oracle's sequential sums over ridges) are computed redundantly by every lane from the
+//     published terms, so scalars (box-QP value, line-search tests, costs, lambda) are uniform in a group without a
+//     second round trip and the four instances of a wavefront diverge only through lane masks;
+//   * the triangular solves (box-QP step, gains) run per lane on a broadcast factor -- no cross-lane dependency chain;
+//     the gains take one right-hand side per lane.
+// The four instances of a wavefront run in lock-step: loops run while ANY instance needs them, an instance that is
+// finished (or whose backward pass failed and waits for its retry) keeps its state through masks.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ddp_core.h"
+
+#if defined(__clang__)
+#  pragma clang fp contract(off)
+#endif
+
+namespace ccc_amd
+{
+namespace ddpg
+{
+constexpr int G = 16;          // lanes per instance = ridges per step the group kernel handles
+constexpr int LS = 17;         // row stride of the 16 x 16 LDS matrices (odd: per-lane row reads spread over the banks)
+using ddp::Params;
+
+struct Batch
+{
+  const int * phase_dim;       // [n][P]
+  const double * phase_vertex; // [n][P][16][3]
+  const double * phase_ridge;  // [n][P][16][3]
+  const int * step_phase;      // [n][N]
+  const double * ref_pos;      // [n][N+1][3]
+  const double * ref_ori;      // [n][N+1][3] (SRB)
+  const double * inertia;      // [n][9]      (SRB)
+  const double * x0;           // [n][S]
+  const double * u_init;       // [n][N][16] or nullptr
+  double * u_out;              // [n][N][16]
+  double * x_out;              // [n][N+1][S] or nullptr
+  int * iters;
+  int * status;
+  double * cost;
+  // workspace, per instance: two trajectory buffers (current / line-search candidate, swapped on acceptance),
+  // the gains, and the per-step terms of the gradient-norm test
+  double * X;  // [n][2][N+1][S]
+  double * U;  // [n][2][N][16]
+  double * TF; // [n][2][N][3]   total contact force sum_r u_r rho_r of the step (the derivative's crossMat term)
+  double * ks; // [n][N][16]
+  double * Ks; // [n][N][16][S]
+  double * gm; // [n][N]
+};
+
+template<int S>
+struct Lds
+{
+  static constexpr int KS = S + 1; // row stride of K (odd at S = 12)
+  double Vxx[S * S];               // [a][b]; parks the columns of Qxx during the box-QP; transposes T
+  double A1[G * LS];               // rows of T2 -> Cholesky factor -> Quu' -> T2'; rollout products
+  double Qxu[S * LS];              // [a][r]
+  double K[G * KS];                // [r][a]
+  double v[4][G];                  // published vectors
+};
+
+// structural non-zeros of the discrete-time Fx = I + dt dF/dx (oracle/ddp_models.c mdl_state_eq_deriv)
+template<int S>
+__device__ constexpr bool fx_nz(int k, int b)
+{
+  if(k == b) return true;
+  if(S == 9) return (k < 3 && b == k + 3) || (k >= 6 && b < 3 && (k - 6) != b);
+  // S == 12
+  if(k < 3) return b == k + 6;
+  if(k < 6) return b == 3 || (b == 4 && k != 4) || b == 9 || b == 10 || (b == 11 && k == 3);
+  if(k < 9) return false;
+  return b < 3 || b >= 9;
+}
+
+template<int S>
+struct Group
+{
+  static constexpr int R0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (rows R0 .. R0+5)
+  static constexpr int KS = Lds<S>::KS;
+
+  const Params & P;
+  Lds<S> & L;
+  const int l;     // lane in the group
+  const bool live; // the instance exists (dead groups of the last workgroup shadow the last instance, stores masked)
+  const unsigned shift; // bit position of the group in a wavefront ballot
+
+  // instance data
+  const int * phase_dim;
+  const double * phase_vertex;
+  const double * phase_ridge;
+  const int * step_phase;
+  const double * ref_pos;
+  const double * ref_ori;
+  const double * inertia;
+  const double * x0;
+  const double * u_init;
+  double *X, *U, *TF, *ks, *Ks, *gm;
+  int N;
+
+  // per-lane constants
+  double wrun_own, wterm_own;
+
+  __device__ __forceinline__ static void sync()
+  {
+    __syncthreads(); // single-wavefront workgroups: orders this wavefront's LDS / global traffic
+  }
+  __device__ __forceinline__ unsigned gballot(bool p) const
+  {
+    return static_cast<unsigned>((__ballot(p) >> shift) & 0xffffull);
+  }
+  __device__ __forceinline__ static bool wany(bool p)
+  {
+    return __ballot(p) != 0ull;
+  }
+
+  __device__ __forceinline__ double ref_entry(int step, int a) const
+  {
+    if(a < 3) return ref_pos[static_cast<long>(step) * 3 + a];
+    if(S == 12 && a < 6) return ref_ori[static_cast<long>(step) * 3 + a - 3];
+    return 0.0;
+  }
+  __device__ __forceinline__ double * xbuf(int cb) const
+  {
+    return X + static_cast<long>(cb) * (N + 1) * S;
+  }
+  __device__ __forceinline__ double * ubuf(int cb) const
+  {
+    return U + static_cast<long>(cb) * N * G;
+  }
+  __device__ __forceinline__ double * tfbuf(int cb) const
+  {
+    return TF + static_cast<long>(cb) * N * 3;
+  }
+
+  // publish one value per lane, read all sixteen (uniform in the group afterwards)
+  __device__ __forceinline__ void share(int slot, double val, double (&out)[G])
+  {
+    L.v[slot][l] = val;
+    sync();
+#pragma unroll
+    for(int k = 0; k < G; k++) out[k] = L.v[slot][k];
+    sync();
+  }
+  // sum_{k < m} t_k in increasing k from 0 (the oracle's sequential sums), t published per lane
+  __device__ __forceinline__ double ordered_sum(int slot, double t, int m)
+  {
+    double f[G];
+    share(slot, t, f);
+    double s = 0.0;
+#pragma unroll
+    for(int k = 0; k < G; k++)
+      if(k < m) s += f[k];
+    return s;
+  }
+
+  // ------------------------------------------------------------------------------------------ contact phase
+  struct Contact
+  {
+    int ph = -1, m = 0;
+    double V[3] = {0, 0, 0}, R[3] = {0, 0, 0};
+  };
+  __device__ __forceinline__ void load_contact(int step, Contact & c) const
+  {
+    const int ph = step_phase[step];
+    if(ph != c.ph)
+    {
+      c.ph = ph;
+      c.m = phase_dim[ph];
+      const long o = (static_cast<long>(ph) * G + l) * 3;
+#pragma unroll
+      for(int a = 0; a < 3; a++)
+      {
+        c.V[a] = phase_vertex[o + a];
+        c.R[a] = phase_ridge[o + a];
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------ rollout
+  // alpha < 0: rollout of the initial inputs into buffer `cb`; otherwise the line-search candidate of `cb` into cb ^ 1.
+  // Returns the trajectory cost (uniform in the group).  run: the group takes part (others execute masked, no stores).
+  __device__ __forceinline__ double rollout(double alpha, int cb, bool run)
+  {
+    const bool initial = alpha < 0;
+    const double * xs = xbuf(cb);
+    const double * us = ubuf(cb);
+    double * xo = initial ? xbuf(cb) : xbuf(cb ^ 1);
+    double * uo = initial ? ubuf(cb) : ubuf(cb ^ 1);
+    double * tfo = initial ? tfbuf(cb) : tfbuf(cb ^ 1);
+    const bool wr = run && live;
+    double x[S];
+#pragma unroll
+    for(int a = 0; a < S; a++) x[a] = initial ? x0[a] : xs[a];
+    if(wr && l < S) xo[l] = initial ? x0[l] : xs[l];
+    double cost = 0.0;
+    Contact c;
+    for(int i = 0; i < N; i++)
+    {
+      load_contact(i, c);
+      const int m = c.m;
+      const bool in = l < m;
+      double u = 0.0;
+      if(initial)
+        u = (in && u_init) ? u_init[static_cast<long>(i) * G + l] : 0.0;
+      else
+      {
+        double s = us[static_cast<long>(i) * G + l] + alpha * ks[static_cast<long>(i) * G + l];
+        const double * Kr = Ks + (static_cast<long>(i) * G + l) * S;
+        const double * xi = xs + static_cast<long>(i) * S;
+#pragma unroll
+        for(int a = 0; a < S; a++) s += Kr[a] * (x[a] - xi[a]);
+        s = fmin(fmax(s, P.flo), P.fhi);
+        u = in ? s : 0.0;
+      }
+      if(wr) uo[static_cast<long>(i) * G + l] = u;
+      // per-ridge products; rows of A1: 0-2 u rho (total force), 3-5 u (p - c) x rho, 6 u^2, (SRB) 7-9 u rho / mass
+      const double d[3] = {c.V[0] - x[0], c.V[1] - x[1], c.V[2] - x[2]};
+      double cr[3];
+      ddp::cross3(d, c.R, cr);
+#pragma unroll
+      for(int k = 0; k < 3; k++)
+      {
+        const double p = u * c.R[k];
+        L.A1[k * G + l] = p;
+        L.A1[(3 + k) * G + l] = u * cr[k];
+        if(S == 12) L.A1[(7 + k) * G + l] = p / P.mass;
+      }
+      L.A1[6 * G + l] = u * u;
+      sync();
+      // ordered sums over the ridges, one row per lane (rows 0..9), then published
+      {
+        constexpr int NROW = (S == 9) ? 7 : 10;
+        double acc = 0.0;
+        if(S == 9)
+        {
+          if(l == 2) acc = -1 * P.mass * ddp::kGravity; // xd[5] starts from -m g (src/DdpCentroidal.cpp:43)
+        }
+        else
+        {
+          if(l == 9) acc = -1 * ddp::kGravity; // xd[8] starts from -g (src/DdpSingleRigidBody.cpp:74)
+          if(l >= 3 && l < 6)
+          {
+            // wd starts from -w x (I w)
+            const double * w = x + 9;
+            double Iw[3], cw[3];
+#pragma unroll
+            for(int b = 0; b < 3; b++) Iw[b] = inertia[b * 3] * w[0] + inertia[b * 3 + 1] * w[1] + inertia[b * 3 + 2] * w[2];
+            ddp::cross3(w, Iw, cw);
+            acc = -1 * (l == 3 ? cw[0] : (l == 4 ? cw[1] : cw[2]));
+          }
+        }
+        // Cen: lanes 0-2 dynamics force rows (0,1 double as tf_x, tf_y), 3-5 moment rows, 6 u^2, 7 tf_z (row 2 from 0)
+        // SRB: lanes 0-2 tf rows, 3-5 moment rows (from -w x I w), 6 u^2, 7-9 force / mass rows
+        const int row = (S == 9 && l == 7) ? 2 : (l < NROW ? l : 0);
+        const double * rowp = L.A1 + row * G;
+#pragma unroll
+        for(int r = 0; r < G; r++)
+          if(r < m) acc += rowp[r];
+        L.v[0][l] = acc;
+      }
+      sync();
+      double sums[10];
+#pragma unroll
+      for(int k = 0; k < ((S == 9) ? 8 : 10); k++) sums[k] = L.v[0][k];
+      sync();
+      // running cost of (x_i, u_i) (src/DdpCentroidal.cpp:66-74): sequential over the state entries
+      {
+        double cs = 0.0;
+#pragma unroll
+        for(int a = 0; a < S; a++)
+        {
+          const double e = x[a] - ref_entry(i, a);
+          cs += 0.5 * P.w_run[a] * e * e;
+        }
+        cost += cs + 0.5 * P.w_force * sums[6];
+      }
+      if(wr && l < 3) tfo[static_cast<long>(i) * 3 + l] = (S == 9 && l == 2) ? sums[7] : sums[l];
+      // x_{i+1} = x_i + dt xdot
+      double xd[S];
+      if(S == 9)
+      {
+#pragma unroll
+        for(int a = 0; a < 3; a++) xd[a] = x[3 + a] / P.mass;
+#pragma unroll
+        for(int a = 0; a < 6; a++) xd[3 + a] = sums[a];
+      }
+      else
+      {
+        double ca, sa, cb_, sb;
+        ddp::det_sincos(x[3], &sa, &ca);
+        ddp::det_sincos(x[4], &sb, &cb_);
+        const double Km[9] = {(ca * sb) / cb_, (sb * sa) / cb_, 1.0, -1 * sa, ca, 0.0, ca / cb_, sa / cb_, 0.0};
+        const double * w = x + 9;
+#pragma unroll
+        for(int a = 0; a < 3; a++)
+        {
+          xd[a] = x[6 + a];
+          xd[3 + a] = Km[a * 3] * w[0] + Km[a * 3 + 1] * w[1] + Km[a * 3 + 2] * w[2];
+          xd[6 + a] = sums[7 + a];
+        }
+        const double wd[3] = {sums[3], sums[4], sums[5]};
+        double In[9], sol[3];
+#pragma unroll
+        for(int e = 0; e < 9; e++) In[e] = inertia[e];
+        ddp::llt3_solve(In, wd, sol);
+#pragma unroll
+        for(int a = 0; a < 3; a++) xd[9 + a] = sol[a];
+      }
+#pragma unroll
+      for(int a = 0; a < S; a++) x[a] = x[a] + P.dt * xd[a];
+      if(wr && l < S)
+      {
+        double xv = x[0];
+#pragma unroll
+        for(int a = 1; a < S; a++) xv = (l == a) ? x[a] : xv;
+        xo[static_cast<long>(i + 1) * S + l] = xv;
+      }
+    }
+    {
+      double cs = 0.0;
+#pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        const double e = x[a] - ref_entry(N, a);
+        cs += 0.5 * P.w_term[a] * e * e;
+      }
+      cost += cs;
+    }
+    sync();
+    return cost;
+  }
+
+  // ------------------------------------------------------------------------------------------ triangular solves
+  // t <- (L L')^-1 t with the factor of the group in LDS (strict lower triangle in A1, reciprocal diagonal in v[3]).
+  // Every lane works on its own right-hand side (all equal in the box-QP, one column of Qxu' per lane in the gains).
+  __device__ __forceinline__ void solve(double (&t)[G]) const
+  {
+    double rd[G];
+#pragma unroll
+    for(int k = 0; k < G; k++) rd[k] = L.v[3][k];
+#pragma unroll
+    for(int a = 0; a < G; a++)
+    {
+      double s = t[a];
+#pragma unroll
+      for(int k = 0; k < a; k++) s -= L.A1[a * LS + k] * t[k];
+      t[a] = s * rd[a];
+    }
+#pragma unroll
+    for(int a = G - 1; a >= 0; a--)
+    {
+      double s = t[a];
+#pragma unroll
+      for(int k = G - 1; k > a; k--) s -= L.A1[k * LS + a] * t[k];
+      t[a] = s * rd[a];
+    }
+  }
+
+  // Cholesky of H~ (H with clamped / absent rows and columns replaced by identity: the factor of H_ff embedded) into
+  // the LDS factor of the groups with `need`; returns false where a free pivot is not positive (oracle: result -1).
+  // Left-looking, lane = row: at pivot a every lane reads row a (written by lane a at the earlier pivots), forms the
+  // pivot redundantly and its own entry of column a -- the oracle's sums in the oracle's order.
+  __device__ __forceinline__ bool cholesky(const double (&Hreg)[G], double hdiag, unsigned clmask, int m, bool need)
+  {
+    const bool mine_free = l < m && !((clmask >> l) & 1u);
+    double df[G];
+    share(2, mine_free ? hdiag : 1.0, df);
+    double Lrow[G];
+    bool ok = true;
+#pragma unroll
+    for(int a = 0; a < G; a++)
+    {
+      const bool a_free = a < m && !((clmask >> a) & 1u);
+      double La[G];
+#pragma unroll
+      for(int k = 0; k < a; k++) La[k] = L.A1[a * LS + k];
+      double d = df[a];
+#pragma unroll
+      for(int k = 0; k < a; k++) d -= La[k] * La[k];
+      ok = ok && (d > 0.0);
+      const double sq = sqrt(d);
+      const double rda = 1.0 / sq;
+      double v = (mine_free && a_free) ? Hreg[a] : 0.0;
+#pragma unroll
+      for(int k = 0; k < a; k++) v -= Lrow[k] * La[k];
+      v = v * rda;
+      Lrow[a] = (l > a) ? v : 0.0;
+      if(need)
+      {
+        if(l > a) L.A1[l * LS + a] = Lrow[a];
+        if(l == 0) L.v[3][a] = rda;
+      }
+      sync();
+    }
+    return ok;
+  }
+
+  // ------------------------------------------------------------------------------------------ box-QP
+  // min 1/2 k'Hk + g'k, lo <= k <= hi (oracle_box_qp): H row l in Hreg (regularised), g_l = gl, limits from the
+  // published inputs uf, warm start kw_l.  Out: the solution in every lane (kf), the clamped set, the boxQP.m result.
+  __device__ __forceinline__ int box_qp(const double (&Hreg)[G], double hdiag, double gl, const double (&uf)[G], double kw,
+                                        int m, bool run, double (&kf)[G], unsigned & clmask_out)
+  {
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
+    const bool in = l < m;
+    const unsigned inmask = m >= G ? 0xffffu : ((1u << m) - 1u);
+    auto lo_of = [&](int k) { return P.flo - uf[k]; };
+    auto hi_of = [&](int k) { return P.fhi - uf[k]; };
+    double ul = uf[0];
+#pragma unroll
+    for(int k = 1; k < G; k++) ul = (l == k) ? uf[k] : ul;
+    const double lo = P.flo - ul, hi = P.fhi - ul;
+    double x = in ? fmin(fmax(kw, lo), hi) : 0.0;
+    double xf[G];
+    share(0, x, xf);
+    auto row_dot = [&](double s0, const double (&y)[G]) {
+      double s = s0;
+#pragma unroll
+      for(int j = 0; j < G; j++)
+        if(j < m) s += Hreg[j] * y[j];
+      return s;
+    };
+    double value;
+    {
+      const double s = row_dot(0.0, xf);
+      value = ordered_sum(1, x * gl + 0.5 * x * s, m);
+    }
+    double oldvalue = 0.0;
+    bool cl = false;
+    unsigned clmask = 0;
+    int result = 0;
+    bool fin = !run || m == 0;
+    if(m == 0) result = 1; // nothing to solve (the oracle does not call the box-QP for a step without contact)
+    int iter = 1;
+    for(; iter <= max_iter; iter++)
+    {
+      if(!wany(!fin)) break;
+      // ---- top of the oracle's loop
+      if(!fin && result != 0) fin = true;
+      if(!fin && iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
+      {
+        result = 4;
+        fin = true;
+      }
+      if(!fin) oldvalue = value;
+      const double grad = row_dot(gl, xf);
+      const bool ncl = in && ((x == lo && grad > 0) || (x == hi && grad < 0));
+      const bool changed_l = !fin && (ncl != cl);
+      if(!fin) cl = ncl;
+      const bool changed = (iter == 1) || (gballot(changed_l) != 0u);
+      if(!fin) clmask = gballot(cl) & inmask;
+      if(!fin && clmask == inmask)
+      {
+        result = 6;
+        fin = true;
+      }
+      const bool need = !fin && changed;
+      if(wany(need))
+      {
+        const bool ok = cholesky(Hreg, hdiag, clmask, m, need);
+        if(need && !ok)
+        {
+          result = -1;
+          fin = true;
+        }
+      }
+      double gf[G];
+      share(0, grad, gf);
+      if(!fin)
+      {
+        double gn = 0.0;
+#pragma unroll
+        for(int k = 0; k < G; k++)
+          if(k < m && !((clmask >> k) & 1u)) gn += gf[k] * gf[k];
+        gn = sqrt(gn);
+        if(gn < min_grad)
+        {
+          result = 5;
+          fin = true;
+        }
+      }
+      // grad_clamped = g + H (x .* clamped) on the free rows, then the Newton step on the free set
+      double gc = gl;
+#pragma unroll
+      for(int j = 0; j < G; j++)
+        if(j < m && ((clmask >> j) & 1u)) gc += Hreg[j] * xf[j];
+      double t[G];
+      share(1, (in && !cl) ? gc : 0.0, t);
+      if(wany(!fin)) solve(t);
+      double srch[G];
+#pragma unroll
+      for(int k = 0; k < G; k++) srch[k] = (k < m && !((clmask >> k) & 1u)) ? -t[k] - xf[k] : 0.0;
+      double sdotg = 0.0;
+#pragma unroll
+      for(int k = 0; k < G; k++)
+        if(k < m) sdotg += srch[k] * gf[k];
+      if(!fin && sdotg >= 0) fin = true; // no descent direction: result stays 0
+      // ---- Armijo line search along the projected step
+      double step = 1.0, vc = value;
+      double xc[G];
+#pragma unroll
+      for(int k = 0; k < G; k++) xc[k] = xf[k];
+      bool ls = !fin;
+      while(wany(ls))
+      {
+        double cand[G];
+#pragma unroll
+        for(int k = 0; k < G; k++) cand[k] = (k < m) ? fmin(fmax(xf[k] + step * srch[k], lo_of(k)), hi_of(k)) : 0.0;
+        double cl_own = cand[0];
+#pragma unroll
+        for(int k = 1; k < G; k++) cl_own = (l == k) ? cand[k] : cl_own;
+        const double s = row_dot(0.0, cand);
+        const double v = ordered_sum(1, cl_own * gl + 0.5 * cl_own * s, m);
+        if(ls)
+        {
+          vc = v;
+#pragma unroll
+          for(int k = 0; k < G; k++) xc[k] = cand[k];
+          if(!((vc - oldvalue) / (step * sdotg) < armijo))
+            ls = false;
+          else
+          {
+            step *= step_dec;
+            if(step < min_step)
+            {
+              result = 2;
+              ls = false;
+            }
+          }
+        }
+      }
+      if(!fin)
+      {
+#pragma unroll
+        for(int k = 0; k < G; k++) xf[k] = xc[k];
+        double xo = xc[0];
+#pragma unroll
+        for(int k = 1; k < G; k++) xo = (l == k) ? xc[k] : xo;
+        x = xo;
+        value = vc;
+      }
+    }
+    if(!fin && iter > max_iter && result == 0) result = 1;
+#pragma unroll
+    for(int k = 0; k < G; k++) kf[k] = xf[k];
+    clmask_out = clmask;
+    return result;
+  }
+
+  // ------------------------------------------------------------------------------------------ backward pass
+  // One sweep over the horizon for the groups with `act`; returns false where a box-QP failed (oracle: retry with a
+  // larger lambda).  dV0 / dV1: the expected-reduction terms; the per-step terms of the gradient norm go to gm.
+  __device__ __forceinline__ bool backward_pass(int cb, double lambda, bool act, double & dV0_out, double & dV1_out)
+  {
+    const double * xs = xbuf(cb);
+    const double * us = ubuf(cb);
+    const double * tfs = tfbuf(cb);
+    bool ok = true;
+    double dV0 = 0.0, dV1 = 0.0;
+    // terminal value (src/DdpCentroidal.cpp:156-177 at x_N)
+    double Vx[S];
+#pragma unroll
+    for(int a = 0; a < S; a++) Vx[a] = P.w_term[a] * (xs[static_cast<long>(N) * S + a] - ref_entry(N, a));
+    if(l < S)
+    {
+#pragma unroll
+      for(int a = 0; a < S; a++) L.Vxx[a * S + l] = (a == l) ? wterm_own : 0.0;
+    }
+    sync();
+    Contact c;
+    double kprev = 0.0;
+    int m_next = -1;
+    for(int i = N - 1; i >= 0; i--)
+    {
+      load_contact(i, c);
+      const int m = c.m;
+      const bool in = l < m;
+      const bool run = act && ok;
+      double x[S];
+#pragma unroll
+      for(int a = 0; a < S; a++) x[a] = xs[static_cast<long>(i) * S + a];
+      const double u = in ? us[static_cast<long>(i) * G + l] : 0.0;
+      double tf[3];
+#pragma unroll
+      for(int a = 0; a < 3; a++) tf[a] = tfs[static_cast<long>(i) * 3 + a];
+      double uf[G];
+      share(0, u, uf);
+      // ---- derivatives at (x_i, u_i): column l of Fu (rows R0..R0+5), the sparse Fx (uniform in the group)
+      double fu[6];
+      double FX[S][S];
+      {
+        const double d[3] = {c.V[0] - x[0], c.V[1] - x[1], c.V[2] - x[2]};
+        double cr[3];
+        ddp::cross3(d, c.R, cr);
+        if(S == 9)
+        {
+#pragma unroll
+          for(int a = 0; a < 3; a++)
+          {
+            fu[a] = in ? c.R[a] * P.dt : 0.0;
+            fu[3 + a] = in ? cr[a] * P.dt : 0.0;
+          }
+          const double cm = (1 / P.mass) * P.dt;
+#pragma unroll
+          for(int a = 0; a < S; a++) FX[a][a] = 1.0;
+          FX[0][3] = cm;
+          FX[1][4] = cm;
+          FX[2][5] = cm;
+          FX[6][1] = (-tf[2]) * P.dt;
+          FX[6][2] = tf[1] * P.dt;
+          FX[7][0] = tf[2] * P.dt;
+          FX[7][2] = (-tf[0]) * P.dt;
+          FX[8][0] = (-tf[1]) * P.dt;
+          FX[8][1] = tf[0] * P.dt;
+        }
+        else
+        {
+          double In[9];
+#pragma unroll
+          for(int e = 0; e < 9; e++) In[e] = inertia[e];
+          double sol[3];
+          ddp::llt3_solve(In, cr, sol);
+#pragma unroll
+          for(int a = 0; a < 3; a++)
+          {
+            fu[a] = in ? (c.R[a] / P.mass) * P.dt : 0.0;
+            fu[3 + a] = in ? sol[a] * P.dt : 0.0;
+          }
+#pragma unroll
+          for(int a = 0; a < S; a++) FX[a][a] = 1.0;
+#pragma unroll
+          for(int a = 0; a < 3; a++) FX[a][6 + a] = 1.0 * P.dt;
+          const double w1 = x[9], w2 = x[10], w3 = x[11];
+          double ca, sa, cb_, sb;
+          ddp::det_sincos(x[3], &sa, &ca);
+          ddp::det_sincos(x[4], &sb, &cb_);
+          const double cb2 = cb_ * cb_, sb2 = sb * sb;
+          const double Km[9] = {(ca * sb) / cb_, (sb * sa) / cb_, 1.0, -1 * sa, ca, 0.0, ca / cb_, sa / cb_, 0.0};
+          FX[3][9] = Km[0] * P.dt;
+          FX[3][10] = Km[1] * P.dt;
+          FX[3][11] = Km[2] * P.dt;
+          FX[4][9] = Km[3] * P.dt;
+          FX[4][10] = Km[4] * P.dt;
+          FX[5][9] = Km[6] * P.dt;
+          FX[5][10] = Km[7] * P.dt;
+          FX[3][3] = (-w1 * sa * sb / cb_ + w2 * sb * ca / cb_) * P.dt + 1.0;
+          FX[4][3] = (-w1 * ca - w2 * sa) * P.dt;
+          FX[5][3] = (-w1 * sa / cb_ + w2 * ca / cb_) * P.dt;
+          FX[3][4] = (w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa) * P.dt;
+          FX[5][4] = (w1 * sb * ca / cb2 + w2 * sa * sb / cb2) * P.dt;
+          const double I11 = In[0], I12 = In[1], I13 = In[2], I22 = In[4], I23 = In[5], I33 = In[8];
+          const double D[9] = {I12 * w3 - I13 * w2,
+                               -I13 * w1 + I22 * w3 - 2 * I23 * w2 - I33 * w3,
+                               I12 * w1 + I22 * w2 + 2 * I23 * w3 - I33 * w2,
+                               -I11 * w3 + 2 * I13 * w1 + I23 * w2 + I33 * w3,
+                               -I12 * w3 + I23 * w1,
+                               -I11 * w1 - I12 * w2 - 2 * I13 * w3 + I33 * w1,
+                               I11 * w2 - 2 * I12 * w1 - I22 * w2 - I23 * w3,
+                               I11 * w1 + 2 * I12 * w2 + I13 * w3 - I22 * w1,
+                               I13 * w2 - I23 * w1};
+          const double CM[9] = {0, -tf[2], tf[1], tf[2], 0, -tf[0], -tf[1], tf[0], 0};
+#pragma unroll
+          for(int b = 0; b < 3; b++)
+          {
+            const double colD[3] = {D[b], D[3 + b], D[6 + b]}, colC[3] = {CM[b], CM[3 + b], CM[6 + b]};
+            double sD[3], sC[3];
+            ddp::llt3_solve(In, colD, sD);
+            ddp::llt3_solve(In, colC, sC);
+#pragma unroll
+            for(int a = 0; a < 3; a++)
+            {
+              FX[9 + a][9 + b] = (a == b) ? sD[a] * P.dt + 1.0 : sD[a] * P.dt;
+              FX[9 + a][b] = sC[a] * P.dt;
+            }
+          }
+        }
+      }
+      // column l of Fx (dense, zeros included) for the lanes that own a state entry
+      double fxcol[S];
+#pragma unroll
+      for(int k = 0; k < S; k++)
+      {
+        double v = 0.0;
+#pragma unroll
+        for(int b = 0; b < S; b++)
+          if(fx_nz<S>(k, b)) v = (l == b) ? FX[k][b] : v;
+        fxcol[k] = v;
+      }
+      double x_own = x[0];
+#pragma unroll
+      for(int a = 1; a < S; a++) x_own = (l == a) ? x[a] : x_own;
+      // ---- Qx (lane a), Qu (lane r)
+      double Qx_own = wrun_own * (x_own - ref_entry(i, l < S ? l : 0));
+#pragma unroll
+      for(int b = 0; b < S; b++) Qx_own += fxcol[b] * Vx[b];
+      double Qu = in ? P.w_force * u : 0.0;
+#pragma unroll
+      for(int j = 0; j < 6; j++) Qu += fu[j] * Vx[R0 + j];
+      // ---- T1 = Vxx Fx (column l), T2 = Vxx Fu (column l)
+      double T1c[S], T2c[S];
+#pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for(int k = 0; k < S; k++)
+        {
+          const double v = L.Vxx[a * S + k];
+          s1 += v * fxcol[k];
+          if(k >= R0 && k < R0 + 6) s2 += v * fu[k - R0];
+        }
+        T1c[a] = s1;
+        T2c[a] = s2;
+      }
+      sync(); // Vxx is consumed: its block now parks the columns of Qxx
+      // ---- Qxx column l, Qxu column l
+      double Qxuc[S];
+#pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        double s = (a == l) ? wrun_own : 0.0;
+        double sx = 0.0;
+#pragma unroll
+        for(int k = 0; k < S; k++)
+          if(fx_nz<S>(k, a))
+          {
+            s += FX[k][a] * T1c[k];
+            sx += FX[k][a] * T2c[k];
+          }
+        if(l < S) L.Vxx[a * S + l] = s;
+        Qxuc[a] = sx;
+        L.Qxu[a * LS + l] = sx;
+      }
+      // ---- rows R0..R0+5 of T2 published, row l of Quu
+#pragma unroll
+      for(int j = 0; j < 6; j++) L.A1[j * G + l] = T2c[R0 + j];
+      sync();
+      double Hreg[G];
+      double quu_own = 0.0;
+#pragma unroll
+      for(int q = 0; q < G; q++)
+      {
+        double s = (l == q) ? P.w_force : 0.0;
+#pragma unroll
+        for(int j = 0; j < 6; j++) s += fu[j] * L.A1[j * G + q];
+        s = (in && q < m) ? s : 0.0;
+        quu_own = (l == q) ? s : quu_own;
+        Hreg[q] = (l == q) ? s + lambda : s; // reg_type 1: Quu_F = Quu + lambda I
+      }
+      const double hdiag = quu_own + lambda;
+      sync(); // the T2 rows are consumed: A1 becomes the Cholesky factor
+      // ---- box-QP for the feed-forward term k
+      double kf[G];
+      unsigned clmask = 0;
+      const bool warm = (i + 1 < N) && (m_next == m);
+      int rc = 1;
+      if(wany(run && m > 0))
+        rc = box_qp(Hreg, hdiag, Qu, uf, warm ? kprev : 0.0, m, run && m > 0, kf, clmask);
+      else
+      {
+#pragma unroll
+        for(int k = 0; k < G; k++) kf[k] = 0.0;
+      }
+      if(m == 0)
+      {
+#pragma unroll
+        for(int k = 0; k < G; k++) kf[k] = 0.0;
+        clmask = 0;
+      }
+      if(run && m > 0 && rc < 1) ok = false;
+      double k_own = kf[0];
+#pragma unroll
+      for(int k = 1; k < G; k++) k_own = (l == k) ? kf[k] : k_own;
+      // ---- gains: K_f = -Quu_F,ff^-1 Qxu_f', one right-hand side (state entry l) per lane
+      double QxuRow[G], Kc[G];
+      {
+        const int a = l < S ? l : 0;
+#pragma unroll
+        for(int r = 0; r < G; r++) QxuRow[r] = L.Qxu[a * LS + r];
+        double t[G];
+#pragma unroll
+        for(int r = 0; r < G; r++) t[r] = (r < m && !((clmask >> r) & 1u)) ? QxuRow[r] : 0.0;
+        if(wany(run && m > 0)) solve(t);
+#pragma unroll
+        for(int r = 0; r < G; r++) Kc[r] = (r < m && !((clmask >> r) & 1u)) ? -t[r] : 0.0;
+        if(l < S)
+        {
+#pragma unroll
+          for(int r = 0; r < G; r++) L.K[r * KS + l] = Kc[r];
+        }
+      }
+      sync();
+      const bool wr = act && ok && live;
+      {
+        double * Kr = Ks + (static_cast<long>(i) * G + l) * S;
+#pragma unroll
+        for(int a = 0; a < S; a++)
+        {
+          const double kv = L.K[l * KS + a];
+          if(wr) Kr[a] = kv;
+        }
+        if(wr) ks[static_cast<long>(i) * G + l] = k_own;
+      }
+      // term of the gradient-norm test: max_r |k_r| / (|u_r| + 1)
+      {
+        double mx = 0.0;
+#pragma unroll
+        for(int r = 0; r < G; r++)
+          if(r < m)
+          {
+            const double v = fabs(kf[r]) / (fabs(uf[r]) + 1.0);
+            if(v > mx) mx = v;
+          }
+        if(wr && l == 0) gm[i] = mx;
+      }
+      // ---- t4 = Quu k, dV, Vx
+      double t4 = 0.0;
+#pragma unroll
+      for(int q = 0; q < G; q++)
+        if(q < m) t4 += ((l == q) ? quu_own : Hreg[q]) * kf[q];
+      L.v[1][l] = t4;
+      L.v[2][l] = Qu;
+      // Quu row l -> LDS for the transposition (A1 is free: the factor is consumed)
+#pragma unroll
+      for(int q = 0; q < G; q++) L.A1[l * LS + q] = (l == q) ? quu_own : Hreg[q];
+      sync();
+      double t4f[G], quf[G], QC[G];
+#pragma unroll
+      for(int r = 0; r < G; r++)
+      {
+        t4f[r] = L.v[1][r];
+        quf[r] = L.v[2][r];
+        QC[r] = L.A1[r * LS + l];
+      }
+      {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for(int r = 0; r < G; r++)
+          if(r < m)
+          {
+            s0 += kf[r] * quf[r];
+            s1 += kf[r] * t4f[r];
+          }
+        if(run)
+        {
+          dV0 += s0;
+          dV1 += 0.5 * s1;
+        }
+      }
+      double Vx_own = Qx_own;
+#pragma unroll
+      for(int r = 0; r < G; r++)
+        if(r < m) Vx_own += Kc[r] * t4f[r] + Kc[r] * quf[r] + QxuRow[r] * kf[r];
+      // ---- T2' = K'Quu (column l)
+      double T2p[S];
+#pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        double s = 0.0;
+#pragma unroll
+        for(int q = 0; q < G; q++)
+          if(q < m) s += L.K[q * KS + a] * QC[q];
+        T2p[a] = s;
+      }
+      sync(); // every lane has its column of Quu: A1 takes T2'
+#pragma unroll
+      for(int a = 0; a < S; a++) L.A1[a * G + l] = T2p[a];
+      L.v[0][l] = Vx_own;
+      sync();
+      // ---- Vxx = sym(Qxx + K'Quu K + K'Qxu' + Qxu K): column l of the sum, then the transposition through LDS
+      double Tc[S];
+#pragma unroll
+      for(int a = 0; a < S; a++)
+      {
+        double s = (l < S) ? L.Vxx[a * S + l] : 0.0;
+#pragma unroll
+        for(int r = 0; r < G; r++)
+          if(r < m) s += L.A1[a * G + r] * Kc[r] + L.K[r * KS + a] * QxuRow[r] + L.Qxu[a * LS + r] * Kc[r];
+        Tc[a] = s;
+      }
+      double Vxn[S];
+#pragma unroll
+      for(int a = 0; a < S; a++) Vxn[a] = L.v[0][a];
+      if(l < S)
+      {
+#pragma unroll
+        for(int a = 0; a < S; a++) L.Vxx[a * S + l] = Tc[a];
+      }
+      sync();
+      double Tr[S];
+#pragma unroll
+      for(int a = 0; a < S; a++) Tr[a] = (l < S) ? L.Vxx[l * S + a] : 0.0;
+      sync();
+      if(l < S)
+      {
+#pragma unroll
+        for(int a = 0; a < S; a++) L.Vxx[a * S + l] = 0.5 * (Tc[a] + Tr[a]);
+      }
+      if(run)
+      {
+#pragma unroll
+        for(int a = 0; a < S; a++) Vx[a] = Vxn[a];
+      }
+      kprev = k_own;
+      m_next = m;
+      sync();
+    }
+    dV0_out = dV0;
+    dV1_out = dV1;
+    return ok;
+  }
+
+  // ------------------------------------------------------------------------------------------ solve
+  __device__ __forceinline__ void solve_instance(int * out_iters, int * out_status, double * out_cost, double * u_out,
+                                                 double * x_out)
+  {
+    {
+      double wr = P.w_run[0], wt = P.w_term[0];
+#pragma unroll
+      for(int a = 1; a < S; a++)
+      {
+        wr = (l == a) ? P.w_run[a] : wr;
+        wt = (l == a) ? P.w_term[a] : wt;
+      }
+      wrun_own = wr;
+      wterm_own = wt;
+    }
+    double lambda = P.lambda0, dlambda = P.dlambda0;
+    int cb = 0;
+    double cost = rollout(-1.0, cb, true);
+    int it = 1, status = 0;
+    bool done = P.max_iter < 1;
+    auto increase = [&]() {
+      dlambda = fmax(dlambda * P.lambda_factor, P.lambda_factor);
+      lambda = fmax(lambda * dlambda, P.lambda_min);
+    };
+    auto decrease = [&]() {
+      dlambda = fmin(dlambda / P.lambda_factor, 1.0 / P.lambda_factor);
+      lambda = lambda * dlambda * (lambda > P.lambda_min ? 1.0 : 0.0);
+    };
+    while(wany(!done))
+    {
+      const bool act = !done;
+      double dV0 = 0.0, dV1 = 0.0;
+      const bool ok = backward_pass(cb, lambda, act, dV0, dV1);
+      sync();
+      bool searching = false;
+      if(act)
+      {
+        if(!ok)
+        {
+          increase();
+          if(lambda > P.lambda_max)
+          {
+            status = -1;
+            done = true;
+          }
+        }
+        else
+        {
+          double gsum = 0.0;
+          for(int i = 0; i < N; i++) gsum += gm[i];
+          gsum = gsum / N;
+          if(gsum < P.k_rel_norm_thre && lambda < P.lambda_thre)
+          {
+            decrease();
+            status = 1;
+            done = true;
+          }
+          else
+            searching = true;
+        }
+      }
+      // ---- line search over alpha_list
+      bool accepted = false;
+      double actual = 0.0, costc = 0.0;
+      for(int a = 0; a < 11; a++)
+      {
+        const bool go = searching && !accepted;
+        if(!wany(go)) break;
+        const double alpha = P.alpha[a];
+        const double cc = rollout(alpha, cb, go);
+        if(go)
+        {
+          costc = cc;
+          actual = cost - costc;
+          const double expected = -alpha * (dV0 + alpha * dV1);
+          const double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
+          if(ratio > P.ratio_thre) accepted = true;
+        }
+      }
+      if(searching)
+      {
+        if(accepted)
+        {
+          decrease();
+          cb ^= 1;
+          cost = costc;
+          if(actual < P.cost_thre)
+          {
+            status = 2;
+            done = true;
+          }
+        }
+        else
+        {
+          increase();
+          if(lambda > P.lambda_max)
+          {
+            status = -1;
+            done = true;
+          }
+        }
+      }
+      if(act && ok && !done)
+      {
+        it++;
+        if(it > P.max_iter) done = true;
+      }
+      sync();
+    }
+    if(it > P.max_iter) it = P.max_iter;
+    // ---- outputs: the current trajectory
+    if(live)
+    {
+      const double * us = ubuf(cb);
+      for(int e = l; e < N * G; e += G) u_out[e] = us[e];
+      if(x_out)
+      {
+        const double * xs = xbuf(cb);
+        for(int e = l; e < (N + 1) * S; e += G) x_out[e] = xs[e];
+      }
+      if(l == 0)
+      {
+        if(out_iters) *out_iters = it;
+        if(out_status) *out_status = status;
+        if(out_cost) *out_cost = cost;
+      }
+    }
+  }
+};
+
+template<int S>
+__global__ __launch_bounds__(64, 2) void ddp_group_kernel(Params P, Batch B, long n)
+{
+  __shared__ Lds<S> lds[4];
+  const int lane = static_cast<int>(threadIdx.x), g = lane >> 4, l = lane & 15;
+  const long inst = static_cast<long>(blockIdx.x) * 4 + g;
+  const bool live = inst < n;
+  const long b = live ? inst : n - 1;
+  const int N = P.N;
+  Group<S> grp{P, lds[g], l, live, static_cast<unsigned>(g * 16)};
+  grp.N = N;
+  grp.phase_dim = B.phase_dim + b * P.P;
+  grp.phase_vertex = B.phase_vertex + b * P.P * G * 3;
+  grp.phase_ridge = B.phase_ridge + b * P.P * G * 3;
+  grp.step_phase = B.step_phase + b * N;
+  grp.ref_pos = B.ref_pos + b * (N + 1) * 3;
+  grp.ref_ori = B.ref_ori ? B.ref_ori + b * (N + 1) * 3 : nullptr;
+  grp.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
+  grp.x0 = B.x0 + b * S;
+  grp.u_init = B.u_init ? B.u_init + b * N * G : nullptr;
+  grp.X = B.X + b * 2 * (N + 1) * S;
+  grp.U = B.U + b * 2 * N * G;
+  grp.TF = B.TF + b * 2 * N * 3;
+  grp.ks = B.ks + b * N * G;
+  grp.Ks = B.Ks + b * N * G * S;
+  grp.gm = B.gm + b * N;
+  grp.solve_instance(B.iters ? B.iters + b : nullptr, B.status ? B.status + b : nullptr, B.cost ? B.cost + b : nullptr,
+                     B.u_out + b * N * G, B.x_out ? B.x_out + b * (N + 1) * S : nullptr);
+}
+} // namespace ddpg
+} // namespace ccc_amd
