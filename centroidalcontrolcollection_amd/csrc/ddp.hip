@@ -218,9 +218,11 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
-  // reg_type 1 (the default): four instances per wavefront (csrc/ddp_group.h); reg_type 2 and the development switch
-  // CCC_DDP_WAVE keep the one-instance-per-wavefront kernel (csrc/ddp_core.h)
-  const bool group = h->cfg.reg_type == 1 && !std::getenv("CCC_DDP_WAVE");
+  // Default: one instance per wavefront (csrc/ddp_core.h).  CCC_DDP_GROUP=1 selects the kernel with four instances per
+  // wavefront (csrc/ddp_group.h; reg_type 1 only): bit-identical results, half the VALU instructions per instance, but
+  // measured SLOWER on MI355X -- 4096 instances are only 1024 wavefronts, one per SIMD, and with
+  // 512 registers and 25 KB of LDS per wavefront nothing hides the dependent LDS / scratch latencies.
+  const bool group = h->cfg.reg_type == 1 && std::getenv("CCC_DDP_GROUP") != nullptr;
   int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp::Params P;

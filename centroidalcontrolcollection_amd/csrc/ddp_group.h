@@ -35,6 +35,27 @@
 #  pragma clang fp contract(off)
 #endif
 
+// Section profiler (development aid, -DCCC_DDPG_PROF): cycles per section accumulated per lane-0 in registers, written
+// over the first entries of the instance's `gm` workspace at the end (scripts/ddpg_sections.py reads them back through a
+// debug copy).  Sections: 0 rollout, 1 backward total, 2 derivatives+products, 3 box-QP, 4 Cholesky, 5 gains, 6 value
+// update; counters: 8 rollouts, 9 backward passes, 10 box-QP iterations, 11 factorisations, 12 line-search steps.
+#if defined(CCC_DDPG_PROF)
+#  define DPROF_T() ((long long)__builtin_readcyclecounter())
+#  define DPROF_ADD(k, t0) prof[k] += (double)(DPROF_T() - (t0))
+#  define DPROF_CNT(k) prof[k] += 1.0
+#else
+#  define DPROF_T() 0LL
+#  define DPROF_ADD(k, t0) \
+    do                     \
+    {                      \
+      (void)(t0);          \
+    } while(0)
+#  define DPROF_CNT(k) \
+    do                 \
+    {                  \
+    } while(0)
+#endif
+
 namespace ccc_amd
 {
 namespace ddpg
@@ -77,7 +98,20 @@ struct Lds
   double A1[G * LS];               // rows of T2 -> Cholesky factor -> Quu' -> T2'; rollout products
   double Qxu[S * LS];              // [a][r]
   double K[G * KS];                // [r][a]
-  double v[4][G];                  // published vectors
+  double v[8][G];                  // published vectors (see the SL_* slots)
+};
+
+// vector slots of Lds::v
+enum
+{
+  SL_T = 0, // terms of an ordered sum / scratch
+  SL_U,     // nominal inputs u_i of the step (box limits lo = flo - u, hi = fhi - u)
+  SL_X,     // box-QP iterate
+  SL_G,     // box-QP gradient
+  SL_R,     // right-hand side of the Newton step
+  SL_D,     // diagonal of the matrix being factorised; later t4 = Quu k
+  SL_RD,    // reciprocal diagonal of the Cholesky factor
+  SL_VX     // Vx (S entries); Qu during the value update
 };
 
 // structural non-zeros of the discrete-time Fx = I + dt dF/dx (oracle/ddp_models.c mdl_state_eq_deriv)
@@ -120,10 +154,23 @@ struct Group
 
   // per-lane constants
   double wrun_own, wterm_own;
+#if defined(CCC_DDPG_PROF)
+  double prof[16];
+#endif
 
+  // Lanes of a group talk through LDS.  One wavefront per workgroup, and the LDS serves the requests of a wavefront in
+  // order, so a write is visible to every later read of the same wavefront: a compiler-level barrier is all it takes
+  // (no s_barrier, no s_waitcnt on the outstanding global loads).
   __device__ __forceinline__ static void sync()
   {
-    __syncthreads(); // single-wavefront workgroups: orders this wavefront's LDS / global traffic
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // lanes talking through GLOBAL memory (trajectories written by the owner lanes, read by all): a real barrier
+  __device__ __forceinline__ static void gsync()
+  {
+    __syncthreads();
   }
   __device__ __forceinline__ unsigned gballot(bool p) const
   {
@@ -153,24 +200,24 @@ struct Group
     return TF + static_cast<long>(cb) * N * 3;
   }
 
-  // publish one value per lane, read all sixteen (uniform in the group afterwards)
-  __device__ __forceinline__ void share(int slot, double val, double (&out)[G])
+  // value of entry l of a vector every lane holds in full (v[k] uniform in the group)
+  __device__ __forceinline__ double own(const double (&v)[G]) const
   {
-    L.v[slot][l] = val;
-    sync();
+    double r = v[0];
 #pragma unroll
-    for(int k = 0; k < G; k++) out[k] = L.v[slot][k];
-    sync();
+    for(int k = 1; k < G; k++) r = (l == k) ? v[k] : r;
+    return r;
   }
-  // sum_{k < m} t_k in increasing k from 0 (the oracle's sequential sums), t published per lane
-  __device__ __forceinline__ double ordered_sum(int slot, double t, int m)
+  // sum_{k < m} t_k in increasing k from 0 (the oracle's sequential sums): the terms are published, every lane adds
+  __device__ __forceinline__ double ordered_sum(double t, int m)
   {
-    double f[G];
-    share(slot, t, f);
+    L.v[SL_T][l] = t;
+    sync();
     double s = 0.0;
 #pragma unroll
     for(int k = 0; k < G; k++)
-      if(k < m) s += f[k];
+      s += L.v[SL_T][k]; // entries >= m are zero
+    sync();
     return s;
   }
 
@@ -202,6 +249,8 @@ struct Group
   // Returns the trajectory cost (uniform in the group).  run: the group takes part (others execute masked, no stores).
   __device__ __forceinline__ double rollout(double alpha, int cb, bool run)
   {
+    const long long t_roll = DPROF_T();
+    DPROF_CNT(8);
     const bool initial = alpha < 0;
     const double * xs = xbuf(cb);
     const double * us = ubuf(cb);
@@ -276,7 +325,7 @@ struct Group
         const double * rowp = L.A1 + row * G;
 #pragma unroll
         for(int r = 0; r < G; r++)
-          if(r < m) acc += rowp[r];
+          acc += rowp[r]; // absent ridges carry u = 0
         L.v[0][l] = acc;
       }
       sync();
@@ -348,24 +397,23 @@ struct Group
       cost += cs;
     }
     sync();
+    DPROF_ADD(0, t_roll);
     return cost;
   }
 
   // ------------------------------------------------------------------------------------------ triangular solves
-  // t <- (L L')^-1 t with the factor of the group in LDS (strict lower triangle in A1, reciprocal diagonal in v[3]).
+  // t <- (L L')^-1 t with the factor of the group in LDS (strict lower triangle in A1, reciprocal diagonal in SL_RD).
   // Every lane works on its own right-hand side (all equal in the box-QP, one column of Qxu' per lane in the gains).
   __device__ __forceinline__ void solve(double (&t)[G]) const
   {
-    double rd[G];
-#pragma unroll
-    for(int k = 0; k < G; k++) rd[k] = L.v[3][k];
 #pragma unroll
     for(int a = 0; a < G; a++)
     {
       double s = t[a];
 #pragma unroll
       for(int k = 0; k < a; k++) s -= L.A1[a * LS + k] * t[k];
-      t[a] = s * rd[a];
+      t[a] = s * L.v[SL_RD][a];
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for(int a = G - 1; a >= 0; a--)
@@ -373,19 +421,22 @@ struct Group
       double s = t[a];
 #pragma unroll
       for(int k = G - 1; k > a; k--) s -= L.A1[k * LS + a] * t[k];
-      t[a] = s * rd[a];
+      t[a] = s * L.v[SL_RD][a];
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
   // Cholesky of H~ (H with clamped / absent rows and columns replaced by identity: the factor of H_ff embedded) into
-  // the LDS factor of the groups with `need`; returns false where a free pivot is not positive (oracle: result -1).
+  // the LDS factor of the groups with `need`; returns false where a pivot is not positive (oracle: result -1).
   // Left-looking, lane = row: at pivot a every lane reads row a (written by lane a at the earlier pivots), forms the
   // pivot redundantly and its own entry of column a -- the oracle's sums in the oracle's order.
   __device__ __forceinline__ bool cholesky(const double (&Hreg)[G], double hdiag, unsigned clmask, int m, bool need)
   {
+    const long long t_ch = DPROF_T();
+    DPROF_CNT(11);
     const bool mine_free = l < m && !((clmask >> l) & 1u);
-    double df[G];
-    share(2, mine_free ? hdiag : 1.0, df);
+    L.v[SL_D][l] = mine_free ? hdiag : 1.0;
+    sync();
     double Lrow[G];
     bool ok = true;
 #pragma unroll
@@ -395,7 +446,7 @@ struct Group
       double La[G];
 #pragma unroll
       for(int k = 0; k < a; k++) La[k] = L.A1[a * LS + k];
-      double d = df[a];
+      double d = L.v[SL_D][a];
 #pragma unroll
       for(int k = 0; k < a; k++) d -= La[k] * La[k];
       ok = ok && (d > 0.0);
@@ -406,46 +457,41 @@ struct Group
       for(int k = 0; k < a; k++) v -= Lrow[k] * La[k];
       v = v * rda;
       Lrow[a] = (l > a) ? v : 0.0;
-      if(need)
-      {
-        if(l > a) L.A1[l * LS + a] = Lrow[a];
-        if(l == 0) L.v[3][a] = rda;
-      }
+      if(need && l > a) L.A1[l * LS + a] = Lrow[a];
+      if(need && l == a) L.v[SL_RD][a] = rda;
       sync();
     }
+    DPROF_ADD(4, t_ch);
     return ok;
   }
 
   // ------------------------------------------------------------------------------------------ box-QP
-  // min 1/2 k'Hk + g'k, lo <= k <= hi (oracle_box_qp): H row l in Hreg (regularised), g_l = gl, limits from the
-  // published inputs uf, warm start kw_l.  Out: the solution in every lane (kf), the clamped set, the boxQP.m result.
-  __device__ __forceinline__ int box_qp(const double (&Hreg)[G], double hdiag, double gl, const double (&uf)[G], double kw,
-                                        int m, bool run, double (&kf)[G], unsigned & clmask_out)
+  // min 1/2 k'Hk + g'k, lo <= k <= hi (oracle_box_qp): H row l in Hreg (regularised), g_l = gl, limits from the nominal
+  // inputs in SL_U, warm start kw_l.  Out: the solution in SL_X (entries >= m zero), the clamped set, the boxQP.m
+  // result.  The iterate, the gradient and the right-hand side live in LDS slots; a lane holds its own entries.
+  __device__ __forceinline__ int box_qp(const double (&Hreg)[G], double hdiag, double gl, double kw, int m, bool run,
+                                        unsigned & clmask_out)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     const bool in = l < m;
     const unsigned inmask = m >= G ? 0xffffu : ((1u << m) - 1u);
-    auto lo_of = [&](int k) { return P.flo - uf[k]; };
-    auto hi_of = [&](int k) { return P.fhi - uf[k]; };
-    double ul = uf[0];
-#pragma unroll
-    for(int k = 1; k < G; k++) ul = (l == k) ? uf[k] : ul;
+    const double ul = L.v[SL_U][l];
     const double lo = P.flo - ul, hi = P.fhi - ul;
     double x = in ? fmin(fmax(kw, lo), hi) : 0.0;
-    double xf[G];
-    share(0, x, xf);
-    auto row_dot = [&](double s0, const double (&y)[G]) {
+    L.v[SL_X][l] = x;
+    sync();
+    auto row_dot = [&](double s0, int slot) {
       double s = s0;
 #pragma unroll
       for(int j = 0; j < G; j++)
-        if(j < m) s += Hreg[j] * y[j];
+        s += Hreg[j] * L.v[slot][j]; // row entries >= m are zero
       return s;
     };
     double value;
     {
-      const double s = row_dot(0.0, xf);
-      value = ordered_sum(1, x * gl + 0.5 * x * s, m);
+      const double s = row_dot(0.0, SL_X);
+      value = ordered_sum(x * gl + 0.5 * x * s, m);
     }
     double oldvalue = 0.0;
     bool cl = false;
@@ -457,114 +503,108 @@ struct Group
     for(; iter <= max_iter; iter++)
     {
       if(!wany(!fin)) break;
-      // ---- top of the oracle's loop
-      if(!fin && result != 0) fin = true;
-      if(!fin && iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
+      DPROF_CNT(10);
+      // ---- top of the oracle's loop (state changes as selects: the four instances differ only through masks)
+      fin = fin || (result != 0);
       {
-        result = 4;
-        fin = true;
+        const bool small = !fin && iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue);
+        result = small ? 4 : result;
+        fin = fin || small;
       }
-      if(!fin) oldvalue = value;
-      const double grad = row_dot(gl, xf);
+      oldvalue = fin ? oldvalue : value;
+      const double grad = row_dot(gl, SL_X);
       const bool ncl = in && ((x == lo && grad > 0) || (x == hi && grad < 0));
       const bool changed_l = !fin && (ncl != cl);
-      if(!fin) cl = ncl;
+      cl = fin ? cl : ncl;
       const bool changed = (iter == 1) || (gballot(changed_l) != 0u);
-      if(!fin) clmask = gballot(cl) & inmask;
-      if(!fin && clmask == inmask)
       {
-        result = 6;
-        fin = true;
+        const unsigned nm = gballot(cl) & inmask;
+        clmask = fin ? clmask : nm;
+      }
+      {
+        const bool all = !fin && clmask == inmask;
+        result = all ? 6 : result;
+        fin = fin || all;
       }
       const bool need = !fin && changed;
       if(wany(need))
       {
         const bool ok = cholesky(Hreg, hdiag, clmask, m, need);
-        if(need && !ok)
-        {
-          result = -1;
-          fin = true;
-        }
+        const bool bad = need && !ok;
+        result = bad ? -1 : result;
+        fin = fin || bad;
       }
-      double gf[G];
-      share(0, grad, gf);
-      if(!fin)
+      L.v[SL_G][l] = grad;
+      sync();
       {
         double gn = 0.0;
 #pragma unroll
         for(int k = 0; k < G; k++)
-          if(k < m && !((clmask >> k) & 1u)) gn += gf[k] * gf[k];
-        gn = sqrt(gn);
-        if(gn < min_grad)
         {
-          result = 5;
-          fin = true;
+          const double gk = L.v[SL_G][k];
+          gn += ((clmask >> k) & 1u) ? 0.0 : gk * gk;
         }
+        gn = sqrt(gn);
+        const bool tiny = !fin && gn < min_grad;
+        result = tiny ? 5 : result;
+        fin = fin || tiny;
       }
+      if(!wany(!fin)) break;
       // grad_clamped = g + H (x .* clamped) on the free rows, then the Newton step on the free set
       double gc = gl;
 #pragma unroll
       for(int j = 0; j < G; j++)
-        if(j < m && ((clmask >> j) & 1u)) gc += Hreg[j] * xf[j];
-      double t[G];
-      share(1, (in && !cl) ? gc : 0.0, t);
-      if(wany(!fin)) solve(t);
+        gc += ((clmask >> j) & 1u) ? Hreg[j] * L.v[SL_X][j] : 0.0;
+      L.v[SL_R][l] = (in && !cl) ? gc : 0.0;
+      sync();
       double srch[G];
 #pragma unroll
-      for(int k = 0; k < G; k++) srch[k] = (k < m && !((clmask >> k) & 1u)) ? -t[k] - xf[k] : 0.0;
+      for(int k = 0; k < G; k++) srch[k] = L.v[SL_R][k];
+      solve(srch);
+#pragma unroll
+      for(int k = 0; k < G; k++) srch[k] = (k < m && !((clmask >> k) & 1u)) ? -srch[k] - L.v[SL_X][k] : 0.0;
       double sdotg = 0.0;
 #pragma unroll
       for(int k = 0; k < G; k++)
-        if(k < m) sdotg += srch[k] * gf[k];
-      if(!fin && sdotg >= 0) fin = true; // no descent direction: result stays 0
+        sdotg += srch[k] * L.v[SL_G][k];
+      fin = fin || (sdotg >= 0); // no descent direction: result stays 0
       // ---- Armijo line search along the projected step
-      double step = 1.0, vc = value;
-      double xc[G];
-#pragma unroll
-      for(int k = 0; k < G; k++) xc[k] = xf[k];
+      const double srch_own = own(srch);
+      double step = 1.0, step_used = 1.0, vc = value;
       bool ls = !fin;
       while(wany(ls))
       {
+        DPROF_CNT(12);
         double cand[G];
 #pragma unroll
-        for(int k = 0; k < G; k++) cand[k] = (k < m) ? fmin(fmax(xf[k] + step * srch[k], lo_of(k)), hi_of(k)) : 0.0;
-        double cl_own = cand[0];
-#pragma unroll
-        for(int k = 1; k < G; k++) cl_own = (l == k) ? cand[k] : cl_own;
-        const double s = row_dot(0.0, cand);
-        const double v = ordered_sum(1, cl_own * gl + 0.5 * cl_own * s, m);
-        if(ls)
+        for(int k = 0; k < G; k++)
         {
-          vc = v;
-#pragma unroll
-          for(int k = 0; k < G; k++) xc[k] = cand[k];
-          if(!((vc - oldvalue) / (step * sdotg) < armijo))
-            ls = false;
-          else
-          {
-            step *= step_dec;
-            if(step < min_step)
-            {
-              result = 2;
-              ls = false;
-            }
-          }
+          const double uk = L.v[SL_U][k];
+          cand[k] = (k < m) ? fmin(fmax(L.v[SL_X][k] + step * srch[k], P.flo - uk), P.fhi - uk) : 0.0;
         }
+        const double c_own = own(cand);
+        double s = 0.0;
+#pragma unroll
+        for(int j = 0; j < G; j++) s += Hreg[j] * cand[j];
+        const double v = ordered_sum(c_own * gl + 0.5 * c_own * s, m);
+        vc = ls ? v : vc;
+        step_used = ls ? step : step_used;
+        const bool stop = !((v - oldvalue) / (step * sdotg) < armijo);
+        const double nstep = step * step_dec;
+        const bool under = nstep < min_step;
+        result = (ls && !stop && under) ? 2 : result;
+        step = (ls && !stop) ? nstep : step;
+        ls = ls && !stop && !under;
       }
-      if(!fin)
       {
-#pragma unroll
-        for(int k = 0; k < G; k++) xf[k] = xc[k];
-        double xo = xc[0];
-#pragma unroll
-        for(int k = 1; k < G; k++) xo = (l == k) ? xc[k] : xo;
-        x = xo;
-        value = vc;
+        const double xn = in ? fmin(fmax(x + step_used * srch_own, lo), hi) : 0.0; // the accepted candidate (same expression)
+        x = fin ? x : xn;
+        value = fin ? value : vc;
       }
+      L.v[SL_X][l] = x;
+      sync();
     }
     if(!fin && iter > max_iter && result == 0) result = 1;
-#pragma unroll
-    for(int k = 0; k < G; k++) kf[k] = xf[k];
     clmask_out = clmask;
     return result;
   }
@@ -574,17 +614,17 @@ struct Group
   // larger lambda).  dV0 / dV1: the expected-reduction terms; the per-step terms of the gradient norm go to gm.
   __device__ __forceinline__ bool backward_pass(int cb, double lambda, bool act, double & dV0_out, double & dV1_out)
   {
+    const long long t_bw = DPROF_T();
+    DPROF_CNT(9);
     const double * xs = xbuf(cb);
     const double * us = ubuf(cb);
     const double * tfs = tfbuf(cb);
     bool ok = true;
     double dV0 = 0.0, dV1 = 0.0;
-    // terminal value (src/DdpCentroidal.cpp:156-177 at x_N)
-    double Vx[S];
-#pragma unroll
-    for(int a = 0; a < S; a++) Vx[a] = P.w_term[a] * (xs[static_cast<long>(N) * S + a] - ref_entry(N, a));
+    // terminal value (src/DdpCentroidal.cpp:156-177 at x_N): Vx in SL_VX, Vxx in LDS
     if(l < S)
     {
+      L.v[SL_VX][l] = wterm_own * (xs[static_cast<long>(N) * S + l] - ref_entry(N, l));
 #pragma unroll
       for(int a = 0; a < S; a++) L.Vxx[a * S + l] = (a == l) ? wterm_own : 0.0;
     }
@@ -594,23 +634,25 @@ struct Group
     int m_next = -1;
     for(int i = N - 1; i >= 0; i--)
     {
+      const long long t_s0 = DPROF_T();
       load_contact(i, c);
       const int m = c.m;
       const bool in = l < m;
       const bool run = act && ok;
-      double x[S];
-#pragma unroll
-      for(int a = 0; a < S; a++) x[a] = xs[static_cast<long>(i) * S + a];
       const double u = in ? us[static_cast<long>(i) * G + l] : 0.0;
-      double tf[3];
-#pragma unroll
-      for(int a = 0; a < 3; a++) tf[a] = tfs[static_cast<long>(i) * 3 + a];
-      double uf[G];
-      share(0, u, uf);
+      L.v[SL_U][l] = u;
       // ---- derivatives at (x_i, u_i): column l of Fu (rows R0..R0+5), the sparse Fx (uniform in the group)
       double fu[6];
       double FX[S][S];
+      double x_own, Qx_own, Qu;
+      double T1c[S], T2c[S];
       {
+        double x[S];
+#pragma unroll
+        for(int a = 0; a < S; a++) x[a] = xs[static_cast<long>(i) * S + a];
+        double tf[3];
+#pragma unroll
+        for(int a = 0; a < 3; a++) tf[a] = tfs[static_cast<long>(i) * 3 + a];
         const double d[3] = {c.V[0] - x[0], c.V[1] - x[1], c.V[2] - x[2]};
         double cr[3];
         ddp::cross3(d, c.R, cr);
@@ -696,6 +738,9 @@ struct Group
             }
           }
         }
+        x_own = x[0];
+#pragma unroll
+        for(int a = 1; a < S; a++) x_own = (l == a) ? x[a] : x_own;
       }
       // column l of Fx (dense, zeros included) for the lanes that own a state entry
       double fxcol[S];
@@ -708,18 +753,14 @@ struct Group
           if(fx_nz<S>(k, b)) v = (l == b) ? FX[k][b] : v;
         fxcol[k] = v;
       }
-      double x_own = x[0];
-#pragma unroll
-      for(int a = 1; a < S; a++) x_own = (l == a) ? x[a] : x_own;
       // ---- Qx (lane a), Qu (lane r)
-      double Qx_own = wrun_own * (x_own - ref_entry(i, l < S ? l : 0));
+      Qx_own = wrun_own * (x_own - ref_entry(i, l < S ? l : 0));
 #pragma unroll
-      for(int b = 0; b < S; b++) Qx_own += fxcol[b] * Vx[b];
-      double Qu = in ? P.w_force * u : 0.0;
+      for(int b = 0; b < S; b++) Qx_own += fxcol[b] * L.v[SL_VX][b];
+      Qu = in ? P.w_force * u : 0.0;
 #pragma unroll
-      for(int j = 0; j < 6; j++) Qu += fu[j] * Vx[R0 + j];
+      for(int j = 0; j < 6; j++) Qu += fu[j] * L.v[SL_VX][R0 + j];
       // ---- T1 = Vxx Fx (column l), T2 = Vxx Fu (column l)
-      double T1c[S], T2c[S];
 #pragma unroll
       for(int a = 0; a < S; a++)
       {
@@ -733,10 +774,10 @@ struct Group
         }
         T1c[a] = s1;
         T2c[a] = s2;
+        __builtin_amdgcn_sched_barrier(0);
       }
       sync(); // Vxx is consumed: its block now parks the columns of Qxx
-      // ---- Qxx column l, Qxu column l
-      double Qxuc[S];
+      // ---- Qxx column l (parked in LDS), Qxu column l (to LDS: the gains read its rows)
 #pragma unroll
       for(int a = 0; a < S; a++)
       {
@@ -750,7 +791,6 @@ struct Group
             sx += FX[k][a] * T2c[k];
           }
         if(l < S) L.Vxx[a * S + l] = s;
-        Qxuc[a] = sx;
         L.Qxu[a * LS + l] = sx;
       }
       // ---- rows R0..R0+5 of T2 published, row l of Quu
@@ -768,43 +808,39 @@ struct Group
         s = (in && q < m) ? s : 0.0;
         quu_own = (l == q) ? s : quu_own;
         Hreg[q] = (l == q) ? s + lambda : s; // reg_type 1: Quu_F = Quu + lambda I
+        if((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       const double hdiag = quu_own + lambda;
       sync(); // the T2 rows are consumed: A1 becomes the Cholesky factor
-      // ---- box-QP for the feed-forward term k
-      double kf[G];
+      DPROF_ADD(2, t_s0);
+      const long long t_s1 = DPROF_T();
+      // ---- box-QP for the feed-forward term k (result in SL_X)
       unsigned clmask = 0;
       const bool warm = (i + 1 < N) && (m_next == m);
       int rc = 1;
       if(wany(run && m > 0))
-        rc = box_qp(Hreg, hdiag, Qu, uf, warm ? kprev : 0.0, m, run && m > 0, kf, clmask);
+        rc = box_qp(Hreg, hdiag, Qu, warm ? kprev : 0.0, m, run && m > 0, clmask);
       else
       {
-#pragma unroll
-        for(int k = 0; k < G; k++) kf[k] = 0.0;
+        L.v[SL_X][l] = 0.0;
+        sync();
       }
-      if(m == 0)
-      {
-#pragma unroll
-        for(int k = 0; k < G; k++) kf[k] = 0.0;
-        clmask = 0;
-      }
+      if(m == 0) clmask = 0;
       if(run && m > 0 && rc < 1) ok = false;
-      double k_own = kf[0];
-#pragma unroll
-      for(int k = 1; k < G; k++) k_own = (l == k) ? kf[k] : k_own;
+      const double k_own = L.v[SL_X][l];
+      DPROF_ADD(3, t_s1);
+      const long long t_s2 = DPROF_T();
       // ---- gains: K_f = -Quu_F,ff^-1 Qxu_f', one right-hand side (state entry l) per lane
       double QxuRow[G], Kc[G];
       {
         const int a = l < S ? l : 0;
 #pragma unroll
         for(int r = 0; r < G; r++) QxuRow[r] = L.Qxu[a * LS + r];
-        double t[G];
 #pragma unroll
-        for(int r = 0; r < G; r++) t[r] = (r < m && !((clmask >> r) & 1u)) ? QxuRow[r] : 0.0;
-        if(wany(run && m > 0)) solve(t);
+        for(int r = 0; r < G; r++) Kc[r] = (r < m && !((clmask >> r) & 1u)) ? QxuRow[r] : 0.0;
+        if(wany(run && m > 0)) solve(Kc);
 #pragma unroll
-        for(int r = 0; r < G; r++) Kc[r] = (r < m && !((clmask >> r) & 1u)) ? -t[r] : 0.0;
+        for(int r = 0; r < G; r++) Kc[r] = (r < m && !((clmask >> r) & 1u)) ? -Kc[r] : 0.0;
         if(l < S)
         {
 #pragma unroll
@@ -823,46 +859,39 @@ struct Group
         }
         if(wr) ks[static_cast<long>(i) * G + l] = k_own;
       }
+      DPROF_ADD(5, t_s2);
+      const long long t_s3 = DPROF_T();
       // term of the gradient-norm test: max_r |k_r| / (|u_r| + 1)
       {
         double mx = 0.0;
 #pragma unroll
         for(int r = 0; r < G; r++)
-          if(r < m)
-          {
-            const double v = fabs(kf[r]) / (fabs(uf[r]) + 1.0);
-            if(v > mx) mx = v;
-          }
+        {
+          const double v = fabs(L.v[SL_X][r]) / (fabs(L.v[SL_U][r]) + 1.0); // zero for absent ridges
+          mx = (v > mx) ? v : mx;
+        }
         if(wr && l == 0) gm[i] = mx;
       }
-      // ---- t4 = Quu k, dV, Vx
-      double t4 = 0.0;
-#pragma unroll
-      for(int q = 0; q < G; q++)
-        if(q < m) t4 += ((l == q) ? quu_own : Hreg[q]) * kf[q];
-      L.v[1][l] = t4;
-      L.v[2][l] = Qu;
-      // Quu row l -> LDS for the transposition (A1 is free: the factor is consumed)
-#pragma unroll
-      for(int q = 0; q < G; q++) L.A1[l * LS + q] = (l == q) ? quu_own : Hreg[q];
-      sync();
-      double t4f[G], quf[G], QC[G];
-#pragma unroll
-      for(int r = 0; r < G; r++)
+      // ---- t4 = Quu k (SL_D), Qu (SL_VX: Vx is consumed), row l of Quu to LDS for the transposition
       {
-        t4f[r] = L.v[1][r];
-        quf[r] = L.v[2][r];
-        QC[r] = L.A1[r * LS + l];
+        double t4 = 0.0;
+#pragma unroll
+        for(int q = 0; q < G; q++)
+          t4 += ((l == q) ? quu_own : Hreg[q]) * L.v[SL_X][q];
+        L.v[SL_D][l] = t4;
+        L.v[SL_VX][l] = Qu;
+#pragma unroll
+        for(int q = 0; q < G; q++) L.A1[l * LS + q] = (l == q) ? quu_own : Hreg[q];
       }
+      sync();
       {
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for(int r = 0; r < G; r++)
-          if(r < m)
-          {
-            s0 += kf[r] * quf[r];
-            s1 += kf[r] * t4f[r];
-          }
+        {
+          s0 += L.v[SL_X][r] * L.v[SL_VX][r];
+          s1 += L.v[SL_X][r] * L.v[SL_D][r];
+        }
         if(run)
         {
           dV0 += s0;
@@ -872,22 +901,27 @@ struct Group
       double Vx_own = Qx_own;
 #pragma unroll
       for(int r = 0; r < G; r++)
-        if(r < m) Vx_own += Kc[r] * t4f[r] + Kc[r] * quf[r] + QxuRow[r] * kf[r];
+        Vx_own += Kc[r] * L.v[SL_D][r] + Kc[r] * L.v[SL_VX][r] + QxuRow[r] * L.v[SL_X][r];
       // ---- T2' = K'Quu (column l)
       double T2p[S];
-#pragma unroll
-      for(int a = 0; a < S; a++)
       {
-        double s = 0.0;
+        double QC[G];
 #pragma unroll
-        for(int q = 0; q < G; q++)
-          if(q < m) s += L.K[q * KS + a] * QC[q];
-        T2p[a] = s;
+        for(int r = 0; r < G; r++) QC[r] = L.A1[r * LS + l];
+#pragma unroll
+        for(int a = 0; a < S; a++)
+        {
+          double s = 0.0;
+#pragma unroll
+          for(int q = 0; q < G; q++)
+            s += L.K[q * KS + a] * QC[q];
+          T2p[a] = s;
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       sync(); // every lane has its column of Quu: A1 takes T2'
 #pragma unroll
       for(int a = 0; a < S; a++) L.A1[a * G + l] = T2p[a];
-      L.v[0][l] = Vx_own;
       sync();
       // ---- Vxx = sym(Qxx + K'Quu K + K'Qxu' + Qxu K): column l of the sum, then the transposition through LDS
       double Tc[S];
@@ -897,12 +931,10 @@ struct Group
         double s = (l < S) ? L.Vxx[a * S + l] : 0.0;
 #pragma unroll
         for(int r = 0; r < G; r++)
-          if(r < m) s += L.A1[a * G + r] * Kc[r] + L.K[r * KS + a] * QxuRow[r] + L.Qxu[a * LS + r] * Kc[r];
+          s += L.A1[a * G + r] * Kc[r] + L.K[r * KS + a] * QxuRow[r] + L.Qxu[a * LS + r] * Kc[r];
         Tc[a] = s;
+        __builtin_amdgcn_sched_barrier(0);
       }
-      double Vxn[S];
-#pragma unroll
-      for(int a = 0; a < S; a++) Vxn[a] = L.v[0][a];
       if(l < S)
       {
 #pragma unroll
@@ -917,18 +949,16 @@ struct Group
       {
 #pragma unroll
         for(int a = 0; a < S; a++) L.Vxx[a * S + l] = 0.5 * (Tc[a] + Tr[a]);
-      }
-      if(run)
-      {
-#pragma unroll
-        for(int a = 0; a < S; a++) Vx[a] = Vxn[a];
+        L.v[SL_VX][l] = Vx_own;
       }
       kprev = k_own;
       m_next = m;
       sync();
+      DPROF_ADD(6, t_s3);
     }
     dV0_out = dV0;
     dV1_out = dV1;
+    DPROF_ADD(1, t_bw);
     return ok;
   }
 
@@ -947,11 +977,17 @@ struct Group
       wrun_own = wr;
       wterm_own = wt;
     }
+#if defined(CCC_DDPG_PROF)
+#pragma unroll
+    for(int k = 0; k < 16; k++) prof[k] = 0.0;
+    const long long t_all = DPROF_T();
+#endif
     double lambda = P.lambda0, dlambda = P.dlambda0;
     int cb = 0;
-    double cost = rollout(-1.0, cb, true);
+    double cost = 0.0;
     int it = 1, status = 0;
-    bool done = P.max_iter < 1;
+    bool done = false;
+    bool first = true; // the rollout of the initial inputs runs through the line-search slot of the first round
     auto increase = [&]() {
       dlambda = fmax(dlambda * P.lambda_factor, P.lambda_factor);
       lambda = fmax(lambda * dlambda, P.lambda_min);
@@ -960,49 +996,56 @@ struct Group
       dlambda = fmin(dlambda / P.lambda_factor, 1.0 / P.lambda_factor);
       lambda = lambda * dlambda * (lambda > P.lambda_min ? 1.0 : 0.0);
     };
-    while(wany(!done))
+    while(first || wany(!done))
     {
-      const bool act = !done;
+      const bool act = !first && !done;
       double dV0 = 0.0, dV1 = 0.0;
-      const bool ok = backward_pass(cb, lambda, act, dV0, dV1);
-      sync();
+      bool ok = true;
       bool searching = false;
-      if(act)
+      if(!first)
       {
-        if(!ok)
+        ok = backward_pass(cb, lambda, act, dV0, dV1);
+        gsync();
+        if(act)
         {
-          increase();
-          if(lambda > P.lambda_max)
+          if(!ok)
           {
-            status = -1;
-            done = true;
-          }
-        }
-        else
-        {
-          double gsum = 0.0;
-          for(int i = 0; i < N; i++) gsum += gm[i];
-          gsum = gsum / N;
-          if(gsum < P.k_rel_norm_thre && lambda < P.lambda_thre)
-          {
-            decrease();
-            status = 1;
-            done = true;
+            increase();
+            if(lambda > P.lambda_max)
+            {
+              status = -1;
+              done = true;
+            }
           }
           else
-            searching = true;
+          {
+            double gsum = 0.0;
+            for(int i = 0; i < N; i++) gsum += gm[i];
+            gsum = gsum / N;
+            if(gsum < P.k_rel_norm_thre && lambda < P.lambda_thre)
+            {
+              decrease();
+              status = 1;
+              done = true;
+            }
+            else
+              searching = true;
+          }
         }
       }
-      // ---- line search over alpha_list
+      // ---- line search over alpha_list (first round: the one rollout of the initial inputs)
       bool accepted = false;
       double actual = 0.0, costc = 0.0;
       for(int a = 0; a < 11; a++)
       {
-        const bool go = searching && !accepted;
+        const bool go = first ? (a == 0) : (searching && !accepted);
         if(!wany(go)) break;
-        const double alpha = P.alpha[a];
+        const double alpha = first ? -1.0 : P.alpha[a];
         const double cc = rollout(alpha, cb, go);
-        if(go)
+        gsync();
+        if(first)
+          cost = cc;
+        else if(go)
         {
           costc = cc;
           actual = cost - costc;
@@ -1010,6 +1053,12 @@ struct Group
           const double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
           if(ratio > P.ratio_thre) accepted = true;
         }
+      }
+      if(first)
+      {
+        first = false;
+        done = P.max_iter < 1;
+        continue;
       }
       if(searching)
       {
@@ -1039,7 +1088,6 @@ struct Group
         it++;
         if(it > P.max_iter) done = true;
       }
-      sync();
     }
     if(it > P.max_iter) it = P.max_iter;
     // ---- outputs: the current trajectory
@@ -1058,12 +1106,18 @@ struct Group
         if(out_status) *out_status = status;
         if(out_cost) *out_cost = cost;
       }
+#if defined(CCC_DDPG_PROF)
+      prof[7] = (double)(DPROF_T() - t_all);
+      if(l == 0)
+#pragma unroll
+        for(int k = 0; k < 16; k++) u_out[k] = prof[k]; // a profiling build returns timings INSTEAD of a plan
+#endif
     }
   }
 };
 
 template<int S>
-__global__ __launch_bounds__(64, 2) void ddp_group_kernel(Params P, Batch B, long n)
+__global__ __launch_bounds__(64, 1) void ddp_group_kernel(Params P, Batch B, long n)
 {
   __shared__ Lds<S> lds[4];
   const int lane = static_cast<int>(threadIdx.x), g = lane >> 4, l = lane & 15;

@@ -194,6 +194,25 @@ def test_srb_reference_closed_loop_through_planonce():
     assert np.linalg.norm(sim.vel) < 0.1 and np.linalg.norm(sim.ang_vel) < 0.1
 
 
+@pytest.mark.parametrize("srb", [False, True])
+def test_group_kernel_matches_the_oracle_bit_for_bit(monkeypatch, srb):
+    """CCC_DDP_GROUP=1: the kernel with one instance per 16-lane group, four per wavefront (csrc/ddp_group.h; kept as an
+    opt-in, it is slower than the wavefront-per-instance kernel on MI355X -- DESIGN.md section 7).  Same specification,
+    same bits: force scales, states, cost, iteration count and status on a batch that is not a multiple of four, with a
+    warm start as well."""
+    monkeypatch.setenv("CCC_DDP_GROUP", "1")
+    N, dt, n = (50, 0.03, 203) if srb else (100, 0.03, 131)
+    prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=17, srb=srb)
+    o = _oracle().Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20)
+    d = (_srb if srb else _cen)(N, dt, 20)
+    ro = o.plan_batch(prob, x0, nthreads=8)
+    rg = d.planOnceBatch(prob, x0, want_x=True)
+    _assert_bitwise(rg, ro, ("u", "x", "cost", "iters", "status"))
+    d.ddp_solver_.config().max_iter = 1
+    o1 = _oracle().Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=1)
+    _assert_bitwise(d.planOnceBatch(prob, x0 + 0.01, u_init=rg["u"]), o1.plan_batch(prob, x0 + 0.01, u_init=ro["u"]))
+
+
 def test_device_entry_and_determinism():
     import torch
 
