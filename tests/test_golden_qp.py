@@ -1,0 +1,65 @@
+"""Known answers for LinearMpcXY / IntrinsicallyStableMpc / LinearMpcZ from an independent construction and solver
+(tests/golden/make_golden_qp.py: model by scipy.linalg.expm + simulation, primal active set on dense KKT systems,
+long-double polish, KKT certificate).  Here the CPU oracle is checked against them; the `-m gpu` tests check the HIP
+kernels against the same vectors (tests/test_xy_gpu.py, test_ism_gpu.py, test_z_gpu.py)."""
+import os
+
+import numpy as np
+
+from oracle import oracle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def xy_cases():
+    g = np.load(os.path.join(GOLD, "xy_golden.npz"))
+    for tag, N in (("n20", 20), ("n15", 15)):
+        prob = {k: g["%s_%s" % (tag, k)] for k in ("dim", "vertex", "ridge", "com_z", "total_force_z", "ref_out")}
+        yield tag, N, prob, g[tag + "_x0"], g[tag + "_lambda"], g[tag + "_cert"]
+
+
+def test_golden_certificates():
+    """The stored answers satisfy the KKT conditions of their QP (residuals written by the generator)."""
+    for tag, N, prob, x0, lam, cert in xy_cases():
+        assert cert.max() <= 1e-12 * 1e3  # stationarity / equality / bounds / multiplier signs, forces of order 1e2..1e3
+        dims = prob["dim"]
+        for k in range(len(x0)):
+            for i in range(N):
+                m = dims[k, i]
+                if m:
+                    assert abs(lam[k, i, :m] @ prob["ridge"][k, i, :m, 2] - prob["total_force_z"][k, i]) < 1e-9
+                    assert lam[k, i, :m].min() >= 3.0 - 1e-12
+                assert np.all(lam[k, i, m:] == 0.0)
+
+
+def test_oracle_xy_against_golden():
+    """The oracle factorises the condensed H (condition number 1e6..1e7) in double: 1e-5..1e-6 absolute on force scales
+    of a few hundred -- the golden vectors are the sharper yardstick, the kernels are held to
+    1e-9 against them."""
+    for tag, N, prob, x0, lam_g, _ in xy_cases():
+        o = oracle.LinearMpcXY(100.0, 0.1, N).plan_batch(prob, x0, nthreads=4, want_all=True)
+        for k in range(len(x0)):
+            c = 0
+            for s in range(N):
+                m = prob["dim"][k, s]
+                ref = lam_g[k, s, :m]
+                assert np.abs(o["lam"][k, c:c + m] - ref).max(initial=0.0) <= 1e-6 * np.abs(lam_g[k]).max()
+                c += m
+
+
+def test_oracle_ism_against_golden():
+    g = np.load(os.path.join(GOLD, "ism_golden.npz"))
+    for tag, N, hd in (("n100", 100, 2.0), ("n20", 20, 0.4)):
+        ok = g[tag + "_ok"].astype(bool)
+        assert ok.sum() >= 16
+        o = oracle.IntrinsicallyStableMpc(1.0, hd, hd / N).plan_batch(g[tag + "_init"], g[tag + "_ref"], 0.005)
+        assert np.abs(o["zmp"] - g[tag + "_zmp"])[ok].max() <= 1e-12
+        assert np.abs(o["vel"] - g[tag + "_vel"])[ok].max() <= 1e-9 * max(1.0, np.abs(g[tag + "_vel"]).max())
+
+
+def test_oracle_z_against_golden():
+    g = np.load(os.path.join(GOLD, "z_golden.npz"))
+    for tag, N, dt in (("n40", 40, 0.05), ("n12", 12, 0.1)):
+        o = oracle.LinearMpcZ(100.0, dt, N).plan_batch(g[tag + "_contact"], g[tag + "_ref_pos"], g[tag + "_x0"])
+        scale = np.maximum(1.0, np.abs(g[tag + "_force"]))
+        assert (np.abs(o["force"] - g[tag + "_force"]) / scale).max() <= 1e-10

@@ -97,6 +97,20 @@ def test_device_entry_and_determinism():
     assert np.array_equal(mpc.planOnceBatch(b["init"], b["ref"], 0.005)["zmp"], z1.cpu().numpy())
 
 
+def test_against_golden_vectors():
+    """tests/golden/ism_golden.npz (make_golden_qp.py: the QP of src/IntrinsicallyStableMpc.cpp:8-104 built with numpy,
+    solved in the ZMP-position variables by a primal active set, polished in long double with a KKT certificate):
+    planned ZMP within 1e-12, the whole ZMP-velocity sequence within 1e-8 relative."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ism_golden.npz"))
+    for tag, N, hd in (("n100", 100, 2.0), ("n20", 20, 0.4)):
+        ok = g[tag + "_ok"].astype(bool)
+        r = IntrinsicallyStableMpc(1.0, hd, hd / N).planOnceBatch(g[tag + "_init"], g[tag + "_ref"], 0.005, want_vel=True)
+        assert np.abs(r["zmp"] - g[tag + "_zmp"])[ok].max() <= 1e-12
+        assert np.abs(r["vel"] - g[tag + "_vel"])[ok].max() <= 1e-8 * max(1.0, np.abs(g[tag + "_vel"]).max())
+
+
 def test_cpp_header_shim_matches_python_mirror():
     """Host C++ against include/CCC/IntrinsicallyStableMpc.h (examples/plan_once_intrinsically_stable_mpc.cpp): same
     kernel, same sampled inputs as the Python mirror -> identical planned ZMPs, for planOnce and planOnceBatch."""

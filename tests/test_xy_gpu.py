@@ -45,6 +45,25 @@ def _compare(prob, r, o, N):
         assert abs(fg[2] - prob["total_force_z"][k, 0]) <= 1e-10 * prob["total_force_z"][k, 0]
 
 
+def test_against_golden_vectors():
+    """tests/golden/xy_golden.npz (make_golden_qp.py: independent model construction, primal active set, long-double KKT
+    polish with a certificate): every force scale of the whole horizon within 1e-9 of the largest one of the instance --
+    a hundred times tighter than what the oracle itself achieves against these vectors (5e-8: it factorises the condensed
+    Hessian in double), which is why the golden vectors and not the oracle are the yardstick of this class."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xy_golden.npz"))
+    for tag, N in (("n20", 20), ("n15", 15)):
+        prob = {k: g["%s_%s" % (tag, k)] for k in ("dim", "vertex", "ridge", "com_z", "total_force_z", "ref_out")}
+        x0, lam = g[tag + "_x0"], g[tag + "_lambda"]
+        r = LinearMpcXY(100.0, 0.1, N).planOnceBatch(prob, x0, want_all=True)
+        assert np.all(r["status"] == 0)
+        scale = np.abs(lam).reshape(len(x0), -1).max(axis=1)
+        err = np.abs(r["lam"] - lam).reshape(len(x0), -1).max(axis=1)
+        assert (err / scale).max() <= 1e-9, (tag, (err / scale).max())
+        assert np.array_equal(r["u0"], r["lam"][:, 0, :])
+
+
 @pytest.mark.parametrize("N,dt", [(15, 0.1), (20, 0.1)])
 def test_parity_with_oracle(N, dt):
     """N = 15: the reference test's horizon (TestLinearMpcXY.cpp:17-19); N = 20: BASELINE.json configs[3]."""

@@ -57,6 +57,22 @@ def test_parity_with_oracle(N, dt, n):
     assert r["force_all"][act].min() >= 10.0 - 1e-9 and r["force_all"][act].max() <= 10.0 * mass * fx.G + 1e-6
 
 
+def test_against_golden_vectors():
+    """tests/golden/z_golden.npz (make_golden_qp.py: both phase models through scipy.linalg.expm, the condensed QP by
+    simulation, primal active set + long-double polish with a KKT certificate): the planned force and the whole force
+    sequence within 1e-9 relative (the oracle agrees with these vectors to 6e-13)."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "z_golden.npz"))
+    for tag, N, dt in (("n40", 40, 0.05), ("n12", 12, 0.1)):
+        r = LinearMpcZ(100.0, dt, N).planOnceBatch(g[tag + "_contact"], g[tag + "_ref_pos"], g[tag + "_x0"], want_all=True)
+        assert np.all(r["status"] == 0)
+        scale = np.maximum(1.0, np.abs(g[tag + "_force_all"]).max(axis=1))
+        assert (np.abs(r["force"] - g[tag + "_force"]) / scale).max() <= 1e-9
+        started = g[tag + "_contact"][:, 0] != 0  # no contact now -> the reference returns 0 without solving
+        assert (np.abs(r["force_all"] - g[tag + "_force_all"])[started].max(axis=1) / scale[started]).max() <= 1e-9
+
+
 def test_non_default_weights():
     mass, dt, N = 60.0, 0.04, 32
     b = fx.make_z_batch(96, N, dt, seed=10)
