@@ -25,6 +25,13 @@ CCC_STATUS_MAX_ITER = 2
 
 # every symbol include/ccc_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
+    "ccc_shard_bounds",
+    "ccc_device_count",
+    "ccc_zmp_sharded_create",
+    "ccc_zmp_sharded_destroy",
+    "ccc_zmp_sharded_num_devices",
+    "ccc_zmp_sharded_plan_batch",
+    "ccc_zmp_sharded_plan_batch_device",
     "ccc_last_error_string",
     "ccc_abi_version",
     "ccc_zmp_create",

@@ -63,5 +63,18 @@ extern "C" const char * ccc_last_error_string(void)
 
 extern "C" int ccc_abi_version(void)
 {
-  return 1;
+  return 2; // 2: ccc_ddp_config_t::reg_type, sharded entry points, ccc_device_count
+}
+
+extern "C" int ccc_device_count(void)
+{
+  int count = 0;
+  if(hipGetDeviceCount(&count) != hipSuccess) return 0;
+  int ok = 0;
+  for(int d = 0; d < count; d++)
+  {
+    hipDeviceProp_t prop;
+    if(hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+  }
+  return ok;
 }

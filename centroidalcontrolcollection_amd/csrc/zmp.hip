@@ -1704,7 +1704,7 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
   int rc = ensure_staging(h, n);
   if(rc != CCC_OK) return rc;
   const size_t N = (size_t)h->N;
-  const size_t nx = (size_t)n * 6, nl = (size_t)n * 4 * N, nz = (size_t)n * 2, nj = (size_t)n * 2 * N;
+  const size_t nx = (size_t)n * 6, nz = (size_t)n * 2, nj = (size_t)n * 2 * N;
   const bool in_pinned = is_pinned_host(x0) && is_pinned_host(zlim);
   const bool out_pinned = is_pinned_host(zmp) && (!jerk || is_pinned_host(jerk)) && (!status || is_pinned_host(status));
   // chunks small enough for the static-pairing kernel (the work-queue kernel keeps per-handle counters: two launches of

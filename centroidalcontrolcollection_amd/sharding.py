@@ -57,3 +57,73 @@ def plan_sharded(solve_local, x0, zlim, group=None):
     s, e = shard_bounds(n, world)[rank]
     local = solve_local(x0[s:e], zlim[s:e])
     return all_gather_outputs(local, n, group)
+
+
+class ShardedLinearMpcZmp:
+    """The C-ABI's own multi-GPU path (include/ccc_amd.h "One node, several GPUs", csrc/sharded.hip) for a host that is
+    ONE process -- what a C++ controller linking libccc_amd.so gets: contiguous shards over a device list, one
+    ccc_zmp_t per device, host arrays in / out (`planOnceBatch`) or device-resident shards with an RCCL all-gather of the
+    planned ZMPs onto every device (`plan_batch_device`).  (torch.distributed, above, is the one-process-per-GPU path the
+    benchmark driver uses.)"""
+
+    def __init__(self, com_height, horizon_duration, horizon_dt, devices):
+        import ctypes
+
+        from . import _lib
+
+        self._ct, self._lib = ctypes, _lib
+        L = _lib.load()
+        vp, dp = ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)
+        L.ccc_zmp_sharded_create.restype = ctypes.c_int
+        L.ccc_zmp_sharded_create.argtypes = [ctypes.c_double] * 3 + [ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                                     ctypes.POINTER(vp)]
+        L.ccc_zmp_sharded_destroy.restype = None
+        L.ccc_zmp_sharded_destroy.argtypes = [vp]
+        L.ccc_zmp_sharded_plan_batch.restype = ctypes.c_int
+        L.ccc_zmp_sharded_plan_batch.argtypes = [vp, ctypes.c_int64, dp, dp, ctypes.c_double, dp,
+                                                 ctypes.POINTER(ctypes.c_int32)]
+        L.ccc_zmp_sharded_plan_batch_device.restype = ctypes.c_int
+        L.ccc_zmp_sharded_plan_batch_device.argtypes = [vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                        ctypes.c_double, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        self._L = L
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = vp()
+        _lib.check(L.ccc_zmp_sharded_create(float(com_height), float(horizon_duration), float(horizon_dt), arr,
+                                            len(self.devices), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.ccc_zmp_sharded_destroy(h)
+            self._h = None
+
+    def planOnceBatch(self, x0, zlim, control_dt=-1.0):
+        """Host arrays x0 [n,2,3], zlim [n,2,2,N] -> dict(zmp [n,2], status [n,2], pivots [n,2])."""
+        import numpy as np
+
+        ct = self._ct
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        zlim = np.ascontiguousarray(zlim, dtype=np.float64)
+        n = x0.shape[0]
+        zmp = np.empty((n, 2))
+        status = np.empty((n, 2), dtype=np.int32)
+        dp = ct.POINTER(ct.c_double)
+        self._lib.check(self._L.ccc_zmp_sharded_plan_batch(self._h, n, x0.ctypes.data_as(dp), zlim.ctypes.data_as(dp),
+                                                            float(control_dt), zmp.ctypes.data_as(dp),
+                                                            status.ctypes.data_as(ct.POINTER(ct.c_int32))))
+        return dict(zmp=zmp, status=status & 0xff, pivots=status >> 8)
+
+    def plan_batch_device(self, x0, zlim, control_dt, zmp_all, status=None):
+        """Lists (one CUDA tensor per device of the handle): x0[r] [m,2,3], zlim[r] [m,2,2,N] on devices[r]; zmp_all[r]
+        [D*m,2] on devices[r] receives the planned ZMPs of ALL shards (RCCL all-gather).  Synchronous."""
+        ct = self._ct
+        D = len(self.devices)
+        m = x0[0].shape[0]
+
+        def arr(ts):
+            return (ct.c_void_p * D)(*[ct.c_void_p(t.data_ptr()) for t in ts])
+
+        self._lib.check(self._L.ccc_zmp_sharded_plan_batch_device(self._h, m, arr(x0), arr(zlim), float(control_dt),
+                                                                   arr(zmp_all), arr(status) if status else None))

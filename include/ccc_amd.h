@@ -44,6 +44,9 @@ extern "C" {
 const char * ccc_last_error_string(void);
 /* version of this ABI (bumped on incompatible change) */
 int ccc_abi_version(void);
+/* number of visible HIP devices that are gfx950 parts (0 when none: every create call then fails with
+ * CCC_ERR_NO_DEVICE); device ordinals are HIP's */
+int ccc_device_count(void);
 
 /* =========================================================================================
  * CCC::LinearMpcZmp      /root/reference/include/CCC/LinearMpcZmp.h:97-165
@@ -383,6 +386,40 @@ int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K, const doub
 int ccc_total_wrench_device(int64_t n, int max_ridges, const int32_t * dim, const double * vertex, const double * ridge,
                             const double * scales, int scale_stride, const double * origin, double * wrench,
                             void * stream);
+
+/* =========================================================================================
+ * One node, several GPUs behind the C-ABI (north_star: "the batch dimension shards trivially across the
+ * 8 GPUs of one node with an RCCL all-gather of the planned CoM/ZMP outputs over xGMI").  The reference has no
+ * counterpart: one CCC::LinearMpcZmp object plans one instance on one CPU thread (src/LinearMpcZmp.cpp:83-112).
+ * A sharded handle owns one ccc_zmp_t per listed device; instances are split into contiguous, balanced shards
+ * (ccc_shard_bounds: the first n % D shards get one instance more), constants are replicated.
+ * ========================================================================================= */
+typedef struct ccc_zmp_sharded ccc_zmp_sharded_t;
+
+/* [begin, end) of shard `shard` of n instances over num_shards (the partition every sharded entry point uses) */
+int ccc_shard_bounds(int64_t n, int num_shards, int shard, int64_t * begin, int64_t * end);
+
+/* devices [num_devices]: HIP ordinals, each at most once */
+int ccc_zmp_sharded_create(double com_height, double horizon_duration, double horizon_dt, const int * devices,
+                           int num_devices, ccc_zmp_sharded_t ** out);
+void ccc_zmp_sharded_destroy(ccc_zmp_sharded_t * h);
+int ccc_zmp_sharded_num_devices(const ccc_zmp_sharded_t * h);
+
+/* Host arrays in, host arrays out, as ccc_zmp_plan_batch (same layouts): shard r is planned on devices[r], one host
+ * thread per device drives its chunked copy / kernel pipeline; pinned caller buffers are read and written by DMA
+ * directly.  No collective: the caller's arrays ARE the gathered result. */
+int ccc_zmp_sharded_plan_batch(ccc_zmp_sharded_t * h, int64_t n, const double * x0, const double * zlim,
+                               double control_dt, double * zmp, int32_t * status);
+
+/* Device-resident shards + RCCL all-gather: on devices[r], x0[r] / zlim[r] hold n_per_device instances (layouts of
+ * ccc_zmp_plan_batch_device), zmp_all[r] is a [num_devices * n_per_device][2] array ON devices[r].  Every device plans
+ * its shard into its own slot of zmp_all[r]; one in-place ncclAllGather per device (grouped, each on that device's
+ * stream, RCCL over xGMI) then leaves the planned ZMPs of ALL shards on EVERY device.  status[r] ([n_per_device][2] on
+ * devices[r]) may be NULL.  Synchronous (returns when every device is done).  RCCL is loaded at first use
+ * (librccl.so); CCC_ERR_UNSUPPORTED if it is not there. */
+int ccc_zmp_sharded_plan_batch_device(ccc_zmp_sharded_t * h, int64_t n_per_device, const double * const * x0,
+                                      const double * const * zlim, double control_dt, double * const * zmp_all,
+                                      int32_t * const * status);
 
 #ifdef __cplusplus
 }

@@ -68,3 +68,23 @@ def test_invalid_arguments_are_rejected_before_touching_the_device():
     assert L.ccc_zmp_create(1.0, 2.0, 0.0, 0, ctypes.byref(h)) == _lib.CCC_ERR_INVALID_ARGUMENT
     assert b"must be > 0" in L.ccc_last_error_string()
     assert L.ccc_zmp_horizon_steps(None) == -1
+
+
+def test_shard_bounds_partition():
+    """ccc_shard_bounds (no device needed): contiguous, balanced, covering -- the partition of SURVEY.md 8(e) and the
+    same one sharding.shard_bounds gives the torch.distributed path."""
+    from centroidalcontrolcollection_amd import sharding
+
+    L = ctypes.CDLL(build.build_lib())
+    L.ccc_shard_bounds.restype = ctypes.c_int
+    L.ccc_shard_bounds.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                   ctypes.POINTER(ctypes.c_int64)]
+    for n, world in ((65536, 8), (10, 3), (5, 8), (0, 4), (4097, 2)):
+        got = []
+        for r in range(world):
+            b, e = ctypes.c_int64(), ctypes.c_int64()
+            assert L.ccc_shard_bounds(n, world, r, ctypes.byref(b), ctypes.byref(e)) == 0
+            got.append((b.value, e.value))
+        assert got == sharding.shard_bounds(n, world)
+    b, e = ctypes.c_int64(), ctypes.c_int64()
+    assert L.ccc_shard_bounds(10, 0, 0, ctypes.byref(b), ctypes.byref(e)) != 0
