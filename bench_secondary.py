@@ -60,9 +60,8 @@ def _xy(n, dev, rank):
 
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
-                algo_bytes=_xy_algo, kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0),
-                note="algorithmic bytes = inputs + outputs + the stage data the primal-dual active-set iteration streams "
-                     "through the HBM workspace per iteration (one instance per lane, DESIGN.md 7b)")
+                algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, stream_bytes=_xy_algo,
+                kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0))
 
 
 def _ddp(n, dev, rank, srb):
@@ -164,10 +163,9 @@ def _z(n, dev, rank):
         return N * 4 + N * 8 + 16 + 8 + N * 16 + (it + 1.0) * N * (8 + 8 + 1 + 1 + 24) + it * N * (8 + 1 + 24 + 8 + 8)
 
     return dict(name="LinearMpcZ planOnce() solves/sec (N=40, fp64, inputs resident in HBM)", step=step, out=out, status=st,
-                workload="LinearMpcZ N=40 (2 s horizon @ 50 ms), batch=%d per GPU" % n, algo_bytes=algo,
-                kernel="z_plan_stream_kernel", cpu=cpu, keep=(mpc, tc, tr, tx),
-                note="algorithmic bytes = inputs + outputs + the sweeps of the projected-Newton iteration through the HBM "
-                     "workspace (one instance per lane, DESIGN.md 7d)")
+                workload="LinearMpcZ N=40 (2 s horizon @ 50 ms), batch=%d per GPU" % n,
+                algo_bytes=N * 4 + N * 8 + 16 + 8, stream_bytes=algo,
+                kernel="z_plan_stream_kernel", cpu=cpu, keep=(mpc, tc, tr, tx))
 
 
 def _ddpzmp(n, dev, rank):
@@ -202,9 +200,8 @@ def _ddpzmp(n, dev, rank):
     return dict(name="DdpZmp planOnce() solves/sec (horizon 100, 3 DDP iterations, fp64, inputs resident in HBM)", step=step,
                 out=out, status=st, iters=it,
                 workload="DdpZmp horizon=100 @ 20 ms, max_iter=3, warm start (TestDdpZmp.cpp:17-29), batch=%d per GPU" % n,
-                algo_bytes=algo, kernel="ddpzmp_plan_kernel", cpu=cpu, keep=(d, tr, tx, tu, u),
-                note="algorithmic bytes = inputs + outputs + the trajectories and gains each DDP iteration streams through "
-                     "the HBM workspace (one instance per lane, DESIGN.md 7f)")
+                algo_bytes=8 * ((N + 1) * 4 + N * 3 + 6 + N * 3), stream_bytes=algo, kernel="ddpzmp_plan_kernel", cpu=cpu,
+                keep=(d, tr, tx, tu, u))
 
 
 DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536)
@@ -252,8 +249,13 @@ def run(args, rank, world, local_rank, dist):
         return
     kavg = float(kern_ms.mean()) * 1e-3
     st = w["status"].cpu().numpy()
-    if callable(w["algo_bytes"]):  # depends on the iteration counts of the run
-        w["algo_bytes"] = w["algo_bytes"](st)
+    # ALGORITHMIC bytes = the mandatory inputs + outputs of an instance, nothing else.  The kernels that
+    # stream their per-instance state through an HBM workspace (one instance per lane) also report that stream --
+    # modelled bytes per instance from the iteration counts of the run -- as `workspace`: a TRAFFIC figure (how close the
+    # streaming is to the HBM peak), not a roofline fraction.
+    sb = w.get("stream_bytes")
+    if callable(sb):
+        sb = sb(st)
     achieved = w["algo_bytes"] * n / kavg / 1e9
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
@@ -263,9 +265,14 @@ def run(args, rank, world, local_rank, dist):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": w["algo_bytes"] * n,
                         "kernel": w["kernel"], "kernel_avg_ms": kavg * 1e3,
-                        "note": w.get("note", "algorithmic bytes = mandatory inputs + outputs per instance x batch; the "
-                                              "kernel is bound by dependent-operation latency / LDS, not by HBM "
-                                              "(DESIGN.md)")},
+                        "workspace": None if sb is None else {
+                            "modelled_bytes": sb * n, "achieved": sb * n / kavg / 1e9, "unit": "GB/s",
+                            "frac_of_hbm_peak": sb * n / kavg / 1e9 / HBM_PEAK_GBS,
+                            "what": "inputs + outputs + the per-iteration state this kernel streams through its HBM "
+                                    "workspace (model from the iteration counts; the measured counter traffic is in "
+                                    "profiles/): a traffic figure, not the roofline fraction"},
+                        "note": "algorithmic bytes = mandatory inputs + outputs per instance x batch (SURVEY.md 8d); "
+                                "none of these kernels is bound by that stream (DESIGN.md says what binds each)"},
            "unsolved": int((st < 0).sum()) if "iters" in w else int(((st & 0xff) != 0).sum())}  # DDP: status < 0 = failure,
     #                                      0 = iteration limit, 1 / 2 = converged (oracle/ddp.c); QPs: low byte != 0
     if "iters" in w:
