@@ -26,6 +26,12 @@ CCC_STATUS_MAX_ITER = 2
 # every symbol include/ccc_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "ccc_shard_bounds",
+    "ccc_ddp_get_params",
+    "ccc_ddp_get_config",
+    "ccc_ddp_get_device",
+    "ccc_xy_get_params",
+    "ccc_ddp_closed_loop_device",
+    "ccc_xy_closed_loop_device",
     "ccc_device_count",
     "ccc_zmp_sharded_create",
     "ccc_zmp_sharded_destroy",

@@ -168,6 +168,27 @@ extern "C" int ccc_ddp_state_dim(const ccc_ddp_t * h)
   return h ? h->S : -1;
 }
 
+extern "C" int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params)
+{
+  if(!h || !params) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_get_params: NULL argument");
+  *params = h->prm;
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_get_config(const ccc_ddp_t * h, ccc_ddp_config_t * cfg)
+{
+  if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_get_config: NULL argument");
+  *cfg = h->cfg;
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_get_device(const ccc_ddp_t * h, int * device)
+{
+  if(!h || !device) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_get_device: NULL argument");
+  *device = h->device;
+  return CCC_OK;
+}
+
 static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
 {
   if(n <= h->cap) return CCC_OK;

@@ -1218,6 +1218,14 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   return CCC_OK;
 }
 
+extern "C" int ccc_xy_get_params(const ccc_xy_t * h, ccc_xy_params_t * params, int * device)
+{
+  if(!h || !params) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_get_params: NULL argument");
+  *params = h->prm;
+  if(device) *device = h->device;
+  return CCC_OK;
+}
+
 extern "C" void ccc_xy_destroy(ccc_xy_t * h)
 {
   if(!h) return;

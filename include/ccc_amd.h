@@ -172,6 +172,10 @@ void ccc_ddp_destroy(ccc_ddp_t * h);
 /* ddp_solver_->config() = cfg   (e.g. max_iter = 1 after the first control cycle, TestDdpCentroidal.cpp:116) */
 int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg);
 int ccc_ddp_state_dim(const ccc_ddp_t * h);
+/* the constructor arguments / the current configuration / the device of a handle */
+int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params);
+int ccc_ddp_get_config(const ccc_ddp_t * h, ccc_ddp_config_t * cfg);
+int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
 
 /* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,
  * initial_param, current_time) (src/DdpCentroidal.cpp:213-237, src/DdpSingleRigidBody.cpp:283-307) including the
@@ -227,6 +231,7 @@ typedef struct
 
 int ccc_xy_create(const ccc_xy_params_t * params, int device, ccc_xy_t ** out);
 void ccc_xy_destroy(ccc_xy_t * h);
+int ccc_xy_get_params(const ccc_xy_t * h, ccc_xy_params_t * params, int * device);
 
 /* Replaces n calls of LinearMpcXY::planOnce(motion_param_func, ref_data_func, initial_param, current_time)
  * (include/CCC/LinearMpcXY.h:224-227, src/LinearMpcXY.cpp:96-182: per-step models :59-83 with their ZOH
@@ -386,6 +391,56 @@ int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K, const doub
 int ccc_total_wrench_device(int64_t n, int max_ridges, const int32_t * dim, const double * vertex, const double * ridge,
                             const double * scales, int scale_stride, const double * origin, double * wrench,
                             void * stream);
+
+/* =========================================================================================
+ * The closed-loop tests of the force-scale planners on the device -- csrc/centroidal_loop.hip:
+ *   plan -> ForceColl::calcTotalWrench about the CoM -> CentroidalSim::update (+ addDisturb) -> plan ...
+ * for n instances, replacing the host loops of tests/src/TestDdpCentroidal.cpp:96-150,
+ * TestDdpSingleRigidBody.cpp:103-170 and TestLinearMpcXY.cpp:98-132 around tests/src/SimModels.h:233-340.
+ * The tests' motion_param_func / ref_data_func are piecewise constant in time; here they are a per-instance CONTACT
+ * TIMELINE (all DEVICE pointers):
+ *   seg_end      [n][K]        f64  end time of segment k (the last segment never ends; its entry is ignored)
+ *   seg_contact  [n][K]        i32  contact-table entry in force during the segment
+ *   seg_ref      [n][K][6]     f64  RefData of the segment: CoM position (3), base orientation ZYX (3; SRB only)
+ *   contact_dim  [n][C]        i32  ridges of contact-table entry c (0 = flight)
+ *   contact_vertex / contact_ridge  [n][C][16][3]  f64  flattened contact -> vertex -> ridge
+ *   time_eps                        added to every sampling time (the DDP tests add 1e-6, TestDdpCentroidal.cpp:39)
+ * A sample at time t takes the first segment with t < seg_end.
+ * ========================================================================================= */
+typedef struct
+{
+  int K, C;
+  const double * seg_end;
+  const int32_t * seg_contact;
+  const double * seg_ref;
+  const int32_t * contact_dim;
+  const double * contact_vertex;
+  const double * contact_ridge;
+  double time_eps;
+} ccc_contact_timeline_t;
+
+/* DdpCentroidal / DdpSingleRigidBody closed loop (C of the timeline = max_phases of the handle: the contact table IS
+ * the planner's phase table).  Per cycle: RefData and contact phases sampled at t + i dt, InitialParam from the
+ * simulator state (SRB: orientation reversed into Z, Y, X, TestDdpSingleRigidBody.cpp:110-115), warm start = the previous
+ * input sequence UNSHIFTED with the steps whose input dimension changed zeroed (:118-127), planOnce with max_iter =
+ * first_max_iter in the first cycle and warm_max_iter afterwards (:125), t += sim_dt, CentroidalSim::update with the
+ * total wrench of u_list[0] about the CoM, the linear kick disturb_lin when disturb_time <= t < disturb_time + sim_dt.
+ *   inertia_diag [n][3]   f64  moment of inertia of the simulator (the SRB planner takes diag(inertia_diag))
+ *   sim_state    [n][18]  f64  in/out: pos, ori (X, Y, Z), vel, ang_vel, linear momentum, angular momentum
+ *   stats        [n][8]   f64  optional: max over the cycles, taken where the test asserts (before the update), of
+ *                              |pos - ref|, |ori - ref_ori| (unreversed vectors, as the test), |vel|, |ang_vel|, |ang_mom|
+ *   log          [cycles][n][9] f64 optional: pos, planned force, planned moment about the CoM of every cycle
+ *   t_end                      optional (host): the time after the last cycle
+ * Synchronous (returns when the last cycle is done; its workspaces live and die inside the call). */
+int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_contact_timeline_t * timeline,
+                               const double * inertia_diag, double * sim_state, double t0, double sim_dt, int cycles,
+                               int first_max_iter, int warm_max_iter, int n_disturb, const double * disturb_times,
+                               const double * disturb_lin, double * stats, double * log, double * t_end, void * stream);
+/* LinearMpcXY closed loop (TestLinearMpcXY.cpp:98-132): MotionParam{com_z, total_force_z = mass g, contact of the
+ * segment}, RefData::pos = the first two entries of seg_ref (the third is the height the statistics compare with). */
+int ccc_xy_closed_loop_device(ccc_xy_t * h, int64_t n, const ccc_contact_timeline_t * timeline, double com_z,
+                              const double * inertia_diag, double * sim_state, double t0, double sim_dt, int cycles,
+                              double * stats, double * log, double * t_end, void * stream);
 
 /* =========================================================================================
  * One node, several GPUs behind the C-ABI (north_star: "the batch dimension shards trivially across the

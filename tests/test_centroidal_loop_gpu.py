@@ -1,0 +1,145 @@
+"""The reference's closed-loop tests of the force-scale planners as ONE device call each (csrc/centroidal_loop.hip):
+TestDdpCentroidal.cpp:15-174, TestDdpSingleRigidBody.cpp:15-195, TestLinearMpcXY.cpp:15-152.  The property assertions
+of the tests are evaluated from the per-instance statistics the loop keeps; the trajectories are compared with the same
+loop driven from the host (GPU planner through the Python mirror, numpy CentroidalSim)."""
+import numpy as np
+import pytest
+
+from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, LinearMpcXY
+from centroidalcontrolcollection_amd import centroidal_loop as cl
+from centroidalcontrolcollection_amd import fixtures_ddp as fd
+
+pytestmark = pytest.mark.gpu
+
+INERTIA = (40.0, 20.0, 10.0)
+
+
+def _ddp_timeline(n, srb, device=0):
+    """The schedule of TestDdpCentroidal.cpp:35-80 / TestDdpSingleRigidBody.cpp:36-87 (epsilon_t = 1e-6)."""
+    hy = 0.5 if srb else 0.1
+    V0, R0 = fd.contact_from_rect((-0.1, -hy), (0.1, hy))
+    V2, R2 = fd.contact_from_rect((0.4, -hy), (0.6, hy))
+    K = 5
+    seg_end = np.tile(np.array([1.4, 1.6, 2.2, 2.4, 1e30]), (n, 1))
+    seg_contact = np.tile(np.array([0, 1, 2, 2, 2], dtype=np.int32), (n, 1))
+    seg_ref = np.zeros((n, K, 6))
+    seg_ref[:, 0, :3] = [0.0, 0.0, 1.0]
+    seg_ref[:, 1, :3] = [0.25, 0.0, 1.2]
+    seg_ref[:, 2:, :3] = [0.5, 0.0, 1.0]
+    if srb:
+        seg_ref[:, 3, 3:] = [0.0, 0.0, 0.3]  # roll reference between 2.2 s and 2.4 s (ZYX order)
+    dim = np.tile(np.array([16, 0, 16, 0], dtype=np.int32), (n, 1))
+    vert = np.zeros((n, 4, 16, 3))
+    ridge = np.zeros((n, 4, 16, 3))
+    vert[:, 0], ridge[:, 0], vert[:, 2], ridge[:, 2] = V0, R0, V2, R2
+    return cl.ContactTimeline(seg_end, seg_contact, seg_ref, dim, vert, ridge, 1e-6, device)
+
+
+def _sim_state(n, pos, perturb=0.0, seed=0):
+    s = np.zeros((n, 18))
+    s[:, :3] = pos
+    if perturb:
+        s[1:, :3] += perturb * np.random.default_rng(seed).uniform(-1, 1, size=(n - 1, 3))
+    return s
+
+
+@pytest.mark.parametrize("srb", [False, True])
+def test_ddp_reference_closed_loop_on_the_device(srb):
+    import torch
+
+    dev = torch.device("cuda:0")
+    n, N, dt = 6, 100, 0.03
+    if srb:
+        w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3,
+                                           terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3)
+        d = DdpSingleRigidBody(100.0, dt, N, w)
+    else:
+        d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0)))
+    tl = _ddp_timeline(n, srb)
+    # instance 0 = the reference test; the others start up to 1 cm off
+    state0 = _sim_state(n, (0.0, 0.0, 1.0), perturb=0.01, seed=3)
+    sim = torch.from_numpy(state0).to(dev)
+    inertia = torch.from_numpy(np.tile(np.array(INERTIA), (n, 1))).to(dev)
+    cycles = 601  # while(t < 3.0) with t += 0.005 in floating point: 601 passes (fixtures_ddp.run_closed_loop_ddp)
+    stats = torch.zeros((n, 8), dtype=torch.float64, device=dev)
+    log = torch.zeros((cycles, n, 9), dtype=torch.float64, device=dev)
+    t_end = cl.ddp_closed_loop(d, tl, inertia, sim, 0.0, 0.005, cycles, 500, 1, disturb_times=(1.0,),
+                               disturb_lin=(0.05, 0.05, 0.0), stats=stats, log=log)
+    st, fin, lg = stats.cpu().numpy(), sim.cpu().numpy(), log.cpu().numpy()
+    assert abs(t_end - 3.005) < 1e-9
+    # per-cycle assertions (TestDdpCentroidal.cpp:133-135 / TestDdpSingleRigidBody.cpp:150-153) on the reference instance
+    # and on the perturbed ones of the centroidal model (the SRB protocol is chaotic under perturbation, test_oracle_ddp.py)
+    who = slice(0, 1) if srb else slice(0, n)
+    assert st[who, 0].max() < 2.0 and st[who, 2].max() < 2.0
+    ref_end = np.array([0.5, 0.0, 1.0])
+    if srb:
+        assert st[0, 1] < 1.0 and st[0, 3] < 2.0
+        assert np.linalg.norm(fin[0, :3] - ref_end) < 0.1 and np.linalg.norm(fin[0, 3:6]) < 0.1
+        assert np.linalg.norm(fin[0, 6:9]) < 0.1 and np.linalg.norm(fin[0, 9:12]) < 0.1
+    else:
+        assert st[:, 4].max() < 1.0
+        assert np.linalg.norm(fin[:, :3] - ref_end, axis=1).max() < 0.1
+        assert np.linalg.norm(fin[:, 6:9], axis=1).max() < 0.1 and np.linalg.norm(fin[:, 15:18], axis=1).max() < 0.01
+    # the same loop driven from the host for the reference instance: planner through planOnceBatch, numpy simulator
+    d.ddp_solver_.config().max_iter = 500
+    pos_host = []
+
+    def plan(prob, x0, u_init, max_iter):
+        d.ddp_solver_.config().max_iter = max_iter
+        return d.planOnceBatch(prob, x0, u_init)["u"]
+
+    hlog, hfin = fd.run_closed_loop_ddp(plan, srb=srb)
+    hp = np.array([r["pos"] for r in hlog])
+    k = 120 if srb else len(hlog)  # the SRB loop amplifies last-bit differences of the wrench sums after the take-off
+    assert np.abs(lg[:k, 0, :3] - hp[:k]).max() < 1e-7
+    if not srb:
+        assert np.abs(fin[0, :3] - hfin["pos"]).max() < 1e-6
+
+
+def test_xy_reference_closed_loop_on_the_device():
+    import torch
+
+    dev = torch.device("cuda:0")
+    n, N, dt, mass = 5, 15, 0.1, 100.0
+    mpc = LinearMpcXY(mass, dt, N)
+    # TestLinearMpcXY.cpp:29-80 (no epsilon in this test)
+    rects = [((0.9, -0.15), (1.1, 0.15)), ((0.9, 0.05), (1.1, 0.15)), ((1.15, -0.15), (1.35, -0.05)),
+             ((1.4, 0.05), (1.6, 0.15)), ((1.4, -0.15), (1.6, 0.15))]
+    refs = [(1.0, 0.0), (1.0, 0.1), (1.25, -0.1), (1.5, 0.1), (1.5, 0.0)]
+    K = C = 5
+    seg_end = np.tile(np.array([3.0, 4.0, 5.0, 6.0, 1e30]), (n, 1))
+    seg_contact = np.tile(np.arange(5, dtype=np.int32), (n, 1))
+    seg_ref = np.zeros((n, K, 6))
+    dim = np.full((n, C), 16, dtype=np.int32)
+    vert, ridge = np.zeros((n, C, 16, 3)), np.zeros((n, C, 16, 3))
+    for c in range(5):
+        vert[:, c], ridge[:, c] = fd.contact_from_rect(*rects[c])
+        seg_ref[:, c, :3] = [refs[c][0], refs[c][1], 1.0]
+    tl = cl.ContactTimeline(seg_end, seg_contact, seg_ref, dim, vert, ridge, 0.0)
+    state0 = _sim_state(n, (1.0, 0.0, 1.0), perturb=0.01, seed=4)
+    state0[:, 2] = 1.0
+    sim = torch.from_numpy(state0).to(dev)
+    inertia = torch.from_numpy(np.tile(np.array(INERTIA), (n, 1))).to(dev)
+    cycles = 160  # while(t < 8.0) with t += 0.05
+    stats = torch.zeros((n, 8), dtype=torch.float64, device=dev)
+    t_end = cl.xy_closed_loop(mpc, tl, 1.0, inertia, sim, 0.0, 0.05, cycles, stats=stats)
+    st, fin = stats.cpu().numpy(), sim.cpu().numpy()
+    assert abs(t_end - 8.0) < 1e-6
+    # TestLinearMpcXY.cpp:126-128 per cycle, :140-142 at the end
+    assert st[:, 0].max() < 2.0 and st[:, 2].max() < 2.0 and st[:, 4].max() < 5.0
+    ref_end = np.array([1.5, 0.0, 1.0])
+    assert np.linalg.norm(fin[:, :3] - ref_end, axis=1).max() < 0.1
+    assert np.linalg.norm(fin[:, 6:9], axis=1).max() < 0.1 and np.linalg.norm(fin[:, 15:18], axis=1).max() < 0.1
+    # host-driven loop of the reference instance (planOnce through the mirror, numpy simulator)
+    sim_h = fd.CentroidalSim(mass, np.array(INERTIA), 0.05)
+    sim_h.pos = np.array([1.0, 0.0, 1.0])
+    t = 0.0
+    for _ in range(cycles):
+        prob = fd.xy_problem(t, N, dt, mass)
+        x0 = np.array([[mass * sim_h.pos[0], mass * sim_h.vel[0], mass * sim_h.pos[1], mass * sim_h.vel[1],
+                        sim_h.ang_mom[0], sim_h.ang_mom[1]]])
+        u0 = mpc.planOnceBatch(prob, x0)["u0"][0]
+        moment, force = fd.total_wrench(prob["vertex"][0, 0], prob["ridge"][0, 0], u0[:prob["dim"][0, 0]], sim_h.pos)
+        t += 0.05
+        sim_h.update(force, moment)
+    assert np.abs(fin[0, :3] - sim_h.pos).max() < 1e-6 and np.abs(fin[0, 6:9] - sim_h.vel).max() < 1e-6
