@@ -64,7 +64,7 @@ def _xy(n, dev, rank):
                 kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0))
 
 
-def _ddp(n, dev, rank, srb):
+def _ddp(n, dev, rank, srb, precision=64):
     from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
     N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
     prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
@@ -78,6 +78,7 @@ def _ddp(n, dev, rank, srb):
         d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
                           device=dev.index)
     d.ddp_solver_.config().max_iter = 20
+    d.ddp_solver_.config().precision = precision
     tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
     out = torch.zeros((n, N, 16), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -95,16 +96,28 @@ def _ddp(n, dev, rank, srb):
         r = o.plan_batch(sub, x0[:ns], nthreads=cores)
         t = time.perf_counter() - t0
         same = bool(np.array_equal(out.cpu().numpy()[:ns], r["u"]))
+        if precision == 32:
+            # single-precision storage: a tolerance, not bits -- share of the sample whose first-step force scales agree
+            # with the fp64 oracle to 1e-3 of the largest one (the rest sit on another branch of the chaotic cold solve,
+            # as the oracle itself does under a 1e-10 perturbation: tests/test_ddp_gpu.py)
+            g = out.cpu().numpy()[:ns, 0, :]
+            e = np.abs(g - r["u"][:, 0, :]).max(axis=1) / (np.abs(r["u"][:, 0, :]).max(axis=1) + 1.0)
+            return ns / t, ns, float((e <= 1e-3).mean()), "share of instances with |d u0| <= 1e-3 (1 + max u0) vs the fp64 oracle"
         return ns / t, ns, 0.0 if same else float(np.abs(out.cpu().numpy()[:ns] - r["u"]).max()), \
             "max |d force scale| over the whole planned sequence (0.0 = bit-identical)"
 
     S = 12 if srb else 9
-    return dict(name="%s planOnce() solves/sec (horizon %d, <= 20 DDP iterations, fp64, inputs resident in HBM)"
-                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N), step=step, out=out, status=st, iters=it,
+    return dict(name="%s planOnce() solves/sec (horizon %d, <= 20 DDP iterations, %s, inputs resident in HBM)"
+                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N,
+                   "fp64" if precision == 64 else "fp32 storage / fp64 arithmetic in the backward pass"),
+                step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f32",
                 workload="%s horizon=%d @ 30 ms, max_iter=20, batch=%d per GPU (BASELINE config %s)"
-                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, n, "5 shape, fp64" if srb else "3"),
+                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, n,
+                   ("5" if precision == 32 else "5 shape, fp64") if srb else "3"),
                 algo_bytes=4 * 4 + 2 * 4 * 16 * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
-                + S * 8 + N * 16 * 8, kernel="ddp_plan_kernel<%d,16>" % S, cpu=cpu, keep=(d, tp, tx0))
+                + S * 8 + N * 16 * 8,
+                kernel=("ddp_plan_kernel<%d,16>" % S) if precision == 64 else ("ddp_group_kernel<%d,float>" % S), cpu=cpu,
+                keep=(d, tp, tx0))
 
 
 def _ism(n, dev, rank):
@@ -204,15 +217,16 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3))
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3))
 
 
 def run(args, rank, world, local_rank, dist):
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
-    make = dict(xy=_xy, ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True))
+    make = dict(xy=_xy, ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
+                srb32=lambda a, b, c: _ddp(a, b, c, True, 32))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)
@@ -259,7 +273,7 @@ def run(args, rank, world, local_rank, dist):
     achieved = w["algo_bytes"] * n / kavg / 1e9
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
            "config": {"workload": w["workload"], "batch_per_gpu": n, "parallelism": "batch-sharded x%d" % world,
                       "collective": "all_gather(planned outputs)" if world > 1 else "none"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -103,6 +103,7 @@ extern "C" void ccc_ddp_default_config(ccc_ddp_config_t * c)
   c->cost_update_thre = 1e-7;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
   c->reg_type = 1;
+  c->precision = 64;
 }
 
 extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t ** out)
@@ -159,6 +160,10 @@ extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
   if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: NULL argument");
   if(cfg->max_iter < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: max_iter < 0");
   if(cfg->reg_type != 1 && cfg->reg_type != 2) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: reg_type must be 1 or 2");
+  if(cfg->precision != 64 && cfg->precision != 32)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: precision must be 64 or 32");
+  if(cfg->precision == 32 && cfg->reg_type != 1)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_set_config: precision 32 is built for reg_type 1 only");
   h->cfg = *cfg;
   return CCC_OK;
 }
@@ -243,7 +248,8 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   // wavefront (csrc/ddp_group.h; reg_type 1 only): bit-identical results, half the VALU instructions per instance, but
   // measured SLOWER on MI355X -- 4096 instances are only 1024 wavefronts, one per SIMD, and with
   // 512 registers and 25 KB of LDS per wavefront nothing hides the dependent LDS / scratch latencies.
-  const bool group = h->cfg.reg_type == 1 && std::getenv("CCC_DDP_GROUP") != nullptr;
+  // precision 32 (BASELINE configs[4]) exists in the group kernel only: its backward pass in single precision
+  const bool group = h->cfg.reg_type == 1 && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
   int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp::Params P;
@@ -305,10 +311,15 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     G.gm = w;
     hipStream_t gs = reinterpret_cast<hipStream_t>(stream);
     const int64_t blocks = (n + 3) / 4;
-    if(h->S == 9)
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+    const bool f32 = h->cfg.precision == 32;
+    if(h->S == 9 && !f32)
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9, double>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+    else if(h->S == 9)
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9, float>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+    else if(!f32)
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12, double>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
     else
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
+      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12, float>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }

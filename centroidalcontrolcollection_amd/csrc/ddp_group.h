@@ -90,15 +90,47 @@ struct Batch
   double * gm; // [n][N]
 };
 
-template<int S>
+// A stored number: kept as Real, computed with as double.  Real = double: a no-op (the oracle's arithmetic, bit for bit).
+// Real = float (ccc_ddp_config_t::precision = 32, BASELINE configs[4]): the matrices of the backward pass -- Vxx, T2, Quu,
+// the Cholesky factor, Qxu, K and the box-QP vectors -- are STORED in single precision (half the LDS and half the
+// registers of the arrays), every product and sum is still formed in double.  A straight fp32 solver does not work on
+// this problem: the reference's constants (box-QP gradient threshold 1e-8, cost_update_thre 1e-7, force weight 1e-6
+// against curvatures of 1e-2) sit below single-precision resolution and the backward pass fails on every instance.
+template<typename Real>
+struct Stored
+{
+  Real v;
+  __device__ __forceinline__ Stored() = default;
+  __device__ __forceinline__ Stored & operator=(double x)
+  {
+    v = static_cast<Real>(x);
+    return *this;
+  }
+  __device__ __forceinline__ operator double() const
+  {
+    return static_cast<double>(v);
+  }
+};
+
+template<int S, typename Real>
 struct Lds
 {
+  using St = Stored<Real>;
   static constexpr int KS = S + 1; // row stride of K (odd at S = 12)
-  double Vxx[S * S];               // [a][b]; parks the columns of Qxx during the box-QP; transposes T
-  double A1[G * LS];               // rows of T2 -> Cholesky factor -> Quu' -> T2'; rollout products
-  double Qxu[S * LS];              // [a][r]
-  double K[G * KS];                // [r][a]
-  double v[8][G];                  // published vectors (see the SL_* slots)
+  static constexpr int kA1Bytes = (G * LS * (int)sizeof(Real)) > (11 * G * 8) ? (G * LS * (int)sizeof(Real)) : (11 * G * 8);
+  St Vxx[S * S];                   // [a][b]; parks the columns of Qxx during the box-QP; transposes T
+  alignas(16) unsigned char A1raw[kA1Bytes]; // rows of T2 -> Cholesky factor -> Quu' -> T2'; the rollout's products (double)
+  St Qxu[S * LS];                  // [a][r]
+  St K[G * KS];                    // [r][a]
+  St v[8][G];                      // published vectors (see the SL_* slots)
+  __device__ __forceinline__ St * A1()
+  {
+    return reinterpret_cast<St *>(A1raw);
+  }
+  __device__ __forceinline__ double * roll()
+  {
+    return reinterpret_cast<double *>(A1raw);
+  }
 };
 
 // vector slots of Lds::v
@@ -127,14 +159,15 @@ __device__ constexpr bool fx_nz(int k, int b)
   return b < 3 || b >= 9;
 }
 
-template<int S>
+template<int S, typename Real>
 struct Group
 {
+  using St = Stored<Real>;
   static constexpr int R0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (rows R0 .. R0+5)
-  static constexpr int KS = Lds<S>::KS;
+  static constexpr int KS = Lds<S, Real>::KS;
 
   const Params & P;
-  Lds<S> & L;
+  Lds<S, Real> & L;
   const int l;     // lane in the group
   const bool live; // the instance exists (dead groups of the last workgroup shadow the last instance, stores masked)
   const unsigned shift; // bit position of the group in a wavefront ballot
@@ -201,7 +234,7 @@ struct Group
   }
 
   // value of entry l of a vector every lane holds in full (v[k] uniform in the group)
-  __device__ __forceinline__ double own(const double (&v)[G]) const
+  __device__ __forceinline__ double own(const St (&v)[G]) const
   {
     double r = v[0];
 #pragma unroll
@@ -291,11 +324,11 @@ struct Group
       for(int k = 0; k < 3; k++)
       {
         const double p = u * c.R[k];
-        L.A1[k * G + l] = p;
-        L.A1[(3 + k) * G + l] = u * cr[k];
-        if(S == 12) L.A1[(7 + k) * G + l] = p / P.mass;
+        L.roll()[k * G + l] = p;
+        L.roll()[(3 + k) * G + l] = u * cr[k];
+        if(S == 12) L.roll()[(7 + k) * G + l] = p / P.mass;
       }
-      L.A1[6 * G + l] = u * u;
+      L.roll()[6 * G + l] = u * u;
       sync();
       // ordered sums over the ridges, one row per lane (rows 0..9), then published
       {
@@ -322,16 +355,16 @@ struct Group
         // Cen: lanes 0-2 dynamics force rows (0,1 double as tf_x, tf_y), 3-5 moment rows, 6 u^2, 7 tf_z (row 2 from 0)
         // SRB: lanes 0-2 tf rows, 3-5 moment rows (from -w x I w), 6 u^2, 7-9 force / mass rows
         const int row = (S == 9 && l == 7) ? 2 : (l < NROW ? l : 0);
-        const double * rowp = L.A1 + row * G;
+        const double * rowp = L.roll() + row * G;
 #pragma unroll
         for(int r = 0; r < G; r++)
           acc += rowp[r]; // absent ridges carry u = 0
-        L.v[0][l] = acc;
+        L.roll()[10 * G + l] = acc;
       }
       sync();
       double sums[10];
 #pragma unroll
-      for(int k = 0; k < ((S == 9) ? 8 : 10); k++) sums[k] = L.v[0][k];
+      for(int k = 0; k < ((S == 9) ? 8 : 10); k++) sums[k] = L.roll()[10 * G + k];
       sync();
       // running cost of (x_i, u_i) (src/DdpCentroidal.cpp:66-74): sequential over the state entries
       {
@@ -404,14 +437,14 @@ struct Group
   // ------------------------------------------------------------------------------------------ triangular solves
   // t <- (L L')^-1 t with the factor of the group in LDS (strict lower triangle in A1, reciprocal diagonal in SL_RD).
   // Every lane works on its own right-hand side (all equal in the box-QP, one column of Qxu' per lane in the gains).
-  __device__ __forceinline__ void solve(double (&t)[G]) const
+  __device__ __forceinline__ void solve(St (&t)[G]) const
   {
 #pragma unroll
     for(int a = 0; a < G; a++)
     {
       double s = t[a];
 #pragma unroll
-      for(int k = 0; k < a; k++) s -= L.A1[a * LS + k] * t[k];
+      for(int k = 0; k < a; k++) s -= L.A1()[a * LS + k] * t[k];
       t[a] = s * L.v[SL_RD][a];
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -420,7 +453,7 @@ struct Group
     {
       double s = t[a];
 #pragma unroll
-      for(int k = G - 1; k > a; k--) s -= L.A1[k * LS + a] * t[k];
+      for(int k = G - 1; k > a; k--) s -= L.A1()[k * LS + a] * t[k];
       t[a] = s * L.v[SL_RD][a];
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -430,22 +463,22 @@ struct Group
   // the LDS factor of the groups with `need`; returns false where a pivot is not positive (oracle: result -1).
   // Left-looking, lane = row: at pivot a every lane reads row a (written by lane a at the earlier pivots), forms the
   // pivot redundantly and its own entry of column a -- the oracle's sums in the oracle's order.
-  __device__ __forceinline__ bool cholesky(const double (&Hreg)[G], double hdiag, unsigned clmask, int m, bool need)
+  __device__ __forceinline__ bool cholesky(const St (&Hreg)[G], double hdiag, unsigned clmask, int m, bool need)
   {
     const long long t_ch = DPROF_T();
     DPROF_CNT(11);
     const bool mine_free = l < m && !((clmask >> l) & 1u);
     L.v[SL_D][l] = mine_free ? hdiag : 1.0;
     sync();
-    double Lrow[G];
+    St Lrow[G];
     bool ok = true;
 #pragma unroll
     for(int a = 0; a < G; a++)
     {
       const bool a_free = a < m && !((clmask >> a) & 1u);
-      double La[G];
+      St La[G];
 #pragma unroll
-      for(int k = 0; k < a; k++) La[k] = L.A1[a * LS + k];
+      for(int k = 0; k < a; k++) La[k] = L.A1()[a * LS + k];
       double d = L.v[SL_D][a];
 #pragma unroll
       for(int k = 0; k < a; k++) d -= La[k] * La[k];
@@ -457,7 +490,7 @@ struct Group
       for(int k = 0; k < a; k++) v -= Lrow[k] * La[k];
       v = v * rda;
       Lrow[a] = (l > a) ? v : 0.0;
-      if(need && l > a) L.A1[l * LS + a] = Lrow[a];
+      if(need && l > a) L.A1()[l * LS + a] = Lrow[a];
       if(need && l == a) L.v[SL_RD][a] = rda;
       sync();
     }
@@ -469,7 +502,7 @@ struct Group
   // min 1/2 k'Hk + g'k, lo <= k <= hi (oracle_box_qp): H row l in Hreg (regularised), g_l = gl, limits from the nominal
   // inputs in SL_U, warm start kw_l.  Out: the solution in SL_X (entries >= m zero), the clamped set, the boxQP.m
   // result.  The iterate, the gradient and the right-hand side live in LDS slots; a lane holds its own entries.
-  __device__ __forceinline__ int box_qp(const double (&Hreg)[G], double hdiag, double gl, double kw, int m, bool run,
+  __device__ __forceinline__ int box_qp(const St (&Hreg)[G], double hdiag, double gl, double kw, int m, bool run,
                                         unsigned & clmask_out)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
@@ -481,6 +514,7 @@ struct Group
     double x = in ? fmin(fmax(kw, lo), hi) : 0.0;
     L.v[SL_X][l] = x;
     sync();
+    x = L.v[SL_X][l];
     auto row_dot = [&](double s0, int slot) {
       double s = s0;
 #pragma unroll
@@ -557,7 +591,7 @@ struct Group
         gc += ((clmask >> j) & 1u) ? Hreg[j] * L.v[SL_X][j] : 0.0;
       L.v[SL_R][l] = (in && !cl) ? gc : 0.0;
       sync();
-      double srch[G];
+      St srch[G];
 #pragma unroll
       for(int k = 0; k < G; k++) srch[k] = L.v[SL_R][k];
       solve(srch);
@@ -567,7 +601,14 @@ struct Group
 #pragma unroll
       for(int k = 0; k < G; k++)
         sdotg += srch[k] * L.v[SL_G][k];
-      fin = fin || (sdotg >= 0); // no descent direction: result stays 0
+      {
+        // no descent direction: in double the oracle's failure (result stays 0).  With single-precision storage the Newton
+        // step of an iterate that is optimal TO THAT RESOLUTION is rounding noise (the solve loses 6e-8 |x| against a true
+        // step of |grad| / |H|), so its sign against the gradient is a coin toss: there it means "converged" (result 5).
+        const bool nodesc = !fin && sdotg >= 0;
+        if(sizeof(Real) < 8) result = nodesc ? 5 : result;
+        fin = fin || nodesc;
+      }
       // ---- Armijo line search along the projected step
       const double srch_own = own(srch);
       double step = 1.0, step_used = 1.0, vc = value;
@@ -575,7 +616,7 @@ struct Group
       while(wany(ls))
       {
         DPROF_CNT(12);
-        double cand[G];
+        St cand[G];
 #pragma unroll
         for(int k = 0; k < G; k++)
         {
@@ -603,6 +644,7 @@ struct Group
       }
       L.v[SL_X][l] = x;
       sync();
+      x = L.v[SL_X][l]; // the stored iterate is THE iterate (a no-op in double)
     }
     if(!fin && iter > max_iter && result == 0) result = 1;
     clmask_out = clmask;
@@ -645,7 +687,7 @@ struct Group
       double fu[6];
       double FX[S][S];
       double x_own, Qx_own, Qu;
-      double T1c[S], T2c[S];
+      St T1c[S], T2c[S];
       {
         double x[S];
 #pragma unroll
@@ -743,7 +785,7 @@ struct Group
         for(int a = 1; a < S; a++) x_own = (l == a) ? x[a] : x_own;
       }
       // column l of Fx (dense, zeros included) for the lanes that own a state entry
-      double fxcol[S];
+      St fxcol[S];
 #pragma unroll
       for(int k = 0; k < S; k++)
       {
@@ -795,16 +837,16 @@ struct Group
       }
       // ---- rows R0..R0+5 of T2 published, row l of Quu
 #pragma unroll
-      for(int j = 0; j < 6; j++) L.A1[j * G + l] = T2c[R0 + j];
+      for(int j = 0; j < 6; j++) L.A1()[j * G + l] = T2c[R0 + j];
       sync();
-      double Hreg[G];
+      St Hreg[G];
       double quu_own = 0.0;
 #pragma unroll
       for(int q = 0; q < G; q++)
       {
         double s = (l == q) ? P.w_force : 0.0;
 #pragma unroll
-        for(int j = 0; j < 6; j++) s += fu[j] * L.A1[j * G + q];
+        for(int j = 0; j < 6; j++) s += fu[j] * L.A1()[j * G + q];
         s = (in && q < m) ? s : 0.0;
         quu_own = (l == q) ? s : quu_own;
         Hreg[q] = (l == q) ? s + lambda : s; // reg_type 1: Quu_F = Quu + lambda I
@@ -831,7 +873,7 @@ struct Group
       DPROF_ADD(3, t_s1);
       const long long t_s2 = DPROF_T();
       // ---- gains: K_f = -Quu_F,ff^-1 Qxu_f', one right-hand side (state entry l) per lane
-      double QxuRow[G], Kc[G];
+      St QxuRow[G], Kc[G];
       {
         const int a = l < S ? l : 0;
 #pragma unroll
@@ -881,7 +923,7 @@ struct Group
         L.v[SL_D][l] = t4;
         L.v[SL_VX][l] = Qu;
 #pragma unroll
-        for(int q = 0; q < G; q++) L.A1[l * LS + q] = (l == q) ? quu_own : Hreg[q];
+        for(int q = 0; q < G; q++) L.A1()[l * LS + q] = (l == q) ? quu_own : Hreg[q];
       }
       sync();
       {
@@ -903,11 +945,11 @@ struct Group
       for(int r = 0; r < G; r++)
         Vx_own += Kc[r] * L.v[SL_D][r] + Kc[r] * L.v[SL_VX][r] + QxuRow[r] * L.v[SL_X][r];
       // ---- T2' = K'Quu (column l)
-      double T2p[S];
+      St T2p[S];
       {
-        double QC[G];
+        St QC[G];
 #pragma unroll
-        for(int r = 0; r < G; r++) QC[r] = L.A1[r * LS + l];
+        for(int r = 0; r < G; r++) QC[r] = L.A1()[r * LS + l];
 #pragma unroll
         for(int a = 0; a < S; a++)
         {
@@ -921,17 +963,17 @@ struct Group
       }
       sync(); // every lane has its column of Quu: A1 takes T2'
 #pragma unroll
-      for(int a = 0; a < S; a++) L.A1[a * G + l] = T2p[a];
+      for(int a = 0; a < S; a++) L.A1()[a * G + l] = T2p[a];
       sync();
       // ---- Vxx = sym(Qxx + K'Quu K + K'Qxu' + Qxu K): column l of the sum, then the transposition through LDS
-      double Tc[S];
+      St Tc[S];
 #pragma unroll
       for(int a = 0; a < S; a++)
       {
         double s = (l < S) ? L.Vxx[a * S + l] : 0.0;
 #pragma unroll
         for(int r = 0; r < G; r++)
-          s += L.A1[a * G + r] * Kc[r] + L.K[r * KS + a] * QxuRow[r] + L.Qxu[a * LS + r] * Kc[r];
+          s += L.A1()[a * G + r] * Kc[r] + L.K[r * KS + a] * QxuRow[r] + L.Qxu[a * LS + r] * Kc[r];
         Tc[a] = s;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -941,7 +983,7 @@ struct Group
         for(int a = 0; a < S; a++) L.Vxx[a * S + l] = Tc[a];
       }
       sync();
-      double Tr[S];
+      St Tr[S];
 #pragma unroll
       for(int a = 0; a < S; a++) Tr[a] = (l < S) ? L.Vxx[l * S + a] : 0.0;
       sync();
@@ -1116,16 +1158,16 @@ struct Group
   }
 };
 
-template<int S>
+template<int S, typename Real>
 __global__ __launch_bounds__(64, 1) void ddp_group_kernel(Params P, Batch B, long n)
 {
-  __shared__ Lds<S> lds[4];
+  __shared__ Lds<S, Real> lds[4];
   const int lane = static_cast<int>(threadIdx.x), g = lane >> 4, l = lane & 15;
   const long inst = static_cast<long>(blockIdx.x) * 4 + g;
   const bool live = inst < n;
   const long b = live ? inst : n - 1;
   const int N = P.N;
-  Group<S> grp{P, lds[g], l, live, static_cast<unsigned>(g * 16)};
+  Group<S, Real> grp{P, lds[g], l, live, static_cast<unsigned>(g * 16)};
   grp.N = N;
   grp.phase_dim = B.phase_dim + b * P.P;
   grp.phase_vertex = B.phase_vertex + b * P.P * G * 3;
