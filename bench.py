@@ -208,9 +208,10 @@ def main():
         elapsed = float(t.item())
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])  # HIP events on the launch stream
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
-    # ccc_zmp_plan_batch (pinned staging, H2D, kernel, D2H); PCIe-inclusive, never the `value` above
-    # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the DMA engines read the inputs
-    # and write the ZMPs in place, chunked beside the kernel) and from pageable numpy arrays (one more host copy each way)
+    # ccc_zmp_plan_batch; PCIe-inclusive, never the `value` above
+    # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the kernel reads the inputs
+    # and writes the ZMPs in the caller's page-locked memory, no copy) and from pageable numpy arrays (staged chunk by
+    # chunk through the handle's pinned buffers)
     h2h, h2h_pageable = [], []
     px0 = torch.from_numpy(batch["x0"]).pin_memory()
     pzl = torch.from_numpy(batch["zlim"]).pin_memory()

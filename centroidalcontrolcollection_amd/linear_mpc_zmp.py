@@ -99,22 +99,25 @@ class LinearMpcZmp:
             jerk.ctypes.data_as(_lib.c_double_p) if want_jerk else None, status.ctypes.data_as(_lib.c_int32_p)))
         return dict(zmp=zmp, jerk=jerk, status=status & 0xff, pivots=status >> 8)
 
-    def plan_batch_pinned(self, x0, zlim, control_dt, zmp, status=None):
-        """ccc_zmp_plan_batch on PINNED host tensors (torch ... pin_memory=True): the DMA engines read the inputs and
-        write the planned ZMPs in place, chunk by chunk beside the kernel (the p50 path).  Synchronous."""
+    def plan_batch_pinned(self, x0, zlim, control_dt, zmp, status=None, jerk=None):
+        """ccc_zmp_plan_batch on PINNED host tensors (torch ... pin_memory=True): for N <= 32 the kernel reads the
+        inputs and writes the results in the caller's page-locked memory, no copy (the p50 path).
+        Synchronous."""
         import torch
 
         N = self.horizon_steps_
         n = x0.shape[0]
         for name, t, shape, dt in (("x0", x0, (n, 2, 3), torch.float64), ("zlim", zlim, (n, 2, 2, N), torch.float64),
-                                   ("zmp", zmp, (n, 2), torch.float64), ("status", status, (n, 2), torch.int32)):
+                                   ("zmp", zmp, (n, 2), torch.float64), ("status", status, (n, 2), torch.int32),
+                                   ("jerk", jerk, (n, 2, N), torch.float64)):
             if t is None:
                 continue
             if t.is_cuda or not t.is_pinned() or t.dtype != dt or tuple(t.shape) != shape or not t.is_contiguous():
                 raise ValueError("%s must be a contiguous pinned host %s tensor of shape %s" % (name, dt, shape))
         _lib.check(self._L.ccc_zmp_plan_batch(
             self._h, n, ctypes.cast(x0.data_ptr(), _lib.c_double_p), ctypes.cast(zlim.data_ptr(), _lib.c_double_p),
-            float(control_dt), ctypes.cast(zmp.data_ptr(), _lib.c_double_p), None,
+            float(control_dt), ctypes.cast(zmp.data_ptr(), _lib.c_double_p),
+            ctypes.cast(jerk.data_ptr(), _lib.c_double_p) if jerk is not None else None,
             ctypes.cast(status.data_ptr(), _lib.c_int32_p) if status is not None else None))
 
     def plan_batch_device(self, x0, zlim, control_dt, zmp, jerk=None, status=None, stream=None):

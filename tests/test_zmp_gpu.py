@@ -301,3 +301,40 @@ def test_random_horizons_sweep():
         assert np.all(r["status"] == 0), N
         assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL, N
         assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL, N
+
+
+@pytest.mark.parametrize("n", [1, 700, 20001])
+def test_host_entry_in_place_on_pinned_buffers(mpc32, n):
+    """ccc_zmp_plan_batch on page-locked caller buffers (N <= 32: the kernel works on them in place, no copy) gives,
+    bit for bit, what the pageable route (pinned staging, chunked) gives: ZMP, jerk and status; and a call without
+    jerk / status arrays leaves nothing behind."""
+    import torch
+
+    b = fx.make_zmp_batch(n, 32, 0.0625, seed=41)
+    ref = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)  # pageable numpy arrays
+    x0 = torch.from_numpy(b["x0"]).pin_memory()
+    zl = torch.from_numpy(b["zlim"]).pin_memory()
+    zmp = torch.full((n, 2), np.nan, dtype=torch.float64).pin_memory()
+    jerk = torch.full((n, 2, 32), np.nan, dtype=torch.float64).pin_memory()
+    st = torch.full((n, 2), -1, dtype=torch.int32).pin_memory()
+    mpc32.plan_batch_pinned(x0, zl, 0.005, zmp, status=st, jerk=jerk)
+    assert np.array_equal(zmp.numpy(), ref["zmp"])
+    assert np.array_equal(jerk.numpy(), ref["jerk"])
+    assert np.array_equal(st.numpy() & 0xFF, ref["status"]) and np.array_equal(st.numpy() >> 8, ref["pivots"])
+    zmp2 = torch.full((n, 2), np.nan, dtype=torch.float64).pin_memory()
+    mpc32.plan_batch_pinned(x0, zl, 0.005, zmp2)
+    assert np.array_equal(zmp2.numpy(), ref["zmp"])
+
+
+def test_host_entry_long_horizon_pinned_buffers():
+    """N > 32 keeps the copy route (those kernels stream their operands more than once); pinned and pageable agree."""
+    import torch
+
+    mpc = LinearMpcZmp(1.0, 100 * 0.05, 0.05)
+    b = fx.make_zmp_batch(37, 100, 0.05, seed=5)
+    ref = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005)
+    x0 = torch.from_numpy(b["x0"]).pin_memory()
+    zl = torch.from_numpy(b["zlim"]).pin_memory()
+    zmp = torch.empty((37, 2), dtype=torch.float64).pin_memory()
+    mpc.plan_batch_pinned(x0, zl, 0.005, zmp)
+    assert np.array_equal(zmp.numpy(), ref["zmp"])
