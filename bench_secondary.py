@@ -64,23 +64,31 @@ def _xy(n, dev, rank):
                 kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0))
 
 
-def _ddp(n, dev, rank, srb, precision=64):
+def _ddp(n, dev, rank, srb, precision=64, walking=False):
     from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
     N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
-    prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
+    kw, M, P = {}, 16, 4
+    if walking:
+        # double-support walking sequences: 32-ridge steps, 8-10 contact phases -> the wide kernel (csrc/ddp_wide.hip)
+        N, dt, base, M = 40, 0.05, min(n, 1024), 32
+        prob, x0 = fd.make_walking_batch(base, N, dt, seed=20250928 + rank, srb=srb)
+        P = prob["phase_dim"].shape[1]
+        kw = dict(max_phases=P, max_ridges=32)
+    else:
+        prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
     prob = _tile(prob, n, base)
     x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
     if srb:
         w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0),
                                            terminal_ori=(0.5,) * 3)
-        d = DdpSingleRigidBody(100.0, dt, N, w, device=dev.index)
+        d = DdpSingleRigidBody(100.0, dt, N, w, device=dev.index, **kw)
     else:
         d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
-                          device=dev.index)
+                          device=dev.index, **kw)
     d.ddp_solver_.config().max_iter = 20
     d.ddp_solver_.config().precision = precision
     tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
-    out = torch.zeros((n, N, 16), dtype=torch.float64, device=dev)
+    out = torch.zeros((n, N, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
     it = torch.zeros(n, dtype=torch.int32, device=dev)
 
@@ -91,7 +99,8 @@ def _ddp(n, dev, rank, srb, precision=64):
         from oracle import oracle
         ns = min(n, 2048)
         sub = {a: v[:ns] for a, v in prob.items()}
-        o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20)
+        o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20,
+                       P=P, M=M)
         t0 = time.perf_counter()
         r = o.plan_batch(sub, x0[:ns], nthreads=cores)
         t = time.perf_counter() - t0
@@ -111,12 +120,15 @@ def _ddp(n, dev, rank, srb, precision=64):
                 % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N,
                    "fp64" if precision == 64 else "fp32 storage / fp64 arithmetic in the backward pass"),
                 step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f32",
-                workload="%s horizon=%d @ 30 ms, max_iter=20, batch=%d per GPU (BASELINE config %s)"
-                % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, n,
-                   ("5" if precision == 32 else "5 shape, fp64") if srb else "3"),
-                algo_bytes=4 * 4 + 2 * 4 * 16 * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
-                + S * 8 + N * 16 * 8,
-                kernel=("ddp_plan_kernel<%d,16>" % S) if precision == 64 else ("ddp_group_kernel<%d,float>" % S), cpu=cpu,
+                workload=("%s horizon=%d @ %d ms, max_iter=20, batch=%d per GPU (%s)"
+                          % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, round(dt * 1e3), n,
+                             "walking with 32-ridge double support, %d contact phases: beyond BASELINE's configs, "
+                             "src/DdpCentroidal.cpp:49-60" % P if walking else
+                             "BASELINE config %s" % (("5" if precision == 32 else "5 shape, fp64") if srb else "3"))),
+                algo_bytes=P * 4 + 2 * P * M * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
+                + S * 8 + N * M * 8,
+                kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
+                (("ddp_plan_kernel<%d,16>" % S) if precision == 64 else ("ddp_group_kernel<%d,float>" % S)), cpu=cpu,
                 keep=(d, tp, tx0))
 
 
@@ -217,8 +229,9 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3))
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
+                     walk=(3, 1))
 
 
 def run(args, rank, world, local_rank, dist):
@@ -226,7 +239,7 @@ def run(args, rank, world, local_rank, dist):
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     make = dict(xy=_xy, ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
-                srb32=lambda a, b, c: _ddp(a, b, c, True, 32))
+                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)

@@ -325,6 +325,9 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
   if(tl->C != prm.max_phases)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_closed_loop_device: the timeline has %d contact entries, the handle %d phases",
                 tl->C, prm.max_phases);
+  if(prm.max_ridges != kLoopM)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_closed_loop_device: the contact timeline carries %d ridges per entry, the handle %d",
+                kLoopM, prm.max_ridges);
   const int N = prm.horizon_steps, S = ccc_ddp_state_dim(h), model = prm.model == CCC_DDP_SINGLE_RIGID_BODY ? 1 : 0;
   int device = 0;
   if(int rc = ccc_ddp_get_device(h, &device)) return rc;

@@ -5,7 +5,13 @@
 // per-step matrices live in LDS (struct Mem, ~20 KB per wavefront); trajectories, candidate trajectories and the
 // feedback gains K (N x 16 x S doubles = 115 KB at N = 100) live in an HBM workspace owned by the handle, laid out
 // per instance so that a wavefront streams through contiguous memory.
+//
+// Three kernels behind one entry (dispatch in ccc_ddp_plan_batch_device):
+//   fast   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps
+//   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
+//   group  ddp_group_kernel (csrc/ddp_group.h)             four instances per wavefront; precision 32 (configs[4])
 #include "common.h"
+#include "ddp_batch.h"
 #include "ddp_core.h"
 #include "ddp_group.h"
 
@@ -15,25 +21,6 @@
 
 namespace ccc_amd
 {
-struct DdpBatch
-{
-  const int * phase_dim;
-  const double * phase_vertex;
-  const double * phase_ridge;
-  const int * step_phase;
-  const double * ref_pos;
-  const double * ref_ori;
-  const double * inertia;
-  const double * x0;
-  const double * u_init;
-  double * u_out;
-  double * x_out; // may alias the workspace
-  double *xc, *uc, *ks, *Ks;
-  int * iters;
-  int * status;
-  double * cost;
-};
-
 template<int S, int M>
 __global__ __launch_bounds__(64, 2) void ddp_plan_kernel(ddp::Params P, DdpBatch B, long n)
 {
@@ -75,6 +62,8 @@ struct ccc_ddp
   ccc_ddp_params_t prm{};
   ccc_ddp_config_t cfg{};
   int S = 9;
+  int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
+  bool wide = false;          // the fast kernel's tables do not hold this handle's problems
   int num_cu = 0;
   // device workspace (grown on demand)
   int64_t cap = 0;
@@ -114,12 +103,18 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: unknown model %d", p->model);
   if(!(p->mass > 0) || !(p->horizon_dt > 0) || p->horizon_steps <= 0 || p->max_phases <= 0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: mass, horizon_dt, horizon_steps, max_phases must be > 0");
+  if(p->max_ridges != 0 && p->max_ridges != CCC_DDP_MAX_RIDGES && p->max_ridges != CCC_DDP_MAX_RIDGES_WIDE)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_create: max_ridges = %d, the kernels are built for %d and %d",
+                p->max_ridges, CCC_DDP_MAX_RIDGES, CCC_DDP_MAX_RIDGES_WIDE);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   CCC_DEVICE_GUARD(device);
   ccc_ddp * h = new ccc_ddp();
   h->device = device;
   h->prm = *p;
+  h->M = p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES;
+  h->prm.max_ridges = h->M;
+  h->wide = h->M != CCC_DDP_MAX_RIDGES || p->max_phases > ddp::kMaxPhases || p->horizon_steps > ddp::kMaxSteps;
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -199,7 +194,7 @@ static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
   if(n <= h->cap) return CCC_OK;
   CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
   free_ws(h);
-  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES;
+  const size_t N = h->prm.horizon_steps, S = h->S, M = h->M;
   CCC_HIP_CHECK(hipMalloc(&h->ws_x, (size_t)n * (N + 1) * S * sizeof(double)));
   CCC_HIP_CHECK(hipMalloc(&h->ws_xc, (size_t)n * (N + 1) * S * sizeof(double)));
   CCC_HIP_CHECK(hipMalloc(&h->ws_uc, (size_t)n * N * M * sizeof(double)));
@@ -249,10 +244,14 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   // measured SLOWER on MI355X -- 4096 instances are only 1024 wavefronts, one per SIMD, and with
   // 512 registers and 25 KB of LDS per wavefront nothing hides the dependent LDS / scratch latencies.
   // precision 32 (BASELINE configs[4]) exists in the group kernel only: its backward pass in single precision
-  const bool group = h->cfg.reg_type == 1 && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
+  if(h->wide && h->cfg.precision == 32)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 is built for max_ridges = %d, max_phases <= %d, "
+                "horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
+  const bool group =
+      !h->wide && h->cfg.reg_type == 1 && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
   int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
-  ddp::Params P;
+  ddp_common::Params P;
   std::memset(&P, 0, sizeof(P));
   P.model = h->prm.model;
   P.N = h->prm.horizon_steps;
@@ -327,7 +326,12 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
              x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the gains of the last horizon step are read as a box-QP warm start before they are first written
-  CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * CCC_DDP_MAX_RIDGES * sizeof(double), s));
+  CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * h->M * sizeof(double), s));
+  if(h->wide)
+  {
+    CCC_HIP_CHECK(launch_ddp_wide(P, B, (long)n, h->S, h->M, s));
+    return CCC_OK;
+  }
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances
   if(h->S == 9)
     hipLaunchKernelGGL((ddp_plan_kernel<9, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
@@ -349,7 +353,7 @@ extern "C" int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phas
   if(!phase_dim || !phase_vertex || !phase_ridge || !step_phase || !ref_pos || !x0 || !u_out)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch: NULL required array");
   CCC_DEVICE_GUARD(h->device);
-  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES, Pn = h->prm.max_phases;
+  const size_t N = h->prm.horizon_steps, S = h->S, M = h->M, Pn = h->prm.max_phases;
   if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   // one staging allocation, carved into the arrays (all sizes are multiples of 4 bytes; doubles first)
   struct Seg

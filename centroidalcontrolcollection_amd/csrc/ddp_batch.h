@@ -1,0 +1,36 @@
+// ddp_batch.h -- what csrc/ddp.hip hands to a DDP kernel launch: the batch's arrays (C-ABI layouts of ccc_amd.h) plus the
+// handle's workspaces.  Shared by the fast build (csrc/ddp.hip) and the wide build (csrc/ddp_wide.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ccc_amd
+{
+namespace ddp_common
+{
+struct Params;
+}
+
+struct DdpBatch
+{
+  const int * phase_dim;
+  const double * phase_vertex;
+  const double * phase_ridge;
+  const int * step_phase;
+  const double * ref_pos;
+  const double * ref_ori;
+  const double * inertia;
+  const double * x0;
+  const double * u_init;
+  double * u_out;
+  double * x_out; // may alias the workspace
+  double *xc, *uc, *ks, *Ks;
+  int * iters;
+  int * status;
+  double * cost;
+};
+
+// csrc/ddp_wide.hip: one instance per wavefront, phase versions of csrc/ddp_core.h, S in {9, 12}, M in {16, 32}
+// (ridge stride of the arrays = the handle's max_ridges), any number of contact phases and horizon steps.
+hipError_t launch_ddp_wide(const ddp_common::Params & P, const DdpBatch & B, long n, int S, int M, hipStream_t stream);
+} // namespace ccc_amd

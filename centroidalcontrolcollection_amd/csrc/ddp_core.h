@@ -25,6 +25,27 @@
 #  define CCC_DDP_FN inline
 #endif
 
+// Two device builds of this file, same algorithm and same register-resident code (an M-lane group holds a row of the
+// M x M input-space matrices per lane), different table layouts:
+//   - the FAST build (csrc/ddp.hip, M = 16): contact phases of up to 16 ridges, at most kMaxPhases of them and
+//     kMaxSteps horizon steps, all staged in LDS (20 KB per wavefront, eight wavefronts per CU);
+//   - the WIDE build (csrc/ddp_wide.hip, -DCCC_DDP_WIDE, namespace ddp_wide, M = 16 or 32): up to 32 ridges per step
+//     (two surface contacts; src/DdpCentroidal.cpp:49-60 iterates arbitrary contact lists), one contact phase per
+//     horizon step if need be, any horizon length: the contact tables stay in global memory and the M x M matrices are
+//     padded to a row stride of M + 1 (50 KB of LDS per wavefront at M = 32).
+// The host build (tests/emu) compiles the plain PHASE versions (the "#else" branches of "#if CCC_DDP_FAST"), lanes one
+// after the other, for either table layout.
+#if defined(CCC_DDP_WIDE)
+#  define CCC_DDP_NS ddp_wide
+#else
+#  define CCC_DDP_NS ddp
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#  define CCC_DDP_FAST 1
+#else
+#  define CCC_DDP_FAST 0
+#endif
+
 // No FMA contraction in this translation unit: every product and sum rounds separately, exactly as in the
 // oracle (oracle/ddp.c, gcc -std=c11 => -ffp-contract=off).  With IEEE sqrt and division on both sides the
 // centroidal model then reproduces the oracle's iterates bit for bit, so that the discrete decisions of the
@@ -64,8 +85,51 @@
 
 namespace ccc_amd
 {
-namespace ddp
+// plain data shared by the two device builds (and by the launch code of csrc/ddp.hip / csrc/ddp_wide.hip)
+namespace ddp_common
 {
+// Batch-constant parameters (by value to the kernel)
+struct Params
+{
+  int model; // 0 = DdpCentroidal (S = 9), 1 = DdpSingleRigidBody (S = 12)
+  int N, P;  // horizon steps, contact phases per instance
+  double mass, dt;
+  double w_run[12], w_term[12], w_force; // WeightParam
+  double flo, fhi;                       // force_scale_limits_
+  // nmpc_ddp configuration (SURVEY.md App. B.2 + overrides of src/DdpCentroidal.cpp:197-201)
+  int max_iter;
+  double lambda0, dlambda0, lambda_factor, lambda_min, lambda_max;
+  double k_rel_norm_thre, lambda_thre, ratio_thre, cost_thre;
+  double alpha[11];
+  int reg_type; // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
+};
+
+// Per-instance problem data and workspace (global memory)
+struct Instance
+{
+  const int * phase_dim;       // [P]
+  const double * phase_vertex; // [P][M][3]
+  const double * phase_ridge;  // [P][M][3]
+  const int * step_phase;      // [N]
+  const double * ref_pos;      // [N+1][3]
+  const double * ref_ori;      // [N+1][3]  (SRB)
+  const double * inertia;      // [9]       (SRB)
+  const double * x0;           // [S]
+  const double * u_init;       // [N][M] or nullptr
+  double *xs, *us;             // current trajectory   [(N+1)][S], [N][M]   (us is the u_out of the C-ABI)
+  double *xc, *uc;             // line-search candidate
+  double *ks, *Ks;             // gains [N][M], [N][M][S]
+  int * out_iters;
+  int * out_status;
+  double * out_cost;
+};
+} // namespace ddp_common
+
+namespace CCC_DDP_NS
+{
+using ddp_common::Instance;
+using ddp_common::Params;
+
 // profiler sections
 enum
 {
@@ -102,48 +166,22 @@ CCC_DDP_FN void phase(F && f)
 #endif
 }
 
-// Batch-constant parameters (by value to the kernel)
-struct Params
-{
-  int model; // 0 = DdpCentroidal (S = 9), 1 = DdpSingleRigidBody (S = 12)
-  int N, P;  // horizon steps, contact phases per instance
-  double mass, dt;
-  double w_run[12], w_term[12], w_force; // WeightParam
-  double flo, fhi;                       // force_scale_limits_
-  // nmpc_ddp configuration (SURVEY.md App. B.2 + overrides of src/DdpCentroidal.cpp:197-201)
-  int max_iter;
-  double lambda0, dlambda0, lambda_factor, lambda_min, lambda_max;
-  double k_rel_norm_thre, lambda_thre, ratio_thre, cost_thre;
-  double alpha[11];
-  int reg_type; // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
-};
-
-// Per-instance problem data and workspace (global memory)
-struct Instance
-{
-  const int * phase_dim;       // [P]
-  const double * phase_vertex; // [P][M][3]
-  const double * phase_ridge;  // [P][M][3]
-  const int * step_phase;      // [N]
-  const double * ref_pos;      // [N+1][3]
-  const double * ref_ori;      // [N+1][3]  (SRB)
-  const double * inertia;      // [9]       (SRB)
-  const double * x0;           // [S]
-  const double * u_init;       // [N][M] or nullptr
-  double *xs, *us;             // current trajectory   [(N+1)][S], [N][M]   (us is the u_out of the C-ABI)
-  double *xc, *uc;             // line-search candidate
-  double *ks, *Ks;             // gains [N][M], [N][M][S]
-  int * out_iters;
-  int * out_status;
-  double * out_cost;
-};
+// row stride of the M x M matrices Quu, QuuF, Lf in LDS.  FAST build: M (padding to M + 1 removes their bank conflicts but
+// costs 384 B, which is the difference between eight and seven resident workgroups per CU -- not worth it); WIDE build:
+// M + 1, where lane = row accesses with a stride of 32 doubles would all fall into one bank.
+#if defined(CCC_DDP_WIDE)
+template<int M> constexpr int row_stride() { return M + 1; }
+#else
+template<int M> constexpr int row_stride() { return M; }
+#endif
 
 template<int S, int M>
 struct Mem
 {
+  static constexpr int LQ = row_stride<M>();
   double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
-  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * M], QuuF[M * M];
-  double T1[S * S], T2[S * M], Lf[M * M], K[M * S];
+  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * LQ], QuuF[M * LQ];
+  double T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
   double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
   double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
@@ -153,10 +191,13 @@ struct Mem
 #endif
   int clamped[M], oldc[M];
   int ic[8]; // uniform ints
-  // per-instance problem tables, staged once per solve (every model evaluation reads them)
+  // per-instance problem tables, staged once per solve (every model evaluation reads them); the WIDE build keeps them
+  // in global memory (any horizon length, up to one contact phase per horizon step)
+#if !defined(CCC_DDP_WIDE)
   double pV[kMaxPhases * M * 3], pR[kMaxPhases * M * 3];
   int pdim[kMaxPhases];
   unsigned char sphase[kMaxSteps];
+#endif
 };
 
 // indices into Mem::sc / Mem::ic
@@ -268,9 +309,9 @@ CCC_DDP_FN double lane_value(double v, int k)
 template<int S, int M>
 struct Solver
 {
-  // row stride of the M x M matrices Quu, QuuF, Lf in LDS.  (Padding it to M + 1 removes their bank conflicts but
-  // costs 384 B, which is the difference between eight and seven resident workgroups per CU -- not worth it.)
-  static constexpr int LQ = M;
+  static constexpr int LQ = Mem<S, M>::LQ;
+  static_assert(M == 16 || M == 32, "a row of the M x M matrices per lane of an M-lane group");
+  static constexpr unsigned long long kRowMask = (1ull << M) - 1ull; // the lanes of the first M-lane group
 
   const Params & P;
   const Instance & I;
@@ -278,6 +319,20 @@ struct Solver
 
   CCC_DDP_FN Solver(const Params & p, const Instance & i, Mem<S, M> & m) : P(p), I(i), mem(m) {}
 
+#if defined(CCC_DDP_WIDE)
+  CCC_DDP_FN int dim_of(int step) const
+  {
+    return I.phase_dim[I.step_phase[step]];
+  }
+  CCC_DDP_FN const double * vert_of(int step) const
+  {
+    return I.phase_vertex + static_cast<long>(I.step_phase[step]) * M * 3;
+  }
+  CCC_DDP_FN const double * ridge_of(int step) const
+  {
+    return I.phase_ridge + static_cast<long>(I.step_phase[step]) * M * 3;
+  }
+#else
   CCC_DDP_FN int dim_of(int step) const
   {
     return mem.pdim[mem.sphase[step]];
@@ -290,9 +345,11 @@ struct Solver
   {
     return mem.pR + static_cast<int>(mem.sphase[step]) * M * 3;
   }
+#endif
   // stage the contact tables of this instance in LDS
   CCC_DDP_FN void stage_problem()
   {
+#if !defined(CCC_DDP_WIDE)
     phase([&](int lane) {
       for(int e = lane; e < P.P * M * 3; e += kWave)
       {
@@ -302,6 +359,7 @@ struct Solver
       if(lane < P.P) mem.pdim[lane] = I.phase_dim[lane];
       for(int e = lane; e < P.N; e += kWave) mem.sphase[e] = static_cast<unsigned char>(I.step_phase[e]);
     });
+#endif
   }
 
   // reference of the weighted state entries at a step (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0])
@@ -561,7 +619,7 @@ struct Solver
   // ---- box-QP: min 1/2 k'Hk + g'k, lo <= k <= hi with H = mem.QuuF (m x m, stride m), g = mem.Qu,
   //      warm start in mem.kq; result in mem.kq / mem.clamped / mem.Lf (Cholesky of H with the clamped rows and
   //      columns replaced by identity = the factor of H_ff embedded).  Tassa's boxQP.m; returns result >= 1 on success.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   // Device box-QP: the whole projected-Newton iteration as ONE phase.  Lane i (mod 16) keeps row i of H, its
   // entries of g / lo / hi / x / gradient and the clamped flag in registers; every vector entry another lane needs
   // arrives by v_readlane, every reduction is the oracle's sequential sum run as a readlane chain (same order,
@@ -571,7 +629,7 @@ struct Solver
   // emulation (tests/emu) keeps using.
   CCC_DDP_FN int box_qp(int m)
   {
-    return m == 16 ? box_qp_dev<16>(m) : box_qp_dev<0>(m);
+    return m == M ? box_qp_dev<M>(m) : box_qp_dev<0>(m);
   }
 
   template<int MM>
@@ -580,15 +638,15 @@ struct Solver
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     const int m = MM ? MM : __builtin_amdgcn_readfirstlane(m_rt);
-    const int lane = static_cast<int>(threadIdx.x & 63), i = lane & 15;
+    const int lane = static_cast<int>(threadIdx.x & 63), i = lane & (M - 1);
     const bool in = i < m;
     CCC_PROF_START();
 #if defined(CCC_DDP_PROF)
     if(lane == 0) mem.prof[PR_BOXQP_CALLS] += 1.0;
 #endif
-    double Hr[16];
+    double Hr[M];
 #  pragma unroll
-    for(int k = 0; k < 16; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * LQ + k] : 0.0;
+    for(int k = 0; k < M; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * LQ + k] : 0.0;
     const double gi = in ? mem.Qu[i] : 0.0;
     const double lo = in ? mem.lo[i] : 0.0, hi = in ? mem.hi[i] : 0.0;
     double x = in ? fmin(fmax(mem.kq[i], lo), hi) : 0.0;
@@ -597,7 +655,7 @@ struct Solver
     auto seq_sum = [&](double t) {
       double v = 0;
 #  pragma unroll
-      for(int k = 0; k < 16; ++k)
+      for(int k = 0; k < M; ++k)
         if(k < m) v += lane_value(t, k);
       return v;
     };
@@ -605,7 +663,7 @@ struct Solver
     auto row_dot = [&](double s0, double y) {
       double s = s0;
 #  pragma unroll
-      for(int j = 0; j < 16; ++j)
+      for(int j = 0; j < M; ++j)
         if(j < m) s += Hr[j] * lane_value(y, j);
       return s;
     };
@@ -631,7 +689,7 @@ struct Solver
       const double grad = row_dot(gi, x);
       const bool oldc = cl;
       cl = in && ((x == lo && grad > 0) || (x == hi && grad < 0));
-      const unsigned long long inmask = (m >= 16) ? 0xffffull : ((1ull << m) - 1ull);
+      const unsigned long long inmask = (m >= M) ? kRowMask : ((1ull << m) - 1ull);
       const unsigned long long clmask = __ballot(cl) & inmask;
       const bool changed = (iter == 1) || ((__ballot(cl != oldc) & inmask) != 0ull);
       CCC_PROF_ADD(PR_BOXQP_GRAD);
@@ -660,7 +718,7 @@ struct Solver
       {
         const double g2 = grad * grad;
 #  pragma unroll
-        for(int k = 0; k < 16; ++k)
+        for(int k = 0; k < M; ++k)
           if(k < m && !((clmask >> k) & 1ull)) gn += lane_value(g2, k);
       }
       gn = sqrt(gn);
@@ -668,7 +726,7 @@ struct Solver
       // grad_clamped = g + H (x .* clamped) on the free rows
       double gc = gi;
 #  pragma unroll
-      for(int j = 0; j < 16; ++j)
+      for(int j = 0; j < M; ++j)
         if(j < m && ((clmask >> j) & 1ull)) gc += Hr[j] * lane_value(x, j);
       CCC_PROF_ADD(PR_BOXQP_GRAD);
       if(result != 0) break;
@@ -676,7 +734,7 @@ struct Solver
       {
         // the factor is re-read from LDS for every solve: keeping its 32 entries live across the factorisation would
         // not fit the register budget of two waves per SIMD
-        double lr[16], lc[16], rdi;
+        double lr[M], lc[M], rdi;
         load_factor_lane<MM>(m, i, lr, lc, rdi);
         sol = solve_lane<64, MM>(m, i, (in && !cl) ? gc : 0.0, lr, lc, rdi);
       }
@@ -882,39 +940,56 @@ struct Solver
   // v_readlane (constant lane numbers after unrolling) -- no LDS round trips, no barriers inside.
   CCC_DDP_FN bool cholesky_free(int m)
   {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if(m == 16)
-      cholesky_phase<16>(m);
+#if CCC_DDP_FAST
+    if(m == M)
+      cholesky_phase<M>(m);
     else
       cholesky_phase<0>(m);
     return mem.ic[IC_OK] != 0;
 #else
+    // Phase version, right-looking, lane = row: per column j one phase scales the column below the pivot, the next
+    // writes the pivot and subtracts the column's outer product from row i (entries k = j+1 .. i).  Every entry
+    // (i, k) thus has its products subtracted in increasing j, as the oracle does.
     const double * H = mem.QuuF;
-    bool ok = true;
-    for(int i = 0; i < m; i++)
-      for(int k = 0; k <= i; k++)
-      {
-        const bool cl = mem.clamped[i] || mem.clamped[k];
-        mem.Lf[i * LQ + k] = cl ? (i == k ? 1.0 : 0.0) : H[i * LQ + k];
-      }
+    phase([&](int lane) {
+      if(lane < m)
+        for(int k = 0; k <= lane; k++)
+        {
+          const bool cl = mem.clamped[lane] || mem.clamped[k];
+          mem.Lf[lane * LQ + k] = cl ? (lane == k ? 1.0 : 0.0) : H[lane * LQ + k];
+        }
+      if(lane == 0) mem.ic[IC_OK] = 1;
+    });
     for(int j = 0; j < m; j++)
     {
-      const double d = mem.Lf[j * LQ + j];
-      ok = ok && (d > 0.0);
-      const double sq = sqrt(d);
-      const double r = 1.0 / sq;
-      mem.Lf[j * LQ + j] = sq;
-      mem.rd[j] = r;
-      for(int i = j + 1; i < m; i++) mem.Lf[i * LQ + j] = mem.Lf[i * LQ + j] * r;
-      for(int k = j + 1; k < m; k++)
-        for(int i = k; i < m; i++) mem.Lf[i * LQ + k] -= mem.Lf[i * LQ + j] * mem.Lf[k * LQ + j];
+      phase([&](int lane) {
+        if(lane > j && lane < m)
+        {
+          const double r = 1.0 / sqrt(mem.Lf[j * LQ + j]);
+          mem.Lf[lane * LQ + j] = mem.Lf[lane * LQ + j] * r;
+        }
+      });
+      phase([&](int lane) {
+        if(lane == j)
+        {
+          const double d = mem.Lf[j * LQ + j];
+          if(!(d > 0.0)) mem.ic[IC_OK] = 0;
+          const double sq = sqrt(d);
+          mem.Lf[j * LQ + j] = sq;
+          mem.rd[j] = 1.0 / sq;
+        }
+        else if(lane > j && lane < m)
+        {
+          const double lij = mem.Lf[lane * LQ + j];
+          for(int k = j + 1; k <= lane; k++) mem.Lf[lane * LQ + k] -= lij * mem.Lf[k * LQ + j];
+        }
+      });
     }
-    mem.ic[IC_OK] = ok ? 1 : 0;
-    return ok;
+    return mem.ic[IC_OK] != 0;
 #endif
   }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   // MM = 16: every step has the full 16 ridges (the usual case) -- all size tests fold away and the factorisation is
   // straight-line code; MM = 0: size m at run time.
   template<int MM>
@@ -923,10 +998,10 @@ struct Solver
     const double * H = mem.QuuF;
     const int m = MM ? MM : m_rt;
     phase([&](int lane) {
-      const int i = lane & 15;
-      double a[16];
+      const int i = lane & (M - 1);
+      double a[M];
 #  pragma unroll
-      for(int k = 0; k < 16; ++k)
+      for(int k = 0; k < M; ++k)
       {
         const bool in = (i < m) && (k < m);
         const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
@@ -935,7 +1010,7 @@ struct Solver
       bool ok = true;
       double rdi = 1.0;
 #  pragma unroll
-      for(int j = 0; j < 16; ++j)
+      for(int j = 0; j < M; ++j)
       {
         if(j < m)
         {
@@ -951,7 +1026,7 @@ struct Solver
           else if(i > j)
             a[j] = a[j] * r;
 #  pragma unroll
-          for(int k = j + 1; k < 16; ++k)
+          for(int k = j + 1; k < M; ++k)
           {
             if(k < m)
             {
@@ -964,7 +1039,7 @@ struct Solver
       if(lane < m)
       {
 #  pragma unroll
-        for(int k = 0; k < 16; ++k)
+        for(int k = 0; k < M; ++k)
           if(k <= i) mem.Lf[i * LQ + k] = a[k];
         mem.rd[i] = rdi;
       }
@@ -974,13 +1049,13 @@ struct Solver
 #endif
 
   // registers of lane i for the triangular solves: row i of L left of the diagonal, column i below it
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   template<int MM>
-  CCC_DDP_FN void load_factor_lane(int m_rt, int i, double (&lr)[16], double (&lc)[16], double & rdi) const
+  CCC_DDP_FN void load_factor_lane(int m_rt, int i, double (&lr)[M], double (&lc)[M], double & rdi) const
   {
     const int m = MM ? MM : m_rt;
 #  pragma unroll
-    for(int k = 0; k < 16; ++k)
+    for(int k = 0; k < M; ++k)
     {
       lr[k] = (i < m && k < i) ? mem.Lf[i * LQ + k] : 0.0;
       lc[k] = (i < m && k < m && k > i) ? mem.Lf[k * LQ + i] : 0.0;
@@ -989,11 +1064,11 @@ struct Solver
   }
   // acc <- (L L')^-1 acc inside a 16-lane group (WIDTH = 16) or with every group redundant (WIDTH = 64)
   template<int WIDTH, int MM>
-  static CCC_DDP_FN double solve_lane(int m_rt, int i, double acc, const double (&lr)[16], const double (&lc)[16], double rdi)
+  static CCC_DDP_FN double solve_lane(int m_rt, int i, double acc, const double (&lr)[M], const double (&lc)[M], double rdi)
   {
     const int m = MM ? MM : m_rt;
 #  pragma unroll
-    for(int k = 0; k < 16; ++k)
+    for(int k = 0; k < M; ++k)
     {
       if(k < m)
       {
@@ -1005,7 +1080,7 @@ struct Solver
       }
     }
 #  pragma unroll
-    for(int k = 15; k >= 0; --k)
+    for(int k = M - 1; k >= 0; --k)
     {
       if(k < m)
       {
@@ -1024,12 +1099,21 @@ struct Solver
   // multiplying by the reciprocal diagonal (the oracle's order).  v is an LDS vector of length m.
   CCC_DDP_FN void solve_free(int m, double * v)
   {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if(m == 16)
-      solve_free_phase<16>(m, v);
+#if CCC_DDP_FAST
+    if(m == M)
+      solve_free_phase<M>(m, v);
     else
       solve_free_phase<0>(m, v);
 #else
+    phase([&](int lane) {
+      if(lane == 0) solve_free_seq(m, v);
+    });
+#endif
+  }
+
+  // the two substitutions by ONE lane (phase versions: box-QP direction by lane 0, the S gain columns by S lanes)
+  CCC_DDP_FN void solve_free_seq(int m, double * v) const
+  {
     for(int a = 0; a < m; a++)
     {
       double s = v[a];
@@ -1042,17 +1126,16 @@ struct Solver
       for(int k = m - 1; k > a; k--) s -= mem.Lf[k * LQ + a] * v[k];
       v[a] = s * mem.rd[a];
     }
-#endif
   }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   template<int MM>
   CCC_DDP_FN void solve_free_phase(int m_rt, double * v)
   {
     const int m = MM ? MM : m_rt;
     phase([&](int lane) {
-      const int i = lane & 15;
-      double lr[16], lc[16], rdi;
+      const int i = lane & (M - 1);
+      double lr[M], lc[M], rdi;
       load_factor_lane<MM>(m, i, lr, lc, rdi);
       const double acc = solve_lane<64, MM>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi);
       if(lane < m) v[i] = acc;
@@ -1110,24 +1193,30 @@ struct Solver
   // wavefront each solve one right-hand side (state index) at a time.
   CCC_DDP_FN void gains(int m)
   {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if(m == 16)
-      gains_phase<16>(m);
+#if CCC_DDP_FAST
+    if(m == M)
+      gains_phase<M>(m);
     else
       gains_phase<0>(m);
 #else
-    for(int a = 0; a < S; a++)
-    {
-      double t3[M];
-      for(int f = 0; f < m; f++) t3[f] = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
-      solve_free(m, t3);
-      for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
-    }
-    for(int r = 0; r < m; r++) mem.k[r] = mem.kq[r];
+    // lane a < S solves for state index a; its right-hand side lives in row a of mem.T2 (free between the products
+    // and the value update)
+    phase([&](int lane) {
+      if(lane < S)
+      {
+        const int a = lane;
+        double * t3 = mem.T2 + a * M;
+        for(int f = 0; f < m; f++) t3[f] = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
+        solve_free_seq(m, t3);
+        for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
+      }
+      else if(lane >= 32 && lane - 32 < m)
+        mem.k[lane - 32] = mem.kq[lane - 32];
+    });
 #endif
   }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   // Device matrix product with one OUTPUT COLUMN per lane: lane (g, c) = (lane / 16, lane % 16) keeps column c of the
   // right factor in registers and produces C(a, c) for the rows a = g, g + 4, ..; the left factor's entries are read
   // from LDS as broadcasts (one address per 16-lane group).  The element-per-lane loops of the phase version read two
@@ -1139,12 +1228,12 @@ struct Solver
   CCC_DDP_FN void colprod(int lane, int rows, int ncols, const double * A, int lda, const double * B, int ldb, double lam,
                           double * C, int ldc) const
   {
-    const int c = lane & 15, g = lane >> 4;
+    const int c = lane & (M - 1), g = lane / M;
     const bool act = c < ncols;
     double Bc[S];
 #  pragma unroll
     for(int k = 0; k < S; k++) Bc[k] = act ? B[k * ldb + c] : 0.0;
-    for(int a = g; a < rows; a += 4)
+    for(int a = g; a < rows; a += kWave / M)
     {
       double sum = 0.0;
       if(DIAG == 1) sum = (a == c) ? P.w_run[a] : 0.0;
@@ -1177,7 +1266,7 @@ struct Solver
       }
     });
     StepRegs sr;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
     fetch_step(N - 1, static_cast<int>(threadIdx.x & 63), sr);
 #endif
     for(int i = N - 1; i >= 0; i--)
@@ -1213,7 +1302,7 @@ struct Solver
       const int m = MM ? MM : m_rt;
       const double lambda_v = P.reg_type == 2 ? mem.sc[SC_LAMBDA] : 0.0;
       const double lambda_q = P.reg_type == 2 ? 0.0 : mem.sc[SC_LAMBDA];
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
       const StepRegs cur = sr;
       {
         const int lane = static_cast<int>(threadIdx.x & 63);
@@ -1221,7 +1310,7 @@ struct Solver
       }
 #endif
       phase([&](int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
         if(lane < S) mem.x[lane] = cur.x;
         if(lane < M) mem.u[lane] = (lane < m) ? cur.u : 0.0;
 #else
@@ -1236,7 +1325,7 @@ struct Solver
         // Qx = Lx + Fx'Vx ; Qu = Lu + Fu'Vx
         if(lane < S)
         {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
           double s = P.w_run[lane] * (mem.x[lane] - cur.ref);
 #else
           double s = P.w_run[lane] * (mem.x[lane] - ref_entry(i, lane));
@@ -1254,7 +1343,7 @@ struct Solver
         // T1 = Vxx Fx ; T2 = Vxx Fu ; regularised T2r = (Vxx + lambda I) Fu, parked in mem.Lf (free until the box-QP
         // factorises) so that everything built from T1 / T2 / T2r fits one more phase
         double * const T2r = mem.Lf;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
         colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
         colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
         colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda_v, T2r, M);
@@ -1284,7 +1373,7 @@ struct Solver
       });
       phase([&](int lane) {
         // Qxx = Lxx + Fx'T1 ; Qxu = Fx'T2 ; Quu = Luu + Fu'T2   (Lxu = 0, Lxx = diag(w_run), Luu = w_force I)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
         colprod<true, 1, false>(lane, S, S, mem.Fx, S, mem.T1, S, 0.0, mem.Qxx, S);
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxu, M);
         colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.Quu, LQ);
@@ -1313,7 +1402,7 @@ struct Solver
 #endif
         // regularised versions from T2r
         const double * const T2r = mem.Lf;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
         colprod<true, 3, false>(lane, m, m, mem.Fu, M, T2r, M, lambda_q, mem.QuuF, LQ);
 #else
@@ -1339,7 +1428,7 @@ struct Solver
           mem.lo[lane] = P.flo - mem.u[lane];
           mem.hi[lane] = P.fhi - mem.u[lane];
           const bool warm = (i + 1 < N) && (dim_of(i + 1) == m);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
           mem.kq[lane] = (warm && lane < m) ? cur.kprev : 0.0;
 #else
           mem.kq[lane] = (warm && lane < m) ? I.ks[static_cast<long>(i + 1) * M + lane] : 0.0;
@@ -1369,7 +1458,7 @@ struct Solver
         if(lane < M)
         {
           I.ks[static_cast<long>(i) * M + lane] = mem.k[lane];
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
           sr.kprev = mem.k[lane];
 #endif
         }
@@ -1426,7 +1515,7 @@ struct Solver
   }
 
   // ---- rollout of the initial inputs / line-search candidate.  alpha < 0: plain rollout of I.us into I.xs.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
   // Device rollout for the centroidal model (S = 9): ONE phase for the whole trajectory.  Lane a keeps state entry a,
   // lane r the input of ridge r; the feedback, the dynamics and the cost reach across lanes with v_readlane in the
   // oracle's summation order (no LDS staging, no barriers per step), and the gains / nominal trajectory of the next
@@ -1449,7 +1538,7 @@ struct Solver
     // 3-5 u_r (p_r - c) x rho_r, 6 u_r^2 (columns = ridges), row 7 the state-cost terms.  The block of backward-pass
     // matrices Qxx .. of Mem is idle during a rollout.
     double * const pr = mem.Qxx;
-    static_assert(8 * 16 <= 2 * S * S + 3 * S * M, "staging area too small");
+    static_assert(8 * M <= 2 * S * S + 3 * S * M, "staging area too small");
     // operands of step 0 (the next step's are fetched from HBM while the current one computes)
     double us_c = 0.0, ks_c = 0.0, Kr_c[S], xi_c[S], ref_c = 0.0;
     auto fetch = [&](int i, double & us_v, double & ks_v, double (&Kr_v)[S], double (&xi_v)[S], double & ref_v) {
@@ -1519,22 +1608,22 @@ struct Solver
 #  pragma unroll
         for(int k = 0; k < 3; k++)
         {
-          pr[k * 16 + lane] = u * rr[k];
-          pr[(3 + k) * 16 + lane] = u * c[k];
+          pr[k * M + lane] = u * rr[k];
+          pr[(3 + k) * M + lane] = u * c[k];
         }
-        pr[6 * 16 + lane] = u * u;
+        pr[6 * M + lane] = u * u;
       }
       if(st)
       {
         const double e = x - ref_c;
-        pr[7 * 16 + lane] = 0.5 * wr * e * e;
+        pr[7 * M + lane] = 0.5 * wr * e * e;
       }
       __syncthreads();
       double acc = (lane == 5) ? -1 * P.mass * kGravity : 0.0;
       if(sums)
       {
         const int cnt = (lane == kTermLane) ? S : m;
-        const double * row = pr + myrow * 16;
+        const double * row = pr + myrow * M;
         for(int r = 0; r < cnt; r++) acc += row[r];
       }
       const double cterm = lane_value(acc, kTermLane);
@@ -1573,7 +1662,7 @@ struct Solver
 
   CCC_DDP_FN void rollout(double alpha)
   {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if CCC_DDP_FAST
     if constexpr(S == 9)
     {
       rollout_centroidal(alpha);
@@ -1780,5 +1869,5 @@ struct Solver
     });
   }
 };
-} // namespace ddp
+} // namespace CCC_DDP_NS
 } // namespace ccc_amd

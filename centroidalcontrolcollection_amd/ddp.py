@@ -13,13 +13,14 @@ import numpy as np
 
 from . import _lib
 
-MAX_RIDGES = 16
+MAX_RIDGES = 16  # default ridge stride (one surface contact per step)
+MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support), the wide kernel
 
 
 class _Params(ctypes.Structure):
     _fields_ = [("model", ctypes.c_int), ("mass", ctypes.c_double), ("horizon_dt", ctypes.c_double),
                 ("horizon_steps", ctypes.c_int), ("w_run", ctypes.c_double * 12), ("w_term", ctypes.c_double * 12),
-                ("w_force", ctypes.c_double), ("force_scale_limits", ctypes.c_double * 2), ("max_phases", ctypes.c_int)]
+                ("w_force", ctypes.c_double), ("force_scale_limits", ctypes.c_double * 2), ("max_phases", ctypes.c_int), ("max_ridges", ctypes.c_int)]
 
 
 class Config(ctypes.Structure):
@@ -77,7 +78,8 @@ class _DdpBase:
     MODEL = 0
     S = 9
 
-    def __init__(self, mass, horizon_dt, horizon_steps, w_run, w_term, w_force, device=0, max_phases=4):
+    def __init__(self, mass, horizon_dt, horizon_steps, w_run, w_term, w_force, device=0, max_phases=4,
+                 max_ridges=MAX_RIDGES):
         L = _lib.load()
         _bind(L)
         self._L = L
@@ -88,6 +90,9 @@ class _DdpBase:
         p.w_force = float(w_force)
         p.force_scale_limits[0], p.force_scale_limits[1] = 0.0, 1e6  # force_scale_limits_, DdpCentroidal.h:364
         p.max_phases = int(max_phases)
+        p.max_ridges = int(max_ridges)
+        self.max_ridges_ = int(max_ridges)
+        self._w_run, self._w_term, self._w_force = list(w_run), list(w_term), float(w_force)
         h = ctypes.c_void_p()
         _lib.check(L.ccc_ddp_create(ctypes.byref(p), int(device), ctypes.byref(h)))
         self._h = h
@@ -105,10 +110,10 @@ class _DdpBase:
 
     # ------------------------------------------------------------------ batched entry points
     def planOnceBatch(self, prob, x0, u_init=None, want_x=False):
-        """Host arrays in / out (ccc_ddp_plan_batch).  prob: dict(phase_dim [n,P] i32, phase_vertex [n,P,16,3],
-        phase_ridge [n,P,16,3], step_phase [n,N] i32, ref_pos [n,N+1,3] (+ ref_ori [n,N+1,3], inertia [n,3,3]));
-        x0 [n,S]; u_init [n,N,16] | None.  Returns dict(u [n,N,16], x | None, iters, status, cost)."""
-        N, P, S, M = self.horizon_steps_, self.max_phases_, self.S, MAX_RIDGES
+        """Host arrays in / out (ccc_ddp_plan_batch).  prob: dict(phase_dim [n,P] i32, phase_vertex [n,P,M,3],
+        phase_ridge [n,P,M,3], step_phase [n,N] i32, ref_pos [n,N+1,3] (+ ref_ori [n,N+1,3], inertia [n,3,3]));
+        x0 [n,S]; u_init [n,N,M] | None, M = max_ridges.  Returns dict(u [n,N,M], x | None, iters, status, cost)."""
+        N, P, S, M = self.horizon_steps_, self.max_phases_, self.S, self.max_ridges_
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         n = x0.shape[0]
         arr = dict(phase_dim=np.ascontiguousarray(prob["phase_dim"], dtype=np.int32),
@@ -172,21 +177,19 @@ class _DdpBase:
     # ------------------------------------------------------------------ reference surface
     def _sample(self, motion_param_func, ref_data_func, current_time):
         """src/DdpCentroidal.cpp:218-229: sample the callbacks at current_time + i*dt and flatten the contact lists
-        into contact phases (consecutive steps with the same contact list share a phase)."""
-        N, P, M = self.horizon_steps_, self.max_phases_, MAX_RIDGES
-        prob = dict(phase_dim=np.zeros((1, P), dtype=np.int32), phase_vertex=np.zeros((1, P, M, 3)),
-                    phase_ridge=np.zeros((1, P, M, 3)), step_phase=np.zeros((1, N), dtype=np.int32),
-                    ref_pos=np.zeros((1, N + 1, 3)))
-        if self.MODEL == 1:
-            prob["ref_ori"] = np.zeros((1, N + 1, 3))
-            prob["inertia"] = np.zeros((1, 3, 3))
+        into contact phases (consecutive steps with the same contact list share a phase).  Returns (planner, prob): this
+        object when its tables hold the problem, else a wide twin (max_ridges = 32, one phase per step if need be)
+        created on first need -- the reference takes any contact_list (src/DdpCentroidal.cpp:49-60)."""
+        N = self.horizon_steps_
+        ref_pos, ref_ori, inertia = np.zeros((1, N + 1, 3)), np.zeros((1, N + 1, 3)), np.zeros((1, 3, 3))
+        step_phase = np.zeros((1, N), dtype=np.int32)
         phases = []
         for i in range(N + 1):
             t = current_time + i * self.dt_
             ref = ref_data_func(t)
-            prob["ref_pos"][0, i] = ref.pos
+            ref_pos[0, i] = ref.pos
             if self.MODEL == 1:
-                prob["ref_ori"][0, i] = ref.ori
+                ref_ori[0, i] = ref.ori
             if i == N:
                 break
             mp = motion_param_func(t)
@@ -195,28 +198,44 @@ class _DdpBase:
                 R = np.concatenate([np.asarray(c[1], dtype=np.float64).reshape(-1, 3) for c in mp.contact_list])
             else:
                 V, R = np.zeros((0, 3)), np.zeros((0, 3))
-            if len(V) > M:
-                raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "more than %d ridges in one contact list" % M)
+            if len(V) > MAX_RIDGES_WIDE:
+                raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "%d ridges in one contact list, the kernels are built "
+                                    "for %d (two 4-vertex surface contacts)" % (len(V), MAX_RIDGES_WIDE))
             if self.MODEL == 1 and i == 0:
-                prob["inertia"][0] = mp.inertia_mat
+                inertia[0] = mp.inertia_mat
             for k, (Vk, Rk) in enumerate(phases):
                 if Vk.shape == V.shape and np.array_equal(Vk, V) and np.array_equal(Rk, R):
-                    prob["step_phase"][0, i] = k
+                    step_phase[0, i] = k
                     break
             else:
-                if len(phases) >= P:
-                    raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "more than max_phases=%d contact phases in the horizon" % P)
                 phases.append((V, R))
-                k = len(phases) - 1
-                prob["phase_dim"][0, k] = len(V)
-                prob["phase_vertex"][0, k, :len(V)] = V
-                prob["phase_ridge"][0, k, :len(V)] = R
-                prob["step_phase"][0, i] = k
-        return prob
+                step_phase[0, i] = len(phases) - 1
+        planner = self
+        if len(phases) > self.max_phases_ or max([len(V) for V, _ in phases] + [0]) > self.max_ridges_:
+            planner = self._wide_twin()
+        P, M = planner.max_phases_, planner.max_ridges_
+        prob = dict(phase_dim=np.zeros((1, P), dtype=np.int32), phase_vertex=np.zeros((1, P, M, 3)),
+                    phase_ridge=np.zeros((1, P, M, 3)), step_phase=step_phase, ref_pos=ref_pos)
+        if self.MODEL == 1:
+            prob["ref_ori"], prob["inertia"] = ref_ori, inertia
+        for k, (V, R) in enumerate(phases):
+            prob["phase_dim"][0, k] = len(V)
+            prob["phase_vertex"][0, k, :len(V)] = V
+            prob["phase_ridge"][0, k, :len(V)] = R
+        return planner, prob
+
+    def _wide_twin(self):
+        if getattr(self, "_wide", None) is None:
+            self._wide = _DdpBase.__new__(type(self))
+            _DdpBase.__init__(self._wide, self.mass_, self.dt_, self.horizon_steps_, self._w_run, self._w_term,
+                              self._w_force, self.device, max_phases=self.horizon_steps_, max_ridges=MAX_RIDGES_WIDE)
+        self._wide.ddp_solver_ = self.ddp_solver_  # one configuration / control data, as the caller sees one solver
+        return self._wide
 
     def _plan_once(self, motion_param_func, ref_data_func, x0, u_list, current_time):
-        N, M = self.horizon_steps_, MAX_RIDGES
-        prob = self._sample(motion_param_func, ref_data_func, current_time)
+        N = self.horizon_steps_
+        planner, prob = self._sample(motion_param_func, ref_data_func, current_time)
+        M = planner.max_ridges_
         dims = prob["phase_dim"][0][prob["step_phase"][0]]
         u_init = None
         if u_list:
@@ -228,7 +247,7 @@ class _DdpBase:
                 if len(ui) != dims[i]:
                     raise ValueError("u_list[%d] has %d entries, inputDim is %d" % (i, len(ui), dims[i]))
                 u_init[0, i, :len(ui)] = ui
-        r = self.planOnceBatch(prob, x0[None], u_init, want_x=True)
+        r = planner.planOnceBatch(prob, x0[None], u_init, want_x=True)
         cd = self.ddp_solver_.controlData()
         cd.u_list = [r["u"][0, i, :dims[i]].copy() for i in range(N)]
         cd.x_list = [r["x"][0, i].copy() for i in range(N + 1)]
@@ -271,12 +290,13 @@ class DdpCentroidal(_DdpBase):
             # src/DdpCentroidal.cpp:186-191
             return np.concatenate([self.pos, mass * self.vel, self.angular_momentum])
 
-    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0, max_phases=4):
+    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0, max_phases=4,
+                 max_ridges=MAX_RIDGES):
         w = weight_param or DdpCentroidal.WeightParam()
         super().__init__(mass, horizon_dt, horizon_steps,
                          np.concatenate([w.running_pos, w.running_linear_momentum, w.running_angular_momentum]),
                          np.concatenate([w.terminal_pos, w.terminal_linear_momentum, w.terminal_angular_momentum]),
-                         w.running_force, device, max_phases)
+                         w.running_force, device, max_phases, max_ridges)
 
     def planOnce(self, motion_param_func, ref_data_func, initial_param, current_time):
         """src/DdpCentroidal.cpp:213-237: returns controlData().u_list[0] (planned force scales)."""
@@ -319,9 +339,11 @@ class DdpSingleRigidBody(_DdpBase):
             # src/DdpSingleRigidBody.cpp:253-258
             return np.concatenate([self.pos, self.ori, self.linear_vel, self.angular_vel])
 
-    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0, max_phases=4):
+    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0, max_phases=4,
+                 max_ridges=MAX_RIDGES):
         w = weight_param or DdpSingleRigidBody.WeightParam()
-        super().__init__(mass, horizon_dt, horizon_steps, w.running, w.terminal, w.running_force, device, max_phases)
+        super().__init__(mass, horizon_dt, horizon_steps, w.running, w.terminal, w.running_force, device, max_phases,
+                         max_ridges)
 
     def planOnce(self, motion_param_func, ref_data_func, initial_param, current_time):
         """src/DdpSingleRigidBody.cpp:283-307."""

@@ -171,6 +171,72 @@ def make_centroidal_batch(n, N=100, dt=0.03, mass=100.0, P=4, M=16, seed=2025092
     return prob, np.ascontiguousarray(x0)
 
 
+def make_walking_batch(n, N=40, dt=0.05, mass=100.0, M=32, seed=20250928, srb=False, step_duration=(0.3, 0.5),
+                       double_support=(0.1, 0.2), flight_prob=0.25):
+    """Walking sequences that need the contact lists of the reference in full (src/DdpCentroidal.cpp:49-60 iterates
+    an arbitrary contact_list): DOUBLE support = two surface contacts = 32 ridges, single support = 16, an
+    occasional flight phase = 0, and as many distinct contact phases as the horizon holds (P = number of phases of the
+    longest instance, typically 6-10, i.e. more than the four of the reference test scenario).
+
+    Per instance: feet 0.2 x 0.1 rects at y = +-0.1, the swing foot lands 0.1-0.25 m ahead of the stance foot; phases
+    alternate double support / single support (left, right, ...), a single support being replaced by a short flight
+    with probability flight_prob; durations U(step_duration), U(double_support).  Reference CoM: mid-point of the
+    supporting feet at height 1.0.  x0: c = ref + U(-0.03, 0.03)^3, v ~ U(-0.1, 0.1)^3.
+    PRNG numpy default_rng(seed) (PCG64).  Returns (prob, x0 [n,S]) with P = prob["phase_dim"].shape[1]."""
+    rng = np.random.default_rng(seed)
+    hx, hy = 0.1, 0.05
+    plans = []
+    for k in range(n):
+        feet = {0: np.array([0.0, 0.1]), 1: np.array([rng.uniform(-0.05, 0.05), -0.1])}  # left, right
+        swing = int(rng.integers(0, 2))
+        t, phases = 0.0, []  # (end time, [foot centres], ref xy)
+        horizon = N * dt + 1e-3
+        while t < horizon:
+            dur = rng.uniform(*double_support)
+            both = [feet[0].copy(), feet[1].copy()]
+            t += dur
+            phases.append((t, both, 0.5 * (both[0] + both[1])))
+            if t >= horizon:
+                break
+            stance = 1 - swing
+            dur = rng.uniform(*step_duration)
+            t += dur
+            if rng.uniform() < flight_prob:
+                phases.append((t - 0.5 * dur, [feet[stance].copy()], feet[stance].copy()))
+                phases.append((t, [], feet[stance] + np.array([0.05, 0.0])))
+            else:
+                phases.append((t, [feet[stance].copy()], feet[stance].copy()))
+            feet[swing] = np.array([feet[stance][0] + rng.uniform(0.1, 0.25), feet[swing][1]])
+            swing = stance
+        plans.append(phases)
+    P = max(len(ph) for ph in plans)
+    prob = empty_problem(n, N, P, M, srb)
+    for k, phases in enumerate(plans):
+        ends = np.array([e for e, _, _ in phases])
+        for p, (_, centres, _) in enumerate(phases):
+            r = 0
+            for c in centres:
+                V, R = contact_from_rect((c[0] - hx, c[1] - hy), (c[0] + hx, c[1] + hy))
+                prob["phase_vertex"][k, p, r:r + 16], prob["phase_ridge"][k, p, r:r + 16] = V, R
+                r += 16
+            prob["phase_dim"][k, p] = r
+        for i in range(N + 1):
+            p = min(int(np.searchsorted(ends, i * dt + 1e-6, side="right")), len(phases) - 1)
+            if i < N:
+                prob["step_phase"][k, i] = p
+            prob["ref_pos"][k, i] = [phases[p][2][0], phases[p][2][1], 1.0]
+    ref0 = prob["ref_pos"][:, 0, :]
+    c0 = ref0 + rng.uniform(-0.03, 0.03, size=(n, 3))
+    v0 = rng.uniform(-0.1, 0.1, size=(n, 3))
+    if srb:
+        prob["inertia"][:] = np.diag([40.0, 20.0, 10.0])
+        x0 = np.concatenate([c0, rng.uniform(-0.05, 0.05, size=(n, 3)), v0, rng.uniform(-0.1, 0.1, size=(n, 3))],
+                            axis=1)
+    else:
+        x0 = np.concatenate([c0, mass * v0, np.zeros((n, 3))], axis=1)
+    return prob, np.ascontiguousarray(x0)
+
+
 def srb_ori_ref(t):
     """TestDdpSingleRigidBody.cpp:78-85 (the +1e-6 included): roll reference bump between 2.2 s and 2.4 s."""
     t = t + 1e-6

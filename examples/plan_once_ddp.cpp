@@ -85,6 +85,51 @@ int main()
       for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
       std::printf("\n");
     }
+    {
+      // Walking with double support: a two-element contact_list (32 ridges, src/DdpCentroidal.cpp:49-60) and six
+      // distinct contact lists inside the horizon -- beyond the fast kernel's tables; the shim routes the call to the
+      // wide kernel behind the same planOnce().
+      const double wdt = 0.05;
+      const int WN = 40;
+      CCC::DdpCentroidal::WeightParam w;
+      w.running_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      w.terminal_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      CCC::DdpCentroidal ddp(mass, wdt, WN, w);
+      ddp.ddp_solver_->config().max_iter = 30;
+      auto foot = [](double x, double y) {
+        return CCC::makeContactFromRect({CCC::Vector2d(x - 0.1, y - 0.05), CCC::Vector2d(x + 0.1, y + 0.05)});
+      };
+      // left foot at y = +0.1, right foot at y = -0.1; phases of 0.4 s: DS, right swings, DS, left swings, DS, flight, DS
+      const std::vector<std::shared_ptr<CCC::Contact>> L = {foot(0.0, 0.1), foot(0.3, 0.1), foot(0.6, 0.1)};
+      const std::vector<std::shared_ptr<CCC::Contact>> R = {foot(0.0, -0.1), foot(0.15, -0.1), foot(0.45, -0.1)};
+      auto motion = [&](double t) {
+        t += 1e-6;
+        CCC::DdpCentroidal::MotionParam mp;
+        const int ph = static_cast<int>(t / 0.3);
+        switch(ph)
+        {
+          case 0: mp.contact_list = {L[0], R[0]}; break;
+          case 1: mp.contact_list = {L[0]}; break;
+          case 2: mp.contact_list = {L[0], R[1]}; break;
+          case 3: mp.contact_list = {R[1]}; break;
+          case 4: mp.contact_list = {L[1], R[1]}; break;
+          case 5: mp.contact_list = {L[1]}; break;
+          default: mp.contact_list = {L[1], R[2]}; break;
+        }
+        return mp;
+      };
+      auto ref = [](double t) {
+        CCC::DdpCentroidal::RefData r;
+        r.pos = CCC::Vector3d(0.15 * t, 0.0, 1.0);
+        return r;
+      };
+      CCC::DdpCentroidal::InitialParam ip;
+      ip.pos = CCC::Vector3d(0.0, 0.01, 1.0);
+      CCC::VectorXd u = ddp.planOnce(motion, ref, ip, 0.0);
+      std::printf("walking iter=%d dim=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size());
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+    }
     return 0;
   }
   catch(const std::exception & e)

@@ -116,9 +116,7 @@ public:
     p.force_scale_limits[0] = force_scale_limits_[0];
     p.force_scale_limits[1] = force_scale_limits_[1];
     p.max_phases = max_phases;
-    ccc_ddp_t * h = nullptr;
-    ddp_shim::check(ccc_ddp_create(&p, device, &h), "DdpCentroidal");
-    handle_.reset(h, ccc_ddp_destroy);
+    handles_.create(p, device, "DdpCentroidal");
     ddp_solver_->config().horizon_steps = horizon_steps; // src/DdpCentroidal.cpp:198
     ddp_solver_->config().max_iter = 500; // nmpc_ddp default
   }
@@ -133,7 +131,7 @@ public:
     ddp_problem_->motion_param_func_ = motion_param_func;
     ddp_problem_->ref_data_func_ = ref_data_func;
     ddp_shim::Flat f;
-    f.init(horizon_steps_, max_phases_);
+    f.init(horizon_steps_);
     for(int i = 0; i <= horizon_steps_; i++)
     {
       const double t = current_time + i * ddp_problem_->dt();
@@ -141,14 +139,16 @@ public:
       for(int a = 0; a < 3; a++) f.ref_pos[static_cast<size_t>(i) * 3 + a] = ref.pos[a];
       if(i < horizon_steps_) f.setStepContacts(i, motion_param_func(t).contact_list);
     }
-    return ddp_shim::solveOne(handle_.get(), *ddp_solver_, f, false, initial_param.toState(ddp_problem_->mass_),
+    return ddp_shim::solveOne(handles_.select(f, "DdpCentroidal"), *ddp_solver_, f, false, initial_param.toState(ddp_problem_->mass_),
                               initial_param.u_list, "DdpCentroidal");
   }
 
-  /** \brief The C-ABI handle, for the flat-array batch entry points of ccc_amd.h. */
+  /** \brief The C-ABI handle (<= 16 ridges per step, <= max_phases phases), for the flat-array batch entry points of
+      ccc_amd.h.  planOnce() itself takes any contact list up to 32 ridges per step and any number of phases: what the
+      fast kernel is not built for goes to a second, wide handle created on first need (ddp_shim::Handles). */
   ccc_ddp_t * handle() const
   {
-    return handle_.get();
+    return handles_.fast.get();
   }
 
 public:
@@ -162,7 +162,7 @@ public:
   std::array<double, 2> force_scale_limits_ = {0.0, 1e6};
 
 protected:
-  std::shared_ptr<ccc_ddp_t> handle_;
+  ddp_shim::Handles handles_;
   int horizon_steps_ = 0;
   int max_phases_ = 4;
 };

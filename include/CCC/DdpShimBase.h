@@ -6,6 +6,7 @@
  */
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <functional>
@@ -68,30 +69,29 @@ public:
   std::vector<TraceData> trace_data_list_;
 };
 
-/** Flattened problem of ONE instance (the n = 1 case of the C-ABI arrays). */
+/** Flattened problem of ONE instance (the n = 1 case of the C-ABI arrays).  Contact phases are collected without a
+    limit; pack() lays them out for the handle that can take them. */
 struct Flat
 {
-  int N = 0, P = 0;
+  int N = 0, P = 0, M = 0; // P, M: layout of the packed arrays (set by pack())
   std::vector<int32_t> phase_dim, step_phase;
   std::vector<double> phase_vertex, phase_ridge, ref_pos, ref_ori, inertia;
   std::vector<int> dims; // input dimension per step
 
-  void init(int n_steps, int n_phases)
+  void init(int n_steps)
   {
     N = n_steps;
-    P = n_phases;
-    phase_dim.assign(static_cast<size_t>(P), 0);
     step_phase.assign(static_cast<size_t>(N), 0);
-    phase_vertex.assign(static_cast<size_t>(P) * CCC_DDP_MAX_RIDGES * 3, 0.0);
-    phase_ridge.assign(static_cast<size_t>(P) * CCC_DDP_MAX_RIDGES * 3, 0.0);
     ref_pos.assign(static_cast<size_t>(N + 1) * 3, 0.0);
     ref_ori.assign(static_cast<size_t>(N + 1) * 3, 0.0);
     inertia.assign(9, 0.0);
     dims.assign(static_cast<size_t>(N), 0);
-    n_used_ = 0;
+    phases_V_.clear();
+    phases_R_.clear();
+    max_dim_ = 0;
   }
 
-  /** Register the contact list of step i (find or append its contact phase). */
+  /** Register the contact list of step i (find or append its contact phase); src/DdpCentroidal.cpp:49-60 order. */
   void setStepContacts(int i, const std::vector<std::shared_ptr<Contact>> & contact_list)
   {
     std::vector<double> V, R;
@@ -104,36 +104,50 @@ struct Flat
             R.push_back(ridge[a]);
           }
     const int m = static_cast<int>(V.size() / 3);
-    if(m > CCC_DDP_MAX_RIDGES)
-      throw std::runtime_error("[DDP shim] more than " + std::to_string(CCC_DDP_MAX_RIDGES) + " ridges in a contact list");
-    for(int k = 0; k < n_used_; k++)
-    {
-      if(phase_dim[static_cast<size_t>(k)] != m) continue;
-      bool same = true;
-      for(int e = 0; e < m * 3 && same; e++)
-        same = phase_vertex[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] == V[static_cast<size_t>(e)]
-               && phase_ridge[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] == R[static_cast<size_t>(e)];
-      if(same)
+    if(m > CCC_DDP_MAX_RIDGES_WIDE)
+      throw std::runtime_error("[DDP shim] " + std::to_string(m) + " ridges in a contact list, the kernels are built for "
+                               + std::to_string(CCC_DDP_MAX_RIDGES_WIDE) + " (two 4-vertex surface contacts)");
+    dims[static_cast<size_t>(i)] = m;
+    max_dim_ = std::max(max_dim_, m);
+    for(size_t k = 0; k < phases_V_.size(); k++)
+      if(phases_V_[k] == V && phases_R_[k] == R)
       {
-        step_phase[static_cast<size_t>(i)] = k;
-        dims[static_cast<size_t>(i)] = m;
+        step_phase[static_cast<size_t>(i)] = static_cast<int32_t>(k);
         return;
       }
-    }
-    if(n_used_ >= P) throw std::runtime_error("[DDP shim] more than max_phases distinct contact lists in the horizon");
-    const int k = n_used_++;
-    phase_dim[static_cast<size_t>(k)] = m;
-    for(int e = 0; e < m * 3; e++)
+    phases_V_.push_back(V);
+    phases_R_.push_back(R);
+    step_phase[static_cast<size_t>(i)] = static_cast<int32_t>(phases_V_.size() - 1);
+  }
+
+  int numPhases() const
+  {
+    return static_cast<int>(phases_V_.size());
+  }
+  int maxDim() const
+  {
+    return max_dim_;
+  }
+
+  /** Lay the phase tables out as [P][M][3] (the C-ABI layout of a handle with max_phases = P, max_ridges = M). */
+  void pack(int n_phases, int ridge_stride)
+  {
+    P = n_phases;
+    M = ridge_stride;
+    phase_dim.assign(static_cast<size_t>(P), 0);
+    phase_vertex.assign(static_cast<size_t>(P) * M * 3, 0.0);
+    phase_ridge.assign(static_cast<size_t>(P) * M * 3, 0.0);
+    for(size_t k = 0; k < phases_V_.size(); k++)
     {
-      phase_vertex[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] = V[static_cast<size_t>(e)];
-      phase_ridge[static_cast<size_t>(k) * CCC_DDP_MAX_RIDGES * 3 + e] = R[static_cast<size_t>(e)];
+      phase_dim[k] = static_cast<int32_t>(phases_V_[k].size() / 3);
+      std::copy(phases_V_[k].begin(), phases_V_[k].end(), phase_vertex.begin() + static_cast<long>(k) * M * 3);
+      std::copy(phases_R_[k].begin(), phases_R_[k].end(), phase_ridge.begin() + static_cast<long>(k) * M * 3);
     }
-    step_phase[static_cast<size_t>(i)] = k;
-    dims[static_cast<size_t>(i)] = m;
   }
 
 private:
-  int n_used_ = 0;
+  std::vector<std::vector<double>> phases_V_, phases_R_;
+  int max_dim_ = 0;
 };
 
 inline void check(int rc, const char * who)
@@ -141,11 +155,51 @@ inline void check(int rc, const char * who)
   if(rc != CCC_OK) throw std::runtime_error(std::string("[") + who + "] " + ccc_last_error_string());
 }
 
+/** The library handles behind one shim object: the FAST one (<= 16 ridges per step, <= max_phases contact phases; made
+    by the constructor) and, created on first need, the WIDE one (32 ridges, one phase per horizon step if need be) --
+    the reference takes any contact_list (src/DdpCentroidal.cpp:49-60), so must planOnce(). */
+struct Handles
+{
+  ccc_ddp_params_t params{};
+  int device = 0;
+  std::shared_ptr<ccc_ddp_t> fast, wide;
+
+  void create(const ccc_ddp_params_t & p, int dev, const char * who)
+  {
+    params = p;
+    device = dev;
+    ccc_ddp_t * h = nullptr;
+    check(ccc_ddp_create(&params, device, &h), who);
+    fast.reset(h, ccc_ddp_destroy);
+  }
+
+  /** Pack f for the handle that takes it and return that handle. */
+  ccc_ddp_t * select(Flat & f, const char * who)
+  {
+    if(f.maxDim() <= CCC_DDP_MAX_RIDGES && f.numPhases() <= params.max_phases)
+    {
+      f.pack(params.max_phases, CCC_DDP_MAX_RIDGES);
+      return fast.get();
+    }
+    if(!wide)
+    {
+      ccc_ddp_params_t p = params;
+      p.max_phases = params.horizon_steps;
+      p.max_ridges = CCC_DDP_MAX_RIDGES_WIDE;
+      ccc_ddp_t * h = nullptr;
+      check(ccc_ddp_create(&p, device, &h), who);
+      wide.reset(h, ccc_ddp_destroy);
+    }
+    f.pack(params.horizon_steps, CCC_DDP_MAX_RIDGES_WIDE);
+    return wide.get();
+  }
+};
+
 /** Run one instance through ccc_ddp_plan_batch and fill the solver stand-in; returns u_list[0]. */
 inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool srb, const std::vector<double> & x0,
                          const std::vector<VectorXd> & u_init_list, const char * who)
 {
-  const int N = f.N, M = CCC_DDP_MAX_RIDGES, S = static_cast<int>(x0.size());
+  const int N = f.N, M = f.M, S = static_cast<int>(x0.size());
   std::vector<double> u_init, u(static_cast<size_t>(N) * M, 0.0), x(static_cast<size_t>(N + 1) * S, 0.0);
   if(!u_init_list.empty())
   {

@@ -121,9 +121,7 @@ public:
     p.force_scale_limits[0] = force_scale_limits_[0];
     p.force_scale_limits[1] = force_scale_limits_[1];
     p.max_phases = max_phases;
-    ccc_ddp_t * h = nullptr;
-    ddp_shim::check(ccc_ddp_create(&p, device, &h), "DdpSingleRigidBody");
-    handle_.reset(h, ccc_ddp_destroy);
+    handles_.create(p, device, "DdpSingleRigidBody");
     ddp_solver_->config().horizon_steps = horizon_steps; // src/DdpCentroidal.cpp:198
     ddp_solver_->config().max_iter = 500;
   }
@@ -138,7 +136,7 @@ public:
     ddp_problem_->motion_param_func_ = motion_param_func;
     ddp_problem_->ref_data_func_ = ref_data_func;
     ddp_shim::Flat f;
-    f.init(horizon_steps_, max_phases_);
+    f.init(horizon_steps_);
     for(int i = 0; i <= horizon_steps_; i++)
     {
       const double t = current_time + i * ddp_problem_->dt();
@@ -157,13 +155,14 @@ public:
             for(int c = 0; c < 3; c++) f.inertia[static_cast<size_t>(r * 3 + c)] = mp.inertia_mat(r, c);
       }
     }
-    return ddp_shim::solveOne(handle_.get(), *ddp_solver_, f, true, initial_param.toState(), initial_param.u_list,
+    return ddp_shim::solveOne(handles_.select(f, "DdpSingleRigidBody"), *ddp_solver_, f, true, initial_param.toState(), initial_param.u_list,
                               "DdpSingleRigidBody");
   }
 
+  /** \brief The C-ABI handle of the fast kernel (see DdpCentroidal::handle()). */
   ccc_ddp_t * handle() const
   {
-    return handle_.get();
+    return handles_.fast.get();
   }
 
 public:
@@ -172,7 +171,7 @@ public:
   std::array<double, 2> force_scale_limits_ = {0.0, 1e6};
 
 protected:
-  std::shared_ptr<ccc_ddp_t> handle_;
+  ddp_shim::Handles handles_;
   int horizon_steps_ = 0;
   int max_phases_ = 4;
 };

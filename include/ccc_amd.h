@@ -136,7 +136,8 @@ typedef struct ccc_ddp ccc_ddp_t;
 
 #define CCC_DDP_CENTROIDAL 0        /* 9 states  [c, P, L]         src/DdpCentroidal.cpp:32-64 */
 #define CCC_DDP_SINGLE_RIGID_BODY 1 /* 12 states [c, alpha, v, w]  src/DdpSingleRigidBody.cpp:52-91 */
-#define CCC_DDP_MAX_RIDGES 16       /* ridges per contact phase the kernels are built for (one 4-vertex surface) */
+#define CCC_DDP_MAX_RIDGES 16       /* default ridge stride: one 4-vertex surface contact per step (the fast kernel) */
+#define CCC_DDP_MAX_RIDGES_WIDE 32  /* params.max_ridges = 32: two surface contacts per step (double support) */
 
 /* Constructor arguments of DdpCentroidal(mass, horizon_dt, horizon_steps, weight_param)
  * (include/CCC/DdpCentroidal.h:342) / DdpSingleRigidBody (include/CCC/DdpSingleRigidBody.h:379-394), with the
@@ -152,7 +153,12 @@ typedef struct
   int horizon_steps;
   double w_run[12], w_term[12], w_force;
   double force_scale_limits[2];
-  int max_phases; /* P: contact phases per instance (distinct contact lists inside one horizon) */
+  int max_phases; /* P: contact phases per instance (distinct contact lists inside one horizon); any value >= 1, up to
+                   * one phase per horizon step.  P <= 4 with max_ridges 16 and horizon_steps <= 128 runs the fast kernel,
+                   * anything beyond the wide kernel (same results, several times slower per instance). */
+  int max_ridges; /* M: ridge stride of phase_vertex / phase_ridge / u_init / u_out: 0 or 16 = CCC_DDP_MAX_RIDGES, 32 =
+                   * CCC_DDP_MAX_RIDGES_WIDE (a step with two 4-vertex surface contacts, src/DdpCentroidal.cpp:49-60
+                   * over a two-element contact_list).  Other values: CCC_ERR_UNSUPPORTED. */
 } ccc_ddp_params_t;
 
 /* ddp_solver_->config() (nmpc_ddp::DDPSolver::Configuration, external).  ccc_ddp_default_config
@@ -188,16 +194,16 @@ int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
  * contact lists flattened in contact -> vertex -> ridge order (src/DdpCentroidal.cpp:49-60):
  *
  *   phase_dim    [n][P]            i32  ridges of contact phase p (0 = no contact)        inputDim(t)
- *   phase_vertex [n][P][16][3]     f64  vertex of ridge r         (Contact::vertexWithRidgeList_[..].vertex)
- *   phase_ridge  [n][P][16][3]     f64  ridge direction r         (..ridgeList[..])
+ *   phase_vertex [n][P][M][3]      f64  vertex of ridge r         (Contact::vertexWithRidgeList_[..].vertex); M = max_ridges
+ *   phase_ridge  [n][P][M][3]      f64  ridge direction r         (..ridgeList[..])
  *   step_phase   [n][N]            i32  contact phase of horizon step i
  *   ref_pos      [n][N+1][3]       f64  RefData::pos at step i (i = N: terminal cost)
  *   ref_ori      [n][N+1][3]       f64  RefData::ori            (SRB only, else NULL)
  *   inertia      [n][3][3]         f64  MotionParam::inertia_mat (SRB only, else NULL; constant over the horizon)
  *   x0           [n][S]            f64  InitialParam::toState()  (S = 9: [pos, mass*vel, angular_momentum];
  *                                       S = 12: [pos, ori, linear_vel, angular_vel])
- *   u_init       [n][N][16]        f64  InitialParam::u_list (warm start) or NULL (zeros, src/DdpCentroidal.cpp:221-229)
- *   u_out        [n][N][16]        f64  controlData().u_list; planOnce returns u_out[k][0][0 : phase_dim of step 0]
+ *   u_init       [n][N][M]         f64  InitialParam::u_list (warm start) or NULL (zeros, src/DdpCentroidal.cpp:221-229)
+ *   u_out        [n][N][M]         f64  controlData().u_list; planOnce returns u_out[k][0][0 : phase_dim of step 0]
  *   x_out        [n][N+1][S]       f64  optional: controlData().x_list
  *   iters        [n]               i32  optional: traceDataList().back().iter
  *   status       [n]               i32  optional: 0 max_iter reached, 1 gradient small, 2 cost change small,

@@ -23,38 +23,49 @@ class Params(ctypes.Structure):
                 ("max_iter", ctypes.c_int), ("lambda0", ctypes.c_double), ("dlambda0", ctypes.c_double),
                 ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
                 ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double), ("ratio_thre", ctypes.c_double),
-                ("cost_thre", ctypes.c_double), ("alpha", ctypes.c_double * 11)]
+                ("cost_thre", ctypes.c_double), ("alpha", ctypes.c_double * 11), ("reg_type", ctypes.c_int)]
 
 
-@pytest.fixture(scope="module")
-def emu():
-    so = os.path.join(ROOT, "tests", "emu", "libddp_emu.so")
+def _build(wide):
+    so = os.path.join(ROOT, "tests", "emu", "libddp_emu_wide.so" if wide else "libddp_emu.so")
     src = os.path.join(ROOT, "tests", "emu", "ddp_emu.cpp")
     hdr = os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", "ddp_core.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
-    L = ctypes.CDLL(so)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off"]
+                              + (["-DCCC_DDP_WIDE"] if wide else []) + ["-o", so, src])
+    return ctypes.CDLL(so)
+
+
+@pytest.fixture(scope="module", params=["fast-tables", "wide"])
+def emu(request):
+    """The phase versions of csrc/ddp_core.h compiled for the host, in both table layouts: "fast-tables" = the LDS
+    tables of the fast build (<= 16 ridges, <= 4 phases), "wide" = the build csrc/ddp_wide.hip runs on the GPU."""
+    wide = request.param == "wide"
+    L = _build(wide)
 
     def run(model, N, dt, w, prob, x0, max_iter, u_init=None):
+        M = prob["phase_vertex"].shape[2]
+        if not wide and (M != 16 or prob["phase_dim"].shape[1] > 4):
+            pytest.skip("beyond the fast build's tables")
         P = Params()
         P.model, P.N, P.P, P.mass, P.dt = model, N, prob["phase_dim"].shape[1], 100.0, dt
         S = 9 if model == 0 else 12
         for a in range(S):
             P.w_run[a], P.w_term[a] = w["run"][a], w["term"][a]
-        P.w_force, P.flo, P.fhi, P.max_iter = w["force"], 0.0, 1e6, max_iter
+        P.w_force, P.flo, P.fhi, P.max_iter, P.reg_type = w["force"], 0.0, 1e6, max_iter, 1
         P.lambda0, P.dlambda0, P.lambda_factor, P.lambda_min, P.lambda_max = 1e-6, 1.0, 1.6, 1e-8, 1e10
         P.k_rel_norm_thre, P.lambda_thre, P.ratio_thre, P.cost_thre = 1e-4, 1e-7, 0.0, 1e-7
         for i in range(11):
             P.alpha[i] = 10 ** (-3.0 * i / 10)
         n = x0.shape[0]
-        u, x = np.zeros((n, N, 16)), np.zeros((n, N + 1, S))
+        u, x = np.zeros((n, N, M)), np.zeros((n, N + 1, S))
         it, st, c = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n)
         arr = {k: np.ascontiguousarray(v) for k, v in prob.items()}
 
         def p(a):
             return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
-        rc = L.ccc_ddp_emu_plan_batch(ctypes.byref(P), ctypes.c_long(n), 16, p(arr["phase_dim"]),
+        rc = L.ccc_ddp_emu_plan_batch(ctypes.byref(P), ctypes.c_long(n), M, p(arr["phase_dim"]),
                                       p(arr["phase_vertex"]), p(arr["phase_ridge"]), p(arr["step_phase"]),
                                       p(arr["ref_pos"]), p(arr.get("ref_ori")), p(arr.get("inertia")),
                                       p(np.ascontiguousarray(x0)), p(u_init), p(u), p(x), p(it), p(st), p(c))
@@ -92,3 +103,19 @@ def test_warm_start_path_matches_oracle(emu):
     e = emu(0, N, dt, fd.centroidal_weights(), prob, x1, 1, u_init=np.ascontiguousarray(cold["u"]))
     o = oracle.Ddp(0, 100.0, dt, N, fd.centroidal_weights(), max_iter=1).plan_batch(prob, x1, u_init=cold["u"])
     assert np.array_equal(e["u"], o["u"])
+
+
+@pytest.mark.parametrize("model,max_iter", [(0, 1), (0, 30), (1, 1), (1, 15)])
+def test_double_support_and_many_phases_match_oracle_exactly(emu, model, max_iter):
+    """Walking sequences with 32-ridge double-support steps, 16-ridge single support, flight, and 8-10 contact phases
+    per horizon (src/DdpCentroidal.cpp:49-60: arbitrary contact lists): the wide build's logic against the oracle."""
+    N, dt = 40, 0.05
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_walking_batch(5, N, dt, seed=21, srb=bool(model))
+    assert prob["phase_dim"].max() == 32 and prob["phase_dim"].shape[1] > 4
+    e = emu(model, N, dt, w, prob, x0, max_iter)
+    P, M = prob["phase_dim"].shape[1], 32
+    o = oracle.Ddp(model, 100.0, dt, N, w, max_iter=max_iter, P=P, M=M).plan_batch(prob, x0)
+    assert np.array_equal(e["iters"], o["iters"]) and np.array_equal(e["status"], o["status"])
+    assert np.array_equal(e["u"], o["u"]) and np.array_equal(e["x"], o["x"]) and np.array_equal(e["cost"], o["cost"])
+    assert np.all(o["status"] >= 0)

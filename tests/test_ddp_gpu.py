@@ -166,7 +166,7 @@ def test_srb_reference_closed_loop_through_planonce():
         max_iter = d.ddp_solver_.config().max_iter
         scales = d.planOnce(motion, ref, ip, t)
         if cycle % 25 == 0:  # the oracle on the same inputs
-            prob = d._sample(motion, ref, t)
+            _, prob = d._sample(motion, ref, t)
             u_init = None
             if ip.u_list:
                 u_init = np.zeros((1, N, 16))
@@ -307,3 +307,91 @@ def test_cpp_header_shims_match_python_mirror():
                     lambda t: DdpSingleRigidBody.RefData(fd.reference_schedule(t)[1]), ips, 0.0)
     cpps = np.array([float(v) for v in lines["srb"].split("u0=")[1].split()])
     assert np.array_equal(cpps, us)
+    # walking with double support: 32-ridge contact lists and 7 phases, routed to the wide kernel by both front ends
+    def foot(x, y):
+        return fd.contact_from_rect((x - 0.1, y - 0.05), (x + 0.1, y + 0.05))
+
+    Lf, Rf = [foot(0.0, 0.1), foot(0.3, 0.1), foot(0.6, 0.1)], [foot(0.0, -0.1), foot(0.15, -0.1), foot(0.45, -0.1)]
+    table = [[Lf[0], Rf[0]], [Lf[0]], [Lf[0], Rf[1]], [Rf[1]], [Lf[1], Rf[1]], [Lf[1]], [Lf[1], Rf[2]]]
+    wd = _cen(40, 0.05, 30)
+    uw = wd.planOnce(lambda t: DdpCentroidal.MotionParam(table[min(int((t + 1e-6) / 0.3), 6)]),
+                     lambda t: DdpCentroidal.RefData((0.15 * t, 0.0, 1.0)),
+                     DdpCentroidal.InitialParam((0.0, 0.01, 1.0), (0, 0, 0), (0, 0, 0)), 0.0)
+    cppw = np.array([float(v) for v in lines["walking"].split("u0=")[1].split()])
+    assert "dim=32" in lines["walking"] and len(uw) == 32
+    assert np.array_equal(cppw, uw)
+    assert "iter=%d" % wd.ddp_solver_.last_iter in lines["walking"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Contact lists beyond one surface contact / four phases: the wide kernel (csrc/ddp_wide.hip)
+@pytest.mark.parametrize("srb,max_iter", [(False, 1), (False, 30), (True, 1), (True, 15)])
+def test_double_support_walking_sequences_match_the_oracle_bit_for_bit(srb, max_iter):
+    """src/DdpCentroidal.cpp:49-60 / src/DdpSingleRigidBody.cpp:74-85 iterate arbitrary contact lists: walking
+    sequences with 32-ridge double-support steps (two surface contacts), 16-ridge single support, flight, and 8-10
+    distinct contact phases inside one horizon.  max_ridges = 32 selects the wide kernel; same bar as the fast one."""
+    N, dt, n = 40, 0.05, 96
+    prob, x0 = fd.make_walking_batch(n, N, dt, seed=33, srb=srb)
+    P = prob["phase_dim"].shape[1]
+    assert prob["phase_dim"].max() == 32 and P > 4
+    if srb:
+        w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3,
+                                           terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3)
+        d = DdpSingleRigidBody(100.0, dt, N, w, max_phases=P, max_ridges=32)
+        wo = fd.srb_weights()
+    else:
+        w = DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0))
+        d = DdpCentroidal(100.0, dt, N, w, max_phases=P, max_ridges=32)
+        wo = fd.centroidal_weights()
+    d.ddp_solver_.config().max_iter = max_iter
+    r = d.planOnceBatch(prob, x0, want_x=True)
+    o = _oracle().Ddp(int(srb), 100.0, dt, N, wo, max_iter=max_iter, P=P, M=32).plan_batch(prob, x0, nthreads=16)
+    assert np.all(o["status"] >= 0)
+    assert np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["status"], o["status"])
+    assert np.array_equal(r["u"], o["u"]) and np.array_equal(r["x"], o["x"]) and np.array_equal(r["cost"], o["cost"])
+    # the double-support steps really carry force on both feet
+    dims = np.take_along_axis(prob["phase_dim"], prob["step_phase"], axis=1)
+    ds = dims == 32
+    assert ds.any() and (r["u"][ds][:, :16].sum(axis=1) > 1.0).mean() > 0.5 and (r["u"][ds][:, 16:].sum(axis=1) > 1.0).mean() > 0.5
+
+
+def test_many_phases_of_single_contacts_route_to_the_wide_kernel_and_agree_with_the_fast_one():
+    """More than four contact phases with 16-ridge contacts (max_ridges stays 16): the wide kernel's <9|12, 16>
+    instantiation.  The same problems with the phase table compacted to the four phases the fast kernel holds give
+    the identical plan -- the two kernels are interchangeable where both apply."""
+    N, dt, n = 100, 0.03, 64
+    prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=8)
+    fast = _cen(N, dt, 12).planOnceBatch(prob, x0, want_x=True)
+    # spread the three used phases over a 7-entry table (unused entries in between)
+    P2 = 7
+    wide_prob = fd.empty_problem(n, N, P2, 16)
+    remap = np.array([5, 2, 6, 0])
+    for p in range(4):
+        wide_prob["phase_dim"][:, remap[p]] = prob["phase_dim"][:, p]
+        wide_prob["phase_vertex"][:, remap[p]] = prob["phase_vertex"][:, p]
+        wide_prob["phase_ridge"][:, remap[p]] = prob["phase_ridge"][:, p]
+    wide_prob["step_phase"][:] = remap[prob["step_phase"]]
+    wide_prob["ref_pos"][:] = prob["ref_pos"]
+    w = DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0))
+    d = DdpCentroidal(100.0, dt, N, w, max_phases=P2)
+    d.ddp_solver_.config().max_iter = 12
+    wide = d.planOnceBatch(wide_prob, x0, want_x=True)
+    for k in ("u", "x", "cost", "iters", "status"):
+        assert np.array_equal(fast[k], wide[k]), k
+
+
+def test_wide_limits_are_reported():
+    """max_ridges other than 16 / 32 and precision 32 on a wide handle: CCC_ERR_UNSUPPORTED, as documented."""
+    from centroidalcontrolcollection_amd import _lib
+
+    w = DdpCentroidal.WeightParam()
+    with pytest.raises(_lib.CccError) as e:
+        DdpCentroidal(100.0, 0.05, 20, w, max_ridges=48)
+    assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
+    prob, x0 = fd.make_walking_batch(2, 20, 0.05, seed=1)
+    P = prob["phase_dim"].shape[1]
+    d2 = DdpCentroidal(100.0, 0.05, 20, w, max_phases=P, max_ridges=32)
+    d2.ddp_solver_.config().precision = 32
+    with pytest.raises(_lib.CccError) as e:
+        d2.planOnceBatch(prob, x0)
+    assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
