@@ -33,15 +33,21 @@ def _xy_algo(status):
     return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (43 + 69 + 80 + 16 * 7 + 36) * 8
 
 
-def _xy(n, dev, rank):
+def _xy(n, dev, rank, walking=False):
     from centroidalcontrolcollection_amd import LinearMpcXY, fixtures_ddp as fd
-    N, dt, base = 20, 0.1, min(n, 2048)
-    prob, x0 = fd.make_xy_batch(base, N, dt, seed=20250928 + rank)
+    N, dt, base, M = 20, 0.1, min(n, 2048), 16
+    if walking:
+        # two separate foot contacts in double support (32 ridges per step), 30 steps: beyond the dual kernel, the
+        # stage-recursion kernel with its single-change safeguard rounds
+        N, M, base = 30, 32, min(n, 512)
+        prob, x0 = fd.make_xy_walking_batch(base, N, dt, M=32, seed=20250928 + rank)
+    else:
+        prob, x0 = fd.make_xy_batch(base, N, dt, seed=20250928 + rank)
     prob = _tile(prob, n, base)
     x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
-    mpc = LinearMpcXY(100.0, dt, N, device=dev.index)
+    mpc = LinearMpcXY(100.0, dt, N, device=dev.index, max_ridges=M)
     tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
-    out = torch.zeros((n, 16), dtype=torch.float64, device=dev)
+    out = torch.zeros((n, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
 
     def step(stream):
@@ -49,19 +55,26 @@ def _xy(n, dev, rank):
 
     def cpu(cores):
         from oracle import oracle
-        ns = min(n, 2048)
+        ns = min(n, 512 if walking else 2048)
         sub = {a: v[:ns] for a, v in prob.items()}
-        o = oracle.LinearMpcXY(100.0, dt, N)
+        o = oracle.LinearMpcXY(100.0, dt, N, M=M)
         t0 = time.perf_counter()
         r = o.plan_batch(sub, x0[:ns], nthreads=cores)
         t = time.perf_counter() - t0
         err = np.abs(out.cpu().numpy()[:ns] - r["u0"]).max() / (np.abs(r["u0"]).max() + 1.0)
         return ns / t, ns, float(err), "max |d force scale| / (1 + max force scale)"
 
+    if walking:
+        return dict(name="LinearMpcXY planOnce() solves/sec (N=30, 32 ridge slots, fp64, inputs resident in HBM)", step=step,
+                    out=out, status=st,
+                    workload="LinearMpcXY N=30 (3 s horizon @ 100 ms), walking with two foot contacts in double support (32 "
+                             "ridges), batch=%d per GPU (beyond BASELINE's configs: src/LinearMpcXY.cpp:69-82)" % n,
+                    algo_bytes=N * (4 + M * 3 * 8 * 2 + 16 + 48) + 48 + M * 8, kernel="xy_plan_stream_kernel<32,false>", cpu=cpu,
+                    keep=(mpc, tp, tx0))
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
                 algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, stream_bytes=_xy_algo,
-                kernel="xy_plan_stream_kernel", cpu=cpu, keep=(mpc, tp, tx0))
+                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0))
 
 
 def _ddp(n, dev, rank, srb, precision=64, walking=False):
@@ -229,16 +242,16 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096)
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, xywalk=32768)
 DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
-                     walk=(3, 1))
+                     walk=(3, 1), xywalk=(3, 1))
 
 
 def run(args, rank, world, local_rank, dist):
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
-    make = dict(xy=_xy, ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
+    make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
                 srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)

@@ -425,6 +425,9 @@ extern "C" int ccc_xy_closed_loop_device(ccc_xy_t * h, int64_t n, const ccc_cont
   ccc_xy_params_t prm;
   int device = 0;
   if(int rc = ccc_xy_get_params(h, &prm, &device)) return rc;
+  if(prm.max_ridges != kLoopM)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_closed_loop_device: the contact timeline carries %d ridges per entry, the handle %d",
+                kLoopM, prm.max_ridges);
   const int N = prm.horizon_steps;
   CCC_DEVICE_GUARD(device);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -63,7 +63,7 @@ extern "C" const char * ccc_last_error_string(void)
 
 extern "C" int ccc_abi_version(void)
 {
-  return 2; // 2: ccc_ddp_config_t::reg_type, sharded entry points, ccc_device_count
+  return 3; // 2: ccc_ddp_config_t::reg_type, sharded entry points, ccc_device_count; 3: max_ridges in ccc_ddp_params_t / ccc_xy_params_t
 }
 
 extern "C" int ccc_device_count(void)

@@ -31,6 +31,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 // profiling switches (scripts/xy_variants.sh): number of active-set/refinement rounds, skip the set-up updates
@@ -657,20 +658,27 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 //     active set above needs 340 set-up updates + ~94 pivots of a 140 x 140 operator.
 // E, f, Pt, pt, t, alpha, d' and the clamped set live in an HBM workspace laid out [stage][field][instance] (coalesced).
 // Instances that do not settle within kXsMaxIt iterations (the iteration can cycle; none of the reference scenarios
-// does) go onto a work list for the dual active-set kernel above.
+// does) go onto a work list: for the dual active-set kernel above when the problem fits it (<= 20 steps of <= 16
+// ridges), else for this kernel again in SINGLE-CHANGE mode -- per iteration only the most violated condition (bound
+// violation of a free variable, or wrong-sign multiplier of a clamped one, on a common force scale) changes sides.  That
+// is a principal pivoting method with the largest-violation rule on the strictly convex QP; it took 150-210 sweeps on
+// the instances that cycle (prototype on the bench data: all converged, same answers) where the block update needs ~7.
+// The kernel is a template on the ridge slots per step: 16 (one surface contact) or 32 (two: double support,
+// src/LinearMpcXY.cpp:69-82 iterates the whole contact_list); the horizon length is a run-time value.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kXsMaxIt = 16;
 // fields of a stage in the workspace: feedback E (36), f (6), P~ (upper triangle, 21), p~ (6); the clamped set's sums
 // t (6), alpha, d', S (upper triangle, 21), c (6); the step's ridge count, f_z and reference (6); the clamped set
 // (2 bits per ridge: 0 free, 1 at the lower bound, 2 at the upper bound)
 constexpr int kXsE = 0, kXsF = 36, kXsPt = 42, kXsPv = 63, kXsT = 69, kXsAl = 75, kXsDp = 76, kXsDim = 77, kXsFz = 78,
-              kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsFields = 120; // (120 + 16 x 7 fields x 512 B: stages start on 4 KB boundaries)
+              kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsSt2 = 113, // (ridges 0-15 / 16-31: each exact in a double)
+              kXsFields = 120; // (120 + 16 x 8 fields x 512 B: stages start on 4 KB boundaries)
 
 struct XyWork
 {
   double * ws;         // [N][kXsFields][n]
   double * rb;         // [N][16][7][n]: impulse vector (6) and rho_z of every ridge
-  unsigned * st;       // [N][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
+  unsigned long long * st; // [N][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
   int * redo_list;     // [n]
   int * redo_count;    // [1]
   size_t ws_stride, rb_stride; // doubles from one wavefront's region to the next
@@ -681,6 +689,7 @@ struct XyWork
   const int * in_count;
   int * out_list;
   int * out_count;
+  int single; // 1: single-change mode from the saved sets (the safeguard round)
 };
 
 // index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
@@ -746,13 +755,17 @@ __device__ __forceinline__ void xs_accumulate(unsigned state, double val, const 
   }
 }
 
-constexpr int kXsStage = kXsFields + kXyM * 8; // fields of a stage + 16 ridges x (7 + 1 pad)
 constexpr int kXsRounds = 4;
 constexpr const char * kXsRoundsDefault = "6,10";
 constexpr int kXsLanes = 64; // instances per wavefront
+// M: ridge slots per step; SINGLE: the single-change rounds (a separate instantiation: the block iteration, which nearly
+// every instance finishes in, does not carry their registers)
+template<int M, bool SINGLE>
 __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int it_begin, int max_it)
 {
-  constexpr int M = kXyM;
+  static_assert(M == 16 || M == 32, "ridge slots per step");
+  constexpr int kXsStage = kXsFields + M * 8; // fields of a stage + M ridges x (7 + 1 pad)
+  using Bits = typename std::conditional<M == 16, unsigned, unsigned long long>::type; // 2 bits per ridge
   const long slot = (long)blockIdx.x * kXsLanes + threadIdx.x;
   if(slot >= (W.in_list ? (long)*W.in_count : n)) return;
   const long b = W.in_list ? (long)W.in_list[slot] : slot;
@@ -772,9 +785,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    const unsigned bits0 = W.in_list ? W.st[(size_t)s * W.st_stride + b] : 0u; // (a resumed instance: the set it had)
-    WS(s, kXsSt) = (double)bits0;
-    const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..16: the slots there are)
+    const Bits bits0 = W.in_list ? (Bits)W.st[(size_t)s * W.st_stride + b] : Bits(0); // (a resumed instance: the set it had)
+    WS(s, kXsSt) = (double)(unsigned)bits0;
+    if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits0 >> 32);
+    const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..M: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
     const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
     WS(s, kXsDim) = (double)m; // the step's scalars, so that the sweeps read nothing instance-major
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
       for(int a = 0; a < 6; a++) RB(s, r, a) = bb[a];
       RB(s, r, 6) = az;
-      const unsigned st0 = (bits0 >> (2 * r)) & 3u;
+      const unsigned st0 = (unsigned)(bits0 >> (2 * r)) & 3u;
       xs_accumulate(st0, st0 == 1u ? P.flo : P.fhi, bb, az, S, t, cc, alpha, dprime);
     }
 #pragma unroll
@@ -814,9 +828,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
   for(int a = 0; a < 6; a++) x0[a] = B.x0[b * 6 + a];
   int it = 0;
-  bool converged = false, cycling = false;
+  constexpr bool single = SINGLE;
+  bool converged = false, cycling = false, gaveup = false;
   unsigned long long h1 = 0, h2 = 0; // hashes of the clamped sets of the last two iterations
-  for(it = it_begin; it < max_it && !converged && !cycling; it++)
+  for(it = it_begin; it < max_it && !converged && !cycling && !gaveup; it++)
   {
     // ---- backward recursion on the current clamped set
     double Pm[6][6], pv[6];
@@ -995,10 +1010,16 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       xs_adT(dt, k2, k3, gv, pv);
     }
     // ---- forward pass: new clamped set (and, once it repeats, the outputs)
+    //      single-change mode: the set is left as it is, the most violated condition is looked for and applied after
+    //      the pass (cand_*), the sums of that one stage are rebuilt
+    double cand_v = 0.0;
+    int cand_s = -1, cand_r = 0, cand_forced = -1;
+    unsigned cand_ns = 0u;
+    const bool last_chance = single && it + 1 >= max_it; // out of budget: emit what there is, clipped, flagged
     for(int pass = 0; pass < 2; pass++)
     {
       const bool emit = pass == 1;
-      if(emit && !converged) break;
+      if(emit && !converged && !gaveup) break;
       bool changed = false;
       unsigned long long hh = 1469598103934665603ull;
       double x[6];
@@ -1029,8 +1050,9 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         }
         const double alpha = WS(s, kXsAl), dprime = WS(s, kXsDp);
         const double nu = alpha > 0.0 ? -(wf * dprime + tpi) / alpha : 0.0;
-        const unsigned bits = (unsigned)WS(s, kXsSt); // (2 bits per ridge, exact in a double)
-        unsigned nb = bits;
+        Bits bits = (Bits)(unsigned)WS(s, kXsSt); // (2 bits per ridge, 16 ridges exact in a double)
+        if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+        Bits nb = bits;
         bool anyfree = false;
         const double fz = WS(s, kXsFz);
         double nS[21], nt[6], nc[6], nal = 0.0, ndp = fz; // the sums over the set this pass chooses
@@ -1039,14 +1061,22 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
         for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
         double bestm = kXyInf;
-        int besti = 0;
+        int besti = 0, nfree = 0;
+        // (single-change mode) the clamped variables that most want to leave their bound: lowest multiplier at the lower
+        // bound, highest at the upper
+        double rel_lo_m = kXyInf, rel_hi_m = -kXyInf;
+        int rel_lo_i = -1, rel_hi_i = -1;
+        bool cand_here = false;
+        if(single) // (free variables of the stage: clamping the only one is a move only if another can be released)
+          for(int r = 0; r < m; r++) nfree += ((bits >> (2 * r)) & 3ull) == 0ull ? 1 : 0;
+        const bool may_clamp = nfree > 1 || m > nfree;
         for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
         {
           double rbv[8][7];
 #pragma unroll
           for(int u = 0; u < 8; u++)
 #pragma unroll
-            for(int a = 0; a < 7; a++) rbv[u][a] = RB(s, r0 + u, a); // (all 16 slots exist; those past m are not used)
+            for(int a = 0; a < 7; a++) rbv[u][a] = RB(s, r0 + u, a); // (all M slots exist; those past m are not used)
 #pragma unroll
           for(int u = 0; u < 8; u++)
           {
@@ -1059,36 +1089,60 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             double bpi = nu * az;
 #pragma unroll
             for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
-            const unsigned stt = (bits >> (2 * r)) & 3u;
-            double lam;
+            const unsigned stt = (unsigned)(bits >> (2 * r)) & 3u;
+            double lam, viol = 0.0;
             unsigned ns;
             if(stt == 0u)
             {
               lam = -bpi * iwf;
               ns = lam < P.flo ? 1u : (lam > P.fhi ? 2u : 0u);
-              nb = (nb & ~(3u << (2 * r))) | (ns << (2 * r));
-              anyfree = anyfree || ns == 0u;
+              viol = !may_clamp ? 0.0 : (ns == 1u ? P.flo - lam : (ns == 2u ? lam - P.fhi : 0.0));
+              if(!single)
+              {
+                nb = (nb & ~(Bits(3) << (2 * r))) | ((Bits)ns << (2 * r));
+                anyfree = anyfree || ns == 0u;
+              }
+              if(emit && gaveup) lam = fmin(fmax(lam, P.flo), P.fhi);
             }
             else
             {
               lam = stt == 1u ? P.flo : P.fhi;
               const double mult = wf * lam + bpi;
               const bool release = (stt == 1u && mult < 0.0) || (stt == 2u && mult > 0.0);
-              if(release) nb &= ~(3u << (2 * r));
+              if(release && !single) nb &= ~(Bits(3) << (2 * r));
               ns = release ? 0u : stt;
+              viol = release ? fabs(mult) * iwf : 0.0; // (a multiplier on the scale of a force: mult / w_f)
               anyfree = anyfree || release;
               if(fabs(mult) < bestm)
               {
                 bestm = fabs(mult);
                 besti = r;
               }
+              if(stt == 1u && mult < rel_lo_m)
+              {
+                rel_lo_m = mult;
+                rel_lo_i = r;
+              }
+              if(stt == 2u && mult > rel_hi_m)
+              {
+                rel_hi_m = mult;
+                rel_hi_i = r;
+              }
+            }
+            if(single && !emit && viol > cand_v)
+            {
+              cand_v = viol;
+              cand_s = s;
+              cand_r = r;
+              cand_ns = ns;
+              cand_here = true;
             }
             if(emit)
             {
               if(s == 0) B.u0[b * M + r] = lam;
               if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
             }
-            else
+            else if(!single)
               xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, az, nS, nt, nc, nal, ndp);
           }
         }
@@ -1098,9 +1152,21 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             if(s == 0) B.u0[b * M + r] = 0.0;
             if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = 0.0;
           }
-        const bool forced = m > 0 && !anyfree;
-        if(forced) nb &= ~(3u << (2 * besti)); // the stage equality needs a free variable
-        if(!emit)
+        if(single && !emit && cand_here)
+        {
+          // clamping the stage's only free variable: the stage equality needs one, so a clamped variable is released
+          // with it -- one that can move the right way: the free variable ran into its UPPER bound, the stage needs more
+          // force from a variable at its lower bound (the one whose multiplier asks for it most), and vice versa
+          cand_forced = -1;
+          if(cand_ns != 0u && nfree <= 1)
+          {
+            const int want = cand_ns == 2u ? rel_lo_i : rel_hi_i, other = cand_ns == 2u ? rel_hi_i : rel_lo_i;
+            cand_forced = want >= 0 ? want : other;
+          }
+        }
+        const bool forced = !single && m > 0 && !anyfree;
+        if(forced) nb &= ~(Bits(3) << (2 * besti)); // the stage equality needs a free variable
+        if(!emit && !single)
         {
           if(forced) // (rare) the sums again, in ridge order, for the set with the forced release
           {
@@ -1115,7 +1181,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
               double bb[6];
 #pragma unroll
               for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
-              const unsigned ns = (nb >> (2 * r)) & 3u;
+              const unsigned ns = (unsigned)(nb >> (2 * r)) & 3u;
               xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
             }
           }
@@ -1130,13 +1196,14 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
           WS(s, kXsAl) = nal;
           WS(s, kXsDp) = ndp;
           changed = changed || nb != bits;
-          WS(s, kXsSt) = (double)nb;
+          WS(s, kXsSt) = (double)(unsigned)nb;
+          if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(nb >> 32);
           hh = (hh ^ nb) * 1099511628211ull;
         }
 #pragma unroll
         for(int a = 0; a < 6; a++) x[a] = y[a];
       }
-      if(!emit)
+      if(!emit && !single)
       {
         converged = !changed;
         // back at the set of two iterations ago: a 2-cycle, hand the instance over (longer periods were looked for and
@@ -1145,20 +1212,71 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         h2 = h1;
         h1 = hh;
       }
+      if(!emit && single)
+      {
+        converged = cand_s < 0;
+        gaveup = !converged && last_chance;
+        if(!converged && !gaveup)
+        {
+          // apply the one change and rebuild the sums of its stage
+          const int s = cand_s, m = (int)WS(s, kXsDim);
+          Bits bits = (Bits)(unsigned)WS(s, kXsSt);
+          if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+          bits = (bits & ~(Bits(3) << (2 * cand_r))) | ((Bits)cand_ns << (2 * cand_r));
+          if(cand_forced >= 0) bits &= ~(Bits(3) << (2 * cand_forced));
+          double nS[21], nt[6], nc[6], nal = 0.0, ndp = WS(s, kXsFz);
+#pragma unroll
+          for(int a = 0; a < 21; a++) nS[a] = 0.0;
+#pragma unroll
+          for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
+          for(int r = 0; r < m; r++)
+          {
+            double bb[6];
+#pragma unroll
+            for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
+            const unsigned ns = (unsigned)(bits >> (2 * r)) & 3u;
+            xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
+          }
+#pragma unroll
+          for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
+#pragma unroll
+          for(int a = 0; a < 6; a++)
+          {
+            WS(s, kXsT + a) = nt[a];
+            WS(s, kXsC + a) = nc[a];
+          }
+          WS(s, kXsAl) = nal;
+          WS(s, kXsDp) = ndp;
+          WS(s, kXsSt) = (double)(unsigned)bits;
+          if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
+        }
+      }
     }
   }
-  if(!converged && !cycling && W.out_list)
+  if(single)
   {
-    for(int s = 0; s < N; s++) W.st[(size_t)s * W.st_stride + b] = (unsigned)WS(s, kXsSt);
-    const int q = atomicAdd(W.out_count, 1);
-    W.out_list[q] = (int)b;
-    return; // the next round goes on from this set
+    // (converged or out of budget: the outputs are written either way)
+    if(B.status) B.status[b] = ((it - 1) << 8) | (converged ? CCC_STATUS_SOLVED : CCC_STATUS_MAX_ITER);
+    return;
   }
   if(!converged)
   {
+    // the set goes with the instance: the next round, or the safeguard round, goes on from it (the dual kernel starts anew)
+    for(int s = 0; s < N; s++)
+    {
+      Bits bits = (Bits)(unsigned)WS(s, kXsSt);
+      if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+      W.st[(size_t)s * W.st_stride + b] = bits;
+    }
+    if(!cycling && W.out_list)
+    {
+      const int q = atomicAdd(W.out_count, 1);
+      W.out_list[q] = (int)b;
+      return;
+    }
     const int q = atomicAdd(W.redo_count, 1);
     W.redo_list[q] = (int)b;
-    return; // the dual active-set kernel writes this instance's outputs
+    return;
   }
   if(B.status) B.status[b] = ((it - 1) << 8) | CCC_STATUS_SOLVED; // changes of the clamped set before it repeated
 }
@@ -1171,6 +1289,8 @@ struct ccc_xy
   int device = 0;
   ccc_xy_params_t prm{};
   int num_cu = 0, blocks = 0;
+  int M = 16;        // ridge slots per step (params.max_ridges)
+  bool wide = false; // beyond the dual active-set kernel's tables (more than 20 steps or 32 ridge slots)
   int64_t hcap = 0;
   void * d_stage = nullptr;
   hipStream_t stream = nullptr;
@@ -1188,15 +1308,20 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   *out = nullptr;
   if(!(p->mass > 0) || !(p->horizon_dt > 0) || p->horizon_steps <= 0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_create: mass, horizon_dt, horizon_steps must be > 0");
-  if(p->horizon_steps > CCC_XY_MAX_STEPS)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: horizon_steps %d > %d is not built into this library",
-                p->horizon_steps, CCC_XY_MAX_STEPS);
+  if(p->max_ridges != 0 && p->max_ridges != CCC_XY_MAX_RIDGES && p->max_ridges != CCC_XY_MAX_RIDGES_WIDE)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: max_ridges = %d, the kernels are built for %d and %d", p->max_ridges,
+                CCC_XY_MAX_RIDGES, CCC_XY_MAX_RIDGES_WIDE);
+  if(p->horizon_steps > CCC_XY_MAX_STEPS_WIDE)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: horizon_steps %d > %d", p->horizon_steps, CCC_XY_MAX_STEPS_WIDE);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   CCC_DEVICE_GUARD(device);
   ccc_xy * h = new ccc_xy();
   h->device = device;
   h->prm = *p;
+  h->M = p->max_ridges ? p->max_ridges : CCC_XY_MAX_RIDGES;
+  h->prm.max_ridges = h->M;
+  h->wide = h->M != kXyM || p->horizon_steps > kXyMaxN;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if(e != hipSuccess)
@@ -1270,9 +1395,10 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t n64 = ((size_t)n + kXsLanes - 1) / kXsLanes * kXsLanes; // whole wavefronts
   // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
+  const size_t kXsStage = kXsFields + (size_t)h->M * 8;
   const size_t nwave = n64 / kXsLanes, ws_stride = N * kXsStage * kXsLanes, rb_stride = ws_stride;
   const size_t o_ws = 0, o_rb = o_ws + (size_t)kXsFields * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
-               o_li = o_st + up(N * n64 * 4), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
+               o_li = o_st + up(N * n64 * 8), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
                o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
@@ -1284,9 +1410,9 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
     h->ws_cap = n;
   }
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
-           reinterpret_cast<unsigned *>(h->ws + o_st),
+           reinterpret_cast<unsigned long long *>(h->ws + o_st),
            reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), ws_stride, rb_stride, n64,
-           nullptr, nullptr, nullptr, nullptr};
+           nullptr, nullptr, nullptr, nullptr, 0};
   int * const round_list[2] = {reinterpret_cast<int *>(h->ws + o_l1), reinterpret_cast<int *>(h->ws + o_l2)};
   int * const round_count = reinterpret_cast<int *>(h->ws + o_cn) + 1; // [kXsRounds], after the redo count
   // hand-overs to the dual kernel: a list per round (the first round's is W.redo_list)
@@ -1299,7 +1425,22 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   // per instance, is faster (measured: 4.2 against 7.3 ms at 2048, 7.6 / 7.3 at 4096, 14.5 / 8.1 at 8192, 28 / 9.4 at
   // 16384); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
-  const bool dual_only = std::getenv("CCC_XY_DUAL") != nullptr || (n < 4096 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS"));
+  // CCC_XY_SAFEGUARD (development switch): the single-change rounds instead of the dual kernel where both apply
+  const bool safeguard = h->wide || std::getenv("CCC_XY_SAFEGUARD") != nullptr;
+  const bool dual_only = !safeguard
+                         && (std::getenv("CCC_XY_DUAL") != nullptr
+                             || (n < 4096 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS")));
+  auto launch_stream = [&](const XyWork & Wk, int it_begin, int it_end) {
+    const dim3 g((unsigned)((n + kXsLanes - 1) / kXsLanes)), b(kXsLanes);
+    if(h->M == 16 && !Wk.single)
+      hipLaunchKernelGGL((xy_plan_stream_kernel<16, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+    else if(h->M == 16)
+      hipLaunchKernelGGL((xy_plan_stream_kernel<16, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+    else if(!Wk.single)
+      hipLaunchKernelGGL((xy_plan_stream_kernel<32, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+    else
+      hipLaunchKernelGGL((xy_plan_stream_kernel<32, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+  };
   if(!dual_only)
   {
     const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
@@ -1330,11 +1471,11 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       Wk.in_count = k ? round_count + (k - 1) : nullptr;
       Wk.out_list = k + 1 < nr ? round_list[k & 1] : nullptr;
       Wk.out_count = k + 1 < nr ? round_count + k : nullptr;
-      Wk.redo_list = redo_list_of(k);
-      Wk.redo_count = redo_count_of(k);
-      hipLaunchKernelGGL(xy_plan_stream_kernel, dim3((unsigned)((n + kXsLanes - 1) / kXsLanes)), dim3(kXsLanes), 0, s, P,
-                         B, Wk, (long)n, k ? ends[k - 1] : 0, ends[k]);
-      if(k + 1 < nr)
+      // (safeguard: every round hands over to ONE list, worked off by the single-change round after the last)
+      Wk.redo_list = redo_list_of(safeguard ? 0 : k);
+      Wk.redo_count = redo_count_of(safeguard ? 0 : k);
+      launch_stream(Wk, k ? ends[k - 1] : 0, ends[k]);
+      if(k + 1 < nr && !safeguard)
       {
         // this round's hand-overs (the instances found cycling) start on the dual kernel now, beside the next round:
         // the later rounds run few wavefronts and leave most of the device idle
@@ -1345,6 +1486,20 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       }
     }
     CCC_HIP_CHECK(hipGetLastError());
+    if(safeguard)
+    {
+      // the instances whose block iteration cycles or wanders, from the sets they were handed over with: one change of
+      // the clamped set per sweep (budget: the prototype's worst case was 213 sweeps at 20 x 16 variables; it scales
+      // with the number of variables that end up at a bound)
+      XyWork Ws = W;
+      Ws.in_list = redo_list_of(0);
+      Ws.in_count = redo_count_of(0);
+      Ws.single = 1;
+      const int budget = 200 + 4 * P.N * (h->M / 16) * 8;
+      launch_stream(Ws, ends[nr - 1], ends[nr - 1] + budget);
+      CCC_HIP_CHECK(hipGetLastError());
+      return CCC_OK;
+    }
     if(nr > 1)
     {
       CCC_HIP_CHECK(hipEventRecord(h->ev_join, h->side));
@@ -1373,7 +1528,7 @@ extern "C" int ccc_xy_plan_batch(ccc_xy_t * h, int64_t n, const int32_t * dim, c
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_plan_batch: NULL required array");
   CCC_DEVICE_GUARD(h->device);
   if(!h->stream) CCC_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  const size_t N = h->prm.horizon_steps, M = kXyM;
+  const size_t N = h->prm.horizon_steps, M = h->M;
   struct Seg
   {
     const void * src;

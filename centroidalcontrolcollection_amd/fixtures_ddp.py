@@ -335,3 +335,56 @@ def make_xy_batch(n, N=20, dt=0.1, mass=100.0, M=16, seed=20250928):
     am = rng.uniform(-0.5, 0.5, size=(n, 2))
     x0 = np.stack([mass * pos[:, 0], mass * vel[:, 0], mass * pos[:, 1], mass * vel[:, 1], am[:, 0], am[:, 1]], axis=1)
     return prob, np.ascontiguousarray(x0)
+
+
+def make_xy_walking_batch(n, N=30, dt=0.1, mass=100.0, M=32, seed=20250928, step_duration=(0.5, 0.8),
+                          double_support=(0.2, 0.4), flight_prob=0.1):
+    """LinearMpcXY walking sequences that use the reference's contact lists in full (src/LinearMpcXY.cpp:69-82 and
+    :126-133 iterate an arbitrary contact_list per step): DOUBLE support = two separate foot contacts = 32 ridges, single
+    support = 16, an occasional flight step = 0 ridges (no variables, no equality row), over horizons longer than the 20
+    steps of the reference test.  Feet 0.2 x 0.1 rects at y = +-0.1, the swing foot lands 0.15-0.3 m ahead of the stance
+    foot; reference = mid-point of the supporting feet; x0 near the reference as in make_xy_batch.
+    PRNG numpy default_rng(seed) (PCG64).  Returns (prob, x0 [n,6])."""
+    rng = np.random.default_rng(seed)
+    hx, hy = 0.1, 0.05
+    prob = dict(dim=np.zeros((n, N), dtype=np.int32), vertex=np.zeros((n, N, M, 3)), ridge=np.zeros((n, N, M, 3)),
+                com_z=np.full((n, N), 1.0), total_force_z=np.full((n, N), mass * G), ref_out=np.zeros((n, N, 6)))
+    for k in range(n):
+        feet = {0: np.array([1.0, 0.1]), 1: np.array([1.0 + rng.uniform(-0.05, 0.05), -0.1])}
+        swing = int(rng.integers(0, 2))
+        t, phases = -rng.uniform(0.0, 0.3), []  # (end time, [foot centres], ref xy)
+        horizon = N * dt
+        while t < horizon:
+            t += rng.uniform(*double_support)
+            both = [feet[0].copy(), feet[1].copy()]
+            phases.append((t, both, 0.5 * (both[0] + both[1])))
+            if t >= horizon:
+                break
+            stance = 1 - swing
+            dur = rng.uniform(*step_duration)
+            t += dur
+            if rng.uniform() < flight_prob:
+                phases.append((t - 0.2, [feet[stance].copy()], feet[stance].copy()))
+                phases.append((t, [], feet[stance] + np.array([0.05, 0.0])))
+            else:
+                phases.append((t, [feet[stance].copy()], feet[stance].copy()))
+            feet[swing] = np.array([feet[stance][0] + rng.uniform(0.15, 0.3), feet[swing][1]])
+            swing = stance
+        ends = np.array([e for e, _, _ in phases])
+        for i in range(N):
+            p = min(int(np.searchsorted(ends, i * dt, side="right")), len(phases) - 1)
+            r = 0
+            for c in phases[p][1]:
+                V, R = contact_from_rect((c[0] - hx, c[1] - hy), (c[0] + hx, c[1] + hy))
+                prob["vertex"][k, i, r:r + 16], prob["ridge"][k, i, r:r + 16] = V, R
+                r += 16
+            prob["dim"][k, i] = r
+            if r == 0:
+                prob["total_force_z"][k, i] = 0.0  # no contact, no force (src/LinearMpcXY.cpp:126-133 skips the row)
+            prob["ref_out"][k, i] = [mass * phases[p][2][0], 0.0, mass * phases[p][2][1], 0.0, 0.0, 0.0]
+    ref0 = prob["ref_out"][:, 0, :]
+    pos = np.stack([ref0[:, 0] / mass, ref0[:, 2] / mass], axis=1) + rng.uniform(-0.03, 0.03, size=(n, 2))
+    vel = rng.uniform(-0.1, 0.1, size=(n, 2))
+    am = rng.uniform(-0.5, 0.5, size=(n, 2))
+    x0 = np.stack([mass * pos[:, 0], mass * vel[:, 0], mass * pos[:, 1], mass * vel[:, 1], am[:, 0], am[:, 1]], axis=1)
+    return prob, np.ascontiguousarray(x0)

@@ -12,14 +12,15 @@ import numpy as np
 
 from . import _lib
 
-MAX_RIDGES = 16
-MAX_STEPS = 20
+MAX_RIDGES = 16  # default ridge slots per step (one surface contact)
+MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support)
+MAX_STEPS = 20  # horizon steps both kernels take; beyond (<= 256) the stage-recursion kernel alone
 
 
 class _Params(ctypes.Structure):
     _fields_ = [("mass", ctypes.c_double), ("horizon_dt", ctypes.c_double), ("horizon_steps", ctypes.c_int),
                 ("w_lmi", ctypes.c_double * 2), ("w_lm", ctypes.c_double * 2), ("w_am", ctypes.c_double * 2),
-                ("w_force", ctypes.c_double)]
+                ("w_force", ctypes.c_double), ("max_ridges", ctypes.c_int)]
 
 
 def _bind(L):
@@ -74,7 +75,7 @@ class LinearMpcXY:
             self.angular_momentum = np.asarray(angular_momentum, float)
             self.force = float(force)
 
-    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0):
+    def __init__(self, mass, horizon_dt, horizon_steps, weight_param=None, device=0, max_ridges=MAX_RIDGES):
         L = _lib.load()
         _bind(L)
         self._L = L
@@ -84,6 +85,8 @@ class LinearMpcXY:
         for a in range(2):
             p.w_lmi[a], p.w_lm[a], p.w_am[a] = w.linear_momentum_integral[a], w.linear_momentum[a], w.angular_momentum[a]
         p.w_force = w.force
+        p.max_ridges = int(max_ridges)
+        self.max_ridges_, self._weight_param = int(max_ridges), w
         h = ctypes.c_void_p()
         _lib.check(L.ccc_xy_create(ctypes.byref(p), int(device), ctypes.byref(h)))
         self._h = h
@@ -97,9 +100,10 @@ class LinearMpcXY:
             self._h = None
 
     def planOnceBatch(self, prob, x0, want_all=False):
-        """Host arrays (ccc_xy_plan_batch).  prob: dict(dim [n,N] i32, vertex/ridge [n,N,16,3], com_z [n,N],
-        total_force_z [n,N], ref_out [n,N,6]); x0 [n,6].  Returns dict(u0 [n,16], lam [n,N,16] | None, status, pivots)."""
-        N, M = self.horizon_steps_, MAX_RIDGES
+        """Host arrays (ccc_xy_plan_batch).  prob: dict(dim [n,N] i32, vertex/ridge [n,N,M,3], com_z [n,N],
+        total_force_z [n,N], ref_out [n,N,6]); x0 [n,6]; M = max_ridges.  Returns dict(u0 [n,M], lam [n,N,M] | None,
+        status, pivots)."""
+        N, M = self.horizon_steps_, self.max_ridges_
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         n = x0.shape[0]
         arr = dict(dim=np.ascontiguousarray(prob["dim"], dtype=np.int32),
@@ -144,7 +148,7 @@ class LinearMpcXY:
 
     def planOnce(self, motion_param_func, ref_data_func, initial_param, current_time):
         """CCC::LinearMpcXY::planOnce (LinearMpcXY.h:224-227, src/LinearMpcXY.cpp:96-114)."""
-        N, M = self.horizon_steps_, MAX_RIDGES
+        N, M = self.horizon_steps_, MAX_RIDGES_WIDE
         prob = dict(dim=np.zeros((1, N), dtype=np.int32), vertex=np.zeros((1, N, M, 3)), ridge=np.zeros((1, N, M, 3)),
                     com_z=np.zeros((1, N)), total_force_z=np.zeros((1, N)), ref_out=np.zeros((1, N, 6)))
         for i in range(N):
@@ -156,10 +160,20 @@ class LinearMpcXY:
             else:
                 V, R = np.zeros((0, 3)), np.zeros((0, 3))
             if len(V) > M:
-                raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "more than %d ridges in one contact list" % M)
+                raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "%d ridges in one contact list, the kernels are built for "
+                                    "%d (two 4-vertex surface contacts)" % (len(V), M))
             prob["dim"][0, i] = len(V)
             prob["vertex"][0, i, :len(V)], prob["ridge"][0, i, :len(V)] = V, R
             prob["com_z"][0, i], prob["total_force_z"][0, i] = mp.com_z, mp.total_force_z
             prob["ref_out"][0, i] = ref_data_func(t).toOutput(self.mass_)
-        r = self.planOnceBatch(prob, initial_param.toState(self.mass_)[None])
+        # the reference takes any contact_list (src/LinearMpcXY.cpp:69-82): what this object's ridge slots do not hold goes
+        # to a twin with max_ridges = 32, created on first need
+        planner = self
+        if prob["dim"].max() > self.max_ridges_:
+            if getattr(self, "_wide", None) is None:
+                self._wide = LinearMpcXY(self.mass_, self.horizon_dt_, N, self._weight_param, self.device, MAX_RIDGES_WIDE)
+            planner = self._wide
+        Mp = planner.max_ridges_
+        prob["vertex"], prob["ridge"] = prob["vertex"][:, :, :Mp], prob["ridge"][:, :, :Mp]
+        r = planner.planOnceBatch(prob, initial_param.toState(self.mass_)[None])
         return r["u0"][0, :prob["dim"][0, 0]].copy()

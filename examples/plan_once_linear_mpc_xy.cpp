@@ -53,6 +53,40 @@ int main()
     std::vector<CCC::LinearMpcXY::InitialParam> ips(3, ip);
     auto all = mpc.planOnceBatch(mf, rf, ips, {times[0], times[1], times[2]});
     for(size_t k = 0; k < all.size(); k++) std::printf("batch[%zu] dim=%d u0[0]=%.17g\n", k, all[k].size(), all[k][0]);
+    {
+      // Walking with two separate foot contacts in double support (a two-element contact_list = 32 ridges,
+      // src/LinearMpcXY.cpp:69-82) over 30 steps: beyond the 20 x 16 tables, routed to the 32-slot handle by the shim.
+      const int WN = 30;
+      CCC::LinearMpcXY wmpc(mass, dt, WN);
+      auto foot = [](double x, double y) {
+        return CCC::makeContactFromRect({CCC::Vector2d(x - 0.1, y - 0.05), CCC::Vector2d(x + 0.1, y + 0.05)});
+      };
+      auto wmotion = [&](double t) {
+        CCC::LinearMpcXY::MotionParam mp;
+        mp.com_z = 1.0;
+        mp.total_force_z = mass * g;
+        const int ph = static_cast<int>((t + 1e-9) / 0.5); // 0.5 s phases: DS, left, DS, right, DS, ...
+        const double xl = 1.0 + 0.4 * ((ph + 1) / 4), xr = 1.2 + 0.4 * ((ph + 3) / 4 - 1 >= 0 ? (ph + 3) / 4 - 1 : 0);
+        if(ph % 2 == 0)
+          mp.contact_list = {foot(xl, 0.1), foot(xr, -0.1)};
+        else if(ph % 4 == 1)
+          mp.contact_list = {foot(xl, 0.1)};
+        else
+          mp.contact_list = {foot(xr, -0.1)};
+        return mp;
+      };
+      auto wref = [&](double t) {
+        CCC::LinearMpcXY::RefData rd;
+        rd.pos = CCC::Vector2d(1.1 + 0.2 * t, 0.0);
+        return rd;
+      };
+      CCC::LinearMpcXY::InitialParam wip;
+      wip.pos = CCC::Vector2d(1.1, 0.01);
+      CCC::VectorXd u = wmpc.planOnce(wmotion, wref, wip, 0.0);
+      std::printf("walking dim=%d status=%d u0=", u.size(), wmpc.lastStatuses()[0] & 0xff);
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+    }
     return 0;
   }
   catch(const std::exception & e)

@@ -93,7 +93,7 @@ public:
   /** \brief Constructor (LinearMpcXY.h:211-215, src/LinearMpcXY.cpp:85-94).
       \param mass robot mass [kg]
       \param horizon_dt discretization timestep in horizon [sec]
-      \param horizon_steps number of steps in horizon (<= CCC_XY_MAX_STEPS)
+      \param horizon_steps number of steps in horizon (<= CCC_XY_MAX_STEPS_WIDE)
       \param weight_param objective weight parameter
       \param qp_solver_type ignored (kept for source compatibility)
       \param device HIP device ordinal (new) */
@@ -117,6 +117,8 @@ public:
       p.w_am[a] = weight_param.angular_momentum[a];
     }
     p.w_force = weight_param.force;
+    params_ = p;
+    device_ = device;
     ccc_xy_t * h = nullptr;
     check(ccc_xy_create(&p, device, &h));
     handle_.reset(h, ccc_xy_destroy);
@@ -136,9 +138,10 @@ public:
   {
     Flat f(1, horizon_steps_);
     const int m0 = sample(f, 0, motion_param_func, ref_data_func, initial_param, current_time);
-    std::vector<double> u0(CCC_DDP_MAX_RIDGES);
+    ccc_xy_t * const h = select(f);
+    std::vector<double> u0(static_cast<size_t>(f.M));
     last_status_.assign(1, 0);
-    check(ccc_xy_plan_batch(handle_.get(), 1, f.dim.data(), f.vertex.data(), f.ridge.data(), f.com_z.data(),
+    check(ccc_xy_plan_batch(h, 1, f.dim.data(), f.vertex.data(), f.ridge.data(), f.com_z.data(),
                             f.total_force_z.data(), f.ref_out.data(), f.x0.data(), u0.data(), nullptr,
                             last_status_.data()));
     shim::reportStatus("LinearMpcXY", last_status_);
@@ -163,9 +166,11 @@ public:
     std::vector<int> m0(n);
     for(size_t k = 0; k < n; k++)
       m0[k] = sample(f, k, motion_param_funcs[k], ref_data_funcs[k], initial_params[k], current_times[k]);
-    std::vector<double> u0(n * CCC_DDP_MAX_RIDGES);
+    ccc_xy_t * const h = select(f);
+    const size_t M = static_cast<size_t>(f.M);
+    std::vector<double> u0(n * M);
     last_status_.assign(n, 0);
-    check(ccc_xy_plan_batch(handle_.get(), static_cast<int64_t>(n), f.dim.data(), f.vertex.data(), f.ridge.data(),
+    check(ccc_xy_plan_batch(h, static_cast<int64_t>(n), f.dim.data(), f.vertex.data(), f.ridge.data(),
                             f.com_z.data(), f.total_force_z.data(), f.ref_out.data(), f.x0.data(), u0.data(), nullptr,
                             last_status_.data()));
     shim::reportStatus("LinearMpcXY", last_status_);
@@ -173,12 +178,14 @@ public:
     for(size_t k = 0; k < n; k++)
     {
       out[k] = VectorXd(m0[k]);
-      for(int r = 0; r < m0[k]; r++) out[k][r] = u0[k * CCC_DDP_MAX_RIDGES + static_cast<size_t>(r)];
+      for(int r = 0; r < m0[k]; r++) out[k][r] = u0[k * M + static_cast<size_t>(r)];
     }
     return out;
   }
 
-  /** \brief The C-ABI handle, for the flat-array entry points of ccc_amd.h. */
+  /** \brief The C-ABI handle (16 ridge slots per step), for the flat-array entry points of ccc_amd.h.  planOnce() and
+      planOnceBatch() take any contact list up to 32 ridges per step: what 16 slots do not hold goes to a second handle
+      with max_ridges = 32, created on first need. */
   ccc_xy_t * handle() const
   {
     return handle_.get();
@@ -207,17 +214,48 @@ protected:
   std::vector<int32_t> last_status_;
 
 protected:
-  /** Flat arrays of ccc_xy_plan_batch for n instances. */
+  /** Flat arrays of ccc_xy_plan_batch for n instances; sampled with 32 ridge slots per step, see select(). */
   struct Flat
   {
     Flat(size_t n, int N)
-    : dim(n * N, 0), vertex(n * N * CCC_DDP_MAX_RIDGES * 3, 0.0), ridge(n * N * CCC_DDP_MAX_RIDGES * 3, 0.0),
+    : dim(n * N, 0), vertex(n * N * CCC_XY_MAX_RIDGES_WIDE * 3, 0.0), ridge(n * N * CCC_XY_MAX_RIDGES_WIDE * 3, 0.0),
       com_z(n * N, 0.0), total_force_z(n * N, 0.0), ref_out(n * N * 6, 0.0), x0(n * 6, 0.0)
     {
     }
     std::vector<int32_t> dim;
     std::vector<double> vertex, ridge, com_z, total_force_z, ref_out, x0;
+    int M = CCC_XY_MAX_RIDGES_WIDE; //!< ridge slots per step of vertex / ridge
   };
+
+  /** The handle that takes the sampled problems: 16 ridge slots per step when no contact list has more (the arrays are
+      compacted to that stride), else the handle with 32, created on first need -- the reference takes any contact_list
+      (src/LinearMpcXY.cpp:69-82). */
+  ccc_xy_t * select(Flat & f)
+  {
+    int32_t mx = 0;
+    for(int32_t d : f.dim) mx = d > mx ? d : mx;
+    if(mx <= CCC_XY_MAX_RIDGES)
+    {
+      const size_t steps = f.dim.size(), Mw = CCC_XY_MAX_RIDGES_WIDE, Mn = CCC_XY_MAX_RIDGES;
+      for(size_t e = 0; e < steps; e++)
+        for(size_t j = 0; j < Mn * 3; j++)
+        {
+          f.vertex[e * Mn * 3 + j] = f.vertex[e * Mw * 3 + j];
+          f.ridge[e * Mn * 3 + j] = f.ridge[e * Mw * 3 + j];
+        }
+      f.M = CCC_XY_MAX_RIDGES;
+      return handle_.get();
+    }
+    if(!wide_handle_)
+    {
+      ccc_xy_params_t p = params_;
+      p.max_ridges = CCC_XY_MAX_RIDGES_WIDE;
+      ccc_xy_t * h = nullptr;
+      check(ccc_xy_create(&p, device_, &h));
+      wide_handle_.reset(h, ccc_xy_destroy);
+    }
+    return wide_handle_.get();
+  }
 
   /** src/LinearMpcXY.cpp:102-110 (sampling) and :69-82 (contact -> vertex -> ridge order); returns dim of step 0 */
   int sample(Flat & f,
@@ -227,7 +265,7 @@ protected:
              const InitialParam & initial_param,
              double current_time) const
   {
-    const size_t N = static_cast<size_t>(horizon_steps_), M = CCC_DDP_MAX_RIDGES;
+    const size_t N = static_cast<size_t>(horizon_steps_), M = CCC_XY_MAX_RIDGES_WIDE;
     for(size_t i = 0; i < N; i++)
     {
       const double t = current_time + static_cast<double>(i) * horizon_dt_;
@@ -239,7 +277,9 @@ protected:
         {
           for(const auto & rd : vr.ridgeList)
           {
-            if(r >= M) throw std::runtime_error("[LinearMpcXY] more than 16 ridges in one contact list");
+            if(r >= M)
+              throw std::runtime_error("[LinearMpcXY] more than 32 ridges in one contact list (the kernels are built for two "
+                                       "4-vertex surface contacts)");
             for(int a = 0; a < 3; a++)
             {
               f.vertex[((k * N + i) * M + r) * 3 + static_cast<size_t>(a)] = vr.vertex[a];
@@ -270,6 +310,8 @@ protected:
 
 protected:
   WeightParam weight_param_;
-  std::shared_ptr<ccc_xy_t> handle_;
+  std::shared_ptr<ccc_xy_t> handle_, wide_handle_;
+  ccc_xy_params_t params_{};
+  int device_ = 0;
 };
 } // namespace CCC

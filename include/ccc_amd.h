@@ -226,7 +226,10 @@ int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, cons
  * ========================================================================================= */
 typedef struct ccc_xy ccc_xy_t;
 
-#define CCC_XY_MAX_STEPS 20 /* horizon steps the kernel is built for (BASELINE config 4: N = 20) */
+#define CCC_XY_MAX_STEPS 20       /* horizon steps both XY kernels take (BASELINE config 4: N = 20) */
+#define CCC_XY_MAX_STEPS_WIDE 256 /* ... beyond that, up to here, the stage-recursion kernel alone (workspace: 64 KB x N / 20 per instance) */
+#define CCC_XY_MAX_RIDGES 16      /* default ridge slots per step (one 4-vertex surface contact) */
+#define CCC_XY_MAX_RIDGES_WIDE 32 /* params.max_ridges = 32: two surface contacts per step (double support) */
 
 /* Constructor arguments of LinearMpcXY(mass, horizon_dt, horizon_steps, weight_param, qp_solver_type)
  * (include/CCC/LinearMpcXY.h:211-215, src/LinearMpcXY.cpp:85-94); WeightParam (:104-142) flattened:
@@ -238,6 +241,9 @@ typedef struct
   double horizon_dt;
   int horizon_steps;
   double w_lmi[2], w_lm[2], w_am[2], w_force;
+  int max_ridges; /* M: ridge slots per horizon step: 0 or 16 = CCC_XY_MAX_RIDGES (one 4-vertex surface contact), 32 =
+                   * CCC_XY_MAX_RIDGES_WIDE (two: double support; src/LinearMpcXY.cpp:69-82 walks the whole contact_list).
+                   * Other values: CCC_ERR_UNSUPPORTED. */
 } ccc_xy_params_t;
 
 int ccc_xy_create(const ccc_xy_params_t * params, int device, ccc_xy_t ** out);
@@ -250,13 +256,13 @@ int ccc_xy_get_params(const ccc_xy_t * h, ccc_xy_params_t * params, int * device
  * current_time + i*dt, contact lists flattened in contact -> vertex -> ridge order (:69-82):
  *
  *   dim            [n][N]          i32  ridges of step i (0: no contact -> no variables, no equality row, :126-133)
- *   vertex, ridge  [n][N][16][3]   f64  per-ridge vertex / ridge direction of step i
+ *   vertex, ridge  [n][N][M][3]    f64  per-ridge vertex / ridge direction of step i; M = max_ridges
  *   com_z          [n][N]          f64  MotionParam::com_z
  *   total_force_z  [n][N]          f64  MotionParam::total_force_z
  *   ref_out        [n][N][6]       f64  RefData::toOutput(mass) = [m px, m vx, m py, m vy, Lx, Ly]   (:33-38)
  *   x0             [n][6]          f64  InitialParam::toState(mass)                                  (:26-31)
- *   u0             [n][16]         f64  planned force scales of step 0 (first dim[.][0] entries = the return value)
- *   lambda_all     [n][N][16]      f64  optional: every QP variable, per step
+ *   u0             [n][M]          f64  planned force scales of step 0 (first dim[.][0] entries = the return value)
+ *   lambda_all     [n][N][M]       f64  optional: every QP variable, per step
  *   status         [n]             i32  optional: CCC_STATUS_*
  * All DEVICE pointers, asynchronous on `stream`. */
 int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t * dim, const double * vertex, const double * ridge,

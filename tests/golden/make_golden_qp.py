@@ -14,7 +14,8 @@ computed it.  This script therefore
   * stores the KKT certificate next to the answer: stationarity, primal feasibility and the signs of the bound / row
     multipliers, all checked below before anything is written.
 
-Run:  python tests/golden/make_golden_qp.py [xy|ism|z ...]   (needs scipy; writes *_golden.npz next to this file)
+Run:  python tests/golden/make_golden_qp.py [xy|xy_wide|ism|z ...]   (needs scipy; writes *_golden.npz next to this file;
+      xy_wide -- 700-variable QPs in long double -- takes several minutes and is not part of the default set)
 """
 import os
 import sys
@@ -51,7 +52,7 @@ def solve_ld(A, b):
     return x
 
 
-def active_set_qp(H, g, A, b, lo, hi, x, max_iter=5000):
+def active_set_qp(H, g, A, b, lo, hi, x, max_iter=5000, mult_tol=1e-9):
     """min 1/2 x'Hx + g'x, A x = b, lo <= x <= hi from a feasible x: primal active set, one change per iteration.
     Returns (x, stat) with stat = -1 / 0 / +1 for variables at the lower bound / free / at the upper bound."""
     n, me = len(g), len(b)
@@ -73,7 +74,7 @@ def active_set_qp(H, g, A, b, lo, hi, x, max_iter=5000):
         # a zero step up to the accuracy of the float64 KKT solve (the long-double polish and its certificate decide)
         if np.abs(p).max(initial=0.0) <= 1e-7 * max(1.0, np.abs(x).max()) or -(grad @ p) <= 1e-13 * max(1.0, abs(g @ x)):
             mu = grad + A.T @ nu  # multipliers of the bounds: must be >= 0 at lo, <= 0 at hi
-            tol = 1e-9 * max(1.0, np.abs(mu).max())
+            tol = mult_tol * max(1.0, np.abs(mu).max())
             bad = np.where(((stat == -1) & (mu < -tol)) | ((stat == 1) & (mu > tol)))[0]
             if len(bad) == 0:
                 return x, stat
@@ -118,11 +119,11 @@ def polish(H, g, A, b, lo, hi, stat):
     return x.astype(np.float64), nu.astype(np.float64), mu.astype(np.float64), cert
 
 
-def solve_certified(H, g, A, b, lo, hi, x_feasible, scale):
-    x, stat = active_set_qp(H, g, A, b, lo, hi, x_feasible.copy())
+def solve_certified(H, g, A, b, lo, hi, x_feasible, scale, mult_tol=1e-9, sign_tol=1e-9):
+    x, stat = active_set_qp(H, g, A, b, lo, hi, x_feasible.copy(), mult_tol=mult_tol)
     x, nu, mu, cert = polish(H, g, A, b, lo, hi, stat)
     assert cert["stationarity"] <= 1e-9 * scale and cert["equality"] <= 1e-9 * scale, cert
-    assert cert["bound_violation"] <= 1e-9 * scale and cert["multiplier_sign"] <= 1e-9 * scale, cert
+    assert cert["bound_violation"] <= 1e-9 * scale and cert["multiplier_sign"] <= sign_tol * scale, cert
     return x, stat, cert
 
 
@@ -213,6 +214,51 @@ def make_xy():
         out[tag + "_cert"] = certs
     np.savez_compressed(os.path.join(HERE, "xy_golden.npz"), **out)
     print("wrote xy_golden.npz", {k: v.shape for k, v in out.items()})
+
+
+def make_xy_wide():
+    """Beyond one surface contact and 20 steps: walking with two separate foot contacts in double support (32 ridges per
+    step) over 30 steps, and the reference scenario over 40 steps (src/LinearMpcXY.cpp:69-82, :126-133).  Instances whose
+    active set the float64 iteration cannot settle to the long-double certificate (a bound multiplier within 1e-6 of
+    zero: degenerate at this precision) are left out."""
+    out = {}
+    mass, dt = 100.0, 0.1
+    for tag, N, M, n, seed in (("w30", 30, 32, 5, 41), ("l40", 40, 16, 4, 42)):
+        if M == 32:
+            prob, x0 = fd.make_xy_walking_batch(n + 3, N, dt, mass, M=32, seed=seed)
+        else:
+            prob, x0 = fd.make_xy_batch(n + 3, N, dt, mass, seed=seed)
+        keep, lams, certs = [], [], []
+        for k in range(n + 3):
+            if len(keep) == n:
+                break
+            H, g, A, b, lo, hi, dims = xy_qp(prob, k, x0[k], mass, dt)
+            xf = np.zeros(len(g))
+            off = np.concatenate([[0], np.cumsum(dims)])
+            for e, i in enumerate([i for i in range(N) if dims[i] > 0]):
+                xf[off[i]:off[i + 1]] = b[e] / A[e, off[i]:off[i + 1]].sum()
+            try:
+                # (multipliers here are of order w_force x force ~ 1e-3: the certificate at 1e-13 of the force scale)
+                lam, stat, cert = solve_certified(H, g, A, b, lo, hi, xf, scale=np.abs(b).max(), mult_tol=1e-12,
+                                                  sign_tol=1e-13)
+            except AssertionError as err:
+                print("xy", tag, k, "left out:", err, flush=True)
+                continue
+            la = np.zeros((N, M))
+            for i in range(N):
+                la[i, :dims[i]] = lam[off[i]:off[i + 1]]
+            keep.append(k)
+            lams.append(la)
+            certs.append([cert["stationarity"], cert["equality"], cert["bound_violation"], cert["multiplier_sign"]])
+            print("xy", tag, k, "variables", len(g), "clamped", int((stat != 0).sum()), cert, flush=True)
+        assert len(keep) == n
+        for key, v in prob.items():
+            out["%s_%s" % (tag, key)] = v[keep]
+        out[tag + "_x0"] = x0[keep]
+        out[tag + "_lambda"] = np.array(lams)
+        out[tag + "_cert"] = np.array(certs)
+    np.savez_compressed(os.path.join(HERE, "xy_wide_golden.npz"), **out)
+    print("wrote xy_wide_golden.npz", {k: v.shape for k, v in out.items()})
 
 
 # ------------------------------------------------------------------------------------------------ IntrinsicallyStableMpc
@@ -351,3 +397,5 @@ if __name__ == "__main__":
         make_ism()
     if "xy" in which:
         make_xy()
+    if "xy_wide" in which:
+        make_xy_wide()
