@@ -1154,8 +1154,9 @@ struct Solver
       {
         const int a = lane;
         double t3[M];
+        const double * const Qxur = P.reg_type == 2 ? mem.Qxur : mem.Qxu; // (reg_type 1: the same matrix)
 #  pragma unroll
-        for(int f = 0; f < M; f++) t3[f] = (f < m && !mem.clamped[f]) ? mem.Qxur[a * M + f] : 0.0;
+        for(int f = 0; f < M; f++) t3[f] = (f < m && !mem.clamped[f]) ? Qxur[a * M + f] : 0.0;
 #  pragma unroll
         for(int r = 0; r < M; r++)
         {
@@ -1224,9 +1225,10 @@ struct Solver
   // words, almost all of them broadcasts.  Sums run over k = 0 .. S-1 in increasing order from the same start value:
   // identical results.   C(a,c) = [DIAG] + sum_k Aop(a,k) B(k,c),  Aop = A or A' (TRANS), optionally A + lam I (LAM);
   //   DIAG 0: none, 1: w_run[a] on a == c, 2: w_force on a == c, 3: as 2 and lam added to the diagonal after the sum.
+  //   C2 (optional): a second copy of C with lam added to the diagonal after the sum (Quu and Quu + lambda I at once).
   template<bool TRANS, int DIAG, bool LAM>
   CCC_DDP_FN void colprod(int lane, int rows, int ncols, const double * A, int lda, const double * B, int ldb, double lam,
-                          double * C, int ldc) const
+                          double * C, int ldc, double * C2 = nullptr) const
   {
     const int c = lane & (M - 1), g = lane / M;
     const bool act = c < ncols;
@@ -1247,6 +1249,7 @@ struct Solver
       }
       if(DIAG == 3) sum = (a == c) ? sum + lam : sum;
       if(act) C[a * ldc + c] = sum;
+      if(C2 && act) C2[a * ldc + c] = (a == c) ? sum + lam : sum;
     }
   }
 #endif
@@ -1346,7 +1349,9 @@ struct Solver
 #if CCC_DDP_FAST
         colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
         colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
-        colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda_v, T2r, M);
+        // (reg_type 1 regularises Quu, not Vxx: T2r = T2, Qxur = Qxu and Quu_F = Quu + lambda I -- the same sums, so the
+        //  three products are not repeated)
+        if(P.reg_type == 2) colprod<false, 0, true>(lane, S, m, mem.Vxx, S, mem.Fu, M, lambda_v, T2r, M);
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
@@ -1376,7 +1381,7 @@ struct Solver
 #if CCC_DDP_FAST
         colprod<true, 1, false>(lane, S, S, mem.Fx, S, mem.T1, S, 0.0, mem.Qxx, S);
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxu, M);
-        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, 0.0, mem.Quu, LQ);
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, lambda_q, mem.Quu, LQ, P.reg_type == 2 ? nullptr : mem.QuuF);
 #else
         for(int e = lane; e < S * S; e += kWave)
         {
@@ -1403,8 +1408,11 @@ struct Solver
         // regularised versions from T2r
         const double * const T2r = mem.Lf;
 #if CCC_DDP_FAST
-        colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
-        colprod<true, 3, false>(lane, m, m, mem.Fu, M, T2r, M, lambda_q, mem.QuuF, LQ);
+        if(P.reg_type == 2)
+        {
+          colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);
+          colprod<true, 3, false>(lane, m, m, mem.Fu, M, T2r, M, lambda_q, mem.QuuF, LQ);
+        }
 #else
         for(int e = lane; e < S * m; e += kWave)
         {
