@@ -27,7 +27,7 @@ def source_hash():
     import hashlib
 
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + sorted(
         glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
     for d in deps:
         h.update(os.path.basename(d).encode())

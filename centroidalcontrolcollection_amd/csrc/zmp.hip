@@ -90,6 +90,8 @@ __device__ __forceinline__ double row_at_group_uniform(const RowRegs<NP> & T, in
   return (threadIdx.x & 32) ? c1 : c0;
 }
 
+// K1, static pairing: QP (instance, axis) = (qp / 2, qp % 2), the two axes of an instance in the two halves of a
+// wavefront.  The steps of the iteration are the sections of csrc/zmp_k1.inc, shared with zmp_plan_kernel_dyn.
 template<int LG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                              const double * __restrict__ zlim, double control_dt,
@@ -123,64 +125,26 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
     const long qp = task * QPW + grp; // (instance, axis) = (qp / 2, qp % 2)
     const bool valid = qp < nqp;
     const bool row = valid && li < N;
-
-    // ---- src/LinearMpcZmp.cpp:54-66: lo/hi of the box on B u
-    double lo = -kInf, hi = kInf;
-    if(row)
-    {
-      const double fr = As[li * 3 + 0] * x0[qp * 3 + 0] + As[li * 3 + 1] * x0[qp * 3 + 1]
-                        + As[li * 3 + 2] * x0[qp * 3 + 2]; // (A_seq x0)_i
-      lo = zlim[qp * 2 * N + li] - fr;
-      hi = zlim[qp * 2 * N + N + li] - fr;
-    }
-
+    double lo, hi;
+    // tableau T = G (W empty): lane li holds row li = column li of the symmetric G.  The diagonal lives in dg: the
+    // in-row copy T[li][li] is never read by its owner (dgm mirrors its bits for the closing refinement).
+    RowRegs<NP> T;
+    double dg, dgm;
+    double z, mu;      // z = (G mu)_li, mu = multiplier of row li
+    bool inW, side;    // while in W: side = sits on lo
+    int p;             // entering row   (group uniform)
+    double sig;        // its side +1/-1 (group uniform)
+    int passes;
+#define K1_LOAD
+#include "zmp_k1.inc"
+#undef K1_LOAD
     int st = CCC_STATUS_SOLVED;
     if(Grp::any(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
-
-    // ---- tableau T = G (W empty): lane li holds row li = column li of the symmetric G.  The diagonal lives
-    //      in dg: the in-row copy T[li][li] is never read by its owner (dgm mirrors its bits for the
-    //      closing refinement).
-    RowRegs<NP> T;
-#pragma unroll
-    for(int j = 0; j < NP; ++j)
-    {
-      if(j % 8 == 0) asm volatile("" ::: "memory");
-      T.t[j / 16][j % 16] = Gs[j * NP + li];
-    }
-    double dg = Gs[li * NP + li];
-    double dgm = dg;
-
-    double z = 0.0, mu = 0.0; // z = (G mu)_li, mu = multiplier of row li
-    bool inW = false;
-    bool side = false;        // while in W: true = sits on lo, false = sits on hi
-    int p = 0;                // entering row   (group uniform)
-    double sig = 0.0;         // its side +1/-1 (group uniform)
     bool done = !valid || st != CCC_STATUS_SOLVED;
     bool need_select = true;
-    int passes = 0;
-
-    // -- Goldfarb-Idnani step 1: the most violated row enters (group-uniform result in p / sig / done)
-    auto select_entering = [&]() {
-      // Any violated row is a valid entering row; "most violated" is only a heuristic, so the argmax runs on
-      // fp32 keys (one v_max_f32 + DPP per butterfly step) while the violated / not-violated decision stays exact.
-      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
-      const double score = fmax(sl, sh);
-      const bool violated = row && !inW && score > 0.0;
-      const float key = violated ? fmaxf((float)score, 1.17549435e-38f) : -1.0f;
-      const float m = Grp::max(key);
-      const int cand = Grp::first(key == m);
-      const bool cand_lower = Grp::bit(sl >= sh, cand);
-      if(need_select && !done)
-      {
-        if(m > 0.0f)
-        {
-          p = cand;
-          sig = cand_lower ? 1.0 : -1.0;
-        }
-        else
-          done = true;
-      }
-    };
+#define K1_SELECT
+#include "zmp_k1.inc"
+#undef K1_SELECT
 
     for(int round = 0; round < 3; ++round)
     {
@@ -189,204 +153,24 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
       // top-tested loop hipcc keeps a second copy of the register-resident row and moves it back every trip
       if(__ballot(!done) != 0ull) do
         {
-          // -- column p of T = {T[i][p]}: search direction on W, Schur complement elsewhere
-          const bool isp = (li == p);
-          double c = row_at_group_uniform<LG, NP>(T, p);
-          c = isp ? dg : c;
-
-          // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
-          const double dm = -sig * c;
-          const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-          const double pd = sig > 0.0 ? lo : hi;
-          const double num = isp ? sig * (pd - z) : -mu;
-          const double den = isp ? dg : dm;
-          const double ratio = (!done && (isp || blocking)) ? num * fast_rcp(den) : kInf;
-          const double t = Grp::min(ratio);
-          int kk = Grp::first(ratio == t);
-          if(!done && kk >= LG)
-          { // NaN step: numerical breakdown, report instead of spinning
-            done = true;
-            st = CCC_STATUS_MAX_ITER;
-          }
-          kk = kk >= LG ? 0 : kk;
-          const bool isadd = (kk == p);
-          const bool isk = (li == kk);
-          const double s = isadd ? 1.0 : -1.0;
-          if(!done)
-          {
-            if(inW)
-              mu = fma(t, dm, mu);
-            else
-              z = fma(sig * t, c, z);
-            if(isp) mu += sig * t;
-          }
-
-          // -- pivot row kk (add: p itself; drop: the blocking row).  Every lane publishes its element of
-          //    column kk; lane kk publishes (pivot - s) instead, which makes the generic update write column kk:
-          //    T'_ij = T_ij - (v_i rp) v_j ;  column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ;  row kk: g = 1 - s rp
-          double v = c;
-          if(__ballot(!done && !isadd) != 0ull)
-          {
-            const double vk = row_at_group_uniform<LG, NP>(T, kk);
-            v = isadd ? c : vk;
-          }
-          v = isk ? dg - s : v;
-          scr[li] = v;
-          if(isk) scr[Scr::kRp] = fast_rcp(dg);
-          __builtin_amdgcn_wave_barrier();
-          const double rp = scr[Scr::kRp];
-          double g = isk ? (1.0 - s * rp) : v * rp;
-          g = done ? 0.0 : g;
-          const double ng = -g;
-          {
-            // rank-1 update of the register-resident row, in place.  Software pipeline: two chunks of 8
-            // broadcast values in flight (32 VGPRs) so that row + state fit the VGPR budget; the empty asm
-            // statements pin the issue order, the tied operands keep the FMAs in place.
-            constexpr int CH = 8, NCH = NP / CH;
-            double2 buf[2][CH / 2];
-#pragma unroll
-            for(int ch = 0; ch < 2 && ch < NCH; ++ch)
-#pragma unroll
-              for(int q = 0; q < CH / 2; ++q) buf[ch][q] = scr2[ch * (CH / 2) + q];
-#pragma unroll
-            for(int ch = 0; ch < NCH; ++ch)
-            {
-              asm volatile("" ::: "memory");
-#pragma unroll
-              for(int q = 0; q < CH / 2; ++q)
-              {
-                const int j = ch * CH + 2 * q;
-                double t0 = T.t[j / 16][j % 16], t1 = T.t[(j + 1) / 16][(j + 1) % 16];
-                asm("v_fma_f64 %0, %2, %3, %0\n\tv_fma_f64 %1, %2, %4, %1"
-                    : "+v"(t0), "+v"(t1)
-                    : "v"(ng), "v"(buf[ch & 1][q].x), "v"(buf[ch & 1][q].y));
-                T.t[j / 16][j % 16] = t0;
-                T.t[(j + 1) / 16][(j + 1) % 16] = t1;
-              }
-              if(ch + 2 < NCH)
-              {
-#pragma unroll
-                for(int q = 0; q < CH / 2; ++q) buf[ch & 1][q] = scr2[(ch + 2) * (CH / 2) + q];
-              }
-            }
-          }
-          if(!done)
-          {
-            dg = isk ? -rp : fma(ng, v, dg);
-            dgm = fma(ng, v, dgm);
-            if(isadd)
-            {
-              if(isp)
-              {
-                inW = true;
-                side = sig > 0.0;
-                z = pd;
-              }
-              need_select = true;
-            }
-            else
-            {
-              if(isk)
-              {
-                inW = false;
-                mu = 0.0;
-              }
-              need_select = false;
-            }
-            if(++passes > maxpass)
-            {
-              done = true;
-              st = CCC_STATUS_MAX_ITER;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-          if(__ballot(need_select && !done) != 0ull) select_entering();
+#define K1_PIVOT
+#include "zmp_k1.inc"
+#undef K1_PIVOT
         } while(__ballot(!done) != 0ull);
 
-      // ---- closing iterative refinement against the untouched G (removes the drift of the rank-1 updates):
-      //      rho = d_W - (G mu)_W ;  mu_W += G_WW^-1 rho = -T_WW rho ;  z = G mu recomputed; a row the fresh z
-      //      shows violated re-opens the iteration (rare: rows that sat within the drift of their bound)
-      const bool ok = valid && st == CCC_STATUS_SOLVED;
-      const bool act = inW && ok;
-      const double dact = side ? lo : hi;
-      scr[li] = act ? mu : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      double acc = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
-        const double2 mb = scr2[j / 2];
-        acc = fma(Gs[j * NP + li], mb.x, acc);
-        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
-      }
-      const double rho = act ? dact - acc : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      scr[li] = rho;
-      __builtin_amdgcn_wave_barrier();
-      double tr = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory");
-        const double2 rb = scr2[j / 2];
-        tr = fma(T.t[j / 16][j % 16], rb.x, tr);
-        tr = fma(T.t[(j + 1) / 16][(j + 1) % 16], rb.y, tr);
-      }
-      tr = fma(dg - dgm, rho, tr); // replace the stale in-row diagonal by the true one
-      if(act) mu -= tr;
-      __builtin_amdgcn_wave_barrier();
-      scr[li] = act ? mu : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      acc = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
-        const double2 mb = scr2[j / 2];
-        acc = fma(Gs[j * NP + li], mb.x, acc);
-        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
-      }
-      if(ok) z = inW ? dact : acc;
-      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
-      const bool reopen = Grp::any(ok && row && !inW && fmax(sl, sh) > 0.0);
+      const bool fin = true;
+#define K1_REFINE
+#include "zmp_k1.inc"
+#undef K1_REFINE
       done = !reopen;
       need_select = true;
       __builtin_amdgcn_wave_barrier();
       if(__ballot(reopen) == 0ull) break;
     }
-
-    // ---- outputs: jerk[0] = (B' mu)_0, then src/LinearMpcZmp.cpp:72-78
-    const double u0 = Grp::sum(row ? bs[li] * mu : 0.0);
-    if(valid && li == 0)
-    {
-      const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
-      const double zl = zlim[qp * 2 * N], zh = zlim[qp * 2 * N + N];
-      const double cdt = control_dt < 0 ? P.dt : control_dt;
-      const double com_acc = ax + cdt * u0;
-      const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
-      double zv = com_pos + P.c2 * com_acc;
-      zv = zv < zl ? zl : (zh < zv ? zh : zv);
-      zmp[qp] = zv;
-      if(status) status[qp] = (passes << 8) | st;
-    }
-    if(jerk)
-    {
-      // u_j = sum_{i >= j} b[i - j] mu_i   (mu is zero outside W)
-      scr[li] = row ? mu : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      double uj = 0.0;
-#pragma unroll 4
-      for(int i = 0; i < NP; ++i)
-      {
-        const double m = scr[i];
-        const int dlt = i - li;
-        const double bv = bs[dlt >= 0 ? dlt : 0];
-        uj = (dlt >= 0) ? fma(bv, m, uj) : uj;
-      }
-      if(row) jerk[qp * N + li] = uj;
-      __builtin_amdgcn_wave_barrier();
-    }
+    const bool emit = true;
+#define K1_WRITE
+#include "zmp_k1.inc"
+#undef K1_WRITE
   }
 }
 
@@ -394,9 +178,13 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp
 // wavefront spends max(pivots_x, pivots_y) trips on a pair (measured: 24.7 against a mean of 17.9 per QP).  Here every group
 // takes its QPs from a global queue on its own: when one group finishes (refinement, outputs) it fetches and sets up the
 // next QP while the other keeps pivoting -- the set-up / refinement code runs under divergence, once per QP, the pivot trip
-// stays the same straight-line code.  The arithmetic of a QP is unchanged.
+// stays the same straight-line code.  The arithmetic of a QP is unchanged: the same sections of csrc/zmp_k1.inc.
 constexpr int kQueues = 64;      // ticket counters of zmp_plan_kernel_dyn
 constexpr int kQueueStride = 16; // in counters: one 128-byte line each
+
+#ifndef CCC_ZMP_BATCH
+#define CCC_ZMP_BATCH 1
+#endif
 
 template<int LG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long nqp, const double * __restrict__ x0,
@@ -428,9 +216,6 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
 
   // group state (uniform inside a group)
   enum { kNeed = 0, kActive = 1, kIdle = 2 };
-#ifndef CCC_ZMP_BATCH
-#define CCC_ZMP_BATCH 1
-#endif
   constexpr int kBatch = CCC_ZMP_BATCH;
   int phase = kNeed, left = 0;
   long qp = 0, next = 0;
@@ -448,30 +233,9 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
   double sig = 0.0;
   bool done = true, need_select = false;
   int passes = 0, round = 0;
-
-    // -- Goldfarb-Idnani step 1: the most violated row enters (group-uniform result in p / sig / done)
-    auto select_entering = [&]() {
-      // Any violated row is a valid entering row; "most violated" is only a heuristic, so the argmax runs on
-      // fp32 keys (one v_max_f32 + DPP per butterfly step) while the violated / not-violated decision stays exact.
-      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
-      const double score = fmax(sl, sh);
-      const bool violated = row && !inW && score > 0.0;
-      const float key = violated ? fmaxf((float)score, 1.17549435e-38f) : -1.0f;
-      const float m = Grp::max(key);
-      const int cand = Grp::first(key == m);
-      const bool cand_lower = Grp::bit(sl >= sh, cand);
-      if(need_select && !done)
-      {
-        if(m > 0.0f)
-        {
-          p = cand;
-          sig = cand_lower ? 1.0 : -1.0;
-        }
-        else
-          done = true;
-      }
-    };
-
+#define K1_SELECT
+#include "zmp_k1.inc"
+#undef K1_SELECT
 
   for(;;)
   {
@@ -529,32 +293,9 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
         {
           fresh = true;
           row = li < N;
-          // ---- src/LinearMpcZmp.cpp:54-66: lo/hi of the box on B u
-          lo = -kInf;
-          hi = kInf;
-          if(row)
-          {
-            const double fr = As[li * 3 + 0] * x0[qp * 3 + 0] + As[li * 3 + 1] * x0[qp * 3 + 1]
-                              + As[li * 3 + 2] * x0[qp * 3 + 2]; // (A_seq x0)_i
-            lo = zlim[qp * 2 * N + li] - fr;
-            hi = zlim[qp * 2 * N + N + li] - fr;
-          }
-          // ---- tableau T = G (W empty), see zmp_plan_kernel
-#pragma unroll
-          for(int j = 0; j < NP; ++j)
-          {
-            if(j % 8 == 0) asm volatile("" ::: "memory");
-            T.t[j / 16][j % 16] = Gs[j * NP + li];
-          }
-          dg = Gs[li * NP + li];
-          dgm = dg;
-          z = 0.0;
-          mu = 0.0;
-          inW = false;
-          side = false;
-          p = 0;
-          sig = 0.0;
-          passes = 0;
+#define K1_LOAD
+#include "zmp_k1.inc"
+#undef K1_LOAD
           round = 0;
           need_select = true;
           phase = kActive;
@@ -574,168 +315,18 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
     // ---- one pivot for every group that is iterating
     if(__ballot(phase == kActive && !done) != 0ull)
     {
-        // -- column p of T = {T[i][p]}: search direction on W, Schur complement elsewhere
-        const bool isp = (li == p);
-        double c = row_at_group_uniform<LG, NP>(T, p);
-        c = isp ? dg : c;
-
-        // -- step length: full step (row p reaches its bound) vs dual ratio test over W, in ONE min
-        const double dm = -sig * c;
-        const bool blocking = inW && ((mu > 0.0 && dm < 0.0) || (mu < 0.0 && dm > 0.0));
-        const double pd = sig > 0.0 ? lo : hi;
-        const double num = isp ? sig * (pd - z) : -mu;
-        const double den = isp ? dg : dm;
-        const double ratio = (!done && (isp || blocking)) ? num * fast_rcp(den) : kInf;
-        const double t = Grp::min(ratio);
-        int kk = Grp::first(ratio == t);
-        if(!done && kk >= LG)
-        { // NaN step: numerical breakdown, report instead of spinning
-          done = true;
-          st = CCC_STATUS_MAX_ITER;
-        }
-        kk = kk >= LG ? 0 : kk;
-        const bool isadd = (kk == p);
-        const bool isk = (li == kk);
-        const double s = isadd ? 1.0 : -1.0;
-        if(!done)
-        {
-          if(inW)
-            mu = fma(t, dm, mu);
-          else
-            z = fma(sig * t, c, z);
-          if(isp) mu += sig * t;
-        }
-
-        // -- pivot row kk (add: p itself; drop: the blocking row).  Every lane publishes its element of
-        //    column kk; lane kk publishes (pivot - s) instead, which makes the generic update write column kk:
-        //    T'_ij = T_ij - (v_i rp) v_j ;  column kk: v_i - (v_i rp)(v_kk - s) = s v_i rp ;  row kk: g = 1 - s rp
-        double v = c;
-        if(__ballot(!done && !isadd) != 0ull)
-        {
-          const double vk = row_at_group_uniform<LG, NP>(T, kk);
-          v = isadd ? c : vk;
-        }
-        v = isk ? dg - s : v;
-        scr[li] = v;
-        if(isk) scr[Scr::kRp] = fast_rcp(dg);
-        __builtin_amdgcn_wave_barrier();
-        const double rp = scr[Scr::kRp];
-        double g = isk ? (1.0 - s * rp) : v * rp;
-        g = done ? 0.0 : g;
-        const double ng = -g;
-        {
-          // rank-1 update of the register-resident row, in place.  Software pipeline: two chunks of 8
-          // broadcast values in flight (32 VGPRs) so that row + state fit the VGPR budget; the empty asm
-          // statements pin the issue order, the tied operands keep the FMAs in place.
-          constexpr int CH = 8, NCH = NP / CH;
-          double2 buf[2][CH / 2];
-#pragma unroll
-          for(int ch = 0; ch < 2 && ch < NCH; ++ch)
-#pragma unroll
-            for(int q = 0; q < CH / 2; ++q) buf[ch][q] = scr2[ch * (CH / 2) + q];
-#pragma unroll
-          for(int ch = 0; ch < NCH; ++ch)
-          {
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for(int q = 0; q < CH / 2; ++q)
-            {
-              const int j = ch * CH + 2 * q;
-              double t0 = T.t[j / 16][j % 16], t1 = T.t[(j + 1) / 16][(j + 1) % 16];
-              asm("v_fma_f64 %0, %2, %3, %0\n\tv_fma_f64 %1, %2, %4, %1"
-                  : "+v"(t0), "+v"(t1)
-                  : "v"(ng), "v"(buf[ch & 1][q].x), "v"(buf[ch & 1][q].y));
-              T.t[j / 16][j % 16] = t0;
-              T.t[(j + 1) / 16][(j + 1) % 16] = t1;
-            }
-            if(ch + 2 < NCH)
-            {
-#pragma unroll
-              for(int q = 0; q < CH / 2; ++q) buf[ch & 1][q] = scr2[(ch + 2) * (CH / 2) + q];
-            }
-          }
-        }
-        if(!done)
-        {
-          dg = isk ? -rp : fma(ng, v, dg);
-          dgm = fma(ng, v, dgm);
-          if(isadd)
-          {
-            if(isp)
-            {
-              inW = true;
-              side = sig > 0.0;
-              z = pd;
-            }
-            need_select = true;
-          }
-          else
-          {
-            if(isk)
-            {
-              inW = false;
-              mu = 0.0;
-            }
-            need_select = false;
-          }
-          if(++passes > maxpass)
-          {
-            done = true;
-            st = CCC_STATUS_MAX_ITER;
-          }
-        }
-      __builtin_amdgcn_wave_barrier();
-      if(__ballot(need_select && !done) != 0ull) select_entering();
+#define K1_PIVOT
+#include "zmp_k1.inc"
+#undef K1_PIVOT
     }
 
     // ---- groups whose iteration stopped: closing refinement, then either re-open or emit and ask for the next QP
     if(__ballot(phase == kActive && done) != 0ull)
     {
       const bool fin = phase == kActive && done;
-      const bool ok = fin && valid && st == CCC_STATUS_SOLVED;
-      const bool act = inW && ok;
-      const double dact = side ? lo : hi;
-      scr[li] = act ? mu : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      double acc = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
-        const double2 mb = scr2[j / 2];
-        acc = fma(Gs[j * NP + li], mb.x, acc);
-        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
-      }
-      const double rho = act ? dact - acc : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      scr[li] = rho;
-      __builtin_amdgcn_wave_barrier();
-      double tr = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory");
-        const double2 rb = scr2[j / 2];
-        tr = fma(T.t[j / 16][j % 16], rb.x, tr);
-        tr = fma(T.t[(j + 1) / 16][(j + 1) % 16], rb.y, tr);
-      }
-      tr = fma(dg - dgm, rho, tr); // replace the stale in-row diagonal by the true one
-      if(act) mu -= tr;
-      __builtin_amdgcn_wave_barrier();
-      scr[li] = act ? mu : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      acc = 0.0;
-#pragma unroll
-      for(int j = 0; j < NP; j += 2)
-      {
-        if(j % 8 == 0) asm volatile("" ::: "memory"); // bound the loads in flight (VGPR budget)
-        const double2 mb = scr2[j / 2];
-        acc = fma(Gs[j * NP + li], mb.x, acc);
-        acc = fma(Gs[(j + 1) * NP + li], mb.y, acc);
-      }
-      if(ok) z = inW ? dact : acc;
-      const double sl = (lo - z) - 1e-12 * (1.0 + fabs(lo)), sh = (z - hi) - 1e-12 * (1.0 + fabs(hi));
-      const bool reopen = Grp::any(ok && row && !inW && fmax(sl, sh) > 0.0);
+#define K1_REFINE
+#include "zmp_k1.inc"
+#undef K1_REFINE
       const bool again = fin && reopen && round + 1 < 3;
       if(fin)
       {
@@ -748,37 +339,9 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
       const bool emit = fin && !again;
       if(__ballot(emit) != 0ull)
       {
-        // ---- outputs: jerk[0] = (B' mu)_0, then src/LinearMpcZmp.cpp:72-78
-        const double u0 = Grp::sum((emit && row) ? bs[li] * mu : 0.0);
-        if(emit && valid && li == 0)
-        {
-          const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
-          const double zl = zlim[qp * 2 * N], zh = zlim[qp * 2 * N + N];
-          const double cdt = control_dt < 0 ? P.dt : control_dt;
-          const double com_acc = ax + cdt * u0;
-          const double com_pos = px + cdt * vx + 0.5 * (cdt * cdt) * ax;
-          double zv = com_pos + P.c2 * com_acc;
-          zv = zv < zl ? zl : (zh < zv ? zh : zv);
-          zmp[qp] = zv;
-          if(status) status[qp] = (passes << 8) | st;
-        }
-        if(jerk)
-        {
-          // u_j = sum_{i >= j} b[i - j] mu_i   (mu is zero outside W)
-          scr[li] = (emit && row) ? mu : 0.0;
-          __builtin_amdgcn_wave_barrier();
-          double uj = 0.0;
-#pragma unroll 4
-          for(int i = 0; i < NP; ++i)
-          {
-            const double m = scr[i];
-            const int dlt = i - li;
-            const double bv = bs[dlt >= 0 ? dlt : 0];
-            uj = (dlt >= 0) ? fma(bv, m, uj) : uj;
-          }
-          if(emit && row) jerk[qp * N + li] = uj;
-          __builtin_amdgcn_wave_barrier();
-        }
+#define K1_WRITE
+#include "zmp_k1.inc"
+#undef K1_WRITE
         if(emit) phase = kNeed;
       }
     }

@@ -33,8 +33,11 @@ def test_xy_single_step_and_no_contact_at_all():
 
 
 def test_xy_rejects_unsupported_sizes():
+    LinearMpcXY(100.0, 0.1, 21)  # (beyond the dual kernel's 20 steps: the stage-recursion kernel alone, tests/test_xy_gpu.py)
     with pytest.raises(CccError):
-        LinearMpcXY(100.0, 0.1, 21)
+        LinearMpcXY(100.0, 0.1, 257)
+    with pytest.raises(CccError):
+        LinearMpcXY(100.0, 0.1, 20, max_ridges=48)
     with pytest.raises(CccError):
         LinearMpcXY(-1.0, 0.1, 10)
 
