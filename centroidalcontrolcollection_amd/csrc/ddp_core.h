@@ -706,7 +706,7 @@ struct Solver
         __syncthreads();
         if(lane < m) mem.clamped[lane] = cl ? 1 : 0;
         __syncthreads();
-        cholesky_phase<MM>(m);
+        cholesky_phase<MM>(m, clmask);
         if(mem.ic[IC_OK] == 0)
         {
           result = -1;
@@ -736,7 +736,7 @@ struct Solver
         // not fit the register budget of two waves per SIMD
         double lr[M], lc[M], rdi;
         load_factor_lane<MM>(m, i, lr, lc, rdi);
-        sol = solve_lane<64, MM>(m, i, (in && !cl) ? gc : 0.0, lr, lc, rdi);
+        sol = solve_lane<64, MM>(m, i, (in && !cl) ? gc : 0.0, lr, lc, rdi, clmask);
       }
       const double srch = (in && !cl) ? -sol - x : 0.0;
       const double sdotg = seq_sum(srch * grad);
@@ -941,10 +941,11 @@ struct Solver
   CCC_DDP_FN bool cholesky_free(int m)
   {
 #if CCC_DDP_FAST
+    const unsigned long long clm = clamped_mask(m);
     if(m == M)
-      cholesky_phase<M>(m);
+      cholesky_phase<M>(m, clm);
     else
-      cholesky_phase<0>(m);
+      cholesky_phase<0>(m, clm);
     return mem.ic[IC_OK] != 0;
 #else
     // Phase version, right-looking, lane = row: per column j one phase scales the column below the pivot, the next
@@ -992,8 +993,16 @@ struct Solver
 #if CCC_DDP_FAST
   // MM = 16: every step has the full 16 ridges (the usual case) -- all size tests fold away and the factorisation is
   // straight-line code; MM = 0: size m at run time.
+  // the clamped rows as a wavefront-uniform bit mask (bit i = row i): their columns of the factor are identity columns,
+  // and every step below that would only multiply by their zeros is skipped -- exactly: x - 0 * y = x
+  CCC_DDP_FN unsigned long long clamped_mask(int m) const
+  {
+    const int lane = static_cast<int>(threadIdx.x & 63);
+    return __ballot(lane < m && mem.clamped[lane] != 0) & kRowMask;
+  }
+
   template<int MM>
-  CCC_DDP_FN void cholesky_phase(int m_rt)
+  CCC_DDP_FN void cholesky_phase(int m_rt, unsigned long long clmask)
   {
     const double * H = mem.QuuF;
     const int m = MM ? MM : m_rt;
@@ -1012,7 +1021,7 @@ struct Solver
 #  pragma unroll
       for(int j = 0; j < M; ++j)
       {
-        if(j < m)
+        if(j < m && !((clmask >> j) & 1ull)) // (a clamped column is e_j already: pivot 1, nothing below, nothing to subtract)
         {
           const double d = lane_value(a[j], j);
           ok = ok && (d > 0.0);
@@ -1064,13 +1073,14 @@ struct Solver
   }
   // acc <- (L L')^-1 acc inside a 16-lane group (WIDTH = 16) or with every group redundant (WIDTH = 64)
   template<int WIDTH, int MM>
-  static CCC_DDP_FN double solve_lane(int m_rt, int i, double acc, const double (&lr)[M], const double (&lc)[M], double rdi)
+  static CCC_DDP_FN double solve_lane(int m_rt, int i, double acc, const double (&lr)[M], const double (&lc)[M], double rdi,
+                                      unsigned long long clmask)
   {
     const int m = MM ? MM : m_rt;
 #  pragma unroll
     for(int k = 0; k < M; ++k)
     {
-      if(k < m)
+      if(k < m && !((clmask >> k) & 1ull)) // (clamped: right-hand side and solution entry are zero)
       {
         const double yk = (WIDTH == 64) ? lane_value(acc * rdi, k) : __shfl(acc * rdi, k, WIDTH);
         if(i == k)
@@ -1082,7 +1092,7 @@ struct Solver
 #  pragma unroll
     for(int k = M - 1; k >= 0; --k)
     {
-      if(k < m)
+      if(k < m && !((clmask >> k) & 1ull))
       {
         const double zk = (WIDTH == 64) ? lane_value(acc * rdi, k) : __shfl(acc * rdi, k, WIDTH);
         if(i == k)
@@ -1133,11 +1143,12 @@ struct Solver
   CCC_DDP_FN void solve_free_phase(int m_rt, double * v)
   {
     const int m = MM ? MM : m_rt;
+    const unsigned long long clm = clamped_mask(m);
     phase([&](int lane) {
       const int i = lane & (M - 1);
       double lr[M], lc[M], rdi;
       load_factor_lane<MM>(m, i, lr, lc, rdi);
-      const double acc = solve_lane<64, MM>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi);
+      const double acc = solve_lane<64, MM>(m, i, (i < m) ? v[i] : 0.0, lr, lc, rdi, clm);
       if(lane < m) v[i] = acc;
     });
   }
@@ -1149,6 +1160,7 @@ struct Solver
   CCC_DDP_FN void gains_phase(int m_rt)
   {
     const int m = MM ? MM : m_rt;
+    const unsigned long long clm = clamped_mask(m);
     phase([&](int lane) {
       if(lane < S)
       {
@@ -1160,7 +1172,7 @@ struct Solver
 #  pragma unroll
         for(int r = 0; r < M; r++)
         {
-          if(r < m)
+          if(r < m && !((clm >> r) & 1ull)) // (a clamped row: t3[r] is zero and stays zero)
           {
             double sum = t3[r];
 #  pragma unroll
@@ -1172,7 +1184,7 @@ struct Solver
 #  pragma unroll
         for(int r = M - 1; r >= 0; r--)
         {
-          if(r < m)
+          if(r < m && !((clm >> r) & 1ull))
           {
             double sum = t3[r];
 #  pragma unroll
