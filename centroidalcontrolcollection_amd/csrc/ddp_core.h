@@ -166,14 +166,11 @@ CCC_DDP_FN void phase(F && f)
 #endif
 }
 
-// row stride of the M x M matrices Quu, QuuF, Lf in LDS.  FAST build: M (padding to M + 1 removes their bank conflicts but
-// costs 384 B, which is the difference between eight and seven resident workgroups per CU -- not worth it); WIDE build:
-// M + 1, where lane = row accesses with a stride of 32 doubles would all fall into one bank.
-#if defined(CCC_DDP_WIDE)
+// Row stride of the M x M matrices Quu, QuuF, Lf in LDS: M + 1.  Lane = row accesses (the factor's rows into registers,
+// the rows of Quu_F for the box-QP) at a stride of M doubles fall into one bank group -- 43 % of the LDS-active cycles of
+// the round-1 kernel were bank conflicts.  The padding costs 3 x 16 x 8 B at M = 16; the device build pays for it with
+// the box-QP work vectors only the phase versions use (below), so eight wavefronts per CU still fit.
 template<int M> constexpr int row_stride() { return M + 1; }
-#else
-template<int M> constexpr int row_stride() { return M; }
-#endif
 
 template<int S, int M>
 struct Mem
@@ -182,14 +179,20 @@ struct Mem
   double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
   double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * LQ], QuuF[M * LQ];
   double T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
-  double k[M], kq[M], lo[M], hi[M], grad[M], srch[M], xcand[M], tmp[M], t4[M];
+  double k[M], kq[M], lo[M], hi[M], t4[M];
+#if !CCC_DDP_FAST
+  double grad[M], srch[M], xcand[M], tmp[M]; // (box-QP state of the phase versions; the device build keeps it in registers)
+#endif
   double x[S], xn[S], xd[S], u[M], un[M], ref[S], tf[4], wd[4];
   double rd[M];  // reciprocal diagonal of the box-QP Cholesky factor
   double sc[16]; // uniform scalars
 #if defined(CCC_DDP_PROF)
   double prof[16];
 #endif
-  int clamped[M], oldc[M];
+  int clamped[M];
+#if !CCC_DDP_FAST
+  int oldc[M];
+#endif
   int ic[8]; // uniform ints
   // per-instance problem tables, staged once per solve (every model evaluation reads them); the WIDE build keeps them
   // in global memory (any horizon length, up to one contact phase per horizon step)
