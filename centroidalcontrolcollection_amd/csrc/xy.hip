@@ -830,6 +830,43 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   int it = 0;
   constexpr bool single = SINGLE;
   bool converged = false, cycling = false, gaveup = false;
+  // single-change rounds: one change PER STAGE and sweep (the most violated condition of each stage) until the set
+  // returns to where it was two sweeps ago, from then on (strict) one change per sweep (the most violated of all)
+  bool strict = false;
+  // one variable of stage s changes sides (and, with it, `forced` is released: see below); the sums of the stage are rebuilt
+  auto apply_change = [&](int s, int r, unsigned ns, int forced) -> Bits {
+    const int m = (int)WS(s, kXsDim);
+    Bits bits = (Bits)(unsigned)WS(s, kXsSt);
+    if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+    bits = (bits & ~(Bits(3) << (2 * r))) | ((Bits)ns << (2 * r));
+    if(forced >= 0) bits &= ~(Bits(3) << (2 * forced));
+    double nS[21], nt[6], nc[6], nal = 0.0, ndp = WS(s, kXsFz);
+#pragma unroll
+    for(int a = 0; a < 21; a++) nS[a] = 0.0;
+#pragma unroll
+    for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
+    for(int q = 0; q < m; q++)
+    {
+      double bb[6];
+#pragma unroll
+      for(int a = 0; a < 6; a++) bb[a] = RB(s, q, a);
+      const unsigned st = (unsigned)(bits >> (2 * q)) & 3u;
+      xs_accumulate(st, st == 1u ? P.flo : P.fhi, bb, RB(s, q, 6), nS, nt, nc, nal, ndp);
+    }
+#pragma unroll
+    for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
+#pragma unroll
+    for(int a = 0; a < 6; a++)
+    {
+      WS(s, kXsT + a) = nt[a];
+      WS(s, kXsC + a) = nc[a];
+    }
+    WS(s, kXsAl) = nal;
+    WS(s, kXsDp) = ndp;
+    WS(s, kXsSt) = (double)(unsigned)bits;
+    if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
+    return bits;
+  };
   unsigned long long h1 = 0, h2 = 0; // hashes of the clamped sets of the last two iterations
   for(it = it_begin; it < max_it && !converged && !cycling && !gaveup; it++)
   {
@@ -1067,6 +1104,9 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         double rel_lo_m = kXyInf, rel_hi_m = -kXyInf;
         int rel_lo_i = -1, rel_hi_i = -1;
         bool cand_here = false;
+        double sc_v = 0.0; // the stage's own most violated condition
+        int sc_r = 0;
+        unsigned sc_ns = 0u;
         if(single) // (free variables of the stage: clamping the only one is a move only if another can be released)
           for(int r = 0; r < m; r++) nfree += ((bits >> (2 * r)) & 3ull) == 0ull ? 1 : 0;
         const bool may_clamp = nfree > 1 || m > nfree;
@@ -1129,6 +1169,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
                 rel_hi_i = r;
               }
             }
+            if(single && !emit && viol > sc_v)
+            {
+              sc_v = viol;
+              sc_r = r;
+              sc_ns = ns;
+            }
             if(single && !emit && viol > cand_v)
             {
               cand_v = viol;
@@ -1152,17 +1198,24 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             if(s == 0) B.u0[b * M + r] = 0.0;
             if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = 0.0;
           }
-        if(single && !emit && cand_here)
+        if(single && !emit)
         {
           // clamping the stage's only free variable: the stage equality needs one, so a clamped variable is released
           // with it -- one that can move the right way: the free variable ran into its UPPER bound, the stage needs more
           // force from a variable at its lower bound (the one whose multiplier asks for it most), and vice versa
-          cand_forced = -1;
-          if(cand_ns != 0u && nfree <= 1)
+          auto partner = [&](unsigned ns) -> int {
+            if(ns == 0u || nfree > 1) return -1;
+            const int want = ns == 2u ? rel_lo_i : rel_hi_i, other = ns == 2u ? rel_hi_i : rel_lo_i;
+            return want >= 0 ? want : other;
+          };
+          if(cand_here) cand_forced = partner(cand_ns);
+          Bits now = bits;
+          if(!strict && sc_v > 0.0)
           {
-            const int want = cand_ns == 2u ? rel_lo_i : rel_hi_i, other = cand_ns == 2u ? rel_hi_i : rel_lo_i;
-            cand_forced = want >= 0 ? want : other;
+            now = apply_change(s, sc_r, sc_ns, partner(sc_ns));
+            changed = true;
           }
+          hh = (hh ^ now) * 1099511628211ull;
         }
         const bool forced = !single && m > 0 && !anyfree;
         if(forced) nb &= ~(Bits(3) << (2 * besti)); // the stage equality needs a free variable
@@ -1216,39 +1269,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       {
         converged = cand_s < 0;
         gaveup = !converged && last_chance;
-        if(!converged && !gaveup)
+        if(!converged && !gaveup && strict) apply_change(cand_s, cand_r, cand_ns, cand_forced);
+        if(!strict)
         {
-          // apply the one change and rebuild the sums of its stage
-          const int s = cand_s, m = (int)WS(s, kXsDim);
-          Bits bits = (Bits)(unsigned)WS(s, kXsSt);
-          if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
-          bits = (bits & ~(Bits(3) << (2 * cand_r))) | ((Bits)cand_ns << (2 * cand_r));
-          if(cand_forced >= 0) bits &= ~(Bits(3) << (2 * cand_forced));
-          double nS[21], nt[6], nc[6], nal = 0.0, ndp = WS(s, kXsFz);
-#pragma unroll
-          for(int a = 0; a < 21; a++) nS[a] = 0.0;
-#pragma unroll
-          for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
-          for(int r = 0; r < m; r++)
-          {
-            double bb[6];
-#pragma unroll
-            for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
-            const unsigned ns = (unsigned)(bits >> (2 * r)) & 3u;
-            xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
-          }
-#pragma unroll
-          for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
-#pragma unroll
-          for(int a = 0; a < 6; a++)
-          {
-            WS(s, kXsT + a) = nt[a];
-            WS(s, kXsC + a) = nc[a];
-          }
-          WS(s, kXsAl) = nal;
-          WS(s, kXsDp) = ndp;
-          WS(s, kXsSt) = (double)(unsigned)bits;
-          if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
+          strict = !converged && hh == h2; // the per-stage changes brought the set of two sweeps ago back
+          h2 = h1;
+          h1 = hh;
         }
       }
     }
