@@ -141,7 +141,8 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                 algo_bytes=P * 4 + 2 * P * M * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
                 + S * 8 + N * M * 8,
                 kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
-                (("ddp_plan_kernel<%d,16>" % S) if precision == 64 else ("ddp_group_kernel<%d,float>" % S)), cpu=cpu,
+                ((("ddp_lean_kernel<%d,16>" if srb else "ddp_plan_kernel<%d,16>") % S) if precision == 64
+                 else ("ddp_group_kernel<%d,float>" % S)), cpu=cpu,
                 keep=(d, tp, tx0))
 
 
@@ -311,6 +312,10 @@ def run(args, rank, world, local_rank, dist):
                             "what": "inputs + outputs + the per-iteration state this kernel streams through its HBM "
                                     "workspace (model from the iteration counts; the measured counter traffic is in "
                                     "profiles/): a traffic figure, not the roofline fraction"},
+                        "mfma": {"utilisation": 0.0,
+                                 "why": w.get("mfma", "no GEMM-shaped work: per-instance fp64 recursions over 6 x 6 .. 32 x 32 "
+                                              "blocks with data-dependent pivots / active sets, rank-1 updates and "
+                                              "triangular solves on dependent chains (DESIGN.md per class)")},
                         "note": "algorithmic bytes = mandatory inputs + outputs per instance x batch (SURVEY.md 8d); "
                                 "none of these kernels is bound by that stream (DESIGN.md says what binds each)"},
            "unsolved": int((st < 0).sum()) if "iters" in w else int(((st & 0xff) != 0).sum())}  # DDP: status < 0 = failure,

@@ -7,7 +7,9 @@
 // per instance so that a wavefront streams through contiguous memory.
 //
 // Three kernels behind one entry (dispatch in ccc_ddp_plan_batch_device):
-//   fast   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps
+//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps
+//   lean   ddp_lean_kernel (csrc/ddp_lean.hip)            the same sizes compiled for reg_type 1 (the default) only: what a
+//                                                         DdpSingleRigidBody handle runs (less LDS, more wavefronts)
 //   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
 //   group  ddp_group_kernel (csrc/ddp_group.h)             four instances per wavefront; precision 32 (configs[4])
 #include "common.h"
@@ -115,6 +117,7 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   h->M = p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES;
   h->prm.max_ridges = h->M;
   h->wide = h->M != CCC_DDP_MAX_RIDGES || p->max_phases > ddp::kMaxPhases || p->horizon_steps > ddp::kMaxSteps;
+  if(std::getenv("CCC_DDP_WIDE")) h->wide = true; // (development switch: the wide build on problems both builds take)
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -247,6 +250,9 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->wide && h->cfg.precision == 32)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 is built for max_ridges = %d, max_phases <= %d, "
                 "horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
+  if(h->wide && h->cfg.reg_type != 1)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: the wide kernel (max_ridges = %d, max_phases > %d or "
+                "horizon_steps > %d) is built for reg_type 1", CCC_DDP_MAX_RIDGES_WIDE, ddp::kMaxPhases, ddp::kMaxSteps);
   const bool group =
       !h->wide && h->cfg.reg_type == 1 && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
   int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
@@ -330,6 +336,15 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->wide)
   {
     CCC_HIP_CHECK(launch_ddp_wide(P, B, (long)n, h->S, h->M, s));
+    return CCC_OK;
+  }
+  // the lean build for the single-rigid-body model (eight wavefronts per CU instead of six: 46.0 k against 38.4 k solves/s at
+  // the shape of config 5); for the centroidal model both builds hold eight and the full one measured 3 % faster
+  // (CCC_DDP_LEAN / CCC_DDP_FULL, development switches, force either)
+  const bool lean = h->cfg.reg_type == 1 && !std::getenv("CCC_DDP_FULL") && (h->S == 12 || std::getenv("CCC_DDP_LEAN"));
+  if(lean)
+  {
+    CCC_HIP_CHECK(launch_ddp_lean(P, B, (long)n, h->S, s));
     return CCC_OK;
   }
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances

@@ -33,4 +33,7 @@ struct DdpBatch
 // csrc/ddp_wide.hip: one instance per wavefront, phase versions of csrc/ddp_core.h, S in {9, 12}, M in {16, 32}
 // (ridge stride of the arrays = the handle's max_ridges), any number of contact phases and horizon steps.
 hipError_t launch_ddp_wide(const ddp_common::Params & P, const DdpBatch & B, long n, int S, int M, hipStream_t stream);
+
+// csrc/ddp_lean.hip: the fast build's sizes (M = 16, tables in LDS) compiled for reg_type 1 only.
+hipError_t launch_ddp_lean(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 } // namespace ccc_amd

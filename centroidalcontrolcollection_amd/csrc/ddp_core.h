@@ -29,6 +29,8 @@
 // M x M input-space matrices per lane), different table layouts:
 //   - the FAST build (csrc/ddp.hip, M = 16): contact phases of up to 16 ridges, at most kMaxPhases of them and
 //     kMaxSteps horizon steps, all staged in LDS (20 KB per wavefront, eight wavefronts per CU);
+//   - the LEAN build (csrc/ddp_lean.hip, namespace ddp_lean): the fast build's tables, compiled for reg_type 1 only
+//     (see CCC_DDP_REG1_ONLY below) -- what a handle with the default regularisation runs;
 //   - the WIDE build (csrc/ddp_wide.hip, -DCCC_DDP_WIDE, namespace ddp_wide, M = 16 or 32): up to 32 ridges per step
 //     (two surface contacts; src/DdpCentroidal.cpp:49-60 iterates arbitrary contact lists), one contact phase per
 //     horizon step if need be, any horizon length: the contact tables stay in global memory and the M x M matrices are
@@ -37,6 +39,8 @@
 // after the other, for either table layout.
 #if defined(CCC_DDP_WIDE)
 #  define CCC_DDP_NS ddp_wide
+#elif defined(CCC_DDP_LEAN)
+#  define CCC_DDP_NS ddp_lean
 #else
 #  define CCC_DDP_NS ddp
 #endif
@@ -44,6 +48,14 @@
 #  define CCC_DDP_FAST 1
 #else
 #  define CCC_DDP_FAST 0
+#endif
+// The wide and the lean device builds are compiled for reg_type 1 only (lambda on Quu: the default): Quu_F = Quu +
+// lambda I and Qxu_r = Qxu are then not stored -- 10.7 KB less LDS at M = 32 (four or five wavefronts per CU instead of
+// three), 3.7 KB less for the single-rigid-body model at M = 16 (eight instead of six: csrc/ddp_lean.hip).
+#if CCC_DDP_FAST && (defined(CCC_DDP_WIDE) || defined(CCC_DDP_LEAN))
+#  define CCC_DDP_REG1_ONLY 1
+#else
+#  define CCC_DDP_REG1_ONLY 0
 #endif
 
 // No FMA contraction in this translation unit: every product and sum rounds separately, exactly as in the
@@ -177,7 +189,10 @@ struct Mem
 {
   static constexpr int LQ = row_stride<M>();
   double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
-  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Qxur[S * M], Quu[M * LQ], QuuF[M * LQ];
+  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Quu[M * LQ];
+#if !CCC_DDP_REG1_ONLY
+  double Qxur[S * M], QuuF[M * LQ];
+#endif
   double T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
   double k[M], kq[M], lo[M], hi[M], t4[M];
 #if !CCC_DDP_FAST
@@ -315,6 +330,17 @@ struct Solver
   static constexpr int LQ = Mem<S, M>::LQ;
   static_assert(M == 16 || M == 32, "a row of the M x M matrices per lane of an M-lane group");
   static constexpr unsigned long long kRowMask = (1ull << M) - 1ull; // the lanes of the first M-lane group
+
+  // entry (i, k) of the regularised Quu_F the box-QP works on
+  CCC_DDP_FN double quuF(int i, int k) const
+  {
+#if CCC_DDP_REG1_ONLY
+    const double q = mem.Quu[i * LQ + k]; // reg_type 1: the same sums, lambda added to the diagonal last
+    return i == k ? q + mem.sc[SC_LAMBDA] : q;
+#else
+    return mem.QuuF[i * LQ + k];
+#endif
+  }
 
   const Params & P;
   const Instance & I;
@@ -649,7 +675,7 @@ struct Solver
 #endif
     double Hr[M];
 #  pragma unroll
-    for(int k = 0; k < M; ++k) Hr[k] = (in && k < m) ? mem.QuuF[i * LQ + k] : 0.0;
+    for(int k = 0; k < M; ++k) Hr[k] = (in && k < m) ? quuF(i, k) : 0.0;
     const double gi = in ? mem.Qu[i] : 0.0;
     const double lo = in ? mem.lo[i] : 0.0, hi = in ? mem.hi[i] : 0.0;
     double x = in ? fmin(fmax(mem.kq[i], lo), hi) : 0.0;
@@ -1007,7 +1033,6 @@ struct Solver
   template<int MM>
   CCC_DDP_FN void cholesky_phase(int m_rt, unsigned long long clmask)
   {
-    const double * H = mem.QuuF;
     const int m = MM ? MM : m_rt;
     phase([&](int lane) {
       const int i = lane & (M - 1);
@@ -1017,7 +1042,7 @@ struct Solver
       {
         const bool in = (i < m) && (k < m);
         const bool cl = in && (mem.clamped[i] || mem.clamped[k]);
-        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : H[i * LQ + k]) : (i == k ? 1.0 : 0.0);
+        a[k] = in ? (cl ? (i == k ? 1.0 : 0.0) : quuF(i, k)) : (i == k ? 1.0 : 0.0);
       }
       bool ok = true;
       double rdi = 1.0;
@@ -1169,7 +1194,11 @@ struct Solver
       {
         const int a = lane;
         double t3[M];
+#if CCC_DDP_REG1_ONLY
+        const double * const Qxur = mem.Qxu;
+#else
         const double * const Qxur = P.reg_type == 2 ? mem.Qxur : mem.Qxu; // (reg_type 1: the same matrix)
+#endif
 #  pragma unroll
         for(int f = 0; f < M; f++) t3[f] = (f < m && !mem.clamped[f]) ? Qxur[a * M + f] : 0.0;
 #  pragma unroll
@@ -1396,7 +1425,11 @@ struct Solver
 #if CCC_DDP_FAST
         colprod<true, 1, false>(lane, S, S, mem.Fx, S, mem.T1, S, 0.0, mem.Qxx, S);
         colprod<true, 0, false>(lane, S, m, mem.Fx, S, mem.T2, M, 0.0, mem.Qxu, M);
+#if CCC_DDP_REG1_ONLY
+        colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, lambda_q, mem.Quu, LQ);
+#else
         colprod<true, 2, false>(lane, m, m, mem.Fu, M, mem.T2, M, lambda_q, mem.Quu, LQ, P.reg_type == 2 ? nullptr : mem.QuuF);
+#endif
 #else
         for(int e = lane; e < S * S; e += kWave)
         {
@@ -1422,7 +1455,9 @@ struct Solver
 #endif
         // regularised versions from T2r
         const double * const T2r = mem.Lf;
-#if CCC_DDP_FAST
+#if CCC_DDP_REG1_ONLY
+        (void)T2r;
+#elif CCC_DDP_FAST
         if(P.reg_type == 2)
         {
           colprod<true, 0, false>(lane, S, m, mem.Fx, S, T2r, M, 0.0, mem.Qxur, M);

@@ -19,7 +19,7 @@
 namespace ccc_amd
 {
 template<int S, int M>
-__global__ __launch_bounds__(64) void ddp_wide_kernel(ddp_common::Params P, DdpBatch B, long n)
+__global__ __launch_bounds__(64, (M == 16 ? 2 : 1)) void ddp_wide_kernel(ddp_common::Params P, DdpBatch B, long n)
 {
   __shared__ ddp_wide::Mem<S, M> mem;
   const long N = P.N;
