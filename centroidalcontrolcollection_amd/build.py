@@ -53,10 +53,31 @@ def build_lib(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", LIB_PATH]
+    # one hipcc per translation unit, side by side (no device code crosses a unit: every kernel is launched from the
+    # unit that defines it), then one link
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, sources()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    import shutil
+
+    shutil.rmtree(obj_dir, ignore_errors=True)
     with open(HASH_PATH, "w") as f:
         f.write(source_hash() + "\n")
     return LIB_PATH
