@@ -19,7 +19,8 @@ class ContactTimeline:
     """Per-instance piecewise-constant contact / reference schedule on the device.
 
     seg_end [n,K], seg_contact [n,K] i32, seg_ref [n,K,6], contact_dim [n,C] i32, contact_vertex / contact_ridge
-    [n,C,16,3] (numpy, host) -> CUDA tensors on `device`."""
+    [n,C,M,3] with M = the planner's max_ridges (16, or 32: two surface contacts per entry) (numpy, host) -> CUDA tensors
+    on `device`."""
 
     def __init__(self, seg_end, seg_contact, seg_ref, contact_dim, contact_vertex, contact_ridge, time_eps, device=0):
         import torch
@@ -28,7 +29,8 @@ class ContactTimeline:
         self.n, self.K = seg_end.shape
         self.C = contact_dim.shape[1]
         assert seg_contact.shape == (self.n, self.K) and seg_ref.shape == (self.n, self.K, 6)
-        assert contact_vertex.shape == (self.n, self.C, 16, 3) and contact_ridge.shape == (self.n, self.C, 16, 3)
+        self.M = contact_vertex.shape[2]
+        assert contact_vertex.shape == (self.n, self.C, self.M, 3) and contact_ridge.shape == (self.n, self.C, self.M, 3)
         f = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
         self.t = dict(seg_end=f(seg_end, np.float64), seg_contact=f(seg_contact, np.int32), seg_ref=f(seg_ref, np.float64),
                       contact_dim=f(contact_dim, np.int32), contact_vertex=f(contact_vertex, np.float64),
@@ -71,6 +73,8 @@ def ddp_closed_loop(planner, timeline, inertia_diag, sim_state, t0, sim_dt, cycl
     _bind(L)
     if stream is None:
         stream = torch.cuda.current_stream(planner.device)
+    if timeline.M != planner.max_ridges_:
+        raise ValueError("the timeline carries %d ridges per contact entry, the planner %d" % (timeline.M, planner.max_ridges_))
     tl = timeline.c_struct()
     dts = (ctypes.c_double * max(1, len(disturb_times)))(*disturb_times)
     dl = (ctypes.c_double * 3)(*disturb_lin)
@@ -90,6 +94,8 @@ def xy_closed_loop(planner, timeline, com_z, inertia_diag, sim_state, t0, sim_dt
     _bind(L)
     if stream is None:
         stream = torch.cuda.current_stream(planner.device)
+    if timeline.M != planner.max_ridges_:
+        raise ValueError("the timeline carries %d ridges per contact entry, the planner %d" % (timeline.M, planner.max_ridges_))
     tl = timeline.c_struct()
     t_end = ctypes.c_double(0.0)
     _lib.check(L.ccc_xy_closed_loop_device(planner._h, timeline.n, ctypes.byref(tl), float(com_z), _ptr(inertia_diag),

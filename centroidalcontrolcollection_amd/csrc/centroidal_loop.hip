@@ -19,11 +19,10 @@
 namespace ccc_amd
 {
 constexpr double kLoopG = 9.80665;
-constexpr int kLoopM = CCC_DDP_MAX_RIDGES;
 
 struct Timeline
 {
-  int K, C;
+  int K, C, M; // M: ridge slots per contact entry = the planner handle's max_ridges
   const double * seg_end;
   const int * seg_contact;
   const double * seg_ref;
@@ -72,10 +71,10 @@ __global__ void sample_xy_kernel(Timeline T, long n, int N, double t, double dt,
   const int c = T.seg_contact[k * T.K + s];
   const int m = T.contact_dim[k * T.C + c];
   dim[id] = m;
-  for(int e = 0; e < kLoopM * 3; e++)
+  for(int e = 0; e < T.M * 3; e++)
   {
-    vertex[id * kLoopM * 3 + e] = T.contact_vertex[(k * T.C + c) * kLoopM * 3 + e];
-    ridge[id * kLoopM * 3 + e] = T.contact_ridge[(k * T.C + c) * kLoopM * 3 + e];
+    vertex[id * T.M * 3 + e] = T.contact_vertex[(k * T.C + c) * T.M * 3 + e];
+    ridge[id * T.M * 3 + e] = T.contact_ridge[(k * T.C + c) * T.M * 3 + e];
   }
   cz[id] = com_z;
   fz[id] = total_force_z;
@@ -133,15 +132,15 @@ __global__ void planner_state_kernel(long n, int model, double mass, const doubl
 
 // warm start of the next cycle (TestDdpCentroidal.cpp:102-114): the previous input sequence UNSHIFTED, zeroed where the
 // input dimension of the step changed; dims_prev is updated.  One thread per (instance, step).
-__global__ void warm_start_kernel(long n, int N, int P, const int * phase_dim, const int * step_phase, int * dims_prev,
-                                  double * u)
+__global__ void warm_start_kernel(long n, int N, int P, int M, const int * phase_dim, const int * step_phase,
+                                  int * dims_prev, double * u)
 {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if(id >= n * N) return;
   const long k = id / N;
   const int m = phase_dim[k * P + step_phase[id]];
   if(dims_prev[id] != m)
-    for(int r = 0; r < kLoopM; r++) u[id * kLoopM + r] = 0.0;
+    for(int r = 0; r < M; r++) u[id * M + r] = 0.0;
   dims_prev[id] = m;
 }
 
@@ -151,7 +150,7 @@ struct SimArgs
 {
   long n;
   int model;        // 0 / 1: contact of step 0 from the phase tables; 2: from the per-step XY arrays
-  int N, P;
+  int N, P, M; // M: ridge stride of the contact arrays
   const int * phase_dim;
   const double * phase_vertex;
   const double * phase_ridge;
@@ -179,15 +178,15 @@ __global__ void sim_step_kernel(SimArgs A)
   if(A.model == 2)
   {
     m = A.step_phase[k * A.N];
-    V = A.phase_vertex + k * A.N * kLoopM * 3;
-    R = A.phase_ridge + k * A.N * kLoopM * 3;
+    V = A.phase_vertex + k * A.N * A.M * 3;
+    R = A.phase_ridge + k * A.N * A.M * 3;
   }
   else
   {
     const int ph = A.step_phase[k * A.N];
     m = A.phase_dim[k * A.P + ph];
-    V = A.phase_vertex + (k * A.P + ph) * kLoopM * 3;
-    R = A.phase_ridge + (k * A.P + ph) * kLoopM * 3;
+    V = A.phase_vertex + (k * A.P + ph) * A.M * 3;
+    R = A.phase_ridge + (k * A.P + ph) * A.M * 3;
   }
   // ForceColl::calcTotalWrench(contact_list, scales, sim.state_.pos.linear())
   double f[3] = {0, 0, 0}, tq[3] = {0, 0, 0};
@@ -294,9 +293,9 @@ int check_timeline(const ccc_contact_timeline_t * tl, const char * who)
   return CCC_OK;
 }
 
-Timeline to_dev(const ccc_contact_timeline_t * tl)
+Timeline to_dev(const ccc_contact_timeline_t * tl, int M)
 {
-  return Timeline{tl->K, tl->C, tl->seg_end, tl->seg_contact, tl->seg_ref, tl->contact_dim, tl->contact_vertex,
+  return Timeline{tl->K, tl->C, M, tl->seg_end, tl->seg_contact, tl->seg_ref, tl->contact_dim, tl->contact_vertex,
                   tl->contact_ridge, tl->time_eps};
 }
 
@@ -325,9 +324,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
   if(tl->C != prm.max_phases)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_closed_loop_device: the timeline has %d contact entries, the handle %d phases",
                 tl->C, prm.max_phases);
-  if(prm.max_ridges != kLoopM)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_closed_loop_device: the contact timeline carries %d ridges per entry, the handle %d",
-                kLoopM, prm.max_ridges);
+  const int kLoopM = prm.max_ridges; // ridge slots per contact entry of the timeline = the handle's ridge stride
   const int N = prm.horizon_steps, S = ccc_ddp_state_dim(h), model = prm.model == CCC_DDP_SINGLE_RIGID_BODY ? 1 : 0;
   int device = 0;
   if(int rc = ccc_ddp_get_device(h, &device)) return rc;
@@ -358,7 +355,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
   CCC_HIP_CHECK(hipMemsetAsync(dims_prev, 0xff, (size_t)n * N * sizeof(int), s)); // -1: "no previous plan"
   CCC_HIP_CHECK(hipMemsetAsync(u, 0, (size_t)n * N * kLoopM * sizeof(double), s));
   if(stats) CCC_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)n * 8 * sizeof(double), s));
-  const Timeline T = to_dev(tl);
+  const Timeline T = to_dev(tl, kLoopM);
   double t = t0;
   int rc = CCC_OK;
   for(int c = 0; c < cycles && rc == CCC_OK; c++)
@@ -368,7 +365,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
     hipLaunchKernelGGL(ref_now_kernel, dim3(blocks(n)), dim3(256), 0, s, T, (long)n, t, ref_now);
     hipLaunchKernelGGL(planner_state_kernel, dim3(blocks(n)), dim3(256), 0, s, (long)n, model, prm.mass, sim_state, x0);
     // first cycle: cold start (zeros) with the full budget; afterwards the unshifted warm start with max_iter = warm
-    hipLaunchKernelGGL(warm_start_kernel, dim3(blocks(n * N)), dim3(256), 0, s, (long)n, N, tl->C, tl->contact_dim,
+    hipLaunchKernelGGL(warm_start_kernel, dim3(blocks(n * N)), dim3(256), 0, s, (long)n, N, tl->C, kLoopM, tl->contact_dim,
                        step_phase, dims_prev, u);
     ccc_ddp_config_t cfg = cfg0;
     cfg.max_iter = c == 0 ? first_max_iter : warm_max_iter;
@@ -383,6 +380,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
     A.model = model;
     A.N = N;
     A.P = tl->C;
+    A.M = kLoopM;
     A.phase_dim = tl->contact_dim;
     A.phase_vertex = tl->contact_vertex;
     A.phase_ridge = tl->contact_ridge;
@@ -425,9 +423,7 @@ extern "C" int ccc_xy_closed_loop_device(ccc_xy_t * h, int64_t n, const ccc_cont
   ccc_xy_params_t prm;
   int device = 0;
   if(int rc = ccc_xy_get_params(h, &prm, &device)) return rc;
-  if(prm.max_ridges != kLoopM)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_closed_loop_device: the contact timeline carries %d ridges per entry, the handle %d",
-                kLoopM, prm.max_ridges);
+  const int kLoopM = prm.max_ridges; // ridge slots per contact entry of the timeline = the handle's ridge stride
   const int N = prm.horizon_steps;
   CCC_DEVICE_GUARD(device);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -444,7 +440,7 @@ extern "C" int ccc_xy_closed_loop_device(ccc_xy_t * h, int64_t n, const ccc_cont
   if(int rc = buf.get(&u0, (size_t)n * kLoopM)) return rc;
   if(int rc = buf.get(&ref_now, (size_t)n * 6)) return rc;
   if(stats) CCC_HIP_CHECK(hipMemsetAsync(stats, 0, (size_t)n * 8 * sizeof(double), s));
-  const Timeline T = to_dev(tl);
+  const Timeline T = to_dev(tl, kLoopM);
   const double total_force_z = prm.mass * kLoopG; // MotionParam::total_force_z of the test (TestLinearMpcXY.cpp:33)
   double t = t0;
   int rc = CCC_OK;
@@ -462,6 +458,7 @@ extern "C" int ccc_xy_closed_loop_device(ccc_xy_t * h, int64_t n, const ccc_cont
     A.model = 2;
     A.N = N;
     A.P = 0;
+    A.M = kLoopM;
     A.phase_vertex = vertex;
     A.phase_ridge = ridge;
     A.step_phase = dim;
