@@ -349,17 +349,24 @@ struct Solver
   CCC_DDP_FN Solver(const Params & p, const Instance & i, Mem<S, M> & m) : P(p), I(i), mem(m) {}
 
 #if defined(CCC_DDP_WIDE)
+  // (phase indices and ridge counts are clamped to the tables: caller data cannot make the kernel read outside them)
+  CCC_DDP_FN int phase_of(int step) const
+  {
+    const int p = I.step_phase[step];
+    return p < 0 ? 0 : (p >= P.P ? P.P - 1 : p);
+  }
   CCC_DDP_FN int dim_of(int step) const
   {
-    return I.phase_dim[I.step_phase[step]];
+    const int d = I.phase_dim[phase_of(step)];
+    return d < 0 ? 0 : (d > M ? M : d);
   }
   CCC_DDP_FN const double * vert_of(int step) const
   {
-    return I.phase_vertex + static_cast<long>(I.step_phase[step]) * M * 3;
+    return I.phase_vertex + static_cast<long>(phase_of(step)) * M * 3;
   }
   CCC_DDP_FN const double * ridge_of(int step) const
   {
-    return I.phase_ridge + static_cast<long>(I.step_phase[step]) * M * 3;
+    return I.phase_ridge + static_cast<long>(phase_of(step)) * M * 3;
   }
 #else
   CCC_DDP_FN int dim_of(int step) const
@@ -385,8 +392,17 @@ struct Solver
         mem.pV[e] = I.phase_vertex[e];
         mem.pR[e] = I.phase_ridge[e];
       }
-      if(lane < P.P) mem.pdim[lane] = I.phase_dim[lane];
-      for(int e = lane; e < P.N; e += kWave) mem.sphase[e] = static_cast<unsigned char>(I.step_phase[e]);
+      // (phase indices and ridge counts are clamped to the tables: caller data cannot make the kernel read outside them)
+      if(lane < P.P)
+      {
+        const int d = I.phase_dim[lane];
+        mem.pdim[lane] = d < 0 ? 0 : (d > M ? M : d);
+      }
+      for(int e = lane; e < P.N; e += kWave)
+      {
+        const int p = I.step_phase[e];
+        mem.sphase[e] = static_cast<unsigned char>(p < 0 ? 0 : (p >= P.P ? P.P - 1 : p));
+      }
     });
 #endif
   }

@@ -262,11 +262,13 @@ struct Group
   };
   __device__ __forceinline__ void load_contact(int step, Contact & c) const
   {
-    const int ph = step_phase[step];
+    int ph = step_phase[step]; // (clamped to the tables, as in csrc/ddp_core.h)
+    ph = ph < 0 ? 0 : (ph >= P.P ? P.P - 1 : ph);
     if(ph != c.ph)
     {
       c.ph = ph;
-      c.m = phase_dim[ph];
+      const int d = phase_dim[ph];
+      c.m = d < 0 ? 0 : (d > G ? G : d);
       const long o = (static_cast<long>(ph) * G + l) * 3;
 #pragma unroll
       for(int a = 0; a < 3; a++)
