@@ -68,7 +68,7 @@ __global__ void sample_xy_kernel(Timeline T, long n, int N, double t, double dt,
   if(id >= n * N) return;
   const long k = id / N;
   const int s = segment_at(T, k, t + (int)(id % N) * dt + T.eps);
-  const int c = T.seg_contact[k * T.K + s];
+  const int c = min(max(T.seg_contact[k * T.K + s], 0), T.C - 1); // (clamped to the contact table)
   const int m = T.contact_dim[k * T.C + c];
   dim[id] = m;
   for(int e = 0; e < T.M * 3; e++)

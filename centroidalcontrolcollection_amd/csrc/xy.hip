@@ -280,11 +280,11 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
       sh.fz[i] = fz;
       sh.c2[i] = kap * P.dt;
       sh.c3[i] = kap * P.dt * P.dt / 2;
-      sh.dims[i] = B.dim[b * N + i];
+      sh.dims[i] = min(max(B.dim[b * N + i], 0), kXyM); // (clamped to the slots there are)
     }
     for(int e = i; e < N * 6; e += kXyNT) sh.ref[e / 6][e % 6] = B.ref_out[(size_t)b * N * 6 + e];
     if(i < 6) sh.x0[i] = B.x0[b * 6 + i];
-    const bool valid = s_i < N && r_i < B.dim[b * N + (s_i < N ? s_i : 0)];
+    const bool valid = s_i < N && r_i < min(max(B.dim[b * N + (s_i < N ? s_i : 0)], 0), kXyM);
     if(i < kXyNV)
     {
       double btv[NB];
