@@ -697,20 +697,45 @@ struct Solver
     const double lo = in ? mem.lo[i] : 0.0, hi = in ? mem.hi[i] : 0.0;
     double x = in ? fmin(fmax(mem.kq[i], lo), hi) : 0.0;
     bool cl = false;
+    // A vector held one entry per lane reaches all lanes either by a readlane pair per entry or -- at M = 32, where the
+    // 64 readlanes of every sum were what the iteration spent its time on -- through LDS: every lane publishes its
+    // entry (mem.t4, free until the value update), all read the vector back as 128-bit broadcasts.  The sums themselves
+    // run in the same order either way.
+    constexpr bool kVectorViaLds = (M == 32);
+    double * const vbuf = mem.t4;
+    auto everywhere = [&](double v, double (&out)[M]) {
+      if constexpr(kVectorViaLds)
+      {
+        if(lane < M) vbuf[i] = v;
+        __builtin_amdgcn_wave_barrier();
+#  pragma unroll
+        for(int k = 0; k < M; ++k) out[k] = vbuf[k];
+        __builtin_amdgcn_wave_barrier();
+      }
+      else
+      {
+#  pragma unroll
+        for(int k = 0; k < M; ++k) out[k] = lane_value(v, k);
+      }
+    };
     // sum_{k<m} t_k in increasing k, starting from 0 (the oracle's loops)
     auto seq_sum = [&](double t) {
+      double tv[M];
+      everywhere(t, tv);
       double v = 0;
 #  pragma unroll
       for(int k = 0; k < M; ++k)
-        if(k < m) v += lane_value(t, k);
+        if(k < m) v += tv[k];
       return v;
     };
     // s0 + sum_{j<m} H[i][j] y_j in increasing j
     auto row_dot = [&](double s0, double y) {
+      double yv[M];
+      everywhere(y, yv);
       double s = s0;
 #  pragma unroll
       for(int j = 0; j < M; ++j)
-        if(j < m) s += Hr[j] * lane_value(y, j);
+        if(j < m) s += Hr[j] * yv[j];
       return s;
     };
     auto value_of = [&](double y) {
@@ -762,7 +787,7 @@ struct Solver
       }
       double gn = 0;
       {
-        const double g2 = grad * grad;
+        const double g2 = grad * grad; // (sums over a subset of the rows: readlanes for those only, also at M = 32)
 #  pragma unroll
         for(int k = 0; k < M; ++k)
           if(k < m && !((clmask >> k) & 1ull)) gn += lane_value(g2, k);
