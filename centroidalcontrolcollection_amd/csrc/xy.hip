@@ -830,15 +830,19 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   int it = 0;
   constexpr bool single = SINGLE;
   bool converged = false, cycling = false, gaveup = false;
-  // single-change rounds: one change PER STAGE and sweep (the most violated condition of each stage) until the set
-  // returns to where it was two sweeps ago, from then on (strict) one change per sweep (the most violated of all)
+  // single-change rounds: up to TWO changes PER STAGE and sweep (the two most violated conditions of each stage) until
+  // the set returns to where it was two sweeps ago, from then on (strict) one change per sweep (the most violated of
+  // all).  (Prototype, 600 instances of the bench data, 36 of them cycling, this fallback: one per stage 67 sweeps on
+  // average / 91 at most, two per stage 45 / 59, three per stage no longer converges on all.)
   bool strict = false;
-  // one variable of stage s changes sides (and, with it, `forced` is released: see below); the sums of the stage are rebuilt
-  auto apply_change = [&](int s, int r, unsigned ns, int forced) -> Bits {
+  // variable r (and r2, if >= 0) of stage s change sides (and, with them, `forced` is released: see below); the sums of
+  // the stage are rebuilt
+  auto apply_change = [&](int s, int r, unsigned ns, int r2, unsigned ns2, int forced) -> Bits {
     const int m = (int)WS(s, kXsDim);
     Bits bits = (Bits)(unsigned)WS(s, kXsSt);
     if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
     bits = (bits & ~(Bits(3) << (2 * r))) | ((Bits)ns << (2 * r));
+    if(r2 >= 0) bits = (bits & ~(Bits(3) << (2 * r2))) | ((Bits)ns2 << (2 * r2));
     if(forced >= 0) bits &= ~(Bits(3) << (2 * forced));
     double nS[21], nt[6], nc[6], nal = 0.0, ndp = WS(s, kXsFz);
 #pragma unroll
@@ -867,7 +871,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
     return bits;
   };
-  unsigned long long h1 = 0, h2 = 0; // hashes of the clamped sets of the last two iterations
+  unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0; // hashes of the clamped sets of the last iterations
   for(it = it_begin; it < max_it && !converged && !cycling && !gaveup; it++)
   {
     // ---- backward recursion on the current clamped set
@@ -1104,9 +1108,9 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         double rel_lo_m = kXyInf, rel_hi_m = -kXyInf;
         int rel_lo_i = -1, rel_hi_i = -1;
         bool cand_here = false;
-        double sc_v = 0.0; // the stage's own most violated condition
-        int sc_r = 0;
-        unsigned sc_ns = 0u;
+        double sc_v = 0.0, sc_v2 = 0.0; // the stage's own two most violated conditions
+        int sc_r = 0, sc_r2 = -1;
+        unsigned sc_ns = 0u, sc_ns2 = 0u;
         if(single) // (free variables of the stage: clamping the only one is a move only if another can be released)
           for(int r = 0; r < m; r++) nfree += ((bits >> (2 * r)) & 3ull) == 0ull ? 1 : 0;
         const bool may_clamp = nfree > 1 || m > nfree;
@@ -1169,11 +1173,23 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
                 rel_hi_i = r;
               }
             }
-            if(single && !emit && viol > sc_v)
+            if(single && !emit && viol > sc_v2)
             {
-              sc_v = viol;
-              sc_r = r;
-              sc_ns = ns;
+              if(viol > sc_v)
+              {
+                sc_v2 = sc_v;
+                sc_r2 = sc_v > 0.0 ? sc_r : -1;
+                sc_ns2 = sc_ns;
+                sc_v = viol;
+                sc_r = r;
+                sc_ns = ns;
+              }
+              else
+              {
+                sc_v2 = viol;
+                sc_r2 = r;
+                sc_ns2 = ns;
+              }
             }
             if(single && !emit && viol > cand_v)
             {
@@ -1203,16 +1219,21 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
           // clamping the stage's only free variable: the stage equality needs one, so a clamped variable is released
           // with it -- one that can move the right way: the free variable ran into its UPPER bound, the stage needs more
           // force from a variable at its lower bound (the one whose multiplier asks for it most), and vice versa
-          auto partner = [&](unsigned ns) -> int {
-            if(ns == 0u || nfree > 1) return -1;
+          auto partner = [&](unsigned ns, int free_left) -> int {
+            if(ns == 0u || free_left > 0) return -1;
             const int want = ns == 2u ? rel_lo_i : rel_hi_i, other = ns == 2u ? rel_hi_i : rel_lo_i;
             return want >= 0 ? want : other;
           };
-          if(cand_here) cand_forced = partner(cand_ns);
+          if(cand_here) cand_forced = partner(cand_ns, nfree - 1);
           Bits now = bits;
           if(!strict && sc_v > 0.0)
           {
-            now = apply_change(s, sc_r, sc_ns, partner(sc_ns));
+            // free variables the stage keeps after the one or two moves (a clamp takes one away, a release adds one)
+            int left = nfree + (sc_ns == 0u ? 1 : -1);
+            if(sc_r2 >= 0) left += sc_ns2 == 0u ? 1 : -1;
+            int forced_i = partner(sc_ns != 0u ? sc_ns : sc_ns2, left);
+            if(forced_i == sc_r || forced_i == sc_r2) forced_i = -1; // (one of the moves is that release already)
+            now = apply_change(s, sc_r, sc_ns, sc_r2, sc_ns2, forced_i);
             changed = true;
           }
           hh = (hh ^ now) * 1099511628211ull;
@@ -1269,10 +1290,14 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       {
         converged = cand_s < 0;
         gaveup = !converged && last_chance;
-        if(!converged && !gaveup && strict) apply_change(cand_s, cand_r, cand_ns, cand_forced);
+        if(!converged && !gaveup && strict) apply_change(cand_s, cand_r, cand_ns, -1, 0u, cand_forced);
         if(!strict)
         {
-          strict = !converged && hh == h2; // the per-stage changes brought the set of two sweeps ago back
+          // the per-stage changes brought back a set of two, three or four sweeps ago, or have used up their share of
+          // the budget (the prototype's worst case was 59 sweeps): one change per sweep from here on
+          strict = !converged && (hh == h2 || hh == h3 || hh == h4 || it - it_begin >= 96);
+          h4 = h3;
+          h3 = h2;
           h2 = h1;
           h1 = hh;
         }
