@@ -39,6 +39,8 @@
 // after the other, for either table layout.
 #if defined(CCC_DDP_WIDE)
 #  define CCC_DDP_NS ddp_wide
+#elif defined(CCC_DDP_LEAN) && defined(CCC_DDP_STORE_FLOAT)
+#  define CCC_DDP_NS ddp_lean32
 #elif defined(CCC_DDP_LEAN)
 #  define CCC_DDP_NS ddp_lean
 #else
@@ -142,6 +144,33 @@ namespace CCC_DDP_NS
 using ddp_common::Instance;
 using ddp_common::Params;
 
+// Storage type of the backward pass's matrices in LDS.  double everywhere, except in the build with
+// CCC_DDP_STORE_FLOAT (csrc/ddp_lean32.hip: ccc_ddp_config_t::precision = 32, BASELINE configs[4] "fp32 with fp64 tolerance
+// check"): single-precision STORAGE, double arithmetic -- every read widens, every write rounds once.  (The host pass of
+// that translation unit, which only parses the kernel, keeps double.)
+#if defined(CCC_DDP_STORE_FLOAT) && defined(__HIP_DEVICE_COMPILE__)
+struct St
+{
+  float v;
+  CCC_DDP_FN St & operator=(double x)
+  {
+    v = static_cast<float>(x);
+    return *this;
+  }
+  CCC_DDP_FN operator double() const
+  {
+    return static_cast<double>(v);
+  }
+  CCC_DDP_FN St & operator*=(double x)
+  {
+    v = static_cast<float>(static_cast<double>(v) * x);
+    return *this;
+  }
+};
+#else
+using St = double;
+#endif
+
 // profiler sections
 enum
 {
@@ -188,12 +217,12 @@ template<int S, int M>
 struct Mem
 {
   static constexpr int LQ = row_stride<M>();
-  double Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
-  double Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Quu[M * LQ];
+  St Vxx[S * S], Vx[S], Fx[S * S], Fu[S * M];
+  St Qx[S], Qu[M], Qxx[S * S], Qxu[S * M], Quu[M * LQ];
 #if !CCC_DDP_REG1_ONLY
-  double Qxur[S * M], QuuF[M * LQ];
+  St Qxur[S * M], QuuF[M * LQ];
 #endif
-  double T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
+  St T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
   double k[M], kq[M], lo[M], hi[M];
   alignas(16) double t4[M]; // (also the column buffer of the device factorisation: read back as 128-bit broadcasts)
 #if !CCC_DDP_FAST
@@ -813,7 +842,18 @@ struct Solver
       const double sdotg = seq_sum(srch * grad);
       CCC_PROF_ADD(PR_BOXQP_SOLVE);
       double step = 1.0;
+#if defined(CCC_DDP_STORE_FLOAT)
+      // With single-precision storage the Newton step of an iterate that is optimal TO THAT RESOLUTION is rounding noise,
+      // its sign against the gradient a coin toss: "no descent direction" then means converged (csrc/ddp_group.h has
+      // the same rule and the measurements behind it)
+      if(sdotg >= 0)
+      {
+        result = 5;
+        break;
+      }
+#else
       if(sdotg >= 0) break; // no descent direction: result stays 0
+#endif
       double xc, vc;
       for(;;)
       {
@@ -846,8 +886,8 @@ struct Solver
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
-    const double * H = mem.QuuF;
-    const double * g = mem.Qu;
+    const St * H = mem.QuuF;
+    const St * g = mem.Qu;
     phase([&](int lane) {
       if(lane < m)
       {
@@ -1022,7 +1062,7 @@ struct Solver
     // Phase version, right-looking, lane = row: per column j one phase scales the column below the pivot, the next
     // writes the pivot and subtracts the column's outer product from row i (entries k = j+1 .. i).  Every entry
     // (i, k) thus has its products subtracted in increasing j, as the oracle does.
-    const double * H = mem.QuuF;
+    const St * H = mem.QuuF;
     phase([&](int lane) {
       if(lane < m)
         for(int k = 0; k <= lane; k++)
@@ -1250,9 +1290,9 @@ struct Solver
         const int a = lane;
         double t3[M];
 #if CCC_DDP_REG1_ONLY
-        const double * const Qxur = mem.Qxu;
+        const St * const Qxur = mem.Qxu;
 #else
-        const double * const Qxur = P.reg_type == 2 ? mem.Qxur : mem.Qxu; // (reg_type 1: the same matrix)
+        const St * const Qxur = P.reg_type == 2 ? mem.Qxur : mem.Qxu; // (reg_type 1: the same matrix)
 #endif
 #  pragma unroll
         for(int f = 0; f < M; f++) t3[f] = (f < m && !mem.clamped[f]) ? Qxur[a * M + f] : 0.0;
@@ -1305,7 +1345,7 @@ struct Solver
       if(lane < S)
       {
         const int a = lane;
-        double * t3 = mem.T2 + a * M;
+        St * t3 = mem.T2 + a * M;
         for(int f = 0; f < m; f++) t3[f] = mem.clamped[f] ? 0.0 : mem.Qxur[a * M + f];
         solve_free_seq(m, t3);
         for(int f = 0; f < m; f++) mem.K[f * S + a] = mem.clamped[f] ? 0.0 : -t3[f];
@@ -1326,14 +1366,14 @@ struct Solver
   //   DIAG 0: none, 1: w_run[a] on a == c, 2: w_force on a == c, 3: as 2 and lam added to the diagonal after the sum.
   //   C2 (optional): a second copy of C with lam added to the diagonal after the sum (Quu and Quu + lambda I at once).
   template<bool TRANS, int DIAG, bool LAM>
-  CCC_DDP_FN void colprod(int lane, int rows, int ncols, const double * A, int lda, const double * B, int ldb, double lam,
-                          double * C, int ldc, double * C2 = nullptr) const
+  CCC_DDP_FN void colprod(int lane, int rows, int ncols, const St * A, int lda, const St * B, int ldb, double lam,
+                          St * C, int ldc, St * C2 = nullptr) const
   {
     const int c = lane & (M - 1), g = lane / M;
     const bool act = c < ncols;
     double Bc[S];
 #  pragma unroll
-    for(int k = 0; k < S; k++) Bc[k] = act ? B[k * ldb + c] : 0.0;
+    for(int k = 0; k < S; k++) Bc[k] = act ? static_cast<double>(B[k * ldb + c]) : 0.0;
     for(int a = g; a < rows; a += kWave / M)
     {
       double sum = 0.0;
@@ -1342,7 +1382,7 @@ struct Solver
 #  pragma unroll
       for(int k = 0; k < S; k++)
       {
-        double av = TRANS ? A[k * lda + a] : A[a * lda + k];
+        double av = TRANS ? static_cast<double>(A[k * lda + a]) : static_cast<double>(A[a * lda + k]);
         if(LAM) av = av + (a == k ? lam : 0.0);
         sum += av * Bc[k];
       }
@@ -1444,7 +1484,7 @@ struct Solver
         }
         // T1 = Vxx Fx ; T2 = Vxx Fu ; regularised T2r = (Vxx + lambda I) Fu, parked in mem.Lf (free until the box-QP
         // factorises) so that everything built from T1 / T2 / T2r fits one more phase
-        double * const T2r = mem.Lf;
+        St * const T2r = mem.Lf;
 #if CCC_DDP_FAST
         colprod<false, 0, false>(lane, S, S, mem.Vxx, S, mem.Fx, S, 0.0, mem.T1, S);
         colprod<false, 0, false>(lane, S, m, mem.Vxx, S, mem.Fu, M, 0.0, mem.T2, M);
@@ -1509,7 +1549,7 @@ struct Solver
         }
 #endif
         // regularised versions from T2r
-        const double * const T2r = mem.Lf;
+        const St * const T2r = mem.Lf;
 #if CCC_DDP_REG1_ONLY
         (void)T2r;
 #elif CCC_DDP_FAST
@@ -1650,7 +1690,8 @@ struct Solver
     // per-step staging of the products whose ordered sums the dynamics and the cost need: rows 0-2 u_r rho_r,
     // 3-5 u_r (p_r - c) x rho_r, 6 u_r^2 (columns = ridges), row 7 the state-cost terms.  The block of backward-pass
     // matrices Qxx .. of Mem is idle during a rollout.
-    double * const pr = mem.Qxx;
+    static_assert(sizeof(St) == sizeof(double), "the one-phase rollout stages doubles in Qxx");
+    double * const pr = reinterpret_cast<double *>(mem.Qxx);
     static_assert(8 * M <= 2 * S * S + 3 * S * M, "staging area too small");
     // operands of step 0 (the next step's are fetched from HBM while the current one computes)
     double us_c = 0.0, ks_c = 0.0, Kr_c[S], xi_c[S], ref_c = 0.0;

@@ -172,9 +172,10 @@ typedef struct
   double alpha_list[11];
   int reg_type; /* 1: Quu_F + lambda I (default; iLQG regType 1), 2: Vxx + lambda I */
   int precision; /* 64 (default): everything in double, bit-identical to the oracle.  32 (BASELINE configs[4], "fp32
-                  * with fp64 tolerance check"): the BACKWARD pass of every DDP iteration -- products, box-QP, Cholesky,
-                  * gains, value function -- in single precision; trajectories, rollouts, costs and all line-search and
-                  * termination decisions stay in double.  Not a nmpc_ddp option. */
+                  * with fp64 tolerance check"): the matrices of the BACKWARD pass of every DDP iteration -- value function,
+                  * derivatives, Q blocks, Cholesky factor, gains -- STORED in single precision, operated on in double;
+                  * trajectories, rollouts, costs and all line-search and termination decisions stay in double.
+                  * Not a nmpc_ddp option. */
 } ccc_ddp_config_t;
 
 void ccc_ddp_default_config(ccc_ddp_config_t * cfg);
