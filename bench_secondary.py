@@ -142,7 +142,7 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                 + S * 8 + N * M * 8,
                 kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
                 ((("ddp_lean_kernel<%d,16>" if srb else "ddp_plan_kernel<%d,16>") % S) if precision == 64
-                 else ("ddp_group_kernel<%d,float>" % S)), cpu=cpu,
+                 else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
                 keep=(d, tp, tx0))
 
 
@@ -243,9 +243,9 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, xywalk=32768)
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, xywalk=32768, ddp32=4096)
 DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
-                     walk=(3, 1), xywalk=(3, 1))
+                     walk=(3, 1), xywalk=(3, 1), ddp32=(3, 1))
 
 
 def run(args, rank, world, local_rank, dist):
@@ -253,7 +253,7 @@ def run(args, rank, world, local_rank, dist):
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
-                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True))
+                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True), ddp32=lambda a, b, c: _ddp(a, b, c, False, 32))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)

@@ -11,9 +11,10 @@
 //   lean   ddp_lean_kernel (csrc/ddp_lean.hip)            the same sizes compiled for reg_type 1 (the default) only: what a
 //                                                         DdpSingleRigidBody handle runs (less LDS, more wavefronts)
 //   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
-//   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32 for
-//                                                         DdpSingleRigidBody (BASELINE configs[4])
-//   group  ddp_group_kernel (csrc/ddp_group.h)             four instances per wavefront; precision 32 for DdpCentroidal
+//   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32
+//                                                         (BASELINE configs[4])
+//   group  ddp_group_kernel (csrc/ddp_group.h)             four instances per wavefront (development switch
+//                                                         CCC_DDP_GROUP; measured slower)
 #include "common.h"
 #include "ddp_batch.h"
 #include "ddp_core.h"
@@ -255,10 +256,11 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->wide && h->cfg.reg_type != 1)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: the wide kernel (max_ridges = %d, max_phases > %d or "
                 "horizon_steps > %d) is built for reg_type 1", CCC_DDP_MAX_RIDGES_WIDE, ddp::kMaxPhases, ddp::kMaxSteps);
-  // precision 32: the single-rigid-body model (BASELINE configs[4]) on the lean build with single-precision storage
-  // (csrc/ddp_lean32.hip), the centroidal model on the group kernel, where the mode was first built
-  const bool lean32 = !h->wide && h->cfg.reg_type == 1 && h->cfg.precision == 32 && h->S == 12
-                      && std::getenv("CCC_DDP_GROUP") == nullptr;
+  // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip: 48.2 k / 14.7 k
+  // solves/s for the single-rigid-body / centroidal model; the group kernel, where the mode was first built, 25.9 k /
+  // 7.6 k -- CCC_DDP_GROUP, a development switch, still selects it)
+  const bool lean32 =
+      !h->wide && h->cfg.reg_type == 1 && h->cfg.precision == 32 && std::getenv("CCC_DDP_GROUP") == nullptr;
   const bool group = !h->wide && !lean32 && h->cfg.reg_type == 1
                      && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
   int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
@@ -349,7 +351,7 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   // (CCC_DDP_LEAN / CCC_DDP_FULL, development switches, force either)
   if(lean32)
   {
-    CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, s));
+    CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, h->S, s));
     return CCC_OK;
   }
   const bool lean = h->cfg.reg_type == 1 && !std::getenv("CCC_DDP_FULL") && (h->S == 12 || std::getenv("CCC_DDP_LEAN"));

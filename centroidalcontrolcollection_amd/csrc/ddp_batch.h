@@ -37,6 +37,6 @@ hipError_t launch_ddp_wide(const ddp_common::Params & P, const DdpBatch & B, lon
 // csrc/ddp_lean.hip: the fast build's sizes (M = 16, tables in LDS) compiled for reg_type 1 only.
 hipError_t launch_ddp_lean(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 
-// csrc/ddp_lean32.hip: the lean build with single-precision storage of the backward pass (precision = 32), S = 12.
-hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, hipStream_t stream);
+// csrc/ddp_lean32.hip: the lean build with single-precision storage of the backward pass (precision = 32).
+hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 } // namespace ccc_amd

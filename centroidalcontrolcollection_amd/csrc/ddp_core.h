@@ -223,6 +223,9 @@ struct Mem
   St Qxur[S * M], QuuF[M * LQ];
 #endif
   St T1[S * S], T2[S * M], Lf[M * LQ], K[M * S];
+#if defined(CCC_DDP_STORE_FLOAT)
+  double stage[8 * M]; // staging of the one-phase centroidal rollout (doubles; the other builds borrow Qxx ..)
+#endif
   double k[M], kq[M], lo[M], hi[M];
   alignas(16) double t4[M]; // (also the column buffer of the device factorisation: read back as 128-bit broadcasts)
 #if !CCC_DDP_FAST
@@ -1690,8 +1693,11 @@ struct Solver
     // per-step staging of the products whose ordered sums the dynamics and the cost need: rows 0-2 u_r rho_r,
     // 3-5 u_r (p_r - c) x rho_r, 6 u_r^2 (columns = ridges), row 7 the state-cost terms.  The block of backward-pass
     // matrices Qxx .. of Mem is idle during a rollout.
-    static_assert(sizeof(St) == sizeof(double), "the one-phase rollout stages doubles in Qxx");
-    double * const pr = reinterpret_cast<double *>(mem.Qxx);
+#if defined(CCC_DDP_STORE_FLOAT)
+    double * const pr = mem.stage; // (the backward-pass block is single precision in this build)
+#else
+    double * const pr = mem.Qxx;
+#endif
     static_assert(8 * M <= 2 * S * S + 3 * S * M, "staging area too small");
     // operands of step 0 (the next step's are fetched from HBM while the current one computes)
     double us_c = 0.0, ks_c = 0.0, Kr_c[S], xi_c[S], ref_c = 0.0;

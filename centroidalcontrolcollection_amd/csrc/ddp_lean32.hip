@@ -1,9 +1,8 @@
-// ddp_lean32.hip -- ccc_ddp_config_t::precision = 32 for CCC::DdpSingleRigidBody (BASELINE configs[4]: "12-state SRB ...
-// fp32 with fp64 tolerance check"): the lean build of csrc/ddp_lean.hip with the backward pass's matrices STORED in single
+// ddp_lean32.hip -- ccc_ddp_config_t::precision = 32 (BASELINE configs[4]: "DdpSingleRigidBody 12-state SRB ... fp32 with
+// fp64 tolerance check"; the centroidal model takes the mode as well): the lean build of csrc/ddp_lean.hip with the backward pass's matrices STORED in single
 // precision in LDS (value function, derivatives, Q blocks, Cholesky factor, gains) and every operation on them in
 // double -- reads widen, writes round once.  Trajectories, rollouts, costs, the box-QP iterate and every line-search /
-// termination decision stay in double, as in the mode's first implementation (csrc/ddp_group.h, which keeps serving the
-// centroidal model).  12.6 KB of LDS per wavefront instead of 20.3.  Not a nmpc_ddp option; results are compared with
+// termination decision stay in double, as in the mode's first implementation (csrc/ddp_group.h, now a development switch).  12.6 KB of LDS per wavefront instead of 20.3.  Not a nmpc_ddp option; results are compared with
 // the fp64 oracle through a tolerance (tests/test_ddp_gpu.py::test_srb_fp32_storage_against_fp64_oracle_config5).
 #define CCC_DDP_LEAN 1
 #define CCC_DDP_STORE_FLOAT 1
@@ -45,10 +44,13 @@ __global__ __launch_bounds__(64, 2) void ddp_lean32_kernel(ddp_common::Params P,
   }
 }
 
-hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, hipStream_t stream)
+hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream)
 {
   const int grid = (int)(n < (1L << 22) ? n : (1L << 22)); // one workgroup per instance: the dispatcher balances
-  hipLaunchKernelGGL((ddp_lean32_kernel<12, 16>), dim3(grid), dim3(64), 0, stream, P, B, n);
+  if(S == 9)
+    hipLaunchKernelGGL((ddp_lean32_kernel<9, 16>), dim3(grid), dim3(64), 0, stream, P, B, n);
+  else
+    hipLaunchKernelGGL((ddp_lean32_kernel<12, 16>), dim3(grid), dim3(64), 0, stream, P, B, n);
   return hipGetLastError();
 }
 } // namespace ccc_amd
