@@ -392,3 +392,15 @@ def test_xy_limits_are_reported():
     with pytest.raises(_lib.CccError) as e:
         LinearMpcXY(100.0, 0.1, 257)
     assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n", [1, 63, 65])
+def test_wide_configuration_ragged_batches(n):
+    """32 ridge slots: batches that do not fill a wavefront, and one that spills into a second (the stage-recursion
+    kernel is the only path here, whatever the batch size)."""
+    prob, x0 = fd.make_xy_walking_batch(65, 22, 0.1, M=32, seed=11)
+    mpc = LinearMpcXY(100.0, 0.1, 22, max_ridges=32)
+    full = mpc.planOnceBatch(prob, x0, want_all=True)
+    part = mpc.planOnceBatch({k: v[:n] for k, v in prob.items()}, x0[:n], want_all=True)
+    assert np.all(part["status"] == 0)
+    assert np.array_equal(part["u0"], full["u0"][:n]) and np.array_equal(part["lam"], full["lam"][:n])
