@@ -6,7 +6,7 @@
 // feedback gains K (N x 16 x S doubles = 115 KB at N = 100) live in an HBM workspace owned by the handle, laid out
 // per instance so that a wavefront streams through contiguous memory.
 //
-// Three kernels behind one entry (dispatch in ccc_ddp_plan_batch_device):
+// The builds of csrc/ddp_core.h behind one entry (dispatch in ccc_ddp_plan_batch_device):
 //   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps
 //   lean   ddp_lean_kernel (csrc/ddp_lean.hip)            the same sizes compiled for reg_type 1 (the default) only: what a
 //                                                         DdpSingleRigidBody handle runs (less LDS, more wavefronts)

@@ -7,10 +7,13 @@
 //     iterate an arbitrary contact_list; two surface contacts (double support) are 2 x 4 vertices x 4 ridges = 32;
 //   - more than four distinct contact lists fall into one horizon (up to one per step), or the horizon is longer than
 //     the 128 steps the fast kernel's LDS tables hold.
-// One instance per wavefront; the per-step matrices (Quu, its regularised copy and the Cholesky factor are 32 x 33
-// doubles each) take 50 KB of LDS, so three wavefronts share a CU; the contact tables and step -> phase map are read
-// from global memory (L2-resident: 26 KB per instance at 10 phases).  The arithmetic -- statement by statement the phase
-// versions the CPU test-suite runs through tests/emu -- is the oracle's, bit for bit.
+// One instance per wavefront.  Compiled for the default regularisation only (reg_type 1: Quu_F = Quu + lambda I and
+// Qxu_r = Qxu are formed on the fly, not stored), the per-step matrices take 31.8 KB (centroidal) / 37.0 KB (single rigid
+// body) of LDS at M = 32 -- Quu and the Cholesky factor are 32 x 33 doubles each -- so five / four wavefronts share a CU;
+// the contact tables and the step -> phase map are read from global memory (L2-resident: 26 KB per instance at 10
+// phases).  The code is csrc/ddp_core.h's register-resident device path with M lanes per row; its plain phase versions,
+// which the CPU test-suite runs through tests/emu for this table layout as well, and the device path both reproduce
+// the oracle bit for bit.
 #define CCC_DDP_WIDE 1
 #include "ddp_core.h"
 

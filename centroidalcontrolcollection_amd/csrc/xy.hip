@@ -8,7 +8,11 @@
 //   src/LinearMpcXY.cpp:116-182    procOnce: H = B'WB + w I, g = -B'W(ref - A x0), one equality row per contact step,
 //                                  bounds [3, 3 m g], the external QP solve (:181), head(m0)
 //
-// One problem instance per 320-thread workgroup (5 wavefronts), thread i = variable (step i/16, ridge i%16); nothing
+// Two kernels.  The default (large batches, and every problem beyond 20 steps x 16 ridges) is the STAGE-RECURSION kernel
+// further down: a primal-dual active set, one instance per lane, 16 or 32 ridge slots per step, any horizon length, with
+// single-change safeguard rounds.  First in this file, its fallback for <= 20 steps x 16 ridges and the path of small
+// batches, the DUAL ACTIVE-SET kernel:
+// One problem instance per 448-thread workgroup (7 wavefronts), thread i < 320 = variable (step i/16, ridge i%16); nothing
 // but the inputs and outputs touches HBM.  The QP is solved by the Goldfarb-Idnani dual active-set iteration of the
 // oracle (most violated bound enters, blocking multipliers leave), but in "stage space":
 //   column i of B_seq is the response of the N six-dimensional states to the impulse b_i = Bd_s[:, r] applied at step
