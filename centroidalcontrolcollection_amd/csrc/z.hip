@@ -347,7 +347,10 @@ struct ZWork
   int * redo_count;   // [1]
 };
 
-__global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B, ZWork W, long n, int max_newton)
+// emit_unfinished: horizons beyond the tableau kernel's 64 steps have no second kernel to hand over to: an instance that
+// uses up the (then much larger) budget writes the iterate it has, flagged CCC_STATUS_MAX_ITER.
+__global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B, ZWork W, long n, int max_newton,
+                                                           int emit_unfinished)
 {
   const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if(b >= n) return;
@@ -360,17 +363,9 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
   const double dt = P.dt, im = 1.0 / P.mass;
   const double B0 = 0.5 * dt * dt * im, B1 = dt * im;    // B
   const double e0 = -kZG * (0.5 * dt * dt), e1 = -kZG * dt; // e
-  unsigned long long cmask = 0;
-  for(int jc = 0; jc < N; jc += 8) // (eight strided loads in flight)
-  {
-    int cc[8];
-#pragma unroll
-    for(int u = 0; u < 8; u++) cc[u] = jc + u < N ? B.contact[b * N + jc + u] : 0;
-#pragma unroll
-    for(int u = 0; u < 8; u++)
-      if(cc[u] != 0) cmask |= 1ull << (jc + u);
-  }
-  if(!(cmask & 1ull)) // src/LinearMpcZ.cpp:54-57
+  // (the contact flag of a step lives in bit 1 of its flag byte in the workspace, beside the free flag in bit 0: any
+  //  horizon length)
+  if(B.contact[b * N] == 0) // src/LinearMpcZ.cpp:54-57
   {
     B.force[b] = 0.0;
     if(B.status) B.status[b] = CCC_STATUS_SOLVED;
@@ -386,15 +381,21 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
   for(int jc = 0; jc < N; jc += 8)
   {
     double rr[8];
+    int cc[8];
 #pragma unroll
-    for(int u = 0; u < 8; u++) rr[u] = jc + u < N ? B.ref[b * N + jc + u] : 0.0;
+    for(int u = 0; u < 8; u++) // (eight strided loads of each in flight)
+    {
+      rr[u] = jc + u < N ? B.ref[b * N + jc + u] : 0.0;
+      cc[u] = jc + u < N ? B.contact[b * N + jc + u] : 0;
+    }
 #pragma unroll
     for(int u = 0; u < 8; u++)
     {
       const int j = jc + u;
       if(j >= N) break;
       WZ(j, 5) = rr[u];
-      const double f = ((cmask >> j) & 1ull) ? fstart : 0.0;
+      WF(j) = cc[u] != 0 ? 2 : 0;
+      const double f = cc[u] != 0 ? fstart : 0.0;
       WZ(j, cur) = f;
       const double zn = zN + dt * vN + B0 * f + e0;
       vN = vN + B1 * f + e1;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         const int j = jc - u;
         rr[u] = j >= 0 ? WZ(j, 5) : 0.0;
         ff[u] = j >= 0 ? WZ(j, cur) : 0.0;
-        of[u] = (j >= 0 && it > 0) ? WF(j) : 0;
+        of[u] = j >= 0 ? WF(j) : 0;
       }
 #pragma unroll
       for(int u = 0; u < 8; u++)
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         const int j = jc - u;
         if(j < 0) break;
         const double rj = rr[u];
-        const bool ct = (cmask >> j) & 1ull;
+        const bool ct = (of[u] & 2) != 0;
         const double f = ff[u];
       l0 += P.w_pos * (z - rj);
       const double T00 = P00 + P.w_pos, T01 = P01, T11 = P11; // P~ = P + w_pos e1 e1'
@@ -442,8 +443,8 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
       {
         const double grad = P.w_force * f + (B0 * l0 + B1 * l1);
         fr = !((f <= P.fmin && grad > 0.0) || (f >= P.fmax && grad < 0.0));
-        if(it > 0 && (of[u] != 0) != fr) changed = true;
-        WF(j) = fr ? 1 : 0;
+        if(it > 0 && ((of[u] & 1) != 0) != fr) changed = true;
+        WF(j) = fr ? 3 : 2;
       }
       // P~ A, A'P~A  (A = [[1, dt], [0, 1]])
       const double M00 = T00, M01 = T00 * dt + T01, M11 = T01 * dt + T11; // P~ A (M10 = T01)
@@ -525,9 +526,9 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
           if(j >= N) break;
           const double f = ff[u];
           double fn = f, fp = f;
-          if((cmask >> j) & 1ull)
+          if(fl[u] & 2)
           {
-            if(fl[u]) fn = g0[u] * zn_ + g1[u] * vn_ + g2[u];
+            if(fl[u] & 1) fn = g0[u] * zn_ + g1[u] * vn_ + g2[u];
             fp = fmin(fmax(f + alpha * (fn - f), P.fmin), P.fmax);
           }
           WZ(j, cur ^ 1) = fp;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
     }
     if(out_of_budget) break;
   }
-  if(st != CCC_STATUS_SOLVED)
+  if(st != CCC_STATUS_SOLVED && !emit_unfinished)
   {
     const int q = atomicAdd(W.redo_count, 1);
     W.redo_list[q] = (int)b;
@@ -590,9 +591,9 @@ extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, d
   if(!(mass > 0) || !(horizon_dt > 0) || horizon_steps <= 0 || !(w_pos >= 0) || !(w_force > 0))
     return fail(CCC_ERR_INVALID_ARGUMENT,
                 "ccc_z_create: mass, horizon_dt, horizon_steps, w_force must be > 0 and w_pos >= 0");
-  if(horizon_steps > kZNP)
+  if(horizon_steps > CCC_Z_MAX_STEPS_WIDE)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_z_create: horizon_steps %d > %d is not built into this library",
-                horizon_steps, kZNP);
+                horizon_steps, CCC_Z_MAX_STEPS_WIDE);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   CCC_DEVICE_GUARD(device);
@@ -658,15 +659,19 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   // full; below ~24 k instances at N = 40 the LDS-tableau kernel, one wavefront per instance, is faster (measured 0.05
   // against 0.31 ms at 512, 0.17 / 0.36 at 8192, 0.41 / 0.45 at 24576, 0.53 / 0.45 at 32768); its cost per instance grows
   // faster with N than the floor does, hence n N.  CCC_Z_TABLEAU / CCC_Z_STREAM force either path (development switches)
-  const bool tableau_only = std::getenv("CCC_Z_TABLEAU") != nullptr ||
-                            (n * (int64_t)h->N < (int64_t)24576 * 40 && !std::getenv("CCC_Z_STREAM") && !std::getenv("CCC_Z_SWEEPS"));
+  // beyond the 64 steps of the tableau kernel: the streaming kernel alone, whatever the batch size, with a budget that
+  // is a bound on the projected-Newton iteration (a descent method on a convex QP: it converges), not a hand-over point
+  const bool wide = h->N > kZNP;
+  const bool tableau_only = !wide && (std::getenv("CCC_Z_TABLEAU") != nullptr ||
+                            (n * (int64_t)h->N < (int64_t)24576 * 40 && !std::getenv("CCC_Z_STREAM") && !std::getenv("CCC_Z_SWEEPS")));
   if(!tableau_only)
   {
     if(int zrc = zero_words(W.redo_count, 1, s)) return zrc;
     const char * mi = std::getenv("CCC_Z_SWEEPS"); // (development switch: the sweep budget; small values exercise the fallback)
     hipLaunchKernelGGL(z_plan_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, B, W, (long)n,
-                       mi ? std::atoi(mi) : kZMaxSweeps);
+                       wide ? 40 * kZMaxSweeps : (mi ? std::atoi(mi) : kZMaxSweeps), wide ? 1 : 0);
     CCC_HIP_CHECK(hipGetLastError());
+    if(wide) return CCC_OK;
   }
   // the LDS-tableau kernel: works off the (normally empty) list of instances the streaming kernel gave up on
   const int grid = tableau_only ? (int)std::min<int64_t>(n, (int64_t)1 << 22) : (int)std::min<int64_t>(n, (int64_t)h->num_cu * 4);

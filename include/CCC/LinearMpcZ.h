@@ -43,7 +43,7 @@ public:
   /** \brief Constructor (LinearMpcZ.h:127-131, src/LinearMpcZ.cpp:31-46).
       \param mass robot mass [kg]
       \param horizon_dt discretization timestep in horizon [sec]
-      \param horizon_steps number of steps in horizon (<= 64)
+      \param horizon_steps number of steps in horizon (<= CCC_Z_MAX_STEPS_WIDE)
       \param weight_param objective weight parameter
       \param qp_solver_type ignored (kept for source compatibility)
       \param device HIP device ordinal (new) */

@@ -313,7 +313,9 @@ typedef struct ccc_z ccc_z_t;
 
 /* Replaces LinearMpcZ::LinearMpcZ(mass, horizon_dt, horizon_steps, weight_param, qp_solver_type)
  * (LinearMpcZ.h:127-131, src/LinearMpcZ.cpp:31-46).  WeightParam{pos = 1, force = 1e-7} (LinearMpcZ.h:34-47);
- * force_range_ = (10, 10 m g) (:37).  horizon_steps <= 64. */
+ * force_range_ = (10, 10 m g) (:37).  horizon_steps <= CCC_Z_MAX_STEPS_WIDE (up to 64 steps both kernels apply, beyond
+ * the streaming projected-Newton kernel alone). */
+#define CCC_Z_MAX_STEPS_WIDE 256
 int ccc_z_create(double mass, double horizon_dt, int horizon_steps, double w_pos, double w_force, int device,
                  ccc_z_t ** out);
 void ccc_z_destroy(ccc_z_t * h);

@@ -69,8 +69,9 @@ def test_z_single_step_and_all_flight():
     b["contact"][:] = 0
     r = LinearMpcZ(mass, 0.05, 40).planOnceBatch(b["contact"], b["ref_pos"], b["x0"], want_all=True)
     assert np.all(r["force"] == 0.0) and np.all(r["force_all"] == 0.0) and np.all(r["status"] == 0)
+    LinearMpcZ(mass, 0.05, 65)  # (beyond the tableau kernel's 64 steps: the streaming kernel alone, tests/test_z_gpu.py)
     with pytest.raises(CccError):
-        LinearMpcZ(mass, 0.05, 65)
+        LinearMpcZ(mass, 0.05, 257)
 
 
 def test_zmp_timeline_without_footsteps_and_single_instance_loop():
