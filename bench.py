@@ -328,7 +328,8 @@ def main():
                                   "what": "useful fp64 flop = pivots x 2048 (rank-1 update of the 32 x 32 tableau) over "
                                           "the kernel time, against the vector-fp64 peak; issue_frac = VALU wave-"
                                           "instructions x 4 clk / (SIMDs x clk) from the PMC pass in profiles/"},
-                         "mfma": {"utilisation": 0.0,
+                         "mfma": {"utilisation": 0.0, "measured": "SQ_INSTS_MFMA = 0, SQ_VALU_MFMA_BUSY_CYCLES = 0 per launch "
+                                                                      "(profiles/r02_zmp_mfma_counters.csv)",
                                   "why": "the pivot is a rank-1 update of a register-resident 32 x 32 tableau whose pivot "
                                          "row and column depend on the previous pivot: no GEMM-shaped work to tile "
                                          "(the smallest fp64 MFMA, 4x4x4, would run at 1/4 fill on a rank-1 product)"},
