@@ -831,6 +831,8 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   double x0[6];
 #pragma unroll
   for(int a = 0; a < 6; a++) x0[a] = B.x0[b * 6 + a];
+  if(!SINGLE && !B.lambda_all) // (the slots of step 0 past its ridge count: written once, see the forward pass)
+    for(int r = (int)WS(0, kXsDim); r < M; r++) B.u0[b * M + r] = 0.0;
   int it = 0;
   constexpr bool single = SINGLE;
   bool converged = false, cycling = false, gaveup = false;
@@ -1065,6 +1067,9 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     {
       const bool emit = pass == 1;
       if(emit && !converged && !gaveup) break;
+      // (the block iteration has written the first-step force scales in its last forward pass already -- the pass that
+      //  found the set unchanged computes exactly the values an extra pass would: that pass is only run for lambda_all)
+      if(emit && !single && !B.lambda_all) break;
       bool changed = false;
       unsigned long long hh = 1469598103934665603ull;
       double x[6];
@@ -1209,7 +1214,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
               if(B.lambda_all) B.lambda_all[((size_t)b * N + s) * M + r] = lam;
             }
             else if(!single)
+            {
+              if(s == 0 && !B.lambda_all) B.u0[b * M + r] = lam;
               xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, az, nS, nt, nc, nal, ndp);
+            }
           }
         }
         if(emit)
