@@ -1271,19 +1271,22 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
               xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
             }
           }
-#pragma unroll
-          for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
-#pragma unroll
-          for(int a = 0; a < 6; a++)
+          if(nb != bits) // (a stage whose set stays has its sums in the workspace already: the same values, not rewritten)
           {
-            WS(s, kXsT + a) = nt[a];
-            WS(s, kXsC + a) = nc[a];
+#pragma unroll
+            for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
+#pragma unroll
+            for(int a = 0; a < 6; a++)
+            {
+              WS(s, kXsT + a) = nt[a];
+              WS(s, kXsC + a) = nc[a];
+            }
+            WS(s, kXsAl) = nal;
+            WS(s, kXsDp) = ndp;
+            WS(s, kXsSt) = (double)(unsigned)nb;
+            if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(nb >> 32);
+            changed = true;
           }
-          WS(s, kXsAl) = nal;
-          WS(s, kXsDp) = ndp;
-          changed = changed || nb != bits;
-          WS(s, kXsSt) = (double)(unsigned)nb;
-          if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(nb >> 32);
           hh = (hh ^ nb) * 1099511628211ull;
         }
 #pragma unroll
