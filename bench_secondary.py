@@ -33,6 +33,12 @@ def _xy_algo(status):
     return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (43 + 69 + 80 + 16 * 7 + 36) * 8
 
 
+XY_MFMA = ("the block Hessian B'WB (the one genuine dense GEMM of this class: 120 x 320 x 120 per instance) is never formed: "
+           "the QP is solved in stage space by 6 x 6 Riccati recursions over the horizon (csrc/xy.hip), ~100 kflop per "
+           "instance and iteration instead of the 9.2 Mflop of the contraction -- forming it on MFMA at this solve rate "
+           "would need ~30 TFLOP/s of fp64 for a matrix the solver then has to factorise (DESIGN.md section 7b); 0 v_mfma in the ISA")
+
+
 def _xy(n, dev, rank, walking=False):
     from centroidalcontrolcollection_amd import LinearMpcXY, fixtures_ddp as fd
     N, dt, base, M = 20, 0.1, min(n, 2048), 16
@@ -70,11 +76,11 @@ def _xy(n, dev, rank, walking=False):
                     workload="LinearMpcXY N=30 (3 s horizon @ 100 ms), walking with two foot contacts in double support (32 "
                              "ridges), batch=%d per GPU (beyond BASELINE's configs: src/LinearMpcXY.cpp:69-82)" % n,
                     algo_bytes=N * (4 + M * 3 * 8 * 2 + 16 + 48) + 48 + M * 8, kernel="xy_plan_stream_kernel<32,false>", cpu=cpu,
-                    keep=(mpc, tp, tx0))
+                    keep=(mpc, tp, tx0), mfma=XY_MFMA)
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
                 algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, stream_bytes=_xy_algo,
-                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0))
+                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0), mfma=XY_MFMA)
 
 
 def _ddp(n, dev, rank, srb, precision=64, walking=False):
