@@ -33,10 +33,10 @@ def _xy_algo(status):
     return 20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128 + 20 * 16 * 7 * 8 + it * 20 * (43 + 69 + 80 + 16 * 7 + 36) * 8
 
 
-XY_MFMA = ("the block Hessian B'WB (the one genuine dense GEMM of this class: 120 x 320 x 120 per instance) is never formed: "
-           "the QP is solved in stage space by 6 x 6 Riccati recursions over the horizon (csrc/xy.hip), ~100 kflop per "
-           "instance and iteration instead of the 9.2 Mflop of the contraction -- forming it on MFMA at this solve rate "
-           "would need ~30 TFLOP/s of fp64 for a matrix the solver then has to factorise (DESIGN.md section 7b); 0 v_mfma in the ISA")
+XY_MFMA = ("the block Hessian B'WB (the one genuine dense GEMM of this class: 320 x 120 x 320 per instance at config 4, "
+           "24.6 Mflop) is never formed: the QP is solved in stage space by 6 x 6 Riccati recursions over the horizon "
+           "(csrc/xy.hip), ~0.1 Mflop per instance and iteration -- forming it on MFMA at this solve rate would need ~80 "
+           "TFLOP/s of fp64 for a matrix the solver then still has to factorise (DESIGN.md section 7b); 0 v_mfma in the ISA")
 
 
 def _xy(n, dev, rank, walking=False):
