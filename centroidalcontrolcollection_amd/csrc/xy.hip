@@ -676,6 +676,7 @@ constexpr int kXsMaxIt = 16;
 // (2 bits per ridge: 0 free, 1 at the lower bound, 2 at the upper bound)
 constexpr int kXsE = 0, kXsF = 36, kXsPt = 42, kXsPv = 63, kXsT = 69, kXsAl = 75, kXsDp = 76, kXsDim = 77, kXsFz = 78,
               kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsSt2 = 113, // (ridges 0-15 / 16-31: each exact in a double)
+              kXsPin = 114, // (6) the linear term of the value function ENTERING the stage, beside its matrix in kXsPt
               kXsFields = 120; // (120 + 16 x 8 fields x 512 B: stages start on 4 KB boundaries)
 
 struct XyWork
@@ -878,6 +879,14 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     return bits;
   };
   unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0; // hashes of the clamped sets of the last iterations
+  // The value function of a stage depends on the sets of the LATER stages only: when the last forward pass changed
+  // nothing beyond stage smax, the backward recursion resumes there, from the value function it stored on its way in
+  // (kXsPt / kXsPin then hold it as it ENTERED the stage: the very numbers a full recursion would produce again).
+  // Single-change rounds only (kResume): there the changes are few and a wavefront's lanes are few; in the block
+  // iteration some lane of the 64 nearly always changes a late stage, the wavefront runs the whole loop anyway, and the
+  // extra stores cost 4 % (measured).
+  constexpr bool kResume = SINGLE;
+  int smax = N - 1;
   for(it = it_begin; it < max_it && !converged && !cycling && !gaveup; it++)
   {
     // ---- backward recursion on the current clamped set
@@ -891,6 +900,17 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     }
     for(int s = N - 1; s >= 0; s--)
     {
+      if(kResume && s > smax) continue;
+      if(kResume && s == smax && s < N - 1)
+      {
+#pragma unroll
+        for(int a = 0; a < 6; a++)
+        {
+          pv[a] = WS(s, kXsPin + a);
+#pragma unroll
+          for(int c = 0; c < 6; c++) Pm[a][c] = WS(s, kXsPt + (c >= a ? xs_tri(a, c) : xs_tri(c, a)));
+        }
+      }
       const int m = (int)WS(s, kXsDim);
       const double fz = WS(s, kXsFz);
       const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
@@ -1017,10 +1037,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         for(int c = 0; c < 6; c++)
         {
           WS(s, kXsE + a * 6 + c) = E[a][c];
-          if(c >= a) WS(s, kXsPt + xs_tri(a, c)) = Pt[a][c]; // (symmetric: the upper triangle)
+          // (symmetric: the upper triangle.  kResume: the matrix as it entered the stage, P~ = this + diag(w))
+          if(c >= a) WS(s, kXsPt + xs_tri(a, c)) = kResume ? Pm[a][c] : Pt[a][c];
         }
         WS(s, kXsF + a) = fv[a];
         WS(s, kXsPv + a) = pt[a];
+        if(kResume) WS(s, kXsPin + a) = pv[a];
       }
       double Gm[6][6], gv[6];
 #pragma unroll
@@ -1059,6 +1081,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     // ---- forward pass: new clamped set (and, once it repeats, the outputs)
     //      single-change mode: the set is left as it is, the most violated condition is looked for and applied after
     //      the pass (cand_*), the sums of that one stage are rebuilt
+    int smax_new = -1; // the last stage whose set this pass changes
     double cand_v = 0.0;
     int cand_s = -1, cand_r = 0, cand_forced = -1;
     unsigned cand_ns = 0u;
@@ -1093,7 +1116,8 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         {
           double acc = WS(s, kXsPv + a);
 #pragma unroll
-          for(int c = 0; c < 6; c++) acc += WS(s, kXsPt + (c >= a ? xs_tri(a, c) : xs_tri(c, a))) * y[c];
+          for(int c = 0; c < 6; c++)
+            acc += (WS(s, kXsPt + (c >= a ? xs_tri(a, c) : xs_tri(c, a))) + ((kResume && a == c) ? P.w[a] : 0.0)) * y[c];
           pi[a] = acc;
           tv[a] = WS(s, kXsT + a);
           tpi += tv[a] * acc;
@@ -1247,6 +1271,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             if(forced_i == sc_r || forced_i == sc_r2) forced_i = -1; // (one of the moves is that release already)
             now = apply_change(s, sc_r, sc_ns, sc_r2, sc_ns2, forced_i);
             changed = true;
+            smax_new = s;
           }
           hh = (hh ^ now) * 1099511628211ull;
         }
@@ -1286,6 +1311,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             WS(s, kXsSt) = (double)(unsigned)nb;
             if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(nb >> 32);
             changed = true;
+            smax_new = s;
           }
           hh = (hh ^ nb) * 1099511628211ull;
         }
@@ -1300,12 +1326,18 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         cycling = !converged && hh == h2;
         h2 = h1;
         h1 = hh;
+        smax = smax_new;
       }
       if(!emit && single)
       {
         converged = cand_s < 0;
         gaveup = !converged && last_chance;
-        if(!converged && !gaveup && strict) apply_change(cand_s, cand_r, cand_ns, -1, 0u, cand_forced);
+        if(!converged && !gaveup && strict)
+        {
+          apply_change(cand_s, cand_r, cand_ns, -1, 0u, cand_forced);
+          smax_new = cand_s;
+        }
+        smax = smax_new;
         if(!strict)
         {
           // the per-stage changes brought back a set of two, three or four sweeps ago, or have used up their share of
