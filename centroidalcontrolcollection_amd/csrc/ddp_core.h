@@ -1147,12 +1147,14 @@ struct Solver
           ok = ok && (d > 0.0);
           const double sq = sqrt(d);
           const double r = 1.0 / sq;
+          // (entries above the diagonal -- a[k] of a lane i < k -- are never read: they take part in the arithmetic
+          //  unpredicated, which saves two selects per multiply-subtract)
           if(i == j)
           {
             a[j] = sq;
             rdi = r;
           }
-          else if(i > j)
+          else
             a[j] = a[j] * r;
           if constexpr(kColumnViaLds)
           {
@@ -1165,7 +1167,7 @@ struct Solver
             if(k < m)
             {
               const double lkj = kColumnViaLds ? col[k] : lane_value(a[j], k);
-              if(i >= k) a[k] -= a[j] * lkj;
+              a[k] -= a[j] * lkj;
             }
           }
           if constexpr(kColumnViaLds) __builtin_amdgcn_wave_barrier();
