@@ -363,6 +363,7 @@ struct Solver
   static constexpr int LQ = Mem<S, M>::LQ;
   static_assert(M == 16 || M == 32, "a row of the M x M matrices per lane of an M-lane group");
   static constexpr unsigned long long kRowMask = (1ull << M) - 1ull; // the lanes of the first M-lane group
+  static constexpr bool kHalf = (M == 32); // a second compile-time size, M / 2 = 16 ridges (see box_qp)
 
   // entry (i, k) of the regularised Quu_F the box-QP works on
   CCC_DDP_FN double quuF(int i, int k) const
@@ -707,7 +708,8 @@ struct Solver
   // emulation (tests/emu) keeps using.
   CCC_DDP_FN int box_qp(int m)
   {
-    return m == M ? box_qp_dev<M>(m) : box_qp_dev<0>(m);
+    // (compile-time sizes: the full M, and at M = 32 also 16 -- a single-support step of a walk: size tests fold away)
+    return m == M ? box_qp_dev<M>(m) : (kHalf && m == M / 2 ? box_qp_dev<kHalf ? M / 2 : M>(m) : box_qp_dev<0>(m));
   }
 
   template<int MM>
@@ -1058,6 +1060,8 @@ struct Solver
     const unsigned long long clm = clamped_mask(m);
     if(m == M)
       cholesky_phase<M>(m, clm);
+    else if(kHalf && m == M / 2)
+      cholesky_phase<kHalf ? M / 2 : M>(m, clm);
     else
       cholesky_phase<0>(m, clm);
     return mem.ic[IC_OK] != 0;
@@ -1240,6 +1244,8 @@ struct Solver
 #if CCC_DDP_FAST
     if(m == M)
       solve_free_phase<M>(m, v);
+    else if(kHalf && m == M / 2)
+      solve_free_phase<kHalf ? M / 2 : M>(m, v);
     else
       solve_free_phase<0>(m, v);
 #else
@@ -1341,6 +1347,8 @@ struct Solver
 #if CCC_DDP_FAST
     if(m == M)
       gains_phase<M>(m);
+    else if(kHalf && m == M / 2)
+      gains_phase<kHalf ? M / 2 : M>(m);
     else
       gains_phase<0>(m);
 #else
@@ -1421,7 +1429,8 @@ struct Solver
       const int m = dim_of(i);
       // the usual case of a full 16-ridge contact gets its own instantiation: index arithmetic by constants, loops the
       // compiler can unroll (same statements, same results)
-      const bool ok = (m == M) ? backward_step<M>(i, m, sr) : backward_step<0>(i, m, sr);
+      const bool ok = (m == M) ? backward_step<M>(i, m, sr)
+                               : ((kHalf && m == M / 2) ? backward_step<kHalf ? M / 2 : M>(i, m, sr) : backward_step<0>(i, m, sr));
       if(!ok) return false;
     }
     return true;
