@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-p50", action="store_true",
+                    help="skip the host-to-host p50 loops (scripts/prof_zmp.sh: their launches read pinned host memory "
+                         "through the same kernel and would be averaged into its rocprofv3 --stats line)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
                          "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
@@ -217,11 +220,12 @@ def main():
     pzl = torch.from_numpy(batch["zlim"]).pin_memory()
     pz = torch.empty((n, 2), dtype=torch.float64).pin_memory()
     pgath = torch.empty((world * n, 2), dtype=torch.float64).pin_memory() if world > 1 else None
-    for _ in range(20):
+    n_h2h = 0 if args.no_host_p50 else 200
+    for _ in range(20 if n_h2h else 0):
         mpc.plan_batch_pinned(px0, pzl, 0.005, pz)
     if world > 1:
         dist.barrier()
-    for _ in range(200):
+    for _ in range(n_h2h):
         t1 = time.perf_counter()
         mpc.plan_batch_pinned(px0, pzl, 0.005, pz)
         if world > 1:  # "outputs gathered on every rank": through the device buffers RCCL works on
@@ -230,14 +234,14 @@ def main():
             pgath.copy_(gathered[0], non_blocking=True)
             torch.cuda.synchronize(dev)
         h2h.append(1e3 * (time.perf_counter() - t1))
-    assert np.array_equal(pz.numpy(), zbuf[(counter[0] - 1) & 1].cpu().numpy()), "pinned path differs from the device path"
-    if rank == 0:
+    assert not n_h2h or np.array_equal(pz.numpy(), zbuf[(counter[0] - 1) & 1].cpu().numpy()), "pinned path differs from the device path"
+    if rank == 0 and n_h2h:
         for _ in range(8):
             t1 = time.perf_counter()
             mpc.planOnceBatch(batch["x0"], batch["zlim"], 0.005)
             h2h_pageable.append(1e3 * (time.perf_counter() - t1))
         h2h_pageable = h2h_pageable[2:]
-    p50_h2h = float(np.median(h2h))
+    p50_h2h = float(np.median(h2h)) if h2h else 0.0
     if world > 1:
         t = torch.tensor([p50_h2h], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,9 +303,9 @@ def main():
             "ms_per_step": ms_per_step,
             # median wall time from "inputs resident in pinned host memory" to "planned ZMPs back in pinned
             # host memory on every rank" (max over ranks); PCIe-inclusive, never the `value` above
-            "p50_ms": p50_h2h,
+            "p50_ms": p50_h2h if n_h2h else None,
             "p50_kernel_ms": float(np.median(kern_ms)),
-            "p50_pageable_host_ms": float(np.median(h2h_pageable)),
+            "p50_pageable_host_ms": float(np.median(h2h_pageable)) if n_h2h else None,
             "higher_is_better": True,
             "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,

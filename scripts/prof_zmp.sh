@@ -5,7 +5,9 @@
 # Raw output goes to gpurun_out/<tag>_*/ ; scripts/summarize_prof.py turns it into profiles/<tag>_*.
 TAG=${1:-r01}
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline"
+# --no-host-p50: the p50 loops launch the same kernel on pinned HOST memory (PCIe-bound, 1.3 ms); left in, they are
+# averaged into the kernel's --stats line, which is meant to be compared with bench.py's device-resident kernel_ms
+B="python bench.py --no-cpu-baseline --no-host-p50"
 for d in trace pmc_sq1 pmc_sq2 pmc_fetch pmc_write; do mkdir -p gpurun_out/${TAG}_$d; done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o zmp -- $B --steps 50 --warmup 5 > gpurun_out/${TAG}_trace/bench.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/${TAG}_pmc_sq1 -o zmp -- $B --steps 3 --warmup 1 > gpurun_out/${TAG}_pmc_sq1/bench.log 2>&1
