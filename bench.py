@@ -91,6 +91,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-steps", type=int, default=300,
+                    help="untimed launches BEFORE the W warm-up steps (the same count on every rank): after the idle "
+                         "seconds of set-up the GPU needs some tens of ms of continuous load to reach its sustained clock "
+                         "(measured: kernel time 0.75 -> 0.68 ms over the first 20 launches); 0 disables")
     ap.add_argument("--no-host-p50", action="store_true",
                     help="skip the host-to-host p50 loops (scripts/prof_zmp.sh: their launches read pinned host memory "
                          "through the same kernel and would be averaged into its rocprofv3 --stats line)")
@@ -190,6 +194,11 @@ def main():
     n_bad = int(((st & 0xff) != 0).sum())
     pivots_per_solve = float((st >> 8).sum()) / n
 
+    # clock ramp (untimed, before the W warm-up steps): see --ramp-steps
+    for _ in range(args.ramp_steps):
+        step()
+    drain()
+    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     drain()
@@ -210,6 +219,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])  # HIP events on the launch stream
+    if os.environ.get("CCC_BENCH_DEBUG") and rank == 0:
+        print("kern_ms", np.round(kern_ms[:24], 3).tolist(), "wall_ms", 1e3 * elapsed,
+              "span_ms", evs[0][0].elapsed_time(evs[-1][1]), file=sys.stderr)
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
     # ccc_zmp_plan_batch; PCIe-inclusive, never the `value` above
     # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the kernel reads the inputs
@@ -300,6 +312,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "ramp_steps": args.ramp_steps,  # untimed launches before the warm-up (GPU clock ramp), see --ramp-steps
             "ms_per_step": ms_per_step,
             # median wall time from "inputs resident in pinned host memory" to "planned ZMPs back in pinned
             # host memory on every rank" (max over ranks); PCIe-inclusive, never the `value` above
