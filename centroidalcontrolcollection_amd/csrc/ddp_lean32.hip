@@ -12,8 +12,11 @@
 
 namespace ccc_amd
 {
+// Three wavefronts per SIMD for the single-rigid-body model (168 VGPRs, 816 B of scratch; 13.6 KB of LDS: eleven per CU):
+// 50.0 -> 51.6 k solves/s at config 5.  The centroidal model keeps two: at config 3's batch (4096 = two turns of the
+// 2048 resident wavefronts) a third resident wavefront only slows the first turn down (15.0 -> 14.2 k).
 template<int S, int M>
-__global__ __launch_bounds__(64, 2) void ddp_lean32_kernel(ddp_common::Params P, DdpBatch B, long n)
+__global__ __launch_bounds__(64, (S == 12 ? 3 : 2)) void ddp_lean32_kernel(ddp_common::Params P, DdpBatch B, long n)
 {
   __shared__ ddp_lean32::Mem<S, M> mem;
   const int N = P.N;
