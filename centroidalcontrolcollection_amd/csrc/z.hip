@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void z_plan_stream_kernel(ZParams P, ZBatch B,
         const double qx0 = pb0, qx1 = pb0 * dt + pb1;                      // B'P~A
         const double pe0 = T00 * e0 + T01 * e1 + t0, pe1 = T01 * e0 + T11 * e1 + t1; // P~ e + p~
         const double qu = B0 * pe0 + B1 * pe1;
-        const double iq = 1.0 / quu;
+        const double iq = fast_rcp(quu); // (v_rcp_f64 + two Newton steps: 9 dependent instructions instead of the 14 of a division)
         const double K0 = -qx0 * iq, K1 = -qx1 * iq, kk = -qu * iq;
         WZ(j, 2) = K0;
         WZ(j, 3) = K1;
