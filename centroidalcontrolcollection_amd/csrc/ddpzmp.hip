@@ -14,7 +14,7 @@
 // Mapping: ONE INSTANCE PER LANE.  Value function (6 + 36 doubles), the step's derivatives and Q-function blocks live in
 // the lane's registers as fully unrolled scalar code whose structural zeros (Fx has 13 non-zeros, Fu 5, Lxx 1) are
 // compile-time masks.  The trajectories (x, u, candidate x / u), the gains (k, K) and the sampled RefData live in an HBM
-// workspace laid out [step][field][instance]: every load / store of a wavefront is 64 consecutive doubles (512 B,
+// workspace laid out [wavefront][step][field][lane]: every load / store of a wavefront is 64 consecutive doubles (512 B,
 // coalesced).  Unlike the wave-per-instance kernels of this library this one streams: per DDP iteration and horizon step
 // a lane reads 13 + 34 and writes 21 + 9 doubles (backward + one forward pass) = 616 B against ~1.5 k flops, i.e. the
 // kernel is HBM-bound by design.
@@ -55,36 +55,47 @@ struct Batch
   double * ws;           // workspace, see Ws
 };
 
-// workspace [step][field][instance] (instance fastest), all fp64
+// workspace [wavefront][step][field][lane], all fp64
 struct Ws
 {
   double * base;
   long n;
   int N;
-  // field blocks: X[2] (N+1 steps x 6), U[2] (N x 3), K1 (N x 3), K2 (N x 18), R (N+1 x 4)
+  // one region per wavefront, [step][field][lane]: X[2] (6 each), U[2] (3 each), K1 (3), K2 (18), R (4) = 43 fields of
+  // 512 B per step -- what a wavefront touches in a step is ONE contiguous 22 KB run, step after step (with the fields
+  // laid out [field][instance] over the whole batch every 512-byte access opened a DRAM page of its own)
+  static constexpr int kFields = 43, kX = 0, kU = 12, kK1 = 18, kK2 = 21, kR = 39;
   __host__ __device__ static size_t doubles_per_instance(int N)
   {
-    return (size_t)2 * (N + 1) * 6 + (size_t)2 * N * 3 + (size_t)N * 3 + (size_t)N * 18 + (size_t)(N + 1) * 4;
+    return (size_t)(N + 1) * kFields;
+  }
+  __host__ __device__ static size_t instances_padded(long n) // (whole wavefronts)
+  {
+    return ((size_t)n + 63) / 64 * 64;
+  }
+  __device__ double * at(int step, int f, long inst) const
+  {
+    return base + (((size_t)(inst >> 6) * (N + 1) + step) * kFields + f) * 64 + (inst & 63);
   }
   __device__ double * X(int buf, int step, int f, long inst) const
   {
-    return base + ((size_t)buf * (N + 1) * 6 + (size_t)step * 6 + f) * n + inst;
+    return at(step, kX + buf * 6 + f, inst);
   }
   __device__ double * U(int buf, int step, int f, long inst) const
   {
-    return base + ((size_t)2 * (N + 1) * 6 + (size_t)buf * N * 3 + (size_t)step * 3 + f) * n + inst;
+    return at(step, kU + buf * 3 + f, inst);
   }
   __device__ double * K1(int step, int f, long inst) const
   {
-    return base + ((size_t)2 * (N + 1) * 6 + (size_t)2 * N * 3 + (size_t)step * 3 + f) * n + inst;
+    return at(step, kK1 + f, inst);
   }
   __device__ double * K2(int step, int f, long inst) const
   {
-    return base + ((size_t)2 * (N + 1) * 6 + (size_t)3 * N * 3 + (size_t)step * 18 + f) * n + inst;
+    return at(step, kK2 + f, inst);
   }
   __device__ double * R(int step, int f, long inst) const
   {
-    return base + ((size_t)2 * (N + 1) * 6 + (size_t)3 * N * 3 + (size_t)N * 18 + (size_t)step * 4 + f) * n + inst;
+    return at(step, kR + f, inst);
   }
 };
 
@@ -1004,7 +1015,7 @@ extern "C" int ccc_ddpzmp_set_config(ccc_ddpzmp_t * h, const ccc_ddp_config_t * 
 extern "C" int64_t ccc_ddpzmp_workspace_bytes(const ccc_ddpzmp_t * h, int64_t n)
 {
   if(!h || n < 0) return 0;
-  return (int64_t)(dz::Ws::doubles_per_instance(h->P.N) * sizeof(double)) * n;
+  return (int64_t)(dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * dz::Ws::instances_padded(n));
 }
 
 extern "C" int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const double * ref, const double * x0,
@@ -1022,7 +1033,7 @@ extern "C" int ccc_ddpzmp_plan_batch_device(ccc_ddpzmp_t * h, int64_t n, const d
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;
-    CCC_HIP_CHECK(hipMalloc(&h->ws, dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * (size_t)n));
+    CCC_HIP_CHECK(hipMalloc(&h->ws, dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * dz::Ws::instances_padded(n)));
     h->ws_cap = n;
   }
   dz::Batch B{ref, x0, u_init, u_out, x_out, iters, status, cost, h->ws};
@@ -1096,7 +1107,7 @@ extern "C" int ccc_ddpzmp_closed_loop_device(ccc_ddpzmp_t * h, int64_t n, int K,
     if(h->ws) CCC_HIP_CHECK(hipFree(h->ws));
     h->ws = nullptr;
     h->ws_cap = 0;
-    CCC_HIP_CHECK(hipMalloc(&h->ws, dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * (size_t)n));
+    CCC_HIP_CHECK(hipMalloc(&h->ws, dz::Ws::doubles_per_instance(h->P.N) * sizeof(double) * dz::Ws::instances_padded(n)));
     h->ws_cap = n;
   }
   dz::Loop L{};
