@@ -334,6 +334,9 @@ def main():
             # HBM figures the contract asks for, `valu` the ones that say how far the kernel is from ITS roofline
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         # (PMC counters need rocprofv3 around the process: collected by scripts/prof_zmp.sh -- this command
+                         #  under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, one pass each -- and read back from profiles/)
+                         "traffic_source": "profiles/zmp_hbm_traffic.json",
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
                          "kernel": "zmp_plan_kernel_dyn<32,2>" if 2 * n >= 6 * 256 * 12 * 2 else "zmp_plan_kernel<32,2>",
                          "kernel_avg_ms": kavg * 1e3,
