@@ -92,8 +92,10 @@ __device__ __forceinline__ double row_at_group_uniform(const RowRegs<NP> & T, in
 
 // K1, static pairing: QP (instance, axis) = (qp / 2, qp % 2), the two axes of an instance in the two halves of a
 // wavefront.  The steps of the iteration are the sections of csrc/zmp_k1.inc, shared with zmp_plan_kernel_dyn.
+// (three wavefronts per SIMD asked for explicitly: left alone hipcc allocates 169 VGPRs, one more than three wavefronts
+//  allow, and the kernel runs a quarter slower -- 67.7 against 84.2 M solves/s at 16384 instances)
 template<int LG, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+__global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                              const double * __restrict__ zlim, double control_dt,
                                                              double * __restrict__ zmp, double * __restrict__ jerk,
                                                              int * __restrict__ status)
@@ -1019,9 +1021,11 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   const int64_t resident = (int64_t)h->num_cu * (16 / WAVES);
   const int grid = (int)std::min<int64_t>(want, resident * 8);
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
-  // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~6 QPs per resident group the queue cannot
-  // balance anything and the static pairing (one instance per wavefront, more workgroups than fit) is faster
-  int64_t queue_min = (int64_t)6 * h->num_cu * 12 * QPW;
+  // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~18 QPs per resident group the static
+  // pairing (one instance per wavefront, more workgroups than fit: the hardware dispatcher balances) is faster -- measured
+  // static / queue in M solves/s: 83.7 / 65.4 at 16384 instances, 90.3 / 83.3 at 32768, 95.1 / 93.2 at 49152,
+  // 96.2 / 96.5 at 57344, 94.4 / 98.3 at 65536
+  int64_t queue_min = (int64_t)18 * h->num_cu * 12 * QPW;
   if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) queue_min = std::atoll(qm); // (development switch)
   const bool use_queue = !std::getenv("CCC_ZMP_STATIC") && nqp >= queue_min;
   if(use_queue)
