@@ -36,7 +36,9 @@ struct SymTab
   static constexpr int NTP = NTILE;                // tiles per slot plane
   static constexpr int kDoubles = 2 * SL * NTP;    // LDS doubles
   // waves per SIMD the kernels ask the compiler for: two or three workgroups share a CU up to 320 threads
-  static constexpr int kMinWaves = NT <= 256 ? 3 : (NT <= 320 ? 4 : (NT <= 512 ? 2 : 4));
+  // (40 rows: 129 VGPRs left alone, one over what four wavefronts allow; asked for, 127 without a spill and sixteen
+  //  7 KB workgroups per CU instead of twelve: 29.7 -> 33.7 M solves/s at N = 40.  48 / 56 rows would spill: measured slower)
+  static constexpr int kMinWaves = (NT <= 64 && NR <= 40) ? 4 : (NT <= 256 ? 3 : (NT <= 320 ? 4 : (NT <= 512 ? 2 : 4)));
 
   // tile (a, b) of thread t: a (a + 1) / 2 + b = t
   static __device__ __forceinline__ void tile_of(int t, int & a, int & b)
