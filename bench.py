@@ -338,7 +338,7 @@ def main():
                          #  under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, one pass each -- and read back from profiles/)
                          "traffic_source": "profiles/zmp_hbm_traffic.json",
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
-                         "kernel": "zmp_plan_kernel_dyn<32,2>" if 2 * n >= 6 * 256 * 12 * 2 else "zmp_plan_kernel<32,2>",
+                         "kernel": mpc.last_kernel(),  # asked of the library (ccc_zmp_last_kernel), not re-derived
                          "kernel_avg_ms": kavg * 1e3,
                          "valu": {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,

@@ -119,7 +119,7 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
         ns = min(n, 2048)
         sub = {a: v[:ns] for a, v in prob.items()}
         o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20,
-                       P=P, M=M)
+                       P=P, M=M, arith=d.arithmetic() if precision == 64 else 0)
         t0 = time.perf_counter()
         r = o.plan_batch(sub, x0[:ns], nthreads=cores)
         t = time.perf_counter() - t0
@@ -147,7 +147,7 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                 algo_bytes=P * 4 + 2 * P * M * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
                 + S * 8 + N * M * 8,
                 kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
-                ((("ddp_lean_kernel<%d,16>" if srb else "ddp_plan_kernel<%d,16>") % S) if precision == 64
+                (("ddp_tile_kernel<%d>" % S) if precision == 64
                  else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
                 keep=(d, tp, tx0))
 

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "ccc_ddp_get_params",
     "ccc_ddp_get_config",
     "ccc_ddp_get_device",
+    "ccc_ddp_arithmetic",
     "ccc_xy_get_params",
     "ccc_ddp_closed_loop_device",
     "ccc_xy_closed_loop_device",
@@ -44,6 +45,7 @@ ABI_SYMBOLS = [
     "ccc_zmp_destroy",
     "ccc_zmp_horizon_steps",
     "ccc_zmp_get_seq",
+    "ccc_zmp_last_kernel",
     "ccc_zmp_plan_batch_device",
     "ccc_zmp_plan_batch",
     "ccc_zmp_get_model",
@@ -129,6 +131,8 @@ def load():
     L.ccc_zmp_destroy.argtypes = [ctypes.c_void_p]
     L.ccc_zmp_horizon_steps.restype = ctypes.c_int
     L.ccc_zmp_horizon_steps.argtypes = [ctypes.c_void_p]
+    L.ccc_zmp_last_kernel.restype = ctypes.c_char_p
+    L.ccc_zmp_last_kernel.argtypes = [ctypes.c_void_p]
     L.ccc_zmp_get_seq.restype = ctypes.c_int
     L.ccc_zmp_get_seq.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.ccc_zmp_plan_batch_device.restype = ctypes.c_int

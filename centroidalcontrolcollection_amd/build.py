@@ -27,6 +27,7 @@ def source_hash():
     import hashlib
 
     h = hashlib.sha256(" ".join(FLAGS).encode())
+    # (csrc/ includes ../../include/ccc_amd.h; a package installed without the include/ directory hashes csrc/ alone)
     deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + sorted(
         glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
     for d in deps:
@@ -49,37 +50,58 @@ _stale = is_stale
 
 
 def build_lib(force=False, verbose=False):
-    """Compile every HIP source into one shared library. Returns the library path."""
+    """Compile every HIP source into one shared library. Returns the library path.
+
+    Safe under concurrent callers (every rank of a torchrun job imports the package): the build is serialised by a file
+    lock, objects go to a per-process directory, and the library and its source hash are moved into place atomically --
+    a rank that waited for the lock finds the library fresh and returns without compiling."""
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    # one hipcc per translation unit, side by side (no device code crosses a unit: every kernel is launched from the
-    # unit that defines it), then one link
-    from concurrent.futures import ThreadPoolExecutor
-
-    obj_dir = os.path.join(LIB_DIR, "obj")
-    os.makedirs(obj_dir, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"]
-
-    def compile_one(src):
-        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
-        cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return obj
-
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        objs = list(pool.map(compile_one, sources()))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    import fcntl
     import shutil
 
-    shutil.rmtree(obj_dir, ignore_errors=True)
-    with open(HASH_PATH, "w") as f:
-        f.write(source_hash() + "\n")
+    want = source_hash()
+    with open(os.path.join(LIB_DIR, ".buildlock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH  # another process built it while this one waited
+            # one hipcc per translation unit, side by side (no device code crosses a unit: every kernel is launched from
+            # the unit that defines it), then one link
+            from concurrent.futures import ThreadPoolExecutor
+
+            obj_dir = os.path.join(LIB_DIR, "obj.%d" % os.getpid())
+            os.makedirs(obj_dir, exist_ok=True)
+            cflags = [f for f in FLAGS if f != "-shared"]
+
+            def compile_one(src):
+                obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+                cmd = [HIPCC] + cflags + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                return obj
+
+            try:
+                with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+                    objs = list(pool.map(compile_one, sources()))
+                tmp_lib = os.path.join(obj_dir, "libccc_amd.so")
+                cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp_lib]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                tmp_hash = os.path.join(obj_dir, "srchash")
+                with open(tmp_hash, "w") as f:
+                    f.write(want + "\n")
+                if os.path.exists(HASH_PATH):
+                    os.remove(HASH_PATH)  # (never a fresh hash beside a stale library)
+                os.replace(tmp_lib, LIB_PATH)
+                os.replace(tmp_hash, HASH_PATH)
+            finally:
+                shutil.rmtree(obj_dir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

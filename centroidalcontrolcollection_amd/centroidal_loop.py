@@ -76,6 +76,8 @@ def ddp_closed_loop(planner, timeline, inertia_diag, sim_state, t0, sim_dt, cycl
     if timeline.M != planner.max_ridges_:
         raise ValueError("the timeline carries %d ridges per contact entry, the planner %d" % (timeline.M, planner.max_ridges_))
     tl = timeline.c_struct()
+    # the loop plans with the object's solver configuration (first_max_iter / warm_max_iter override max_iter per cycle)
+    _lib.check(L.ccc_ddp_set_config(planner._h, ctypes.byref(planner.ddp_solver_.config())))
     dts = (ctypes.c_double * max(1, len(disturb_times)))(*disturb_times)
     dl = (ctypes.c_double * 3)(*disturb_lin)
     t_end = ctypes.c_double(0.0)

@@ -56,7 +56,7 @@ __global__ void sample_ddp_kernel(Timeline T, long n, int N, double t, double dt
     ref_pos[(k * (N + 1) + i) * 3 + a] = r[a];
     if(ref_ori) ref_ori[(k * (N + 1) + i) * 3 + a] = r[3 + a];
   }
-  if(i < N) step_phase[k * N + i] = T.seg_contact[k * T.K + s];
+  if(i < N) step_phase[k * N + i] = min(max(T.seg_contact[k * T.K + s], 0), T.C - 1); // (clamped to the contact table)
 }
 
 // LinearMpcXY: the per-step arrays of ccc_xy_plan_batch_device

@@ -7,18 +7,18 @@
 // per instance so that a wavefront streams through contiguous memory.
 //
 // The builds of csrc/ddp_core.h behind one entry (dispatch in ccc_ddp_plan_batch_device):
-//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps
+//   tile   ddp_tile_kernel (csrc/ddp_tile.hip, csrc/ddp_tile.h)  THE DEFAULT for <= 16 ridges per step, reg_type 1, fp64:
+//                                                         matrices distributed over the lanes, 16 instances per CU; arithmetic
+//                                                         = the tile specification (oracle/ddp_tile.c, ccc_ddp_arithmetic = 1)
+//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps (reg_type 2)
 //   lean   ddp_lean_kernel (csrc/ddp_lean.hip)            the same sizes compiled for reg_type 1 (the default) only: what a
 //                                                         DdpSingleRigidBody handle runs (less LDS, more wavefronts)
 //   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
 //   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32
 //                                                         (BASELINE configs[4])
-//   group  ddp_group_kernel (csrc/ddp_group.h)             four instances per wavefront (development switch
-//                                                         CCC_DDP_GROUP; measured slower)
 #include "common.h"
 #include "ddp_batch.h"
 #include "ddp_core.h"
-#include "ddp_group.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -69,13 +69,15 @@ struct ccc_ddp
   int S = 9;
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
   bool wide = false;          // the fast kernel's tables do not hold this handle's problems
+  bool env_lean = false, env_full = false; // development switches CCC_DDP_LEAN / CCC_DDP_FULL, read once in ccc_ddp_create
+  bool env_legacy = false;    // CCC_DDP_LEGACY: the row-per-lane kernels of csrc/ddp_core.h instead of the tile kernel
+  bool fits_fast = false;     // the tables of the row-per-lane fast builds hold this handle's problems
+  int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip), grown on demand
+  double * ws_t = nullptr;
   int num_cu = 0;
   // device workspace (grown on demand)
   int64_t cap = 0;
   double *ws_x = nullptr, *ws_xc = nullptr, *ws_uc = nullptr, *ws_k = nullptr, *ws_K = nullptr;
-  // workspace of the group kernel (csrc/ddp_group.h): one allocation, carved per array
-  int64_t gcap = 0;
-  double * ws_g = nullptr;
   // staging for the host entry
   int64_t hcap = 0;
   void * d_stage = nullptr;
@@ -119,8 +121,12 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   h->prm = *p;
   h->M = p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES;
   h->prm.max_ridges = h->M;
-  h->wide = h->M != CCC_DDP_MAX_RIDGES || p->max_phases > ddp::kMaxPhases || p->horizon_steps > ddp::kMaxSteps;
+  h->fits_fast = h->M == CCC_DDP_MAX_RIDGES && p->max_phases <= ddp::kMaxPhases && p->horizon_steps <= ddp::kMaxSteps;
+  h->wide = !h->fits_fast;
+  h->env_legacy = std::getenv("CCC_DDP_LEGACY") != nullptr;
   if(std::getenv("CCC_DDP_WIDE")) h->wide = true; // (development switch: the wide build on problems both builds take)
+  h->env_lean = std::getenv("CCC_DDP_LEAN") != nullptr;
+  h->env_full = std::getenv("CCC_DDP_FULL") != nullptr;
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -150,10 +156,52 @@ extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   free_ws(h);
-  if(h->ws_g) (void)hipFree(h->ws_g);
+  if(h->ws_t) (void)hipFree(h->ws_t);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
+{
+  std::memset(&P, 0, sizeof(P));
+  P.model = h->prm.model;
+  P.N = h->prm.horizon_steps;
+  P.P = h->prm.max_phases;
+  P.mass = h->prm.mass;
+  P.dt = h->prm.horizon_dt;
+  for(int a = 0; a < 12; a++)
+  {
+    P.w_run[a] = h->prm.w_run[a];
+    P.w_term[a] = h->prm.w_term[a];
+  }
+  P.w_force = h->prm.w_force;
+  P.flo = h->prm.force_scale_limits[0];
+  P.fhi = h->prm.force_scale_limits[1];
+  P.max_iter = h->cfg.max_iter;
+  P.lambda0 = h->cfg.initial_lambda;
+  P.dlambda0 = h->cfg.initial_dlambda;
+  P.lambda_factor = h->cfg.lambda_factor;
+  P.lambda_min = h->cfg.lambda_min;
+  P.lambda_max = h->cfg.lambda_max;
+  P.k_rel_norm_thre = h->cfg.k_rel_norm_thre;
+  P.lambda_thre = h->cfg.lambda_thre;
+  P.ratio_thre = h->cfg.cost_update_ratio_thre;
+  P.cost_thre = h->cfg.cost_update_thre;
+  for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
+  P.reg_type = h->cfg.reg_type;
+}
+
+// the tile kernel takes: 16-ridge strides (any number of phases and steps), the default regularisation, fp64
+static bool use_tile(const ccc_ddp * h)
+{
+  return !h->env_legacy && h->M == CCC_DDP_MAX_RIDGES && h->cfg.reg_type == 1 && h->cfg.precision == 64;
+}
+
+extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
+{
+  if(!h) return -1;
+  return use_tile(h) ? 1 : 0;
 }
 
 extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
@@ -210,26 +258,6 @@ static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
   return CCC_OK;
 }
 
-// doubles per instance of the group kernel's workspace: X [2][N+1][S], U [2][N][16], TF [2][N][3], ks [N][16],
-// Ks [N][16][S], gm [N]
-static size_t group_ws_doubles(const ccc_ddp * h)
-{
-  const size_t N = h->prm.horizon_steps, S = h->S, M = CCC_DDP_MAX_RIDGES;
-  return 2 * (N + 1) * S + 2 * N * M + 2 * N * 3 + N * M + N * M * S + N;
-}
-
-static int ensure_group_ws(ccc_ddp * h, int64_t n, void * stream)
-{
-  if(n <= h->gcap) return CCC_OK;
-  CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
-  if(h->ws_g) (void)hipFree(h->ws_g);
-  h->ws_g = nullptr;
-  h->gcap = 0;
-  CCC_HIP_CHECK(hipMalloc(&h->ws_g, (size_t)n * group_ws_doubles(h) * sizeof(double)));
-  h->gcap = n;
-  return CCC_OK;
-}
-
 extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim,
                                          const double * phase_vertex, const double * phase_ridge,
                                          const int32_t * step_phase, const double * ref_pos, const double * ref_ori,
@@ -245,97 +273,36 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
-  // Default: one instance per wavefront (csrc/ddp_core.h).  CCC_DDP_GROUP=1 selects the kernel with four instances per
-  // wavefront (csrc/ddp_group.h; reg_type 1 only): bit-identical results, half the VALU instructions per instance, but
-  // measured SLOWER on MI355X -- 4096 instances are only 1024 wavefronts, one per SIMD, and with
-  // 512 registers and 25 KB of LDS per wavefront nothing hides the dependent LDS / scratch latencies.
-  // precision 32 (BASELINE configs[4]) exists in the group kernel only: its backward pass in single precision
+  if(use_tile(h))
+  {
+    if(n > h->tcap)
+    {
+      CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
+      if(h->ws_t) (void)hipFree(h->ws_t);
+      h->ws_t = nullptr;
+      h->tcap = 0;
+      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)n * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S) * sizeof(double)));
+      h->tcap = n;
+    }
+    ddp_common::Params P;
+    fill_params(h, P);
+    DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
+               x_out, nullptr, nullptr, nullptr, nullptr, iters, status, cost};
+    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, (long)n, h->S, reinterpret_cast<hipStream_t>(stream)));
+    return CCC_OK;
+  }
   if(h->wide && h->cfg.precision == 32)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 is built for max_ridges = %d, max_phases <= %d, "
                 "horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
   if(h->wide && h->cfg.reg_type != 1)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: the wide kernel (max_ridges = %d, max_phases > %d or "
                 "horizon_steps > %d) is built for reg_type 1", CCC_DDP_MAX_RIDGES_WIDE, ddp::kMaxPhases, ddp::kMaxSteps);
-  // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip: 48.2 k / 14.7 k
-  // solves/s for the single-rigid-body / centroidal model; the group kernel, where the mode was first built, 25.9 k /
-  // 7.6 k -- CCC_DDP_GROUP, a development switch, still selects it)
-  const bool lean32 =
-      !h->wide && h->cfg.reg_type == 1 && h->cfg.precision == 32 && std::getenv("CCC_DDP_GROUP") == nullptr;
-  const bool group = !h->wide && !lean32 && h->cfg.reg_type == 1
-                     && (h->cfg.precision == 32 || std::getenv("CCC_DDP_GROUP") != nullptr);
-  int rc = group ? ensure_group_ws(h, n, stream) : ensure_ws(h, n, stream);
+  // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip)
+  const bool lean32 = !h->wide && h->cfg.reg_type == 1 && h->cfg.precision == 32;
+  int rc = ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp_common::Params P;
-  std::memset(&P, 0, sizeof(P));
-  P.model = h->prm.model;
-  P.N = h->prm.horizon_steps;
-  P.P = h->prm.max_phases;
-  P.mass = h->prm.mass;
-  P.dt = h->prm.horizon_dt;
-  for(int a = 0; a < 12; a++)
-  {
-    P.w_run[a] = h->prm.w_run[a];
-    P.w_term[a] = h->prm.w_term[a];
-  }
-  P.w_force = h->prm.w_force;
-  P.flo = h->prm.force_scale_limits[0];
-  P.fhi = h->prm.force_scale_limits[1];
-  P.max_iter = h->cfg.max_iter;
-  P.lambda0 = h->cfg.initial_lambda;
-  P.dlambda0 = h->cfg.initial_dlambda;
-  P.lambda_factor = h->cfg.lambda_factor;
-  P.lambda_min = h->cfg.lambda_min;
-  P.lambda_max = h->cfg.lambda_max;
-  P.k_rel_norm_thre = h->cfg.k_rel_norm_thre;
-  P.lambda_thre = h->cfg.lambda_thre;
-  P.ratio_thre = h->cfg.cost_update_ratio_thre;
-  P.cost_thre = h->cfg.cost_update_thre;
-  for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
-  P.reg_type = h->cfg.reg_type;
-  if(group)
-  {
-    const size_t N = P.N, S = h->S, M = CCC_DDP_MAX_RIDGES, nn = (size_t)n;
-    ddpg::Batch G{};
-    G.phase_dim = phase_dim;
-    G.phase_vertex = phase_vertex;
-    G.phase_ridge = phase_ridge;
-    G.step_phase = step_phase;
-    G.ref_pos = ref_pos;
-    G.ref_ori = ref_ori;
-    G.inertia = inertia;
-    G.x0 = x0;
-    G.u_init = u_init;
-    G.u_out = u_out;
-    G.x_out = x_out;
-    G.iters = iters;
-    G.status = status;
-    G.cost = cost;
-    double * w = h->ws_g;
-    G.X = w;
-    w += nn * 2 * (N + 1) * S;
-    G.U = w;
-    w += nn * 2 * N * M;
-    G.TF = w;
-    w += nn * 2 * N * 3;
-    G.ks = w;
-    w += nn * N * M;
-    G.Ks = w;
-    w += nn * N * M * S;
-    G.gm = w;
-    hipStream_t gs = reinterpret_cast<hipStream_t>(stream);
-    const int64_t blocks = (n + 3) / 4;
-    const bool f32 = h->cfg.precision == 32;
-    if(h->S == 9 && !f32)
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9, double>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
-    else if(h->S == 9)
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<9, float>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
-    else if(!f32)
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12, double>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
-    else
-      hipLaunchKernelGGL((ddpg::ddp_group_kernel<12, float>), dim3((unsigned)blocks), dim3(64), 0, gs, P, G, (long)n);
-    CCC_HIP_CHECK(hipGetLastError());
-    return CCC_OK;
-  }
+  fill_params(h, P);
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
              x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -354,7 +321,7 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, h->S, s));
     return CCC_OK;
   }
-  const bool lean = h->cfg.reg_type == 1 && !std::getenv("CCC_DDP_FULL") && (h->S == 12 || std::getenv("CCC_DDP_LEAN"));
+  const bool lean = h->cfg.reg_type == 1 && !h->env_full && (h->S == 12 || h->env_lean);
   if(lean)
   {
     CCC_HIP_CHECK(launch_ddp_lean(P, B, (long)n, h->S, s));

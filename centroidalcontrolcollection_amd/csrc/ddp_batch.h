@@ -39,4 +39,9 @@ hipError_t launch_ddp_lean(const ddp_common::Params & P, const DdpBatch & B, lon
 
 // csrc/ddp_lean32.hip: the lean build with single-precision storage of the backward pass (precision = 32).
 hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
+
+// csrc/ddp_tile.hip: the tile build (csrc/ddp_tile.h), S in {9, 12}, 16-ridge strides, reg_type 1; ws = n x
+// ddp_tile_ws_doubles(N, S) doubles of workspace
+size_t ddp_tile_ws_doubles(int N, int S);
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, hipStream_t stream);
 } // namespace ccc_amd

@@ -849,8 +849,8 @@ struct Solver
       double step = 1.0;
 #if defined(CCC_DDP_STORE_FLOAT)
       // With single-precision storage the Newton step of an iterate that is optimal TO THAT RESOLUTION is rounding noise,
-      // its sign against the gradient a coin toss: "no descent direction" then means converged (csrc/ddp_group.h has
-      // the same rule and the measurements behind it)
+      // its sign against the gradient a coin toss: "no descent direction" then means converged (DESIGN.md 7c has
+      // the measurements behind the rule)
       if(sdotg >= 0)
       {
         result = 5;

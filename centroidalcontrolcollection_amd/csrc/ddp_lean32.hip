@@ -2,7 +2,7 @@
 // fp64 tolerance check"; the centroidal model takes the mode as well): the lean build of csrc/ddp_lean.hip with the backward pass's matrices STORED in single
 // precision in LDS (value function, derivatives, Q blocks, Cholesky factor, gains) and every operation on them in
 // double -- reads widen, writes round once.  Trajectories, rollouts, costs, the box-QP iterate and every line-search /
-// termination decision stay in double, as in the mode's first implementation (csrc/ddp_group.h, now a development switch).  12.6 KB of LDS per wavefront instead of 20.3.  Not a nmpc_ddp option; results are compared with
+// termination decision stay in double.  12.6 KB of LDS per wavefront instead of 20.3.  Not a nmpc_ddp option; results are compared with
 // the fp64 oracle through a tolerance (tests/test_ddp_gpu.py::test_srb_fp32_storage_against_fp64_oracle_config5).
 #define CCC_DDP_LEAN 1
 #define CCC_DDP_STORE_FLOAT 1

@@ -1,0 +1,984 @@
+// ddp_tile.h -- control-limited DDP for CCC::DdpCentroidal (S = 9) and CCC::DdpSingleRigidBody (S = 12), <= 16 ridges per
+// step: one instance per wavefront, every matrix DISTRIBUTED over the 64 lanes (round 3; replaces the
+// row-per-lane kernels of csrc/ddp_core.h as the default for these sizes).
+//
+// Replaces (reference file:line under /root/reference):
+//   src/DdpCentroidal.cpp:32-64, :66-83, :85-121, :123-177          problem callbacks (S = 9)
+//   src/DdpSingleRigidBody.cpp:26-38, :52-91, :93-112, :114-243     problem callbacks (S = 12)
+//   src/DdpCentroidal.cpp:229,233 / src/DdpSingleRigidBody.cpp:299,303   the external nmpc_ddp::DDPSolver::solve
+// Algorithm: the one frozen in oracle/ddp.c (Tassa's control-limited DDP, reg_type 1).  ARITHMETIC: the "tile"
+// specification of oracle/ddp_tile.c -- the same operations as oracle/ddp.c with every long sum re-associated into a
+// fixed tree or fma chain that maps onto the CDNA4 cross-lane paths.  Kernel and oracle
+// implement that specification independently and agree bit for bit.
+//
+// Lane = 16 g + c (g = row of the wavefront, c = lane in the row).  Layouts:
+//   vectors over the 16 ridges       lane (g, c) holds v[c]                       (replicated in the four rows)
+//   state vectors                    lane (g, a), a < S, holds x[a]               (replicated)
+//   M x M matrices (Quu, its factor) lane (g, c) holds H[c][4g .. 4g+3]           (row c, column block g)
+//   S x M matrices (T2, Qxu, K')     lane (g, c) holds rows a = g, g+4, g+8 of column c
+//   S x S matrices                   the same on lanes c < S; Vxx itself lives in LDS
+// Sums over ridges are 16-lane DPP trees (w64::sum16), sums over column blocks cross the rows with
+// v_permlane16/32_swap (w64::sum_rows), broadcasts inside a row are DPP row_newbcast; LDS (<= 10 KB per wavefront:
+// sixteen wavefronts per CU) carries what changes layout: Vxx, Fx, T1/Qxx, T2/K', Z, the factor L.
+// The line search runs FOUR step sizes at once, one per row (nmpc_ddp tries them in order and takes the first that is
+// accepted; evaluating four side by side and taking the first accepted gives the same answer).
+//
+// Written against csrc/w64.h: the same source runs on the host with 64 lanes in lock step (tests/emu), which is how the
+// CPU suite checks this kernel bit for bit against the oracle without a GPU.
+#pragma once
+
+#include "ddp_core.h" // ddp_common::Params, kGravity
+#include "w64.h"
+
+#if defined(__clang__)
+#  pragma clang fp contract(off)
+#endif
+
+namespace ccc_amd
+{
+namespace ddp_tile
+{
+// -DCCC_TILE_PROBE: the large pieces as separate functions, so that -Rpass-analysis=kernel-resource-usage reports
+// their registers one by one (development aid)
+#if defined(CCC_TILE_PROBE) && defined(__HIP_DEVICE_COMPILE__)
+#  define CCC_TILE_PIECE __device__ __attribute__((noinline))
+#else
+#  define CCC_TILE_PIECE W64_FN
+#endif
+using namespace w64;
+using ddp_common::Params;
+
+constexpr int kM = 16;      // ridges per step (lanes of a row)
+constexpr int kSlots = 5;   // trajectory buffers: the current one + four line-search candidates
+constexpr double kGravity = 9.80665; // include/CCC/Constants.h:10
+
+// Per-instance problem data and workspace (global memory)
+struct Instance
+{
+  const int * phase_dim;       // [P]
+  const double * phase_vertex; // [P][16][3]
+  const double * phase_ridge;  // [P][16][3]
+  const int * step_phase;      // [N]
+  const double * ref_pos;      // [N+1][3]
+  const double * ref_ori;      // [N+1][3]  (SRB)
+  const double * inertia;      // [9]       (SRB)
+  const double * x0;           // [S]
+  const double * u_init;       // [N][16] or nullptr
+  double * xbuf;               // [kSlots][N+1][S]
+  double * ubuf;               // [kSlots][N][16]
+  double * ks;                 // [N][16]
+  double * Ks;                 // [N][16][S]
+  double * u_out;              // [N][16]
+  double * x_out;              // [N+1][S] or nullptr
+  int * out_iters;
+  int * out_status;
+  double * out_cost;
+};
+
+template<int S>
+struct alignas(16) Mem
+{
+  static constexpr int LT = 17; // row stride of the 16-wide tables read with a per-lane ROW index (bank-conflict free)
+  alignas(16) double Vxx[S * S];
+  alignas(16) double Fx[S * S];        // [b][c]
+  alignas(16) double T1[S * S];        // Vxx Fx, then Qxx
+  alignas(16) double T2[S * LT];       // Vxx Fu [a*16 + c]; later K' [a*LT + c]
+  alignas(16) double Zl[S * LT];       // Quu K + 2 Qux, [a*LT + c]
+  alignas(16) double L[kM * LT];       // unit lower factor of H~ = L D L', zeros on and above the diagonal
+  alignas(16) double cb[2][kM];        // column / vector broadcast buffers
+  alignas(16) double Vx[16], Qx[16], vxn[16];
+  double wrun[16], wterm[16];
+  double alpha[12];
+  double inertia[9];
+};
+
+// Deterministic sin / cos on every lane (the restatement csrc/ddp_core.h and the oracle share: Cody-Waite reduction by
+// pi/2 + the fdlibm minimax kernels; <= 1 ulp for |x| < 1e3)
+W64_FN void vsincos(vf x, vf & s, vf & c)
+{
+  const vf fn = vfloor(x * 6.36619772367581382433e-01 + 0.5);
+  const vi n = to_int(fn);
+  vf r = x - fn * 1.57079632673412561417e+00;
+  r = r - fn * 6.07710050650619224932e-11;
+  const vf z = r * r;
+  const vf ps = -1.66666666666666324348e-01
+                + z * (8.33333333332248946124e-03
+                       + z * (-1.98412698298579493134e-04
+                              + z * (2.75573137070700676789e-06
+                                     + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const vf pc = 4.16666666666666019037e-02
+                + z * (-1.38888888888741095749e-03
+                       + z * (2.48015872894767294178e-05
+                              + z * (-2.75573143513906633035e-07
+                                     + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const vf sn = r + r * z * ps;
+  const vf cs = 1.0 - (0.5 * z - z * z * pc);
+  const vi q = n & 3;
+  s = sel(q == 0, sn, sel(q == 1, cs, sel(q == 2, -sn, -cs)));
+  c = sel(q == 0, cs, sel(q == 1, -sn, sel(q == 2, -cs, sn)));
+}
+
+// Eigen::LLT<Matrix3d>::solve on every lane (src/DdpSingleRigidBody.cpp:88,122-123): the statements of csrc/ddp_core.h
+W64_FN void vllt3(const double * I, const vf (&b)[3], vf (&x)[3])
+{
+  const double l00 = std::sqrt(I[0]);
+  const double l10 = I[3] / l00, l20 = I[6] / l00;
+  const double l11 = std::sqrt(I[4] - l10 * l10);
+  const double l21 = (I[7] - l20 * l10) / l11;
+  const double l22 = std::sqrt(I[8] - l20 * l20 - l21 * l21);
+  const vf y0 = b[0] / l00;
+  const vf y1 = (b[1] - l10 * y0) / l11;
+  const vf y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
+  x[2] = y2 / l22;
+  x[1] = (y1 - l21 * x[2]) / l11;
+  x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+}
+
+template<int S>
+struct Solver
+{
+  static constexpr int LT = Mem<S>::LT;
+  static constexpr int FU0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (its six non-zero rows are FU0 .. FU0+5)
+  static constexpr int NP = S * (S + 1) / 2;   // entries of the upper triangle of Vxx
+  static constexpr int NPASS = (NP + 63) / 64;
+
+  const Params & P;
+  const Instance & I;
+  Mem<S> & mem;
+
+  // lane coordinates
+  vi lane, c, g;
+  vb inS;            // c < S
+  vi arow[3];        // rows of the S x M matrices this lane holds: g, g + 4, g + 8 (clamped to S - 1 when not valid)
+  vb aval[3];
+  vi pa[NPASS], pb[NPASS]; // (a, b), a <= b: the entries of Vxx this lane updates
+  vb pval[NPASS];
+
+  // solver state (wave-uniform scalars)
+  double lambda, dlambda, cost, dV0, dV1;
+  int cur;           // slot of the current trajectory
+  // vertex and ridge of ridge c in the contact phase `ph_cached` (zero beyond its dimension): reloaded only when a step
+  // is in another phase than the one before -- a horizon has a handful of phases
+  int ph_cached;
+  vf Vc[3], Rc[3];
+
+  W64_FN Solver(const Params & p, const Instance & i, Mem<S> & m) : P(p), I(i), mem(m) {}
+
+  // ------------------------------------------------------------------------------------------------ set-up
+  W64_FN void init()
+  {
+    lane = lane_id();
+    c = lane & 15;
+    g = lane >> 4;
+    inS = c < S;
+    for(int t = 0; t < 3; t++)
+    {
+      const vi a = g + 4 * t;
+      aval[t] = a < S;
+      arow[t] = seli(aval[t], a, spl(S - 1));
+    }
+    // pair index -> (a, b), row-major over the upper triangle: (0,0) (0,1) .. (0,S-1) (1,1) ..
+    for(int q = 0; q < NPASS; q++)
+    {
+      vi rem = lane + 64 * q, a = spl(0);
+      pval[q] = rem < NP;
+      for(int r = 0; r < S - 1; r++)
+      {
+        const vb more = (a == r) && (rem >= S - r);
+        rem = seli(more, rem - (S - r), rem);
+        a = seli(more, a + 1, a);
+      }
+      pa[q] = seli(pval[q], a, spl(0));
+      pb[q] = seli(pval[q], a + rem, spl(0));
+    }
+    // small tables -> LDS (per-lane indexed reads of kernel arguments would go through scratch)
+    for(int e = 0; e < 16; e++)
+    {
+      mem.wrun[e] = e < S ? P.w_run[e] : 0.0;
+      mem.wterm[e] = e < S ? P.w_term[e] : 0.0;
+    }
+    for(int e = 0; e < 12; e++) mem.alpha[e] = e < 11 ? P.alpha[e] : 0.0;
+    for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12) ? I.inertia[e] : 0.0;
+    ph_cached = -1;
+    wave_sync();
+  }
+
+  W64_FN int phase_of(int step) const
+  {
+    const int p = I.step_phase[step];
+    return p < 0 ? 0 : (p >= P.P ? P.P - 1 : p);
+  }
+  W64_FN int dim_of_phase(int ph) const
+  {
+    const int d = I.phase_dim[ph];
+    return d < 0 ? 0 : (d > kM ? kM : d);
+  }
+  // the step's contact phase into Vc / Rc
+  W64_FN void contact_of(int ph, int dim)
+  {
+    if(ph == ph_cached) return;
+    ph_cached = ph;
+    const long base = static_cast<long>(ph) * kM * 3;
+    const vb in = c < dim;
+    for(int k = 0; k < 3; k++)
+    {
+      Vc[k] = ld_if(I.phase_vertex + base, c * 3 + k, in);
+      Rc[k] = ld_if(I.phase_ridge + base, c * 3 + k, in);
+    }
+  }
+  // reference of the weighted state entries (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0]) on the lanes a < S
+  W64_FN vf ref_of(int step) const
+  {
+    vf r = ld_if(I.ref_pos + static_cast<long>(step) * 3, c, c < 3);
+    if(S == 12) r = sel(c >= 3 && c < 6, ld_if(I.ref_ori + static_cast<long>(step) * 3, c - 3, c >= 3 && c < 6), r);
+    return r;
+  }
+
+  // ------------------------------------------------------------------------------------------------ the model
+  // Everything a step of the model needs from (x, u) that is shared between stateEq and its derivatives.
+  struct Terms
+  {
+    vf cr[3];             // (vertex - pos) x ridge of ridge c
+    vf force[3];          // sum_r u_r ridge_r                          (tree16)
+    vf moment[3];         // sum_r u_r (vertex_r - pos) x ridge_r       (tree16)
+    vf accel[3];          // sum_r (u_r ridge_r) / m                    (tree16; single-rigid-body model)
+  };
+  // x: state on the lanes a < S of every row (rows may differ: the line search), u: ridge c's force scale
+  CCC_TILE_PIECE void terms_of(int ph, int dim, vf x, vf u, Terms & T)
+  {
+    contact_of(ph, dim);
+    const vf p0 = row_bcast<0>(x), p1 = row_bcast<1>(x), p2 = row_bcast<2>(x);
+    const vf d0 = Vc[0] - p0, d1 = Vc[1] - p1, d2 = Vc[2] - p2;
+    T.cr[0] = d1 * Rc[2] - d2 * Rc[1];
+    T.cr[1] = d2 * Rc[0] - d0 * Rc[2];
+    T.cr[2] = d0 * Rc[1] - d1 * Rc[0];
+    for(int k = 0; k < 3; k++)
+    {
+      T.force[k] = sum16(u * Rc[k]);
+      T.moment[k] = sum16(u * T.cr[k]);
+      if(S == 12) T.accel[k] = sum16((u * Rc[k]) / P.mass);
+    }
+  }
+  // x_next = stateEq(step, x, u): src/DdpCentroidal.cpp:32-64 / src/DdpSingleRigidBody.cpp:52-91
+  CCC_TILE_PIECE vf state_eq(const Terms & T, vf x) const
+  {
+    vf xd;
+    if(S == 9)
+    {
+      // pos' = P / m, P' = -m g e_z + force, L' = moment
+      const vf shifted = sel(c == 0, row_bcast<3>(x), sel(c == 1, row_bcast<4>(x), row_bcast<5>(x)));
+      const vf fz = -1 * P.mass * kGravity + T.force[2];
+      xd = sel(c < 3, shifted / P.mass,
+               sel(c == 3, T.force[0], sel(c == 4, T.force[1], sel(c == 5, fz,
+               sel(c == 6, T.moment[0], sel(c == 7, T.moment[1], T.moment[2]))))));
+    }
+    else
+    {
+      const vf w0 = row_bcast<9>(x), w1 = row_bcast<10>(x), w2 = row_bcast<11>(x);
+      vf sa, ca, sb, cb;
+      vsincos(row_bcast<3>(x), sa, ca);
+      vsincos(row_bcast<4>(x), sb, cb);
+      // matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72
+      const vf e0 = ((ca * sb) / cb) * w0 + ((sb * sa) / cb) * w1 + 1.0 * w2;
+      const vf e1 = (-1 * sa) * w0 + ca * w1 + 0.0 * w2;
+      const vf e2 = (ca / cb) * w0 + (sa / cb) * w1 + 0.0 * w2;
+      const double * In = mem.inertia;
+      const vf Iw0 = In[0] * w0 + In[1] * w1 + In[2] * w2;
+      const vf Iw1 = In[3] * w0 + In[4] * w1 + In[5] * w2;
+      const vf Iw2 = In[6] * w0 + In[7] * w1 + In[8] * w2;
+      const vf cw0 = w1 * Iw2 - w2 * Iw1, cw1 = w2 * Iw0 - w0 * Iw2, cw2 = w0 * Iw1 - w1 * Iw0;
+      const vf wd[3] = {-1 * cw0 + T.moment[0], -1 * cw1 + T.moment[1], -1 * cw2 + T.moment[2]};
+      vf sol[3];
+      vllt3(In, wd, sol);
+      const vf az = -1 * kGravity + T.accel[2];
+      const vf vshift = sel(c == 0, row_bcast<6>(x), sel(c == 1, row_bcast<7>(x), row_bcast<8>(x)));
+      xd = sel(c < 3, vshift,
+               sel(c == 3, e0, sel(c == 4, e1, sel(c == 5, e2,
+               sel(c == 6, T.accel[0], sel(c == 7, T.accel[1], sel(c == 8, az,
+               sel(c == 9, sol[0], sel(c == 10, sol[1], sol[2])))))))));
+    }
+    return sel(inS, x + P.dt * xd, 0.0);
+  }
+  // running / terminal cost of (x, u) per row: src/DdpCentroidal.cpp:66-83
+  W64_FN vf running_cost(int step, vf x, vf u) const
+  {
+    const vf e = x - ref_of(step);
+    const vf cx = sum16(sel(inS, 0.5 * ld(mem.wrun, c) * e * e, 0.0));
+    const vf un = sum16(u * u);
+    return cx + 0.5 * P.w_force * un;
+  }
+  W64_FN vf terminal_cost(vf x) const
+  {
+    const vf e = x - ref_of(P.N);
+    return sum16(sel(inS, 0.5 * ld(mem.wterm, c) * e * e, 0.0));
+  }
+
+  // Fx -> mem.Fx ([b][c], dense), Fu: the six non-zero rows of column c in registers
+  // (src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185), at (x, u) with the step's Terms
+  CCC_TILE_PIECE void state_eq_deriv(const Terms & T, vf x, vf (&Fu)[6])
+  {
+    const vb first = lane == 0;
+    for(int e = 0; e < S * S; e += 64) st(mem.Fx, lane + e, splat(0.0), lane + e < S * S);
+    wave_sync();
+    const double dt = P.dt;
+    if(S == 9)
+    {
+      for(int k = 0; k < 3; k++)
+      {
+        Fu[k] = Rc[k] * dt;
+        Fu[3 + k] = T.cr[k] * dt;
+      }
+      // (the scalars are the same on every lane: lane 0 stores them)
+      const vf tf0 = T.force[0], tf1 = T.force[1], tf2 = T.force[2];
+      for(int a = 0; a < 3; a++) st(mem.Fx, spl(a * S + 3 + a), splat((1 / P.mass) * dt), first);
+      st(mem.Fx, spl(6 * S + 1), (-tf2) * dt, first);
+      st(mem.Fx, spl(6 * S + 2), tf1 * dt, first);
+      st(mem.Fx, spl(7 * S + 0), tf2 * dt, first);
+      st(mem.Fx, spl(7 * S + 2), (-tf0) * dt, first);
+      st(mem.Fx, spl(8 * S + 0), (-tf1) * dt, first);
+      st(mem.Fx, spl(8 * S + 1), tf0 * dt, first);
+    }
+    else
+    {
+      const double * In = mem.inertia;
+      vf sol[3];
+      vllt3(In, T.cr, sol);
+      for(int k = 0; k < 3; k++)
+      {
+        Fu[k] = (Rc[k] / P.mass) * dt;
+        Fu[3 + k] = sol[k] * dt;
+      }
+      const vf w1 = row_bcast<9>(x), w2 = row_bcast<10>(x), w3 = row_bcast<11>(x);
+      const double I11 = In[0], I12 = In[1], I13 = In[2], I22 = In[4], I23 = In[5], I33 = In[8];
+      const vf D[9] = {I12 * w3 - I13 * w2,
+                       -I13 * w1 + I22 * w3 - 2 * I23 * w2 - I33 * w3,
+                       I12 * w1 + I22 * w2 + 2 * I23 * w3 - I33 * w2,
+                       -I11 * w3 + 2 * I13 * w1 + I23 * w2 + I33 * w3,
+                       -I12 * w3 + I23 * w1,
+                       -I11 * w1 - I12 * w2 - 2 * I13 * w3 + I33 * w1,
+                       I11 * w2 - 2 * I12 * w1 - I22 * w2 - I23 * w3,
+                       I11 * w1 + 2 * I12 * w2 + I13 * w3 - I22 * w1,
+                       I13 * w2 - I23 * w1};
+      const vf tf0 = T.force[0], tf1 = T.force[1], tf2 = T.force[2];
+      const vf zero = splat(0.0);
+      const vf CM[9] = {zero, -tf2, tf1, tf2, zero, -tf0, -tf1, tf0, zero};
+      for(int b = 0; b < 3; b++)
+      {
+        // column b of I^-1 d(-w x I w)/dw -> block (9, 9); column b of I^-1 crossMat(totalForce) -> block (9, 0)
+        const vf colD[3] = {D[b], D[3 + b], D[6 + b]}, colC[3] = {CM[b], CM[3 + b], CM[6 + b]};
+        vf sD[3], sC[3];
+        vllt3(In, colD, sD);
+        vllt3(In, colC, sC);
+        for(int a = 0; a < 3; a++)
+        {
+          st(mem.Fx, spl((9 + a) * S + 9 + b), sD[a] * dt, first);
+          st(mem.Fx, spl((9 + a) * S + b), sC[a] * dt, first);
+        }
+      }
+      vf sa, ca, sb, cb;
+      vsincos(row_bcast<3>(x), sa, ca);
+      vsincos(row_bcast<4>(x), sb, cb);
+      const vf cb2 = cb * cb, sb2 = sb * sb;
+      for(int a = 0; a < 3; a++) st(mem.Fx, spl(a * S + 6 + a), splat(1.0 * dt), first);
+      const vf K[9] = {(ca * sb) / cb, (sb * sa) / cb, splat(1.0), -1 * sa, ca, zero, ca / cb, sa / cb, zero};
+      for(int a = 0; a < 3; a++)
+        for(int b = 0; b < 3; b++) st(mem.Fx, spl((3 + a) * S + 9 + b), K[a * 3 + b] * dt, first);
+      st(mem.Fx, spl(3 * S + 3), (-w1 * sa * sb / cb + w2 * sb * ca / cb) * dt, first);
+      st(mem.Fx, spl(4 * S + 3), (-w1 * ca - w2 * sa) * dt, first);
+      st(mem.Fx, spl(5 * S + 3), (-w1 * sa / cb + w2 * ca / cb) * dt, first);
+      st(mem.Fx, spl(3 * S + 4), (w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa) * dt, first);
+      st(mem.Fx, spl(5 * S + 4), (w1 * sb * ca / cb2 + w2 * sa * sb / cb2) * dt, first);
+    }
+    wave_sync();
+    // diagonal: entry * dt + 1
+    st(mem.Fx, c * S + c, ld(mem.Fx, seli(inS, c * S + c, spl(0))) + 1.0, inS && (g == 0));
+    wave_sync();
+  }
+
+  // ------------------------------------------------------------------------------------------------ linear algebra
+  // y on every row -> the entries 4g .. 4g+3 this lane's column block needs (through LDS buffer `slot`)
+  W64_FN void block_of(vf y, int slot, vf (&yb)[4])
+  {
+    st(mem.cb[slot], c, y, g == 0);
+    wave_sync();
+    for(int s = 0; s < 4; s++) yb[s] = ld(mem.cb[slot], g * 4 + s);
+  }
+  // (H y)_c, H in row blocks: SPEC p = H[c][4g] y_4g; p = fma(H[c][4g+s], y_4g+s, p), s = 1..3; (p_0 + p_1) + (p_2 + p_3)
+  W64_FN vf matvec(const vf (&H)[4], vf y, int slot)
+  {
+    vf yb[4];
+    block_of(y, slot, yb);
+    vf p = H[0] * yb[0];
+    for(int s = 1; s < 4; s++) p = vfma(H[s], yb[s], p);
+    return sum_rows(p);
+  }
+
+  // L D L' of H~ (H with the rows and columns of `skip` -- clamped or beyond the step's dimension -- replaced by
+  // identity): unit lower L -> mem.L (zeros on and above the diagonal), 1 / D -> rdv.  SPEC, column j = 0 .. 15, not skipped:
+  //   d = a[j][j]; fail unless d > 0; r = 1 / d; L[c][j] = a[c][j] r (c > j);
+  //   a[c][k] = fma(-(a[c][j] a[k][j]), r, a[c][k])       (the product of the two column entries first: symmetric)
+  // Returns false when a pivot is not positive.
+  CCC_TILE_PIECE bool factorize(const vf (&HF)[4], unsigned skip, vf & rdv)
+  {
+    vf a[4];
+    const vb rskip = ((spl(static_cast<int>(skip)) >> c) & 1) != 0;
+    for(int s = 0; s < 4; s++)
+    {
+      const vi k = g * 4 + s;
+      const vb cskip = ((spl(static_cast<int>(skip)) >> k) & 1) != 0;
+      a[s] = sel(rskip || cskip, sel(c == k, 1.0, 0.0), HF[s]);
+    }
+    rdv = splat(1.0);
+    bool ok = true;
+    for(int j = 0; j < kM; j++)
+    {
+      const int gj = j >> 2, sj = j & 3;
+      if((skip >> j) & 1u)
+      {
+        st(mem.L, c * LT + j, splat(0.0), g == 0);
+        continue;
+      }
+      const double d = read_lane(a[sj], 16 * gj + j);
+      if(!(d > 0.0)) ok = false;
+      const double r = 1.0 / d;
+      st(mem.cb[j & 1], c, a[sj], g == gj);
+      wave_sync();
+      const vf uc = ld(mem.cb[j & 1], c);
+      st(mem.L, c * LT + j, sel(c > j, uc * r, 0.0), g == 0);
+      rdv = sel(c == j, splat(r), rdv);
+      for(int s = 0; s < 4; s++)
+      {
+        const vf uk = ld(mem.cb[j & 1], g * 4 + s);
+        a[s] = vfma(-(uc * uk), splat(r), a[s]);
+      }
+    }
+    wave_sync();
+    return ok;
+  }
+
+  // b <- H~^-1 b for NR right-hand sides held one entry per lane (rows may hold different ones), zero on the skipped
+  // rows.  SPEC: forward, k = 0 .. 15: b_c = fma(-L[c][k], b_k, b_c) (c > k); b_c = b_c rd_c; backward, k = 15 .. 0:
+  // b_c = fma(-L[k][c], b_k, b_c) (c < k).  Skipped columns are identity columns: nothing to do.
+  template<int NR>
+  W64_FN void solve(vf (&b)[NR], unsigned skip, vf rdv)
+  {
+    solve_fwd<0>(b, skip);
+    for(int t = 0; t < NR; t++) b[t] = b[t] * rdv;
+    solve_bwd<kM - 1>(b, skip);
+  }
+  template<int K, int NR>
+  W64_FN void solve_fwd(vf (&b)[NR], unsigned skip)
+  {
+    if constexpr(K < kM)
+    {
+      if(!((skip >> K) & 1u))
+      {
+        const vf lk = ld(mem.L, c * LT + K);
+        for(int t = 0; t < NR; t++) b[t] = vfma(-lk, row_bcast<K>(b[t]), b[t]);
+      }
+      solve_fwd<K + 1>(b, skip);
+    }
+  }
+  template<int K, int NR>
+  W64_FN void solve_bwd(vf (&b)[NR], unsigned skip)
+  {
+    if constexpr(K >= 0)
+    {
+      if(!((skip >> K) & 1u))
+      {
+        const vf lk = ld(mem.L, c + K * LT);
+        for(int t = 0; t < NR; t++) b[t] = vfma(-lk, row_bcast<K>(b[t]), b[t]);
+      }
+      solve_bwd<K - 1>(b, skip);
+    }
+  }
+
+  // Box-QP (Tassa's boxQP.m, nmpc_ddp's parameters): min 1/2 x'Hx + q'x, lo <= x <= hi over the first m ridges,
+  // H = HF (row blocks, lambda on the diagonal).  x enters as the warm start.  On success (result >= 1) x is the
+  // minimiser, skip the clamped-or-unused rows as a bit mask, and mem.L / rdv hold the factor of H~ for that set.
+  CCC_TILE_PIECE int box_qp(int m, const vf (&HF)[4], vf q, vf lo, vf hi, vf & x, unsigned & skip, vf & rdv)
+  {
+    const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+    const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
+    const vb in = c < m;
+    const unsigned inmask = (m >= kM) ? 0xffffu : ((1u << m) - 1u);
+    x = sel(in, vmin(vmax(x, lo), hi), 0.0);
+    // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); tree16
+    auto value_of = [&](vf y) { return read_lane(sum16(vfma(0.5 * y, matvec(HF, y, 0), y * q)), 0); };
+    double value = value_of(x), oldvalue = 0.0;
+    vb cl = lane < 0; // all false
+    skip = ~inmask & 0xffffu;
+    rdv = splat(1.0);
+    int result = 0, iter;
+    for(iter = 1; iter <= max_iter; iter++)
+    {
+      if(result != 0) break;
+      if(iter > 1 && (oldvalue - value) < min_rel_improve * std::fabs(oldvalue))
+      {
+        result = 4;
+        break;
+      }
+      oldvalue = value;
+      const vf grad = q + matvec(HF, x, 1);
+      const vb oldc = cl;
+      cl = in && (((x == lo) && (grad > 0.0)) || ((x == hi) && (grad < 0.0)));
+      const unsigned clmask = static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask;
+      const bool changed = (iter == 1) || ((static_cast<unsigned>(ballot(cl != oldc) & 0xffffull) & inmask) != 0u);
+      if(clmask == inmask)
+      {
+        result = 6;
+        break;
+      }
+      if(changed)
+      {
+        skip = clmask | (~inmask & 0xffffu);
+        if(!factorize(HF, skip, rdv))
+        {
+          result = -1;
+          break;
+        }
+      }
+      const vb fr = in && !cl;
+      // |grad| on the free rows.  SPEC: sqrt(tree16(free ? grad^2 : 0))
+      const double gn = std::sqrt(read_lane(sum16(sel(fr, grad * grad, 0.0)), 0));
+      if(gn < min_grad)
+      {
+        result = 5;
+        break;
+      }
+      // grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x
+      vf rhs[1] = {sel(fr, q + matvec(HF, sel(cl, x, 0.0), 0), 0.0)};
+      solve<1>(rhs, skip, rdv);
+      const vf srch = sel(fr, -rhs[0] - x, 0.0);
+      const double sdotg = read_lane(sum16(srch * grad), 0);
+      if(sdotg >= 0) break; // no descent direction: result stays 0
+      double step = 1.0, vc;
+      vf xc;
+      for(;;)
+      {
+        xc = sel(in, vmin(vmax(x + step * srch, lo), hi), 0.0);
+        vc = value_of(xc);
+        if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
+        step *= step_dec;
+        if(step < min_step)
+        {
+          result = 2;
+          break;
+        }
+      }
+      x = xc;
+      value = vc;
+    }
+    if(iter > max_iter && result == 0) result = 1;
+    skip = (static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask) | (~inmask & 0xffffu);
+    return result;
+  }
+
+  // ------------------------------------------------------------------------------------------------ backward pass
+  W64_FN const double * xcur() const { return I.xbuf + static_cast<long>(cur) * (P.N + 1) * S; }
+  W64_FN const double * ucur() const { return I.ubuf + static_cast<long>(cur) * P.N * kM; }
+
+  // oracle/ddp_tile.c backward_pass; returns false when a box-QP fails.  gnorm: sum_i max_c |k_c| / (|u_c| + 1)
+  CCC_TILE_PIECE bool backward_pass(double & gsum)
+  {
+    const int N = P.N;
+    const double * xs = xcur();
+    const double * us = ucur();
+    mem_sync(); // (the trajectory was written by other lanes of this wavefront)
+    // terminal value: src/DdpCentroidal.cpp:156-177 at x_N
+    for(int e = 0; e < S * S; e += 64) st(mem.Vxx, lane + e, splat(0.0), lane + e < S * S);
+    wave_sync();
+    st(mem.Vxx, seli(inS, c * S + c, spl(0)), ld(mem.wterm, c), inS && (g == 0));
+    {
+      const vf xN = ld_if(xs + static_cast<long>(N) * S, c, inS);
+      st(mem.Vx, c, sel(inS, ld(mem.wterm, c) * (xN - ref_of(N)), 0.0), g == 0);
+    }
+    wave_sync();
+    dV0 = 0.0;
+    dV1 = 0.0;
+    gsum = 0.0;
+    vf kprev = splat(0.0);
+    int mprev = -1;
+    // the operands of step i - 1 are fetched while step i computes
+    int ph_n = phase_of(N - 1), m_n = dim_of_phase(ph_n);
+    vf x_n = ld_if(xs + static_cast<long>(N - 1) * S, c, inS);
+    vf u_n = ld_if(us + static_cast<long>(N - 1) * kM, c, c < m_n);
+    for(int i = N - 1; i >= 0; i--)
+    {
+      const int m = m_n, ph = ph_n;
+      const vb in = c < m;
+      const vf x = x_n, u = u_n;
+      if(i > 0)
+      {
+        ph_n = phase_of(i - 1);
+        m_n = dim_of_phase(ph_n);
+        x_n = ld_if(xs + static_cast<long>(i - 1) * S, c, inS);
+        u_n = ld_if(us + static_cast<long>(i - 1) * kM, c, c < m_n);
+      }
+      Terms T;
+      terms_of(ph, m, x, u, T);
+      vf Fu[6];
+      state_eq_deriv(T, x, Fu);
+      // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
+      {
+        vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
+        const vi col = seli(inS, c, spl(0));
+        for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
+        st(mem.Qx, c, s, inS && (g == 0));
+      }
+      // Qu = Lu + Fu' Vx.  SPEC: s = w_force u_c; s = fma(Fu[b][c], Vx[b], s), b = FU0 .. FU0+5
+      vf Qu = P.w_force * u;
+      for(int b = 0; b < 6; b++) Qu = vfma(Fu[b], splat(mem.Vx[FU0 + b]), Qu);
+      Qu = sel(in, Qu, 0.0);
+      // T2 = Vxx Fu (rows a_t of column c).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
+      // (loops over the state index run with the three rows inside and a bounded unroll: fully unrolled, the scheduler
+      //  hoists every LDS load of a product and the registers of 3 x S x 2 operands do not fit four wavefronts per SIMD)
+      {
+        vf s3[3];
+        for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S + FU0) * Fu[0];
+        for(int b = 1; b < 6; b++)
+          for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + (FU0 + b)), Fu[b], s3[t]);
+        for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * kM + c, s3[t], aval[t]);
+      }
+      // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
+      const vi col = seli(inS, c, spl(0));
+      {
+        vf s3[3];
+        const vf f0 = ld(mem.Fx, col);
+        for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
+        W64_UNROLL(2)
+        for(int b = 1; b < S; b++)
+        {
+          const vf fb = ld(mem.Fx, col + b * S);
+          for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + b), fb, s3[t]);
+        }
+        for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
+      }
+      wave_sync();
+      // Quu = Luu + Fu' T2 (row c, columns 4g + s).  SPEC: s = (c == k) w_force; s = fma(Fu[b][c], T2[b][k], s), b ascending
+      // HF: lambda on the diagonal; hd: the unregularised diagonal entry (on the lane and slot that hold it)
+      vf HF[4], hd = splat(0.0);
+      {
+        vf s4v[4];
+        for(int s4 = 0; s4 < 4; s4++) s4v[s4] = sel(c == g * 4 + s4, splat(P.w_force), 0.0);
+        for(int b = 0; b < 6; b++)
+          for(int s4 = 0; s4 < 4; s4++) s4v[s4] = vfma(Fu[b], ld(mem.T2, g * 4 + s4 + (FU0 + b) * kM), s4v[s4]);
+        for(int s4 = 0; s4 < 4; s4++)
+        {
+          const vi k = g * 4 + s4;
+          const vb live = in && (k < m), dg = live && (c == k);
+          hd = sel(dg, s4v[s4], hd);
+          HF[s4] = sel(dg, s4v[s4] + lambda, sel(live, s4v[s4], 0.0));
+        }
+      }
+      // Qxu = Fx' T2 (rows a_t of column c).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
+      vf Qxu[3];
+      {
+        const vf t0 = ld(mem.T2, c);
+        for(int t = 0; t < 3; t++) Qxu[t] = ld(mem.Fx, arow[t]) * t0;
+        W64_UNROLL(2)
+        for(int b = 1; b < S; b++)
+        {
+          const vf tb = ld(mem.T2, c + b * kM);
+          for(int t = 0; t < 3; t++) Qxu[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxu[t]);
+        }
+        for(int t = 0; t < 3; t++) Qxu[t] = sel(in && aval[t], Qxu[t], 0.0);
+      }
+      // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
+      vf Qxx[3];
+      {
+        for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
+        W64_UNROLL(2)
+        for(int b = 0; b < S; b++)
+        {
+          const vf tb = ld(mem.T1, col + b * S);
+          for(int t = 0; t < 3; t++) Qxx[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxx[t]);
+        }
+      }
+      wave_sync();
+      for(int t = 0; t < 3; t++)
+      {
+        st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
+        st(mem.Zl, arow[t] * LT + c, Qxu[t], aval[t]);         // (Qxu waits in Z's place while the box-QP runs)
+      }
+      // box-QP and gains
+      vf k = splat(0.0);
+      vf K[3] = {splat(0.0), splat(0.0), splat(0.0)};
+      if(m > 0)
+      {
+        const vf lo = sel(in, P.flo - u, 0.0), hi = sel(in, P.fhi - u, 0.0);
+        // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
+        k = (mprev == m) ? kprev : splat(0.0);
+        unsigned skip;
+        vf rdv;
+        const int rc = box_qp(m, HF, Qu, lo, hi, k, skip, rdv);
+        if(rc < 1) return false;
+        // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
+        const vb fr = ((spl(static_cast<int>(skip)) >> c) & 1) == 0;
+        vf rhs[3];
+        for(int t = 0; t < 3; t++) rhs[t] = sel(fr, ld(mem.Zl, arow[t] * LT + c), 0.0);
+        solve<3>(rhs, skip, rdv);
+        for(int t = 0; t < 3; t++) K[t] = sel(fr && aval[t], -rhs[t], 0.0);
+      }
+      // gains -> global memory (the forward passes read them) and K' -> LDS
+      st(I.ks + static_cast<long>(i) * kM, c, k, g == 0);
+      for(int t = 0; t < 3; t++)
+      {
+        st(I.Ks + static_cast<long>(i) * kM * S, c * S + arow[t], K[t], aval[t]);
+        st(mem.T2, arow[t] * LT + c, K[t], aval[t]);
+      }
+      // termination measure: max_c |k_c| / (|u_c| + 1)
+      gsum += read_lane(max16(sel(in, vabs(k) / (vabs(u) + 1.0), 0.0)), 0);
+      // dV += [k'Qu, 1/2 k'Quu k].  SPEC: tree16(k_c Qu_c), 0.5 tree16(k_c (Quu k)_c)
+      vf H[4];
+      for(int s4 = 0; s4 < 4; s4++) H[s4] = sel(c == g * 4 + s4, hd, HF[s4]);
+      for(int t = 0; t < 3; t++) Qxu[t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c), 0.0);
+      const vf t4 = matvec(H, k, 0);
+      dV0 += read_lane(sum16(k * Qu), 0);
+      dV1 += 0.5 * read_lane(sum16(k * t4), 0);
+      // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + tree16
+      {
+        const vf q2 = t4 + Qu;
+        for(int t = 0; t < 3; t++)
+        {
+          const vf v = sum16(vfma(Qxu[t], k, K[t] * q2));
+          st(mem.vxn, arow[t], v, aval[t] && (c == 0));
+        }
+      }
+      wave_sync();
+      // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [matvec] + 2 Qxu[a][c]
+      wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
+      for(int t = 0; t < 3; t++)
+      {
+        W64_UNROLL(1)
+        for(int gg = 0; gg < 4; gg++)
+        {
+          const int a = gg + 4 * t;
+          if(a >= S) break;
+          vf yb[4];
+          for(int s4 = 0; s4 < 4; s4++) yb[s4] = ld(mem.T2, g * 4 + s4 + a * LT);
+          vf p = H[0] * yb[0];
+          for(int s4 = 1; s4 < 4; s4++) p = vfma(H[s4], yb[s4], p);
+          const vf z = sum_rows(p) + 2.0 * Qxu[t];
+          st(mem.Zl, c + a * LT, z, g == gg);
+        }
+      }
+      st(mem.Vx, c, ld(mem.Qx, seli(inS, c, spl(0))) + ld(mem.vxn, seli(inS, c, spl(0))), inS && (g == 0));
+      wave_sync();
+      // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + sum_c (K[c][a] Z[c][b] + K[c][b] Z[c][a]))
+      // SPEC: acc = 0; for c = 0 .. 15: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
+      for(int q = 0; q < NPASS; q++)
+      {
+        vf acc = splat(0.0);
+        W64_UNROLL(4)
+        for(int r = 0; r < kM; r++)
+        {
+          acc = vfma(ld(mem.T2, pa[q] * LT + r), ld(mem.Zl, pb[q] * LT + r), acc);
+          acc = vfma(ld(mem.T2, pb[q] * LT + r), ld(mem.Zl, pa[q] * LT + r), acc);
+        }
+        const vf v = 0.5 * ((ld(mem.T1, pa[q] * S + pb[q]) + ld(mem.T1, pb[q] * S + pa[q])) + acc);
+        st(mem.Vxx, pa[q] * S + pb[q], v, pval[q]);
+        st(mem.Vxx, pb[q] * S + pa[q], v, pval[q]);
+      }
+      wave_sync();
+      kprev = k;
+      mprev = m;
+    }
+    return true;
+  }
+
+  // ------------------------------------------------------------------------------------------------ forward passes
+  // Four candidates at once: row g rolls out alpha[first + g] into slot cand[g].  Returns the costs per row.
+  CCC_TILE_PIECE vf forward_pass(int first, const int (&cand)[4])
+  {
+    const int N = P.N;
+    const double * xs = xcur();
+    const double * us = ucur();
+    const vf alpha = ld(mem.alpha, seli(g + first < 12, g + first, spl(11)));
+    const vi slot = seli(g == 0, spl(cand[0]), seli(g == 1, spl(cand[1]), seli(g == 2, spl(cand[2]), spl(cand[3]))));
+    const vi xoff = slot * ((N + 1) * S), uoff = slot * (N * kM);
+    mem_sync(); // (the gains were written by other lanes of this wavefront)
+    vf x = ld_if(I.x0, c, inS);
+    vf costc = splat(0.0);
+    st(I.xbuf, xoff + c, x, inS);
+    // the operands of step i + 1 are fetched while step i computes
+    int ph_n = phase_of(0), m_n = dim_of_phase(ph_n);
+    vf xi_n = ld_if(xs, c, inS), ui_n = ld_if(us, c, c < m_n), ki_n = ld_if(I.ks, c, c < m_n);
+    vf Kr_n[S];
+    for(int a = 0; a < S; a++) Kr_n[a] = ld_if(I.Ks, c * S + a, c < m_n);
+    for(int i = 0; i < N; i++)
+    {
+      const int m = m_n, ph = ph_n;
+      const vb in = c < m;
+      const vf xi = xi_n, ui = ui_n, ki = ki_n;
+      vf Kr[S];
+      for(int a = 0; a < S; a++) Kr[a] = Kr_n[a];
+      if(i + 1 < N)
+      {
+        ph_n = phase_of(i + 1);
+        m_n = dim_of_phase(ph_n);
+        const vb inn = c < m_n;
+        xi_n = ld_if(xs + static_cast<long>(i + 1) * S, c, inS);
+        ui_n = ld_if(us + static_cast<long>(i + 1) * kM, c, inn);
+        ki_n = ld_if(I.ks + static_cast<long>(i + 1) * kM, c, inn);
+        for(int a = 0; a < S; a++) Kr_n[a] = ld_if(I.Ks + static_cast<long>(i + 1) * kM * S, c * S + a, inn);
+      }
+      const vf dx = x - xi;
+      // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
+      vf s = ui + alpha * ki;
+      s = feedback<0>(s, dx, Kr);
+      const vf un = sel(in, vmin(vmax(s, P.flo), P.fhi), 0.0);
+      st(I.ubuf, uoff + i * kM + c, un, c < kM);
+      costc = costc + running_cost(i, x, un);
+      Terms T;
+      terms_of(ph, m, x, un, T);
+      x = state_eq(T, x);
+      st(I.xbuf, xoff + (i + 1) * S + c, x, inS);
+    }
+    return costc + terminal_cost(x);
+  }
+  template<int A>
+  W64_FN vf feedback(vf s, vf dx, const vf (&Kr)[S]) const
+  {
+    if constexpr(A < S)
+    {
+      s = vfma(Kr[A], row_bcast<A>(dx), s);
+      return feedback<A + 1>(s, dx, Kr);
+    }
+    else
+      return s;
+  }
+
+  // the trajectory of the initial inputs (slot 0) and its cost
+  CCC_TILE_PIECE void initial_rollout()
+  {
+    const int N = P.N;
+    cur = 0;
+    vf x = ld_if(I.x0, c, inS);
+    vf cc = splat(0.0);
+    st(I.xbuf, c, x, inS && (g == 0));
+    for(int i = 0; i < N; i++)
+    {
+      const int ph = phase_of(i), m = dim_of_phase(ph);
+      const vb in = c < m;
+      const vf u = I.u_init ? ld_if(I.u_init + static_cast<long>(i) * kM, c, in) : splat(0.0);
+      st(I.ubuf, i * kM + c, u, g == 0);
+      cc = cc + running_cost(i, x, u);
+      Terms T;
+      terms_of(ph, m, x, u, T);
+      x = state_eq(T, x);
+      st(I.xbuf, (i + 1) * S + c, x, inS && (g == 0));
+    }
+    cost = read_lane(cc + terminal_cost(x), 0);
+  }
+
+  // ------------------------------------------------------------------------------------------------ the solve
+  W64_FN void increase_lambda()
+  {
+    dlambda = std::fmax(dlambda * P.lambda_factor, P.lambda_factor);
+    lambda = std::fmax(lambda * dlambda, P.lambda_min);
+  }
+  W64_FN void decrease_lambda()
+  {
+    dlambda = std::fmin(dlambda / P.lambda_factor, 1.0 / P.lambda_factor);
+    lambda = lambda * dlambda * (lambda > P.lambda_min ? 1.0 : 0.0);
+  }
+
+  // oracle/ddp.c oracle_ddp_solve
+  W64_FN void solve_instance()
+  {
+    init();
+    lambda = P.lambda0;
+    dlambda = P.dlambda0;
+    initial_rollout();
+    int iter = 0, status = 0;
+    for(iter = 1; iter <= P.max_iter; iter++)
+    {
+      bool bp_ok = false;
+      double gsum = 0.0;
+      for(;;)
+      {
+        if(backward_pass(gsum))
+        {
+          bp_ok = true;
+          break;
+        }
+        increase_lambda();
+        if(lambda > P.lambda_max) break;
+      }
+      if(!bp_ok)
+      {
+        status = -1;
+        break;
+      }
+      const double gn = gsum / P.N;
+      if(gn < P.k_rel_norm_thre && lambda < P.lambda_thre)
+      {
+        decrease_lambda();
+        status = 1;
+        break;
+      }
+      bool accepted = false;
+      double actual = 0.0;
+      int win = 0;
+      // the four slots that do not hold the current trajectory
+      int cand[4];
+      for(int q = 0, s = 0; s < kSlots; s++)
+        if(s != cur) cand[q++] = s;
+      for(int first = 0; first < 11 && !accepted; first += 4)
+      {
+        const vf costc = forward_pass(first, cand);
+        const vf alpha = ld(mem.alpha, seli(g + first < 12, g + first, spl(11)));
+        const vf act = cost - costc;
+        const vf expected = -alpha * (dV0 + alpha * dV1);
+        const vf ratio = sel(expected > 0.0, act / expected, sel(act > 0.0, 1.0, sel(act < 0.0, -1.0, 0.0)));
+        const vb acc = (ratio > P.ratio_thre) && (g + first < 11);
+        const unsigned long long am = ballot(acc);
+        if(am != 0ull)
+        {
+          // the first accepted step size in the list's order = the lowest row
+          win = (am & 0xffffull) ? 0 : ((am & 0xffff0000ull) ? 1 : ((am & 0xffff00000000ull) ? 2 : 3));
+          accepted = true;
+          actual = read_lane(act, 16 * win);
+          cost = read_lane(costc, 16 * win);
+        }
+      }
+      if(accepted)
+      {
+        decrease_lambda();
+        cur = cand[win];
+        if(actual < P.cost_thre)
+        {
+          status = 2;
+          break;
+        }
+      }
+      else
+      {
+        increase_lambda();
+        if(lambda > P.lambda_max)
+        {
+          status = -1;
+          break;
+        }
+      }
+    }
+    if(iter > P.max_iter) iter = P.max_iter;
+    mem_sync();
+    // results
+    {
+      const int N = P.N;
+      const double * xs = xcur();
+      const double * us = ucur();
+      for(int e = 0; e < N * kM; e += 64) st(I.u_out, lane + e, ld_if(us, lane + e, lane + e < N * kM), lane + e < N * kM);
+      if(I.x_out)
+        for(int e = 0; e < (N + 1) * S; e += 64)
+          st(I.x_out, lane + e, ld_if(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
+      if(I.out_iters) I.out_iters[0] = iter;
+      if(I.out_status) I.out_status[0] = status;
+      if(I.out_cost) I.out_cost[0] = cost;
+    }
+  }
+};
+} // namespace ddp_tile
+} // namespace ccc_amd

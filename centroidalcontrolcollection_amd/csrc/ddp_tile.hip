@@ -1,0 +1,71 @@
+// ddp_tile.hip -- the TILE build of the DDP planners (csrc/ddp_tile.h): CCC::DdpCentroidal / CCC::DdpSingleRigidBody with
+// <= 16 ridges per step and the default regularisation, one instance per wavefront, every matrix distributed over the
+// 64 lanes, <= 128 VGPRs and <= 10 KB of LDS per wavefront: four wavefronts per SIMD, sixteen instances per CU.
+// What ccc_ddp_plan_batch_device runs by default for these sizes (csrc/ddp.hip); its arithmetic is the tile
+// specification of oracle/ddp_tile.c, reproduced bit for bit (tests/test_ddp_gpu.py, tests/test_ddp_tile_emu.py).
+// Replaces the same reference code as csrc/ddp.hip.
+#include "ddp_tile.h"
+
+#include "ddp_batch.h"
+
+namespace ccc_amd
+{
+// doubles of workspace per instance: trajectories [kSlots][N+1][S] and [kSlots][N][16], gains [N][16] and [N][16][S]
+size_t ddp_tile_ws_doubles(int N, int S)
+{
+  return (size_t)ddp_tile::kSlots * ((size_t)(N + 1) * S + (size_t)N * ddp_tile::kM) + (size_t)N * ddp_tile::kM
+         + (size_t)N * ddp_tile::kM * S;
+}
+
+#ifndef CCC_TILE_WAVES
+#  define CCC_TILE_WAVES 4
+#endif
+template<int S>
+__global__ __launch_bounds__(64, CCC_TILE_WAVES) void ddp_tile_kernel(ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride,
+                                                         long n)
+{
+  __shared__ ddp_tile::Mem<S> mem;
+  constexpr int M = ddp_tile::kM;
+  const int N = P.N;
+  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  {
+    ddp_tile::Instance I;
+    I.phase_dim = B.phase_dim + b * P.P;
+    I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
+    I.phase_ridge = B.phase_ridge + b * P.P * M * 3;
+    I.step_phase = B.step_phase + b * N;
+    I.ref_pos = B.ref_pos + b * (N + 1) * 3;
+    I.ref_ori = B.ref_ori ? B.ref_ori + b * (N + 1) * 3 : nullptr;
+    I.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
+    I.x0 = B.x0 + b * S;
+    I.u_init = B.u_init ? B.u_init + b * N * M : nullptr;
+    double * w = ws + (size_t)b * ws_stride;
+    I.xbuf = w;
+    w += (size_t)ddp_tile::kSlots * (N + 1) * S;
+    I.ubuf = w;
+    w += (size_t)ddp_tile::kSlots * N * M;
+    I.ks = w;
+    w += (size_t)N * M;
+    I.Ks = w;
+    I.u_out = B.u_out + b * N * M;
+    I.x_out = B.x_out ? B.x_out + b * (N + 1) * S : nullptr;
+    I.out_iters = B.iters ? B.iters + b : nullptr;
+    I.out_status = B.status ? B.status + b : nullptr;
+    I.out_cost = B.cost ? B.cost + b : nullptr;
+    ddp_tile::Solver<S> solver(P, I, mem);
+    solver.solve_instance();
+    __syncthreads();
+  }
+}
+
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, hipStream_t stream)
+{
+  const int grid = (int)(n < (1L << 22) ? n : (1L << 22)); // one workgroup per instance: the dispatcher balances
+  const size_t stride = ddp_tile_ws_doubles(P.N, S);
+  if(S == 9)
+    hipLaunchKernelGGL((ddp_tile_kernel<9>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n);
+  else
+    hipLaunchKernelGGL((ddp_tile_kernel<12>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n);
+  return hipGetLastError();
+}
+} // namespace ccc_amd

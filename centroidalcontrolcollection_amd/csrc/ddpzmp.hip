@@ -961,6 +961,7 @@ extern "C" void ccc_ddpzmp_default_config(ccc_ddp_config_t * c)
   c->cost_update_thre = 1e-7;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
   c->reg_type = 1;
+  c->precision = 64;
 }
 
 extern "C" int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_steps, const double * weights, int device,
@@ -1008,6 +1009,8 @@ extern "C" int ccc_ddpzmp_set_config(ccc_ddpzmp_t * h, const ccc_ddp_config_t * 
   if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: NULL argument");
   if(cfg->max_iter < 0) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: max_iter < 0");
   if(cfg->reg_type != 1 && cfg->reg_type != 2) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddpzmp_set_config: reg_type must be 1 or 2");
+  if(cfg->precision != 64)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddpzmp_set_config: precision = %d, the DdpZmp kernel is fp64 only", cfg->precision);
   h->P.cfg = *cfg;
   return CCC_OK;
 }

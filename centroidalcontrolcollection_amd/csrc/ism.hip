@@ -626,6 +626,9 @@ struct ccc_ism
   double *d_in = nullptr, *d_out = nullptr;
   int32_t * d_status = nullptr;
   hipStream_t stream = nullptr;
+  // development switches, read ONCE in ccc_ism_create (never per launch)
+  bool env_tableau = false;
+  int env_pcr_outer = -1; // CCC_ISM_PCR_OUTER: the outer budget (small values exercise the list); < 0: the default
 };
 
 namespace
@@ -738,6 +741,8 @@ extern "C" int ccc_ism_create(double com_height, double horizon_duration, double
   CCC_DEVICE_GUARD(device);
   ccc_ism * h = new ccc_ism();
   h->device = device;
+  h->env_tableau = std::getenv("CCC_ISM_TABLEAU") != nullptr;
+  if(const char * mo = std::getenv("CCC_ISM_PCR_OUTER")) h->env_pcr_outer = std::atoi(mo);
   h->N = N;
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
@@ -801,15 +806,14 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
     CCC_HIP_CHECK(hipMalloc(&h->redo, (size_t)(nqp + 1) * sizeof(int)));
     h->redo_cap = nqp;
   }
-  const bool tableau_only = std::getenv("CCC_ISM_TABLEAU") != nullptr || h->N > kPcrNP; // (development switch)
+  const bool tableau_only = h->env_tableau || h->N > kPcrNP;
   if(!tableau_only)
   {
     // default path: tridiagonal projected Newton, one QP per wavefront; what it cannot finish goes onto the list
     if(int zrc = zero_words(h->redo, 1, s)) return zrc;
     IsmPcrDev Q{h->N, h->dAt, h->a0_dt, h->w_zmp, h->w_zmp_vel, h->horizon_dt};
-    const char * mo = std::getenv("CCC_ISM_PCR_OUTER"); // (development switch: the outer budget; small values exercise the list)
     hipLaunchKernelGGL(ism_plan_pcr_kernel, dim3((unsigned)((nqp + 3) / 4)), dim3(256), 0, s, Q, (long)nqp, init, ref,
-                       control_dt, zmp, vel, status, h->redo + 1, h->redo, mo ? std::atoi(mo) : kPcrOuter);
+                       control_dt, zmp, vel, status, h->redo + 1, h->redo, h->env_pcr_outer >= 0 ? h->env_pcr_outer : kPcrOuter);
     CCC_HIP_CHECK(hipGetLastError());
   }
   const int * rl = tableau_only ? nullptr : h->redo + 1;

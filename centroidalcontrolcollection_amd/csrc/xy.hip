@@ -1402,6 +1402,10 @@ struct ccc_xy
   // the dual active-set kernel works off the first round's hand-overs beside the later rounds, on a stream of its own
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // development switches, read ONCE in ccc_xy_create (never per launch)
+  bool env_safeguard = false, env_dual = false, env_stream = false;
+  int env_pdas_iters = -1; // CCC_XY_PDAS_ITERS (< 0: the default cap)
+  std::string env_rounds;  // CCC_XY_ROUNDS ("": the default round boundaries)
 };
 
 extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** out)
@@ -1424,6 +1428,11 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   h->M = p->max_ridges ? p->max_ridges : CCC_XY_MAX_RIDGES;
   h->prm.max_ridges = h->M;
   h->wide = h->M != kXyM || p->horizon_steps > kXyMaxN;
+  h->env_safeguard = std::getenv("CCC_XY_SAFEGUARD") != nullptr;
+  h->env_dual = std::getenv("CCC_XY_DUAL") != nullptr;
+  h->env_stream = std::getenv("CCC_XY_STREAM") != nullptr;
+  if(const char * mi = std::getenv("CCC_XY_PDAS_ITERS")) h->env_pdas_iters = std::atoi(mi);
+  if(const char * rs = std::getenv("CCC_XY_ROUNDS")) h->env_rounds = rs;
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if(e != hipSuccess)
@@ -1528,10 +1537,8 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   // 16384); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
   // CCC_XY_SAFEGUARD (development switch): the single-change rounds instead of the dual kernel where both apply
-  const bool safeguard = h->wide || std::getenv("CCC_XY_SAFEGUARD") != nullptr;
-  const bool dual_only = !safeguard
-                         && (std::getenv("CCC_XY_DUAL") != nullptr
-                             || (n < 4096 && !std::getenv("CCC_XY_STREAM") && !std::getenv("CCC_XY_PDAS_ITERS")));
+  const bool safeguard = h->wide || h->env_safeguard;
+  const bool dual_only = !safeguard && (h->env_dual || (n < 4096 && !h->env_stream && h->env_pdas_iters < 0));
   auto launch_stream = [&](const XyWork & Wk, int it_begin, int it_end) {
     const dim3 g((unsigned)((n + kXsLanes - 1) / kXsLanes)), b(kXsLanes);
     if(h->M == 16 && !Wk.single)
@@ -1545,15 +1552,13 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   };
   if(!dual_only)
   {
-    const char * mi = std::getenv("CCC_XY_PDAS_ITERS"); // (development switch: small values exercise the work list)
-    const int cap = mi ? std::atoi(mi) : kXsMaxIt;
+    const int cap = h->env_pdas_iters >= 0 ? h->env_pdas_iters : kXsMaxIt; // (small values exercise the work list)
     // rounds of iterations (development switch CCC_XY_ROUNDS="a,b": the iteration counts at which the instances still
     // going are repacked; the instances of a wavefront need very different numbers of iterations, and a wavefront is as
     // slow as its slowest lane)
     int ends[kXsRounds], nr = 0;
     {
-      const char * rs = std::getenv("CCC_XY_ROUNDS");
-      std::string spec = rs ? rs : kXsRoundsDefault;
+      std::string spec = h->env_rounds.empty() ? std::string(kXsRoundsDefault) : h->env_rounds;
       size_t pos = 0;
       while(pos < spec.size() && nr < kXsRounds - 1)
       {

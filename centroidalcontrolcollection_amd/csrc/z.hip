@@ -581,6 +581,9 @@ struct ccc_z
   // workspace of the streaming kernel, grown to the largest batch seen
   char * ws = nullptr;
   int64_t ws_cap = 0;
+  // development switches, read ONCE in ccc_z_create (never per launch)
+  bool env_tableau = false, env_stream = false;
+  int env_sweeps = -1; // CCC_Z_SWEEPS: the sweep budget (small values exercise the fallback); < 0: the default
 };
 
 extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, double w_pos, double w_force, int device,
@@ -599,6 +602,9 @@ extern "C" int ccc_z_create(double mass, double horizon_dt, int horizon_steps, d
   CCC_DEVICE_GUARD(device);
   ccc_z * h = new ccc_z();
   h->device = device;
+  h->env_tableau = std::getenv("CCC_Z_TABLEAU") != nullptr;
+  h->env_stream = std::getenv("CCC_Z_STREAM") != nullptr;
+  if(const char * mi = std::getenv("CCC_Z_SWEEPS")) h->env_sweeps = std::atoi(mi);
   h->N = horizon_steps;
   h->mass = mass;
   h->dt = horizon_dt;
@@ -662,14 +668,13 @@ extern "C" int ccc_z_plan_batch_device(ccc_z_t * h, int64_t n, const int32_t * c
   // beyond the 64 steps of the tableau kernel: the streaming kernel alone, whatever the batch size, with a budget that
   // is a bound on the projected-Newton iteration (a descent method on a convex QP: it converges), not a hand-over point
   const bool wide = h->N > kZNP;
-  const bool tableau_only = !wide && (std::getenv("CCC_Z_TABLEAU") != nullptr ||
-                            (n * (int64_t)h->N < (int64_t)24576 * 40 && !std::getenv("CCC_Z_STREAM") && !std::getenv("CCC_Z_SWEEPS")));
+  const bool tableau_only = !wide && (h->env_tableau ||
+                            (n * (int64_t)h->N < (int64_t)24576 * 40 && !h->env_stream && h->env_sweeps < 0));
   if(!tableau_only)
   {
     if(int zrc = zero_words(W.redo_count, 1, s)) return zrc;
-    const char * mi = std::getenv("CCC_Z_SWEEPS"); // (development switch: the sweep budget; small values exercise the fallback)
     hipLaunchKernelGGL(z_plan_stream_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P, B, W, (long)n,
-                       wide ? 40 * kZMaxSweeps : (mi ? std::atoi(mi) : kZMaxSweeps), wide ? 1 : 0);
+                       wide ? 40 * kZMaxSweeps : (h->env_sweeps >= 0 ? h->env_sweeps : kZMaxSweeps), wide ? 1 : 0);
     CCC_HIP_CHECK(hipGetLastError());
     if(wide) return CCC_OK;
   }

@@ -942,6 +942,12 @@ struct ccc_zmp
   double *d_in = nullptr, *d_out = nullptr;
   int32_t *h_status = nullptr, *d_status = nullptr;
   hipStream_t stream = nullptr;
+  // development switches, read ONCE in ccc_zmp_create (never per launch)
+  int64_t env_queue_min = -1;   // CCC_ZMP_QUEUE_MIN: QPs from which the work-queue kernel runs (< 0: the measured default)
+  bool env_static = false;      // CCC_ZMP_STATIC: never the work-queue kernel
+  bool env_debug = false;       // CCC_ZMP_DEBUG: print the occupancy of the LDS-tableau kernels
+  int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
+  const char * last_kernel = "none"; // the kernel the last plan call launched (ccc_zmp_last_kernel)
 };
 
 namespace
@@ -1025,9 +1031,10 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   // pairing (one instance per wavefront, more workgroups than fit: the hardware dispatcher balances) is faster -- measured
   // static / queue in M solves/s: 83.7 / 65.4 at 16384 instances, 90.3 / 83.3 at 32768, 95.1 / 93.2 at 49152,
   // 96.2 / 96.5 at 57344, 94.4 / 98.3 at 65536
-  int64_t queue_min = (int64_t)18 * h->num_cu * 12 * QPW;
-  if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) queue_min = std::atoll(qm); // (development switch)
-  const bool use_queue = !std::getenv("CCC_ZMP_STATIC") && nqp >= queue_min;
+  const int64_t queue_min = h->env_queue_min >= 0 ? h->env_queue_min : (int64_t)18 * h->num_cu * 12 * QPW;
+  const bool use_queue = !h->env_static && nqp >= queue_min;
+  h->last_kernel = use_queue ? (LG == 32 ? "zmp_plan_kernel_dyn<32,2>" : "zmp_plan_kernel_dyn")
+                             : (LG == 32 ? "zmp_plan_kernel<32,2>" : "zmp_plan_kernel");
   if(use_queue)
   {
     if(!h->attr_dyn)
@@ -1067,6 +1074,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 {
   const int64_t nqp = 2 * n;
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  h->last_kernel = h->N > 200 ? "zmp_plan_block_kernel" : "zmp_plan_sym_kernel";
   if(h->N > 200) // beyond the LDS: the tableau in HBM
   {
     const int blocks = h->num_cu * 2;
@@ -1091,7 +1099,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
-    if(std::getenv("CCC_ZMP_DEBUG"))
+    if(h->env_debug)
     {
       int nb = -1;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, ST::NT, lds);
@@ -1125,6 +1133,11 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 }
 } // namespace
 
+extern "C" const char * ccc_zmp_last_kernel(const ccc_zmp_t * h)
+{
+  return h ? h->last_kernel : "none";
+}
+
 extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double horizon_dt, int device,
                               ccc_zmp_t ** out)
 {
@@ -1145,6 +1158,10 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
   h->horizon_dt = horizon_dt;
+  if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) h->env_queue_min = std::atoll(qm);
+  h->env_static = std::getenv("CCC_ZMP_STATIC") != nullptr;
+  h->env_debug = std::getenv("CCC_ZMP_DEBUG") != nullptr;
+  if(const char * ce = std::getenv("CCC_ZMP_HOST_CHUNK")) h->env_host_chunk = std::atoll(ce);
   build_model(h);
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -1346,8 +1363,7 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
       o_st = h->d_status;
     }
     int64_t chunk = in_pinned ? n : 8192;
-    if(const char * ce = std::getenv("CCC_ZMP_HOST_CHUNK")) // (development switch)
-      chunk = std::max<int64_t>(256, std::min<int64_t>(std::atoll(ce), n));
+    if(h->env_host_chunk > 0) chunk = std::max<int64_t>(256, std::min<int64_t>(h->env_host_chunk, n));
     for(int64_t b = 0; b < n; b += chunk)
     {
       const size_t m = (size_t)std::min<int64_t>(chunk, n - b), o = (size_t)b;

@@ -46,6 +46,8 @@ def _bind(L):
     L.ccc_ddp_set_config.argtypes = [vp, ctypes.POINTER(Config)]
     L.ccc_ddp_state_dim.restype = ctypes.c_int
     L.ccc_ddp_state_dim.argtypes = [vp]
+    L.ccc_ddp_arithmetic.restype = ctypes.c_int
+    L.ccc_ddp_arithmetic.argtypes = [vp]
     L.ccc_ddp_plan_batch_device.restype = ctypes.c_int
     L.ccc_ddp_plan_batch_device.argtypes = [vp, ctypes.c_int64] + [vp] * 15
     L.ccc_ddp_plan_batch.restype = ctypes.c_int
@@ -90,8 +92,9 @@ class _DdpBase:
         p.w_force = float(w_force)
         p.force_scale_limits[0], p.force_scale_limits[1] = 0.0, 1e6  # force_scale_limits_, DdpCentroidal.h:364
         p.max_phases = int(max_phases)
-        p.max_ridges = int(max_ridges)
-        self.max_ridges_ = int(max_ridges)
+        max_ridges = int(max_ridges) or MAX_RIDGES  # (the C-ABI reads 0 as the default stride, 16)
+        p.max_ridges = max_ridges
+        self.max_ridges_ = max_ridges
         self._w_run, self._w_term, self._w_force = list(w_run), list(w_term), float(w_force)
         h = ctypes.c_void_p()
         _lib.check(L.ccc_ddp_create(ctypes.byref(p), int(device), ctypes.byref(h)))
@@ -152,6 +155,12 @@ class _DdpBase:
                                               p(arr.get("ref_ori")), p(arr.get("inertia")), p(x0), p(ui), p(u), p(x),
                                               p(iters), p(status), p(cost)))
         return dict(u=u, x=x, iters=iters, status=status, cost=cost)
+
+    def arithmetic(self):
+        """ccc_ddp_arithmetic for the object's current solver configuration: 1 = the tile arithmetic
+        (oracle/ddp_tile.c), 0 = left-to-right sums (oracle/ddp.c)."""
+        _lib.check(self._L.ccc_ddp_set_config(self._h, ctypes.byref(self.ddp_solver_.config())))
+        return int(self._L.ccc_ddp_arithmetic(self._h))
 
     def plan_batch_device(self, prob, x0, u_out, u_init=None, x_out=None, iters=None, status=None, cost=None,
                           stream=None):

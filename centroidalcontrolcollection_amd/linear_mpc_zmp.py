@@ -60,6 +60,10 @@ class LinearMpcZmp:
                                            B.ctypes.data_as(_lib.c_double_p)))
         return A, B
 
+    def last_kernel(self):
+        """Name of the kernel the last plan call launched (ccc_zmp_last_kernel): what a profile of that call lists."""
+        return self._L.ccc_zmp_last_kernel(self._h).decode()
+
     # ------------------------------------------------------------------ reference surface
     def sample(self, ref_data_func, current_time):
         """src/LinearMpcZmp.cpp:86-98: sample the callback at current_time + i*horizon_dt into [2,2,N]."""

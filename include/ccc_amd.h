@@ -66,6 +66,10 @@ int ccc_zmp_horizon_steps(const ccc_zmp_t * h);
 /* host copies of seq_ext_->A_seq_ (N x 3) and seq_ext_->B_seq_ (N x N), row-major
  * (include/CCC/InvariantSequentialExtension.h:191-194); either pointer may be NULL */
 int ccc_zmp_get_seq(const ccc_zmp_t * h, double * A_seq, double * B_seq);
+/* Name of the kernel the handle's last plan call launched ("zmp_plan_kernel_dyn<32,2>", "zmp_plan_kernel<32,2>",
+ * "zmp_plan_sym_kernel", "zmp_plan_block_kernel", "none" before the first call): what a profile of that call lists.
+ * New -- no reference counterpart; for measurement code (bench.py's roofline object). */
+const char * ccc_zmp_last_kernel(const ccc_zmp_t * h);
 
 /* Replaces n calls of CCC::LinearMpcZmp::planOnce(ref_data_func, initial_param, current_time, control_dt)
  * (include/CCC/LinearMpcZmp.h:151-154, src/LinearMpcZmp.cpp:83-112) with the callbacks already
@@ -188,6 +192,11 @@ int ccc_ddp_state_dim(const ccc_ddp_t * h);
 int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params);
 int ccc_ddp_get_config(const ccc_ddp_t * h, ccc_ddp_config_t * cfg);
 int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
+/* Which frozen ORDER OF THE LONG SUMS the handle's current configuration computes in (nmpc_ddp forms them with Eigen,
+ * whose order is not pinned): 1 = the tile arithmetic (oracle/ddp_tile.c: trees, fma chains, LDL') of the default kernel
+ * for max_ridges = 16, reg_type 1, precision 64; 0 = left-to-right sums (oracle/ddp.c: max_ridges = 32, reg_type 2,
+ * precision 32).  Results of the two agree to rounding; bit-for-bit parity tests ask which one applies.  New. */
+int ccc_ddp_arithmetic(const ccc_ddp_t * h);
 
 /* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,
  * initial_param, current_time) (src/DdpCentroidal.cpp:213-237, src/DdpSingleRigidBody.cpp:283-307) including the
@@ -446,6 +455,8 @@ typedef struct
  * input sequence UNSHIFTED with the steps whose input dimension changed zeroed (:118-127), planOnce with max_iter =
  * first_max_iter in the first cycle and warm_max_iter afterwards (:125), t += sim_dt, CentroidalSim::update with the
  * total wrench of u_list[0] about the CoM, the linear kick disturb_lin when disturb_time <= t < disturb_time + sim_dt.
+ *   disturb_times [n_disturb <= 8], disturb_lin [3]  HOST arrays (read before the first cycle is enqueued): one
+ *                              linear kick vector, applied at every disturb_times[d]; every other pointer is a DEVICE pointer
  *   inertia_diag [n][3]   f64  moment of inertia of the simulator (the SRB planner takes diag(inertia_diag))
  *   sim_state    [n][18]  f64  in/out: pos, ori (X, Y, Z), vel, ang_vel, linear momentum, angular momentum
  *   stats        [n][8]   f64  optional: max over the cycles, taken where the test asserts (before the update), of

@@ -51,6 +51,7 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
   c->cost_update_ratio_thre = 0.0;
   c->cost_update_thre = 1e-7;
   c->reg_type = 1;
+  c->arith = 0;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = pow(10.0, -3.0 * i / 10.0);
 }
 

@@ -391,8 +391,13 @@ int oracle_ddp_plan_batch(const oracle_ddp_model_t * shared, const oracle_ddp_co
     oracle_ddp_problem_t prob;
     oracle_ddp_model_problem(&mdl, &prob);
     oracle_ddp_result_t res;
-    int st = oracle_ddp_solve(&prob, cfg, x0 + (size_t)b * S, u_init ? u_init + (size_t)b * N * M : NULL,
-                              x_out ? x_out + (size_t)b * (N + 1) * S : NULL, u_out + (size_t)b * N * M, &res);
+    int st;
+    if(cfg->arith == 1)
+      st = oracle_ddp_solve_tile(&mdl, cfg, x0 + (size_t)b * S, u_init ? u_init + (size_t)b * N * M : NULL,
+                                 x_out ? x_out + (size_t)b * (N + 1) * S : NULL, u_out + (size_t)b * N * M, &res);
+    else
+      st = oracle_ddp_solve(&prob, cfg, x0 + (size_t)b * S, u_init ? u_init + (size_t)b * N * M : NULL,
+                            x_out ? x_out + (size_t)b * (N + 1) * S : NULL, u_out + (size_t)b * N * M, &res);
     if(iters) iters[b] = res.iters;
     if(status) status[b] = st;
     if(cost) cost[b] = res.cost;

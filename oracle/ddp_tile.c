@@ -1,0 +1,752 @@
+/* ddp_tile.c -- the DDP solver of oracle/ddp.c + the problems of oracle/ddp_models.c in the "TILE" ARITHMETIC
+ * (oracle_ddp_config_t::arith = 1; TEST INFRASTRUCTURE ONLY, see ccc_oracle.h).
+ *
+ * Same algorithm, same reference lines (nmpc_ddp::DDPSolver::solve at /root/reference/src/DdpCentroidal.cpp:229,233 and
+ * src/DdpSingleRigidBody.cpp:299,303; the problem callbacks src/DdpCentroidal.cpp:32-177 and
+ * src/DdpSingleRigidBody.cpp:26-243): every statement below has its counterpart in ddp.c / ddp_models.c.  What changes
+ * is the ORDER in which the long sums are formed -- nmpc_ddp forms them with Eigen, whose order is not pinned either, so
+ * no order is more faithful than another (parity unpinned at this boundary).  Round 1-2 froze plain
+ * left-to-right sums (arith = 0, still what the 32-ridge "wide" kernels run); this file freezes the orders a 64-lane
+ * wavefront produces without serialising:
+ *   tree16   sums over the (up to) 16 ridges of a step:  ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)) + the same of t8..t15
+ *   rows4    16-term dot products with a row of Quu: four fma chains over 4 consecutive columns, then (p0+p1)+(p2+p3)
+ *   chains   products over the state dimension: one fma chain in increasing index
+ *   LDL'     the box-QP factorisation without square roots: d_j = a_jj, r_j = 1/d_j, l_cj = a_cj r_j,
+ *            a_ck <- fma(-(a_cj a_kj), r_j, a_ck); substitutions column by column with fma
+ *   value    Vxx = sym(Qxx) + 1/2 (K'Z + Z'K) with Z = Quu K + 2 Qux (algebraically the Vxx of ddp.c)
+ * Inputs beyond a step's dimension are exact zeros and take part in the sums (x + 0 = x).  Only 16-ridge strides
+ * (M = 16) and reg_type 1 exist in this arithmetic.  All elementwise formulas (cross products, Euler-angle kinematics,
+ * the 3x3 inertia solves, cost terms) are those of ddp_models.c, unfused; fma() appears exactly where written.
+ * The two arithmetics agree to rounding (tests/test_oracle_ddp_tile.py) and the HIP kernel csrc/ddp_tile.h reproduces
+ * this file bit for bit.
+ */
+#include "ccc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define G_ 9.80665
+#define M_ 16
+
+static double tree16(const double * t)
+{
+  double a[8], b[4];
+  for(int j = 0; j < 8; j++) a[j] = t[2 * j] + t[2 * j + 1];
+  for(int j = 0; j < 4; j++) b[j] = a[2 * j] + a[2 * j + 1];
+  const double c0 = b[0] + b[1], c1 = b[2] + b[3];
+  return c0 + c1;
+}
+
+/* (H y)_c for a 16 x 16 row-major H: four fma chains over the column blocks, then (p0 + p1) + (p2 + p3) */
+static double rows4(const double * Hrow, const double * y)
+{
+  double p[4];
+  for(int g = 0; g < 4; g++)
+  {
+    double s = Hrow[4 * g] * y[4 * g];
+    for(int k = 1; k < 4; k++) s = fma(Hrow[4 * g + k], y[4 * g + k], s);
+    p[g] = s;
+  }
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
+static void cross3(const double * a, const double * b, double * c)
+{
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* Eigen::LLT<Matrix3d>::solve, src/DdpSingleRigidBody.cpp:88,122-123 (as ddp_models.c) */
+static void llt3_solve(const double * I, const double * b, double * x)
+{
+  const double l00 = sqrt(I[0]);
+  const double l10 = I[3] / l00, l20 = I[6] / l00;
+  const double l11 = sqrt(I[4] - l10 * l10);
+  const double l21 = (I[7] - l20 * l10) / l11;
+  const double l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
+  const double y0 = b[0] / l00;
+  const double y1 = (b[1] - l10 * y0) / l11;
+  const double y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
+  x[2] = y2 / l22;
+  x[1] = (y1 - l21 * x[2]) / l11;
+  x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+}
+
+typedef struct
+{
+  const oracle_ddp_model_t * m;
+  const oracle_ddp_config_t * c;
+  int S, N;
+  double *x, *u;          /* current trajectory */
+  double *xc[4], *uc[4];  /* line-search candidates */
+  double *k, *K;          /* gains N x 16, N x 16 x S */
+  double cost, dV[2], lambda, dlambda;
+} tile_t;
+
+static int dim_of(const oracle_ddp_model_t * m, int step)
+{
+  int p = m->step_phase[step];
+  p = p < 0 ? 0 : (p >= m->P ? m->P - 1 : p);
+  int d = m->phase_dim[p];
+  return d < 0 ? 0 : (d > M_ ? M_ : d);
+}
+static int phase_of(const oracle_ddp_model_t * m, int step)
+{
+  int p = m->step_phase[step];
+  return p < 0 ? 0 : (p >= m->P ? m->P - 1 : p);
+}
+
+static void ref_of(const oracle_ddp_model_t * m, int step, double * buf)
+{
+  const int S = m->model == 0 ? 9 : 12;
+  for(int a = 0; a < S; a++) buf[a] = 0;
+  for(int a = 0; a < 3; a++) buf[a] = m->ref_pos[(size_t)step * 3 + a];
+  if(m->model == 1)
+    for(int a = 0; a < 3; a++) buf[3 + a] = m->ref_ori[(size_t)step * 3 + a];
+}
+
+/* what stateEq and its derivatives share: per ridge (zero beyond the dimension) vertex, ridge, arm x ridge, and the
+ * ridge sums as trees */
+typedef struct
+{
+  double V[M_][3], R[M_][3], cr[M_][3];
+  double force[3], moment[3], accel[3];
+} terms_t;
+
+static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, const double * u, terms_t * T)
+{
+  const int dim = dim_of(m, step), ph = phase_of(m, step);
+  const double * V = m->phase_vertex + (size_t)ph * M_ * 3;
+  const double * R = m->phase_ridge + (size_t)ph * M_ * 3;
+  for(int r = 0; r < M_; r++)
+  {
+    for(int k = 0; k < 3; k++)
+    {
+      T->V[r][k] = r < dim ? V[r * 3 + k] : 0.0;
+      T->R[r][k] = r < dim ? R[r * 3 + k] : 0.0;
+    }
+    const double d[3] = {T->V[r][0] - x[0], T->V[r][1] - x[1], T->V[r][2] - x[2]};
+    cross3(d, T->R[r], T->cr[r]);
+  }
+  for(int k = 0; k < 3; k++)
+  {
+    double t[M_];
+    for(int r = 0; r < M_; r++) t[r] = u[r] * T->R[r][k];
+    T->force[k] = tree16(t);
+    for(int r = 0; r < M_; r++) t[r] = u[r] * T->cr[r][k];
+    T->moment[k] = tree16(t);
+    for(int r = 0; r < M_; r++) t[r] = (u[r] * T->R[r][k]) / m->mass;
+    T->accel[k] = tree16(t);
+  }
+}
+
+/* src/DdpCentroidal.cpp:32-64 / src/DdpSingleRigidBody.cpp:52-91 */
+static void state_eq(const oracle_ddp_model_t * m, const terms_t * T, const double * x, double * xn)
+{
+  if(m->model == 0)
+  {
+    double xd[9];
+    for(int a = 0; a < 3; a++) xd[a] = x[3 + a] / m->mass;
+    xd[3] = T->force[0];
+    xd[4] = T->force[1];
+    xd[5] = -1 * m->mass * G_ + T->force[2];
+    for(int a = 0; a < 3; a++) xd[6 + a] = T->moment[a];
+    for(int a = 0; a < 9; a++) xn[a] = x[a] + m->dt * xd[a];
+  }
+  else
+  {
+    const double * I = m->inertia;
+    const double * w = x + 9;
+    double xd[12], sa, ca, sb, cb;
+    for(int a = 0; a < 3; a++) xd[a] = x[6 + a];
+    oracle_det_sincos(x[3], &sa, &ca);
+    oracle_det_sincos(x[4], &sb, &cb);
+    /* matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72 */
+    xd[3] = ((ca * sb) / cb) * w[0] + ((sb * sa) / cb) * w[1] + 1.0 * w[2];
+    xd[4] = (-1 * sa) * w[0] + ca * w[1] + 0.0 * w[2];
+    xd[5] = (ca / cb) * w[0] + (sa / cb) * w[1] + 0.0 * w[2];
+    xd[6] = T->accel[0];
+    xd[7] = T->accel[1];
+    xd[8] = -1 * G_ + T->accel[2];
+    double Iw[3], cw[3], wd[3];
+    for(int a = 0; a < 3; a++) Iw[a] = I[a * 3] * w[0] + I[a * 3 + 1] * w[1] + I[a * 3 + 2] * w[2];
+    cross3(w, Iw, cw);
+    for(int a = 0; a < 3; a++) wd[a] = -1 * cw[a] + T->moment[a];
+    llt3_solve(I, wd, xd + 9);
+    for(int a = 0; a < 12; a++) xn[a] = x[a] + m->dt * xd[a];
+  }
+}
+
+/* src/DdpCentroidal.cpp:66-83 */
+static double running_cost(const oracle_ddp_model_t * m, int step, const double * x, const double * u)
+{
+  const int S = m->model == 0 ? 9 : 12;
+  double ref[12], t[M_];
+  ref_of(m, step, ref);
+  for(int a = 0; a < M_; a++)
+  {
+    const double e = a < S ? x[a] - ref[a] : 0.0;
+    t[a] = a < S ? 0.5 * m->w_run[a] * e * e : 0.0;
+  }
+  const double cx = tree16(t);
+  for(int r = 0; r < M_; r++) t[r] = u[r] * u[r];
+  const double un = tree16(t);
+  return cx + 0.5 * m->w_force * un;
+}
+static double terminal_cost(const oracle_ddp_model_t * m, const double * x)
+{
+  const int S = m->model == 0 ? 9 : 12;
+  double ref[12], t[M_];
+  ref_of(m, m->N, ref);
+  for(int a = 0; a < M_; a++)
+  {
+    const double e = a < S ? x[a] - ref[a] : 0.0;
+    t[a] = a < S ? 0.5 * m->w_term[a] * e * e : 0.0;
+  }
+  return tree16(t);
+}
+
+/* Fx (S x S, dense) and the six non-zero rows of Fu (rows FU0 .. FU0+5, 16 columns):
+ * src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185 with totalForce as a tree */
+static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, const double * x, double * Fx,
+                           double (*Fu)[M_])
+{
+  const int S = m->model == 0 ? 9 : 12;
+  const double dt = m->dt;
+  memset(Fx, 0, sizeof(double) * S * S);
+  const double * tf = T->force;
+  if(m->model == 0)
+  {
+    for(int r = 0; r < M_; r++)
+      for(int k = 0; k < 3; k++)
+      {
+        Fu[k][r] = T->R[r][k] * dt;
+        Fu[3 + k][r] = T->cr[r][k] * dt;
+      }
+    for(int a = 0; a < 3; a++) Fx[a * S + 3 + a] = (1 / m->mass) * dt;
+    Fx[6 * S + 1] = (-tf[2]) * dt;
+    Fx[6 * S + 2] = tf[1] * dt;
+    Fx[7 * S + 0] = tf[2] * dt;
+    Fx[7 * S + 2] = (-tf[0]) * dt;
+    Fx[8 * S + 0] = (-tf[1]) * dt;
+    Fx[8 * S + 1] = tf[0] * dt;
+  }
+  else
+  {
+    const double * I = m->inertia;
+    for(int r = 0; r < M_; r++)
+    {
+      double sol[3];
+      llt3_solve(I, T->cr[r], sol);
+      for(int k = 0; k < 3; k++)
+      {
+        Fu[k][r] = (T->R[r][k] / m->mass) * dt;
+        Fu[3 + k][r] = sol[k] * dt;
+      }
+    }
+    const double w1 = x[9], w2 = x[10], w3 = x[11];
+    const double I11 = I[0], I12 = I[1], I13 = I[2], I22 = I[4], I23 = I[5], I33 = I[8];
+    const double D[9] = {I12 * w3 - I13 * w2,
+                         -I13 * w1 + I22 * w3 - 2 * I23 * w2 - I33 * w3,
+                         I12 * w1 + I22 * w2 + 2 * I23 * w3 - I33 * w2,
+                         -I11 * w3 + 2 * I13 * w1 + I23 * w2 + I33 * w3,
+                         -I12 * w3 + I23 * w1,
+                         -I11 * w1 - I12 * w2 - 2 * I13 * w3 + I33 * w1,
+                         I11 * w2 - 2 * I12 * w1 - I22 * w2 - I23 * w3,
+                         I11 * w1 + 2 * I12 * w2 + I13 * w3 - I22 * w1,
+                         I13 * w2 - I23 * w1};
+    const double CM[9] = {0.0, -tf[2], tf[1], tf[2], 0.0, -tf[0], -tf[1], tf[0], 0.0};
+    for(int b = 0; b < 3; b++)
+    {
+      const double colD[3] = {D[b], D[3 + b], D[6 + b]}, colC[3] = {CM[b], CM[3 + b], CM[6 + b]};
+      double sD[3], sC[3];
+      llt3_solve(I, colD, sD);
+      llt3_solve(I, colC, sC);
+      for(int a = 0; a < 3; a++)
+      {
+        Fx[(9 + a) * S + 9 + b] = sD[a] * dt;
+        Fx[(9 + a) * S + b] = sC[a] * dt;
+      }
+    }
+    double sa, ca, sb, cb;
+    oracle_det_sincos(x[3], &sa, &ca);
+    oracle_det_sincos(x[4], &sb, &cb);
+    const double cb2 = cb * cb, sb2 = sb * sb;
+    for(int a = 0; a < 3; a++) Fx[a * S + 6 + a] = 1.0 * dt;
+    const double K[9] = {(ca * sb) / cb, (sb * sa) / cb, 1.0, -1 * sa, ca, 0.0, ca / cb, sa / cb, 0.0};
+    for(int a = 0; a < 3; a++)
+      for(int b = 0; b < 3; b++) Fx[(3 + a) * S + 9 + b] = K[a * 3 + b] * dt;
+    Fx[3 * S + 3] = (-w1 * sa * sb / cb + w2 * sb * ca / cb) * dt;
+    Fx[4 * S + 3] = (-w1 * ca - w2 * sa) * dt;
+    Fx[5 * S + 3] = (-w1 * sa / cb + w2 * ca / cb) * dt;
+    Fx[3 * S + 4] = (w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa) * dt;
+    Fx[5 * S + 4] = (w1 * sb * ca / cb2 + w2 * sa * sb / cb2) * dt;
+  }
+  for(int a = 0; a < S; a++) Fx[a * S + a] = Fx[a * S + a] + 1.0;
+}
+
+/* ------------------------------------------------------------------------------------------- box QP (LDL')
+ * H: 16 x 16 row-major, zero outside the leading m x m block; skip: bit i set = row / column i is clamped or unused.
+ * L: 16 x 16, unit lower factor of H~ (zeros on and above the diagonal); rd: 1 / D. */
+static int factorize(const double * H, unsigned skip, double * L, double * rd)
+{
+  double a[M_][M_];
+  int ok = 1;
+  for(int c = 0; c < M_; c++)
+    for(int k = 0; k < M_; k++)
+      a[c][k] = (((skip >> c) & 1u) || ((skip >> k) & 1u)) ? (c == k ? 1.0 : 0.0) : H[c * M_ + k];
+  for(int c = 0; c < M_; c++) rd[c] = 1.0;
+  for(int j = 0; j < M_; j++)
+  {
+    if((skip >> j) & 1u)
+    {
+      for(int c = 0; c < M_; c++) L[c * M_ + j] = 0.0;
+      continue;
+    }
+    const double d = a[j][j];
+    if(!(d > 0.0)) ok = 0;
+    const double r = 1.0 / d;
+    double col[M_];
+    for(int c = 0; c < M_; c++) col[c] = a[c][j];
+    for(int c = 0; c < M_; c++) L[c * M_ + j] = c > j ? col[c] * r : 0.0;
+    rd[j] = r;
+    for(int c = 0; c < M_; c++)
+      for(int k = 0; k < M_; k++) a[c][k] = fma(-(col[c] * col[k]), r, a[c][k]);
+  }
+  return ok;
+}
+
+/* b <- H~^-1 b (b zero on the skipped rows) */
+static void solve_ldl(const double * L, const double * rd, unsigned skip, double * b)
+{
+  for(int k = 0; k < M_; k++)
+  {
+    if((skip >> k) & 1u) continue;
+    const double bk = b[k];
+    for(int c = 0; c < M_; c++) b[c] = fma(-L[c * M_ + k], bk, b[c]);
+  }
+  for(int c = 0; c < M_; c++) b[c] = b[c] * rd[c];
+  for(int k = M_ - 1; k >= 0; k--)
+  {
+    if((skip >> k) & 1u) continue;
+    const double bk = b[k];
+    for(int c = 0; c < M_; c++) b[c] = fma(-L[k * M_ + c], bk, b[c]);
+  }
+}
+
+static double qp_value(const double * H, const double * q, const double * y)
+{
+  double t[M_];
+  for(int c = 0; c < M_; c++) t[c] = fma(0.5 * y[c], rows4(H + c * M_, y), y[c] * q[c]);
+  return tree16(t);
+}
+
+/* Tassa's boxQP.m with nmpc_ddp's parameters (oracle/ddp.c oracle_box_qp), in the tile arithmetic */
+static int box_qp_tile(int m, const double * H, const double * q, const double * lo, const double * hi, double * x,
+                       unsigned * skip_out, double * L, double * rd)
+{
+  const int max_iter = 500;
+  const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+  const unsigned inmask = m >= M_ ? 0xffffu : ((1u << m) - 1u);
+  int cl[M_] = {0}, oldc[M_];
+  unsigned skip = ~inmask & 0xffffu;
+  for(int c = 0; c < M_; c++) x[c] = c < m ? fmin(fmax(x[c], lo[c]), hi[c]) : 0.0;
+  for(int c = 0; c < M_; c++) rd[c] = 1.0;
+  double value = qp_value(H, q, x), oldvalue = 0.0;
+  int result = 0, iter;
+  for(iter = 1; iter <= max_iter; iter++)
+  {
+    if(result != 0) break;
+    if(iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
+    {
+      result = 4;
+      break;
+    }
+    oldvalue = value;
+    double grad[M_];
+    for(int c = 0; c < M_; c++) grad[c] = q[c] + rows4(H + c * M_, x);
+    unsigned clmask = 0;
+    int changed = (iter == 1);
+    for(int c = 0; c < M_; c++)
+    {
+      oldc[c] = cl[c];
+      cl[c] = (c < m && ((x[c] == lo[c] && grad[c] > 0) || (x[c] == hi[c] && grad[c] < 0))) ? 1 : 0;
+      if(c < m && cl[c] != oldc[c]) changed = 1;
+      if(c < m && cl[c]) clmask |= 1u << c;
+    }
+    if(clmask == inmask)
+    {
+      result = 6;
+      break;
+    }
+    if(changed)
+    {
+      skip = clmask | (~inmask & 0xffffu);
+      if(!factorize(H, skip, L, rd))
+      {
+        result = -1;
+        break;
+      }
+    }
+    double t[M_];
+    for(int c = 0; c < M_; c++) t[c] = (c < m && !cl[c]) ? grad[c] * grad[c] : 0.0;
+    const double gn = sqrt(tree16(t));
+    if(gn < min_grad)
+    {
+      result = 5;
+      break;
+    }
+    /* grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x */
+    double xcl[M_], rhs[M_], srch[M_];
+    for(int c = 0; c < M_; c++) xcl[c] = cl[c] ? x[c] : 0.0;
+    for(int c = 0; c < M_; c++) rhs[c] = (c < m && !cl[c]) ? q[c] + rows4(H + c * M_, xcl) : 0.0;
+    solve_ldl(L, rd, skip, rhs);
+    for(int c = 0; c < M_; c++) srch[c] = (c < m && !cl[c]) ? -rhs[c] - x[c] : 0.0;
+    for(int c = 0; c < M_; c++) t[c] = srch[c] * grad[c];
+    const double sdotg = tree16(t);
+    if(sdotg >= 0) break; /* no descent direction: result stays 0 */
+    double step = 1.0, vc = 0, xc[M_];
+    for(;;)
+    {
+      for(int c = 0; c < M_; c++) xc[c] = c < m ? fmin(fmax(x[c] + step * srch[c], lo[c]), hi[c]) : 0.0;
+      vc = qp_value(H, q, xc);
+      if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
+      step *= step_dec;
+      if(step < min_step)
+      {
+        result = 2;
+        break;
+      }
+    }
+    for(int c = 0; c < M_; c++) x[c] = xc[c];
+    value = vc;
+  }
+  if(iter > max_iter && result == 0) result = 1;
+  unsigned clmask = 0;
+  for(int c = 0; c < m; c++)
+    if(cl[c]) clmask |= 1u << c;
+  *skip_out = clmask | (~inmask & 0xffffu);
+  return result;
+}
+
+/* ------------------------------------------------------------------------------------------- DDP */
+static void increase_lambda(tile_t * d)
+{
+  d->dlambda = fmax(d->dlambda * d->c->lambda_factor, d->c->lambda_factor);
+  d->lambda = fmax(d->lambda * d->dlambda, d->c->lambda_min);
+}
+static void decrease_lambda(tile_t * d)
+{
+  d->dlambda = fmin(d->dlambda / d->c->lambda_factor, 1.0 / d->c->lambda_factor);
+  d->lambda = d->lambda * d->dlambda * (d->lambda > d->c->lambda_min ? 1.0 : 0.0);
+}
+
+/* oracle/ddp.c backward_pass in the tile arithmetic; gsum = sum_i max_r |k_r| / (|u_r| + 1) */
+static int backward_pass(tile_t * d, double * gsum)
+{
+  const oracle_ddp_model_t * m = d->m;
+  const int S = d->S, N = d->N, FU0 = S == 9 ? 3 : 6;
+  double Vxx[144], Vx[12], ref[12];
+  memset(Vxx, 0, sizeof(Vxx));
+  ref_of(m, N, ref);
+  for(int a = 0; a < S; a++)
+  {
+    Vxx[a * S + a] = m->w_term[a];
+    Vx[a] = m->w_term[a] * (d->x[(size_t)N * S + a] - ref[a]);
+  }
+  d->dV[0] = d->dV[1] = 0;
+  *gsum = 0;
+  double kprev[M_] = {0};
+  int mprev = -1;
+  for(int i = N - 1; i >= 0; i--)
+  {
+    const int dim = dim_of(m, i);
+    const double * x = d->x + (size_t)i * S;
+    double u[M_];
+    for(int r = 0; r < M_; r++) u[r] = r < dim ? d->u[(size_t)i * M_ + r] : 0.0;
+    terms_t T;
+    terms_of(m, i, x, u, &T);
+    double Fx[144], Fu[6][M_];
+    state_eq_deriv(m, &T, x, Fx, Fu);
+    /* Qx = Lx + Fx' Vx ; Qu = Lu + Fu' Vx */
+    double Qx[12], Qu[M_];
+    ref_of(m, i, ref);
+    for(int a = 0; a < S; a++)
+    {
+      double s = m->w_run[a] * (x[a] - ref[a]);
+      for(int b = 0; b < S; b++) s = fma(Fx[b * S + a], Vx[b], s);
+      Qx[a] = s;
+    }
+    for(int r = 0; r < M_; r++)
+    {
+      double s = m->w_force * u[r];
+      for(int b = 0; b < 6; b++) s = fma(Fu[b][r], Vx[FU0 + b], s);
+      Qu[r] = r < dim ? s : 0.0;
+    }
+    /* T2 = Vxx Fu ; T1 = Vxx Fx */
+    double T2[12][M_], T1[144];
+    for(int a = 0; a < S; a++)
+      for(int r = 0; r < M_; r++)
+      {
+        double s = Vxx[a * S + FU0] * Fu[0][r];
+        for(int b = 1; b < 6; b++) s = fma(Vxx[a * S + FU0 + b], Fu[b][r], s);
+        T2[a][r] = s;
+      }
+    for(int a = 0; a < S; a++)
+      for(int b2 = 0; b2 < S; b2++)
+      {
+        double s = Vxx[a * S] * Fx[b2];
+        for(int b = 1; b < S; b++) s = fma(Vxx[a * S + b], Fx[b * S + b2], s);
+        T1[a * S + b2] = s;
+      }
+    /* Quu = Luu + Fu' T2 (H: unregularised, HF: lambda on the diagonal, both zero outside dim x dim) */
+    double H[M_ * M_], HF[M_ * M_];
+    for(int r = 0; r < M_; r++)
+      for(int q = 0; q < M_; q++)
+      {
+        double s = r == q ? m->w_force : 0.0;
+        for(int b = 0; b < 6; b++) s = fma(Fu[b][r], T2[FU0 + b][q], s);
+        const int live = r < dim && q < dim;
+        H[r * M_ + q] = live ? s : 0.0;
+        HF[r * M_ + q] = (live && r == q) ? s + d->lambda : H[r * M_ + q];
+      }
+    /* Qxu = Fx' T2 ; Qxx = Lxx + Fx' T1 */
+    double Qxu[12][M_], Qxx[144];
+    for(int a = 0; a < S; a++)
+      for(int r = 0; r < M_; r++)
+      {
+        double s = Fx[a] * T2[0][r];
+        for(int b = 1; b < S; b++) s = fma(Fx[b * S + a], T2[b][r], s);
+        Qxu[a][r] = r < dim ? s : 0.0;
+      }
+    for(int a = 0; a < S; a++)
+      for(int b2 = 0; b2 < S; b2++)
+      {
+        double s = a == b2 ? m->w_run[a] : 0.0;
+        for(int b = 0; b < S; b++) s = fma(Fx[b * S + a], T1[b * S + b2], s);
+        Qxx[a * S + b2] = s;
+      }
+    /* box-QP and gains */
+    double k[M_] = {0}, K[M_][12];
+    memset(K, 0, sizeof(K));
+    if(dim > 0)
+    {
+      double lo[M_], hi[M_], L[M_ * M_], rd[M_];
+      for(int r = 0; r < M_; r++)
+      {
+        lo[r] = r < dim ? m->force_lo - u[r] : 0.0;
+        hi[r] = r < dim ? m->force_hi - u[r] : 0.0;
+        k[r] = (mprev == dim) ? kprev[r] : 0.0; /* warm start: step i + 1 of this pass */
+      }
+      unsigned skip;
+      const int rc = box_qp_tile(dim, HF, Qu, lo, hi, k, &skip, L, rd);
+      if(rc < 1) return 0;
+      /* K_f = -H_ff^-1 Qxu_f' */
+      for(int a = 0; a < S; a++)
+      {
+        double rhs[M_];
+        for(int r = 0; r < M_; r++) rhs[r] = ((skip >> r) & 1u) ? 0.0 : Qxu[a][r];
+        solve_ldl(L, rd, skip, rhs);
+        for(int r = 0; r < M_; r++) K[r][a] = ((skip >> r) & 1u) ? 0.0 : -rhs[r];
+      }
+    }
+    for(int r = 0; r < M_; r++)
+    {
+      d->k[(size_t)i * M_ + r] = k[r];
+      for(int a = 0; a < S; a++) d->K[((size_t)i * M_ + r) * S + a] = K[r][a];
+    }
+    {
+      double mx = 0.0;
+      for(int r = 0; r < dim; r++) mx = fmax(mx, fabs(k[r]) / (fabs(u[r]) + 1.0));
+      *gsum += mx;
+    }
+    /* dV, Vx, Vxx */
+    double t4[M_], t[M_];
+    for(int r = 0; r < M_; r++) t4[r] = rows4(H + r * M_, k);
+    for(int r = 0; r < M_; r++) t[r] = k[r] * Qu[r];
+    d->dV[0] += tree16(t);
+    for(int r = 0; r < M_; r++) t[r] = k[r] * t4[r];
+    d->dV[1] += 0.5 * tree16(t);
+    double vxn[12];
+    for(int a = 0; a < S; a++)
+    {
+      for(int r = 0; r < M_; r++) t[r] = fma(Qxu[a][r], k[r], K[r][a] * (t4[r] + Qu[r]));
+      vxn[a] = Qx[a] + tree16(t);
+    }
+    /* Z = Quu K + 2 Qux */
+    double Z[M_][12];
+    for(int a = 0; a < S; a++)
+    {
+      double col[M_];
+      for(int r = 0; r < M_; r++) col[r] = K[r][a];
+      for(int r = 0; r < M_; r++) Z[r][a] = rows4(H + r * M_, col) + 2.0 * Qxu[a][r];
+    }
+    for(int a = 0; a < S; a++)
+      for(int b = a; b < S; b++)
+      {
+        double acc = 0.0;
+        for(int r = 0; r < M_; r++)
+        {
+          acc = fma(K[r][a], Z[r][b], acc);
+          acc = fma(K[r][b], Z[r][a], acc);
+        }
+        const double v = 0.5 * ((Qxx[a * S + b] + Qxx[b * S + a]) + acc);
+        Vxx[a * S + b] = v;
+        Vxx[b * S + a] = v;
+      }
+    for(int a = 0; a < S; a++) Vx[a] = vxn[a];
+    memcpy(kprev, k, sizeof(k));
+    mprev = dim;
+  }
+  return 1;
+}
+
+/* forward pass for one step size into candidate slot q; returns its cost */
+static double forward_pass(tile_t * d, double alpha, int q)
+{
+  const oracle_ddp_model_t * m = d->m;
+  const int S = d->S, N = d->N;
+  double * xc = d->xc[q], * uc = d->uc[q];
+  memcpy(xc, d->x, sizeof(double) * S);
+  double cost = 0;
+  for(int i = 0; i < N; i++)
+  {
+    const int dim = dim_of(m, i);
+    const double * xi = d->x + (size_t)i * S, * ui = d->u + (size_t)i * M_;
+    double * xn = xc + (size_t)i * S, * un = uc + (size_t)i * M_;
+    const double * ki = d->k + (size_t)i * M_, * Ki = d->K + (size_t)i * M_ * S;
+    for(int r = 0; r < M_; r++)
+    {
+      double s = ui[r] + alpha * ki[r];
+      for(int a = 0; a < S; a++) s = fma(Ki[r * S + a], xn[a] - xi[a], s);
+      un[r] = r < dim ? fmin(fmax(s, m->force_lo), m->force_hi) : 0.0;
+    }
+    cost = cost + running_cost(m, i, xn, un);
+    terms_t T;
+    terms_of(m, i, xn, un, &T);
+    state_eq(m, &T, xn, xc + (size_t)(i + 1) * S);
+  }
+  return cost + terminal_cost(m, xc + (size_t)N * S);
+}
+
+int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_t * c, const double * x0,
+                          const double * u_init, double * x_out, double * u_out, oracle_ddp_result_t * res)
+{
+  tile_t d;
+  memset(&d, 0, sizeof(d));
+  const int S = m->model == 0 ? 9 : 12, N = m->N;
+  if(m->M != M_ || c->reg_type != 1 || !c->with_input_constraint) return -100; /* not in this arithmetic */
+  d.m = m;
+  d.c = c;
+  d.S = S;
+  d.N = N;
+  const size_t nx = (size_t)(N + 1) * S, nu = (size_t)N * M_;
+  double * buf = (double *)calloc(5 * (nx + nu) + nu + nu * S, sizeof(double));
+  d.x = buf;
+  d.u = buf + nx;
+  for(int q = 0; q < 4; q++)
+  {
+    d.xc[q] = buf + (size_t)(q + 1) * (nx + nu);
+    d.uc[q] = d.xc[q] + nx;
+  }
+  d.k = buf + 5 * (nx + nu);
+  d.K = d.k + nu;
+  d.lambda = c->initial_lambda;
+  d.dlambda = c->initial_dlambda;
+  memcpy(d.x, x0, sizeof(double) * S);
+  d.cost = 0;
+  for(int i = 0; i < N; i++)
+  {
+    const int dim = dim_of(m, i);
+    double * ui = d.u + (size_t)i * M_;
+    for(int r = 0; r < M_; r++) ui[r] = (r < dim && u_init) ? u_init[(size_t)i * M_ + r] : 0.0;
+    d.cost = d.cost + running_cost(m, i, d.x + (size_t)i * S, ui);
+    terms_t T;
+    terms_of(m, i, d.x + (size_t)i * S, ui, &T);
+    state_eq(m, &T, d.x + (size_t)i * S, d.x + (size_t)(i + 1) * S);
+  }
+  d.cost = d.cost + terminal_cost(m, d.x + (size_t)N * S);
+  const double initial_cost = d.cost;
+
+  int iter = 0, status = 0, n_accept = 0;
+  for(iter = 1; iter <= c->max_iter; iter++)
+  {
+    int bp_ok = 0;
+    double gsum = 0;
+    for(;;)
+    {
+      if(backward_pass(&d, &gsum))
+      {
+        bp_ok = 1;
+        break;
+      }
+      increase_lambda(&d);
+      if(d.lambda > c->lambda_max) break;
+    }
+    if(!bp_ok)
+    {
+      status = -1;
+      break;
+    }
+    const double g = gsum / N;
+    if(g < c->k_rel_norm_thre && d.lambda < c->lambda_thre)
+    {
+      decrease_lambda(&d);
+      status = 1;
+      break;
+    }
+    int accepted = 0;
+    double actual = 0;
+    for(int a = 0; a < 11; a++)
+    {
+      const double alpha = c->alpha_list[a];
+      const double costc = forward_pass(&d, alpha, 0);
+      actual = d.cost - costc;
+      const double expected = -alpha * (d.dV[0] + alpha * d.dV[1]);
+      const double ratio = expected > 0 ? actual / expected : (actual > 0 ? 1.0 : (actual < 0 ? -1.0 : 0.0));
+      if(ratio > c->cost_update_ratio_thre)
+      {
+        accepted = 1;
+        memcpy(d.x, d.xc[0], sizeof(double) * nx);
+        memcpy(d.u, d.uc[0], sizeof(double) * nu);
+        d.cost = costc;
+        break;
+      }
+    }
+    if(accepted)
+    {
+      decrease_lambda(&d);
+      n_accept++;
+      if(actual < c->cost_update_thre)
+      {
+        status = 2;
+        break;
+      }
+    }
+    else
+    {
+      increase_lambda(&d);
+      if(d.lambda > c->lambda_max)
+      {
+        status = -1;
+        break;
+      }
+    }
+  }
+  if(iter > c->max_iter) iter = c->max_iter;
+  if(x_out) memcpy(x_out, d.x, sizeof(double) * nx);
+  if(u_out) memcpy(u_out, d.u, sizeof(double) * nu);
+  if(res)
+  {
+    res->iters = iter;
+    res->status = status;
+    res->cost = d.cost;
+    res->initial_cost = initial_cost;
+    res->lambda = d.lambda;
+    res->accepted = n_accept;
+  }
+  free(buf);
+  return status;
+}

@@ -1,0 +1,62 @@
+// ddp_tile_emu.cpp -- TEST AID: compiles the product's tile-layout DDP kernel (csrc/ddp_tile.h, written against
+// csrc/w64.h) for the host, where the 64 lanes of the wavefront run in lock step as 64-element arrays.  Lets the CPU
+// test-suite check the kernel's arithmetic bit for bit against the oracle (oracle/ddp_tile.c) without a GPU.
+// Never linked into, imported by or shipped with the product.
+#include "../../centroidalcontrolcollection_amd/csrc/ddp_tile.h"
+
+#include <cstdint>
+#include <vector>
+
+using namespace ccc_amd;
+using ccc_amd::ddp_common::Params;
+
+template<int S>
+static void run_one(const Params & P, const ddp_tile::Instance & I)
+{
+  static ddp_tile::Mem<S> mem;
+  ddp_tile::Solver<S> solver(P, I, mem);
+  solver.solve_instance();
+}
+
+extern "C" int ccc_ddp_tile_emu_lds_bytes(int S)
+{
+  return S == 9 ? (int)sizeof(ddp_tile::Mem<9>) : (int)sizeof(ddp_tile::Mem<12>);
+}
+
+extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, long n, const int * phase_dim, const double * phase_vertex,
+                                            const double * phase_ridge, const int * step_phase, const double * ref_pos,
+                                            const double * ref_ori, const double * inertia, const double * x0,
+                                            const double * u_init, double * u_out, double * x_out, int * iters,
+                                            int * status, double * cost)
+{
+  const int S = P->model == 0 ? 9 : 12, N = P->N, Pn = P->P, M = ddp_tile::kM;
+  std::vector<double> xbuf((size_t)ddp_tile::kSlots * (N + 1) * S), ubuf((size_t)ddp_tile::kSlots * N * M),
+      ks((size_t)N * M), Ks((size_t)N * M * S);
+  for(long b = 0; b < n; b++)
+  {
+    ddp_tile::Instance I;
+    I.phase_dim = phase_dim + b * Pn;
+    I.phase_vertex = phase_vertex + (size_t)b * Pn * M * 3;
+    I.phase_ridge = phase_ridge + (size_t)b * Pn * M * 3;
+    I.step_phase = step_phase + (size_t)b * N;
+    I.ref_pos = ref_pos + (size_t)b * (N + 1) * 3;
+    I.ref_ori = ref_ori ? ref_ori + (size_t)b * (N + 1) * 3 : nullptr;
+    I.inertia = inertia ? inertia + (size_t)b * 9 : nullptr;
+    I.x0 = x0 + (size_t)b * S;
+    I.u_init = u_init ? u_init + (size_t)b * N * M : nullptr;
+    I.xbuf = xbuf.data();
+    I.ubuf = ubuf.data();
+    I.ks = ks.data();
+    I.Ks = Ks.data();
+    I.u_out = u_out + (size_t)b * N * M;
+    I.x_out = x_out ? x_out + (size_t)b * (N + 1) * S : nullptr;
+    I.out_iters = iters ? iters + b : nullptr;
+    I.out_status = status ? status + b : nullptr;
+    I.out_cost = cost ? cost + b : nullptr;
+    if(S == 9)
+      run_one<9>(*P, I);
+    else
+      run_one<12>(*P, I);
+  }
+  return 0;
+}

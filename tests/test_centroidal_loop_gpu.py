@@ -43,9 +43,15 @@ def _sim_state(n, pos, perturb=0.0, seed=0):
     return s
 
 
-@pytest.mark.parametrize("srb", [False, True])
-def test_ddp_reference_closed_loop_on_the_device(srb):
+@pytest.mark.parametrize("srb,kernel,warm_iter", [(False, "tile", 1), (True, "legacy", 1), (True, "tile", 2)])
+def test_ddp_reference_closed_loop_on_the_device(monkeypatch, srb, kernel, warm_iter):
+    """(The single-rigid-body protocol as written -- one iteration per cycle -- is a knife edge in any frozen arithmetic,
+    tests/test_ddp_gpu.py::test_srb_reference_closed_loop_through_planonce: as written it runs on the left-to-right
+    arithmetic of the row-per-lane kernel, with two iterations per cycle on the default tile kernel.)"""
     import torch
+
+    if kernel == "legacy":
+        monkeypatch.setenv("CCC_DDP_LEGACY", "1")
 
     dev = torch.device("cuda:0")
     n, N, dt = 6, 100, 0.03
@@ -63,7 +69,7 @@ def test_ddp_reference_closed_loop_on_the_device(srb):
     cycles = 601  # while(t < 3.0) with t += 0.005 in floating point: 601 passes (fixtures_ddp.run_closed_loop_ddp)
     stats = torch.zeros((n, 8), dtype=torch.float64, device=dev)
     log = torch.zeros((cycles, n, 9), dtype=torch.float64, device=dev)
-    t_end = cl.ddp_closed_loop(d, tl, inertia, sim, 0.0, 0.005, cycles, 500, 1, disturb_times=(1.0,),
+    t_end = cl.ddp_closed_loop(d, tl, inertia, sim, 0.0, 0.005, cycles, 500, warm_iter, disturb_times=(1.0,),
                                disturb_lin=(0.05, 0.05, 0.0), stats=stats, log=log)
     st, fin, lg = stats.cpu().numpy(), sim.cpu().numpy(), log.cpu().numpy()
     assert abs(t_end - 3.005) < 1e-9
@@ -88,7 +94,7 @@ def test_ddp_reference_closed_loop_on_the_device(srb):
         d.ddp_solver_.config().max_iter = max_iter
         return d.planOnceBatch(prob, x0, u_init)["u"]
 
-    hlog, hfin = fd.run_closed_loop_ddp(plan, srb=srb)
+    hlog, hfin = fd.run_closed_loop_ddp(plan, srb=srb, warm_max_iter=warm_iter)
     hp = np.array([r["pos"] for r in hlog])
     k = 120 if srb else len(hlog)  # the SRB loop amplifies last-bit differences of the wrench sums after the take-off
     assert np.abs(lg[:k, 0, :3] - hp[:k]).max() < 1e-7

@@ -1,0 +1,117 @@
+"""CPU check of the DEFAULT DDP kernel (csrc/ddp_tile.h, written against csrc/w64.h): tests/emu/ddp_tile_emu.cpp compiles
+the product's kernel source for the host, 64 lanes in lock step, and this test compares it BIT FOR BIT with the
+independently written specification of its arithmetic, oracle/ddp_tile.c (oracle_ddp_config_t::arith = 1).  Also pinned
+here: the tile arithmetic and the left-to-right arithmetic of oracle/ddp.c are the same algorithm up to rounding.
+The emulation is a test aid -- the product never runs it."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from centroidalcontrolcollection_amd import fixtures_ddp as fd
+from oracle import oracle
+from test_ddp_emu import Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(ROOT, "tests", "emu", "libddp_tile_emu.so")
+    src = os.path.join(ROOT, "tests", "emu", "ddp_tile_emu.cpp")
+    hdrs = [os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", h) for h in ("ddp_tile.h", "w64.h", "ddp_core.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-o", so, src])
+    L = ctypes.CDLL(so)
+    L.ccc_ddp_tile_emu_lds_bytes.restype = ctypes.c_int
+
+    def run(model, N, dt, w, prob, x0, max_iter, u_init=None):
+        P = Params()
+        P.model, P.N, P.P, P.mass, P.dt = model, N, prob["phase_dim"].shape[1], 100.0, dt
+        S = 9 if model == 0 else 12
+        for a in range(S):
+            P.w_run[a], P.w_term[a] = w["run"][a], w["term"][a]
+        P.w_force, P.flo, P.fhi, P.max_iter, P.reg_type = w["force"], 0.0, 1e6, max_iter, 1
+        P.lambda0, P.dlambda0, P.lambda_factor, P.lambda_min, P.lambda_max = 1e-6, 1.0, 1.6, 1e-8, 1e10
+        P.k_rel_norm_thre, P.lambda_thre, P.ratio_thre, P.cost_thre = 1e-4, 1e-7, 0.0, 1e-7
+        for i in range(11):
+            P.alpha[i] = 10 ** (-3.0 * i / 10)
+        n = x0.shape[0]
+        c = lambda a, t=np.float64: np.ascontiguousarray(a, dtype=t)  # noqa: E731
+        arr = [c(prob["phase_dim"], np.int32), c(prob["phase_vertex"]), c(prob["phase_ridge"]),
+               c(prob["step_phase"], np.int32), c(prob["ref_pos"]), c(prob["ref_ori"]) if model == 1 else None,
+               c(prob["inertia"]) if model == 1 else None, c(x0), None if u_init is None else c(u_init)]
+        u, x = np.zeros((n, N, 16)), np.zeros((n, N + 1, S))
+        it, st, cost = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        rc = L.ccc_ddp_tile_emu_plan_batch(ctypes.byref(P), ctypes.c_long(n), *[p(a) for a in arr], p(u), p(x), p(it),
+                                           p(st), p(cost))
+        assert rc == 0
+        return dict(u=u, x=x, iters=it, status=st, cost=cost)
+
+    run.lds_bytes = L.ccc_ddp_tile_emu_lds_bytes
+    return run
+
+
+def _ora(model, N, dt, w, max_iter, arith, P=4):
+    return oracle.Ddp(model, 100.0, dt, N, w, max_iter=max_iter, arith=arith, P=P)
+
+
+def _same(a, b):
+    for k in ("u", "x", "cost", "iters", "status"):
+        assert np.array_equal(a[k], b[k]), (k, np.abs(a[k].astype(float) - b[k].astype(float)).max())
+
+
+def test_lds_footprint_allows_sixteen_wavefronts_per_cu(emu):
+    """160 KB of LDS per CU / 16 wavefronts = 10240 B: what four wavefronts per SIMD need."""
+    assert emu.lds_bytes(9) <= 10240 and emu.lds_bytes(12) <= 10240
+
+
+@pytest.mark.parametrize("model,N,max_iter", [(0, 100, 3), (0, 60, 500), (1, 50, 3), (1, 50, 500)])
+def test_kernel_source_reproduces_the_tile_specification_bit_for_bit(emu, model, N, max_iter):
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(10, N, 0.03, seed=5 + N, srb=bool(model))
+    _same(emu(model, N, 0.03, w, prob, x0, max_iter), _ora(model, N, 0.03, w, max_iter, 1).plan_batch(prob, x0, nthreads=8))
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_warm_start_partial_contacts_and_many_phases(emu, model):
+    """Ridge counts other than 0 and 16 (a triangle contact: 12 ridges, a line contact: 8), seven contact phases, a warm
+    start: the masks of the kernel (lanes beyond a step's dimension) against the zero-padded sums of the specification."""
+    N, dt = 40, 0.03
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(6, N, dt, seed=3, srb=bool(model), P=7)
+    rng = np.random.default_rng(1)
+    prob["phase_dim"][:, 3], prob["phase_dim"][:, 4] = 12, 8
+    for p, m in ((3, 12), (4, 8)):
+        prob["phase_vertex"][:, p, :m] = prob["phase_vertex"][:, 0, :m]
+        prob["phase_ridge"][:, p, :m] = prob["phase_ridge"][:, 0, :m]
+        prob["phase_vertex"][:, p, m:] = 7.0  # garbage beyond the dimension must not matter
+        prob["phase_ridge"][:, p, m:] = -3.0
+    prob["step_phase"][:, 5:12] = 3
+    prob["step_phase"][:, 30:36] = 4
+    prob["step_phase"][:, 36:] = rng.integers(0, 7, size=(6, N - 36))
+    o1 = _ora(model, N, dt, w, 6, 1, P=7)
+    cold = o1.plan_batch(prob, x0)
+    _same(emu(model, N, dt, w, prob, x0, 6), cold)
+    _same(emu(model, N, dt, w, prob, x0 + 0.01, 2, u_init=cold["u"]),
+          _ora(model, N, dt, w, 2, 1, P=7).plan_batch(prob, x0 + 0.01, u_init=cold["u"]))
+
+
+@pytest.mark.parametrize("model,N", [(0, 100), (1, 50)])
+def test_the_two_arithmetics_are_the_same_algorithm_up_to_rounding(model, N):
+    """oracle/ddp.c (left-to-right sums, Cholesky) and oracle/ddp_tile.c (trees, fma, LDL', the Z form of the value
+    update) on the same problems, run to convergence: same iteration counts and exit codes, costs to 1e-12 relative,
+    force scales to 1e-4 -- the re-specification changed roundings, not the algorithm."""
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(48, N, 0.03, seed=11, srb=bool(model))
+    r0 = _ora(model, N, 0.03, w, 500, 0).plan_batch(prob, x0, nthreads=8)
+    r1 = _ora(model, N, 0.03, w, 500, 1).plan_batch(prob, x0, nthreads=8)
+    same_path = (r0["iters"] == r1["iters"]) & (r0["status"] == r1["status"])
+    assert same_path.mean() >= 0.9, same_path.mean()  # (a discrete decision may flip on a rounding: rare)
+    rel = np.abs(r0["cost"] - r1["cost"]) / np.abs(r0["cost"])
+    assert rel[same_path].max() <= 1e-12
+    assert np.abs(r0["u"] - r1["u"])[same_path].max() <= 1e-4  # (flat directions: held by the 1e-6 force weight only)
+    assert np.all(r1["status"] >= 1)

@@ -284,11 +284,10 @@ def test_rounds_of_the_stage_recursion_kernel_are_bit_identical(monkeypatch):
     monkeypatch.delenv("CCC_XY_DUAL", raising=False)
     monkeypatch.setenv("CCC_XY_STREAM", "1")
     prob, x0 = fd.make_xy_batch(700, 20, 0.1, seed=21)
-    mpc = LinearMpcXY(100.0, 0.1, 20)
     res = []
     for rounds in ("99", "6,10", "2,4,6", "1", "3,4,5"):
-        monkeypatch.setenv("CCC_XY_ROUNDS", rounds)
-        res.append(mpc.planOnceBatch(prob, x0, want_all=True))
+        monkeypatch.setenv("CCC_XY_ROUNDS", rounds)  # (development switches are read when the handle is created)
+        res.append(LinearMpcXY(100.0, 0.1, 20).planOnceBatch(prob, x0, want_all=True))
     assert np.all(res[0]["status"] == 0)
     for r in res[1:]:
         assert np.array_equal(r["u0"], res[0]["u0"]) and np.array_equal(r["lam"], res[0]["lam"])
@@ -374,8 +373,8 @@ def test_safeguard_rounds_take_the_instances_that_cycle(monkeypatch):
     prob, x0 = fd.make_xy_batch(300, 20, 0.1, seed=13)
     mpc = LinearMpcXY(100.0, 0.1, 20)
     full = mpc.planOnceBatch(prob, x0, want_all=True)
-    monkeypatch.setenv("CCC_XY_PDAS_ITERS", "2")
-    starved = mpc.planOnceBatch(prob, x0, want_all=True)
+    monkeypatch.setenv("CCC_XY_PDAS_ITERS", "2")  # (development switches are read when the handle is created)
+    starved = LinearMpcXY(100.0, 0.1, 20).planOnceBatch(prob, x0, want_all=True)
     o = _oracle().LinearMpcXY(100.0, 0.1, 20).plan_batch(prob, x0, nthreads=16)
     _compare(prob, starved, o, 20)
     assert np.all(starved["status"] == 0) and starved["pivots"].mean() > full["pivots"].mean()
@@ -404,3 +403,78 @@ def test_wide_configuration_ragged_batches(n):
     part = mpc.planOnceBatch({k: v[:n] for k, v in prob.items()}, x0[:n], want_all=True)
     assert np.all(part["status"] == 0)
     assert np.array_equal(part["u0"], full["u0"][:n]) and np.array_equal(part["lam"], full["lam"][:n])
+
+
+def _xy_kkt_residuals(prob, x0, lam, mass=100.0, dt=0.1, w_force=1e-5, Wdiag=(1.0, 0.0, 1.0, 0.0, 1.0, 1.0)):
+    """Solver-independent KKT residuals of the LinearMpcXY QP for a whole batch, numpy only, nothing condensed: the
+    states are SIMULATED with the closed-form ZOH of src/LinearMpcXY.cpp:59-83 (A^3 = 0: Ad = I + A dt + A^2 dt^2/2,
+    Bd = B dt + A B dt^2/2 + A^2 B dt^3/6), the gradient of 1/2 sum |x_{i+1} - ref_i|^2_W + w/2 |lam|^2
+    (:141-147, extend_for_output = false) comes from the adjoint recursion, the multiplier of each step's equality
+    sum rho_z lam = total_force_z (:149-176) is fitted on the step's free variables.  Returns per instance
+    (equality residual / f_z, bound violation, stationarity residual relative to the gradient scale)."""
+    n, N, M = lam.shape
+    G = 9.80665
+    lo, hi = 3.0, 3.0 * mass * G  # force_range_, src/LinearMpcXY.cpp:93
+    W = np.asarray(Wdiag)
+    fz, cz = prob["total_force_z"], prob["com_z"]
+    V, R, dim = prob["vertex"], prob["ridge"], prob["dim"]
+    mask = np.arange(M)[None, None, :] < dim[:, :, None]
+    lam = lam * mask
+    A = np.zeros((n, N, 6, 6))
+    A[:, :, 0, 1] = 1.0
+    A[:, :, 2, 3] = 1.0
+    A[:, :, 4, 2] = -fz / mass
+    A[:, :, 5, 0] = fz / mass
+    B = np.zeros((n, N, 6, M))
+    B[:, :, 1] = R[..., 0]
+    B[:, :, 3] = R[..., 1]
+    B[:, :, 4] = -(V[..., 2] - cz[..., None]) * R[..., 1] + V[..., 1] * R[..., 2]
+    B[:, :, 5] = (V[..., 2] - cz[..., None]) * R[..., 0] - V[..., 0] * R[..., 2]
+    B = B * mask[:, :, None, :]
+    A2 = A @ A
+    Ad = np.eye(6) + A * dt + A2 * (dt * dt / 2)
+    Bd = B * dt + (A @ B) * (dt * dt / 2) + (A2 @ B) * (dt ** 3 / 6)
+    x = np.zeros((n, N + 1, 6))
+    x[:, 0] = x0
+    for i in range(N):
+        x[:, i + 1] = np.einsum("nab,nb->na", Ad[:, i], x[:, i]) + np.einsum("nar,nr->na", Bd[:, i], lam[:, i])
+    grad = np.zeros_like(lam)
+    p = np.zeros((n, 6))
+    for i in range(N - 1, -1, -1):
+        p = W * (x[:, i + 1] - prob["ref_out"][:, i]) + (np.einsum("nab,na->nb", Ad[:, i + 1], p) if i + 1 < N else 0.0)
+        grad[:, i] = w_force * lam[:, i] + np.einsum("nar,na->nr", Bd[:, i], p)
+    rz = R[..., 2] * mask
+    eq = np.abs((rz * lam).sum(axis=2) - fz * (dim > 0)).max(axis=1) / fz.max(axis=1)
+    viol = np.maximum(np.where(mask, lo - lam, 0.0), np.where(mask, lam - hi, 0.0)).max(axis=(1, 2))
+    tol = 1e-9 * hi
+    at_lo, at_hi = mask & (lam <= lo + tol), mask & (lam >= hi - tol)
+    free = mask & ~at_lo & ~at_hi
+    # nu_i: least squares of grad + nu rho_z = 0 over the free variables of the step (a step keeps at least one)
+    num = -(grad * rz * free).sum(axis=2)
+    den = (rz * rz * free).sum(axis=2)
+    nu = np.where(den > 0, num / np.where(den > 0, den, 1.0), 0.0)
+    res = grad + nu[:, :, None] * rz
+    stat = np.where(free, np.abs(res), np.where(at_lo, np.maximum(-res, 0.0), np.where(at_hi, np.maximum(res, 0.0), 0.0)))
+    gscale = np.abs(grad).max(axis=(1, 2)) + 1e-300
+    return eq, viol, stat.max(axis=(1, 2)) / gscale, (den > 0) | (dim == 0)
+
+
+def test_config4_full_size_kkt_properties():
+    """BASELINE.json configs[3] AT FULL SIZE: LinearMpcXY, batch 65536, N = 20.  From the planned force scales of the whole
+    horizon alone: every instance solved, bounds respected (1e-9 N), every contact step's vertical-force equality met to 1e-10,
+    and the KKT stationarity residual (adjoint gradient + fitted equality multipliers, wrong-signed part at the bounds)
+    below 1e-7 of the gradient's scale -- a strictly convex QP has one KKT point, so this pins the answer itself."""
+    n, N, base = 65536, 20, 2048
+    pb, xb = fd.make_xy_batch(base, N, 0.1, seed=20250928)
+    prob = {k: np.concatenate([v] * (n // base)) for k, v in pb.items()}
+    rng = np.random.default_rng(4)
+    x0 = np.concatenate([xb] * (n // base)) + rng.uniform(-1.0, 1.0, size=(n, 6)) * np.array([2.0, 5.0, 2.0, 5.0, 0.3, 0.3])
+    r = LinearMpcXY(100.0, 0.1, N).planOnceBatch(prob, x0, want_all=True)
+    assert np.all(r["status"] == 0)
+    assert np.array_equal(r["u0"], r["lam"][:, 0, :])
+    eq, viol, stat, has_free = _xy_kkt_residuals(prob, x0, r["lam"])
+    print("config 4: eq %.2e  bound violation %.2e  stationarity max %.2e median %.2e" % (
+        eq.max(), viol.max(), stat.max(), np.median(stat)))
+    assert np.all(has_free)
+    assert eq.max() <= 1e-10 and viol.max() <= 1e-9
+    assert stat.max() <= 1e-7
