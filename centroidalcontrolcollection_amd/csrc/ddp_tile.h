@@ -48,6 +48,59 @@ namespace ddp_tile
 using namespace w64;
 using ddp_common::Params;
 
+// unroll factors of the loops whose full unrolling costs more registers than four wavefronts per SIMD leave (measured)
+#ifndef CCC_TILE_U_PROD
+#  define CCC_TILE_U_PROD 3
+#endif
+#ifndef CCC_TILE_U_Z
+#  define CCC_TILE_U_Z 1
+#endif
+#ifndef CCC_TILE_U_PAIR
+#  define CCC_TILE_U_PAIR 4
+#endif
+
+// Section profiler (development aid: -DCCC_TILE_PROF, scripts/ddp_tile_sections.py): shader-clock cycles per section
+// accumulated in LDS; solve_instance() then overwrites the first planned inputs with the totals, so a profiling build
+// returns timings INSTEAD of a plan.
+enum
+{
+  TP_DERIV = 0,
+  TP_PRODUCTS,
+  TP_QP_VALUE,
+  TP_QP_GRAD,
+  TP_QP_FACTOR,
+  TP_QP_SOLVE,
+  TP_QP_SEARCH,
+  TP_GAINS,
+  TP_VALUE,
+  TP_FORWARD,
+  TP_OTHER,
+  TP_QP_CALLS,
+  TP_QP_ITERS,
+  TP_QP_FACTORS,
+  TP_FORWARDS,
+  TP_N
+};
+#if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#  define TILE_PROF_START() long long prof_t_ = (long long)__builtin_readcyclecounter()
+#  define TILE_PROF_ADD(k)                                                        \
+    do                                                                            \
+    {                                                                             \
+      const long long prof_n_ = (long long)__builtin_readcyclecounter();          \
+      if((threadIdx.x & 63) == 0) mem.prof[k] += (double)(prof_n_ - prof_t_);     \
+      prof_t_ = prof_n_;                                                          \
+    } while(0)
+#  define TILE_PROF_COUNT(k)                              \
+    do                                                    \
+    {                                                     \
+      if((threadIdx.x & 63) == 0) mem.prof[k] += 1.0;     \
+    } while(0)
+#else
+#  define TILE_PROF_START() do {} while(0)
+#  define TILE_PROF_ADD(k) do {} while(0)
+#  define TILE_PROF_COUNT(k) do {} while(0)
+#endif
+
 constexpr int kM = 16;      // ridges per step (lanes of a row)
 constexpr int kSlots = 5;   // trajectory buffers: the current one + four line-search candidates
 constexpr double kGravity = 9.80665; // include/CCC/Constants.h:10
@@ -90,6 +143,10 @@ struct alignas(16) Mem
   double wrun[16], wterm[16];
   double alpha[12];
   double inertia[9];
+  unsigned char pair[80];              // (a, b), a <= b, of the entries of Vxx's upper triangle: a | b << 4
+#if defined(CCC_TILE_PROF)
+  double prof[TP_N];
+#endif
 };
 
 // Deterministic sin / cos on every lane (the restatement csrc/ddp_core.h and the oracle share: Cody-Waite reduction by
@@ -151,8 +208,6 @@ struct Solver
   vb inS;            // c < S
   vi arow[3];        // rows of the S x M matrices this lane holds: g, g + 4, g + 8 (clamped to S - 1 when not valid)
   vb aval[3];
-  vi pa[NPASS], pb[NPASS]; // (a, b), a <= b: the entries of Vxx this lane updates
-  vb pval[NPASS];
 
   // solver state (wave-uniform scalars)
   double lambda, dlambda, cost, dV0, dV1;
@@ -178,18 +233,11 @@ struct Solver
       arow[t] = seli(aval[t], a, spl(S - 1));
     }
     // pair index -> (a, b), row-major over the upper triangle: (0,0) (0,1) .. (0,S-1) (1,1) ..
-    for(int q = 0; q < NPASS; q++)
     {
-      vi rem = lane + 64 * q, a = spl(0);
-      pval[q] = rem < NP;
-      for(int r = 0; r < S - 1; r++)
-      {
-        const vb more = (a == r) && (rem >= S - r);
-        rem = seli(more, rem - (S - r), rem);
-        a = seli(more, a + 1, a);
-      }
-      pa[q] = seli(pval[q], a, spl(0));
-      pb[q] = seli(pval[q], a + rem, spl(0));
+      int q = 0;
+      for(int a = 0; a < S; a++)
+        for(int b = a; b < S; b++) mem.pair[q++] = static_cast<unsigned char>(a | (b << 4));
+      for(; q < 80; q++) mem.pair[q] = 0;
     }
     // small tables -> LDS (per-lane indexed reads of kernel arguments would go through scratch)
     for(int e = 0; e < 16; e++)
@@ -199,6 +247,9 @@ struct Solver
     }
     for(int e = 0; e < 12; e++) mem.alpha[e] = e < 11 ? P.alpha[e] : 0.0;
     for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12) ? I.inertia[e] : 0.0;
+#if defined(CCC_TILE_PROF)
+    for(int e = 0; e < TP_N; e++) mem.prof[e] = 0.0;
+#endif
     ph_cached = -1;
     wave_sync();
   }
@@ -505,7 +556,10 @@ struct Solver
     x = sel(in, vmin(vmax(x, lo), hi), 0.0);
     // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); tree16
     auto value_of = [&](vf y) { return read_lane(sum16(vfma(0.5 * y, matvec(HF, y, 0), y * q)), 0); };
+    TILE_PROF_START();
+    TILE_PROF_COUNT(TP_QP_CALLS);
     double value = value_of(x), oldvalue = 0.0;
+    TILE_PROF_ADD(TP_QP_VALUE);
     vb cl = lane < 0; // all false
     skip = ~inmask & 0xffffu;
     rdv = splat(1.0);
@@ -513,6 +567,7 @@ struct Solver
     for(iter = 1; iter <= max_iter; iter++)
     {
       if(result != 0) break;
+      TILE_PROF_COUNT(TP_QP_ITERS);
       if(iter > 1 && (oldvalue - value) < min_rel_improve * std::fabs(oldvalue))
       {
         result = 4;
@@ -524,6 +579,7 @@ struct Solver
       cl = in && (((x == lo) && (grad > 0.0)) || ((x == hi) && (grad < 0.0)));
       const unsigned clmask = static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask;
       const bool changed = (iter == 1) || ((static_cast<unsigned>(ballot(cl != oldc) & 0xffffull) & inmask) != 0u);
+      TILE_PROF_ADD(TP_QP_GRAD);
       if(clmask == inmask)
       {
         result = 6;
@@ -531,6 +587,7 @@ struct Solver
       }
       if(changed)
       {
+        TILE_PROF_COUNT(TP_QP_FACTORS);
         skip = clmask | (~inmask & 0xffffu);
         if(!factorize(HF, skip, rdv))
         {
@@ -538,6 +595,7 @@ struct Solver
           break;
         }
       }
+      TILE_PROF_ADD(TP_QP_FACTOR);
       const vb fr = in && !cl;
       // |grad| on the free rows.  SPEC: sqrt(tree16(free ? grad^2 : 0))
       const double gn = std::sqrt(read_lane(sum16(sel(fr, grad * grad, 0.0)), 0));
@@ -551,6 +609,7 @@ struct Solver
       solve<1>(rhs, skip, rdv);
       const vf srch = sel(fr, -rhs[0] - x, 0.0);
       const double sdotg = read_lane(sum16(srch * grad), 0);
+      TILE_PROF_ADD(TP_QP_SOLVE);
       if(sdotg >= 0) break; // no descent direction: result stays 0
       double step = 1.0, vc;
       vf xc;
@@ -568,6 +627,7 @@ struct Solver
       }
       x = xc;
       value = vc;
+      TILE_PROF_ADD(TP_QP_SEARCH);
     }
     if(iter > max_iter && result == 0) result = 1;
     skip = (static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask) | (~inmask & 0xffffu);
@@ -615,10 +675,12 @@ struct Solver
         x_n = ld_if(xs + static_cast<long>(i - 1) * S, c, inS);
         u_n = ld_if(us + static_cast<long>(i - 1) * kM, c, c < m_n);
       }
+      TILE_PROF_START();
       Terms T;
       terms_of(ph, m, x, u, T);
       vf Fu[6];
       state_eq_deriv(T, x, Fu);
+      TILE_PROF_ADD(TP_DERIV);
       // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
       {
         vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
@@ -646,7 +708,7 @@ struct Solver
         vf s3[3];
         const vf f0 = ld(mem.Fx, col);
         for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
-        W64_UNROLL(2)
+        W64_UNROLL(CCC_TILE_U_PROD)
         for(int b = 1; b < S; b++)
         {
           const vf fb = ld(mem.Fx, col + b * S);
@@ -676,7 +738,7 @@ struct Solver
       {
         const vf t0 = ld(mem.T2, c);
         for(int t = 0; t < 3; t++) Qxu[t] = ld(mem.Fx, arow[t]) * t0;
-        W64_UNROLL(2)
+        W64_UNROLL(CCC_TILE_U_PROD)
         for(int b = 1; b < S; b++)
         {
           const vf tb = ld(mem.T2, c + b * kM);
@@ -688,7 +750,7 @@ struct Solver
       vf Qxx[3];
       {
         for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
-        W64_UNROLL(2)
+        W64_UNROLL(CCC_TILE_U_PROD)
         for(int b = 0; b < S; b++)
         {
           const vf tb = ld(mem.T1, col + b * S);
@@ -701,6 +763,7 @@ struct Solver
         st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
         st(mem.Zl, arow[t] * LT + c, Qxu[t], aval[t]);         // (Qxu waits in Z's place while the box-QP runs)
       }
+      TILE_PROF_ADD(TP_PRODUCTS);
       // box-QP and gains
       vf k = splat(0.0);
       vf K[3] = {splat(0.0), splat(0.0), splat(0.0)};
@@ -713,6 +776,7 @@ struct Solver
         vf rdv;
         const int rc = box_qp(m, HF, Qu, lo, hi, k, skip, rdv);
         if(rc < 1) return false;
+        TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
         // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
         const vb fr = ((spl(static_cast<int>(skip)) >> c) & 1) == 0;
         vf rhs[3];
@@ -727,6 +791,7 @@ struct Solver
         st(I.Ks + static_cast<long>(i) * kM * S, c * S + arow[t], K[t], aval[t]);
         st(mem.T2, arow[t] * LT + c, K[t], aval[t]);
       }
+      TILE_PROF_ADD(TP_GAINS);
       // termination measure: max_c |k_c| / (|u_c| + 1)
       gsum += read_lane(max16(sel(in, vabs(k) / (vabs(u) + 1.0), 0.0)), 0);
       // dV += [k'Qu, 1/2 k'Quu k].  SPEC: tree16(k_c Qu_c), 0.5 tree16(k_c (Quu k)_c)
@@ -750,7 +815,7 @@ struct Solver
       wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
       for(int t = 0; t < 3; t++)
       {
-        W64_UNROLL(1)
+        W64_UNROLL(CCC_TILE_U_Z)
         for(int gg = 0; gg < 4; gg++)
         {
           const int a = gg + 4 * t;
@@ -769,18 +834,23 @@ struct Solver
       // SPEC: acc = 0; for c = 0 .. 15: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
       for(int q = 0; q < NPASS; q++)
       {
+        const vi pidx = lane + 64 * q;
+        const vb pv = pidx < NP;
+        const vi ab = ldb(mem.pair, seli(pv, pidx, spl(0)));
+        const vi pa = ab & 15, pb = ab >> 4;
         vf acc = splat(0.0);
-        W64_UNROLL(4)
+        W64_UNROLL(CCC_TILE_U_PAIR)
         for(int r = 0; r < kM; r++)
         {
-          acc = vfma(ld(mem.T2, pa[q] * LT + r), ld(mem.Zl, pb[q] * LT + r), acc);
-          acc = vfma(ld(mem.T2, pb[q] * LT + r), ld(mem.Zl, pa[q] * LT + r), acc);
+          acc = vfma(ld(mem.T2, pa * LT + r), ld(mem.Zl, pb * LT + r), acc);
+          acc = vfma(ld(mem.T2, pb * LT + r), ld(mem.Zl, pa * LT + r), acc);
         }
-        const vf v = 0.5 * ((ld(mem.T1, pa[q] * S + pb[q]) + ld(mem.T1, pb[q] * S + pa[q])) + acc);
-        st(mem.Vxx, pa[q] * S + pb[q], v, pval[q]);
-        st(mem.Vxx, pb[q] * S + pa[q], v, pval[q]);
+        const vf v = 0.5 * ((ld(mem.T1, pa * S + pb) + ld(mem.T1, pb * S + pa)) + acc);
+        st(mem.Vxx, pa * S + pb, v, pv);
+        st(mem.Vxx, pb * S + pa, v, pv);
       }
       wave_sync();
+      TILE_PROF_ADD(TP_VALUE);
       kprev = k;
       mprev = m;
     }
@@ -798,6 +868,8 @@ struct Solver
     const vi slot = seli(g == 0, spl(cand[0]), seli(g == 1, spl(cand[1]), seli(g == 2, spl(cand[2]), spl(cand[3]))));
     const vi xoff = slot * ((N + 1) * S), uoff = slot * (N * kM);
     mem_sync(); // (the gains were written by other lanes of this wavefront)
+    TILE_PROF_START();
+    TILE_PROF_COUNT(TP_FORWARDS);
     vf x = ld_if(I.x0, c, inS);
     vf costc = splat(0.0);
     st(I.xbuf, xoff + c, x, inS);
@@ -835,7 +907,9 @@ struct Solver
       x = state_eq(T, x);
       st(I.xbuf, xoff + (i + 1) * S + c, x, inS);
     }
-    return costc + terminal_cost(x);
+    const vf total = costc + terminal_cost(x);
+    TILE_PROF_ADD(TP_FORWARD);
+    return total;
   }
   template<int A>
   W64_FN vf feedback(vf s, vf dx, const vf (&Kr)[S]) const
@@ -974,6 +1048,11 @@ struct Solver
       if(I.x_out)
         for(int e = 0; e < (N + 1) * S; e += 64)
           st(I.x_out, lane + e, ld_if(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
+#if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+      mem_sync();
+      if((threadIdx.x & 63) == 0)
+        for(int e = 0; e < TP_N; e++) I.u_out[e] = mem.prof[e];
+#endif
       if(I.out_iters) I.out_iters[0] = iter;
       if(I.out_status) I.out_status[0] = status;
       if(I.out_cost) I.out_cost[0] = cost;

@@ -125,6 +125,7 @@ W64_FN void st(double * p, vi idx, vf v, vb m)
   if(m) p[idx] = v;
 }
 W64_FN vi ldi(const int * p, vi idx) { return p[idx]; }
+W64_FN vi ldb(const unsigned char * p, vi idx) { return static_cast<int>(p[idx]); }
 // Orders this wavefront's LDS traffic: the LDS executes one wavefront's operations in order, so all that is needed is that
 // the COMPILER keeps the accesses on their side of this point (a wavefront-scope fence + scheduling barrier: no
 // s_barrier, and above all no s_waitcnt vmcnt(0) -- __syncthreads() would drain every global load in flight here).
@@ -448,6 +449,12 @@ inline vi ldi(const int * p, const vi & idx)
 {
   vi r;
   W64_LOOP r.v[l_] = p[idx.v[l_]];
+  return r;
+}
+inline vi ldb(const unsigned char * p, const vi & idx)
+{
+  vi r;
+  W64_LOOP r.v[l_] = static_cast<int>(p[idx.v[l_]]);
   return r;
 }
 inline void wave_sync() {}
