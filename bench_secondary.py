@@ -10,6 +10,7 @@ import time
 import numpy as np
 import torch
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
 
 
@@ -149,7 +150,28 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                 kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
                 (("ddp_tile_kernel<%d>" % S) if precision == 64
                  else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
+                valu=lambda iters: _ddp_valu(S, M, N, iters, walking, precision),
                 keep=(d, tp, tx0))
+
+
+def _ddp_valu(S, M, N, iters, walking, precision):
+    """Useful flop per solve: SURVEY.md 8(d)'s count per backward step (Quu 2(S^2 m + S m^2), Qxu / Qxx 2(S^3 + S^2 m),
+    Cholesky m^3 / 3, gains 2 m^2 S, value update 6 k at S = 9, m = 16: ~25 kflop) scaled to (S, m) x horizon x the
+    iterations the run executed; the issue share comes from the committed PMC pass of the same kernel."""
+    m = M
+    per_step = 2 * (S * S * m + S * m * m) + 2 * (S ** 3 + S * S * m) + m ** 3 / 3 + 2 * m * m * S + 6e3 * (S / 9.0) ** 2
+    pmc = None
+    if not walking and precision == 64:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_ddp_valu_counters.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                pmc = json.load(f).get("S%d" % S)
+    return dict(flop_per_solve=per_step * N * iters, flop_per_backward_step=per_step,
+                issue_frac=None if pmc is None else pmc["valu_issue_frac"],
+                wait_frac=None if pmc is None else pmc["wait_any_frac"],
+                counters_source="profiles/r03_ddp_valu_counters.json" if pmc else None,
+                what="useful fp64 flop of the backward passes over the kernel time against the vector-fp64 peak; "
+                     "issue_frac = SQ_INSTS_VALU x 4 clk / (SIMDs x kernel clocks), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
 
 
 def _ism(n, dev, rank):
@@ -328,6 +350,15 @@ def run(args, rank, world, local_rank, dist):
     #                                      0 = iteration limit, 1 / 2 = converged (oracle/ddp.c); QPs: low byte != 0
     if "iters" in w:
         out["mean_iterations"] = float(w["iters"].float().mean().item())
+    if "valu" in w:
+        # the DDP planners are bound by the latency of dependent fp64 VALU / LDS operations, not by HBM: the figures that
+        # say how far the kernel is from THAT roofline (useful flop from SURVEY.md 8(d)'s count per backward step x the
+        # steps the run executed, against the vector-fp64 peak; the issue share from the PMC pass in profiles/)
+        v = w["valu"](out["mean_iterations"])
+        tfl = v["flop_per_solve"] * n / kavg / 1e12
+        out["roofline"]["bound"] = "valu"
+        out["roofline"]["valu"] = dict(achieved=tfl, peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s",
+                                       frac=tfl / FP64_VECTOR_PEAK_TFLOPS, **v)
     if not args.no_cpu_baseline and world == 1:
         cores = os.cpu_count() or 1
         rate, ns, err, what = w["cpu"](cores)

@@ -39,6 +39,16 @@ ABI_SYMBOLS = [
     "ccc_zmp_sharded_num_devices",
     "ccc_zmp_sharded_plan_batch",
     "ccc_zmp_sharded_plan_batch_device",
+    "ccc_zmp_sharded_plan_batch_device_ordered",
+    "ccc_xy_sharded_create",
+    "ccc_xy_sharded_destroy",
+    "ccc_xy_sharded_num_devices",
+    "ccc_xy_sharded_plan_batch_device",
+    "ccc_ddp_sharded_create",
+    "ccc_ddp_sharded_destroy",
+    "ccc_ddp_sharded_num_devices",
+    "ccc_ddp_sharded_set_config",
+    "ccc_ddp_sharded_plan_batch_device",
     "ccc_last_error_string",
     "ccc_abi_version",
     "ccc_zmp_create",

@@ -125,5 +125,134 @@ class ShardedLinearMpcZmp:
         def arr(ts):
             return (ct.c_void_p * D)(*[ct.c_void_p(t.data_ptr()) for t in ts])
 
-        self._lib.check(self._L.ccc_zmp_sharded_plan_batch_device(self._h, m, arr(x0), arr(zlim), float(control_dt),
-                                                                   arr(zmp_all), arr(status) if status else None))
+        # the handle's streams wait for what torch has enqueued on each device's current stream (inputs produced by
+        # asynchronous kernels, output buffers still being filled)
+        self._L.ccc_zmp_sharded_plan_batch_device_ordered.restype = ct.c_int
+        self._L.ccc_zmp_sharded_plan_batch_device_ordered.argtypes = [
+            ct.c_void_p, ct.c_int64, ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), ct.c_double,
+            ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p)]
+        self._lib.check(self._L.ccc_zmp_sharded_plan_batch_device_ordered(
+            self._h, m, arr(x0), arr(zlim), float(control_dt), arr(zmp_all), arr(status) if status else None,
+            _current_streams(self.devices)))
+
+
+def _current_streams(devices):
+    """torch's current stream of every listed device, as the void * list the sharded entry points order themselves after."""
+    import ctypes
+
+    import torch
+
+    return (ctypes.c_void_p * len(devices))(*[ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream) for d in devices])
+
+
+def _ptr_list(ts, D):
+    import ctypes
+
+    if ts is None:
+        return None
+    return (ctypes.c_void_p * D)(*[None if t is None else ctypes.c_void_p(t.data_ptr()) for t in ts])
+
+
+class ShardedLinearMpcXY:
+    """ccc_xy_sharded_* (csrc/sharded.hip): LinearMpcXY over a device list in ONE process -- BASELINE config 4's "sharded
+    8xMI355X over xGMI" for a C++ host.  Built from a LinearMpcXY mirror object (its parameters are replicated on every
+    listed device)."""
+
+    def __init__(self, planner, devices):
+        import ctypes
+
+        from . import _lib
+        from .linear_mpc_xy import _Params
+
+        self._lib, L = _lib, _lib.load()
+        vp = ctypes.c_void_p
+        L.ccc_xy_get_params.restype = ctypes.c_int
+        L.ccc_xy_get_params.argtypes = [vp, ctypes.POINTER(_Params), ctypes.POINTER(ctypes.c_int)]
+        L.ccc_xy_sharded_create.restype = ctypes.c_int
+        L.ccc_xy_sharded_create.argtypes = [ctypes.POINTER(_Params), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                            ctypes.POINTER(vp)]
+        L.ccc_xy_sharded_destroy.restype = None
+        L.ccc_xy_sharded_destroy.argtypes = [vp]
+        L.ccc_xy_sharded_plan_batch_device.restype = ctypes.c_int
+        L.ccc_xy_sharded_plan_batch_device.argtypes = [vp, ctypes.c_int64] + [ctypes.POINTER(vp)] * 10
+        self._L = L
+        prm = _Params()
+        _lib.check(L.ccc_xy_get_params(planner._h, ctypes.byref(prm), None))
+        self.max_ridges_ = prm.max_ridges or 16
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = vp()
+        _lib.check(L.ccc_xy_sharded_create(ctypes.byref(prm), arr, len(self.devices), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.ccc_xy_sharded_destroy(h)
+            self._h = None
+
+    def plan_batch_device(self, probs, x0, u0_all, status=None):
+        """probs: one dict of CUDA tensors per device (keys of LinearMpcXY.plan_batch_device), x0[r] [m,6], u0_all[r]
+        [D*m, M] on devices[r]: receives the planned first-step force scales of ALL shards.  Synchronous."""
+        D = len(self.devices)
+        m = x0[0].shape[0]
+        cols = [[p[k] for p in probs] for k in ("dim", "vertex", "ridge", "com_z", "total_force_z", "ref_out")]
+        self._lib.check(self._L.ccc_xy_sharded_plan_batch_device(
+            self._h, m, *[_ptr_list(c, D) for c in cols], _ptr_list(x0, D), _ptr_list(u0_all, D), _ptr_list(status, D),
+            _current_streams(self.devices)))
+
+
+class ShardedDdp:
+    """ccc_ddp_sharded_* (csrc/sharded.hip): DdpCentroidal / DdpSingleRigidBody over a device list in ONE process --
+    BASELINE config 5's "8xMI355X" for a C++ host.  Built from a mirror object (parameters and the current solver
+    configuration are replicated on every listed device)."""
+
+    def __init__(self, planner, devices):
+        import ctypes
+
+        from . import _lib
+        from .ddp import Config, _Params as Params
+
+        self._lib, L = _lib, _lib.load()
+        vp = ctypes.c_void_p
+        L.ccc_ddp_get_params.restype = ctypes.c_int
+        L.ccc_ddp_get_params.argtypes = [vp, ctypes.POINTER(Params)]
+        L.ccc_ddp_sharded_create.restype = ctypes.c_int
+        L.ccc_ddp_sharded_create.argtypes = [ctypes.POINTER(Params), ctypes.POINTER(Config), ctypes.POINTER(ctypes.c_int),
+                                             ctypes.c_int, ctypes.POINTER(vp)]
+        L.ccc_ddp_sharded_destroy.restype = None
+        L.ccc_ddp_sharded_destroy.argtypes = [vp]
+        L.ccc_ddp_sharded_plan_batch_device.restype = ctypes.c_int
+        L.ccc_ddp_sharded_plan_batch_device.argtypes = [vp, ctypes.c_int64] + [ctypes.POINTER(vp)] * 15
+        self._L = L
+        prm = Params()
+        _lib.check(L.ccc_ddp_get_params(planner._h, ctypes.byref(prm)))
+        self.S, self.N, self.M = planner.S, prm.horizon_steps, prm.max_ridges
+        self.devices = [int(d) for d in devices]
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        h = vp()
+        _lib.check(L.ccc_ddp_sharded_create(ctypes.byref(prm), ctypes.byref(planner.ddp_solver_.config()), arr,
+                                            len(self.devices), ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.ccc_ddp_sharded_destroy(h)
+            self._h = None
+
+    def plan_batch_device(self, probs, x0, u_out, u0_all, u_init=None, iters=None, status=None, cost=None):
+        """probs: one dict of CUDA tensors per device (keys of the planners' plan_batch_device); x0[r] [m,S]; u_out[r]
+        [m,N,M] (the shard's whole planned sequence, stays on its device); u0_all[r] [D*m, M]: the planned first-step
+        force scales of ALL shards.  Synchronous."""
+        D = len(self.devices)
+        m = x0[0].shape[0]
+
+        def col(k):
+            return None if k not in probs[0] or probs[0][k] is None else _ptr_list([p[k] for p in probs], D)
+
+        self._lib.check(self._L.ccc_ddp_sharded_plan_batch_device(
+            self._h, m, col("phase_dim"), col("phase_vertex"), col("phase_ridge"), col("step_phase"), col("ref_pos"),
+            col("ref_ori"), col("inertia"), _ptr_list(x0, D), _ptr_list(u_init, D), _ptr_list(u_out, D),
+            _ptr_list(u0_all, D), _ptr_list(iters, D), _ptr_list(status, D), _ptr_list(cost, D),
+            _current_streams(self.devices)))

@@ -507,6 +507,50 @@ int ccc_zmp_sharded_plan_batch(ccc_zmp_sharded_t * h, int64_t n, const double * 
 int ccc_zmp_sharded_plan_batch_device(ccc_zmp_sharded_t * h, int64_t n_per_device, const double * const * x0,
                                       const double * const * zlim, double control_dt, double * const * zmp_all,
                                       int32_t * const * status);
+/* The same with the ORDERING made explicit: caller_streams[r] (a hipStream_t, or NULL = the legacy default stream of
+ * devices[r]) is the stream on which the caller produced x0[r] / zlim[r] and last touched zmp_all[r]; the handle's
+ * stream of that device waits for it (event record + hipStreamWaitEvent) before the plan kernels start, so inputs
+ * written by asynchronous kernels are complete and output buffers still being filled are not overwritten early.
+ * ccc_zmp_sharded_plan_batch_device is this call with caller_streams = NULL (every device's default stream). */
+int ccc_zmp_sharded_plan_batch_device_ordered(ccc_zmp_sharded_t * h, int64_t n_per_device, const double * const * x0,
+                                              const double * const * zlim, double control_dt,
+                                              double * const * zmp_all, int32_t * const * status,
+                                              void * const * caller_streams);
+
+/* The same for the classes BASELINE's configs put on eight GPUs ("LinearMpcXY ... sharded 8xMI355X over xGMI",
+ * "DdpSingleRigidBody ... 8xMI355X"): one planner handle per device, device-resident shards of n_per_device instances in
+ * the layouts of ccc_xy_plan_batch_device / ccc_ddp_plan_batch_device (every argument is a list of num_devices DEVICE
+ * pointers, entry r on devices[r]), each device plans its shard on the handle's stream of that device (ordered behind
+ * caller_streams[r] as above) and one grouped in-place ncclAllGather leaves the planned FIRST-STEP force scales of all
+ * shards on every device:
+ *   u0_all[r]   [num_devices * n_per_device][M]  on devices[r]; slot r is written by the plan, the rest by the all-gather
+ * LinearMpcXY: status[r] [n_per_device] optional.  DDP: u_out[r] [n_per_device][N][M] (the whole planned sequence of the
+ * shard stays on its device: it is the next call's warm start), iters / status / cost lists optional, ref_ori / inertia
+ * lists NULL for DdpCentroidal, u_init list or entries NULL for a cold start.  Synchronous. */
+typedef struct ccc_xy_sharded ccc_xy_sharded_t;
+int ccc_xy_sharded_create(const ccc_xy_params_t * params, const int * devices, int num_devices, ccc_xy_sharded_t ** out);
+void ccc_xy_sharded_destroy(ccc_xy_sharded_t * h);
+int ccc_xy_sharded_num_devices(const ccc_xy_sharded_t * h);
+int ccc_xy_sharded_plan_batch_device(ccc_xy_sharded_t * h, int64_t n_per_device, const int32_t * const * dim,
+                                     const double * const * vertex, const double * const * ridge,
+                                     const double * const * com_z, const double * const * total_force_z,
+                                     const double * const * ref_out, const double * const * x0, double * const * u0_all,
+                                     int32_t * const * status, void * const * caller_streams);
+
+typedef struct ccc_ddp_sharded ccc_ddp_sharded_t;
+/* config may be NULL (ccc_ddp_default_config) */
+int ccc_ddp_sharded_create(const ccc_ddp_params_t * params, const ccc_ddp_config_t * config, const int * devices,
+                           int num_devices, ccc_ddp_sharded_t ** out);
+void ccc_ddp_sharded_destroy(ccc_ddp_sharded_t * h);
+int ccc_ddp_sharded_num_devices(const ccc_ddp_sharded_t * h);
+int ccc_ddp_sharded_set_config(ccc_ddp_sharded_t * h, const ccc_ddp_config_t * config);
+int ccc_ddp_sharded_plan_batch_device(ccc_ddp_sharded_t * h, int64_t n_per_device, const int32_t * const * phase_dim,
+                                      const double * const * phase_vertex, const double * const * phase_ridge,
+                                      const int32_t * const * step_phase, const double * const * ref_pos,
+                                      const double * const * ref_ori, const double * const * inertia,
+                                      const double * const * x0, const double * const * u_init, double * const * u_out,
+                                      double * const * u0_all, int32_t * const * iters, int32_t * const * status,
+                                      double * const * cost, void * const * caller_streams);
 
 #ifdef __cplusplus
 }

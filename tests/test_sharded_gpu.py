@@ -44,6 +44,83 @@ def test_device_shards_with_rccl_all_gather():
     assert torch.cuda.current_device() == 0  # the entry points restore the caller's device
 
 
+def test_device_entry_orders_itself_after_the_callers_stream():
+    """The sharded device entry runs on streams of its own; it has to wait for what the caller enqueued before it.
+    Inputs produced by a long asynchronous chain of kernels on torch's current stream (they are NOT complete when the
+    call is made) and an output buffer whose NaN fill is still queued: the plan must see the finished inputs and its
+    results must survive."""
+    import torch
+
+    devs = _devices()
+    D, m, N, dt = len(devs), 4096, 32, 0.0625
+    b = fx.make_zmp_batch(D * m, N, dt, seed=9)
+    ref = LinearMpcZmp(1.0, 2.0, dt).planOnceBatch(b["x0"], b["zlim"], 0.005)["zmp"]
+    sh = ShardedLinearMpcZmp(1.0, 2.0, dt, devs)
+    x0, zl, out = [], [], []
+    for r, d in enumerate(devs):
+        with torch.cuda.device(d):
+            hx = torch.from_numpy(b["x0"][r * m:(r + 1) * m]).to("cuda:%d" % d)
+            hz = torch.from_numpy(b["zlim"][r * m:(r + 1) * m]).to("cuda:%d" % d)
+            x, z = torch.zeros_like(hx), torch.zeros_like(hz)
+            big = torch.zeros((64, 1 << 20), dtype=torch.float64, device="cuda:%d" % d)
+            for _ in range(20):  # ~ms of queued work in front of the producers
+                big.add_(1.0)
+            x.copy_(hx * 1.0)
+            z.copy_(hz + 0.0)
+            o = torch.empty((D * m, 2), dtype=torch.float64, device="cuda:%d" % d)
+            o.fill_(float("nan"))
+            x0.append(x), zl.append(z), out.append(o)
+    sh.plan_batch_device(x0, zl, 0.005, out)  # (no synchronize in between)
+    for t in out:
+        assert np.array_equal(t.cpu().numpy(), ref)
+
+
+def test_xy_and_ddp_shards_with_rccl_all_gather():
+    """ccc_xy_sharded_* / ccc_ddp_sharded_*: the classes BASELINE's configs 4 and 5 put on eight GPUs, through the same
+    shard group (per-device handle + stream, grouped in-place all-gather of the planned first-step force scales)."""
+    import torch
+
+    from centroidalcontrolcollection_amd import DdpSingleRigidBody, LinearMpcXY, fixtures_ddp as fd
+    from centroidalcontrolcollection_amd.sharding import ShardedDdp, ShardedLinearMpcXY
+
+    devs = _devices()
+    D = len(devs)
+    # LinearMpcXY
+    m, N = 1024, 20
+    prob, x0 = fd.make_xy_batch(D * m, N, 0.1, seed=3)
+    mpc = LinearMpcXY(100.0, 0.1, N)
+    ref = mpc.planOnceBatch(prob, x0)["u0"]
+    sh = ShardedLinearMpcXY(mpc, devs)
+    probs = [{k: torch.from_numpy(np.ascontiguousarray(v[r * m:(r + 1) * m])).to("cuda:%d" % d) for k, v in prob.items()}
+             for r, d in enumerate(devs)]
+    xs = [torch.from_numpy(x0[r * m:(r + 1) * m]).to("cuda:%d" % d) for r, d in enumerate(devs)]
+    outs = [torch.full((D * m, 16), float("nan"), dtype=torch.float64, device="cuda:%d" % d) for d in devs]
+    st = [torch.zeros(m, dtype=torch.int32, device="cuda:%d" % d) for d in devs]
+    sh.plan_batch_device(probs, xs, outs, st)
+    for t in outs:
+        assert np.array_equal(t.cpu().numpy(), ref)
+    # DdpSingleRigidBody
+    m, N, dt = 256, 50, 0.03
+    prob, x0 = fd.make_centroidal_batch(D * m, N, dt, seed=4, srb=True)
+    w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3,
+                                       terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3)
+    d = DdpSingleRigidBody(100.0, dt, N, w)
+    d.ddp_solver_.config().max_iter = 8
+    ref = d.planOnceBatch(prob, x0)
+    sh = ShardedDdp(d, devs)
+    probs = [{k: torch.from_numpy(np.ascontiguousarray(v[r * m:(r + 1) * m])).to("cuda:%d" % dv) for k, v in prob.items()}
+             for r, dv in enumerate(devs)]
+    xs = [torch.from_numpy(x0[r * m:(r + 1) * m]).to("cuda:%d" % dv) for r, dv in enumerate(devs)]
+    us = [torch.zeros((m, N, 16), dtype=torch.float64, device="cuda:%d" % dv) for dv in devs]
+    u0 = [torch.full((D * m, 16), float("nan"), dtype=torch.float64, device="cuda:%d" % dv) for dv in devs]
+    it = [torch.zeros(m, dtype=torch.int32, device="cuda:%d" % dv) for dv in devs]
+    sh.plan_batch_device(probs, xs, us, u0, iters=it)
+    for t in u0:
+        assert np.array_equal(t.cpu().numpy(), ref["u"][:, 0, :])
+    assert np.array_equal(torch.cat([t.cpu() for t in us]).numpy(), ref["u"])
+    assert np.array_equal(torch.cat([t.cpu() for t in it]).numpy(), ref["iters"])
+
+
 def test_duplicate_device_is_refused():
     from centroidalcontrolcollection_amd import _lib
 
