@@ -139,7 +139,7 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
     return dict(name="%s planOnce() solves/sec (horizon %d, <= 20 DDP iterations, %s, inputs resident in HBM)"
                 % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N,
                    "fp64" if precision == 64 else "fp32 storage / fp64 arithmetic in the backward pass"),
-                step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f32",
+                step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f64 (f32 storage)",  # (the arithmetic type of the path, not its storage format)
                 workload=("%s horizon=%d @ %d ms, max_iter=20, batch=%d per GPU (%s)"
                           % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, round(dt * 1e3), n,
                              "walking with 32-ridge double support, %d contact phases: beyond BASELINE's configs, "

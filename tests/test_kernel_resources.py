@@ -1,0 +1,74 @@
+"""The occupancy-step check of DESIGN.md section 9 as a test: every hot kernel is compiled for gfx950 with
+-Rpass-analysis=kernel-resource-usage and its registers are held against the step it was tuned for (168 VGPRs: three
+wavefronts per SIMD, 128: four) -- three kernels once sat ONE register over a step after unrelated edits and lost a
+wavefront per SIMD without a word from the compiler (round 2).  Also pinned: no scratch where there was none, the LDS
+footprint of the kernels whose residency is LDS-limited.  hipcc cross-compiles without a GPU; ~1 minute."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# kernel (demangled prefix) -> (unit, max VGPRs, min waves/SIMD, max scratch bytes/lane, max LDS bytes or None)
+EXPECT = {
+    "void ccc_amd::zmp_plan_kernel<32, 2>": ("zmp", 168, 3, 0, None),          # K1, static pairing (headline, small batches)
+    "void ccc_amd::zmp_plan_kernel_dyn<32, 2>": ("zmp", 168, 3, 0, None),      # K1, work queue (headline)
+    "void ccc_amd::zmp_plan_sym_kernel<40, 4, 2>": ("zmp", 128, 4, 0, None),   # K2 at 40 rows: 16 workgroups per CU
+    "void ccc_amd::zmp_plan_sym_kernel<104, 4, 2>": ("zmp", 168, 3, 0, None),  # K2 at the reference test's horizon
+    "void ccc_amd::ddp_tile_kernel<9>": ("ddp_tile", 128, 4, 600, 10240),      # DDP default kernel: 16 wavefronts per CU
+    "void ccc_amd::ddp_tile_kernel<12>": ("ddp_tile", 128, 4, 700, 10240),
+    "ccc_amd::z_plan_stream_kernel": ("z", 168, 3, 0, None),
+    "void ccc_amd::z_plan_kernel<40, 1>": ("z", 168, 3, 0, 14336),             # eleven workgroups per CU
+    "ccc_amd::ism_plan_pcr_kernel": ("ism", 128, 4, 0, 24576),
+    "ccc_amd::xy_plan_kernel": ("xy", 128, 4, 256, 81920),                     # two 448-thread workgroups per CU
+}
+
+
+def _usage(unit):
+    src = os.path.join(CSRC, unit + ".hip")
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function",
+                          "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", src, "-o", os.devnull],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip().split("(")[0]
+            res[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur:
+            res[cur][m.group(1).strip()] = int(m.group(2))
+    return res
+
+
+@pytest.fixture(scope="module")
+def usage():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    units = sorted({v[0] for v in EXPECT.values()})
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
+        res = {}
+        for r in pool.map(_usage, units):
+            res.update(r)
+    return res
+
+
+@pytest.mark.parametrize("kernel", sorted(EXPECT))
+def test_hot_kernel_stays_on_its_occupancy_step(usage, kernel):
+    unit, max_vgpr, min_waves, max_scratch, max_lds = EXPECT[kernel]
+    assert kernel in usage, "kernel %s not found in %s.hip (renamed?): %s" % (kernel, unit, sorted(usage))
+    u = usage[kernel]
+    assert u["VGPRs"] + u.get("AGPRs", 0) <= max_vgpr, u
+    assert u["Occupancy"] >= min_waves, u
+    assert u["ScratchSize"] <= max_scratch, u
+    if max_scratch == 0:
+        assert u["VGPRs Spill"] == 0, u
+    if max_lds is not None:
+        assert u["LDS Size"] <= max_lds, u
