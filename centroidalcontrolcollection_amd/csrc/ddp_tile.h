@@ -203,6 +203,9 @@ struct Solver
   const Instance & I;
   Mem<S> & mem;
 
+  // masked loads: branch-free for the 9-state model, predicated for the 12-state one (measured, see w64::ld_if_branch)
+  static W64_FN vf ldm(const double * p, vi idx, vb m) { return S == 12 ? ld_if_branch(p, idx, m) : ld_if(p, idx, m); }
+
   // lane coordinates
   vi lane, c, g;
   vb inS;            // c < S
@@ -273,15 +276,15 @@ struct Solver
     const vb in = c < dim;
     for(int k = 0; k < 3; k++)
     {
-      Vc[k] = ld_if(I.phase_vertex + base, c * 3 + k, in);
-      Rc[k] = ld_if(I.phase_ridge + base, c * 3 + k, in);
+      Vc[k] = ldm(I.phase_vertex + base, c * 3 + k, in);
+      Rc[k] = ldm(I.phase_ridge + base, c * 3 + k, in);
     }
   }
   // reference of the weighted state entries (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0]) on the lanes a < S
   W64_FN vf ref_of(int step) const
   {
-    vf r = ld_if(I.ref_pos + static_cast<long>(step) * 3, c, c < 3);
-    if(S == 12) r = sel(c >= 3 && c < 6, ld_if(I.ref_ori + static_cast<long>(step) * 3, c - 3, c >= 3 && c < 6), r);
+    vf r = ldm(I.ref_pos + static_cast<long>(step) * 3, c, c < 3);
+    if(S == 12) r = sel(c >= 3 && c < 6, ldm(I.ref_ori + static_cast<long>(step) * 3, c - 3, c >= 3 && c < 6), r);
     return r;
   }
 
@@ -481,30 +484,56 @@ struct Solver
     }
     rdv = splat(1.0);
     bool ok = true;
-    for(int j = 0; j < kM; j++)
-    {
-      const int gj = j >> 2, sj = j & 3;
-      if((skip >> j) & 1u)
-      {
-        st(mem.L, c * LT + j, splat(0.0), g == 0);
-        continue;
-      }
-      const double d = read_lane(a[sj], 16 * gj + j);
-      if(!(d > 0.0)) ok = false;
-      const double r = 1.0 / d;
-      st(mem.cb[j & 1], c, a[sj], g == gj);
-      wave_sync();
-      const vf uc = ld(mem.cb[j & 1], c);
-      st(mem.L, c * LT + j, sel(c > j, uc * r, 0.0), g == 0);
-      rdv = sel(c == j, splat(r), rdv);
-      for(int s = 0; s < 4; s++)
-      {
-        const vf uk = ld(mem.cb[j & 1], g * 4 + s);
-        a[s] = vfma(-(uc * uk), splat(r), a[s]);
-      }
-    }
+    factor_col<0>(a, skip, rdv, ok);
     wave_sync();
     return ok;
+  }
+
+  // one column of the factorisation (a compile-time column index: the entries of `a` stay in their registers)
+  template<int J>
+  W64_FN void factor_col(vf (&a)[4], unsigned skip, vf & rdv, bool & ok)
+  {
+    if constexpr(J < kM)
+    {
+      constexpr int gj = J >> 2, sj = J & 3;
+      if((skip >> J) & 1u)
+        st(mem.L, c * LT + J, splat(0.0), g == 0);
+      else
+      {
+        // (source order = issue order wanted: the column goes to LDS and its reads are in flight while the pivot's
+        //  reciprocal -- an IEEE division, the longest dependent chain of the step -- is computed)
+#if defined(CCC_TILE_FACTOR_SERIAL)
+        const double d = read_lane(a[sj], 16 * gj + J);
+        if(!(d > 0.0)) ok = false;
+        const double r = 1.0 / d;
+        st(mem.cb[J & 1], c, a[sj], g == gj);
+        wave_sync();
+        const vf uc = ld(mem.cb[J & 1], c);
+        st(mem.L, c * LT + J, sel(c > J, uc * r, 0.0), g == 0);
+        rdv = sel(c == J, splat(r), rdv);
+        for(int s = 0; s < 4; s++)
+        {
+          const vf uk = ld(mem.cb[J & 1], g * 4 + s);
+          a[s] = vfma(-(uc * uk), splat(r), a[s]);
+        }
+#else
+        st(mem.cb[J & 1], c, a[sj], g == gj);
+        wave_sync();
+        const vf uc = ld(mem.cb[J & 1], c);
+        vf uk[4];
+        for(int s = 0; s < 4; s++) uk[s] = ld(mem.cb[J & 1], g * 4 + s);
+        const double d = read_lane(a[sj], 16 * gj + J);
+        if(!(d > 0.0)) ok = false;
+        const double r = 1.0 / d;
+        vf pk[4];
+        for(int s = 0; s < 4; s++) pk[s] = uc * uk[s];
+        st(mem.L, c * LT + J, sel(c > J, uc * r, 0.0), g == 0);
+        rdv = sel(c == J, splat(r), rdv);
+        for(int s = 0; s < 4; s++) a[s] = vfma(-pk[s], splat(r), a[s]);
+#endif
+      }
+      factor_col<J + 1>(a, skip, rdv, ok);
+    }
   }
 
   // b <- H~^-1 b for NR right-hand sides held one entry per lane (rows may hold different ones), zero on the skipped
@@ -650,7 +679,7 @@ struct Solver
     wave_sync();
     st(mem.Vxx, seli(inS, c * S + c, spl(0)), ld(mem.wterm, c), inS && (g == 0));
     {
-      const vf xN = ld_if(xs + static_cast<long>(N) * S, c, inS);
+      const vf xN = ldm(xs + static_cast<long>(N) * S, c, inS);
       st(mem.Vx, c, sel(inS, ld(mem.wterm, c) * (xN - ref_of(N)), 0.0), g == 0);
     }
     wave_sync();
@@ -661,8 +690,8 @@ struct Solver
     int mprev = -1;
     // the operands of step i - 1 are fetched while step i computes
     int ph_n = phase_of(N - 1), m_n = dim_of_phase(ph_n);
-    vf x_n = ld_if(xs + static_cast<long>(N - 1) * S, c, inS);
-    vf u_n = ld_if(us + static_cast<long>(N - 1) * kM, c, c < m_n);
+    vf x_n = ldm(xs + static_cast<long>(N - 1) * S, c, inS);
+    vf u_n = ldm(us + static_cast<long>(N - 1) * kM, c, c < m_n);
     for(int i = N - 1; i >= 0; i--)
     {
       const int m = m_n, ph = ph_n;
@@ -672,8 +701,8 @@ struct Solver
       {
         ph_n = phase_of(i - 1);
         m_n = dim_of_phase(ph_n);
-        x_n = ld_if(xs + static_cast<long>(i - 1) * S, c, inS);
-        u_n = ld_if(us + static_cast<long>(i - 1) * kM, c, c < m_n);
+        x_n = ldm(xs + static_cast<long>(i - 1) * S, c, inS);
+        u_n = ldm(us + static_cast<long>(i - 1) * kM, c, c < m_n);
       }
       TILE_PROF_START();
       Terms T;
@@ -870,14 +899,14 @@ struct Solver
     mem_sync(); // (the gains were written by other lanes of this wavefront)
     TILE_PROF_START();
     TILE_PROF_COUNT(TP_FORWARDS);
-    vf x = ld_if(I.x0, c, inS);
+    vf x = ldm(I.x0, c, inS);
     vf costc = splat(0.0);
     st(I.xbuf, xoff + c, x, inS);
     // the operands of step i + 1 are fetched while step i computes
     int ph_n = phase_of(0), m_n = dim_of_phase(ph_n);
-    vf xi_n = ld_if(xs, c, inS), ui_n = ld_if(us, c, c < m_n), ki_n = ld_if(I.ks, c, c < m_n);
+    vf xi_n = ldm(xs, c, inS), ui_n = ldm(us, c, c < m_n), ki_n = ldm(I.ks, c, c < m_n);
     vf Kr_n[S];
-    for(int a = 0; a < S; a++) Kr_n[a] = ld_if(I.Ks, c * S + a, c < m_n);
+    for(int a = 0; a < S; a++) Kr_n[a] = ldm(I.Ks, c * S + a, c < m_n);
     for(int i = 0; i < N; i++)
     {
       const int m = m_n, ph = ph_n;
@@ -890,10 +919,10 @@ struct Solver
         ph_n = phase_of(i + 1);
         m_n = dim_of_phase(ph_n);
         const vb inn = c < m_n;
-        xi_n = ld_if(xs + static_cast<long>(i + 1) * S, c, inS);
-        ui_n = ld_if(us + static_cast<long>(i + 1) * kM, c, inn);
-        ki_n = ld_if(I.ks + static_cast<long>(i + 1) * kM, c, inn);
-        for(int a = 0; a < S; a++) Kr_n[a] = ld_if(I.Ks + static_cast<long>(i + 1) * kM * S, c * S + a, inn);
+        xi_n = ldm(xs + static_cast<long>(i + 1) * S, c, inS);
+        ui_n = ldm(us + static_cast<long>(i + 1) * kM, c, inn);
+        ki_n = ldm(I.ks + static_cast<long>(i + 1) * kM, c, inn);
+        for(int a = 0; a < S; a++) Kr_n[a] = ldm(I.Ks + static_cast<long>(i + 1) * kM * S, c * S + a, inn);
       }
       const vf dx = x - xi;
       // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
@@ -928,14 +957,14 @@ struct Solver
   {
     const int N = P.N;
     cur = 0;
-    vf x = ld_if(I.x0, c, inS);
+    vf x = ldm(I.x0, c, inS);
     vf cc = splat(0.0);
     st(I.xbuf, c, x, inS && (g == 0));
     for(int i = 0; i < N; i++)
     {
       const int ph = phase_of(i), m = dim_of_phase(ph);
       const vb in = c < m;
-      const vf u = I.u_init ? ld_if(I.u_init + static_cast<long>(i) * kM, c, in) : splat(0.0);
+      const vf u = I.u_init ? ldm(I.u_init + static_cast<long>(i) * kM, c, in) : splat(0.0);
       st(I.ubuf, i * kM + c, u, g == 0);
       cc = cc + running_cost(i, x, u);
       Terms T;
@@ -1044,10 +1073,10 @@ struct Solver
       const int N = P.N;
       const double * xs = xcur();
       const double * us = ucur();
-      for(int e = 0; e < N * kM; e += 64) st(I.u_out, lane + e, ld_if(us, lane + e, lane + e < N * kM), lane + e < N * kM);
+      for(int e = 0; e < N * kM; e += 64) st(I.u_out, lane + e, ldm(us, lane + e, lane + e < N * kM), lane + e < N * kM);
       if(I.x_out)
         for(int e = 0; e < (N + 1) * S; e += 64)
-          st(I.x_out, lane + e, ld_if(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
+          st(I.x_out, lane + e, ldm(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
 #if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
       mem_sync();
       if((threadIdx.x & 63) == 0)

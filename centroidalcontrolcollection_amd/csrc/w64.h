@@ -118,8 +118,26 @@ W64_FN void halves_pair(vf v, vf & a, vf & b)
 }
 
 // per-lane memory access (global or LDS: plain pointers on the device)
-W64_FN vf ld(const double * p, vi idx) { return p[idx]; }
-W64_FN vf ld_if(const double * p, vi idx, vb m, double other = 0.0) { return m ? p[idx] : other; }
+// (base pointer + a 32-bit unsigned BYTE offset: the form the global-memory instructions take as "SGPR base + VGPR
+//  offset" -- with a signed 64-bit index every lane carries a 64-bit address, and those addresses are what the register
+//  allocator then spills.  Indices are non-negative and below 2^29 doubles.)
+W64_FN vf ld(const double * p, vi idx)
+{
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + (static_cast<unsigned>(idx) << 3));
+}
+// masked load WITHOUT a branch: lanes outside the mask read element 0 (always valid) and drop it.  As `m ? p[idx] : other`
+// every such load became a basic block of its own with an s_waitcnt vmcnt(0) behind it: a row of nine prefetches turned
+// into nine serialised memory round trips.
+W64_FN vf ld_if(const double * p, vi idx, vb m, double other = 0.0)
+{
+  const vf v = ld(p, m ? idx : 0);
+  return m ? v : other;
+}
+// the same as a predicated load (exec-masked branch).  Fewer registers -- no address select, nothing in flight beside
+// the load -- at the price of a serialised round trip per load: measured faster where the kernel is short of registers
+// rather than of overlap (the 12-state DDP kernel at large batches: 105 k against 91 k solves/s), slower where latency
+// binds (the 9-state kernel at one instance per wavefront slot: 36.3 k against 39.6 k).
+W64_FN vf ld_if_branch(const double * p, vi idx, vb m, double other = 0.0) { return m ? p[idx] : other; }
 W64_FN void st(double * p, vi idx, vf v, vb m)
 {
   if(m) p[idx] = v;
@@ -441,6 +459,7 @@ inline vf ld_if(const double * p, const vi & idx, const vb & m, double other = 0
   W64_LOOP r.v[l_] = m.v[l_] ? p[idx.v[l_]] : other;
   return r;
 }
+inline vf ld_if_branch(const double * p, const vi & idx, const vb & m, double other = 0.0) { return ld_if(p, idx, m, other); }
 inline void st(double * p, const vi & idx, const vf & v, const vb & m)
 {
   W64_LOOP if(m.v[l_]) p[idx.v[l_]] = v.v[l_];
