@@ -11,8 +11,6 @@
 //                                                         matrices distributed over the lanes, 16 instances per CU; arithmetic
 //                                                         = the tile specification (oracle/ddp_tile.c, ccc_ddp_arithmetic = 1)
 //   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps (reg_type 2)
-//   lean   ddp_lean_kernel (csrc/ddp_lean.hip)            the same sizes compiled for reg_type 1 (the default) only: what a
-//                                                         DdpSingleRigidBody handle runs (less LDS, more wavefronts)
 //   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
 //   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32
 //                                                         (BASELINE configs[4])
@@ -69,7 +67,6 @@ struct ccc_ddp
   int S = 9;
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
   bool wide = false;          // the fast kernel's tables do not hold this handle's problems
-  bool env_lean = false, env_full = false; // development switches CCC_DDP_LEAN / CCC_DDP_FULL, read once in ccc_ddp_create
   bool env_legacy = false;    // CCC_DDP_LEGACY: the row-per-lane kernels of csrc/ddp_core.h instead of the tile kernel
   bool fits_fast = false;     // the tables of the row-per-lane fast builds hold this handle's problems
   int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip), grown on demand
@@ -125,8 +122,6 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   h->wide = !h->fits_fast;
   h->env_legacy = std::getenv("CCC_DDP_LEGACY") != nullptr;
   if(std::getenv("CCC_DDP_WIDE")) h->wide = true; // (development switch: the wide build on problems both builds take)
-  h->env_lean = std::getenv("CCC_DDP_LEAN") != nullptr;
-  h->env_full = std::getenv("CCC_DDP_FULL") != nullptr;
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -313,18 +308,9 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     CCC_HIP_CHECK(launch_ddp_wide(P, B, (long)n, h->S, h->M, s));
     return CCC_OK;
   }
-  // the lean build for the single-rigid-body model (eight wavefronts per CU instead of six: 46.0 k against 38.4 k solves/s at
-  // the shape of config 5); for the centroidal model both builds hold eight and the full one measured 3 % faster
-  // (CCC_DDP_LEAN / CCC_DDP_FULL, development switches, force either)
   if(lean32)
   {
     CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, h->S, s));
-    return CCC_OK;
-  }
-  const bool lean = h->cfg.reg_type == 1 && !h->env_full && (h->S == 12 || h->env_lean);
-  if(lean)
-  {
-    CCC_HIP_CHECK(launch_ddp_lean(P, B, (long)n, h->S, s));
     return CCC_OK;
   }
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances

@@ -34,9 +34,6 @@ struct DdpBatch
 // (ridge stride of the arrays = the handle's max_ridges), any number of contact phases and horizon steps.
 hipError_t launch_ddp_wide(const ddp_common::Params & P, const DdpBatch & B, long n, int S, int M, hipStream_t stream);
 
-// csrc/ddp_lean.hip: the fast build's sizes (M = 16, tables in LDS) compiled for reg_type 1 only.
-hipError_t launch_ddp_lean(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
-
 // csrc/ddp_lean32.hip: the lean build with single-precision storage of the backward pass (precision = 32).
 hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 
