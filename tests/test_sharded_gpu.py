@@ -143,3 +143,21 @@ def test_cpp_host_reaches_every_device_through_the_c_abi():
     out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "differ=0 unsolved=0" in out.stdout and "devices=%d" % len(_devices()) in out.stdout
+
+
+def test_cpp_host_with_device_resident_ddp_shards():
+    """examples/sharded_ddp_device.cpp: plain C++ over include/ccc_amd.h + the HIP runtime for its own buffers;
+    DdpSingleRigidBody shards resident on every visible device, ccc_ddp_sharded_plan_batch_device, the all-gathered
+    first-step force scales on every device bit-identical to the one-device host entry."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "sharded_ddp_device")
+    if not os.path.exists(exe):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    out = subprocess.run([exe, "300"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "differ=0" in out.stdout and "devices=%d" % len(_devices()) in out.stdout
