@@ -89,7 +89,7 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
     N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
     kw, M, P = {}, 16, 4
     if walking:
-        # double-support walking sequences: 32-ridge steps, 8-10 contact phases -> the wide kernel (csrc/ddp_wide.hip)
+        # double-support walking sequences: 32-ridge steps, 8-10 contact phases -> the tile kernel with two ridge blocks
         N, dt, base, M = 40, 0.05, min(n, 1024), 32
         prob, x0 = fd.make_walking_batch(base, N, dt, seed=20250928 + rank, srb=srb)
         P = prob["phase_dim"].shape[1]
@@ -147,9 +147,8 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                              "BASELINE config %s" % (("5" if precision == 32 else "5 shape, fp64") if srb else "3"))),
                 algo_bytes=P * 4 + 2 * P * M * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
                 + S * 8 + N * M * 8,
-                kernel=("ddp_wide_kernel<%d,32>" % S) if walking else
-                (("ddp_tile_kernel<%d>" % S) if precision == 64
-                 else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
+                kernel=(("ddp_tile_kernel<%d, %d>" % (S, M // 16)) if precision == 64
+                        else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
                 valu=lambda iters: _ddp_valu(S, M, N, iters, walking, precision),
                 keep=(d, tp, tx0))
 

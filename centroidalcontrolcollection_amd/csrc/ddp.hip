@@ -7,11 +7,12 @@
 // per instance so that a wavefront streams through contiguous memory.
 //
 // The builds of csrc/ddp_core.h behind one entry (dispatch in ccc_ddp_plan_batch_device):
-//   tile   ddp_tile_kernel (csrc/ddp_tile.hip, csrc/ddp_tile.h)  THE DEFAULT for <= 16 ridges per step, reg_type 1, fp64:
-//                                                         matrices distributed over the lanes, 16 instances per CU; arithmetic
-//                                                         = the tile specification (oracle/ddp_tile.c, ccc_ddp_arithmetic = 1)
-//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   <= 16 ridges per step, <= 4 contact phases, <= 128 steps (reg_type 2)
-//   wide   ddp_wide_kernel (csrc/ddp_wide.hip)             max_ridges = 32 (double support), any number of phases/steps
+//   tile   ddp_tile_kernel (csrc/ddp_tile.hip, csrc/ddp_tile.h)  THE DEFAULT (max_ridges 16, 32, 64; reg_type 1; fp64):
+//                                                         matrices distributed over the lanes, 16 instances per CU at 16
+//                                                         ridges; arithmetic = the tile specification (oracle/ddp_tile.c,
+//                                                         ccc_ddp_arithmetic = 1)
+//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   the row-per-lane solver in the left-to-right arithmetic: <= 16 ridges
+//                                                         per step, <= 4 contact phases, <= 128 steps (reg_type 2, CCC_DDP_LEGACY)
 //   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32
 //                                                         (BASELINE configs[4])
 #include "common.h"
@@ -66,7 +67,6 @@ struct ccc_ddp
   ccc_ddp_config_t cfg{};
   int S = 9;
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
-  bool wide = false;          // the fast kernel's tables do not hold this handle's problems
   bool env_legacy = false;    // CCC_DDP_LEGACY: the row-per-lane kernels of csrc/ddp_core.h instead of the tile kernel
   bool fits_fast = false;     // the tables of the row-per-lane fast builds hold this handle's problems
   int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip), grown on demand
@@ -107,9 +107,10 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: unknown model %d", p->model);
   if(!(p->mass > 0) || !(p->horizon_dt > 0) || p->horizon_steps <= 0 || p->max_phases <= 0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_create: mass, horizon_dt, horizon_steps, max_phases must be > 0");
-  if(p->max_ridges != 0 && p->max_ridges != CCC_DDP_MAX_RIDGES && p->max_ridges != CCC_DDP_MAX_RIDGES_WIDE)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_create: max_ridges = %d, the kernels are built for %d and %d",
-                p->max_ridges, CCC_DDP_MAX_RIDGES, CCC_DDP_MAX_RIDGES_WIDE);
+  if(p->max_ridges != 0 && p->max_ridges != CCC_DDP_MAX_RIDGES && p->max_ridges != CCC_DDP_MAX_RIDGES_WIDE
+     && p->max_ridges != CCC_DDP_MAX_RIDGES_MULTI)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_create: max_ridges = %d, the kernels are built for %d, %d and %d",
+                p->max_ridges, CCC_DDP_MAX_RIDGES, CCC_DDP_MAX_RIDGES_WIDE, CCC_DDP_MAX_RIDGES_MULTI);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   CCC_DEVICE_GUARD(device);
@@ -119,9 +120,7 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   h->M = p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES;
   h->prm.max_ridges = h->M;
   h->fits_fast = h->M == CCC_DDP_MAX_RIDGES && p->max_phases <= ddp::kMaxPhases && p->horizon_steps <= ddp::kMaxSteps;
-  h->wide = !h->fits_fast;
   h->env_legacy = std::getenv("CCC_DDP_LEGACY") != nullptr;
-  if(std::getenv("CCC_DDP_WIDE")) h->wide = true; // (development switch: the wide build on problems both builds take)
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -187,10 +186,11 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   P.reg_type = h->cfg.reg_type;
 }
 
-// the tile kernel takes: 16-ridge strides (any number of phases and steps), the default regularisation, fp64
+// the tile kernel takes: every ridge stride (any number of phases and steps), the default regularisation, fp64
 static bool use_tile(const ccc_ddp * h)
 {
-  return !h->env_legacy && h->M == CCC_DDP_MAX_RIDGES && h->cfg.reg_type == 1 && h->cfg.precision == 64;
+  if(h->M == CCC_DDP_MAX_RIDGES_MULTI) return true; // (the only build for 64 ridges: other configurations are refused)
+  return !h->env_legacy && h->cfg.reg_type == 1 && h->cfg.precision == 64;
 }
 
 extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
@@ -268,6 +268,9 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
+  if(h->M == CCC_DDP_MAX_RIDGES_MULTI && (h->cfg.reg_type != 1 || h->cfg.precision != 64))
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: max_ridges = %d is built for reg_type 1, precision 64",
+                CCC_DDP_MAX_RIDGES_MULTI);
   if(use_tile(h))
   {
     if(n > h->tcap)
@@ -276,24 +279,21 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
       if(h->ws_t) (void)hipFree(h->ws_t);
       h->ws_t = nullptr;
       h->tcap = 0;
-      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)n * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S) * sizeof(double)));
+      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)n * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
       h->tcap = n;
     }
     ddp_common::Params P;
     fill_params(h, P);
     DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
                x_out, nullptr, nullptr, nullptr, nullptr, iters, status, cost};
-    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, (long)n, h->S, reinterpret_cast<hipStream_t>(stream)));
+    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
     return CCC_OK;
   }
-  if(h->wide && h->cfg.precision == 32)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 is built for max_ridges = %d, max_phases <= %d, "
-                "horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
-  if(h->wide && h->cfg.reg_type != 1)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: the wide kernel (max_ridges = %d, max_phases > %d or "
-                "horizon_steps > %d) is built for reg_type 1", CCC_DDP_MAX_RIDGES_WIDE, ddp::kMaxPhases, ddp::kMaxSteps);
+  if(!h->fits_fast)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: reg_type 2, precision 32 and CCC_DDP_LEGACY are built for "
+                "max_ridges = %d, max_phases <= %d, horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
   // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip)
-  const bool lean32 = !h->wide && h->cfg.reg_type == 1 && h->cfg.precision == 32;
+  const bool lean32 = h->cfg.reg_type == 1 && h->cfg.precision == 32;
   int rc = ensure_ws(h, n, stream);
   if(rc != CCC_OK) return rc;
   ddp_common::Params P;
@@ -303,11 +303,6 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // the gains of the last horizon step are read as a box-QP warm start before they are first written
   CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * h->M * sizeof(double), s));
-  if(h->wide)
-  {
-    CCC_HIP_CHECK(launch_ddp_wide(P, B, (long)n, h->S, h->M, s));
-    return CCC_OK;
-  }
   if(lean32)
   {
     CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, h->S, s));

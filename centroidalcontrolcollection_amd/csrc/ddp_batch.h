@@ -1,5 +1,5 @@
 // ddp_batch.h -- what csrc/ddp.hip hands to a DDP kernel launch: the batch's arrays (C-ABI layouts of ccc_amd.h) plus the
-// handle's workspaces.  Shared by the fast build (csrc/ddp.hip) and the wide build (csrc/ddp_wide.hip).
+// handle's workspaces.  Shared by the builds (csrc/ddp.hip, csrc/ddp_tile.hip, csrc/ddp_lean32.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,15 +30,13 @@ struct DdpBatch
   double * cost;
 };
 
-// csrc/ddp_wide.hip: one instance per wavefront, phase versions of csrc/ddp_core.h, S in {9, 12}, M in {16, 32}
-// (ridge stride of the arrays = the handle's max_ridges), any number of contact phases and horizon steps.
-hipError_t launch_ddp_wide(const ddp_common::Params & P, const DdpBatch & B, long n, int S, int M, hipStream_t stream);
-
 // csrc/ddp_lean32.hip: the lean build with single-precision storage of the backward pass (precision = 32).
 hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 
-// csrc/ddp_tile.hip: the tile build (csrc/ddp_tile.h), S in {9, 12}, 16-ridge strides, reg_type 1; ws = n x
-// ddp_tile_ws_doubles(N, S) doubles of workspace
-size_t ddp_tile_ws_doubles(int N, int S);
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, hipStream_t stream);
+// csrc/ddp_tile.hip: the tile build (csrc/ddp_tile.h), S in {9, 12}, M in {16, 32, 64} (ridge stride of the arrays = the
+// handle's max_ridges), any number of contact phases and horizon steps, reg_type 1; ws = n x
+// ddp_tile_ws_doubles(N, S, M) doubles of workspace
+size_t ddp_tile_ws_doubles(int N, int S, int M);
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, int M,
+                           hipStream_t stream);
 } // namespace ccc_amd

@@ -25,21 +25,18 @@
 #  define CCC_DDP_FN inline
 #endif
 
-// Two device builds of this file, same algorithm and same register-resident code (an M-lane group holds a row of the
-// M x M input-space matrices per lane), different table layouts:
-//   - the FAST build (csrc/ddp.hip, M = 16): contact phases of up to 16 ridges, at most kMaxPhases of them and
-//     kMaxSteps horizon steps, all staged in LDS (20 KB per wavefront, eight wavefronts per CU);
-//   - the LEAN build (csrc/ddp_lean.hip, namespace ddp_lean): the fast build's tables, compiled for reg_type 1 only
-//     (see CCC_DDP_REG1_ONLY below) -- what a handle with the default regularisation runs;
-//   - the WIDE build (csrc/ddp_wide.hip, -DCCC_DDP_WIDE, namespace ddp_wide, M = 16 or 32): up to 32 ridges per step
-//     (two surface contacts; src/DdpCentroidal.cpp:49-60 iterates arbitrary contact lists), one contact phase per
-//     horizon step if need be, any horizon length: the contact tables stay in global memory and the M x M matrices are
-//     padded to a row stride of M + 1 (50 KB of LDS per wavefront at M = 32).
+// Since round 3 the DEFAULT kernel of the DDP planners is csrc/ddp_tile.h (matrices distributed over the wavefront, the
+// tile arithmetic, 16 / 32 / 64 ridges per step).  This file is the ROW-PER-LANE solver in the left-to-right arithmetic
+// of oracle/ddp.c, kept for what the tile kernel does not take: reg_type 2, precision 32, and CCC_DDP_LEGACY (the
+// reference's SRB closed loop as written).  Two device builds, same algorithm and same register-resident code (a 16-lane
+// group holds a row of the 16 x 16 input-space matrices per lane):
+//   - the FULL build (csrc/ddp.hip): contact phases of up to 16 ridges, at most kMaxPhases of them and kMaxSteps horizon
+//     steps, all staged in LDS (20 KB per wavefront, eight wavefronts per CU);
+//   - the LEAN32 build (csrc/ddp_lean32.hip, namespace ddp_lean32): the same tables, compiled for reg_type 1 only (see
+//     CCC_DDP_REG1_ONLY below) with single-precision storage of the backward pass.
 // The host build (tests/emu) compiles the plain PHASE versions (the "#else" branches of "#if CCC_DDP_FAST"), lanes one
-// after the other, for either table layout.
-#if defined(CCC_DDP_WIDE)
-#  define CCC_DDP_NS ddp_wide
-#elif defined(CCC_DDP_LEAN) && defined(CCC_DDP_STORE_FLOAT)
+// after the other.
+#if defined(CCC_DDP_LEAN) && defined(CCC_DDP_STORE_FLOAT)
 #  define CCC_DDP_NS ddp_lean32
 #elif defined(CCC_DDP_LEAN)
 #  define CCC_DDP_NS ddp_lean
@@ -51,10 +48,9 @@
 #else
 #  define CCC_DDP_FAST 0
 #endif
-// The wide and the lean device builds are compiled for reg_type 1 only (lambda on Quu: the default): Quu_F = Quu +
-// lambda I and Qxu_r = Qxu are then not stored -- 10.7 KB less LDS at M = 32 (four or five wavefronts per CU instead of
-// three), 3.7 KB less for the single-rigid-body model at M = 16 (eight instead of six: csrc/ddp_lean.hip).
-#if CCC_DDP_FAST && (defined(CCC_DDP_WIDE) || defined(CCC_DDP_LEAN))
+// The lean device build is compiled for reg_type 1 only (lambda on Quu: the default): Quu_F = Quu + lambda I and
+// Qxu_r = Qxu are then not stored -- 3.7 KB less LDS for the single-rigid-body model (eight wavefronts per CU instead of six).
+#if CCC_DDP_FAST && defined(CCC_DDP_LEAN)
 #  define CCC_DDP_REG1_ONLY 1
 #else
 #  define CCC_DDP_REG1_ONLY 0
@@ -99,7 +95,7 @@
 
 namespace ccc_amd
 {
-// plain data shared by the two device builds (and by the launch code of csrc/ddp.hip / csrc/ddp_wide.hip)
+// plain data shared by the two device builds (and by the launch code of csrc/ddp.hip)
 namespace ddp_common
 {
 // Batch-constant parameters (by value to the kernel)
@@ -242,13 +238,11 @@ struct Mem
   int oldc[M];
 #endif
   int ic[8]; // uniform ints
-  // per-instance problem tables, staged once per solve (every model evaluation reads them); the WIDE build keeps them
+  // per-instance problem tables, staged once per solve (every model evaluation reads them)
   // in global memory (any horizon length, up to one contact phase per horizon step)
-#if !defined(CCC_DDP_WIDE)
   double pV[kMaxPhases * M * 3], pR[kMaxPhases * M * 3];
   int pdim[kMaxPhases];
   unsigned char sphase[kMaxSteps];
-#endif
 };
 
 // indices into Mem::sc / Mem::ic
@@ -382,27 +376,6 @@ struct Solver
 
   CCC_DDP_FN Solver(const Params & p, const Instance & i, Mem<S, M> & m) : P(p), I(i), mem(m) {}
 
-#if defined(CCC_DDP_WIDE)
-  // (phase indices and ridge counts are clamped to the tables: caller data cannot make the kernel read outside them)
-  CCC_DDP_FN int phase_of(int step) const
-  {
-    const int p = I.step_phase[step];
-    return p < 0 ? 0 : (p >= P.P ? P.P - 1 : p);
-  }
-  CCC_DDP_FN int dim_of(int step) const
-  {
-    const int d = I.phase_dim[phase_of(step)];
-    return d < 0 ? 0 : (d > M ? M : d);
-  }
-  CCC_DDP_FN const double * vert_of(int step) const
-  {
-    return I.phase_vertex + static_cast<long>(phase_of(step)) * M * 3;
-  }
-  CCC_DDP_FN const double * ridge_of(int step) const
-  {
-    return I.phase_ridge + static_cast<long>(phase_of(step)) * M * 3;
-  }
-#else
   CCC_DDP_FN int dim_of(int step) const
   {
     return mem.pdim[mem.sphase[step]];
@@ -415,11 +388,9 @@ struct Solver
   {
     return mem.pR + static_cast<int>(mem.sphase[step]) * M * 3;
   }
-#endif
   // stage the contact tables of this instance in LDS
   CCC_DDP_FN void stage_problem()
   {
-#if !defined(CCC_DDP_WIDE)
     phase([&](int lane) {
       for(int e = lane; e < P.P * M * 3; e += kWave)
       {
@@ -438,7 +409,6 @@ struct Solver
         mem.sphase[e] = static_cast<unsigned char>(p < 0 ? 0 : (p >= P.P ? P.P - 1 : p));
       }
     });
-#endif
   }
 
   // reference of the weighted state entries at a step (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0])

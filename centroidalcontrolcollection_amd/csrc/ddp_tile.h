@@ -1,6 +1,6 @@
-// ddp_tile.h -- control-limited DDP for CCC::DdpCentroidal (S = 9) and CCC::DdpSingleRigidBody (S = 12), <= 16 ridges per
-// step: one instance per wavefront, every matrix DISTRIBUTED over the 64 lanes (round 3; replaces the
-// row-per-lane kernels of csrc/ddp_core.h as the default for these sizes).
+// ddp_tile.h -- control-limited DDP for CCC::DdpCentroidal (S = 9) and CCC::DdpSingleRigidBody (S = 12), M = 16 B ridges
+// per step (B = 1, 2, 4 blocks of 16: one, two, up to four surface contacts): one instance per wavefront, every matrix
+// DISTRIBUTED over the 64 lanes (round 3; replaces the row-per-lane kernels of csrc/ddp_core.h as the default).
 //
 // Replaces (reference file:line under /root/reference):
 //   src/DdpCentroidal.cpp:32-64, :66-83, :85-121, :123-177          problem callbacks (S = 9)
@@ -11,15 +11,16 @@
 // fixed tree or fma chain that maps onto the CDNA4 cross-lane paths.  Kernel and oracle
 // implement that specification independently and agree bit for bit.
 //
-// Lane = 16 g + c (g = row of the wavefront, c = lane in the row).  Layouts:
-//   vectors over the 16 ridges       lane (g, c) holds v[c]                       (replicated in the four rows)
+// Lane = 16 g + c (g = row of the wavefront, c = lane in the row).  Layouts (b, br, bc = 0 .. B-1 index blocks of 16):
+//   vectors over the M ridges        lane (g, c) holds v[c + 16 b] in v[b]        (replicated in the four rows)
 //   state vectors                    lane (g, a), a < S, holds x[a]               (replicated)
-//   M x M matrices (Quu, its factor) lane (g, c) holds H[c][4g .. 4g+3]           (row c, column block g)
-//   S x M matrices (T2, Qxu, K')     lane (g, c) holds rows a = g, g+4, g+8 of column c
+//   M x M matrices (Quu, its factor) lane (g, c) holds H[c + 16 br][16 bc + 4g .. 16 bc + 4g+3] in H[br][bc][0..3]
+//   S x M matrices (T2, Qxu, K')     lane (g, c) holds rows a = g, g+4, g+8 of the columns c + 16 b
 //   S x S matrices                   the same on lanes c < S; Vxx itself lives in LDS
-// Sums over ridges are 16-lane DPP trees (w64::sum16), sums over column blocks cross the rows with
-// v_permlane16/32_swap (w64::sum_rows), broadcasts inside a row are DPP row_newbcast; LDS (<= 10 KB per wavefront:
-// sixteen wavefronts per CU) carries what changes layout: Vxx, Fx, T1/Qxx, T2/K', Z, the factor L.
+// Sums over ridges add the blocks lane by lane, then run one 16-lane DPP tree (w64::sum16); sums over the columns of a
+// row are four fma chains (one per row of the wavefront) crossed with v_permlane16/32_swap (w64::sum_rows); broadcasts
+// inside a row are DPP row_newbcast; LDS (B = 1: <= 10 KB per wavefront, sixteen wavefronts per CU) carries what changes
+// layout: Vxx, Fx, T1/Qxx, T2/K', Z, the factor L.
 // The line search runs FOUR step sizes at once, one per row (nmpc_ddp tries them in order and takes the first that is
 // accepted; evaluating four side by side and taking the first accepted gives the same answer).
 //
@@ -29,6 +30,8 @@
 
 #include "ddp_core.h" // ddp_common::Params, kGravity
 #include "w64.h"
+
+#include <type_traits>
 
 #if defined(__clang__)
 #  pragma clang fp contract(off)
@@ -101,44 +104,44 @@ enum
 #  define TILE_PROF_COUNT(k) do {} while(0)
 #endif
 
-constexpr int kM = 16;      // ridges per step (lanes of a row)
 constexpr int kSlots = 5;   // trajectory buffers: the current one + four line-search candidates
 constexpr double kGravity = 9.80665; // include/CCC/Constants.h:10
 
-// Per-instance problem data and workspace (global memory)
+// Per-instance problem data and workspace (global memory); M = 16 B is the ridge stride of every array
 struct Instance
 {
   const int * phase_dim;       // [P]
-  const double * phase_vertex; // [P][16][3]
-  const double * phase_ridge;  // [P][16][3]
+  const double * phase_vertex; // [P][M][3]
+  const double * phase_ridge;  // [P][M][3]
   const int * step_phase;      // [N]
   const double * ref_pos;      // [N+1][3]
   const double * ref_ori;      // [N+1][3]  (SRB)
   const double * inertia;      // [9]       (SRB)
   const double * x0;           // [S]
-  const double * u_init;       // [N][16] or nullptr
+  const double * u_init;       // [N][M] or nullptr
   double * xbuf;               // [kSlots][N+1][S]
-  double * ubuf;               // [kSlots][N][16]
-  double * ks;                 // [N][16]
-  double * Ks;                 // [N][16][S]
-  double * u_out;              // [N][16]
+  double * ubuf;               // [kSlots][N][M]
+  double * ks;                 // [N][M]
+  double * Ks;                 // [N][M][S]
+  double * u_out;              // [N][M]
   double * x_out;              // [N+1][S] or nullptr
   int * out_iters;
   int * out_status;
   double * out_cost;
 };
 
-template<int S>
+template<int S, int B>
 struct alignas(16) Mem
 {
-  static constexpr int LT = 17; // row stride of the 16-wide tables read with a per-lane ROW index (bank-conflict free)
+  static constexpr int M = 16 * B;
+  static constexpr int LT = M + 1; // row stride of the M-wide tables read with a per-lane ROW index (bank-conflict free)
   alignas(16) double Vxx[S * S];
   alignas(16) double Fx[S * S];        // [b][c]
   alignas(16) double T1[S * S];        // Vxx Fx, then Qxx
-  alignas(16) double T2[S * LT];       // Vxx Fu [a*16 + c]; later K' [a*LT + c]
+  alignas(16) double T2[S * LT];       // Vxx Fu [a*M + c]; later K' [a*LT + c]
   alignas(16) double Zl[S * LT];       // Quu K + 2 Qux, [a*LT + c]
-  alignas(16) double L[kM * LT];       // unit lower factor of H~ = L D L', zeros on and above the diagonal
-  alignas(16) double cb[2][kM];        // column / vector broadcast buffers
+  alignas(16) double L[M * LT];        // unit lower factor of H~ = L D L', zeros on and above the diagonal
+  alignas(16) double cb[2][M];         // column / vector broadcast buffers
   alignas(16) double Vx[16], Qx[16], vxn[16];
   double wrun[16], wterm[16];
   double alpha[12];
@@ -191,17 +194,22 @@ W64_FN void vllt3(const double * I, const vf (&b)[3], vf (&x)[3])
   x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
 }
 
-template<int S>
+template<int S, int B>
 struct Solver
 {
-  static constexpr int LT = Mem<S>::LT;
+  static_assert(B == 1 || B == 2 || B == 4, "16, 32 or 64 ridges per step");
+  static constexpr int M = 16 * B;
+  static constexpr int LT = Mem<S, B>::LT;
   static constexpr int FU0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (its six non-zero rows are FU0 .. FU0+5)
   static constexpr int NP = S * (S + 1) / 2;   // entries of the upper triangle of Vxx
   static constexpr int NPASS = (NP + 63) / 64;
+  // one bit per ridge: clamped-or-unused sets
+  using mask_t = std::conditional_t<(B <= 2), unsigned, unsigned long long>;
+  static constexpr mask_t kAll = (B == 1) ? static_cast<mask_t>(0xffffu) : static_cast<mask_t>(~static_cast<mask_t>(0));
 
   const Params & P;
   const Instance & I;
-  Mem<S> & mem;
+  Mem<S, B> & mem;
 
   // masked loads: branch-free for the 9-state model, predicated for the 12-state one (measured, see w64::ld_if_branch)
   static W64_FN vf ldm(const double * p, vi idx, vb m) { return S == 12 ? ld_if_branch(p, idx, m) : ld_if(p, idx, m); }
@@ -215,12 +223,38 @@ struct Solver
   // solver state (wave-uniform scalars)
   double lambda, dlambda, cost, dV0, dV1;
   int cur;           // slot of the current trajectory
-  // vertex and ridge of ridge c in the contact phase `ph_cached` (zero beyond its dimension): reloaded only when a step
-  // is in another phase than the one before -- a horizon has a handful of phases
+  // vertex and ridge of the ridges c + 16 b in the contact phase `ph_cached` (zero beyond its dimension): reloaded only
+  // when a step is in another phase than the one before -- a horizon has a handful of phases
   int ph_cached;
-  vf Vc[3], Rc[3];
+  vf Vc[B][3], Rc[B][3];
 
-  W64_FN Solver(const Params & p, const Instance & i, Mem<S> & m) : P(p), I(i), mem(m) {}
+  W64_FN Solver(const Params & p, const Instance & i, Mem<S, B> & m) : P(p), I(i), mem(m) {}
+
+  // ------------------------------------------------------------------------------------------------ ridge vectors
+  // SPEC (sums over the M ridges): w_c = v_c                              (B = 1)
+  //                                w_c = v_c + v_{c+16}                   (B = 2)
+  //                                w_c = (v_c + v_{c+16}) + (v_{c+32} + v_{c+48})   (B = 4), then tree16(w)
+  static W64_FN vf bsum(const vf (&v)[B])
+  {
+    if constexpr(B == 1)
+      return v[0];
+    else if constexpr(B == 2)
+      return v[0] + v[1];
+    else
+      return (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  static W64_FN vf sumM(const vf (&v)[B]) { return sum16(bsum(v)); }
+  // the 16 bits of block b of a set
+  static W64_FN unsigned piece(mask_t m, int b) { return static_cast<unsigned>(m >> (16 * b)) & 0xffffu; }
+  // lane (g, c): is ridge c + 16 b / column 16 b + 4 g + s in the set ?
+  W64_FN vb row_in(mask_t m, int b) const { return ((spl(static_cast<int>(piece(m, b))) >> c) & 1) != 0; }
+  W64_FN vb col_in(mask_t m, int b, int s) const { return ((spl(static_cast<int>(piece(m, b))) >> (g * 4 + s)) & 1) != 0; }
+  W64_FN mask_t ballotM(const vb (&p)[B]) const
+  {
+    mask_t r = 0;
+    for(int b = 0; b < B; b++) r |= static_cast<mask_t>(ballot(p[b]) & 0xffffull) << (16 * b);
+    return r;
+  }
 
   // ------------------------------------------------------------------------------------------------ set-up
   W64_FN void init()
@@ -265,19 +299,23 @@ struct Solver
   W64_FN int dim_of_phase(int ph) const
   {
     const int d = I.phase_dim[ph];
-    return d < 0 ? 0 : (d > kM ? kM : d);
+    return d < 0 ? 0 : (d > M ? M : d);
   }
   // the step's contact phase into Vc / Rc
   W64_FN void contact_of(int ph, int dim)
   {
     if(ph == ph_cached) return;
     ph_cached = ph;
-    const long base = static_cast<long>(ph) * kM * 3;
-    const vb in = c < dim;
-    for(int k = 0; k < 3; k++)
+    const long base = static_cast<long>(ph) * M * 3;
+    for(int b = 0; b < B; b++)
     {
-      Vc[k] = ldm(I.phase_vertex + base, c * 3 + k, in);
-      Rc[k] = ldm(I.phase_ridge + base, c * 3 + k, in);
+      const vi r = c + 16 * b;
+      const vb in = r < dim;
+      for(int k = 0; k < 3; k++)
+      {
+        Vc[b][k] = ldm(I.phase_vertex + base, r * 3 + k, in);
+        Rc[b][k] = ldm(I.phase_ridge + base, r * 3 + k, in);
+      }
     }
   }
   // reference of the weighted state entries (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0]) on the lanes a < S
@@ -292,25 +330,35 @@ struct Solver
   // Everything a step of the model needs from (x, u) that is shared between stateEq and its derivatives.
   struct Terms
   {
-    vf cr[3];             // (vertex - pos) x ridge of ridge c
-    vf force[3];          // sum_r u_r ridge_r                          (tree16)
-    vf moment[3];         // sum_r u_r (vertex_r - pos) x ridge_r       (tree16)
-    vf accel[3];          // sum_r (u_r ridge_r) / m                    (tree16; single-rigid-body model)
+    vf cr[B][3];          // (vertex - pos) x ridge of the ridges c + 16 b
+    vf force[3];          // sum_r u_r ridge_r                          (sumM)
+    vf moment[3];         // sum_r u_r (vertex_r - pos) x ridge_r       (sumM)
+    vf accel[3];          // sum_r (u_r ridge_r) / m                    (sumM; single-rigid-body model)
   };
-  // x: state on the lanes a < S of every row (rows may differ: the line search), u: ridge c's force scale
-  CCC_TILE_PIECE void terms_of(int ph, int dim, vf x, vf u, Terms & T)
+  // x: state on the lanes a < S of every row (rows may differ: the line search), u: the force scales of the ridges c + 16 b
+  CCC_TILE_PIECE void terms_of(int ph, int dim, vf x, const vf (&u)[B], Terms & T)
   {
     contact_of(ph, dim);
     const vf p0 = row_bcast<0>(x), p1 = row_bcast<1>(x), p2 = row_bcast<2>(x);
-    const vf d0 = Vc[0] - p0, d1 = Vc[1] - p1, d2 = Vc[2] - p2;
-    T.cr[0] = d1 * Rc[2] - d2 * Rc[1];
-    T.cr[1] = d2 * Rc[0] - d0 * Rc[2];
-    T.cr[2] = d0 * Rc[1] - d1 * Rc[0];
+    for(int b = 0; b < B; b++)
+    {
+      const vf d0 = Vc[b][0] - p0, d1 = Vc[b][1] - p1, d2 = Vc[b][2] - p2;
+      T.cr[b][0] = d1 * Rc[b][2] - d2 * Rc[b][1];
+      T.cr[b][1] = d2 * Rc[b][0] - d0 * Rc[b][2];
+      T.cr[b][2] = d0 * Rc[b][1] - d1 * Rc[b][0];
+    }
     for(int k = 0; k < 3; k++)
     {
-      T.force[k] = sum16(u * Rc[k]);
-      T.moment[k] = sum16(u * T.cr[k]);
-      if(S == 12) T.accel[k] = sum16((u * Rc[k]) / P.mass);
+      vf t[B];
+      for(int b = 0; b < B; b++) t[b] = u[b] * Rc[b][k];
+      T.force[k] = sumM(t);
+      for(int b = 0; b < B; b++) t[b] = u[b] * T.cr[b][k];
+      T.moment[k] = sumM(t);
+      if(S == 12)
+      {
+        for(int b = 0; b < B; b++) t[b] = (u[b] * Rc[b][k]) / P.mass;
+        T.accel[k] = sumM(t);
+      }
     }
   }
   // x_next = stateEq(step, x, u): src/DdpCentroidal.cpp:32-64 / src/DdpSingleRigidBody.cpp:52-91
@@ -354,11 +402,13 @@ struct Solver
     return sel(inS, x + P.dt * xd, 0.0);
   }
   // running / terminal cost of (x, u) per row: src/DdpCentroidal.cpp:66-83
-  W64_FN vf running_cost(int step, vf x, vf u) const
+  W64_FN vf running_cost(int step, vf x, const vf (&u)[B]) const
   {
     const vf e = x - ref_of(step);
     const vf cx = sum16(sel(inS, 0.5 * ld(mem.wrun, c) * e * e, 0.0));
-    const vf un = sum16(u * u);
+    vf t[B];
+    for(int b = 0; b < B; b++) t[b] = u[b] * u[b];
+    const vf un = sumM(t);
     return cx + 0.5 * P.w_force * un;
   }
   W64_FN vf terminal_cost(vf x) const
@@ -367,9 +417,9 @@ struct Solver
     return sum16(sel(inS, 0.5 * ld(mem.wterm, c) * e * e, 0.0));
   }
 
-  // Fx -> mem.Fx ([b][c], dense), Fu: the six non-zero rows of column c in registers
+  // Fx -> mem.Fx ([b][c], dense), Fu: the six non-zero rows of the columns c + 16 b in registers
   // (src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185), at (x, u) with the step's Terms
-  CCC_TILE_PIECE void state_eq_deriv(const Terms & T, vf x, vf (&Fu)[6])
+  CCC_TILE_PIECE void state_eq_deriv(const Terms & T, vf x, vf (&Fu)[B][6])
   {
     const vb first = lane == 0;
     for(int e = 0; e < S * S; e += 64) st(mem.Fx, lane + e, splat(0.0), lane + e < S * S);
@@ -377,11 +427,12 @@ struct Solver
     const double dt = P.dt;
     if(S == 9)
     {
-      for(int k = 0; k < 3; k++)
-      {
-        Fu[k] = Rc[k] * dt;
-        Fu[3 + k] = T.cr[k] * dt;
-      }
+      for(int b = 0; b < B; b++)
+        for(int k = 0; k < 3; k++)
+        {
+          Fu[b][k] = Rc[b][k] * dt;
+          Fu[b][3 + k] = T.cr[b][k] * dt;
+        }
       // (the scalars are the same on every lane: lane 0 stores them)
       const vf tf0 = T.force[0], tf1 = T.force[1], tf2 = T.force[2];
       for(int a = 0; a < 3; a++) st(mem.Fx, spl(a * S + 3 + a), splat((1 / P.mass) * dt), first);
@@ -395,12 +446,15 @@ struct Solver
     else
     {
       const double * In = mem.inertia;
-      vf sol[3];
-      vllt3(In, T.cr, sol);
-      for(int k = 0; k < 3; k++)
+      for(int b = 0; b < B; b++)
       {
-        Fu[k] = (Rc[k] / P.mass) * dt;
-        Fu[3 + k] = sol[k] * dt;
+        vf sol[3];
+        vllt3(In, T.cr[b], sol);
+        for(int k = 0; k < 3; k++)
+        {
+          Fu[b][k] = (Rc[b][k] / P.mass) * dt;
+          Fu[b][3 + k] = sol[k] * dt;
+        }
       }
       const vf w1 = row_bcast<9>(x), w2 = row_bcast<10>(x), w3 = row_bcast<11>(x);
       const double I11 = In[0], I12 = In[1], I13 = In[2], I22 = In[4], I23 = In[5], I33 = In[8];
@@ -450,39 +504,63 @@ struct Solver
   }
 
   // ------------------------------------------------------------------------------------------------ linear algebra
-  // y on every row -> the entries 4g .. 4g+3 this lane's column block needs (through LDS buffer `slot`)
-  W64_FN void block_of(vf y, int slot, vf (&yb)[4])
+  // y on every row -> the entries 16 bc + 4g .. 16 bc + 4g+3 this lane's column blocks need (through LDS buffer `slot`)
+  W64_FN void block_of(const vf (&y)[B], int slot, vf (&yb)[B][4])
   {
-    st(mem.cb[slot], c, y, g == 0);
+    for(int b = 0; b < B; b++) st(mem.cb[slot], c + 16 * b, y[b], g == 0);
     wave_sync();
-    for(int s = 0; s < 4; s++) yb[s] = ld(mem.cb[slot], g * 4 + s);
+    for(int bc = 0; bc < B; bc++)
+      for(int s = 0; s < 4; s++) yb[bc][s] = ld(mem.cb[slot], g * 4 + s + 16 * bc);
   }
-  // (H y)_c, H in row blocks: SPEC p = H[c][4g] y_4g; p = fma(H[c][4g+s], y_4g+s, p), s = 1..3; (p_0 + p_1) + (p_2 + p_3)
-  W64_FN vf matvec(const vf (&H)[4], vf y, int slot)
+  // one row block of H times the gathered vector.  SPEC (row r, the four chains g = 0 .. 3 over the columns
+  // k = 16 bc + 4g + s, bc ascending, s = 0 .. 3 inside): p_g = H[r][4g] y_4g; p_g = fma(H[r][k], y_k, p_g) for the
+  // following k; (H y)_r = (p_0 + p_1) + (p_2 + p_3).   elem(bc, s): the lane's entry of the row block.
+  template<class E>
+  static W64_FN vf row_dot(E elem, const vf (&yb)[B][4])
   {
-    vf yb[4];
-    block_of(y, slot, yb);
-    vf p = H[0] * yb[0];
-    for(int s = 1; s < 4; s++) p = vfma(H[s], yb[s], p);
+    vf p = elem(0, 0) * yb[0][0];
+    for(int s = 1; s < 4; s++) p = vfma(elem(0, s), yb[0][s], p);
+    for(int bc = 1; bc < B; bc++)
+      for(int s = 0; s < 4; s++) p = vfma(elem(bc, s), yb[bc][s], p);
     return sum_rows(p);
+  }
+  // out = H y for H in row blocks
+  W64_FN void matvec(const vf (&H)[B][B][4], const vf (&y)[B], int slot, vf (&out)[B])
+  {
+    vf yb[B][4];
+    block_of(y, slot, yb);
+    for(int br = 0; br < B; br++) out[br] = row_dot([&](int bc, int s) { return H[br][bc][s]; }, yb);
+  }
+  // the same with the diagonal blocks taken from Hd (the unregularised Quu: HF with lambda taken off the diagonal)
+  W64_FN void matvec_u(const vf (&H)[B][B][4], const vf (&Hd)[B][4], const vf (&y)[B], int slot, vf (&out)[B])
+  {
+    vf yb[B][4];
+    block_of(y, slot, yb);
+    for(int br = 0; br < B; br++)
+      out[br] = row_dot([&](int bc, int s) { return bc == br ? Hd[br][s] : H[br][bc][s]; }, yb);
   }
 
   // L D L' of H~ (H with the rows and columns of `skip` -- clamped or beyond the step's dimension -- replaced by
-  // identity): unit lower L -> mem.L (zeros on and above the diagonal), 1 / D -> rdv.  SPEC, column j = 0 .. 15, not skipped:
+  // identity): unit lower L -> mem.L (zeros on and above the diagonal), 1 / D -> rdv.  SPEC, column j = 0 .. M-1, not skipped:
   //   d = a[j][j]; fail unless d > 0; r = 1 / d; L[c][j] = a[c][j] r (c > j);
   //   a[c][k] = fma(-(a[c][j] a[k][j]), r, a[c][k])       (the product of the two column entries first: symmetric)
-  // Returns false when a pivot is not positive.
-  CCC_TILE_PIECE bool factorize(const vf (&HF)[4], unsigned skip, vf & rdv)
+  // (entries with a row or column index below the first ridge of j's block of 16 are never read again and are left
+  //  alone.)  Returns false when a pivot is not positive.
+  CCC_TILE_PIECE bool factorize(const vf (&HF)[B][B][4], mask_t skip, vf (&rdv)[B])
   {
-    vf a[4];
-    const vb rskip = ((spl(static_cast<int>(skip)) >> c) & 1) != 0;
-    for(int s = 0; s < 4; s++)
+    vf a[B][B][4];
+    for(int br = 0; br < B; br++)
     {
-      const vi k = g * 4 + s;
-      const vb cskip = ((spl(static_cast<int>(skip)) >> k) & 1) != 0;
-      a[s] = sel(rskip || cskip, sel(c == k, 1.0, 0.0), HF[s]);
+      const vb rskip = row_in(skip, br);
+      for(int bc = 0; bc < B; bc++)
+        for(int s = 0; s < 4; s++)
+        {
+          const vb cskip = col_in(skip, bc, s);
+          const vf ident = (br == bc) ? sel(c == g * 4 + s, 1.0, 0.0) : splat(0.0);
+          a[br][bc][s] = sel(rskip || cskip, ident, HF[br][bc][s]);
+        }
+      rdv[br] = splat(1.0);
     }
-    rdv = splat(1.0);
     bool ok = true;
     factor_col<0>(a, skip, rdv, ok);
     wave_sync();
@@ -491,83 +569,89 @@ struct Solver
 
   // one column of the factorisation (a compile-time column index: the entries of `a` stay in their registers)
   template<int J>
-  W64_FN void factor_col(vf (&a)[4], unsigned skip, vf & rdv, bool & ok)
+  W64_FN void factor_col(vf (&a)[B][B][4], mask_t skip, vf (&rdv)[B], bool & ok)
   {
-    if constexpr(J < kM)
+    if constexpr(J < M)
     {
-      constexpr int gj = J >> 2, sj = J & 3;
+      constexpr int jb = J >> 4, jc = J & 15, gj = jc >> 2, sj = jc & 3;
       if((skip >> J) & 1u)
-        st(mem.L, c * LT + J, splat(0.0), g == 0);
+      {
+        for(int br = jb; br < B; br++) st(mem.L, (c + 16 * br) * LT + J, splat(0.0), g == 0);
+      }
       else
       {
         // (source order = issue order wanted: the column goes to LDS and its reads are in flight while the pivot's
         //  reciprocal -- an IEEE division, the longest dependent chain of the step -- is computed)
-#if defined(CCC_TILE_FACTOR_SERIAL)
-        const double d = read_lane(a[sj], 16 * gj + J);
+        for(int br = jb; br < B; br++) st(mem.cb[J & 1], c + 16 * br, a[br][jb][sj], g == gj);
+        wave_sync();
+        vf uc[B], uk[B][4];
+        for(int br = jb; br < B; br++) uc[br] = ld(mem.cb[J & 1], c + 16 * br);
+        for(int bc = jb; bc < B; bc++)
+          for(int s = 0; s < 4; s++) uk[bc][s] = ld(mem.cb[J & 1], g * 4 + s + 16 * bc);
+        const double d = read_lane(a[jb][jb][sj], 16 * gj + jc);
         if(!(d > 0.0)) ok = false;
         const double r = 1.0 / d;
-        st(mem.cb[J & 1], c, a[sj], g == gj);
-        wave_sync();
-        const vf uc = ld(mem.cb[J & 1], c);
-        st(mem.L, c * LT + J, sel(c > J, uc * r, 0.0), g == 0);
-        rdv = sel(c == J, splat(r), rdv);
-        for(int s = 0; s < 4; s++)
-        {
-          const vf uk = ld(mem.cb[J & 1], g * 4 + s);
-          a[s] = vfma(-(uc * uk), splat(r), a[s]);
-        }
-#else
-        st(mem.cb[J & 1], c, a[sj], g == gj);
-        wave_sync();
-        const vf uc = ld(mem.cb[J & 1], c);
-        vf uk[4];
-        for(int s = 0; s < 4; s++) uk[s] = ld(mem.cb[J & 1], g * 4 + s);
-        const double d = read_lane(a[sj], 16 * gj + J);
-        if(!(d > 0.0)) ok = false;
-        const double r = 1.0 / d;
-        vf pk[4];
-        for(int s = 0; s < 4; s++) pk[s] = uc * uk[s];
-        st(mem.L, c * LT + J, sel(c > J, uc * r, 0.0), g == 0);
-        rdv = sel(c == J, splat(r), rdv);
-        for(int s = 0; s < 4; s++) a[s] = vfma(-pk[s], splat(r), a[s]);
-#endif
+        vf pk[B][B][4];
+        for(int br = jb; br < B; br++)
+          for(int bc = jb; bc < B; bc++)
+            for(int s = 0; s < 4; s++) pk[br][bc][s] = uc[br] * uk[bc][s];
+        for(int br = jb; br < B; br++)
+          st(mem.L, (c + 16 * br) * LT + J, sel(c + 16 * br > J, uc[br] * r, 0.0), g == 0);
+        rdv[jb] = sel(c == jc, splat(r), rdv[jb]);
+        for(int br = jb; br < B; br++)
+          for(int bc = jb; bc < B; bc++)
+            for(int s = 0; s < 4; s++) a[br][bc][s] = vfma(-pk[br][bc][s], splat(r), a[br][bc][s]);
       }
       factor_col<J + 1>(a, skip, rdv, ok);
     }
   }
 
-  // b <- H~^-1 b for NR right-hand sides held one entry per lane (rows may hold different ones), zero on the skipped
-  // rows.  SPEC: forward, k = 0 .. 15: b_c = fma(-L[c][k], b_k, b_c) (c > k); b_c = b_c rd_c; backward, k = 15 .. 0:
-  // b_c = fma(-L[k][c], b_k, b_c) (c < k).  Skipped columns are identity columns: nothing to do.
+  // b <- H~^-1 b for NR right-hand sides held one entry per lane and block (rows may hold different ones), zero on the
+  // skipped rows.  SPEC: forward, k = 0 .. M-1: b_c = fma(-L[c][k], b_k, b_c) for the rows c from the first ridge of k's
+  // block of 16 on (L is zero on and above the diagonal); b_c = b_c rd_c; backward, k = M-1 .. 0: b_c = fma(-L[k][c], b_k, b_c)
+  // for the rows c up to the last ridge of k's block.  Skipped columns are identity columns: nothing to do.
   template<int NR>
-  W64_FN void solve(vf (&b)[NR], unsigned skip, vf rdv)
+  W64_FN void solve(vf (&b)[B][NR], mask_t skip, const vf (&rdv)[B])
   {
     solve_fwd<0>(b, skip);
-    for(int t = 0; t < NR; t++) b[t] = b[t] * rdv;
-    solve_bwd<kM - 1>(b, skip);
+    for(int br = 0; br < B; br++)
+      for(int t = 0; t < NR; t++) b[br][t] = b[br][t] * rdv[br];
+    solve_bwd<M - 1>(b, skip);
   }
   template<int K, int NR>
-  W64_FN void solve_fwd(vf (&b)[NR], unsigned skip)
+  W64_FN void solve_fwd(vf (&b)[B][NR], mask_t skip)
   {
-    if constexpr(K < kM)
+    if constexpr(K < M)
     {
+      constexpr int kb = K >> 4, kc = K & 15;
       if(!((skip >> K) & 1u))
       {
-        const vf lk = ld(mem.L, c * LT + K);
-        for(int t = 0; t < NR; t++) b[t] = vfma(-lk, row_bcast<K>(b[t]), b[t]);
+        vf bk[NR];
+        for(int t = 0; t < NR; t++) bk[t] = row_bcast<kc>(b[kb][t]);
+        for(int br = kb; br < B; br++)
+        {
+          const vf lk = ld(mem.L, (c + 16 * br) * LT + K);
+          for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
+        }
       }
       solve_fwd<K + 1>(b, skip);
     }
   }
   template<int K, int NR>
-  W64_FN void solve_bwd(vf (&b)[NR], unsigned skip)
+  W64_FN void solve_bwd(vf (&b)[B][NR], mask_t skip)
   {
     if constexpr(K >= 0)
     {
+      constexpr int kb = K >> 4, kc = K & 15;
       if(!((skip >> K) & 1u))
       {
-        const vf lk = ld(mem.L, c + K * LT);
-        for(int t = 0; t < NR; t++) b[t] = vfma(-lk, row_bcast<K>(b[t]), b[t]);
+        vf bk[NR];
+        for(int t = 0; t < NR; t++) bk[t] = row_bcast<kc>(b[kb][t]);
+        for(int br = 0; br <= kb; br++)
+        {
+          const vf lk = ld(mem.L, c + 16 * br + K * LT);
+          for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
+        }
       }
       solve_bwd<K - 1>(b, skip);
     }
@@ -576,22 +660,32 @@ struct Solver
   // Box-QP (Tassa's boxQP.m, nmpc_ddp's parameters): min 1/2 x'Hx + q'x, lo <= x <= hi over the first m ridges,
   // H = HF (row blocks, lambda on the diagonal).  x enters as the warm start.  On success (result >= 1) x is the
   // minimiser, skip the clamped-or-unused rows as a bit mask, and mem.L / rdv hold the factor of H~ for that set.
-  CCC_TILE_PIECE int box_qp(int m, const vf (&HF)[4], vf q, vf lo, vf hi, vf & x, unsigned & skip, vf & rdv)
+  CCC_TILE_PIECE int box_qp(int m, const vf (&HF)[B][B][4], const vf (&q)[B], const vf (&lo)[B], const vf (&hi)[B],
+                            vf (&x)[B], mask_t & skip, vf (&rdv)[B])
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
-    const vb in = c < m;
-    const unsigned inmask = (m >= kM) ? 0xffffu : ((1u << m) - 1u);
-    x = sel(in, vmin(vmax(x, lo), hi), 0.0);
-    // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); tree16
-    auto value_of = [&](vf y) { return read_lane(sum16(vfma(0.5 * y, matvec(HF, y, 0), y * q)), 0); };
+    vb in[B], cl[B];
+    for(int b = 0; b < B; b++)
+    {
+      in[b] = c + 16 * b < m;
+      cl[b] = lane < 0; // all false
+      x[b] = sel(in[b], vmin(vmax(x[b], lo[b]), hi[b]), 0.0);
+      rdv[b] = splat(1.0);
+    }
+    const mask_t inmask = (m >= M) ? kAll : static_cast<mask_t>((static_cast<mask_t>(1) << m) - 1u);
+    // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); sumM
+    auto value_of = [&](const vf (&y)[B]) {
+      vf hy[B], t[B];
+      matvec(HF, y, 0, hy);
+      for(int b = 0; b < B; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
+      return read_lane(sumM(t), 0);
+    };
     TILE_PROF_START();
     TILE_PROF_COUNT(TP_QP_CALLS);
     double value = value_of(x), oldvalue = 0.0;
     TILE_PROF_ADD(TP_QP_VALUE);
-    vb cl = lane < 0; // all false
-    skip = ~inmask & 0xffffu;
-    rdv = splat(1.0);
+    skip = ~inmask & kAll;
     int result = 0, iter;
     for(iter = 1; iter <= max_iter; iter++)
     {
@@ -603,11 +697,18 @@ struct Solver
         break;
       }
       oldvalue = value;
-      const vf grad = q + matvec(HF, x, 1);
-      const vb oldc = cl;
-      cl = in && (((x == lo) && (grad > 0.0)) || ((x == hi) && (grad < 0.0)));
-      const unsigned clmask = static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask;
-      const bool changed = (iter == 1) || ((static_cast<unsigned>(ballot(cl != oldc) & 0xffffull) & inmask) != 0u);
+      vf grad[B];
+      matvec(HF, x, 1, grad);
+      vb diff[B];
+      for(int b = 0; b < B; b++)
+      {
+        grad[b] = q[b] + grad[b];
+        const vb oldc = cl[b];
+        cl[b] = in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
+        diff[b] = cl[b] != oldc;
+      }
+      const mask_t clmask = ballotM(cl) & inmask;
+      const bool changed = (iter == 1) || ((ballotM(diff) & inmask) != 0u);
       TILE_PROF_ADD(TP_QP_GRAD);
       if(clmask == inmask)
       {
@@ -617,7 +718,7 @@ struct Solver
       if(changed)
       {
         TILE_PROF_COUNT(TP_QP_FACTORS);
-        skip = clmask | (~inmask & 0xffffu);
+        skip = clmask | (~inmask & kAll);
         if(!factorize(HF, skip, rdv))
         {
           result = -1;
@@ -625,26 +726,39 @@ struct Solver
         }
       }
       TILE_PROF_ADD(TP_QP_FACTOR);
-      const vb fr = in && !cl;
-      // |grad| on the free rows.  SPEC: sqrt(tree16(free ? grad^2 : 0))
-      const double gn = std::sqrt(read_lane(sum16(sel(fr, grad * grad, 0.0)), 0));
+      vb fr[B];
+      vf t[B];
+      for(int b = 0; b < B; b++)
+      {
+        fr[b] = in[b] && !cl[b];
+        t[b] = sel(fr[b], grad[b] * grad[b], 0.0);
+      }
+      // |grad| on the free rows.  SPEC: sqrt(sumM(free ? grad^2 : 0))
+      const double gn = std::sqrt(read_lane(sumM(t), 0));
       if(gn < min_grad)
       {
         result = 5;
         break;
       }
       // grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x
-      vf rhs[1] = {sel(fr, q + matvec(HF, sel(cl, x, 0.0), 0), 0.0)};
+      vf xcl[B], hx[B], rhs[B][1], srch[B];
+      for(int b = 0; b < B; b++) xcl[b] = sel(cl[b], x[b], 0.0);
+      matvec(HF, xcl, 0, hx);
+      for(int b = 0; b < B; b++) rhs[b][0] = sel(fr[b], q[b] + hx[b], 0.0);
       solve<1>(rhs, skip, rdv);
-      const vf srch = sel(fr, -rhs[0] - x, 0.0);
-      const double sdotg = read_lane(sum16(srch * grad), 0);
+      for(int b = 0; b < B; b++)
+      {
+        srch[b] = sel(fr[b], -rhs[b][0] - x[b], 0.0);
+        t[b] = srch[b] * grad[b];
+      }
+      const double sdotg = read_lane(sumM(t), 0);
       TILE_PROF_ADD(TP_QP_SOLVE);
       if(sdotg >= 0) break; // no descent direction: result stays 0
       double step = 1.0, vc;
-      vf xc;
+      vf xc[B];
       for(;;)
       {
-        xc = sel(in, vmin(vmax(x + step * srch, lo), hi), 0.0);
+        for(int b = 0; b < B; b++) xc[b] = sel(in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
         vc = value_of(xc);
         if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
         step *= step_dec;
@@ -654,18 +768,18 @@ struct Solver
           break;
         }
       }
-      x = xc;
+      for(int b = 0; b < B; b++) x[b] = xc[b];
       value = vc;
       TILE_PROF_ADD(TP_QP_SEARCH);
     }
     if(iter > max_iter && result == 0) result = 1;
-    skip = (static_cast<unsigned>(ballot(cl) & 0xffffull) & inmask) | (~inmask & 0xffffu);
+    skip = (ballotM(cl) & inmask) | (~inmask & kAll);
     return result;
   }
 
   // ------------------------------------------------------------------------------------------------ backward pass
   W64_FN const double * xcur() const { return I.xbuf + static_cast<long>(cur) * (P.N + 1) * S; }
-  W64_FN const double * ucur() const { return I.ubuf + static_cast<long>(cur) * P.N * kM; }
+  W64_FN const double * ucur() const { return I.ubuf + static_cast<long>(cur) * P.N * M; }
 
   // oracle/ddp_tile.c backward_pass; returns false when a box-QP fails.  gnorm: sum_i max_c |k_c| / (|u_c| + 1)
   CCC_TILE_PIECE bool backward_pass(double & gsum)
@@ -686,28 +800,36 @@ struct Solver
     dV0 = 0.0;
     dV1 = 0.0;
     gsum = 0.0;
-    vf kprev = splat(0.0);
+    vf kprev[B];
+    for(int b = 0; b < B; b++) kprev[b] = splat(0.0);
     int mprev = -1;
     // the operands of step i - 1 are fetched while step i computes
     int ph_n = phase_of(N - 1), m_n = dim_of_phase(ph_n);
     vf x_n = ldm(xs + static_cast<long>(N - 1) * S, c, inS);
-    vf u_n = ldm(us + static_cast<long>(N - 1) * kM, c, c < m_n);
+    vf u_n[B];
+    for(int b = 0; b < B; b++) u_n[b] = ldm(us + static_cast<long>(N - 1) * M, c + 16 * b, c + 16 * b < m_n);
     for(int i = N - 1; i >= 0; i--)
     {
       const int m = m_n, ph = ph_n;
-      const vb in = c < m;
-      const vf x = x_n, u = u_n;
+      vb in[B];
+      vf u[B];
+      for(int b = 0; b < B; b++)
+      {
+        in[b] = c + 16 * b < m;
+        u[b] = u_n[b];
+      }
+      const vf x = x_n;
       if(i > 0)
       {
         ph_n = phase_of(i - 1);
         m_n = dim_of_phase(ph_n);
         x_n = ldm(xs + static_cast<long>(i - 1) * S, c, inS);
-        u_n = ldm(us + static_cast<long>(i - 1) * kM, c, c < m_n);
+        for(int b = 0; b < B; b++) u_n[b] = ldm(us + static_cast<long>(i - 1) * M, c + 16 * b, c + 16 * b < m_n);
       }
       TILE_PROF_START();
       Terms T;
       terms_of(ph, m, x, u, T);
-      vf Fu[6];
+      vf Fu[B][6];
       state_eq_deriv(T, x, Fu);
       TILE_PROF_ADD(TP_DERIV);
       // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
@@ -718,18 +840,31 @@ struct Solver
         st(mem.Qx, c, s, inS && (g == 0));
       }
       // Qu = Lu + Fu' Vx.  SPEC: s = w_force u_c; s = fma(Fu[b][c], Vx[b], s), b = FU0 .. FU0+5
-      vf Qu = P.w_force * u;
-      for(int b = 0; b < 6; b++) Qu = vfma(Fu[b], splat(mem.Vx[FU0 + b]), Qu);
-      Qu = sel(in, Qu, 0.0);
-      // T2 = Vxx Fu (rows a_t of column c).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
+      vf Qu[B];
+      for(int b = 0; b < B; b++)
+      {
+        vf s = P.w_force * u[b];
+        for(int bb = 0; bb < 6; bb++) s = vfma(Fu[b][bb], splat(mem.Vx[FU0 + bb]), s);
+        Qu[b] = sel(in[b], s, 0.0);
+      }
+      // T2 = Vxx Fu (rows a_t of the columns c + 16 b).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
       // (loops over the state index run with the three rows inside and a bounded unroll: fully unrolled, the scheduler
       //  hoists every LDS load of a product and the registers of 3 x S x 2 operands do not fit four wavefronts per SIMD)
       {
-        vf s3[3];
-        for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S + FU0) * Fu[0];
-        for(int b = 1; b < 6; b++)
-          for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + (FU0 + b)), Fu[b], s3[t]);
-        for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * kM + c, s3[t], aval[t]);
+        vf s3[B][3];
+        for(int t = 0; t < 3; t++)
+        {
+          const vf v = ld(mem.Vxx, arow[t] * S + FU0);
+          for(int b = 0; b < B; b++) s3[b][t] = v * Fu[b][0];
+        }
+        for(int bb = 1; bb < 6; bb++)
+          for(int t = 0; t < 3; t++)
+          {
+            const vf v = ld(mem.Vxx, arow[t] * S + (FU0 + bb));
+            for(int b = 0; b < B; b++) s3[b][t] = vfma(v, Fu[b][bb], s3[b][t]);
+          }
+        for(int b = 0; b < B; b++)
+          for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * M + c + 16 * b, s3[b][t], aval[t]);
       }
       // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
       const vi col = seli(inS, c, spl(0));
@@ -746,34 +881,57 @@ struct Solver
         for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
       }
       wave_sync();
-      // Quu = Luu + Fu' T2 (row c, columns 4g + s).  SPEC: s = (c == k) w_force; s = fma(Fu[b][c], T2[b][k], s), b ascending
-      // HF: lambda on the diagonal; hd: the unregularised diagonal entry (on the lane and slot that hold it)
-      vf HF[4], hd = splat(0.0);
+      // Quu = Luu + Fu' T2 (rows c + 16 br, columns 16 bc + 4g + s).  SPEC: s = (r == k) w_force; s = fma(Fu[b][r], T2[b][k], s), b ascending
+      // HF: lambda on the diagonal; Hd: the diagonal blocks with the unregularised diagonal entry
+      vf HF[B][B][4], Hd[B][4];
+      for(int bc = 0; bc < B; bc++)
       {
-        vf s4v[4];
-        for(int s4 = 0; s4 < 4; s4++) s4v[s4] = sel(c == g * 4 + s4, splat(P.w_force), 0.0);
-        for(int b = 0; b < 6; b++)
-          for(int s4 = 0; s4 < 4; s4++) s4v[s4] = vfma(Fu[b], ld(mem.T2, g * 4 + s4 + (FU0 + b) * kM), s4v[s4]);
-        for(int s4 = 0; s4 < 4; s4++)
-        {
-          const vi k = g * 4 + s4;
-          const vb live = in && (k < m), dg = live && (c == k);
-          hd = sel(dg, s4v[s4], hd);
-          HF[s4] = sel(dg, s4v[s4] + lambda, sel(live, s4v[s4], 0.0));
-        }
+        vf s4v[B][4];
+        for(int br = 0; br < B; br++)
+          for(int s4 = 0; s4 < 4; s4++)
+            s4v[br][s4] = (br == bc) ? sel(c == g * 4 + s4, splat(P.w_force), 0.0) : splat(0.0);
+        for(int bb = 0; bb < 6; bb++)
+          for(int s4 = 0; s4 < 4; s4++)
+          {
+            const vf t2 = ld(mem.T2, g * 4 + s4 + 16 * bc + (FU0 + bb) * M);
+            for(int br = 0; br < B; br++) s4v[br][s4] = vfma(Fu[br][bb], t2, s4v[br][s4]);
+          }
+        for(int br = 0; br < B; br++)
+          for(int s4 = 0; s4 < 4; s4++)
+          {
+            const vi k = g * 4 + s4 + 16 * bc;
+            const vb live = in[br] && (k < m);
+            if(br == bc)
+            {
+              const vb dg = live && (c == g * 4 + s4);
+              Hd[br][s4] = sel(live, s4v[br][s4], 0.0);
+              HF[br][bc][s4] = sel(dg, s4v[br][s4] + lambda, Hd[br][s4]);
+            }
+            else
+              HF[br][bc][s4] = sel(live, s4v[br][s4], 0.0);
+          }
       }
-      // Qxu = Fx' T2 (rows a_t of column c).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
-      vf Qxu[3];
+      // Qxu = Fx' T2 (rows a_t of the columns c + 16 b).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
+      vf Qxu[B][3];
       {
-        const vf t0 = ld(mem.T2, c);
-        for(int t = 0; t < 3; t++) Qxu[t] = ld(mem.Fx, arow[t]) * t0;
-        W64_UNROLL(CCC_TILE_U_PROD)
-        for(int b = 1; b < S; b++)
+        for(int t = 0; t < 3; t++)
         {
-          const vf tb = ld(mem.T2, c + b * kM);
-          for(int t = 0; t < 3; t++) Qxu[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxu[t]);
+          const vf f = ld(mem.Fx, arow[t]);
+          for(int b = 0; b < B; b++) Qxu[b][t] = f * ld(mem.T2, c + 16 * b);
         }
-        for(int t = 0; t < 3; t++) Qxu[t] = sel(in && aval[t], Qxu[t], 0.0);
+        W64_UNROLL(CCC_TILE_U_PROD)
+        for(int bb = 1; bb < S; bb++)
+        {
+          vf tb[B];
+          for(int b = 0; b < B; b++) tb[b] = ld(mem.T2, c + 16 * b + bb * M);
+          for(int t = 0; t < 3; t++)
+          {
+            const vf f = ld(mem.Fx, arow[t] + bb * S);
+            for(int b = 0; b < B; b++) Qxu[b][t] = vfma(f, tb[b], Qxu[b][t]);
+          }
+        }
+        for(int b = 0; b < B; b++)
+          for(int t = 0; t < 3; t++) Qxu[b][t] = sel(in[b] && aval[t], Qxu[b][t], 0.0);
       }
       // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
       vf Qxx[3];
@@ -790,57 +948,87 @@ struct Solver
       for(int t = 0; t < 3; t++)
       {
         st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
-        st(mem.Zl, arow[t] * LT + c, Qxu[t], aval[t]);         // (Qxu waits in Z's place while the box-QP runs)
+        for(int b = 0; b < B; b++)
+          st(mem.Zl, arow[t] * LT + c + 16 * b, Qxu[b][t], aval[t]); // (Qxu waits in Z's place while the box-QP runs)
       }
       TILE_PROF_ADD(TP_PRODUCTS);
       // box-QP and gains
-      vf k = splat(0.0);
-      vf K[3] = {splat(0.0), splat(0.0), splat(0.0)};
+      vf k[B], K[B][3];
+      for(int b = 0; b < B; b++)
+      {
+        k[b] = splat(0.0);
+        for(int t = 0; t < 3; t++) K[b][t] = splat(0.0);
+      }
       if(m > 0)
       {
-        const vf lo = sel(in, P.flo - u, 0.0), hi = sel(in, P.fhi - u, 0.0);
-        // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
-        k = (mprev == m) ? kprev : splat(0.0);
-        unsigned skip;
-        vf rdv;
+        vf lo[B], hi[B];
+        for(int b = 0; b < B; b++)
+        {
+          lo[b] = sel(in[b], P.flo - u[b], 0.0);
+          hi[b] = sel(in[b], P.fhi - u[b], 0.0);
+          // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
+          k[b] = (mprev == m) ? kprev[b] : splat(0.0);
+        }
+        mask_t skip;
+        vf rdv[B];
         const int rc = box_qp(m, HF, Qu, lo, hi, k, skip, rdv);
         if(rc < 1) return false;
         TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
         // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
-        const vb fr = ((spl(static_cast<int>(skip)) >> c) & 1) == 0;
-        vf rhs[3];
-        for(int t = 0; t < 3; t++) rhs[t] = sel(fr, ld(mem.Zl, arow[t] * LT + c), 0.0);
+        vb fr[B];
+        vf rhs[B][3];
+        for(int b = 0; b < B; b++)
+        {
+          fr[b] = !row_in(skip, b);
+          for(int t = 0; t < 3; t++) rhs[b][t] = sel(fr[b], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+        }
         solve<3>(rhs, skip, rdv);
-        for(int t = 0; t < 3; t++) K[t] = sel(fr && aval[t], -rhs[t], 0.0);
+        for(int b = 0; b < B; b++)
+          for(int t = 0; t < 3; t++) K[b][t] = sel(fr[b] && aval[t], -rhs[b][t], 0.0);
       }
       // gains -> global memory (the forward passes read them) and K' -> LDS
-      st(I.ks + static_cast<long>(i) * kM, c, k, g == 0);
-      for(int t = 0; t < 3; t++)
+      for(int b = 0; b < B; b++)
       {
-        st(I.Ks + static_cast<long>(i) * kM * S, c * S + arow[t], K[t], aval[t]);
-        st(mem.T2, arow[t] * LT + c, K[t], aval[t]);
+        st(I.ks + static_cast<long>(i) * M, c + 16 * b, k[b], g == 0);
+        for(int t = 0; t < 3; t++)
+        {
+          st(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + arow[t], K[b][t], aval[t]);
+          st(mem.T2, arow[t] * LT + c + 16 * b, K[b][t], aval[t]);
+        }
       }
       TILE_PROF_ADD(TP_GAINS);
       // termination measure: max_c |k_c| / (|u_c| + 1)
-      gsum += read_lane(max16(sel(in, vabs(k) / (vabs(u) + 1.0), 0.0)), 0);
-      // dV += [k'Qu, 1/2 k'Quu k].  SPEC: tree16(k_c Qu_c), 0.5 tree16(k_c (Quu k)_c)
-      vf H[4];
-      for(int s4 = 0; s4 < 4; s4++) H[s4] = sel(c == g * 4 + s4, hd, HF[s4]);
-      for(int t = 0; t < 3; t++) Qxu[t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c), 0.0);
-      const vf t4 = matvec(H, k, 0);
-      dV0 += read_lane(sum16(k * Qu), 0);
-      dV1 += 0.5 * read_lane(sum16(k * t4), 0);
-      // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + tree16
       {
-        const vf q2 = t4 + Qu;
+        vf mx = sel(in[0], vabs(k[0]) / (vabs(u[0]) + 1.0), 0.0);
+        for(int b = 1; b < B; b++) mx = vmax(mx, sel(in[b], vabs(k[b]) / (vabs(u[b]) + 1.0), 0.0));
+        gsum += read_lane(max16(mx), 0);
+      }
+      // dV += [k'Qu, 1/2 k'Quu k].  SPEC: sumM(k_c Qu_c), 0.5 sumM(k_c (Quu k)_c)
+      for(int b = 0; b < B; b++)
+        for(int t = 0; t < 3; t++) Qxu[b][t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+      vf t4[B];
+      matvec_u(HF, Hd, k, 0, t4);
+      {
+        vf t[B];
+        for(int b = 0; b < B; b++) t[b] = k[b] * Qu[b];
+        dV0 += read_lane(sumM(t), 0);
+        for(int b = 0; b < B; b++) t[b] = k[b] * t4[b];
+        dV1 += 0.5 * read_lane(sumM(t), 0);
+      }
+      // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + sumM
+      {
+        vf q2[B];
+        for(int b = 0; b < B; b++) q2[b] = t4[b] + Qu[b];
         for(int t = 0; t < 3; t++)
         {
-          const vf v = sum16(vfma(Qxu[t], k, K[t] * q2));
+          vf w[B];
+          for(int b = 0; b < B; b++) w[b] = vfma(Qxu[b][t], k[b], K[b][t] * q2[b]);
+          const vf v = sumM(w);
           st(mem.vxn, arow[t], v, aval[t] && (c == 0));
         }
       }
       wave_sync();
-      // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [matvec] + 2 Qxu[a][c]
+      // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [row_dot] + 2 Qxu[a][c]
       wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
       for(int t = 0; t < 3; t++)
       {
@@ -849,18 +1037,20 @@ struct Solver
         {
           const int a = gg + 4 * t;
           if(a >= S) break;
-          vf yb[4];
-          for(int s4 = 0; s4 < 4; s4++) yb[s4] = ld(mem.T2, g * 4 + s4 + a * LT);
-          vf p = H[0] * yb[0];
-          for(int s4 = 1; s4 < 4; s4++) p = vfma(H[s4], yb[s4], p);
-          const vf z = sum_rows(p) + 2.0 * Qxu[t];
-          st(mem.Zl, c + a * LT, z, g == gg);
+          vf yb[B][4];
+          for(int bc = 0; bc < B; bc++)
+            for(int s4 = 0; s4 < 4; s4++) yb[bc][s4] = ld(mem.T2, g * 4 + s4 + 16 * bc + a * LT);
+          for(int br = 0; br < B; br++)
+          {
+            const vf z = row_dot([&](int bc, int s) { return bc == br ? Hd[br][s] : HF[br][bc][s]; }, yb) + 2.0 * Qxu[br][t];
+            st(mem.Zl, c + 16 * br + a * LT, z, g == gg);
+          }
         }
       }
       st(mem.Vx, c, ld(mem.Qx, seli(inS, c, spl(0))) + ld(mem.vxn, seli(inS, c, spl(0))), inS && (g == 0));
       wave_sync();
       // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + sum_c (K[c][a] Z[c][b] + K[c][b] Z[c][a]))
-      // SPEC: acc = 0; for c = 0 .. 15: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
+      // SPEC: acc = 0; for c = 0 .. M-1: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
       for(int q = 0; q < NPASS; q++)
       {
         const vi pidx = lane + 64 * q;
@@ -869,7 +1059,7 @@ struct Solver
         const vi pa = ab & 15, pb = ab >> 4;
         vf acc = splat(0.0);
         W64_UNROLL(CCC_TILE_U_PAIR)
-        for(int r = 0; r < kM; r++)
+        for(int r = 0; r < M; r++)
         {
           acc = vfma(ld(mem.T2, pa * LT + r), ld(mem.Zl, pb * LT + r), acc);
           acc = vfma(ld(mem.T2, pb * LT + r), ld(mem.Zl, pa * LT + r), acc);
@@ -880,7 +1070,7 @@ struct Solver
       }
       wave_sync();
       TILE_PROF_ADD(TP_VALUE);
-      kprev = k;
+      for(int b = 0; b < B; b++) kprev[b] = k[b];
       mprev = m;
     }
     return true;
@@ -888,6 +1078,7 @@ struct Solver
 
   // ------------------------------------------------------------------------------------------------ forward passes
   // Four candidates at once: row g rolls out alpha[first + g] into slot cand[g].  Returns the costs per row.
+  static constexpr bool kPrefetchK = (B == 1); // the gain rows of the next step fetched a step ahead (registers permitting)
   CCC_TILE_PIECE vf forward_pass(int first, const int (&cand)[4])
   {
     const int N = P.N;
@@ -895,7 +1086,7 @@ struct Solver
     const double * us = ucur();
     const vf alpha = ld(mem.alpha, seli(g + first < 12, g + first, spl(11)));
     const vi slot = seli(g == 0, spl(cand[0]), seli(g == 1, spl(cand[1]), seli(g == 2, spl(cand[2]), spl(cand[3]))));
-    const vi xoff = slot * ((N + 1) * S), uoff = slot * (N * kM);
+    const vi xoff = slot * ((N + 1) * S), uoff = slot * (N * M);
     mem_sync(); // (the gains were written by other lanes of this wavefront)
     TILE_PROF_START();
     TILE_PROF_COUNT(TP_FORWARDS);
@@ -904,32 +1095,59 @@ struct Solver
     st(I.xbuf, xoff + c, x, inS);
     // the operands of step i + 1 are fetched while step i computes
     int ph_n = phase_of(0), m_n = dim_of_phase(ph_n);
-    vf xi_n = ldm(xs, c, inS), ui_n = ldm(us, c, c < m_n), ki_n = ldm(I.ks, c, c < m_n);
-    vf Kr_n[S];
-    for(int a = 0; a < S; a++) Kr_n[a] = ldm(I.Ks, c * S + a, c < m_n);
+    vf xi_n = ldm(xs, c, inS), ui_n[B], ki_n[B];
+    vf Kr_n[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
+    for(int b = 0; b < B; b++)
+    {
+      const vb inn = c + 16 * b < m_n;
+      ui_n[b] = ldm(us, c + 16 * b, inn);
+      ki_n[b] = ldm(I.ks, c + 16 * b, inn);
+      if constexpr(kPrefetchK)
+        for(int a = 0; a < S; a++) Kr_n[b][a] = ldm(I.Ks, (c + 16 * b) * S + a, inn);
+    }
     for(int i = 0; i < N; i++)
     {
       const int m = m_n, ph = ph_n;
-      const vb in = c < m;
-      const vf xi = xi_n, ui = ui_n, ki = ki_n;
-      vf Kr[S];
-      for(int a = 0; a < S; a++) Kr[a] = Kr_n[a];
+      vb in[B];
+      vf ui[B], ki[B], Kr[B][S];
+      const vf xi = xi_n;
+      for(int b = 0; b < B; b++)
+      {
+        in[b] = c + 16 * b < m;
+        ui[b] = ui_n[b];
+        ki[b] = ki_n[b];
+        for(int a = 0; a < S; a++)
+        {
+          if constexpr(kPrefetchK)
+            Kr[b][a] = Kr_n[b][a];
+          else
+            Kr[b][a] = ldm(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + a, in[b]);
+        }
+      }
       if(i + 1 < N)
       {
         ph_n = phase_of(i + 1);
         m_n = dim_of_phase(ph_n);
-        const vb inn = c < m_n;
         xi_n = ldm(xs + static_cast<long>(i + 1) * S, c, inS);
-        ui_n = ldm(us + static_cast<long>(i + 1) * kM, c, inn);
-        ki_n = ldm(I.ks + static_cast<long>(i + 1) * kM, c, inn);
-        for(int a = 0; a < S; a++) Kr_n[a] = ldm(I.Ks + static_cast<long>(i + 1) * kM * S, c * S + a, inn);
+        for(int b = 0; b < B; b++)
+        {
+          const vb inn = c + 16 * b < m_n;
+          ui_n[b] = ldm(us + static_cast<long>(i + 1) * M, c + 16 * b, inn);
+          ki_n[b] = ldm(I.ks + static_cast<long>(i + 1) * M, c + 16 * b, inn);
+          if constexpr(kPrefetchK)
+            for(int a = 0; a < S; a++) Kr_n[b][a] = ldm(I.Ks + static_cast<long>(i + 1) * M * S, (c + 16 * b) * S + a, inn);
+        }
       }
       const vf dx = x - xi;
       // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
-      vf s = ui + alpha * ki;
-      s = feedback<0>(s, dx, Kr);
-      const vf un = sel(in, vmin(vmax(s, P.flo), P.fhi), 0.0);
-      st(I.ubuf, uoff + i * kM + c, un, c < kM);
+      vf un[B];
+      for(int b = 0; b < B; b++)
+      {
+        vf s = ui[b] + alpha * ki[b];
+        s = feedback<0>(s, dx, Kr[b]);
+        un[b] = sel(in[b], vmin(vmax(s, P.flo), P.fhi), 0.0);
+        st(I.ubuf, uoff + i * M + c + 16 * b, un[b], c < 16);
+      }
       costc = costc + running_cost(i, x, un);
       Terms T;
       terms_of(ph, m, x, un, T);
@@ -963,9 +1181,13 @@ struct Solver
     for(int i = 0; i < N; i++)
     {
       const int ph = phase_of(i), m = dim_of_phase(ph);
-      const vb in = c < m;
-      const vf u = I.u_init ? ldm(I.u_init + static_cast<long>(i) * kM, c, in) : splat(0.0);
-      st(I.ubuf, i * kM + c, u, g == 0);
+      vf u[B];
+      for(int b = 0; b < B; b++)
+      {
+        const vb in = c + 16 * b < m;
+        u[b] = I.u_init ? ldm(I.u_init + static_cast<long>(i) * M, c + 16 * b, in) : splat(0.0);
+        st(I.ubuf, i * M + c + 16 * b, u[b], g == 0);
+      }
       cc = cc + running_cost(i, x, u);
       Terms T;
       terms_of(ph, m, x, u, T);
@@ -1073,7 +1295,7 @@ struct Solver
       const int N = P.N;
       const double * xs = xcur();
       const double * us = ucur();
-      for(int e = 0; e < N * kM; e += 64) st(I.u_out, lane + e, ldm(us, lane + e, lane + e < N * kM), lane + e < N * kM);
+      for(int e = 0; e < N * M; e += 64) st(I.u_out, lane + e, ldm(us, lane + e, lane + e < N * M), lane + e < N * M);
       if(I.x_out)
         for(int e = 0; e < (N + 1) * S; e += 64)
           st(I.x_out, lane + e, ldm(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);

@@ -1,8 +1,11 @@
 // ddp_tile.hip -- the TILE build of the DDP planners (csrc/ddp_tile.h): CCC::DdpCentroidal / CCC::DdpSingleRigidBody with
-// <= 16 ridges per step and the default regularisation, one instance per wavefront, every matrix distributed over the
-// 64 lanes, <= 128 VGPRs and <= 10 KB of LDS per wavefront: four wavefronts per SIMD, sixteen instances per CU.
-// What ccc_ddp_plan_batch_device runs by default for these sizes (csrc/ddp.hip); its arithmetic is the tile
-// specification of oracle/ddp_tile.c, reproduced bit for bit (tests/test_ddp_gpu.py, tests/test_ddp_tile_emu.py).
+// the default regularisation, one instance per wavefront, every matrix distributed over the 64 lanes.
+//   M = 16 ridges per step (one surface contact):  <= 128 VGPRs and <= 10 KB of LDS per wavefront -> four wavefronts per
+//                                                  SIMD, sixteen instances per CU
+//   M = 32 (two surface contacts, double support): 16-20 KB of LDS -> two wavefronts per SIMD
+//   M = 64 (up to four surface contacts):          ~50 KB of LDS -> three wavefronts per CU
+// What ccc_ddp_plan_batch_device runs by default (csrc/ddp.hip); its arithmetic is the tile specification of
+// oracle/ddp_tile.c, reproduced bit for bit (tests/test_ddp_gpu.py, tests/test_ddp_tile_emu.py).
 // Replaces the same reference code as csrc/ddp.hip.
 #include "ddp_tile.h"
 
@@ -10,22 +13,21 @@
 
 namespace ccc_amd
 {
-// doubles of workspace per instance: trajectories [kSlots][N+1][S] and [kSlots][N][16], gains [N][16] and [N][16][S]
-size_t ddp_tile_ws_doubles(int N, int S)
+// doubles of workspace per instance: trajectories [kSlots][N+1][S] and [kSlots][N][M], gains [N][M] and [N][M][S]
+size_t ddp_tile_ws_doubles(int N, int S, int M)
 {
-  return (size_t)ddp_tile::kSlots * ((size_t)(N + 1) * S + (size_t)N * ddp_tile::kM) + (size_t)N * ddp_tile::kM
-         + (size_t)N * ddp_tile::kM * S;
+  return (size_t)ddp_tile::kSlots * ((size_t)(N + 1) * S + (size_t)N * M) + (size_t)N * M + (size_t)N * M * S;
 }
 
 #ifndef CCC_TILE_WAVES
 #  define CCC_TILE_WAVES 4
 #endif
-template<int S>
-__global__ __launch_bounds__(64, CCC_TILE_WAVES) void ddp_tile_kernel(ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride,
-                                                         long n)
+template<int S, int NB>
+__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? 2 : 1))) void ddp_tile_kernel(
+    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n)
 {
-  __shared__ ddp_tile::Mem<S> mem;
-  constexpr int M = ddp_tile::kM;
+  __shared__ ddp_tile::Mem<S, NB> mem;
+  constexpr int M = 16 * NB;
   const int N = P.N;
   for(long b = blockIdx.x; b < n; b += gridDim.x)
   {
@@ -52,20 +54,26 @@ __global__ __launch_bounds__(64, CCC_TILE_WAVES) void ddp_tile_kernel(ddp_common
     I.out_iters = B.iters ? B.iters + b : nullptr;
     I.out_status = B.status ? B.status + b : nullptr;
     I.out_cost = B.cost ? B.cost + b : nullptr;
-    ddp_tile::Solver<S> solver(P, I, mem);
+    ddp_tile::Solver<S, NB> solver(P, I, mem);
     solver.solve_instance();
     __syncthreads();
   }
 }
 
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, hipStream_t stream)
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, int M,
+                           hipStream_t stream)
 {
   const int grid = (int)(n < (1L << 22) ? n : (1L << 22)); // one workgroup per instance: the dispatcher balances
-  const size_t stride = ddp_tile_ws_doubles(P.N, S);
-  if(S == 9)
-    hipLaunchKernelGGL((ddp_tile_kernel<9>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n);
-  else
-    hipLaunchKernelGGL((ddp_tile_kernel<12>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n);
+  const size_t stride = ddp_tile_ws_doubles(P.N, S, M);
+#define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n)
+  if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
+  else if(S == 12 && M == 16) CCC_TILE_LAUNCH(12, 1);
+  else if(S == 9 && M == 32) CCC_TILE_LAUNCH(9, 2);
+  else if(S == 12 && M == 32) CCC_TILE_LAUNCH(12, 2);
+  else if(S == 9 && M == 64) CCC_TILE_LAUNCH(9, 4);
+  else if(S == 12 && M == 64) CCC_TILE_LAUNCH(12, 4);
+  else return hipErrorInvalidValue;
+#undef CCC_TILE_LAUNCH
   return hipGetLastError();
 }
 } // namespace ccc_amd

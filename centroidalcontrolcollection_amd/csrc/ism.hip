@@ -24,7 +24,8 @@
 
 namespace ccc_amd
 {
-constexpr int kIsmNP = 128;   // rows per QP (N + 1 <= 128)
+constexpr int kIsmNP = 192;   // rows per QP (N + 1 <= 192: the largest packed tableau of 4 x 4 tiles that fits the LDS)
+constexpr int kIsmWR = kIsmNP / 64; // wavefronts that hold rows
 constexpr double kIsmInf = __builtin_huge_val();
 
 struct IsmDev
@@ -38,14 +39,14 @@ struct IsmDev
 
 struct IsmRed
 {
-  double val[2];
-  int idx[2];
+  double val[kIsmWR];
+  int idx[kIsmWR];
 };
 
 struct IsmSel
 {
-  double val[2], sig[2];
-  int idx[2];
+  double val[kIsmWR], sig[kIsmWR];
+  int idx[kIsmWR];
 };
 
 __device__ __forceinline__ double ism_lane_value(double v, int k) // k uniform: two v_readlane_b32
@@ -71,11 +72,17 @@ __device__ __forceinline__ void ism_block_argmin(double v, IsmRed * red, double 
     red->idx[w] = wi < 64 ? wi + 64 * w : kIsmNP;
   }
   __syncthreads();
-  const double a = red->val[0], b = WR > 1 ? red->val[1] : kIsmInf;
-  const int ia = red->idx[0], ib = WR > 1 ? red->idx[1] : kIsmNP;
-  const bool first = (ia < kIsmNP) && (a <= b || ib >= kIsmNP);
-  vmin = first ? a : b;
-  imin = first ? ia : ib;
+  vmin = red->val[0];
+  imin = red->idx[0];
+#pragma unroll
+  for(int k = 1; k < WR; ++k) // (ties: the lowest row index)
+  {
+    const double b = red->val[k];
+    const int ib = red->idx[k];
+    const bool take = (ib < kIsmNP) && (imin >= kIsmNP || b < vmin);
+    vmin = take ? b : vmin;
+    imin = take ? ib : imin;
+  }
 }
 
 // init [nqp][2] (capture_point, planned_zmp), ref [nqp][3][N] (ref zmp, zmin, zmax), zmp [nqp], vel [nqp][N] | null,
@@ -170,13 +177,14 @@ __global__ __launch_bounds__((SymTab<NR, 4, TPT>::NT), (SymTab<NR, 4, TPT>::kMin
         {
           double best = sel->val[0], sg = sel->sig[0];
           int cand = sel->idx[0];
-          if(WR > 1)
+#pragma unroll
+          for(int k = 1; k < WR; ++k)
           {
-            const double a2 = sel->val[1];
-            const int i2 = sel->idx[1];
+            const double a2 = sel->val[k];
+            const int i2 = sel->idx[k];
             const bool take = (i2 < NP) && (cand >= NP || a2 < best);
             best = take ? a2 : best;
-            sg = take ? sel->sig[1] : sg;
+            sg = take ? sel->sig[k] : sg;
             cand = take ? i2 : cand;
           }
           if(cand >= NP) break;
@@ -806,7 +814,7 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
     CCC_HIP_CHECK(hipMalloc(&h->redo, (size_t)(nqp + 1) * sizeof(int)));
     h->redo_cap = nqp;
   }
-  const bool tableau_only = h->env_tableau || h->N > kPcrNP;
+  const bool tableau_only = h->env_tableau || h->N >= kPcrNP; // (the tridiagonal kernel: up to 127 steps)
   if(!tableau_only)
   {
     // default path: tridiagonal projected Newton, one QP per wavefront; what it cannot finish goes onto the list
@@ -840,8 +848,12 @@ extern "C" int ccc_ism_plan_batch_device(ccc_ism_t * h, int64_t n, const double 
     rc = go(&ism_plan_kernel<80, 2>, SymTab<80, 4, 2>{});
   else if(R <= 104)
     rc = go(&ism_plan_kernel<104, 2>, SymTab<104, 4, 2>{});
-  else
+  else if(R <= 128)
     rc = go(&ism_plan_kernel<128, 3>, SymTab<128, 4, 3>{});
+  else if(R <= 160)
+    rc = go(&ism_plan_kernel<160, 2>, SymTab<160, 4, 2>{});
+  else
+    rc = go(&ism_plan_kernel<192, 3>, SymTab<192, 4, 3>{});
   if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   return CCC_OK;

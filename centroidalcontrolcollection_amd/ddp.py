@@ -14,7 +14,8 @@ import numpy as np
 from . import _lib
 
 MAX_RIDGES = 16  # default ridge stride (one surface contact per step)
-MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support), the wide kernel
+MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support)
+MAX_RIDGES_MULTI = 64  # max_ridges=64: up to four surface contacts per step (feet + hands)
 
 
 class _Params(ctypes.Structure):
@@ -187,8 +188,9 @@ class _DdpBase:
     def _sample(self, motion_param_func, ref_data_func, current_time):
         """src/DdpCentroidal.cpp:218-229: sample the callbacks at current_time + i*dt and flatten the contact lists
         into contact phases (consecutive steps with the same contact list share a phase).  Returns (planner, prob): this
-        object when its tables hold the problem, else a wide twin (max_ridges = 32, one phase per step if need be)
-        created on first need -- the reference takes any contact_list (src/DdpCentroidal.cpp:49-60)."""
+        object when its tables hold the problem, else a twin with the smallest ridge stride that does (16, 32 or 64; one
+        phase per step if need be) created on first need -- the reference takes any contact_list
+        (src/DdpCentroidal.cpp:49-60)."""
         N = self.horizon_steps_
         ref_pos, ref_ori, inertia = np.zeros((1, N + 1, 3)), np.zeros((1, N + 1, 3)), np.zeros((1, 3, 3))
         step_phase = np.zeros((1, N), dtype=np.int32)
@@ -207,9 +209,9 @@ class _DdpBase:
                 R = np.concatenate([np.asarray(c[1], dtype=np.float64).reshape(-1, 3) for c in mp.contact_list])
             else:
                 V, R = np.zeros((0, 3)), np.zeros((0, 3))
-            if len(V) > MAX_RIDGES_WIDE:
+            if len(V) > MAX_RIDGES_MULTI:
                 raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "%d ridges in one contact list, the kernels are built "
-                                    "for %d (two 4-vertex surface contacts)" % (len(V), MAX_RIDGES_WIDE))
+                                    "for %d (four 4-vertex surface contacts)" % (len(V), MAX_RIDGES_MULTI))
             if self.MODEL == 1 and i == 0:
                 inertia[0] = mp.inertia_mat
             for k, (Vk, Rk) in enumerate(phases):
@@ -220,8 +222,10 @@ class _DdpBase:
                 phases.append((V, R))
                 step_phase[0, i] = len(phases) - 1
         planner = self
-        if len(phases) > self.max_phases_ or max([len(V) for V, _ in phases] + [0]) > self.max_ridges_:
-            planner = self._wide_twin()
+        widest = max([len(V) for V, _ in phases] + [0])
+        if len(phases) > self.max_phases_ or widest > self.max_ridges_:
+            need = MAX_RIDGES if widest <= MAX_RIDGES else (MAX_RIDGES_WIDE if widest <= MAX_RIDGES_WIDE else MAX_RIDGES_MULTI)
+            planner = self._twin(need)
         P, M = planner.max_phases_, planner.max_ridges_
         prob = dict(phase_dim=np.zeros((1, P), dtype=np.int32), phase_vertex=np.zeros((1, P, M, 3)),
                     phase_ridge=np.zeros((1, P, M, 3)), step_phase=step_phase, ref_pos=ref_pos)
@@ -233,13 +237,15 @@ class _DdpBase:
             prob["phase_ridge"][0, k, :len(V)] = R
         return planner, prob
 
-    def _wide_twin(self):
-        if getattr(self, "_wide", None) is None:
-            self._wide = _DdpBase.__new__(type(self))
-            _DdpBase.__init__(self._wide, self.mass_, self.dt_, self.horizon_steps_, self._w_run, self._w_term,
-                              self._w_force, self.device, max_phases=self.horizon_steps_, max_ridges=MAX_RIDGES_WIDE)
-        self._wide.ddp_solver_ = self.ddp_solver_  # one configuration / control data, as the caller sees one solver
-        return self._wide
+    def _twin(self, max_ridges):
+        twins = self.__dict__.setdefault("_twins", {})
+        if max_ridges not in twins:
+            t = _DdpBase.__new__(type(self))
+            _DdpBase.__init__(t, self.mass_, self.dt_, self.horizon_steps_, self._w_run, self._w_term,
+                              self._w_force, self.device, max_phases=self.horizon_steps_, max_ridges=max_ridges)
+            twins[max_ridges] = t
+        twins[max_ridges].ddp_solver_ = self.ddp_solver_  # one configuration / control data, as the caller sees one solver
+        return twins[max_ridges]
 
     def _plan_once(self, motion_param_func, ref_data_func, x0, u_list, current_time):
         N = self.horizon_steps_

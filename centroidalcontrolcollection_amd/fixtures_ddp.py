@@ -237,6 +237,63 @@ def make_walking_batch(n, N=40, dt=0.05, mass=100.0, M=32, seed=20250928, srb=Fa
     return prob, np.ascontiguousarray(x0)
 
 
+def contact_from_pose(centre, normal, tangent, half=(0.05, 0.05), mu=0.5):
+    """A 4-vertex surface contact in an arbitrary pose (a hand on a wall, a foot on a slope): ForceColl::SurfaceContact
+    with pose (R = [tangent, normal x tangent, normal], p = centre) -- vertices and friction-pyramid ridges of
+    `contact_from_rect` mapped by the pose.  Returns (vertex [16,3], ridge [16,3])."""
+    nz = np.asarray(normal, dtype=np.float64)
+    nz = nz / np.linalg.norm(nz)
+    tx = np.asarray(tangent, dtype=np.float64)
+    tx = tx - nz * (tx @ nz)
+    tx = tx / np.linalg.norm(tx)
+    Rm = np.stack([tx, np.cross(nz, tx), nz], axis=1)
+    V, R = contact_from_rect((-half[0], -half[1]), (half[0], half[1]), mu)
+    return V @ Rm.T + np.asarray(centre, dtype=np.float64), R @ Rm.T
+
+
+def make_multicontact_batch(n, N=30, dt=0.05, mass=100.0, M=64, seed=20250928, srb=False, P=6):
+    """Multi-contact motions -- what CCC::DdpCentroidal exists for (src/DdpCentroidal.cpp:49-60 iterates an arbitrary
+    contact_list): both feet on the ground plus one or two HAND contacts on vertical walls at x = 0.45 (normal -x) and
+    y = +-0.4 (normal -+y): 32, 48 or 64 ridges per step.  Per instance P contact phases drawn from
+    {feet, feet + right hand, feet + left hand, feet + both hands, one foot + both hands, left foot only},
+    each held for 3-9 steps; the reference CoM drifts forward at height 0.9.  x0 as in `make_walking_batch`.
+    PRNG numpy default_rng(seed) (PCG64).  Returns (prob, x0 [n,S])."""
+    assert M >= 64
+    rng = np.random.default_rng(seed)
+    prob = empty_problem(n, N, P, M, srb)
+    for k in range(n):
+        lf = contact_from_rect((-0.1, 0.05), (0.1, 0.15))
+        rf = contact_from_rect((-0.1 + rng.uniform(-0.03, 0.03), -0.15), (0.1, -0.05))
+        rh = contact_from_pose((0.45, -0.2 + rng.uniform(-0.05, 0.05), 1.0 + rng.uniform(-0.1, 0.1)), (-1, 0, 0), (0, 1, 0))
+        lh = contact_from_pose((0.1 + rng.uniform(-0.05, 0.05), 0.4, 1.1 + rng.uniform(-0.1, 0.1)), (0, -1, 0), (1, 0, 0))
+        menu = [[lf, rf], [lf, rf, rh], [lf, rf, lh], [lf, rf, rh, lh], [lf, rh, lh], [lf]]
+        order = rng.permutation(len(menu))[:P]
+        if 3 not in order:
+            order[rng.integers(0, P)] = 3  # every instance has a four-contact phase
+        for p, q in enumerate(order):
+            r = 0
+            for V, R in menu[q]:
+                prob["phase_vertex"][k, p, r:r + 16], prob["phase_ridge"][k, p, r:r + 16] = V, R
+                r += 16
+            prob["phase_dim"][k, p] = r
+        i, p = 0, 0
+        while i < N:
+            d = int(rng.integers(3, 10))
+            prob["step_phase"][k, i:i + d] = p % P
+            i, p = i + d, p + 1
+        prob["ref_pos"][k, :, 0] = 0.05 * np.arange(N + 1) * dt
+        prob["ref_pos"][k, :, 2] = 0.9
+    c0 = prob["ref_pos"][:, 0, :] + rng.uniform(-0.03, 0.03, size=(n, 3))
+    v0 = rng.uniform(-0.1, 0.1, size=(n, 3))
+    if srb:
+        prob["inertia"][:] = np.diag([40.0, 20.0, 10.0])
+        x0 = np.concatenate([c0, rng.uniform(-0.05, 0.05, size=(n, 3)), v0, rng.uniform(-0.1, 0.1, size=(n, 3))],
+                            axis=1)
+    else:
+        x0 = np.concatenate([c0, mass * v0, np.zeros((n, 3))], axis=1)
+    return prob, np.ascontiguousarray(x0)
+
+
 def srb_ori_ref(t):
     """TestDdpSingleRigidBody.cpp:78-85 (the +1e-6 included): roll reference bump between 2.2 s and 2.4 s."""
     t = t + 1e-6

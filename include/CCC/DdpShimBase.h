@@ -104,9 +104,9 @@ struct Flat
             R.push_back(ridge[a]);
           }
     const int m = static_cast<int>(V.size() / 3);
-    if(m > CCC_DDP_MAX_RIDGES_WIDE)
+    if(m > CCC_DDP_MAX_RIDGES_MULTI)
       throw std::runtime_error("[DDP shim] " + std::to_string(m) + " ridges in a contact list, the kernels are built for "
-                               + std::to_string(CCC_DDP_MAX_RIDGES_WIDE) + " (two 4-vertex surface contacts)");
+                               + std::to_string(CCC_DDP_MAX_RIDGES_MULTI) + " (four 4-vertex surface contacts)");
     dims[static_cast<size_t>(i)] = m;
     max_dim_ = std::max(max_dim_, m);
     for(size_t k = 0; k < phases_V_.size(); k++)
@@ -156,13 +156,14 @@ inline void check(int rc, const char * who)
 }
 
 /** The library handles behind one shim object: the FAST one (<= 16 ridges per step, <= max_phases contact phases; made
-    by the constructor) and, created on first need, the WIDE one (32 ridges, one phase per horizon step if need be) --
-    the reference takes any contact_list (src/DdpCentroidal.cpp:49-60), so must planOnce(). */
+    by the constructor) and, created on first need, TWINS with the smallest ridge stride that holds the sampled contact
+    lists (16, 32 or 64 ridges; one phase per horizon step if need be) -- the reference takes any contact_list
+    (src/DdpCentroidal.cpp:49-60), so must planOnce(). */
 struct Handles
 {
   ccc_ddp_params_t params{};
   int device = 0;
-  std::shared_ptr<ccc_ddp_t> fast, wide;
+  std::shared_ptr<ccc_ddp_t> fast, twin[3];
 
   void create(const ccc_ddp_params_t & p, int dev, const char * who)
   {
@@ -181,17 +182,19 @@ struct Handles
       f.pack(params.max_phases, CCC_DDP_MAX_RIDGES);
       return fast.get();
     }
-    if(!wide)
+    const int k = f.maxDim() <= CCC_DDP_MAX_RIDGES ? 0 : (f.maxDim() <= CCC_DDP_MAX_RIDGES_WIDE ? 1 : 2);
+    const int stride = k == 0 ? CCC_DDP_MAX_RIDGES : (k == 1 ? CCC_DDP_MAX_RIDGES_WIDE : CCC_DDP_MAX_RIDGES_MULTI);
+    if(!twin[k])
     {
       ccc_ddp_params_t p = params;
       p.max_phases = params.horizon_steps;
-      p.max_ridges = CCC_DDP_MAX_RIDGES_WIDE;
+      p.max_ridges = stride;
       ccc_ddp_t * h = nullptr;
       check(ccc_ddp_create(&p, device, &h), who);
-      wide.reset(h, ccc_ddp_destroy);
+      twin[k].reset(h, ccc_ddp_destroy);
     }
-    f.pack(params.horizon_steps, CCC_DDP_MAX_RIDGES_WIDE);
-    return wide.get();
+    f.pack(params.horizon_steps, stride);
+    return twin[k].get();
   }
 };
 

@@ -142,6 +142,7 @@ typedef struct ccc_ddp ccc_ddp_t;
 #define CCC_DDP_SINGLE_RIGID_BODY 1 /* 12 states [c, alpha, v, w]  src/DdpSingleRigidBody.cpp:52-91 */
 #define CCC_DDP_MAX_RIDGES 16       /* default ridge stride: one 4-vertex surface contact per step (the fast kernel) */
 #define CCC_DDP_MAX_RIDGES_WIDE 32  /* params.max_ridges = 32: two surface contacts per step (double support) */
+#define CCC_DDP_MAX_RIDGES_MULTI 64 /* params.max_ridges = 64: up to four surface contacts per step (feet + hands) */
 
 /* Constructor arguments of DdpCentroidal(mass, horizon_dt, horizon_steps, weight_param)
  * (include/CCC/DdpCentroidal.h:342) / DdpSingleRigidBody (include/CCC/DdpSingleRigidBody.h:379-394), with the
@@ -158,11 +159,12 @@ typedef struct
   double w_run[12], w_term[12], w_force;
   double force_scale_limits[2];
   int max_phases; /* P: contact phases per instance (distinct contact lists inside one horizon); any value >= 1, up to
-                   * one phase per horizon step.  P <= 4 with max_ridges 16 and horizon_steps <= 128 runs the fast kernel,
-                   * anything beyond the wide kernel (same results, several times slower per instance). */
+                   * one phase per horizon step. */
   int max_ridges; /* M: ridge stride of phase_vertex / phase_ridge / u_init / u_out: 0 or 16 = CCC_DDP_MAX_RIDGES, 32 =
                    * CCC_DDP_MAX_RIDGES_WIDE (a step with two 4-vertex surface contacts, src/DdpCentroidal.cpp:49-60
-                   * over a two-element contact_list).  Other values: CCC_ERR_UNSUPPORTED. */
+                   * over a two-element contact_list), 64 = CCC_DDP_MAX_RIDGES_MULTI (up to four: feet and hands).  A
+                   * problem gives the same answer at every stride that holds it; smaller strides run faster.  Other
+                   * values: CCC_ERR_UNSUPPORTED. */
 } ccc_ddp_params_t;
 
 /* ddp_solver_->config() (nmpc_ddp::DDPSolver::Configuration, external).  ccc_ddp_default_config
@@ -292,7 +294,8 @@ typedef struct ccc_ism ccc_ism_t;
 /* Replaces IntrinsicallyStableMpc::IntrinsicallyStableMpc(com_height, horizon_duration, horizon_dt, qp_solver_type,
  * weight_param) (IntrinsicallyStableMpc.h:162-169) -> IntrinsicallyStableMpc1d constructor
  * (src/IntrinsicallyStableMpc.cpp:8-45).  WeightParam{zmp = 1, zmp_vel = 1e-3} (IntrinsicallyStableMpc.h:42-55).
- * horizon_steps = ceil(horizon_duration / horizon_dt) must be <= 127. */
+ * horizon_steps = ceil(horizon_duration / horizon_dt) must be <= 191 (up to 127: the tridiagonal projected-Newton kernel
+ * with the packed LDS tableau as fallback; 128..191: the tableau kernel alone). */
 int ccc_ism_create(double com_height, double horizon_duration, double horizon_dt, double w_zmp, double w_zmp_vel,
                    int device, ccc_ism_t ** out);
 void ccc_ism_destroy(ccc_ism_t * h);

@@ -8,14 +8,18 @@
  * no order is more faithful than another (parity unpinned at this boundary).  Round 1-2 froze plain
  * left-to-right sums (arith = 0, still what the 32-ridge "wide" kernels run); this file freezes the orders a 64-lane
  * wavefront produces without serialising:
- *   tree16   sums over the (up to) 16 ridges of a step:  ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)) + the same of t8..t15
- *   rows4    16-term dot products with a row of Quu: four fma chains over 4 consecutive columns, then (p0+p1)+(p2+p3)
+ *   tree16   sums over 16 terms:  ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)) + the same of t8..t15
+ *   treeM    sums over the M = 16 B ridges of a step (B = 1, 2, 4 blocks of 16: one, two, up to four surface contacts):
+ *            w_c = t_c | t_c + t_{c+16} | (t_c + t_{c+16}) + (t_{c+32} + t_{c+48}), then tree16(w)
+ *   rows4    M-term dot products with a row of Quu: four fma chains, chain g over the columns 16 b + 4g .. 16 b + 4g+3
+ *            of the blocks b = 0 .. B-1 in increasing order, then (p0+p1)+(p2+p3)
  *   chains   products over the state dimension: one fma chain in increasing index
  *   LDL'     the box-QP factorisation without square roots: d_j = a_jj, r_j = 1/d_j, l_cj = a_cj r_j,
- *            a_ck <- fma(-(a_cj a_kj), r_j, a_ck); substitutions column by column with fma
+ *            a_ck <- fma(-(a_cj a_kj), r_j, a_ck); substitutions column by column with fma, over the rows from the first
+ *            ridge of the column's block of 16 on (forward) / up to the last ridge of its block (backward)
  *   value    Vxx = sym(Qxx) + 1/2 (K'Z + Z'K) with Z = Quu K + 2 Qux (algebraically the Vxx of ddp.c)
- * Inputs beyond a step's dimension are exact zeros and take part in the sums (x + 0 = x).  Only 16-ridge strides
- * (M = 16) and reg_type 1 exist in this arithmetic.  All elementwise formulas (cross products, Euler-angle kinematics,
+ * Inputs beyond a step's dimension are exact zeros and take part in the sums (x + 0 = x).  Ridge strides
+ * M = 16, 32, 64 and reg_type 1 exist in this arithmetic.  All elementwise formulas (cross products, Euler-angle kinematics,
  * the 3x3 inertia solves, cost terms) are those of ddp_models.c, unfused; fma() appears exactly where written.
  * The two arithmetics agree to rounding (tests/test_oracle_ddp_tile.py) and the HIP kernel csrc/ddp_tile.h reproduces
  * this file bit for bit.
@@ -27,7 +31,7 @@
 #include <string.h>
 
 #define G_ 9.80665
-#define M_ 16
+#define MMAX 64 /* largest ridge stride */
 
 static double tree16(const double * t)
 {
@@ -38,14 +42,26 @@ static double tree16(const double * t)
   return c0 + c1;
 }
 
-/* (H y)_c for a 16 x 16 row-major H: four fma chains over the column blocks, then (p0 + p1) + (p2 + p3) */
-static double rows4(const double * Hrow, const double * y)
+/* sum over the M = 16 B ridges: the blocks added entry by entry, then the tree */
+static double treeM(const double * t, int M_)
+{
+  double w[16];
+  for(int c = 0; c < 16; c++)
+    w[c] = M_ == 16 ? t[c] : (M_ == 32 ? t[c] + t[c + 16] : (t[c] + t[c + 16]) + (t[c + 32] + t[c + 48]));
+  return tree16(w);
+}
+
+/* (H y)_c for a row of an M x M row-major H: four fma chains (chain g: the columns 16 b + 4g .. 16 b + 4g+3, b ascending),
+ * then (p0 + p1) + (p2 + p3) */
+static double rows4(const double * Hrow, const double * y, int M_)
 {
   double p[4];
   for(int g = 0; g < 4; g++)
   {
     double s = Hrow[4 * g] * y[4 * g];
     for(int k = 1; k < 4; k++) s = fma(Hrow[4 * g + k], y[4 * g + k], s);
+    for(int b = 1; b < M_ / 16; b++)
+      for(int k = 0; k < 4; k++) s = fma(Hrow[16 * b + 4 * g + k], y[16 * b + 4 * g + k], s);
     p[g] = s;
   }
   return (p[0] + p[1]) + (p[2] + p[3]);
@@ -90,7 +106,7 @@ static int dim_of(const oracle_ddp_model_t * m, int step)
   int p = m->step_phase[step];
   p = p < 0 ? 0 : (p >= m->P ? m->P - 1 : p);
   int d = m->phase_dim[p];
-  return d < 0 ? 0 : (d > M_ ? M_ : d);
+  return d < 0 ? 0 : (d > m->M ? m->M : d);
 }
 static int phase_of(const oracle_ddp_model_t * m, int step)
 {
@@ -111,13 +127,13 @@ static void ref_of(const oracle_ddp_model_t * m, int step, double * buf)
  * ridge sums as trees */
 typedef struct
 {
-  double V[M_][3], R[M_][3], cr[M_][3];
+  double V[MMAX][3], R[MMAX][3], cr[MMAX][3];
   double force[3], moment[3], accel[3];
 } terms_t;
 
 static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, const double * u, terms_t * T)
 {
-  const int dim = dim_of(m, step), ph = phase_of(m, step);
+  const int dim = dim_of(m, step), ph = phase_of(m, step), M_ = m->M;
   const double * V = m->phase_vertex + (size_t)ph * M_ * 3;
   const double * R = m->phase_ridge + (size_t)ph * M_ * 3;
   for(int r = 0; r < M_; r++)
@@ -132,13 +148,13 @@ static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, c
   }
   for(int k = 0; k < 3; k++)
   {
-    double t[M_];
+    double t[MMAX];
     for(int r = 0; r < M_; r++) t[r] = u[r] * T->R[r][k];
-    T->force[k] = tree16(t);
+    T->force[k] = treeM(t, M_);
     for(int r = 0; r < M_; r++) t[r] = u[r] * T->cr[r][k];
-    T->moment[k] = tree16(t);
+    T->moment[k] = treeM(t, M_);
     for(int r = 0; r < M_; r++) t[r] = (u[r] * T->R[r][k]) / m->mass;
-    T->accel[k] = tree16(t);
+    T->accel[k] = treeM(t, M_);
   }
 }
 
@@ -182,25 +198,25 @@ static void state_eq(const oracle_ddp_model_t * m, const terms_t * T, const doub
 /* src/DdpCentroidal.cpp:66-83 */
 static double running_cost(const oracle_ddp_model_t * m, int step, const double * x, const double * u)
 {
-  const int S = m->model == 0 ? 9 : 12;
-  double ref[12], t[M_];
+  const int S = m->model == 0 ? 9 : 12, M_ = m->M;
+  double ref[12], t[MMAX];
   ref_of(m, step, ref);
-  for(int a = 0; a < M_; a++)
+  for(int a = 0; a < 16; a++)
   {
     const double e = a < S ? x[a] - ref[a] : 0.0;
     t[a] = a < S ? 0.5 * m->w_run[a] * e * e : 0.0;
   }
   const double cx = tree16(t);
   for(int r = 0; r < M_; r++) t[r] = u[r] * u[r];
-  const double un = tree16(t);
+  const double un = treeM(t, M_);
   return cx + 0.5 * m->w_force * un;
 }
 static double terminal_cost(const oracle_ddp_model_t * m, const double * x)
 {
   const int S = m->model == 0 ? 9 : 12;
-  double ref[12], t[M_];
+  double ref[12], t[MMAX];
   ref_of(m, m->N, ref);
-  for(int a = 0; a < M_; a++)
+  for(int a = 0; a < 16; a++)
   {
     const double e = a < S ? x[a] - ref[a] : 0.0;
     t[a] = a < S ? 0.5 * m->w_term[a] * e * e : 0.0;
@@ -211,9 +227,9 @@ static double terminal_cost(const oracle_ddp_model_t * m, const double * x)
 /* Fx (S x S, dense) and the six non-zero rows of Fu (rows FU0 .. FU0+5, 16 columns):
  * src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185 with totalForce as a tree */
 static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, const double * x, double * Fx,
-                           double (*Fu)[M_])
+                           double (*Fu)[MMAX])
 {
-  const int S = m->model == 0 ? 9 : 12;
+  const int S = m->model == 0 ? 9 : 12, M_ = m->M;
   const double dt = m->dt;
   memset(Fx, 0, sizeof(double) * S * S);
   const double * tf = T->force;
@@ -288,11 +304,12 @@ static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, cons
 }
 
 /* ------------------------------------------------------------------------------------------- box QP (LDL')
- * H: 16 x 16 row-major, zero outside the leading m x m block; skip: bit i set = row / column i is clamped or unused.
- * L: 16 x 16, unit lower factor of H~ (zeros on and above the diagonal); rd: 1 / D. */
-static int factorize(const double * H, unsigned skip, double * L, double * rd)
+ * H: M x M row-major, zero outside the leading m x m block; skip: bit i set = row / column i is clamped or unused.
+ * L: M x M, unit lower factor of H~ (zeros on and above the diagonal); rd: 1 / D. */
+typedef unsigned long long mask_t;
+static int factorize(int M_, const double * H, mask_t skip, double * L, double * rd)
 {
-  double a[M_][M_];
+  double a[MMAX][MMAX];
   int ok = 1;
   for(int c = 0; c < M_; c++)
     for(int k = 0; k < M_; k++)
@@ -308,7 +325,7 @@ static int factorize(const double * H, unsigned skip, double * L, double * rd)
     const double d = a[j][j];
     if(!(d > 0.0)) ok = 0;
     const double r = 1.0 / d;
-    double col[M_];
+    double col[MMAX];
     for(int c = 0; c < M_; c++) col[c] = a[c][j];
     for(int c = 0; c < M_; c++) L[c * M_ + j] = c > j ? col[c] * r : 0.0;
     rd[j] = r;
@@ -319,42 +336,43 @@ static int factorize(const double * H, unsigned skip, double * L, double * rd)
 }
 
 /* b <- H~^-1 b (b zero on the skipped rows) */
-static void solve_ldl(const double * L, const double * rd, unsigned skip, double * b)
+static void solve_ldl(int M_, const double * L, const double * rd, mask_t skip, double * b)
 {
   for(int k = 0; k < M_; k++)
   {
     if((skip >> k) & 1u) continue;
     const double bk = b[k];
-    for(int c = 0; c < M_; c++) b[c] = fma(-L[c * M_ + k], bk, b[c]);
+    for(int c = 16 * (k / 16); c < M_; c++) b[c] = fma(-L[c * M_ + k], bk, b[c]); /* from the first ridge of k's block on */
   }
   for(int c = 0; c < M_; c++) b[c] = b[c] * rd[c];
   for(int k = M_ - 1; k >= 0; k--)
   {
     if((skip >> k) & 1u) continue;
     const double bk = b[k];
-    for(int c = 0; c < M_; c++) b[c] = fma(-L[k * M_ + c], bk, b[c]);
+    for(int c = 0; c < 16 * (k / 16) + 16; c++) b[c] = fma(-L[k * M_ + c], bk, b[c]); /* up to the last ridge of k's block */
   }
 }
 
-static double qp_value(const double * H, const double * q, const double * y)
+static double qp_value(int M_, const double * H, const double * q, const double * y)
 {
-  double t[M_];
-  for(int c = 0; c < M_; c++) t[c] = fma(0.5 * y[c], rows4(H + c * M_, y), y[c] * q[c]);
-  return tree16(t);
+  double t[MMAX];
+  for(int c = 0; c < M_; c++) t[c] = fma(0.5 * y[c], rows4(H + c * M_, y, M_), y[c] * q[c]);
+  return treeM(t, M_);
 }
 
 /* Tassa's boxQP.m with nmpc_ddp's parameters (oracle/ddp.c oracle_box_qp), in the tile arithmetic */
-static int box_qp_tile(int m, const double * H, const double * q, const double * lo, const double * hi, double * x,
-                       unsigned * skip_out, double * L, double * rd)
+static int box_qp_tile(int M_, int m, const double * H, const double * q, const double * lo, const double * hi, double * x,
+                       mask_t * skip_out, double * L, double * rd)
 {
+  const mask_t all = M_ >= 64 ? ~(mask_t)0 : (((mask_t)1 << M_) - 1u);
   const int max_iter = 500;
   const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
-  const unsigned inmask = m >= M_ ? 0xffffu : ((1u << m) - 1u);
-  int cl[M_] = {0}, oldc[M_];
-  unsigned skip = ~inmask & 0xffffu;
+  const mask_t inmask = m >= M_ ? all : (((mask_t)1 << m) - 1u);
+  int cl[MMAX] = {0}, oldc[MMAX];
+  mask_t skip = ~inmask & all;
   for(int c = 0; c < M_; c++) x[c] = c < m ? fmin(fmax(x[c], lo[c]), hi[c]) : 0.0;
   for(int c = 0; c < M_; c++) rd[c] = 1.0;
-  double value = qp_value(H, q, x), oldvalue = 0.0;
+  double value = qp_value(M_, H, q, x), oldvalue = 0.0;
   int result = 0, iter;
   for(iter = 1; iter <= max_iter; iter++)
   {
@@ -365,16 +383,16 @@ static int box_qp_tile(int m, const double * H, const double * q, const double *
       break;
     }
     oldvalue = value;
-    double grad[M_];
-    for(int c = 0; c < M_; c++) grad[c] = q[c] + rows4(H + c * M_, x);
-    unsigned clmask = 0;
+    double grad[MMAX];
+    for(int c = 0; c < M_; c++) grad[c] = q[c] + rows4(H + c * M_, x, M_);
+    mask_t clmask = 0;
     int changed = (iter == 1);
     for(int c = 0; c < M_; c++)
     {
       oldc[c] = cl[c];
       cl[c] = (c < m && ((x[c] == lo[c] && grad[c] > 0) || (x[c] == hi[c] && grad[c] < 0))) ? 1 : 0;
       if(c < m && cl[c] != oldc[c]) changed = 1;
-      if(c < m && cl[c]) clmask |= 1u << c;
+      if(c < m && cl[c]) clmask |= (mask_t)1 << c;
     }
     if(clmask == inmask)
     {
@@ -383,35 +401,35 @@ static int box_qp_tile(int m, const double * H, const double * q, const double *
     }
     if(changed)
     {
-      skip = clmask | (~inmask & 0xffffu);
-      if(!factorize(H, skip, L, rd))
+      skip = clmask | (~inmask & all);
+      if(!factorize(M_, H, skip, L, rd))
       {
         result = -1;
         break;
       }
     }
-    double t[M_];
+    double t[MMAX];
     for(int c = 0; c < M_; c++) t[c] = (c < m && !cl[c]) ? grad[c] * grad[c] : 0.0;
-    const double gn = sqrt(tree16(t));
+    const double gn = sqrt(treeM(t, M_));
     if(gn < min_grad)
     {
       result = 5;
       break;
     }
     /* grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x */
-    double xcl[M_], rhs[M_], srch[M_];
+    double xcl[MMAX], rhs[MMAX], srch[MMAX];
     for(int c = 0; c < M_; c++) xcl[c] = cl[c] ? x[c] : 0.0;
-    for(int c = 0; c < M_; c++) rhs[c] = (c < m && !cl[c]) ? q[c] + rows4(H + c * M_, xcl) : 0.0;
-    solve_ldl(L, rd, skip, rhs);
+    for(int c = 0; c < M_; c++) rhs[c] = (c < m && !cl[c]) ? q[c] + rows4(H + c * M_, xcl, M_) : 0.0;
+    solve_ldl(M_, L, rd, skip, rhs);
     for(int c = 0; c < M_; c++) srch[c] = (c < m && !cl[c]) ? -rhs[c] - x[c] : 0.0;
     for(int c = 0; c < M_; c++) t[c] = srch[c] * grad[c];
-    const double sdotg = tree16(t);
+    const double sdotg = treeM(t, M_);
     if(sdotg >= 0) break; /* no descent direction: result stays 0 */
-    double step = 1.0, vc = 0, xc[M_];
+    double step = 1.0, vc = 0, xc[MMAX];
     for(;;)
     {
       for(int c = 0; c < M_; c++) xc[c] = c < m ? fmin(fmax(x[c] + step * srch[c], lo[c]), hi[c]) : 0.0;
-      vc = qp_value(H, q, xc);
+      vc = qp_value(M_, H, q, xc);
       if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
       step *= step_dec;
       if(step < min_step)
@@ -424,10 +442,10 @@ static int box_qp_tile(int m, const double * H, const double * q, const double *
     value = vc;
   }
   if(iter > max_iter && result == 0) result = 1;
-  unsigned clmask = 0;
+  mask_t clmask = 0;
   for(int c = 0; c < m; c++)
-    if(cl[c]) clmask |= 1u << c;
-  *skip_out = clmask | (~inmask & 0xffffu);
+    if(cl[c]) clmask |= (mask_t)1 << c;
+  *skip_out = clmask | (~inmask & all);
   return result;
 }
 
@@ -447,7 +465,7 @@ static void decrease_lambda(tile_t * d)
 static int backward_pass(tile_t * d, double * gsum)
 {
   const oracle_ddp_model_t * m = d->m;
-  const int S = d->S, N = d->N, FU0 = S == 9 ? 3 : 6;
+  const int S = d->S, N = d->N, FU0 = S == 9 ? 3 : 6, M_ = m->M;
   double Vxx[144], Vx[12], ref[12];
   memset(Vxx, 0, sizeof(Vxx));
   ref_of(m, N, ref);
@@ -458,20 +476,20 @@ static int backward_pass(tile_t * d, double * gsum)
   }
   d->dV[0] = d->dV[1] = 0;
   *gsum = 0;
-  double kprev[M_] = {0};
+  double kprev[MMAX] = {0};
   int mprev = -1;
   for(int i = N - 1; i >= 0; i--)
   {
     const int dim = dim_of(m, i);
     const double * x = d->x + (size_t)i * S;
-    double u[M_];
+    double u[MMAX];
     for(int r = 0; r < M_; r++) u[r] = r < dim ? d->u[(size_t)i * M_ + r] : 0.0;
     terms_t T;
     terms_of(m, i, x, u, &T);
-    double Fx[144], Fu[6][M_];
+    double Fx[144], Fu[6][MMAX];
     state_eq_deriv(m, &T, x, Fx, Fu);
     /* Qx = Lx + Fx' Vx ; Qu = Lu + Fu' Vx */
-    double Qx[12], Qu[M_];
+    double Qx[12], Qu[MMAX];
     ref_of(m, i, ref);
     for(int a = 0; a < S; a++)
     {
@@ -486,7 +504,7 @@ static int backward_pass(tile_t * d, double * gsum)
       Qu[r] = r < dim ? s : 0.0;
     }
     /* T2 = Vxx Fu ; T1 = Vxx Fx */
-    double T2[12][M_], T1[144];
+    double T2[12][MMAX], T1[144];
     for(int a = 0; a < S; a++)
       for(int r = 0; r < M_; r++)
       {
@@ -502,7 +520,7 @@ static int backward_pass(tile_t * d, double * gsum)
         T1[a * S + b2] = s;
       }
     /* Quu = Luu + Fu' T2 (H: unregularised, HF: lambda on the diagonal, both zero outside dim x dim) */
-    double H[M_ * M_], HF[M_ * M_];
+    double H[MMAX * MMAX], HF[MMAX * MMAX];
     for(int r = 0; r < M_; r++)
       for(int q = 0; q < M_; q++)
       {
@@ -513,7 +531,7 @@ static int backward_pass(tile_t * d, double * gsum)
         HF[r * M_ + q] = (live && r == q) ? s + d->lambda : H[r * M_ + q];
       }
     /* Qxu = Fx' T2 ; Qxx = Lxx + Fx' T1 */
-    double Qxu[12][M_], Qxx[144];
+    double Qxu[12][MMAX], Qxx[144];
     for(int a = 0; a < S; a++)
       for(int r = 0; r < M_; r++)
       {
@@ -529,26 +547,26 @@ static int backward_pass(tile_t * d, double * gsum)
         Qxx[a * S + b2] = s;
       }
     /* box-QP and gains */
-    double k[M_] = {0}, K[M_][12];
+    double k[MMAX] = {0}, K[MMAX][12];
     memset(K, 0, sizeof(K));
     if(dim > 0)
     {
-      double lo[M_], hi[M_], L[M_ * M_], rd[M_];
+      double lo[MMAX], hi[MMAX], L[MMAX * MMAX], rd[MMAX];
       for(int r = 0; r < M_; r++)
       {
         lo[r] = r < dim ? m->force_lo - u[r] : 0.0;
         hi[r] = r < dim ? m->force_hi - u[r] : 0.0;
         k[r] = (mprev == dim) ? kprev[r] : 0.0; /* warm start: step i + 1 of this pass */
       }
-      unsigned skip;
-      const int rc = box_qp_tile(dim, HF, Qu, lo, hi, k, &skip, L, rd);
+      mask_t skip;
+      const int rc = box_qp_tile(M_, dim, HF, Qu, lo, hi, k, &skip, L, rd);
       if(rc < 1) return 0;
       /* K_f = -H_ff^-1 Qxu_f' */
       for(int a = 0; a < S; a++)
       {
-        double rhs[M_];
+        double rhs[MMAX];
         for(int r = 0; r < M_; r++) rhs[r] = ((skip >> r) & 1u) ? 0.0 : Qxu[a][r];
-        solve_ldl(L, rd, skip, rhs);
+        solve_ldl(M_, L, rd, skip, rhs);
         for(int r = 0; r < M_; r++) K[r][a] = ((skip >> r) & 1u) ? 0.0 : -rhs[r];
       }
     }
@@ -563,25 +581,25 @@ static int backward_pass(tile_t * d, double * gsum)
       *gsum += mx;
     }
     /* dV, Vx, Vxx */
-    double t4[M_], t[M_];
-    for(int r = 0; r < M_; r++) t4[r] = rows4(H + r * M_, k);
+    double t4[MMAX], t[MMAX];
+    for(int r = 0; r < M_; r++) t4[r] = rows4(H + r * M_, k, M_);
     for(int r = 0; r < M_; r++) t[r] = k[r] * Qu[r];
-    d->dV[0] += tree16(t);
+    d->dV[0] += treeM(t, M_);
     for(int r = 0; r < M_; r++) t[r] = k[r] * t4[r];
-    d->dV[1] += 0.5 * tree16(t);
+    d->dV[1] += 0.5 * treeM(t, M_);
     double vxn[12];
     for(int a = 0; a < S; a++)
     {
       for(int r = 0; r < M_; r++) t[r] = fma(Qxu[a][r], k[r], K[r][a] * (t4[r] + Qu[r]));
-      vxn[a] = Qx[a] + tree16(t);
+      vxn[a] = Qx[a] + treeM(t, M_);
     }
     /* Z = Quu K + 2 Qux */
-    double Z[M_][12];
+    double Z[MMAX][12];
     for(int a = 0; a < S; a++)
     {
-      double col[M_];
+      double col[MMAX];
       for(int r = 0; r < M_; r++) col[r] = K[r][a];
-      for(int r = 0; r < M_; r++) Z[r][a] = rows4(H + r * M_, col) + 2.0 * Qxu[a][r];
+      for(int r = 0; r < M_; r++) Z[r][a] = rows4(H + r * M_, col, M_) + 2.0 * Qxu[a][r];
     }
     for(int a = 0; a < S; a++)
       for(int b = a; b < S; b++)
@@ -607,7 +625,7 @@ static int backward_pass(tile_t * d, double * gsum)
 static double forward_pass(tile_t * d, double alpha, int q)
 {
   const oracle_ddp_model_t * m = d->m;
-  const int S = d->S, N = d->N;
+  const int S = d->S, N = d->N, M_ = m->M;
   double * xc = d->xc[q], * uc = d->uc[q];
   memcpy(xc, d->x, sizeof(double) * S);
   double cost = 0;
@@ -636,8 +654,8 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
 {
   tile_t d;
   memset(&d, 0, sizeof(d));
-  const int S = m->model == 0 ? 9 : 12, N = m->N;
-  if(m->M != M_ || c->reg_type != 1 || !c->with_input_constraint) return -100; /* not in this arithmetic */
+  const int S = m->model == 0 ? 9 : 12, N = m->N, M_ = m->M;
+  if((M_ != 16 && M_ != 32 && M_ != 64) || c->reg_type != 1 || !c->with_input_constraint) return -100; /* not in this arithmetic */
   d.m = m;
   d.c = c;
   d.S = S;

@@ -1,8 +1,7 @@
 // ddp_emu.cpp -- TEST AID: compiles the product's wavefront DDP code (csrc/ddp_core.h) for the host, where the 64
 // lanes of a phase run one after the other.  Lets the CPU test-suite check the phase logic of the HIP kernel against
 // the oracle without a GPU.  Never linked into, imported by or shipped with the product.
-// Built twice by tests/test_ddp_emu.py: as is (the phase versions with the fast build's LDS tables) and with
-// -DCCC_DDP_WIDE (the wide build: up to 32 ridges per step, contact tables in global memory, any number of phases).
+// (The row-per-lane solver in the left-to-right arithmetic; the default kernel's emulation is ddp_tile_emu.cpp.)
 #include "../../centroidalcontrolcollection_amd/csrc/ddp_core.h"
 
 #include <cstdint>
@@ -16,7 +15,7 @@ extern "C" int ccc_ddp_emu_plan_batch(const Params * P, long n, int M, const int
                                        const double * u_init, double * u_out, double * x_out, int * iters, int * status,
                                        double * cost)
 {
-  if(M != 16 && M != 32) return 1;
+  if(M != 16) return 1;
   const int S = P->model == 0 ? 9 : 12, N = P->N, Pn = P->P;
   std::vector<double> xc((size_t)(N + 1) * S), uc((size_t)N * M), ks((size_t)N * M), Ks((size_t)N * M * S),
       xs((size_t)(N + 1) * S);
@@ -43,25 +42,15 @@ extern "C" int ccc_ddp_emu_plan_batch(const Params * P, long n, int M, const int
     I.out_cost = cost ? cost + b : nullptr;
     std::fill(ks.begin(), ks.end(), 0.0);
     std::fill(Ks.begin(), Ks.end(), 0.0);
-    if(P->model == 0 && M == 16)
+    if(P->model == 0)
     {
       static Mem<9, 16> mem;
       Solver<9, 16>(*P, I, mem).solve();
     }
-    else if(P->model == 0)
-    {
-      static Mem<9, 32> mem;
-      Solver<9, 32>(*P, I, mem).solve();
-    }
-    else if(M == 16)
+    else
     {
       static Mem<12, 16> mem;
       Solver<12, 16>(*P, I, mem).solve();
-    }
-    else
-    {
-      static Mem<12, 32> mem;
-      Solver<12, 32>(*P, I, mem).solve();
     }
   }
   return 0;

@@ -10,26 +10,30 @@
 using namespace ccc_amd;
 using ccc_amd::ddp_common::Params;
 
-template<int S>
+template<int S, int B>
 static void run_one(const Params & P, const ddp_tile::Instance & I)
 {
-  static ddp_tile::Mem<S> mem;
-  ddp_tile::Solver<S> solver(P, I, mem);
+  static ddp_tile::Mem<S, B> mem;
+  ddp_tile::Solver<S, B> solver(P, I, mem);
   solver.solve_instance();
 }
 
-extern "C" int ccc_ddp_tile_emu_lds_bytes(int S)
+extern "C" int ccc_ddp_tile_emu_lds_bytes(int S, int M)
 {
-  return S == 9 ? (int)sizeof(ddp_tile::Mem<9>) : (int)sizeof(ddp_tile::Mem<12>);
+  if(M == 16) return S == 9 ? (int)sizeof(ddp_tile::Mem<9, 1>) : (int)sizeof(ddp_tile::Mem<12, 1>);
+  if(M == 32) return S == 9 ? (int)sizeof(ddp_tile::Mem<9, 2>) : (int)sizeof(ddp_tile::Mem<12, 2>);
+  if(M == 64) return S == 9 ? (int)sizeof(ddp_tile::Mem<9, 4>) : (int)sizeof(ddp_tile::Mem<12, 4>);
+  return -1;
 }
 
-extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, long n, const int * phase_dim, const double * phase_vertex,
+extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, int M, long n, const int * phase_dim, const double * phase_vertex,
                                             const double * phase_ridge, const int * step_phase, const double * ref_pos,
                                             const double * ref_ori, const double * inertia, const double * x0,
                                             const double * u_init, double * u_out, double * x_out, int * iters,
                                             int * status, double * cost)
 {
-  const int S = P->model == 0 ? 9 : 12, N = P->N, Pn = P->P, M = ddp_tile::kM;
+  const int S = P->model == 0 ? 9 : 12, N = P->N, Pn = P->P;
+  if(M != 16 && M != 32 && M != 64) return -1;
   std::vector<double> xbuf((size_t)ddp_tile::kSlots * (N + 1) * S), ubuf((size_t)ddp_tile::kSlots * N * M),
       ks((size_t)N * M), Ks((size_t)N * M * S);
   for(long b = 0; b < n; b++)
@@ -53,10 +57,12 @@ extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, long n, const int *
     I.out_iters = iters ? iters + b : nullptr;
     I.out_status = status ? status + b : nullptr;
     I.out_cost = cost ? cost + b : nullptr;
-    if(S == 9)
-      run_one<9>(*P, I);
-    else
-      run_one<12>(*P, I);
+    if(S == 9 && M == 16) run_one<9, 1>(*P, I);
+    else if(S == 12 && M == 16) run_one<12, 1>(*P, I);
+    else if(S == 9 && M == 32) run_one<9, 2>(*P, I);
+    else if(S == 12 && M == 32) run_one<12, 2>(*P, I);
+    else if(S == 9) run_one<9, 4>(*P, I);
+    else run_one<12, 4>(*P, I);
   }
   return 0;
 }

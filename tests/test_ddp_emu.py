@@ -26,27 +26,23 @@ class Params(ctypes.Structure):
                 ("cost_thre", ctypes.c_double), ("alpha", ctypes.c_double * 11), ("reg_type", ctypes.c_int)]
 
 
-def _build(wide):
-    so = os.path.join(ROOT, "tests", "emu", "libddp_emu_wide.so" if wide else "libddp_emu.so")
+def _build():
+    so = os.path.join(ROOT, "tests", "emu", "libddp_emu.so")
     src = os.path.join(ROOT, "tests", "emu", "ddp_emu.cpp")
     hdr = os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", "ddp_core.h")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off"]
-                              + (["-DCCC_DDP_WIDE"] if wide else []) + ["-o", so, src])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     return ctypes.CDLL(so)
 
 
-@pytest.fixture(scope="module", params=["fast-tables", "wide"])
-def emu(request):
-    """The phase versions of csrc/ddp_core.h compiled for the host, in both table layouts: "fast-tables" = the LDS
-    tables of the fast build (<= 16 ridges, <= 4 phases), "wide" = the build csrc/ddp_wide.hip runs on the GPU."""
-    wide = request.param == "wide"
-    L = _build(wide)
+@pytest.fixture(scope="module")
+def emu():
+    """The phase versions of csrc/ddp_core.h (the row-per-lane solver: <= 16 ridges, <= 4 phases) compiled for the host."""
+    L = _build()
 
     def run(model, N, dt, w, prob, x0, max_iter, u_init=None):
         M = prob["phase_vertex"].shape[2]
-        if not wide and (M != 16 or prob["phase_dim"].shape[1] > 4):
-            pytest.skip("beyond the fast build's tables")
+        assert M == 16 and prob["phase_dim"].shape[1] <= 4
         P = Params()
         P.model, P.N, P.P, P.mass, P.dt = model, N, prob["phase_dim"].shape[1], 100.0, dt
         S = 9 if model == 0 else 12
@@ -105,17 +101,3 @@ def test_warm_start_path_matches_oracle(emu):
     assert np.array_equal(e["u"], o["u"])
 
 
-@pytest.mark.parametrize("model,max_iter", [(0, 1), (0, 30), (1, 1), (1, 15)])
-def test_double_support_and_many_phases_match_oracle_exactly(emu, model, max_iter):
-    """Walking sequences with 32-ridge double-support steps, 16-ridge single support, flight, and 8-10 contact phases
-    per horizon (src/DdpCentroidal.cpp:49-60: arbitrary contact lists): the wide build's logic against the oracle."""
-    N, dt = 40, 0.05
-    w = fd.srb_weights() if model else fd.centroidal_weights()
-    prob, x0 = fd.make_walking_batch(5, N, dt, seed=21, srb=bool(model))
-    assert prob["phase_dim"].max() == 32 and prob["phase_dim"].shape[1] > 4
-    e = emu(model, N, dt, w, prob, x0, max_iter)
-    P, M = prob["phase_dim"].shape[1], 32
-    o = oracle.Ddp(model, 100.0, dt, N, w, max_iter=max_iter, P=P, M=M).plan_batch(prob, x0)
-    assert np.array_equal(e["iters"], o["iters"]) and np.array_equal(e["status"], o["status"])
-    assert np.array_equal(e["u"], o["u"]) and np.array_equal(e["x"], o["x"]) and np.array_equal(e["cost"], o["cost"])
-    assert np.all(o["status"] >= 0)

@@ -353,12 +353,13 @@ def test_cpp_header_shims_match_python_mirror():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Contact lists beyond one surface contact / four phases: the wide kernel (csrc/ddp_wide.hip)
+# Contact lists beyond one surface contact / four phases: the tile kernel with two / four blocks of 16 ridges
+# (csrc/ddp_tile.h)
 @pytest.mark.parametrize("srb,max_iter", [(False, 1), (False, 30), (True, 1), (True, 15)])
 def test_double_support_walking_sequences_match_the_oracle_bit_for_bit(srb, max_iter):
     """src/DdpCentroidal.cpp:49-60 / src/DdpSingleRigidBody.cpp:74-85 iterate arbitrary contact lists: walking
     sequences with 32-ridge double-support steps (two surface contacts), 16-ridge single support, flight, and 8-10
-    distinct contact phases inside one horizon.  max_ridges = 32 selects the wide kernel; same bar as the fast one."""
+    distinct contact phases inside one horizon.  max_ridges = 32; same bar as at 16 ridges."""
     N, dt, n = 40, 0.05, 96
     prob, x0 = fd.make_walking_batch(n, N, dt, seed=33, srb=srb)
     P = prob["phase_dim"].shape[1]
@@ -373,8 +374,9 @@ def test_double_support_walking_sequences_match_the_oracle_bit_for_bit(srb, max_
         d = DdpCentroidal(100.0, dt, N, w, max_phases=P, max_ridges=32)
         wo = fd.centroidal_weights()
     d.ddp_solver_.config().max_iter = max_iter
+    assert d.arithmetic() == 1
     r = d.planOnceBatch(prob, x0, want_x=True)
-    o = _oracle().Ddp(int(srb), 100.0, dt, N, wo, max_iter=max_iter, P=P, M=32).plan_batch(prob, x0, nthreads=16)
+    o = _oracle().Ddp(int(srb), 100.0, dt, N, wo, max_iter=max_iter, P=P, M=32, arith=d.arithmetic()).plan_batch(prob, x0, nthreads=16)
     assert np.all(o["status"] >= 0)
     assert np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["status"], o["status"])
     assert np.array_equal(r["u"], o["u"]) and np.array_equal(r["x"], o["x"]) and np.array_equal(r["cost"], o["cost"])
@@ -384,10 +386,65 @@ def test_double_support_walking_sequences_match_the_oracle_bit_for_bit(srb, max_
     assert ds.any() and (r["u"][ds][:, :16].sum(axis=1) > 1.0).mean() > 0.5 and (r["u"][ds][:, 16:].sum(axis=1) > 1.0).mean() > 0.5
 
 
-def test_many_phases_of_single_contacts_route_to_the_wide_kernel_and_agree_with_the_fast_one():
-    """More than four contact phases with 16-ridge contacts (max_ridges stays 16): the wide kernel's <9|12, 16>
-    instantiation.  The same problems with the phase table compacted to the four phases the fast kernel holds give
-    the identical plan -- the two kernels are interchangeable where both apply."""
+@pytest.mark.parametrize("srb,max_iter", [(False, 2), (False, 25), (True, 2), (True, 12)])
+def test_multi_contact_sequences_match_the_oracle_bit_for_bit(srb, max_iter):
+    """More than two surface contacts per step (feet + hands on walls: 48 and 64 ridges):
+    max_ridges = 64, the tile kernel with four blocks of 16 ridges, against the specification -- and the plan uses the
+    hands (force on the ridges of the third and fourth contact)."""
+    N, dt, n = 30, 0.05, 64
+    prob, x0 = fd.make_multicontact_batch(n, N, dt, seed=3, srb=srb)
+    assert set(np.unique(prob["phase_dim"])) >= {48, 64}
+    if srb:
+        w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3,
+                                           terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3)
+        d = DdpSingleRigidBody(100.0, dt, N, w, max_phases=6, max_ridges=64)
+        wo = fd.srb_weights()
+    else:
+        w = DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0))
+        d = DdpCentroidal(100.0, dt, N, w, max_phases=6, max_ridges=64)
+        wo = fd.centroidal_weights()
+    d.ddp_solver_.config().max_iter = max_iter
+    assert d.arithmetic() == 1
+    r = d.planOnceBatch(prob, x0, want_x=True)
+    o = _oracle().Ddp(int(srb), 100.0, dt, N, wo, max_iter=max_iter, P=6, M=64, arith=1).plan_batch(prob, x0, nthreads=16)
+    assert np.all(o["status"] >= 0)
+    for k in ("iters", "status", "u", "x", "cost"):
+        assert np.array_equal(r[k], o[k]), k
+    dims = np.take_along_axis(prob["phase_dim"], prob["step_phase"], axis=1)
+    four = dims == 64
+    assert four.any() and (r["u"][four][:, 32:48].sum(axis=1) > 1.0).mean() > 0.3 and (r["u"][four][:, 48:].sum(axis=1) > 1.0).mean() > 0.3
+    if max_iter > 10:  # the converged plans are feasible and better than doing nothing
+        assert np.all(r["u"] >= 0.0) and np.all(r["u"] <= 1e6)
+
+
+def test_a_problem_gives_the_same_plan_at_every_ridge_stride_that_holds_it():
+    """16-ridge problems through handles with max_ridges 16, 32 and 64 (what the shims do when another horizon needs a
+    wider table): identical bits -- the extra blocks are exact zeros in every sum of the tile arithmetic."""
+    N, dt, n = 60, 0.03, 48
+    prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=17)
+    w = DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0))
+    ref = None
+    for M in (16, 32, 64):
+        d = DdpCentroidal(100.0, dt, N, w, max_ridges=M)
+        d.ddp_solver_.config().max_iter = 15
+        wide = dict(prob)
+        for key in ("phase_vertex", "phase_ridge"):
+            a = np.zeros(prob[key].shape[:2] + (M, 3))
+            a[:, :, :16] = prob[key]
+            wide[key] = a
+        r = d.planOnceBatch(wide, x0, want_x=True)
+        if ref is None:
+            ref = r
+        else:
+            assert np.array_equal(r["u"][:, :, :16], ref["u"]) and np.all(r["u"][:, :, 16:] == 0.0)
+            assert np.array_equal(r["x"], ref["x"]) and np.array_equal(r["cost"], ref["cost"])
+            assert np.array_equal(r["iters"], ref["iters"])
+
+
+def test_unused_entries_of_the_phase_table_do_not_change_the_plan():
+    """More than four contact phases with 16-ridge contacts (max_ridges stays 16; the tile kernel reads its phase tables
+    from global memory: any number of phases).  The same problems with the used phases spread over a 7-entry table give
+    the identical plan."""
     N, dt, n = 100, 0.03, 64
     prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=8)
     fast = _cen(N, dt, 12).planOnceBatch(prob, x0, want_x=True)
@@ -410,7 +467,7 @@ def test_many_phases_of_single_contacts_route_to_the_wide_kernel_and_agree_with_
 
 
 def test_wide_limits_are_reported():
-    """max_ridges other than 16 / 32 and precision 32 on a wide handle: CCC_ERR_UNSUPPORTED, as documented."""
+    """max_ridges other than 16 / 32 / 64 and precision 32 on a wide handle: CCC_ERR_UNSUPPORTED, as documented."""
     from centroidalcontrolcollection_amd import _lib
 
     w = DdpCentroidal.WeightParam()

@@ -43,10 +43,11 @@ def emu():
         arr = [c(prob["phase_dim"], np.int32), c(prob["phase_vertex"]), c(prob["phase_ridge"]),
                c(prob["step_phase"], np.int32), c(prob["ref_pos"]), c(prob["ref_ori"]) if model == 1 else None,
                c(prob["inertia"]) if model == 1 else None, c(x0), None if u_init is None else c(u_init)]
-        u, x = np.zeros((n, N, 16)), np.zeros((n, N + 1, S))
+        M = prob["phase_vertex"].shape[2]
+        u, x = np.zeros((n, N, M)), np.zeros((n, N + 1, S))
         it, st, cost = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n)
         p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)  # noqa: E731
-        rc = L.ccc_ddp_tile_emu_plan_batch(ctypes.byref(P), ctypes.c_long(n), *[p(a) for a in arr], p(u), p(x), p(it),
+        rc = L.ccc_ddp_tile_emu_plan_batch(ctypes.byref(P), ctypes.c_int(M), ctypes.c_long(n), *[p(a) for a in arr], p(u), p(x), p(it),
                                            p(st), p(cost))
         assert rc == 0
         return dict(u=u, x=x, iters=it, status=st, cost=cost)
@@ -55,8 +56,8 @@ def emu():
     return run
 
 
-def _ora(model, N, dt, w, max_iter, arith, P=4):
-    return oracle.Ddp(model, 100.0, dt, N, w, max_iter=max_iter, arith=arith, P=P)
+def _ora(model, N, dt, w, max_iter, arith, P=4, M=16):
+    return oracle.Ddp(model, 100.0, dt, N, w, max_iter=max_iter, arith=arith, P=P, M=M)
 
 
 def _same(a, b):
@@ -66,7 +67,10 @@ def _same(a, b):
 
 def test_lds_footprint_allows_sixteen_wavefronts_per_cu(emu):
     """160 KB of LDS per CU / 16 wavefronts = 10240 B: what four wavefronts per SIMD need."""
-    assert emu.lds_bytes(9) <= 10240 and emu.lds_bytes(12) <= 10240
+    assert emu.lds_bytes(9, 16) <= 10240 and emu.lds_bytes(12, 16) <= 10240
+    # 32 ridges: two wavefronts per SIMD (eight per CU); 64 ridges: three wavefronts per CU
+    assert emu.lds_bytes(9, 32) <= 20480 and emu.lds_bytes(12, 32) <= 20480
+    assert emu.lds_bytes(9, 64) <= 54613 and emu.lds_bytes(12, 64) <= 54613
 
 
 @pytest.mark.parametrize("model,N,max_iter", [(0, 100, 3), (0, 60, 500), (1, 50, 3), (1, 50, 500)])
@@ -115,3 +119,60 @@ def test_the_two_arithmetics_are_the_same_algorithm_up_to_rounding(model, N):
     assert rel[same_path].max() <= 1e-12
     assert np.abs(r0["u"] - r1["u"])[same_path].max() <= 1e-4  # (flat directions: held by the 1e-6 force weight only)
     assert np.all(r1["status"] >= 1)
+
+
+@pytest.mark.parametrize("model,max_iter", [(0, 4), (1, 4), (0, 200)])
+def test_double_support_walking_32_ridges_bit_for_bit(emu, model, max_iter):
+    """M = 32 (two surface contacts per step): the kernel's two blocks of 16 ridges against the specification's treeM /
+    rows4 / block-wise substitutions, on walking sequences with 0-, 16- and 32-ridge steps and 6-10 contact phases."""
+    N, dt = 40, 0.05
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_walking_batch(5, N, dt, seed=77, srb=bool(model))
+    P = prob["phase_dim"].shape[1]
+    assert prob["phase_dim"].max() == 32
+    _same(emu(model, N, dt, w, prob, x0, max_iter), _ora(model, N, dt, w, max_iter, 1, P=P, M=32).plan_batch(prob, x0, nthreads=8))
+
+
+@pytest.mark.parametrize("model,max_iter", [(0, 3), (1, 3), (0, 100)])
+def test_multi_contact_64_ridges_bit_for_bit(emu, model, max_iter):
+    """M = 64: feet + hands (src/DdpCentroidal.cpp:49-60 takes any contact_list) -- steps with 16, 32, 48 and 64 ridges."""
+    N, dt = 30, 0.05
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_multicontact_batch(4, N, dt, seed=13, srb=bool(model))
+    assert set(np.unique(prob["phase_dim"])) >= {32, 48, 64}
+    r = emu(model, N, dt, w, prob, x0, max_iter)
+    _same(r, _ora(model, N, dt, w, max_iter, 1, P=6, M=64).plan_batch(prob, x0, nthreads=8))
+    assert np.all(r["status"] >= 0)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_ridge_stride_does_not_change_the_answer(model):
+    """A 16-ridge problem embedded in 32- and 64-ridge tables (what the shims do when another step of the horizon has more
+    contacts): the extra blocks are exact zeros in every sum, so the specification returns the same bits."""
+    N, dt = 40, 0.03
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(6, N, dt, seed=21, srb=bool(model))
+    r16 = _ora(model, N, dt, w, 50, 1).plan_batch(prob, x0)
+    for M in (32, 64):
+        wide = dict(prob)
+        for key in ("phase_vertex", "phase_ridge"):
+            a = np.zeros(prob[key].shape[:2] + (M, 3))
+            a[:, :, :16] = prob[key]
+            wide[key] = a
+        rM = _ora(model, N, dt, w, 50, 1, M=M).plan_batch(wide, x0)
+        assert np.array_equal(rM["u"][:, :, :16], r16["u"]) and np.all(rM["u"][:, :, 16:] == 0.0)
+        assert np.array_equal(rM["cost"], r16["cost"]) and np.array_equal(rM["iters"], r16["iters"])
+
+
+def test_tile_arithmetic_matches_left_to_right_on_wide_problems():
+    """arith 0 against arith 1 at 32 and 64 ridges, run to convergence: the same algorithm up to rounding."""
+    w = fd.centroidal_weights()
+    for M, (prob, x0), N, dt in ((32, fd.make_walking_batch(12, 40, 0.05, seed=5), 40, 0.05),
+                                 (64, fd.make_multicontact_batch(8, 30, 0.05, seed=5), 30, 0.05)):
+        P = prob["phase_dim"].shape[1]
+        r0 = _ora(0, N, dt, w, 500, 0, P=P, M=M).plan_batch(prob, x0, nthreads=8)
+        r1 = _ora(0, N, dt, w, 500, 1, P=P, M=M).plan_batch(prob, x0, nthreads=8)
+        ok = (r0["status"] >= 1) & (r1["status"] >= 1)
+        assert ok.mean() >= 0.9
+        rel = np.abs(r0["cost"] - r1["cost"]) / np.abs(r0["cost"])
+        assert rel[ok].max() <= 1e-8, rel

@@ -18,10 +18,11 @@ def _oracle():
     return oracle
 
 
-@pytest.mark.parametrize("T,dt,n", [(2.0, 0.02, 192), (1.0, 0.05, 128), (2.5, 0.02, 64)])
+@pytest.mark.parametrize("T,dt,n", [(2.0, 0.02, 192), (1.0, 0.05, 128), (2.5, 0.02, 64), (3.0, 0.02, 48), (3.82, 0.02, 32)])
 def test_parity_with_oracle(T, dt, n):
     """N = 100 is the reference test's horizon (TestIntrinsicallyStableMpc.cpp:17-18); N = 20 and N = 125 cover a
-    short horizon and (almost) the largest one the LDS-resident tableau holds."""
+    short horizon and (almost) the largest one the tridiagonal kernel takes; N = 150 and N = 191 (the largest one built)
+    run the packed LDS tableau alone (160 / 192 rows)."""
     o = _oracle().IntrinsicallyStableMpc(1.0, T, dt)
     N = o.horizon_steps
     b = fx.make_ism_batch(n, N, dt, seed=5)
@@ -37,6 +38,14 @@ def test_parity_with_oracle(T, dt, n):
     P = dt * np.tril(np.ones((N, N)))
     z = b["init"][:, :, 1, None] + np.einsum("ij,kaj->kai", P, r["vel"])
     assert (b["ref"][:, :, 1] - z).max() <= 1e-9 and (z - b["ref"][:, :, 2]).max() <= 1e-9
+
+
+def test_horizon_limit_is_reported():
+    from centroidalcontrolcollection_amd._lib import CccError
+
+    assert IntrinsicallyStableMpc(1.0, 3.82, 0.02).horizon_steps_ == 191
+    with pytest.raises(CccError):
+        IntrinsicallyStableMpc(1.0, 3.84, 0.02)  # 192 steps
 
 
 def test_non_default_weights_and_control_dt():
