@@ -667,8 +667,8 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 // violation of a free variable, or wrong-sign multiplier of a clamped one, on a common force scale) changes sides.  That
 // is a principal pivoting method with the largest-violation rule on the strictly convex QP; it took 150-210 sweeps on
 // the instances that cycle (prototype on the bench data: all converged, same answers) where the block update needs ~7.
-// The kernel is a template on the ridge slots per step: 16 (one surface contact) or 32 (two: double support,
-// src/LinearMpcXY.cpp:69-82 iterates the whole contact_list); the horizon length is a run-time value.
+// The kernel is a template on the ridge slots per step: 16 (one surface contact), 32 (two: double support) or 64 (up to
+// four: feet and hands; src/LinearMpcXY.cpp:69-82 iterates the whole contact_list); the horizon length is a run-time value.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kXsMaxIt = 16;
 // fields of a stage in the workspace: feedback E (36), f (6), P~ (upper triangle, 21), p~ (6); the clamped set's sums
@@ -677,13 +677,22 @@ constexpr int kXsMaxIt = 16;
 constexpr int kXsE = 0, kXsF = 36, kXsPt = 42, kXsPv = 63, kXsT = 69, kXsAl = 75, kXsDp = 76, kXsDim = 77, kXsFz = 78,
               kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsSt2 = 113, // (ridges 0-15 / 16-31: each exact in a double)
               kXsPin = 114, // (6) the linear term of the value function ENTERING the stage, beside its matrix in kXsPt
-              kXsFields = 120; // (120 + 16 x 8 fields x 512 B: stages start on 4 KB boundaries)
+              kXsFields = 120, // (120 + 16 x 8 fields x 512 B: stages start on 4 KB boundaries)
+              kXsSt3 = 120, kXsSt4 = 121, // (64 ridge slots only: ridges 32-47 / 48-63)
+              kXsFields64 = 128;
+// fields of a stage before its ridge vectors, and 64-bit words of a saved clamped set, by ridge slots per step
+constexpr int xs_fields(int M) { return M > 32 ? kXsFields64 : kXsFields; }
+constexpr int xs_st_words(int M) { return M > 32 ? 2 : 1; }
+// the clamped set of a stage: 2 bits per ridge
+template<int M> struct XsBits { using type = unsigned long long; };
+template<> struct XsBits<16> { using type = unsigned; };
+template<> struct XsBits<64> { using type = unsigned __int128; };
 
 struct XyWork
 {
   double * ws;         // [N][kXsFields][n]
   double * rb;         // [N][16][7][n]: impulse vector (6) and rho_z of every ridge
-  unsigned long long * st; // [N][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
+  unsigned long long * st; // [N][words][n]: 2 bits per ridge (0 free, 1 at the lower bound, 2 at the upper bound)
   int * redo_list;     // [n]
   int * redo_count;    // [1]
   size_t ws_stride, rb_stride; // doubles from one wavefront's region to the next
@@ -768,9 +777,10 @@ constexpr int kXsLanes = 64; // instances per wavefront
 template<int M, bool SINGLE>
 __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int it_begin, int max_it)
 {
-  static_assert(M == 16 || M == 32, "ridge slots per step");
-  constexpr int kXsStage = kXsFields + M * 8; // fields of a stage + M ridges x (7 + 1 pad)
-  using Bits = typename std::conditional<M == 16, unsigned, unsigned long long>::type; // 2 bits per ridge
+  static_assert(M == 16 || M == 32 || M == 64, "ridge slots per step");
+  constexpr int kF = xs_fields(M), kStW = xs_st_words(M);
+  constexpr int kXsStage = kF + M * 8; // fields of a stage + M ridges x (7 + 1 pad)
+  using Bits = typename XsBits<M>::type; // 2 bits per ridge
   const long slot = (long)blockIdx.x * kXsLanes + threadIdx.x;
   if(slot >= (W.in_list ? (long)*W.in_count : n)) return;
   const long b = W.in_list ? (long)W.in_list[slot] : slot;
@@ -786,13 +796,40 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     return W.ws[blk * W.ws_stride + (size_t)((s * kXsStage + (g & ~1)) * kXsLanes) + ln * 2 + (g & 1)];
   };
   auto WS = [&](int s, int f) -> double & { return FLD(s, f); };
-  auto RB = [&](int s, int r, int f) -> double & { return FLD(s, kXsFields + r * 8 + f); };
+  auto RB = [&](int s, int r, int f) -> double & { return FLD(s, kF + r * 8 + f); };
+  // the clamped set of a stage in the workspace: 32 bits (16 ridges) per field, each exact in a double
+  auto load_bits = [&](int s) -> Bits {
+    Bits bits = (Bits)(unsigned)WS(s, kXsSt);
+    if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+    if constexpr(M > 32) bits |= ((Bits)(unsigned)WS(s, kXsSt3) << 64) | ((Bits)(unsigned)WS(s, kXsSt4) << 96);
+    return bits;
+  };
+  auto store_bits = [&](int s, Bits bits) {
+    WS(s, kXsSt) = (double)(unsigned)bits;
+    if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
+    if constexpr(M > 32)
+    {
+      WS(s, kXsSt3) = (double)(unsigned)(bits >> 64);
+      WS(s, kXsSt4) = (double)(unsigned)(bits >> 96);
+    }
+  };
+  // ... and in the list of saved sets (instances handed from round to round)
+  auto saved_bits = [&](int s) -> Bits {
+    Bits bits = (Bits)W.st[((size_t)s * kStW) * W.st_stride + b];
+    if constexpr(M > 32) bits |= (Bits)W.st[((size_t)s * kStW + 1) * W.st_stride + b] << 64;
+    return bits;
+  };
+  auto fold = [](Bits bits) -> unsigned long long {
+    if constexpr(M > 32)
+      return (unsigned long long)bits ^ ((unsigned long long)(bits >> 64) * 0x9e3779b97f4a7c15ull);
+    else
+      return (unsigned long long)bits;
+  };
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    const Bits bits0 = W.in_list ? (Bits)W.st[(size_t)s * W.st_stride + b] : Bits(0); // (a resumed instance: the set it had)
-    WS(s, kXsSt) = (double)(unsigned)bits0;
-    if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits0 >> 32);
+    const Bits bits0 = W.in_list ? saved_bits(s) : Bits(0); // (a resumed instance: the set it had)
+    store_bits(s, bits0);
     const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..M: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
     const double cz = B.com_z[b * N + s], kap = fz0 / P.mass;
@@ -846,8 +883,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // the stage are rebuilt
   auto apply_change = [&](int s, int r, unsigned ns, int r2, unsigned ns2, int forced) -> Bits {
     const int m = (int)WS(s, kXsDim);
-    Bits bits = (Bits)(unsigned)WS(s, kXsSt);
-    if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+    Bits bits = load_bits(s);
     bits = (bits & ~(Bits(3) << (2 * r))) | ((Bits)ns << (2 * r));
     if(r2 >= 0) bits = (bits & ~(Bits(3) << (2 * r2))) | ((Bits)ns2 << (2 * r2));
     if(forced >= 0) bits &= ~(Bits(3) << (2 * forced));
@@ -874,8 +910,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     }
     WS(s, kXsAl) = nal;
     WS(s, kXsDp) = ndp;
-    WS(s, kXsSt) = (double)(unsigned)bits;
-    if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(bits >> 32);
+    store_bits(s, bits);
     return bits;
   };
   unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0; // hashes of the clamped sets of the last iterations
@@ -1128,8 +1163,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         }
         const double alpha = WS(s, kXsAl), dprime = WS(s, kXsDp);
         const double nu = alpha > 0.0 ? -(wf * dprime + tpi) / alpha : 0.0;
-        Bits bits = (Bits)(unsigned)WS(s, kXsSt); // (2 bits per ridge, 16 ridges exact in a double)
-        if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
+        const Bits bits = load_bits(s);
         Bits nb = bits;
         bool anyfree = false;
         const double fz = WS(s, kXsFz);
@@ -1277,7 +1311,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             changed = true;
             smax_new = s;
           }
-          hh = (hh ^ now) * 1099511628211ull;
+          hh = (hh ^ fold(now)) * 1099511628211ull;
         }
         const bool forced = !single && m > 0 && !anyfree;
         if(forced) nb &= ~(Bits(3) << (2 * besti)); // the stage equality needs a free variable
@@ -1312,12 +1346,11 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             }
             WS(s, kXsAl) = nal;
             WS(s, kXsDp) = ndp;
-            WS(s, kXsSt) = (double)(unsigned)nb;
-            if constexpr(M > 16) WS(s, kXsSt2) = (double)(unsigned)(nb >> 32);
+            store_bits(s, nb);
             changed = true;
             smax_new = s;
           }
-          hh = (hh ^ nb) * 1099511628211ull;
+          hh = (hh ^ fold(nb)) * 1099511628211ull;
         }
 #pragma unroll
         for(int a = 0; a < 6; a++) x[a] = y[a];
@@ -1366,9 +1399,9 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     // the set goes with the instance: the next round, or the safeguard round, goes on from it (the dual kernel starts anew)
     for(int s = 0; s < N; s++)
     {
-      Bits bits = (Bits)(unsigned)WS(s, kXsSt);
-      if constexpr(M > 16) bits |= (Bits)(unsigned)WS(s, kXsSt2) << 32;
-      W.st[(size_t)s * W.st_stride + b] = bits;
+      const Bits bits = load_bits(s);
+      W.st[((size_t)s * kStW) * W.st_stride + b] = (unsigned long long)bits;
+      if constexpr(M > 32) W.st[((size_t)s * kStW + 1) * W.st_stride + b] = (unsigned long long)(bits >> 64);
     }
     if(!cycling && W.out_list)
     {
@@ -1414,9 +1447,10 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   *out = nullptr;
   if(!(p->mass > 0) || !(p->horizon_dt > 0) || p->horizon_steps <= 0)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_xy_create: mass, horizon_dt, horizon_steps must be > 0");
-  if(p->max_ridges != 0 && p->max_ridges != CCC_XY_MAX_RIDGES && p->max_ridges != CCC_XY_MAX_RIDGES_WIDE)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: max_ridges = %d, the kernels are built for %d and %d", p->max_ridges,
-                CCC_XY_MAX_RIDGES, CCC_XY_MAX_RIDGES_WIDE);
+  if(p->max_ridges != 0 && p->max_ridges != CCC_XY_MAX_RIDGES && p->max_ridges != CCC_XY_MAX_RIDGES_WIDE
+     && p->max_ridges != CCC_XY_MAX_RIDGES_MULTI)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: max_ridges = %d, the kernels are built for %d, %d and %d", p->max_ridges,
+                CCC_XY_MAX_RIDGES, CCC_XY_MAX_RIDGES_WIDE, CCC_XY_MAX_RIDGES_MULTI);
   if(p->horizon_steps > CCC_XY_MAX_STEPS_WIDE)
     return fail(CCC_ERR_UNSUPPORTED, "ccc_xy_create: horizon_steps %d > %d", p->horizon_steps, CCC_XY_MAX_STEPS_WIDE);
   int rc = select_device(device);
@@ -1506,10 +1540,10 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   const size_t n64 = ((size_t)n + kXsLanes - 1) / kXsLanes * kXsLanes; // whole wavefronts
   // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
-  const size_t kXsStage = kXsFields + (size_t)h->M * 8;
+  const size_t kXsStage = (size_t)xs_fields(h->M) + (size_t)h->M * 8;
   const size_t nwave = n64 / kXsLanes, ws_stride = N * kXsStage * kXsLanes, rb_stride = ws_stride;
-  const size_t o_ws = 0, o_rb = o_ws + (size_t)kXsFields * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
-               o_li = o_st + up(N * n64 * 8), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
+  const size_t o_ws = 0, o_rb = o_ws + (size_t)xs_fields(h->M) * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
+               o_li = o_st + up(N * n64 * 8 * (size_t)xs_st_words(h->M)), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
                o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
   {
@@ -1545,10 +1579,14 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       hipLaunchKernelGGL((xy_plan_stream_kernel<16, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
     else if(h->M == 16)
       hipLaunchKernelGGL((xy_plan_stream_kernel<16, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
-    else if(!Wk.single)
+    else if(h->M == 32 && !Wk.single)
       hipLaunchKernelGGL((xy_plan_stream_kernel<32, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
-    else
+    else if(h->M == 32)
       hipLaunchKernelGGL((xy_plan_stream_kernel<32, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+    else if(!Wk.single)
+      hipLaunchKernelGGL((xy_plan_stream_kernel<64, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
+    else
+      hipLaunchKernelGGL((xy_plan_stream_kernel<64, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
   };
   if(!dual_only)
   {

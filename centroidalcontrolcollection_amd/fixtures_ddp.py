@@ -445,3 +445,27 @@ def make_xy_walking_batch(n, N=30, dt=0.1, mass=100.0, M=32, seed=20250928, step
     am = rng.uniform(-0.5, 0.5, size=(n, 2))
     x0 = np.stack([mass * pos[:, 0], mass * vel[:, 0], mass * pos[:, 1], mass * vel[:, 1], am[:, 0], am[:, 1]], axis=1)
     return prob, np.ascontiguousarray(x0)
+
+
+def make_xy_multicontact_batch(n, N=20, dt=0.1, mass=100.0, M=64, seed=20250928):
+    """LinearMpcXY with more than two contacts per step (src/LinearMpcXY.cpp:69-82, :126-133 take any contact_list): the
+    contact phases of `make_multicontact_batch` (feet + hands on walls: 16 .. 64 ridges) laid out per horizon step.
+    com_z 0.9, total_force_z = m g, reference = the drifting CoM of that fixture; x0 near the reference.
+    Returns (prob, x0 [n,6])."""
+    d, _ = make_multicontact_batch(n, N, dt, mass, M, seed)
+    rng = np.random.default_rng(seed + 1)
+    prob = dict(dim=np.zeros((n, N), dtype=np.int32), vertex=np.zeros((n, N, M, 3)), ridge=np.zeros((n, N, M, 3)),
+                com_z=np.full((n, N), 0.9), total_force_z=np.full((n, N), mass * G), ref_out=np.zeros((n, N, 6)))
+    idx = np.arange(n)[:, None]
+    ph = d["step_phase"]
+    prob["dim"][:] = d["phase_dim"][idx, ph]
+    prob["vertex"][:] = d["phase_vertex"][idx, ph]
+    prob["ridge"][:] = d["phase_ridge"][idx, ph]
+    prob["ref_out"][:, :, 0] = mass * d["ref_pos"][:, :N, 0]
+    prob["ref_out"][:, :, 2] = mass * d["ref_pos"][:, :N, 1]
+    ref0 = prob["ref_out"][:, 0, :]
+    pos = np.stack([ref0[:, 0] / mass, ref0[:, 2] / mass], axis=1) + rng.uniform(-0.03, 0.03, size=(n, 2))
+    vel = rng.uniform(-0.1, 0.1, size=(n, 2))
+    am = rng.uniform(-0.5, 0.5, size=(n, 2))
+    x0 = np.stack([mass * pos[:, 0], mass * vel[:, 0], mass * pos[:, 1], mass * vel[:, 1], am[:, 0], am[:, 1]], axis=1)
+    return prob, np.ascontiguousarray(x0)

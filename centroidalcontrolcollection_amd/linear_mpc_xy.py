@@ -14,6 +14,7 @@ from . import _lib
 
 MAX_RIDGES = 16  # default ridge slots per step (one surface contact)
 MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support)
+MAX_RIDGES_MULTI = 64  # max_ridges=64: up to four surface contacts per step (feet + hands)
 MAX_STEPS = 20  # horizon steps both kernels take; beyond (<= 256) the stage-recursion kernel alone
 
 
@@ -148,7 +149,7 @@ class LinearMpcXY:
 
     def planOnce(self, motion_param_func, ref_data_func, initial_param, current_time):
         """CCC::LinearMpcXY::planOnce (LinearMpcXY.h:224-227, src/LinearMpcXY.cpp:96-114)."""
-        N, M = self.horizon_steps_, MAX_RIDGES_WIDE
+        N, M = self.horizon_steps_, MAX_RIDGES_MULTI
         prob = dict(dim=np.zeros((1, N), dtype=np.int32), vertex=np.zeros((1, N, M, 3)), ridge=np.zeros((1, N, M, 3)),
                     com_z=np.zeros((1, N)), total_force_z=np.zeros((1, N)), ref_out=np.zeros((1, N, 6)))
         for i in range(N):
@@ -161,18 +162,20 @@ class LinearMpcXY:
                 V, R = np.zeros((0, 3)), np.zeros((0, 3))
             if len(V) > M:
                 raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "%d ridges in one contact list, the kernels are built for "
-                                    "%d (two 4-vertex surface contacts)" % (len(V), M))
+                                    "%d (four 4-vertex surface contacts)" % (len(V), M))
             prob["dim"][0, i] = len(V)
             prob["vertex"][0, i, :len(V)], prob["ridge"][0, i, :len(V)] = V, R
             prob["com_z"][0, i], prob["total_force_z"][0, i] = mp.com_z, mp.total_force_z
             prob["ref_out"][0, i] = ref_data_func(t).toOutput(self.mass_)
         # the reference takes any contact_list (src/LinearMpcXY.cpp:69-82): what this object's ridge slots do not hold goes
-        # to a twin with max_ridges = 32, created on first need
+        # to a twin with the smallest ridge stride that does (32 or 64), created on first need
         planner = self
         if prob["dim"].max() > self.max_ridges_:
-            if getattr(self, "_wide", None) is None:
-                self._wide = LinearMpcXY(self.mass_, self.horizon_dt_, N, self._weight_param, self.device, MAX_RIDGES_WIDE)
-            planner = self._wide
+            need = MAX_RIDGES_WIDE if prob["dim"].max() <= MAX_RIDGES_WIDE else MAX_RIDGES_MULTI
+            twins = self.__dict__.setdefault("_twins", {})
+            if need not in twins:
+                twins[need] = LinearMpcXY(self.mass_, self.horizon_dt_, N, self._weight_param, self.device, need)
+            planner = twins[need]
         Mp = planner.max_ridges_
         prob["vertex"], prob["ridge"] = prob["vertex"][:, :, :Mp], prob["ridge"][:, :, :Mp]
         r = planner.planOnceBatch(prob, initial_param.toState(self.mass_)[None])

@@ -214,47 +214,50 @@ protected:
   std::vector<int32_t> last_status_;
 
 protected:
-  /** Flat arrays of ccc_xy_plan_batch for n instances; sampled with 32 ridge slots per step, see select(). */
+  /** Flat arrays of ccc_xy_plan_batch for n instances; sampled with 64 ridge slots per step, see select(). */
   struct Flat
   {
     Flat(size_t n, int N)
-    : dim(n * N, 0), vertex(n * N * CCC_XY_MAX_RIDGES_WIDE * 3, 0.0), ridge(n * N * CCC_XY_MAX_RIDGES_WIDE * 3, 0.0),
+    : dim(n * N, 0), vertex(n * N * CCC_XY_MAX_RIDGES_MULTI * 3, 0.0), ridge(n * N * CCC_XY_MAX_RIDGES_MULTI * 3, 0.0),
       com_z(n * N, 0.0), total_force_z(n * N, 0.0), ref_out(n * N * 6, 0.0), x0(n * 6, 0.0)
     {
     }
     std::vector<int32_t> dim;
     std::vector<double> vertex, ridge, com_z, total_force_z, ref_out, x0;
-    int M = CCC_XY_MAX_RIDGES_WIDE; //!< ridge slots per step of vertex / ridge
+    int M = CCC_XY_MAX_RIDGES_MULTI; //!< ridge slots per step of vertex / ridge
   };
 
-  /** The handle that takes the sampled problems: 16 ridge slots per step when no contact list has more (the arrays are
-      compacted to that stride), else the handle with 32, created on first need -- the reference takes any contact_list
-      (src/LinearMpcXY.cpp:69-82). */
+  /** The handle that takes the sampled problems: the smallest ridge stride (16, 32 or 64 slots per step) that holds
+      every sampled contact list -- the arrays are compacted to that stride; handles beyond the constructor's 16 are
+      created on first need.  The reference takes any contact_list (src/LinearMpcXY.cpp:69-82). */
   ccc_xy_t * select(Flat & f)
   {
     int32_t mx = 0;
     for(int32_t d : f.dim) mx = d > mx ? d : mx;
-    if(mx <= CCC_XY_MAX_RIDGES)
+    const int k = mx <= CCC_XY_MAX_RIDGES ? 0 : (mx <= CCC_XY_MAX_RIDGES_WIDE ? 1 : 2);
+    const size_t Mn = k == 0 ? CCC_XY_MAX_RIDGES : (k == 1 ? CCC_XY_MAX_RIDGES_WIDE : CCC_XY_MAX_RIDGES_MULTI);
+    const size_t steps = f.dim.size(), Mw = static_cast<size_t>(f.M);
+    if(Mn < Mw)
     {
-      const size_t steps = f.dim.size(), Mw = CCC_XY_MAX_RIDGES_WIDE, Mn = CCC_XY_MAX_RIDGES;
       for(size_t e = 0; e < steps; e++)
         for(size_t j = 0; j < Mn * 3; j++)
         {
           f.vertex[e * Mn * 3 + j] = f.vertex[e * Mw * 3 + j];
           f.ridge[e * Mn * 3 + j] = f.ridge[e * Mw * 3 + j];
         }
-      f.M = CCC_XY_MAX_RIDGES;
-      return handle_.get();
+      f.M = static_cast<int>(Mn);
     }
-    if(!wide_handle_)
+    if(k == 0) return handle_.get();
+    std::shared_ptr<ccc_xy_t> & twin = k == 1 ? wide_handle_ : multi_handle_;
+    if(!twin)
     {
       ccc_xy_params_t p = params_;
-      p.max_ridges = CCC_XY_MAX_RIDGES_WIDE;
+      p.max_ridges = static_cast<int>(Mn);
       ccc_xy_t * h = nullptr;
       check(ccc_xy_create(&p, device_, &h));
-      wide_handle_.reset(h, ccc_xy_destroy);
+      twin.reset(h, ccc_xy_destroy);
     }
-    return wide_handle_.get();
+    return twin.get();
   }
 
   /** src/LinearMpcXY.cpp:102-110 (sampling) and :69-82 (contact -> vertex -> ridge order); returns dim of step 0 */
@@ -265,7 +268,7 @@ protected:
              const InitialParam & initial_param,
              double current_time) const
   {
-    const size_t N = static_cast<size_t>(horizon_steps_), M = CCC_XY_MAX_RIDGES_WIDE;
+    const size_t N = static_cast<size_t>(horizon_steps_), M = CCC_XY_MAX_RIDGES_MULTI;
     for(size_t i = 0; i < N; i++)
     {
       const double t = current_time + static_cast<double>(i) * horizon_dt_;
@@ -278,7 +281,7 @@ protected:
           for(const auto & rd : vr.ridgeList)
           {
             if(r >= M)
-              throw std::runtime_error("[LinearMpcXY] more than 32 ridges in one contact list (the kernels are built for two "
+              throw std::runtime_error("[LinearMpcXY] more than 64 ridges in one contact list (the kernels are built for four "
                                        "4-vertex surface contacts)");
             for(int a = 0; a < 3; a++)
             {
@@ -310,7 +313,7 @@ protected:
 
 protected:
   WeightParam weight_param_;
-  std::shared_ptr<ccc_xy_t> handle_, wide_handle_;
+  std::shared_ptr<ccc_xy_t> handle_, wide_handle_, multi_handle_;
   ccc_xy_params_t params_{};
   int device_ = 0;
 };

@@ -242,6 +242,7 @@ typedef struct ccc_xy ccc_xy_t;
 #define CCC_XY_MAX_STEPS_WIDE 256 /* ... beyond that, up to here, the stage-recursion kernel alone (workspace: 64 KB x N / 20 per instance) */
 #define CCC_XY_MAX_RIDGES 16      /* default ridge slots per step (one 4-vertex surface contact) */
 #define CCC_XY_MAX_RIDGES_WIDE 32 /* params.max_ridges = 32: two surface contacts per step (double support) */
+#define CCC_XY_MAX_RIDGES_MULTI 64 /* params.max_ridges = 64: up to four surface contacts per step (feet + hands) */
 
 /* Constructor arguments of LinearMpcXY(mass, horizon_dt, horizon_steps, weight_param, qp_solver_type)
  * (include/CCC/LinearMpcXY.h:211-215, src/LinearMpcXY.cpp:85-94); WeightParam (:104-142) flattened:
@@ -254,8 +255,8 @@ typedef struct
   int horizon_steps;
   double w_lmi[2], w_lm[2], w_am[2], w_force;
   int max_ridges; /* M: ridge slots per horizon step: 0 or 16 = CCC_XY_MAX_RIDGES (one 4-vertex surface contact), 32 =
-                   * CCC_XY_MAX_RIDGES_WIDE (two: double support; src/LinearMpcXY.cpp:69-82 walks the whole contact_list).
-                   * Other values: CCC_ERR_UNSUPPORTED. */
+                   * CCC_XY_MAX_RIDGES_WIDE (two: double support; src/LinearMpcXY.cpp:69-82 walks the whole contact_list),
+                   * 64 = CCC_XY_MAX_RIDGES_MULTI (up to four: feet and hands).  Other values: CCC_ERR_UNSUPPORTED. */
 } ccc_xy_params_t;
 
 int ccc_xy_create(const ccc_xy_params_t * params, int device, ccc_xy_t ** out);
