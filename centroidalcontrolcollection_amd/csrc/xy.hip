@@ -359,25 +359,74 @@ __global__ __launch_bounds__(kXyNT, 4) void xy_plan_kernel(XyParams P, XyBatch B
 #pragma unroll
       for(int c = 0; c < 6; c++) Q.q[r][c] *= iwf;
     if(rb == cb && a0 == 4) Q.q[2][6] = 1.0;
-    // ---------------- add every variable (F = all), then remove the regularisation of the contact steps' equality rows
+    // ---------------- add every variable (F = all), then remove the regularisation of the contact steps' equality rows.
+    //                  The m <= 16 variables of a step enter M_F only through the Gram matrix of their 7-vectors,
+    //                  G_s = sum_i bt_i bt_i' (rank <= 6: the two position / momentum entries of an impulse are
+    //                  proportional), so the step is added as the <= 6 columns l_j of its Cholesky factor, G_s = sum_j l_j l_j'
+    //                  -- 120 rank-1 updates instead of 320, each on the CURRENT Qt like any pivot (a block update
+    //                  Qt - Pi K Pi' with the whole step at once was tried: the late, nearly dependent vectors are then
+    //                  formed by cancellation and multiplied by the initial 1 / w_force-sized block column -- Qt lost three
+    //                  digits and the closing refinement no longer reached the KKT tolerances).
     int buf = 0;
 #ifndef XY_PROF_NO_ADDS
-    for(int v = 0; v < N * M; v++)
     {
-      const int sv = v >> 4;
-      if((v & 15) >= sh.dims[sv]) continue;
-      xy_col(Q, owner, rb, cb, a0, sv, sh.bt[v], sh.pi[buf]);
+      double * const lv = &sh.part[0][0][0];             // [7][7]: the factor's columns
+      int * const lflag = reinterpret_cast<int *>(lv + NB * NB); // [7]: column j is there (its pivot was not negligible)
+      for(int sv = 0; sv < N; sv++)
+      {
+        const int m = sh.dims[sv];
+        if(m == 0) continue;
+        __syncthreads(); // (the previous step's columns have been read)
+        if(i < 64)
+        {
+          // lane (a, c) of an 8 x 8 layout: G[a][c], then the outer-product Cholesky with the columns of negligible
+          // pivot skipped (G is positive SEMI-definite)
+          const int a = i >> 3, c = i & 7;
+          const bool ok = a < NB && c < NB;
+          const int aa = ok ? a : 0, cc = ok ? c : 0;
+          double gg = 0.0;
+          for(int v = 0; v < m; v++) gg = fma(sh.bt[sv * M + v][aa], sh.bt[sv * M + v][cc], gg);
+          gg = ok ? gg : 0.0;
+          double tr = (a == c) ? gg : 0.0; // trace -> the scale of the pivot test
+          tr += dpp_f64<kDppQuadXor1>(tr);
+          tr += dpp_f64<kDppQuadXor2>(tr);
+          tr += dpp_f64<kDppRowHalfMirror>(tr);
+          tr += __shfl_xor(tr, 8);
+          tr += __shfl_xor(tr, 16);
+          tr += __shfl_xor(tr, 32);
+          const double tol = 1e-13 * tr;
+#pragma unroll
+          for(int j = 0; j < NB; j++)
+          {
+            const double piv = __shfl(gg, j * 9);
+            const bool take = piv > tol;
+            const double rs = take ? 1.0 / sqrt(piv) : 0.0;
+            const double la = (a >= j) ? __shfl(gg, aa * 8 + j) * rs : 0.0; // l_j[a] = G[a][j] / sqrt(pivot)
+            const double lc = (c >= j) ? __shfl(gg, cc * 8 + j) * rs : 0.0;
+            if(ok && c == j) lv[j * NB + a] = la;
+            if(i == 0) lflag[j] = take ? 1 : 0;
+            gg = (a >= j && c >= j) ? fma(-la, lc, gg) : 0.0; // (rows / columns up to j are finished)
+          }
+        }
+        __syncthreads();
+        for(int j = 0; j < NB; j++)
+        {
+          if(!lflag[j]) continue;
+          xy_col(Q, owner, rb, cb, a0, sv, lv + j * NB, sh.pi[buf]);
+          __syncthreads();
+          xy_rank1(Q, true, rb, cb, a0, sv, lv + j * NB, sh.pi[buf], 1.0);
+          buf ^= 1;
+        }
+      }
       __syncthreads();
-      xy_rank1(Q, true, rb, cb, a0, sv, sh.bt[v], sh.pi[buf], 1.0);
-      buf ^= 1;
-    }
-    for(int sv = 0; sv < N; sv++)
-    {
-      if(sh.dims[sv] == 0) continue;
-      xy_col(Q, owner, rb, cb, a0, sv, sh.e6, sh.pi[buf]);
-      __syncthreads();
-      xy_rank1(Q, true, rb, cb, a0, sv, sh.e6, sh.pi[buf], -1.0);
-      buf ^= 1;
+      for(int sv = 0; sv < N; sv++)
+      {
+        if(sh.dims[sv] == 0) continue;
+        xy_col(Q, owner, rb, cb, a0, sv, sh.e6, sh.pi[buf]);
+        __syncthreads();
+        xy_rank1(Q, true, rb, cb, a0, sv, sh.e6, sh.pi[buf], -1.0);
+        buf ^= 1;
+      }
     }
 #endif
 

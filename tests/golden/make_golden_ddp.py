@@ -21,7 +21,8 @@ local minimiser of the bound-constrained optimal-control problem the reference h
 Instances (PRNG numpy default_rng, seeds below): the synthetic workloads of BASELINE configs 3 and 5
 (fixtures_ddp.make_centroidal_batch: a stance phase, a 0.2 s FLIGHT phase, a shifted stance; N = 100 / 50) and
 walking sequences with 32-ridge DOUBLE support, 16-ridge single support and flight steps
-(fixtures_ddp.make_walking_batch, N = 40), for both models.
+(fixtures_ddp.make_walking_batch, N = 40) and feet + hands multi-contact motions with 48- / 64-ridge steps
+(fixtures_ddp.make_multicontact_batch, N = 30), for both models.
 
 Run:  python tests/golden/make_golden_ddp.py       (about 10 minutes on 8 cores; writes ddp_golden.npz next to this file)
 """
@@ -200,23 +201,35 @@ def make_set(name, model, N, dt, prob, x0, weights, pool):
 
 
 def main():
+    """usage: make_golden_ddp.py [set ...]   -- no argument: every set; with arguments: those sets only, merged into the
+    existing ddp_golden.npz (the sets are independent of each other: each has its own seed)."""
     import multiprocessing as mp
+    import sys
 
-    out = {}
-    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+    sets = {
         # BASELINE config 3 shape: DdpCentroidal, N = 100 @ 30 ms, stance - flight - stance
-        prob, x0 = fd.make_centroidal_batch(16, 100, 0.03, MASS, seed=20260101)
-        out.update(make_set("cen", 0, 100, 0.03, prob, x0, fd.centroidal_weights(), pool))
+        "cen": lambda: (0, 100, 0.03, fd.make_centroidal_batch(16, 100, 0.03, MASS, seed=20260101), fd.centroidal_weights()),
         # BASELINE config 5 shape: DdpSingleRigidBody, N = 50 @ 30 ms
-        prob, x0 = fd.make_centroidal_batch(24, 50, 0.03, MASS, seed=20260102, srb=True)
-        out.update(make_set("srb", 1, 50, 0.03, prob, x0, fd.srb_weights(), pool))
+        "srb": lambda: (1, 50, 0.03, fd.make_centroidal_batch(24, 50, 0.03, MASS, seed=20260102, srb=True), fd.srb_weights()),
         # double-support walking (32 ridges per step), both models
-        prob, x0 = fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260103)
-        out.update(make_set("cenwalk", 0, 40, 0.05, prob, x0, fd.centroidal_weights(), pool))
-        prob, x0 = fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260104, srb=True)
-        out.update(make_set("srbwalk", 1, 40, 0.05, prob, x0, fd.srb_weights(), pool))
-    np.savez_compressed(os.path.join(HERE, "ddp_golden.npz"), **out)
-    print("wrote", os.path.join(HERE, "ddp_golden.npz"))
+        "cenwalk": lambda: (0, 40, 0.05, fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260103), fd.centroidal_weights()),
+        "srbwalk": lambda: (1, 40, 0.05, fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260104, srb=True), fd.srb_weights()),
+        # feet + hands on walls (48 / 64 ridges per step), both models
+        "cenmulti": lambda: (0, 30, 0.05, fd.make_multicontact_batch(8, 30, 0.05, MASS, 64, seed=20260105), fd.centroidal_weights()),
+        "srbmulti": lambda: (1, 30, 0.05, fd.make_multicontact_batch(8, 30, 0.05, MASS, 64, seed=20260106, srb=True), fd.srb_weights()),
+    }
+    want = sys.argv[1:] or list(sets)
+    path = os.path.join(HERE, "ddp_golden.npz")
+    out = {}
+    if sys.argv[1:] and os.path.exists(path):
+        with np.load(path) as z:
+            out = {k: z[k] for k in z.files if k.split("_")[0] not in want}
+    with mp.Pool(min(8, os.cpu_count() or 1)) as pool:
+        for name in want:
+            model, N, dt, (prob, x0), weights = sets[name]()
+            out.update(make_set(name, model, N, dt, prob, x0, weights, pool))
+    np.savez_compressed(path, **out)
+    print("wrote", path)
 
 
 if __name__ == "__main__":
