@@ -22,7 +22,7 @@ Instances (PRNG numpy default_rng, seeds below): the synthetic workloads of BASE
 (fixtures_ddp.make_centroidal_batch: a stance phase, a 0.2 s FLIGHT phase, a shifted stance; N = 100 / 50) and
 walking sequences with 32-ridge DOUBLE support, 16-ridge single support and flight steps
 (fixtures_ddp.make_walking_batch, N = 40) and feet + hands multi-contact motions with 48- / 64-ridge steps
-(fixtures_ddp.make_multicontact_batch, N = 30), for both models.
+(fixtures_ddp.make_multicontact_batch, N = 24), for both models.
 
 Run:  python tests/golden/make_golden_ddp.py       (about 10 minutes on 8 cores; writes ddp_golden.npz next to this file)
 """
@@ -215,8 +215,8 @@ def main():
         "cenwalk": lambda: (0, 40, 0.05, fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260103), fd.centroidal_weights()),
         "srbwalk": lambda: (1, 40, 0.05, fd.make_walking_batch(8, 40, 0.05, MASS, 32, seed=20260104, srb=True), fd.srb_weights()),
         # feet + hands on walls (48 / 64 ridges per step), both models
-        "cenmulti": lambda: (0, 30, 0.05, fd.make_multicontact_batch(8, 30, 0.05, MASS, 64, seed=20260105), fd.centroidal_weights()),
-        "srbmulti": lambda: (1, 30, 0.05, fd.make_multicontact_batch(8, 30, 0.05, MASS, 64, seed=20260106, srb=True), fd.srb_weights()),
+        "cenmulti": lambda: (0, 24, 0.05, fd.make_multicontact_batch(6, 24, 0.05, MASS, 64, seed=20260105), fd.centroidal_weights()),
+        "srbmulti": lambda: (1, 24, 0.05, fd.make_multicontact_batch(6, 24, 0.05, MASS, 64, seed=20260106, srb=True), fd.srb_weights()),
     }
     want = sys.argv[1:] or list(sets)
     path = os.path.join(HERE, "ddp_golden.npz")
