@@ -484,14 +484,15 @@ def test_wide_limits_are_reported():
 
 
 # ------------------------------------------------------------------------------------------ independent known answers
-@pytest.mark.parametrize("name", ["cen", "srb", "cenwalk", "srbwalk"])
+@pytest.mark.parametrize("name", ["cen", "srb", "cenwalk", "srbwalk", "cenmulti", "srbmulti"])
 def test_gpu_reaches_the_golden_minimisers(name):
     """tests/golden/ddp_golden.npz (single-shooting NLP solved by L-BFGS-B + SQP, KKT-certified strict local minimisers;
     nothing of oracle/ or of this library involved -- tests/golden/make_golden_ddp.py): the HIP planners, run to
     convergence from their cold start, reach the golden cost within 1e-8 relative, the force scales within 5e-2 and the
     first step's wrench within 1e-4 on every instance that ends in the golden basin (tolerances and their derivation:
     tests/test_golden_ddp.py), and the share that does is bounded below.  Sets: BASELINE config 3 / 5 workloads
-    (stance - flight - stance) and 32-ridge double-support walking through the wide kernel, both models."""
+    (stance - flight - stance), 32-ridge double-support walking and feet + hands multi-contact motions with 48- / 64-ridge
+    steps, both models."""
     import test_golden_ddp as tg
 
     g = tg.load_set(name)
