@@ -675,8 +675,11 @@ struct Solver
     }
     const mask_t inmask = (m >= M) ? kAll : static_cast<mask_t>((static_cast<mask_t>(1) << m) - 1u);
     // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); sumM
+    // (H y is kept: the gradient of the next iteration is q + H x at the x the last value was taken at -- the same
+    //  product, not formed twice)
+    vf hy[B];
     auto value_of = [&](const vf (&y)[B]) {
-      vf hy[B], t[B];
+      vf t[B];
       matvec(HF, y, 0, hy);
       for(int b = 0; b < B; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
       return read_lane(sumM(t), 0);
@@ -698,11 +701,10 @@ struct Solver
       }
       oldvalue = value;
       vf grad[B];
-      matvec(HF, x, 1, grad);
       vb diff[B];
       for(int b = 0; b < B; b++)
       {
-        grad[b] = q[b] + grad[b];
+        grad[b] = q[b] + hy[b];
         const vb oldc = cl[b];
         cl[b] = in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
         diff[b] = cl[b] != oldc;

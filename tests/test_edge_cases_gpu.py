@@ -43,10 +43,10 @@ def test_xy_rejects_unsupported_sizes():
 
 
 def test_ism_largest_and_smallest_horizon():
-    for T, dt in ((2.54, 0.02), (0.02, 0.02), (0.06, 0.02)):
+    for T, dt in ((2.54, 0.02), (0.02, 0.02), (0.06, 0.02), (2.56, 0.02)):
         o = _oracle().IntrinsicallyStableMpc(1.0, T, dt)
         N = o.horizon_steps
-        assert N in (127, 1, 3)
+        assert N in (127, 1, 3, 128)  # (127: the largest the tridiagonal kernel takes; 128: the first of the tableau alone)
         b = fx.make_ism_batch(24, N, dt, seed=N)
         ro = o.plan_batch(b["init"], b["ref"], 0.005, want_vel=False, nthreads=8)
         r = IntrinsicallyStableMpc(1.0, T, dt).planOnceBatch(b["init"], b["ref"], 0.005)
@@ -55,7 +55,7 @@ def test_ism_largest_and_smallest_horizon():
         assert np.abs(r["zmp"][ok] - ro["zmp"][ok]).max() <= 1e-9
         assert np.all(r["status"][~ok].max(axis=1) != 0) if (~ok).any() else True
     with pytest.raises(CccError):
-        IntrinsicallyStableMpc(1.0, 2.56, 0.02)  # 128 steps + the stability row exceed the LDS-resident tableau
+        IntrinsicallyStableMpc(1.0, 3.84, 0.02)  # 192 steps + the stability row exceed the LDS-resident tableau
 
 
 def test_z_single_step_and_all_flight():
