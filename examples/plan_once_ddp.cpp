@@ -87,8 +87,8 @@ int main()
     }
     {
       // Walking with double support: a two-element contact_list (32 ridges, src/DdpCentroidal.cpp:49-60) and six
-      // distinct contact lists inside the horizon -- beyond the fast kernel's tables; the shim routes the call to the
-      // wide kernel behind the same planOnce().
+      // distinct contact lists inside the horizon; the shim routes the call to a handle with the ridge stride the sampled
+      // contact lists need (here 32) behind the same planOnce().
       const double wdt = 0.05;
       const int WN = 40;
       CCC::DdpCentroidal::WeightParam w;

@@ -8,7 +8,7 @@ import numpy as np
 from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 srb = len(sys.argv) > 2 and sys.argv[2] == "srb"
-walk = len(sys.argv) > 2 and sys.argv[2] == "walk"  # double-support walking: the wide kernel (csrc/ddp_wide.hip)
+walk = len(sys.argv) > 2 and sys.argv[2] == "walk"  # double-support walking (32 ridges per step)
 N, dt = (50, 0.03) if srb else (100, 0.03)
 kw = {}
 if walk:

@@ -336,7 +336,7 @@ def test_cpp_header_shims_match_python_mirror():
                     lambda t: DdpSingleRigidBody.RefData(fd.reference_schedule(t)[1]), ips, 0.0)
     cpps = np.array([float(v) for v in lines["srb"].split("u0=")[1].split()])
     assert np.array_equal(cpps, us)
-    # walking with double support: 32-ridge contact lists and 7 phases, routed to the wide kernel by both front ends
+    # walking with double support: 32-ridge contact lists and 7 phases, routed to a 32-ridge handle by both front ends
     def foot(x, y):
         return fd.contact_from_rect((x - 0.1, y - 0.05), (x + 0.1, y + 0.05))
 
