@@ -130,6 +130,50 @@ int main()
       for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
       std::printf("\n");
     }
+    {
+      // Multi-contact: both feet and, for the first 0.6 s, the right hand on a wall at x = 0.45 (a three-element
+      // contact_list = 48 ridges; src/DdpCentroidal.cpp:49-60 takes any contact_list).  The hand contact is the
+      // rectangle contact mapped by the pose (normal -x, tangent +y): world = centre + (-z, x, -y) of the local frame.
+      const double mdt = 0.05;
+      const int MN = 24;
+      CCC::DdpCentroidal::WeightParam w;
+      w.running_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      w.terminal_pos = CCC::Vector3d(1.0, 1.0, 10.0);
+      CCC::DdpCentroidal ddp(mass, mdt, MN, w);
+      ddp.ddp_solver_->config().max_iter = 25;
+      const auto lf = CCC::makeContactFromRect({CCC::Vector2d(-0.1, 0.05), CCC::Vector2d(0.1, 0.15)});
+      const auto rf = CCC::makeContactFromRect({CCC::Vector2d(-0.1, -0.15), CCC::Vector2d(0.1, -0.05)});
+      auto hand = std::make_shared<CCC::Contact>(*CCC::makeContactFromRect({CCC::Vector2d(-0.05, -0.05), CCC::Vector2d(0.05, 0.05)}));
+      for(auto & vr : hand->vertexWithRidgeList_)
+      {
+        const CCC::Vector3d v = vr.vertex;
+        vr.vertex = CCC::Vector3d(0.45 - v[2], -0.2 + v[0], 1.0 - v[1]);
+        for(auto & rd : vr.ridgeList)
+        {
+          const CCC::Vector3d r = rd;
+          rd = CCC::Vector3d(-r[2], r[0], -r[1]);
+        }
+      }
+      auto motion = [&](double t) {
+        CCC::DdpCentroidal::MotionParam mp;
+        if(t + 1e-6 < 0.6)
+          mp.contact_list = {lf, rf, hand};
+        else
+          mp.contact_list = {lf, rf};
+        return mp;
+      };
+      auto ref = [](double t) {
+        CCC::DdpCentroidal::RefData r;
+        r.pos = CCC::Vector3d(0.05 * t, 0.0, 0.9);
+        return r;
+      };
+      CCC::DdpCentroidal::InitialParam ip;
+      ip.pos = CCC::Vector3d(0.01, -0.01, 0.9);
+      CCC::VectorXd u = ddp.planOnce(motion, ref, ip, 0.0);
+      std::printf("multicontact iter=%d dim=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size());
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+    }
     return 0;
   }
   catch(const std::exception & e)

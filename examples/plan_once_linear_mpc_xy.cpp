@@ -87,6 +87,46 @@ int main()
       for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
       std::printf("\n");
     }
+    {
+      // Multi-contact: both feet and the right hand on a wall at x = 1.45 (a three-element contact_list = 48 ridges,
+      // src/LinearMpcXY.cpp:69-82 walks the whole list) for the first second: routed to the 64-slot handle by the shim.
+      const int MN = 20;
+      CCC::LinearMpcXY mmpc(mass, dt, MN);
+      const auto lf = CCC::makeContactFromRect({CCC::Vector2d(0.9, 0.05), CCC::Vector2d(1.1, 0.15)});
+      const auto rf = CCC::makeContactFromRect({CCC::Vector2d(0.9, -0.15), CCC::Vector2d(1.1, -0.05)});
+      auto hand = std::make_shared<CCC::Contact>(*CCC::makeContactFromRect({CCC::Vector2d(-0.05, -0.05), CCC::Vector2d(0.05, 0.05)}));
+      for(auto & vr : hand->vertexWithRidgeList_)
+      {
+        const CCC::Vector3d v = vr.vertex;
+        vr.vertex = CCC::Vector3d(1.45 - v[2], -0.2 + v[0], 1.0 - v[1]); // pose: normal -x, tangent +y
+        for(auto & rd : vr.ridgeList)
+        {
+          const CCC::Vector3d r = rd;
+          rd = CCC::Vector3d(-r[2], r[0], -r[1]);
+        }
+      }
+      auto mmotion = [&](double t) {
+        CCC::LinearMpcXY::MotionParam mp;
+        mp.com_z = 0.9;
+        mp.total_force_z = mass * g;
+        if(t + 1e-9 < 1.0)
+          mp.contact_list = {lf, rf, hand};
+        else
+          mp.contact_list = {lf, rf};
+        return mp;
+      };
+      auto mref = [&](double t) {
+        CCC::LinearMpcXY::RefData rd;
+        rd.pos = CCC::Vector2d(1.0 + 0.02 * t, 0.0);
+        return rd;
+      };
+      CCC::LinearMpcXY::InitialParam mip;
+      mip.pos = CCC::Vector2d(1.01, -0.01);
+      CCC::VectorXd u = mmpc.planOnce(mmotion, mref, mip, 0.0);
+      std::printf("multicontact dim=%d status=%d u0=", u.size(), mmpc.lastStatuses()[0] & 0xff);
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+    }
     return 0;
   }
   catch(const std::exception & e)

@@ -350,6 +350,19 @@ def test_cpp_header_shims_match_python_mirror():
     assert "dim=32" in lines["walking"] and len(uw) == 32
     assert np.array_equal(cppw, uw)
     assert "iter=%d" % wd.ddp_solver_.last_iter in lines["walking"]
+    # multi-contact: feet + the right hand on a wall for the first 0.6 s (48 ridges): both front ends route to a 64-ridge handle
+    lfoot, rfoot = fd.contact_from_rect((-0.1, 0.05), (0.1, 0.15)), fd.contact_from_rect((-0.1, -0.15), (0.1, -0.05))
+    Vl, Rl = fd.contact_from_rect((-0.05, -0.05), (0.05, 0.05))
+    hand = (np.stack([0.45 - Vl[:, 2], -0.2 + Vl[:, 0], 1.0 - Vl[:, 1]], axis=1), np.stack([-Rl[:, 2], Rl[:, 0], -Rl[:, 1]], axis=1))
+    md = _cen(24, 0.05, 25)
+    um = md.planOnce(lambda t: DdpCentroidal.MotionParam([lfoot, rfoot, hand] if t + 1e-6 < 0.6 else [lfoot, rfoot]),
+                     lambda t: DdpCentroidal.RefData((0.05 * t, 0.0, 0.9)),
+                     DdpCentroidal.InitialParam((0.01, -0.01, 0.9), (0, 0, 0), (0, 0, 0)), 0.0)
+    cppm = np.array([float(v) for v in lines["multicontact"].split("u0=")[1].split()])
+    assert "dim=48" in lines["multicontact"] and len(um) == 48
+    assert np.array_equal(cppm, um)
+    assert um[32:].sum() > 1.0  # the hand carries force
+    assert "iter=%d" % md.ddp_solver_.last_iter in lines["multicontact"]
 
 
 # ---------------------------------------------------------------------------------------------------------------------

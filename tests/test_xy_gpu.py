@@ -275,6 +275,16 @@ def test_cpp_header_shim_matches_python_mirror():
                                             LinearMpcXY.InitialParam((1.1, 0.01), (0.0, 0.0)), 0.0)
     assert "dim=32" in wl and "status=0" in wl and len(uw) == 32
     assert np.array_equal(np.array([float(v) for v in wl.split("u0=")[1].split()]), uw)
+    # multi-contact: feet + the right hand on a wall for the first second (48 ridges): both front ends route to the 64-slot handle
+    lfoot, rfoot = fd.contact_from_rect((0.9, 0.05), (1.1, 0.15)), fd.contact_from_rect((0.9, -0.15), (1.1, -0.05))
+    Vl, Rl = fd.contact_from_rect((-0.05, -0.05), (0.05, 0.05))
+    hand = (np.stack([1.45 - Vl[:, 2], -0.2 + Vl[:, 0], 1.0 - Vl[:, 1]], axis=1), np.stack([-Rl[:, 2], Rl[:, 0], -Rl[:, 1]], axis=1))
+    ml = [ln for ln in lines if ln.startswith("multicontact")][0]
+    um = LinearMpcXY(mass, dt, 20).planOnce(
+        lambda t: LinearMpcXY.MotionParam(0.9, mass * fd.G, [lfoot, rfoot, hand] if t + 1e-9 < 1.0 else [lfoot, rfoot]),
+        lambda t: LinearMpcXY.RefData((1.0 + 0.02 * t, 0.0)), LinearMpcXY.InitialParam((1.01, -0.01), (0.0, 0.0)), 0.0)
+    assert "dim=48" in ml and "status=0" in ml and len(um) == 48
+    assert np.array_equal(np.array([float(v) for v in ml.split("u0=")[1].split()]), um)
 
 
 def test_rounds_of_the_stage_recursion_kernel_are_bit_identical(monkeypatch):
