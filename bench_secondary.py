@@ -88,7 +88,13 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
     from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
     N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
     kw, M, P = {}, 16, 4
-    if walking:
+    if walking == "multi":
+        # feet + hands: 32- / 48- / 64-ridge steps -> the tile kernel with four ridge blocks
+        N, dt, base, M = 30, 0.05, min(n, 512), 64
+        prob, x0 = fd.make_multicontact_batch(base, N, dt, seed=20250928 + rank, srb=srb)
+        P = prob["phase_dim"].shape[1]
+        kw = dict(max_phases=P, max_ridges=64)
+    elif walking:
         # double-support walking sequences: 32-ridge steps, 8-10 contact phases -> the tile kernel with two ridge blocks
         N, dt, base, M = 40, 0.05, min(n, 1024), 32
         prob, x0 = fd.make_walking_batch(base, N, dt, seed=20250928 + rank, srb=srb)
@@ -142,6 +148,8 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
                 step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f64 (f32 storage)",  # (the arithmetic type of the path, not its storage format)
                 workload=("%s horizon=%d @ %d ms, max_iter=20, batch=%d per GPU (%s)"
                           % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, round(dt * 1e3), n,
+                             ("feet + hands multi-contact, 32 / 48 / 64 ridges per step, %d contact phases: beyond BASELINE's configs, "
+                              "src/DdpCentroidal.cpp:49-60" % P) if walking == "multi" else
                              "walking with 32-ridge double support, %d contact phases: beyond BASELINE's configs, "
                              "src/DdpCentroidal.cpp:49-60" % P if walking else
                              "BASELINE config %s" % (("5" if precision == 32 else "5 shape, fp64") if srb else "3"))),
@@ -270,9 +278,9 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, xywalk=32768, ddp32=4096)
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, multi=2048, xywalk=32768, ddp32=4096)
 DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
-                     walk=(3, 1), xywalk=(3, 1), ddp32=(3, 1))
+                     walk=(3, 1), multi=(3, 1), xywalk=(3, 1), ddp32=(3, 1))
 
 
 def run(args, rank, world, local_rank, dist):
@@ -280,7 +288,7 @@ def run(args, rank, world, local_rank, dist):
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
-                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True), ddp32=lambda a, b, c: _ddp(a, b, c, False, 32))
+                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True), multi=lambda a, b, c: _ddp(a, b, c, False, 64, "multi"), ddp32=lambda a, b, c: _ddp(a, b, c, False, 32))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)
