@@ -55,9 +55,7 @@ using ddp_common::Params;
 #ifndef CCC_TILE_U_PROD
 #  define CCC_TILE_U_PROD 3
 #endif
-#ifndef CCC_TILE_U_Z
-#  define CCC_TILE_U_Z 1
-#endif
+// (the Z loop: per model, see Solver::kUnrollZ)
 #ifndef CCC_TILE_U_PAIR
 #  define CCC_TILE_U_PAIR 4
 #endif
@@ -203,6 +201,13 @@ struct Solver
   static constexpr int FU0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (its six non-zero rows are FU0 .. FU0+5)
   static constexpr int NP = S * (S + 1) / 2;   // entries of the upper triangle of Vxx
   static constexpr int NPASS = (NP + 63) / 64;
+  // unroll factor of the Z = Quu K + 2 Qux loop (measured per model, round 3: S = 9: 41.0 k solves/s at 4, 34.7 k at 1;
+  // S = 12: 133 k at 2, 126 k at 4)
+#ifdef CCC_TILE_U_Z
+  static constexpr int kUnrollZ = CCC_TILE_U_Z;
+#else
+  static constexpr int kUnrollZ = (S == 9) ? 4 : 2;
+#endif
   // one bit per ridge: clamped-or-unused sets
   using mask_t = std::conditional_t<(B <= 2), unsigned, unsigned long long>;
   static constexpr mask_t kAll = (B == 1) ? static_cast<mask_t>(0xffffu) : static_cast<mask_t>(~static_cast<mask_t>(0));
@@ -234,25 +239,28 @@ struct Solver
   // SPEC (sums over the M ridges): w_c = v_c                              (B = 1)
   //                                w_c = v_c + v_{c+16}                   (B = 2)
   //                                w_c = (v_c + v_{c+16}) + (v_{c+32} + v_{c+48})   (B = 4), then tree16(w)
+  template<int AB>
   static W64_FN vf bsum(const vf (&v)[B])
   {
-    if constexpr(B == 1)
+    if constexpr(AB == 1)
       return v[0];
-    else if constexpr(B == 2)
+    else if constexpr(AB == 2)
       return v[0] + v[1];
     else
       return (v[0] + v[1]) + (v[2] + v[3]);
   }
-  static W64_FN vf sumM(const vf (&v)[B]) { return sum16(bsum(v)); }
+  template<int AB>
+  static W64_FN vf sumM(const vf (&v)[B]) { return sum16(bsum<AB>(v)); }
   // the 16 bits of block b of a set
   static W64_FN unsigned piece(mask_t m, int b) { return static_cast<unsigned>(m >> (16 * b)) & 0xffffu; }
   // lane (g, c): is ridge c + 16 b / column 16 b + 4 g + s in the set ?
   W64_FN vb row_in(mask_t m, int b) const { return ((spl(static_cast<int>(piece(m, b))) >> c) & 1) != 0; }
   W64_FN vb col_in(mask_t m, int b, int s) const { return ((spl(static_cast<int>(piece(m, b))) >> (g * 4 + s)) & 1) != 0; }
+  template<int AB>
   W64_FN mask_t ballotM(const vb (&p)[B]) const
   {
     mask_t r = 0;
-    for(int b = 0; b < B; b++) r |= static_cast<mask_t>(ballot(p[b]) & 0xffffull) << (16 * b);
+    for(int b = 0; b < AB; b++) r |= static_cast<mask_t>(ballot(p[b]) & 0xffffull) << (16 * b);
     return r;
   }
 
@@ -302,12 +310,13 @@ struct Solver
     return d < 0 ? 0 : (d > M ? M : d);
   }
   // the step's contact phase into Vc / Rc
+  template<int AB>
   W64_FN void contact_of(int ph, int dim)
   {
     if(ph == ph_cached) return;
     ph_cached = ph;
     const long base = static_cast<long>(ph) * M * 3;
-    for(int b = 0; b < B; b++)
+    for(int b = 0; b < AB; b++)
     {
       const vi r = c + 16 * b;
       const vb in = r < dim;
@@ -336,11 +345,12 @@ struct Solver
     vf accel[3];          // sum_r (u_r ridge_r) / m                    (sumM; single-rigid-body model)
   };
   // x: state on the lanes a < S of every row (rows may differ: the line search), u: the force scales of the ridges c + 16 b
+  template<int AB>
   CCC_TILE_PIECE void terms_of(int ph, int dim, vf x, const vf (&u)[B], Terms & T)
   {
-    contact_of(ph, dim);
+    contact_of<AB>(ph, dim);
     const vf p0 = row_bcast<0>(x), p1 = row_bcast<1>(x), p2 = row_bcast<2>(x);
-    for(int b = 0; b < B; b++)
+    for(int b = 0; b < AB; b++)
     {
       const vf d0 = Vc[b][0] - p0, d1 = Vc[b][1] - p1, d2 = Vc[b][2] - p2;
       T.cr[b][0] = d1 * Rc[b][2] - d2 * Rc[b][1];
@@ -350,14 +360,14 @@ struct Solver
     for(int k = 0; k < 3; k++)
     {
       vf t[B];
-      for(int b = 0; b < B; b++) t[b] = u[b] * Rc[b][k];
-      T.force[k] = sumM(t);
-      for(int b = 0; b < B; b++) t[b] = u[b] * T.cr[b][k];
-      T.moment[k] = sumM(t);
+      for(int b = 0; b < AB; b++) t[b] = u[b] * Rc[b][k];
+      T.force[k] = sumM<AB>(t);
+      for(int b = 0; b < AB; b++) t[b] = u[b] * T.cr[b][k];
+      T.moment[k] = sumM<AB>(t);
       if(S == 12)
       {
-        for(int b = 0; b < B; b++) t[b] = (u[b] * Rc[b][k]) / P.mass;
-        T.accel[k] = sumM(t);
+        for(int b = 0; b < AB; b++) t[b] = (u[b] * Rc[b][k]) / P.mass;
+        T.accel[k] = sumM<AB>(t);
       }
     }
   }
@@ -402,13 +412,14 @@ struct Solver
     return sel(inS, x + P.dt * xd, 0.0);
   }
   // running / terminal cost of (x, u) per row: src/DdpCentroidal.cpp:66-83
+  template<int AB>
   W64_FN vf running_cost(int step, vf x, const vf (&u)[B]) const
   {
     const vf e = x - ref_of(step);
     const vf cx = sum16(sel(inS, 0.5 * ld(mem.wrun, c) * e * e, 0.0));
     vf t[B];
-    for(int b = 0; b < B; b++) t[b] = u[b] * u[b];
-    const vf un = sumM(t);
+    for(int b = 0; b < AB; b++) t[b] = u[b] * u[b];
+    const vf un = sumM<AB>(t);
     return cx + 0.5 * P.w_force * un;
   }
   W64_FN vf terminal_cost(vf x) const
@@ -419,6 +430,7 @@ struct Solver
 
   // Fx -> mem.Fx ([b][c], dense), Fu: the six non-zero rows of the columns c + 16 b in registers
   // (src/DdpCentroidal.cpp:85-121 / src/DdpSingleRigidBody.cpp:114-185), at (x, u) with the step's Terms
+  template<int AB>
   CCC_TILE_PIECE void state_eq_deriv(const Terms & T, vf x, vf (&Fu)[B][6])
   {
     const vb first = lane == 0;
@@ -427,7 +439,7 @@ struct Solver
     const double dt = P.dt;
     if(S == 9)
     {
-      for(int b = 0; b < B; b++)
+      for(int b = 0; b < AB; b++)
         for(int k = 0; k < 3; k++)
         {
           Fu[b][k] = Rc[b][k] * dt;
@@ -446,7 +458,7 @@ struct Solver
     else
     {
       const double * In = mem.inertia;
-      for(int b = 0; b < B; b++)
+      for(int b = 0; b < AB; b++)
       {
         vf sol[3];
         vllt3(In, T.cr[b], sol);
@@ -505,39 +517,42 @@ struct Solver
 
   // ------------------------------------------------------------------------------------------------ linear algebra
   // y on every row -> the entries 16 bc + 4g .. 16 bc + 4g+3 this lane's column blocks need (through LDS buffer `slot`)
+  template<int AB>
   W64_FN void block_of(const vf (&y)[B], int slot, vf (&yb)[B][4])
   {
-    for(int b = 0; b < B; b++) st(mem.cb[slot], c + 16 * b, y[b], g == 0);
+    for(int b = 0; b < AB; b++) st(mem.cb[slot], c + 16 * b, y[b], g == 0);
     wave_sync();
-    for(int bc = 0; bc < B; bc++)
+    for(int bc = 0; bc < AB; bc++)
       for(int s = 0; s < 4; s++) yb[bc][s] = ld(mem.cb[slot], g * 4 + s + 16 * bc);
   }
   // one row block of H times the gathered vector.  SPEC (row r, the four chains g = 0 .. 3 over the columns
   // k = 16 bc + 4g + s, bc ascending, s = 0 .. 3 inside): p_g = H[r][4g] y_4g; p_g = fma(H[r][k], y_k, p_g) for the
   // following k; (H y)_r = (p_0 + p_1) + (p_2 + p_3).   elem(bc, s): the lane's entry of the row block.
-  template<class E>
+  template<int AB, class E>
   static W64_FN vf row_dot(E elem, const vf (&yb)[B][4])
   {
     vf p = elem(0, 0) * yb[0][0];
     for(int s = 1; s < 4; s++) p = vfma(elem(0, s), yb[0][s], p);
-    for(int bc = 1; bc < B; bc++)
+    for(int bc = 1; bc < AB; bc++)
       for(int s = 0; s < 4; s++) p = vfma(elem(bc, s), yb[bc][s], p);
     return sum_rows(p);
   }
   // out = H y for H in row blocks
+  template<int AB>
   W64_FN void matvec(const vf (&H)[B][B][4], const vf (&y)[B], int slot, vf (&out)[B])
   {
     vf yb[B][4];
-    block_of(y, slot, yb);
-    for(int br = 0; br < B; br++) out[br] = row_dot([&](int bc, int s) { return H[br][bc][s]; }, yb);
+    block_of<AB>(y, slot, yb);
+    for(int br = 0; br < AB; br++) out[br] = row_dot<AB>([&](int bc, int s) { return H[br][bc][s]; }, yb);
   }
   // the same with the diagonal blocks taken from Hd (the unregularised Quu: HF with lambda taken off the diagonal)
+  template<int AB>
   W64_FN void matvec_u(const vf (&H)[B][B][4], const vf (&Hd)[B][4], const vf (&y)[B], int slot, vf (&out)[B])
   {
     vf yb[B][4];
-    block_of(y, slot, yb);
-    for(int br = 0; br < B; br++)
-      out[br] = row_dot([&](int bc, int s) { return bc == br ? Hd[br][s] : H[br][bc][s]; }, yb);
+    block_of<AB>(y, slot, yb);
+    for(int br = 0; br < AB; br++)
+      out[br] = row_dot<AB>([&](int bc, int s) { return bc == br ? Hd[br][s] : H[br][bc][s]; }, yb);
   }
 
   // L D L' of H~ (H with the rows and columns of `skip` -- clamped or beyond the step's dimension -- replaced by
@@ -546,13 +561,14 @@ struct Solver
   //   a[c][k] = fma(-(a[c][j] a[k][j]), r, a[c][k])       (the product of the two column entries first: symmetric)
   // (entries with a row or column index below the first ridge of j's block of 16 are never read again and are left
   //  alone.)  Returns false when a pivot is not positive.
+  template<int AB>
   CCC_TILE_PIECE bool factorize(const vf (&HF)[B][B][4], mask_t skip, vf (&rdv)[B])
   {
     vf a[B][B][4];
-    for(int br = 0; br < B; br++)
+    for(int br = 0; br < AB; br++)
     {
       const vb rskip = row_in(skip, br);
-      for(int bc = 0; bc < B; bc++)
+      for(int bc = 0; bc < AB; bc++)
         for(int s = 0; s < 4; s++)
         {
           const vb cskip = col_in(skip, bc, s);
@@ -562,47 +578,47 @@ struct Solver
       rdv[br] = splat(1.0);
     }
     bool ok = true;
-    factor_col<0>(a, skip, rdv, ok);
+    factor_col<AB, 0>(a, skip, rdv, ok);
     wave_sync();
     return ok;
   }
 
   // one column of the factorisation (a compile-time column index: the entries of `a` stay in their registers)
-  template<int J>
+  template<int AB, int J>
   W64_FN void factor_col(vf (&a)[B][B][4], mask_t skip, vf (&rdv)[B], bool & ok)
   {
-    if constexpr(J < M)
+    if constexpr(J < 16 * AB)
     {
       constexpr int jb = J >> 4, jc = J & 15, gj = jc >> 2, sj = jc & 3;
       if((skip >> J) & 1u)
       {
-        for(int br = jb; br < B; br++) st(mem.L, (c + 16 * br) * LT + J, splat(0.0), g == 0);
+        for(int br = jb; br < AB; br++) st(mem.L, (c + 16 * br) * LT + J, splat(0.0), g == 0);
       }
       else
       {
         // (source order = issue order wanted: the column goes to LDS and its reads are in flight while the pivot's
         //  reciprocal -- an IEEE division, the longest dependent chain of the step -- is computed)
-        for(int br = jb; br < B; br++) st(mem.cb[J & 1], c + 16 * br, a[br][jb][sj], g == gj);
+        for(int br = jb; br < AB; br++) st(mem.cb[J & 1], c + 16 * br, a[br][jb][sj], g == gj);
         wave_sync();
         vf uc[B], uk[B][4];
-        for(int br = jb; br < B; br++) uc[br] = ld(mem.cb[J & 1], c + 16 * br);
-        for(int bc = jb; bc < B; bc++)
+        for(int br = jb; br < AB; br++) uc[br] = ld(mem.cb[J & 1], c + 16 * br);
+        for(int bc = jb; bc < AB; bc++)
           for(int s = 0; s < 4; s++) uk[bc][s] = ld(mem.cb[J & 1], g * 4 + s + 16 * bc);
         const double d = read_lane(a[jb][jb][sj], 16 * gj + jc);
         if(!(d > 0.0)) ok = false;
         const double r = 1.0 / d;
         vf pk[B][B][4];
-        for(int br = jb; br < B; br++)
-          for(int bc = jb; bc < B; bc++)
+        for(int br = jb; br < AB; br++)
+          for(int bc = jb; bc < AB; bc++)
             for(int s = 0; s < 4; s++) pk[br][bc][s] = uc[br] * uk[bc][s];
-        for(int br = jb; br < B; br++)
+        for(int br = jb; br < AB; br++)
           st(mem.L, (c + 16 * br) * LT + J, sel(c + 16 * br > J, uc[br] * r, 0.0), g == 0);
         rdv[jb] = sel(c == jc, splat(r), rdv[jb]);
-        for(int br = jb; br < B; br++)
-          for(int bc = jb; bc < B; bc++)
+        for(int br = jb; br < AB; br++)
+          for(int bc = jb; bc < AB; bc++)
             for(int s = 0; s < 4; s++) a[br][bc][s] = vfma(-pk[br][bc][s], splat(r), a[br][bc][s]);
       }
-      factor_col<J + 1>(a, skip, rdv, ok);
+      factor_col<AB, J + 1>(a, skip, rdv, ok);
     }
   }
 
@@ -610,34 +626,34 @@ struct Solver
   // skipped rows.  SPEC: forward, k = 0 .. M-1: b_c = fma(-L[c][k], b_k, b_c) for the rows c from the first ridge of k's
   // block of 16 on (L is zero on and above the diagonal); b_c = b_c rd_c; backward, k = M-1 .. 0: b_c = fma(-L[k][c], b_k, b_c)
   // for the rows c up to the last ridge of k's block.  Skipped columns are identity columns: nothing to do.
-  template<int NR>
+  template<int AB, int NR>
   W64_FN void solve(vf (&b)[B][NR], mask_t skip, const vf (&rdv)[B])
   {
-    solve_fwd<0>(b, skip);
-    for(int br = 0; br < B; br++)
+    solve_fwd<AB, 0>(b, skip);
+    for(int br = 0; br < AB; br++)
       for(int t = 0; t < NR; t++) b[br][t] = b[br][t] * rdv[br];
-    solve_bwd<M - 1>(b, skip);
+    solve_bwd<AB, 16 * AB - 1>(b, skip);
   }
-  template<int K, int NR>
+  template<int AB, int K, int NR>
   W64_FN void solve_fwd(vf (&b)[B][NR], mask_t skip)
   {
-    if constexpr(K < M)
+    if constexpr(K < 16 * AB)
     {
       constexpr int kb = K >> 4, kc = K & 15;
       if(!((skip >> K) & 1u))
       {
         vf bk[NR];
         for(int t = 0; t < NR; t++) bk[t] = row_bcast<kc>(b[kb][t]);
-        for(int br = kb; br < B; br++)
+        for(int br = kb; br < AB; br++)
         {
           const vf lk = ld(mem.L, (c + 16 * br) * LT + K);
           for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
         }
       }
-      solve_fwd<K + 1>(b, skip);
+      solve_fwd<AB, K + 1>(b, skip);
     }
   }
-  template<int K, int NR>
+  template<int AB, int K, int NR>
   W64_FN void solve_bwd(vf (&b)[B][NR], mask_t skip)
   {
     if constexpr(K >= 0)
@@ -653,20 +669,21 @@ struct Solver
           for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
         }
       }
-      solve_bwd<K - 1>(b, skip);
+      solve_bwd<AB, K - 1>(b, skip);
     }
   }
 
   // Box-QP (Tassa's boxQP.m, nmpc_ddp's parameters): min 1/2 x'Hx + q'x, lo <= x <= hi over the first m ridges,
   // H = HF (row blocks, lambda on the diagonal).  x enters as the warm start.  On success (result >= 1) x is the
   // minimiser, skip the clamped-or-unused rows as a bit mask, and mem.L / rdv hold the factor of H~ for that set.
+  template<int AB>
   CCC_TILE_PIECE int box_qp(int m, const vf (&HF)[B][B][4], const vf (&q)[B], const vf (&lo)[B], const vf (&hi)[B],
                             vf (&x)[B], mask_t & skip, vf (&rdv)[B])
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     vb in[B], cl[B];
-    for(int b = 0; b < B; b++)
+    for(int b = 0; b < AB; b++)
     {
       in[b] = c + 16 * b < m;
       cl[b] = lane < 0; // all false
@@ -680,9 +697,9 @@ struct Solver
     vf hy[B];
     auto value_of = [&](const vf (&y)[B]) {
       vf t[B];
-      matvec(HF, y, 0, hy);
-      for(int b = 0; b < B; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
-      return read_lane(sumM(t), 0);
+      matvec<AB>(HF, y, 0, hy);
+      for(int b = 0; b < AB; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
+      return read_lane(sumM<AB>(t), 0);
     };
     TILE_PROF_START();
     TILE_PROF_COUNT(TP_QP_CALLS);
@@ -702,15 +719,15 @@ struct Solver
       oldvalue = value;
       vf grad[B];
       vb diff[B];
-      for(int b = 0; b < B; b++)
+      for(int b = 0; b < AB; b++)
       {
         grad[b] = q[b] + hy[b];
         const vb oldc = cl[b];
         cl[b] = in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
         diff[b] = cl[b] != oldc;
       }
-      const mask_t clmask = ballotM(cl) & inmask;
-      const bool changed = (iter == 1) || ((ballotM(diff) & inmask) != 0u);
+      const mask_t clmask = ballotM<AB>(cl) & inmask;
+      const bool changed = (iter == 1) || ((ballotM<AB>(diff) & inmask) != 0u);
       TILE_PROF_ADD(TP_QP_GRAD);
       if(clmask == inmask)
       {
@@ -721,7 +738,7 @@ struct Solver
       {
         TILE_PROF_COUNT(TP_QP_FACTORS);
         skip = clmask | (~inmask & kAll);
-        if(!factorize(HF, skip, rdv))
+        if(!factorize<AB>(HF, skip, rdv))
         {
           result = -1;
           break;
@@ -730,13 +747,13 @@ struct Solver
       TILE_PROF_ADD(TP_QP_FACTOR);
       vb fr[B];
       vf t[B];
-      for(int b = 0; b < B; b++)
+      for(int b = 0; b < AB; b++)
       {
         fr[b] = in[b] && !cl[b];
         t[b] = sel(fr[b], grad[b] * grad[b], 0.0);
       }
       // |grad| on the free rows.  SPEC: sqrt(sumM(free ? grad^2 : 0))
-      const double gn = std::sqrt(read_lane(sumM(t), 0));
+      const double gn = std::sqrt(read_lane(sumM<AB>(t), 0));
       if(gn < min_grad)
       {
         result = 5;
@@ -744,23 +761,23 @@ struct Solver
       }
       // grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x
       vf xcl[B], hx[B], rhs[B][1], srch[B];
-      for(int b = 0; b < B; b++) xcl[b] = sel(cl[b], x[b], 0.0);
-      matvec(HF, xcl, 0, hx);
-      for(int b = 0; b < B; b++) rhs[b][0] = sel(fr[b], q[b] + hx[b], 0.0);
-      solve<1>(rhs, skip, rdv);
-      for(int b = 0; b < B; b++)
+      for(int b = 0; b < AB; b++) xcl[b] = sel(cl[b], x[b], 0.0);
+      matvec<AB>(HF, xcl, 0, hx);
+      for(int b = 0; b < AB; b++) rhs[b][0] = sel(fr[b], q[b] + hx[b], 0.0);
+      solve<AB, 1>(rhs, skip, rdv);
+      for(int b = 0; b < AB; b++)
       {
         srch[b] = sel(fr[b], -rhs[b][0] - x[b], 0.0);
         t[b] = srch[b] * grad[b];
       }
-      const double sdotg = read_lane(sumM(t), 0);
+      const double sdotg = read_lane(sumM<AB>(t), 0);
       TILE_PROF_ADD(TP_QP_SOLVE);
       if(sdotg >= 0) break; // no descent direction: result stays 0
       double step = 1.0, vc;
       vf xc[B];
       for(;;)
       {
-        for(int b = 0; b < B; b++) xc[b] = sel(in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
+        for(int b = 0; b < AB; b++) xc[b] = sel(in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
         vc = value_of(xc);
         if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
         step *= step_dec;
@@ -770,12 +787,12 @@ struct Solver
           break;
         }
       }
-      for(int b = 0; b < B; b++) x[b] = xc[b];
+      for(int b = 0; b < AB; b++) x[b] = xc[b];
       value = vc;
       TILE_PROF_ADD(TP_QP_SEARCH);
     }
     if(iter > max_iter && result == 0) result = 1;
-    skip = (ballotM(cl) & inmask) | (~inmask & kAll);
+    skip = (ballotM<AB>(cl) & inmask) | (~inmask & kAll);
     return result;
   }
 
@@ -784,6 +801,261 @@ struct Solver
   W64_FN const double * ucur() const { return I.ubuf + static_cast<long>(cur) * P.N * M; }
 
   // oracle/ddp_tile.c backward_pass; returns false when a box-QP fails.  gnorm: sum_i max_c |k_c| / (|u_c| + 1)
+  // one step of the backward pass with the first AB <= B blocks of 16 ridges live (m <= 16 AB: the further blocks are
+  // exact zeros in every sum of the specification and are left out); returns false when the box-QP fails
+  template<int AB>
+  CCC_TILE_PIECE bool backward_step(int i, int m, int ph, vf x, const vf (&u)[B], vf (&kprev)[B], int mprev, double & gsum)
+  {
+    vb in[B];
+    for(int b = 0; b < AB; b++) in[b] = c + 16 * b < m;
+    TILE_PROF_START();
+    Terms T;
+    terms_of<AB>(ph, m, x, u, T);
+    vf Fu[B][6];
+    state_eq_deriv<AB>(T, x, Fu);
+    TILE_PROF_ADD(TP_DERIV);
+    // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
+    {
+      vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
+      const vi col = seli(inS, c, spl(0));
+      for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
+      st(mem.Qx, c, s, inS && (g == 0));
+    }
+    // Qu = Lu + Fu' Vx.  SPEC: s = w_force u_c; s = fma(Fu[b][c], Vx[b], s), b = FU0 .. FU0+5
+    vf Qu[B];
+    for(int b = 0; b < AB; b++)
+    {
+      vf s = P.w_force * u[b];
+      for(int bb = 0; bb < 6; bb++) s = vfma(Fu[b][bb], splat(mem.Vx[FU0 + bb]), s);
+      Qu[b] = sel(in[b], s, 0.0);
+    }
+    // T2 = Vxx Fu (rows a_t of the columns c + 16 b).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
+    // (loops over the state index run with the three rows inside and a bounded unroll: fully unrolled, the scheduler
+    //  hoists every LDS load of a product and the registers of 3 x S x 2 operands do not fit four wavefronts per SIMD)
+    {
+      vf s3[B][3];
+      for(int t = 0; t < 3; t++)
+      {
+        const vf v = ld(mem.Vxx, arow[t] * S + FU0);
+        for(int b = 0; b < AB; b++) s3[b][t] = v * Fu[b][0];
+      }
+      for(int bb = 1; bb < 6; bb++)
+        for(int t = 0; t < 3; t++)
+        {
+          const vf v = ld(mem.Vxx, arow[t] * S + (FU0 + bb));
+          for(int b = 0; b < AB; b++) s3[b][t] = vfma(v, Fu[b][bb], s3[b][t]);
+        }
+      for(int b = 0; b < AB; b++)
+        for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * M + c + 16 * b, s3[b][t], aval[t]);
+    }
+    // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
+    const vi col = seli(inS, c, spl(0));
+    {
+      vf s3[3];
+      const vf f0 = ld(mem.Fx, col);
+      for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
+      W64_UNROLL(CCC_TILE_U_PROD)
+      for(int b = 1; b < S; b++)
+      {
+        const vf fb = ld(mem.Fx, col + b * S);
+        for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + b), fb, s3[t]);
+      }
+      for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
+    }
+    wave_sync();
+    // Quu = Luu + Fu' T2 (rows c + 16 br, columns 16 bc + 4g + s).  SPEC: s = (r == k) w_force; s = fma(Fu[b][r], T2[b][k], s), b ascending
+    // HF: lambda on the diagonal; Hd: the diagonal blocks with the unregularised diagonal entry
+    vf HF[B][B][4], Hd[B][4];
+    for(int bc = 0; bc < AB; bc++)
+    {
+      vf s4v[B][4];
+      for(int br = 0; br < AB; br++)
+        for(int s4 = 0; s4 < 4; s4++)
+          s4v[br][s4] = (br == bc) ? sel(c == g * 4 + s4, splat(P.w_force), 0.0) : splat(0.0);
+      for(int bb = 0; bb < 6; bb++)
+        for(int s4 = 0; s4 < 4; s4++)
+        {
+          const vf t2 = ld(mem.T2, g * 4 + s4 + 16 * bc + (FU0 + bb) * M);
+          for(int br = 0; br < AB; br++) s4v[br][s4] = vfma(Fu[br][bb], t2, s4v[br][s4]);
+        }
+      for(int br = 0; br < AB; br++)
+        for(int s4 = 0; s4 < 4; s4++)
+        {
+          const vi k = g * 4 + s4 + 16 * bc;
+          const vb live = in[br] && (k < m);
+          if(br == bc)
+          {
+            const vb dg = live && (c == g * 4 + s4);
+            Hd[br][s4] = sel(live, s4v[br][s4], 0.0);
+            HF[br][bc][s4] = sel(dg, s4v[br][s4] + lambda, Hd[br][s4]);
+          }
+          else
+            HF[br][bc][s4] = sel(live, s4v[br][s4], 0.0);
+        }
+    }
+    // Qxu = Fx' T2 (rows a_t of the columns c + 16 b).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
+    vf Qxu[B][3];
+    {
+      for(int t = 0; t < 3; t++)
+      {
+        const vf f = ld(mem.Fx, arow[t]);
+        for(int b = 0; b < AB; b++) Qxu[b][t] = f * ld(mem.T2, c + 16 * b);
+      }
+      W64_UNROLL(CCC_TILE_U_PROD)
+      for(int bb = 1; bb < S; bb++)
+      {
+        vf tb[B];
+        for(int b = 0; b < AB; b++) tb[b] = ld(mem.T2, c + 16 * b + bb * M);
+        for(int t = 0; t < 3; t++)
+        {
+          const vf f = ld(mem.Fx, arow[t] + bb * S);
+          for(int b = 0; b < AB; b++) Qxu[b][t] = vfma(f, tb[b], Qxu[b][t]);
+        }
+      }
+      for(int b = 0; b < AB; b++)
+        for(int t = 0; t < 3; t++) Qxu[b][t] = sel(in[b] && aval[t], Qxu[b][t], 0.0);
+    }
+    // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
+    vf Qxx[3];
+    {
+      for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
+      W64_UNROLL(CCC_TILE_U_PROD)
+      for(int b = 0; b < S; b++)
+      {
+        const vf tb = ld(mem.T1, col + b * S);
+        for(int t = 0; t < 3; t++) Qxx[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxx[t]);
+      }
+    }
+    wave_sync();
+    for(int t = 0; t < 3; t++)
+    {
+      st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
+      for(int b = 0; b < AB; b++)
+        st(mem.Zl, arow[t] * LT + c + 16 * b, Qxu[b][t], aval[t]); // (Qxu waits in Z's place while the box-QP runs)
+    }
+    TILE_PROF_ADD(TP_PRODUCTS);
+    // box-QP and gains
+    vf k[B], K[B][3];
+    for(int b = 0; b < AB; b++)
+    {
+      k[b] = splat(0.0);
+      for(int t = 0; t < 3; t++) K[b][t] = splat(0.0);
+    }
+    if(m > 0)
+    {
+      vf lo[B], hi[B];
+      for(int b = 0; b < AB; b++)
+      {
+        lo[b] = sel(in[b], P.flo - u[b], 0.0);
+        hi[b] = sel(in[b], P.fhi - u[b], 0.0);
+        // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
+        k[b] = (mprev == m) ? kprev[b] : splat(0.0);
+      }
+      mask_t skip;
+      vf rdv[B];
+      const int rc = box_qp<AB>(m, HF, Qu, lo, hi, k, skip, rdv);
+      if(rc < 1) return false;
+      TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
+      // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
+      vb fr[B];
+      vf rhs[B][3];
+      for(int b = 0; b < AB; b++)
+      {
+        fr[b] = !row_in(skip, b);
+        for(int t = 0; t < 3; t++) rhs[b][t] = sel(fr[b], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+      }
+      solve<AB, 3>(rhs, skip, rdv);
+      for(int b = 0; b < AB; b++)
+        for(int t = 0; t < 3; t++) K[b][t] = sel(fr[b] && aval[t], -rhs[b][t], 0.0);
+    }
+    // gains -> global memory (the forward passes read them) and K' -> LDS
+    for(int b = 0; b < AB; b++)
+    {
+      st(I.ks + static_cast<long>(i) * M, c + 16 * b, k[b], g == 0);
+      for(int t = 0; t < 3; t++)
+      {
+        st(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + arow[t], K[b][t], aval[t]);
+        st(mem.T2, arow[t] * LT + c + 16 * b, K[b][t], aval[t]);
+      }
+    }
+    TILE_PROF_ADD(TP_GAINS);
+    // termination measure: max_c |k_c| / (|u_c| + 1)
+    {
+      vf mx = sel(in[0], vabs(k[0]) / (vabs(u[0]) + 1.0), 0.0);
+      for(int b = 1; b < AB; b++) mx = vmax(mx, sel(in[b], vabs(k[b]) / (vabs(u[b]) + 1.0), 0.0));
+      gsum += read_lane(max16(mx), 0);
+    }
+    // dV += [k'Qu, 1/2 k'Quu k].  SPEC: sumM(k_c Qu_c), 0.5 sumM(k_c (Quu k)_c)
+    for(int b = 0; b < AB; b++)
+      for(int t = 0; t < 3; t++) Qxu[b][t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+    vf t4[B];
+    matvec_u<AB>(HF, Hd, k, 0, t4);
+    {
+      vf t[B];
+      for(int b = 0; b < AB; b++) t[b] = k[b] * Qu[b];
+      dV0 += read_lane(sumM<AB>(t), 0);
+      for(int b = 0; b < AB; b++) t[b] = k[b] * t4[b];
+      dV1 += 0.5 * read_lane(sumM<AB>(t), 0);
+    }
+    // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + sumM
+    {
+      vf q2[B];
+      for(int b = 0; b < AB; b++) q2[b] = t4[b] + Qu[b];
+      for(int t = 0; t < 3; t++)
+      {
+        vf w[B];
+        for(int b = 0; b < AB; b++) w[b] = vfma(Qxu[b][t], k[b], K[b][t] * q2[b]);
+        const vf v = sumM<AB>(w);
+        st(mem.vxn, arow[t], v, aval[t] && (c == 0));
+      }
+    }
+    wave_sync();
+    // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [row_dot] + 2 Qxu[a][c]
+    wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
+    for(int t = 0; t < 3; t++)
+    {
+      W64_UNROLL_T(kUnrollZ)
+      for(int gg = 0; gg < 4; gg++)
+      {
+        const int a = gg + 4 * t;
+        if(a >= S) break;
+        vf yb[B][4];
+        for(int bc = 0; bc < AB; bc++)
+          for(int s4 = 0; s4 < 4; s4++) yb[bc][s4] = ld(mem.T2, g * 4 + s4 + 16 * bc + a * LT);
+        for(int br = 0; br < AB; br++)
+        {
+          const vf z = row_dot<AB>([&](int bc, int s) { return bc == br ? Hd[br][s] : HF[br][bc][s]; }, yb) + 2.0 * Qxu[br][t];
+          st(mem.Zl, c + 16 * br + a * LT, z, g == gg);
+        }
+      }
+    }
+    st(mem.Vx, c, ld(mem.Qx, seli(inS, c, spl(0))) + ld(mem.vxn, seli(inS, c, spl(0))), inS && (g == 0));
+    wave_sync();
+    // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + sum_c (K[c][a] Z[c][b] + K[c][b] Z[c][a]))
+    // SPEC: acc = 0; for c = 0 .. M-1: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
+    for(int q = 0; q < NPASS; q++)
+    {
+      const vi pidx = lane + 64 * q;
+      const vb pv = pidx < NP;
+      const vi ab = ldb(mem.pair, seli(pv, pidx, spl(0)));
+      const vi pa = ab & 15, pb = ab >> 4;
+      vf acc = splat(0.0);
+      W64_UNROLL(CCC_TILE_U_PAIR)
+      for(int r = 0; r < 16 * AB; r++)
+      {
+        acc = vfma(ld(mem.T2, pa * LT + r), ld(mem.Zl, pb * LT + r), acc);
+        acc = vfma(ld(mem.T2, pb * LT + r), ld(mem.Zl, pa * LT + r), acc);
+      }
+      const vf v = 0.5 * ((ld(mem.T1, pa * S + pb) + ld(mem.T1, pb * S + pa)) + acc);
+      st(mem.Vxx, pa * S + pb, v, pv);
+      st(mem.Vxx, pb * S + pa, v, pv);
+    }
+    wave_sync();
+    TILE_PROF_ADD(TP_VALUE);
+    for(int b = 0; b < B; b++) kprev[b] = b < AB ? k[b] : splat(0.0);
+    return true;
+  }
+
   CCC_TILE_PIECE bool backward_pass(double & gsum)
   {
     const int N = P.N;
@@ -813,13 +1085,8 @@ struct Solver
     for(int i = N - 1; i >= 0; i--)
     {
       const int m = m_n, ph = ph_n;
-      vb in[B];
       vf u[B];
-      for(int b = 0; b < B; b++)
-      {
-        in[b] = c + 16 * b < m;
-        u[b] = u_n[b];
-      }
+      for(int b = 0; b < B; b++) u[b] = u_n[b];
       const vf x = x_n;
       if(i > 0)
       {
@@ -828,251 +1095,15 @@ struct Solver
         x_n = ldm(xs + static_cast<long>(i - 1) * S, c, inS);
         for(int b = 0; b < B; b++) u_n[b] = ldm(us + static_cast<long>(i - 1) * M, c + 16 * b, c + 16 * b < m_n);
       }
-      TILE_PROF_START();
-      Terms T;
-      terms_of(ph, m, x, u, T);
-      vf Fu[B][6];
-      state_eq_deriv(T, x, Fu);
-      TILE_PROF_ADD(TP_DERIV);
-      // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
-      {
-        vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
-        const vi col = seli(inS, c, spl(0));
-        for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
-        st(mem.Qx, c, s, inS && (g == 0));
-      }
-      // Qu = Lu + Fu' Vx.  SPEC: s = w_force u_c; s = fma(Fu[b][c], Vx[b], s), b = FU0 .. FU0+5
-      vf Qu[B];
-      for(int b = 0; b < B; b++)
-      {
-        vf s = P.w_force * u[b];
-        for(int bb = 0; bb < 6; bb++) s = vfma(Fu[b][bb], splat(mem.Vx[FU0 + bb]), s);
-        Qu[b] = sel(in[b], s, 0.0);
-      }
-      // T2 = Vxx Fu (rows a_t of the columns c + 16 b).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
-      // (loops over the state index run with the three rows inside and a bounded unroll: fully unrolled, the scheduler
-      //  hoists every LDS load of a product and the registers of 3 x S x 2 operands do not fit four wavefronts per SIMD)
-      {
-        vf s3[B][3];
-        for(int t = 0; t < 3; t++)
-        {
-          const vf v = ld(mem.Vxx, arow[t] * S + FU0);
-          for(int b = 0; b < B; b++) s3[b][t] = v * Fu[b][0];
-        }
-        for(int bb = 1; bb < 6; bb++)
-          for(int t = 0; t < 3; t++)
-          {
-            const vf v = ld(mem.Vxx, arow[t] * S + (FU0 + bb));
-            for(int b = 0; b < B; b++) s3[b][t] = vfma(v, Fu[b][bb], s3[b][t]);
-          }
-        for(int b = 0; b < B; b++)
-          for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * M + c + 16 * b, s3[b][t], aval[t]);
-      }
-      // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
-      const vi col = seli(inS, c, spl(0));
-      {
-        vf s3[3];
-        const vf f0 = ld(mem.Fx, col);
-        for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
-        W64_UNROLL(CCC_TILE_U_PROD)
-        for(int b = 1; b < S; b++)
-        {
-          const vf fb = ld(mem.Fx, col + b * S);
-          for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + b), fb, s3[t]);
-        }
-        for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
-      }
-      wave_sync();
-      // Quu = Luu + Fu' T2 (rows c + 16 br, columns 16 bc + 4g + s).  SPEC: s = (r == k) w_force; s = fma(Fu[b][r], T2[b][k], s), b ascending
-      // HF: lambda on the diagonal; Hd: the diagonal blocks with the unregularised diagonal entry
-      vf HF[B][B][4], Hd[B][4];
-      for(int bc = 0; bc < B; bc++)
-      {
-        vf s4v[B][4];
-        for(int br = 0; br < B; br++)
-          for(int s4 = 0; s4 < 4; s4++)
-            s4v[br][s4] = (br == bc) ? sel(c == g * 4 + s4, splat(P.w_force), 0.0) : splat(0.0);
-        for(int bb = 0; bb < 6; bb++)
-          for(int s4 = 0; s4 < 4; s4++)
-          {
-            const vf t2 = ld(mem.T2, g * 4 + s4 + 16 * bc + (FU0 + bb) * M);
-            for(int br = 0; br < B; br++) s4v[br][s4] = vfma(Fu[br][bb], t2, s4v[br][s4]);
-          }
-        for(int br = 0; br < B; br++)
-          for(int s4 = 0; s4 < 4; s4++)
-          {
-            const vi k = g * 4 + s4 + 16 * bc;
-            const vb live = in[br] && (k < m);
-            if(br == bc)
-            {
-              const vb dg = live && (c == g * 4 + s4);
-              Hd[br][s4] = sel(live, s4v[br][s4], 0.0);
-              HF[br][bc][s4] = sel(dg, s4v[br][s4] + lambda, Hd[br][s4]);
-            }
-            else
-              HF[br][bc][s4] = sel(live, s4v[br][s4], 0.0);
-          }
-      }
-      // Qxu = Fx' T2 (rows a_t of the columns c + 16 b).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
-      vf Qxu[B][3];
-      {
-        for(int t = 0; t < 3; t++)
-        {
-          const vf f = ld(mem.Fx, arow[t]);
-          for(int b = 0; b < B; b++) Qxu[b][t] = f * ld(mem.T2, c + 16 * b);
-        }
-        W64_UNROLL(CCC_TILE_U_PROD)
-        for(int bb = 1; bb < S; bb++)
-        {
-          vf tb[B];
-          for(int b = 0; b < B; b++) tb[b] = ld(mem.T2, c + 16 * b + bb * M);
-          for(int t = 0; t < 3; t++)
-          {
-            const vf f = ld(mem.Fx, arow[t] + bb * S);
-            for(int b = 0; b < B; b++) Qxu[b][t] = vfma(f, tb[b], Qxu[b][t]);
-          }
-        }
-        for(int b = 0; b < B; b++)
-          for(int t = 0; t < 3; t++) Qxu[b][t] = sel(in[b] && aval[t], Qxu[b][t], 0.0);
-      }
-      // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
-      vf Qxx[3];
-      {
-        for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
-        W64_UNROLL(CCC_TILE_U_PROD)
-        for(int b = 0; b < S; b++)
-        {
-          const vf tb = ld(mem.T1, col + b * S);
-          for(int t = 0; t < 3; t++) Qxx[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxx[t]);
-        }
-      }
-      wave_sync();
-      for(int t = 0; t < 3; t++)
-      {
-        st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
-        for(int b = 0; b < B; b++)
-          st(mem.Zl, arow[t] * LT + c + 16 * b, Qxu[b][t], aval[t]); // (Qxu waits in Z's place while the box-QP runs)
-      }
-      TILE_PROF_ADD(TP_PRODUCTS);
-      // box-QP and gains
-      vf k[B], K[B][3];
-      for(int b = 0; b < B; b++)
-      {
-        k[b] = splat(0.0);
-        for(int t = 0; t < 3; t++) K[b][t] = splat(0.0);
-      }
-      if(m > 0)
-      {
-        vf lo[B], hi[B];
-        for(int b = 0; b < B; b++)
-        {
-          lo[b] = sel(in[b], P.flo - u[b], 0.0);
-          hi[b] = sel(in[b], P.fhi - u[b], 0.0);
-          // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
-          k[b] = (mprev == m) ? kprev[b] : splat(0.0);
-        }
-        mask_t skip;
-        vf rdv[B];
-        const int rc = box_qp(m, HF, Qu, lo, hi, k, skip, rdv);
-        if(rc < 1) return false;
-        TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
-        // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
-        vb fr[B];
-        vf rhs[B][3];
-        for(int b = 0; b < B; b++)
-        {
-          fr[b] = !row_in(skip, b);
-          for(int t = 0; t < 3; t++) rhs[b][t] = sel(fr[b], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
-        }
-        solve<3>(rhs, skip, rdv);
-        for(int b = 0; b < B; b++)
-          for(int t = 0; t < 3; t++) K[b][t] = sel(fr[b] && aval[t], -rhs[b][t], 0.0);
-      }
-      // gains -> global memory (the forward passes read them) and K' -> LDS
-      for(int b = 0; b < B; b++)
-      {
-        st(I.ks + static_cast<long>(i) * M, c + 16 * b, k[b], g == 0);
-        for(int t = 0; t < 3; t++)
-        {
-          st(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + arow[t], K[b][t], aval[t]);
-          st(mem.T2, arow[t] * LT + c + 16 * b, K[b][t], aval[t]);
-        }
-      }
-      TILE_PROF_ADD(TP_GAINS);
-      // termination measure: max_c |k_c| / (|u_c| + 1)
-      {
-        vf mx = sel(in[0], vabs(k[0]) / (vabs(u[0]) + 1.0), 0.0);
-        for(int b = 1; b < B; b++) mx = vmax(mx, sel(in[b], vabs(k[b]) / (vabs(u[b]) + 1.0), 0.0));
-        gsum += read_lane(max16(mx), 0);
-      }
-      // dV += [k'Qu, 1/2 k'Quu k].  SPEC: sumM(k_c Qu_c), 0.5 sumM(k_c (Quu k)_c)
-      for(int b = 0; b < B; b++)
-        for(int t = 0; t < 3; t++) Qxu[b][t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
-      vf t4[B];
-      matvec_u(HF, Hd, k, 0, t4);
-      {
-        vf t[B];
-        for(int b = 0; b < B; b++) t[b] = k[b] * Qu[b];
-        dV0 += read_lane(sumM(t), 0);
-        for(int b = 0; b < B; b++) t[b] = k[b] * t4[b];
-        dV1 += 0.5 * read_lane(sumM(t), 0);
-      }
-      // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + sumM
-      {
-        vf q2[B];
-        for(int b = 0; b < B; b++) q2[b] = t4[b] + Qu[b];
-        for(int t = 0; t < 3; t++)
-        {
-          vf w[B];
-          for(int b = 0; b < B; b++) w[b] = vfma(Qxu[b][t], k[b], K[b][t] * q2[b]);
-          const vf v = sumM(w);
-          st(mem.vxn, arow[t], v, aval[t] && (c == 0));
-        }
-      }
-      wave_sync();
-      // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [row_dot] + 2 Qxu[a][c]
-      wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
-      for(int t = 0; t < 3; t++)
-      {
-        W64_UNROLL(CCC_TILE_U_Z)
-        for(int gg = 0; gg < 4; gg++)
-        {
-          const int a = gg + 4 * t;
-          if(a >= S) break;
-          vf yb[B][4];
-          for(int bc = 0; bc < B; bc++)
-            for(int s4 = 0; s4 < 4; s4++) yb[bc][s4] = ld(mem.T2, g * 4 + s4 + 16 * bc + a * LT);
-          for(int br = 0; br < B; br++)
-          {
-            const vf z = row_dot([&](int bc, int s) { return bc == br ? Hd[br][s] : HF[br][bc][s]; }, yb) + 2.0 * Qxu[br][t];
-            st(mem.Zl, c + 16 * br + a * LT, z, g == gg);
-          }
-        }
-      }
-      st(mem.Vx, c, ld(mem.Qx, seli(inS, c, spl(0))) + ld(mem.vxn, seli(inS, c, spl(0))), inS && (g == 0));
-      wave_sync();
-      // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + sum_c (K[c][a] Z[c][b] + K[c][b] Z[c][a]))
-      // SPEC: acc = 0; for c = 0 .. M-1: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
-      for(int q = 0; q < NPASS; q++)
-      {
-        const vi pidx = lane + 64 * q;
-        const vb pv = pidx < NP;
-        const vi ab = ldb(mem.pair, seli(pv, pidx, spl(0)));
-        const vi pa = ab & 15, pb = ab >> 4;
-        vf acc = splat(0.0);
-        W64_UNROLL(CCC_TILE_U_PAIR)
-        for(int r = 0; r < M; r++)
-        {
-          acc = vfma(ld(mem.T2, pa * LT + r), ld(mem.Zl, pb * LT + r), acc);
-          acc = vfma(ld(mem.T2, pb * LT + r), ld(mem.Zl, pa * LT + r), acc);
-        }
-        const vf v = 0.5 * ((ld(mem.T1, pa * S + pb) + ld(mem.T1, pb * S + pa)) + acc);
-        st(mem.Vxx, pa * S + pb, v, pv);
-        st(mem.Vxx, pb * S + pa, v, pv);
-      }
-      wave_sync();
-      TILE_PROF_ADD(TP_VALUE);
-      for(int b = 0; b < B; b++) kprev[b] = k[b];
+      bool ok;
+      if constexpr(B == 1)
+        ok = backward_step<1>(i, m, ph, x, u, kprev, mprev, gsum);
+      else if constexpr(B == 2)
+        ok = m <= 16 ? backward_step<1>(i, m, ph, x, u, kprev, mprev, gsum) : backward_step<2>(i, m, ph, x, u, kprev, mprev, gsum);
+      else
+        ok = m <= 16 ? backward_step<1>(i, m, ph, x, u, kprev, mprev, gsum)
+                     : (m <= 32 ? backward_step<2>(i, m, ph, x, u, kprev, mprev, gsum) : backward_step<4>(i, m, ph, x, u, kprev, mprev, gsum));
+      if(!ok) return false;
       mprev = m;
     }
     return true;
@@ -1081,6 +1112,38 @@ struct Solver
   // ------------------------------------------------------------------------------------------------ forward passes
   // Four candidates at once: row g rolls out alpha[first + g] into slot cand[g].  Returns the costs per row.
   static constexpr bool kPrefetchK = (B == 1); // the gain rows of the next step fetched a step ahead (registers permitting)
+  // one step of the rollouts with the first AB <= B blocks of 16 ridges live (the further ones are written as zeros)
+  template<int AB>
+  W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, const vf (&ui)[B], const vf (&ki)[B],
+                           const vf (&Krp)[kPrefetchK ? B : 1][kPrefetchK ? S : 1], vf & x, vf & costc)
+  {
+    const vf dx = x - xi;
+    // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
+    vf un[B];
+    for(int b = 0; b < AB; b++)
+    {
+      const vb in = c + 16 * b < m;
+      vf Kr[S];
+      for(int a = 0; a < S; a++)
+      {
+        if constexpr(kPrefetchK)
+          Kr[a] = Krp[b][a];
+        else
+          Kr[a] = ldm(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + a, in);
+      }
+      vf s = ui[b] + alpha * ki[b];
+      s = feedback<0>(s, dx, Kr);
+      un[b] = sel(in, vmin(vmax(s, P.flo), P.fhi), 0.0);
+      st(I.ubuf, uoff + i * M + c + 16 * b, un[b], c < 16);
+    }
+    for(int b = AB; b < B; b++) st(I.ubuf, uoff + i * M + c + 16 * b, splat(0.0), c < 16);
+    costc = costc + running_cost<AB>(i, x, un);
+    Terms T;
+    terms_of<AB>(ph, m, x, un, T);
+    x = state_eq(T, x);
+    st(I.xbuf, xoff + (i + 1) * S + c, x, inS);
+  }
+
   CCC_TILE_PIECE vf forward_pass(int first, const int (&cand)[4])
   {
     const int N = P.N;
@@ -1110,21 +1173,15 @@ struct Solver
     for(int i = 0; i < N; i++)
     {
       const int m = m_n, ph = ph_n;
-      vb in[B];
-      vf ui[B], ki[B], Kr[B][S];
+      vf ui[B], ki[B];
+      vf Krp[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
       const vf xi = xi_n;
       for(int b = 0; b < B; b++)
       {
-        in[b] = c + 16 * b < m;
         ui[b] = ui_n[b];
         ki[b] = ki_n[b];
-        for(int a = 0; a < S; a++)
-        {
-          if constexpr(kPrefetchK)
-            Kr[b][a] = Kr_n[b][a];
-          else
-            Kr[b][a] = ldm(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + a, in[b]);
-        }
+        if constexpr(kPrefetchK)
+          for(int a = 0; a < S; a++) Krp[b][a] = Kr_n[b][a];
       }
       if(i + 1 < N)
       {
@@ -1140,21 +1197,24 @@ struct Solver
             for(int a = 0; a < S; a++) Kr_n[b][a] = ldm(I.Ks + static_cast<long>(i + 1) * M * S, (c + 16 * b) * S + a, inn);
         }
       }
-      const vf dx = x - xi;
-      // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
-      vf un[B];
-      for(int b = 0; b < B; b++)
+      if constexpr(B == 1)
+        forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+      else if constexpr(B == 2)
       {
-        vf s = ui[b] + alpha * ki[b];
-        s = feedback<0>(s, dx, Kr[b]);
-        un[b] = sel(in[b], vmin(vmax(s, P.flo), P.fhi), 0.0);
-        st(I.ubuf, uoff + i * M + c + 16 * b, un[b], c < 16);
+        if(m <= 16)
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+        else
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
       }
-      costc = costc + running_cost(i, x, un);
-      Terms T;
-      terms_of(ph, m, x, un, T);
-      x = state_eq(T, x);
-      st(I.xbuf, xoff + (i + 1) * S + c, x, inS);
+      else
+      {
+        if(m <= 16)
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+        else if(m <= 32)
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+        else
+          forward_step<4>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+      }
     }
     const vf total = costc + terminal_cost(x);
     TILE_PROF_ADD(TP_FORWARD);
@@ -1190,9 +1250,9 @@ struct Solver
         u[b] = I.u_init ? ldm(I.u_init + static_cast<long>(i) * M, c + 16 * b, in) : splat(0.0);
         st(I.ubuf, i * M + c + 16 * b, u[b], g == 0);
       }
-      cc = cc + running_cost(i, x, u);
+      cc = cc + running_cost<B>(i, x, u);
       Terms T;
-      terms_of(ph, m, x, u, T);
+      terms_of<B>(ph, m, x, u, T);
       x = state_eq(T, x);
       st(I.xbuf, (i + 1) * S + c, x, inS && (g == 0));
     }

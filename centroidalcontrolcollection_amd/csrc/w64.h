@@ -38,8 +38,10 @@
 #define W64_PRAGMA_(x) _Pragma(#x)
 #if defined(__clang__)
 #  define W64_UNROLL(n) W64_PRAGMA_(unroll n)
+#  define W64_UNROLL_T(n) W64_PRAGMA_(unroll n) // n: a template-dependent constant
 #else
 #  define W64_UNROLL(n) W64_PRAGMA_(GCC unroll n)
+#  define W64_UNROLL_T(n) // (g++ 11 takes literals only; the host build is the emulation: unrolling does not matter)
 #endif
 
 namespace w64
