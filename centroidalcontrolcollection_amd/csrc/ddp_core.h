@@ -355,9 +355,8 @@ template<int S, int M>
 struct Solver
 {
   static constexpr int LQ = Mem<S, M>::LQ;
-  static_assert(M == 16 || M == 32, "a row of the M x M matrices per lane of an M-lane group");
+  static_assert(M == 16, "a row of the 16 x 16 input-space matrices per lane of a 16-lane group");
   static constexpr unsigned long long kRowMask = (1ull << M) - 1ull; // the lanes of the first M-lane group
-  static constexpr bool kHalf = (M == 32); // a second compile-time size, M / 2 = 16 ridges (see box_qp)
 
   // entry (i, k) of the regularised Quu_F the box-QP works on
   CCC_DDP_FN double quuF(int i, int k) const
@@ -679,7 +678,7 @@ struct Solver
   CCC_DDP_FN int box_qp(int m)
   {
     // (compile-time sizes: the full M, and at M = 32 also 16 -- a single-support step of a walk: size tests fold away)
-    return m == M ? box_qp_dev<M>(m) : (kHalf && m == M / 2 ? box_qp_dev<kHalf ? M / 2 : M>(m) : box_qp_dev<0>(m));
+    return m == M ? box_qp_dev<M>(m) : box_qp_dev<0>(m);
   }
 
   template<int MM>
@@ -705,7 +704,7 @@ struct Solver
     // 64 readlanes of every sum were what the iteration spent its time on -- through LDS: every lane publishes its
     // entry (mem.t4, free until the value update), all read the vector back as 128-bit broadcasts.  The sums themselves
     // run in the same order either way.
-    constexpr bool kVectorViaLds = (M == 32);
+    constexpr bool kVectorViaLds = false; // (an LDS broadcast instead of v_readlane: was the 32-ridge build's path)
     double * const vbuf = mem.t4;
     auto everywhere = [&](double v, double (&out)[M]) {
       if constexpr(kVectorViaLds)
@@ -1030,8 +1029,6 @@ struct Solver
     const unsigned long long clm = clamped_mask(m);
     if(m == M)
       cholesky_phase<M>(m, clm);
-    else if(kHalf && m == M / 2)
-      cholesky_phase<kHalf ? M / 2 : M>(m, clm);
     else
       cholesky_phase<0>(m, clm);
     return mem.ic[IC_OK] != 0;
@@ -1110,7 +1107,7 @@ struct Solver
       // until the value update; LDS operations of a wavefront execute in order, so the reads of column j see its writes
       // and are done before column j + 1 is written).  Measured: LDS +1.6 % at M = 32 and +3 % for the 12-state model,
       // -3 % for the 9-state model at M = 16.
-      constexpr bool kColumnViaLds = (M == 32) || (S == 12);
+      constexpr bool kColumnViaLds = (S == 12);
       double * const col = mem.t4;
 #  pragma unroll
       for(int j = 0; j < M; ++j)
@@ -1214,8 +1211,6 @@ struct Solver
 #if CCC_DDP_FAST
     if(m == M)
       solve_free_phase<M>(m, v);
-    else if(kHalf && m == M / 2)
-      solve_free_phase<kHalf ? M / 2 : M>(m, v);
     else
       solve_free_phase<0>(m, v);
 #else
@@ -1317,8 +1312,6 @@ struct Solver
 #if CCC_DDP_FAST
     if(m == M)
       gains_phase<M>(m);
-    else if(kHalf && m == M / 2)
-      gains_phase<kHalf ? M / 2 : M>(m);
     else
       gains_phase<0>(m);
 #else
@@ -1399,8 +1392,7 @@ struct Solver
       const int m = dim_of(i);
       // the usual case of a full 16-ridge contact gets its own instantiation: index arithmetic by constants, loops the
       // compiler can unroll (same statements, same results)
-      const bool ok = (m == M) ? backward_step<M>(i, m, sr)
-                               : ((kHalf && m == M / 2) ? backward_step<kHalf ? M / 2 : M>(i, m, sr) : backward_step<0>(i, m, sr));
+      const bool ok = (m == M) ? backward_step<M>(i, m, sr) : backward_step<0>(i, m, sr);
       if(!ok) return false;
     }
     return true;
