@@ -524,7 +524,7 @@ def test_gpu_reaches_the_golden_minimisers(name):
     assert share >= tg.MIN_SAME_BASIN[name], share
 
 
-def _full_size_properties(model, n, N, dt, max_iter, seed):
+def _full_size_properties(model, n, N, dt, max_iter, seed, make=None):
     """Solver-independent properties of a FULL-SIZE batch computed from the GPU outputs alone with the numpy restatement
     of the problem (tests/ddp_nlp.py): limits, rollout consistency (x is the trajectory of u under the reference's
     stateEq), the reported cost is J(u), the cost never exceeds that of the cold start it began from, and -- on the
@@ -532,8 +532,19 @@ def _full_size_properties(model, n, N, dt, max_iter, seed):
     import ddp_nlp
 
     srb = model == 1
-    prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=seed, srb=srb)
-    d = (_srb if srb else _cen)(N, dt, max_iter)
+    if make is None:
+        prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=seed, srb=srb)
+        d = (_srb if srb else _cen)(N, dt, max_iter)
+    else:
+        # (another workload: `make` returns the problems; the handle gets their phase count and ridge stride)
+        prob, x0 = make(n, N, dt, seed=seed, srb=srb)
+        kw = dict(max_phases=prob["phase_dim"].shape[1], max_ridges=prob["phase_vertex"].shape[2])
+        if srb:
+            d = DdpSingleRigidBody(100.0, dt, N, DdpSingleRigidBody.WeightParam(
+                running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0), terminal_ori=(0.5,) * 3), **kw)
+        else:
+            d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0)), **kw)
+        d.ddp_solver_.config().max_iter = max_iter
     r = d.planOnceBatch(prob, x0, want_x=True)
     u = r["u"]
     assert np.all(np.isfinite(u)) and np.all(u >= 0.0) and np.all(u <= 1e6)
@@ -567,6 +578,27 @@ def test_config3_full_size_properties():
     assert s["conv"].mean() >= 0.5                 # (20 iterations: most, not all, have met a termination test)
     assert s["pg"][s["conv"]].max() <= 5e-3 and np.median(s["pg"][s["conv"]]) <= 1e-4
     assert np.all(s["J"][s["conv"]] < 20.0)        # converged plans track the reference (cold start: J0 ~ 1e5)
+
+
+def test_walking_and_multi_contact_full_size_properties():
+    """The same solver-independent checks on the workloads beyond BASELINE's configs at bench size: double-support walking
+    (32 ridges per step, batch 4096) and feet + hands multi-contact motions (64 ridges, batch 2048) -- the tile kernel with two
+    / four ridge blocks and its per-step block skipping."""
+    def walking(n, N, dt, seed, srb):
+        base, x0 = fd.make_walking_batch(1024, N, dt, seed=seed, srb=srb)
+        k = n // 1024
+        return {a: np.concatenate([v] * k) for a, v in base.items()}, np.concatenate([x0] * k)
+
+    s = _full_size_properties(0, 4096, 40, 0.05, 20, seed=20250928, make=walking)
+    print("walking: converged %.3f, proj-grad median %.2e max %.2e, iters mean %.1f" % (
+        s["conv"].mean(), np.median(s["pg"][s["conv"]]), s["pg"][s["conv"]].max(), s["iters"].mean()))
+    assert np.all(s["status"] >= 0) and s["conv"].mean() >= 0.5
+    assert s["pg"][s["conv"]].max() <= 5e-3 and np.median(s["pg"][s["conv"]]) <= 1e-4
+    s = _full_size_properties(0, 2048, 30, 0.05, 20, seed=20250928, make=lambda n, N, dt, seed, srb: fd.make_multicontact_batch(n, N, dt, seed=seed, srb=srb))
+    print("multi-contact: converged %.3f, proj-grad median %.2e max %.2e, iters mean %.1f" % (
+        s["conv"].mean(), np.median(s["pg"][s["conv"]]), s["pg"][s["conv"]].max(), s["iters"].mean()))
+    assert np.all(s["status"] >= 0) and s["conv"].mean() >= 0.5
+    assert s["pg"][s["conv"]].max() <= 5e-3 and np.median(s["pg"][s["conv"]]) <= 1e-4
 
 
 def test_config5_full_size_properties():
