@@ -521,3 +521,19 @@ def test_config4_full_size_kkt_properties():
     # (relative to the gradient's scale; the Hessian's condition number is 1e6 .. 1e7, the CPU oracle's own answers sit at
     #  6e-8 on this measure.  Measured on MI355X: median 1e-8, max 3e-6 over 65536 instances)
     assert np.median(stat) <= 1e-7 and np.percentile(stat, 99.9) <= 2e-6 and stat.max() <= 2e-5
+
+
+def test_walking_and_multi_contact_bench_size_kkt_properties():
+    """The KKT check of the test above on the workloads beyond BASELINE's configs, at bench size: double-support walking
+    (32 ridge slots, 30 steps, batch 8192) and feet + hands multi-contact steps (64 ridge slots, 20 steps, batch 2048)."""
+    for name, (prob, x0), N, M in (("walking", fd.make_xy_walking_batch(8192, 30, 0.1, M=32, seed=20250928), 30, 32),
+                                   ("multi-contact", fd.make_xy_multicontact_batch(2048, 20, 0.1, seed=20250928), 20, 64)):
+        r = LinearMpcXY(100.0, 0.1, N, max_ridges=M).planOnceBatch(prob, x0, want_all=True)
+        assert np.all(r["status"] == 0), name
+        eq, viol, stat, has_free = _xy_kkt_residuals(prob, x0, r["lam"])
+        print("%s: eq %.2e  bound violation %.2e  stationarity max %.2e p99 %.2e median %.2e" % (
+            name, eq.max(), viol.max(), stat.max(), np.percentile(stat, 99), np.median(stat)))
+        assert np.all(has_free), name
+        assert eq.max() <= 1e-10 and viol.max() <= 1e-9, name
+        # (30 steps: the Hessian's condition number grows with the horizon -- measured median 1.4e-7, max 3.6e-6 for walking)
+        assert np.median(stat) <= 5e-7 and stat.max() <= 5e-5, name
