@@ -168,11 +168,11 @@ def _ddp_valu(S, M, N, iters, walking, precision):
     m = M
     per_step = 2 * (S * S * m + S * m * m) + 2 * (S ** 3 + S * S * m) + m ** 3 / 3 + 2 * m * m * S + 6e3 * (S / 9.0) ** 2
     pmc = None
-    if not walking and precision == 64:
+    if precision == 64:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_ddp_valu_counters.json")
         if os.path.exists(path):
             with open(path) as f:
-                pmc = json.load(f).get("S%d" % S)
+                pmc = json.load(f).get("S%d" % S if M == 16 else "S%dM%d" % (S, M))
     return dict(flop_per_solve=per_step * N * iters, flop_per_backward_step=per_step,
                 issue_frac=None if pmc is None else pmc["valu_issue_frac"],
                 wait_frac=None if pmc is None else pmc["wait_any_frac"],
