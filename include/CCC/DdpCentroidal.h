@@ -144,8 +144,9 @@ public:
   }
 
   /** \brief The C-ABI handle (<= 16 ridges per step, <= max_phases phases), for the flat-array batch entry points of
-      ccc_amd.h.  planOnce() itself takes any contact list up to 32 ridges per step and any number of phases: what the
-      fast kernel is not built for goes to a second, wide handle created on first need (ddp_shim::Handles). */
+      ccc_amd.h.  planOnce() itself takes any contact list up to 64 ridges per step and any number of phases: what the
+      constructor's tables do not hold goes to a further handle with the ridge stride it needs (16, 32 or 64), created on first
+      need (ddp_shim::Handles). */
   ccc_ddp_t * handle() const
   {
     return handles_.fast.get();

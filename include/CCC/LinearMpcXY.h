@@ -184,8 +184,8 @@ public:
   }
 
   /** \brief The C-ABI handle (16 ridge slots per step), for the flat-array entry points of ccc_amd.h.  planOnce() and
-      planOnceBatch() take any contact list up to 32 ridges per step: what 16 slots do not hold goes to a second handle
-      with max_ridges = 32, created on first need. */
+      planOnceBatch() take any contact list up to 64 ridges per step: what 16 slots do not hold goes to a further handle
+      with max_ridges = 32 or 64, created on first need. */
   ccc_xy_t * handle() const
   {
     return handle_.get();

@@ -437,7 +437,7 @@ int ccc_total_wrench_device(int64_t n, int max_ridges, const int32_t * dim, cons
  *   seg_ref      [n][K][6]     f64  RefData of the segment: CoM position (3), base orientation ZYX (3; SRB only)
  *   contact_dim  [n][C]        i32  ridges of contact-table entry c (0 = flight)
  *   contact_vertex / contact_ridge  [n][C][M][3]   f64  flattened contact -> vertex -> ridge; M = the planner handle's
- *                                                       max_ridges (16, or 32 with two surface contacts per entry)
+ *                                                       max_ridges (16, 32 or 64: one, two, up to four surface contacts per entry)
  *   time_eps                        added to every sampling time (the DDP tests add 1e-6, TestDdpCentroidal.cpp:39)
  * A sample at time t takes the first segment with t < seg_end.
  * ========================================================================================= */
