@@ -12,6 +12,21 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libccc_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# the ROCm installation the compiler belongs to ($ROCM_PATH, else two levels above hipcc)
+ROCM_ROOT = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(HIPCC)))
+
+
+def host_fma_flags():
+    """["-mfma"] on an x86 host whose CPU has FMA3 (faster std::fma in the host emulation of the tile kernel), else []."""
+    import platform
+
+    if platform.machine() not in ("x86_64", "AMD64"):
+        return []
+    try:
+        with open("/proc/cpuinfo") as f:
+            return ["-mfma"] if " fma " in f.read().replace("\n", " ") else []
+    except OSError:
+        return []
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

@@ -97,6 +97,7 @@ extern "C" void ccc_ddp_default_config(ccc_ddp_config_t * c)
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
   c->reg_type = 1;
   c->precision = 64;
+  c->warm_start_guard = 1;
 }
 
 extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t ** out)
@@ -184,6 +185,7 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   P.cost_thre = h->cfg.cost_update_thre;
   for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
   P.reg_type = h->cfg.reg_type;
+  P.warm_guard = h->cfg.warm_start_guard ? 1 : 0;
 }
 
 // the tile kernel takes: every ridge stride (any number of phases and steps), the default regularisation, fp64

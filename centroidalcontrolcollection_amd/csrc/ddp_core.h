@@ -112,6 +112,7 @@ struct Params
   double k_rel_norm_thre, lambda_thre, ratio_thre, cost_thre;
   double alpha[11];
   int reg_type; // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
+  int warm_guard; // ccc_ddp_config_t::warm_start_guard
 };
 
 // Per-instance problem data and workspace (global memory)
@@ -1654,8 +1655,9 @@ struct Solver
   {
     const int N = P.N;
     const bool initial = alpha < 0;
-    double * xo = initial ? I.xs : I.xc;
-    double * uo = initial ? I.us : I.uc;
+    const bool cold = alpha < -1.5; // the warm-start guard's rollout of zero inputs from x0 into the candidate buffers
+    double * xo = (initial && !cold) ? I.xs : I.xc;
+    double * uo = (initial && !cold) ? I.us : I.uc;
     const int lane = static_cast<int>(threadIdx.x & 63);
     const bool st = lane < S;
     double x = st ? (initial ? I.x0[lane] : I.xs[lane]) : 0.0;
@@ -1677,7 +1679,7 @@ struct Solver
     auto fetch = [&](int i, double & us_v, double & ks_v, double (&Kr_v)[S], double (&xi_v)[S], double & ref_v) {
       const int ln = lane < M ? lane : 0;
       if(initial)
-        us_v = I.u_init ? I.u_init[static_cast<long>(i) * M + ln] : 0.0;
+        us_v = (I.u_init && !cold) ? I.u_init[static_cast<long>(i) * M + ln] : 0.0;
       else
       {
         us_v = I.us[static_cast<long>(i) * M + ln];
@@ -1788,7 +1790,7 @@ struct Solver
     }
     __syncthreads();
     if(st) mem.x[lane] = x;
-    if(lane == kCostLane) mem.sc[initial ? SC_COST : SC_COSTC] = cost;
+    if(lane == kCostLane) mem.sc[(initial && !cold) ? SC_COST : SC_COSTC] = cost;
     __syncthreads();
   }
 #endif
@@ -1804,8 +1806,10 @@ struct Solver
 #endif
     const int N = P.N;
     const bool initial = alpha < 0;
-    double * xo = initial ? I.xs : I.xc;
-    double * uo = initial ? I.us : I.uc;
+    const bool cold = alpha < -1.5; // the warm-start guard's rollout of zero inputs from x0 into the candidate buffers
+    const int cslot = (initial && !cold) ? SC_COST : SC_COSTC;
+    double * xo = (initial && !cold) ? I.xs : I.xc;
+    double * uo = (initial && !cold) ? I.us : I.uc;
     phase([&](int lane) {
       if(lane < S)
       {
@@ -1813,7 +1817,7 @@ struct Solver
         mem.x[lane] = v;
         xo[lane] = v;
       }
-      if(lane == 0) mem.sc[initial ? SC_COST : SC_COSTC] = 0.0;
+      if(lane == 0) mem.sc[cslot] = 0.0;
     });
     for(int i = 0; i < N; i++)
     {
@@ -1825,7 +1829,7 @@ struct Solver
           if(lane < m)
           {
             if(initial)
-              s = I.u_init ? I.u_init[static_cast<long>(i) * M + lane] : 0.0;
+              s = (I.u_init && !cold) ? I.u_init[static_cast<long>(i) * M + lane] : 0.0;
             else
             {
               s = I.us[static_cast<long>(i) * M + lane] + alpha * I.ks[static_cast<long>(i) * M + lane];
@@ -1841,7 +1845,7 @@ struct Solver
       });
       state_eq(i, mem.x, mem.un, mem.xn);
       phase([&](int lane) {
-        if(lane == 32) mem.sc[initial ? SC_COST : SC_COSTC] += running_cost(i, mem.x, mem.un);
+        if(lane == 32) mem.sc[cslot] += running_cost(i, mem.x, mem.un);
         if(lane < S) xo[static_cast<long>(i + 1) * S + lane] = mem.xn[lane];
       });
       phase([&](int lane) {
@@ -1849,7 +1853,7 @@ struct Solver
       });
     }
     phase([&](int lane) {
-      if(lane == 0) mem.sc[initial ? SC_COST : SC_COSTC] += terminal_cost(mem.x);
+      if(lane == 0) mem.sc[cslot] += terminal_cost(mem.x);
     });
   }
 
@@ -1893,6 +1897,17 @@ struct Solver
     const long long prof_begin_ = (long long)__builtin_readcyclecounter();
 #endif
     rollout(-1.0);
+    if(P.warm_guard && I.u_init)
+    {
+      // warm-start guard (oracle/ddp.c): keep the warm start only if it rolls out no worse than zero inputs
+      rollout(-2.0);
+      if(!(mem.sc[SC_COST] <= mem.sc[SC_COSTC]))
+        phase([&](int lane) {
+          for(int e = lane; e < (N + 1) * S; e += kWave) I.xs[e] = I.xc[e];
+          for(int e = lane; e < N * M; e += kWave) I.us[e] = I.uc[e];
+          if(lane == 0) mem.sc[SC_COST] = mem.sc[SC_COSTC];
+        });
+    }
     int iter = 0, status = 0;
     for(iter = 1; iter <= P.max_iter; iter++)
     {

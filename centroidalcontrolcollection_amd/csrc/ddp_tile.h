@@ -1232,14 +1232,14 @@ struct Solver
       return s;
   }
 
-  // the trajectory of the initial inputs (slot 0) and its cost
-  CCC_TILE_PIECE void initial_rollout()
+  // the trajectory of the initial inputs (u_init, or zeros) into `slot`; returns its cost
+  CCC_TILE_PIECE double initial_rollout(int slot, const double * u_init)
   {
     const int N = P.N;
-    cur = 0;
+    const long xo = static_cast<long>(slot) * (N + 1) * S, uo = static_cast<long>(slot) * N * M;
     vf x = ldm(I.x0, c, inS);
     vf cc = splat(0.0);
-    st(I.xbuf, c, x, inS && (g == 0));
+    st(I.xbuf + xo, c, x, inS && (g == 0));
     for(int i = 0; i < N; i++)
     {
       const int ph = phase_of(i), m = dim_of_phase(ph);
@@ -1247,16 +1247,16 @@ struct Solver
       for(int b = 0; b < B; b++)
       {
         const vb in = c + 16 * b < m;
-        u[b] = I.u_init ? ldm(I.u_init + static_cast<long>(i) * M, c + 16 * b, in) : splat(0.0);
-        st(I.ubuf, i * M + c + 16 * b, u[b], g == 0);
+        u[b] = u_init ? ldm(u_init + static_cast<long>(i) * M, c + 16 * b, in) : splat(0.0);
+        st(I.ubuf + uo, i * M + c + 16 * b, u[b], g == 0);
       }
       cc = cc + running_cost<B>(i, x, u);
       Terms T;
       terms_of<B>(ph, m, x, u, T);
       x = state_eq(T, x);
-      st(I.xbuf, (i + 1) * S + c, x, inS && (g == 0));
+      st(I.xbuf + xo, (i + 1) * S + c, x, inS && (g == 0));
     }
-    cost = read_lane(cc + terminal_cost(x), 0);
+    return read_lane(cc + terminal_cost(x), 0);
   }
 
   // ------------------------------------------------------------------------------------------------ the solve
@@ -1277,7 +1277,19 @@ struct Solver
     init();
     lambda = P.lambda0;
     dlambda = P.dlambda0;
-    initial_rollout();
+    cur = 0;
+    cost = initial_rollout(0, I.u_init);
+    if(P.warm_guard && I.u_init)
+    {
+      // warm-start guard (oracle/ddp_tile.c; not nmpc_ddp): a warm start that rolls out worse than zero inputs -- the
+      // start of src/DdpCentroidal.cpp:221-229 -- or not finite is dropped
+      const double cold = initial_rollout(1, nullptr);
+      if(!(cost <= cold))
+      {
+        cur = 1;
+        cost = cold;
+      }
+    }
     int iter = 0, status = 0;
     for(iter = 1; iter <= P.max_iter; iter++)
     {

@@ -962,6 +962,7 @@ extern "C" void ccc_ddpzmp_default_config(ccc_ddp_config_t * c)
   for(int i = 0; i < 11; i++) c->alpha_list[i] = std::pow(10.0, -3.0 * i / 10.0);
   c->reg_type = 1;
   c->precision = 64;
+  c->warm_start_guard = 0; // (ignored by this class)
 }
 
 extern "C" int ccc_ddpzmp_create(double mass, double horizon_dt, int horizon_steps, const double * weights, int device,

@@ -141,6 +141,15 @@ struct ShardGroup
     if(e != ncclSuccess) return fail(CCC_ERR_HIP, "%s: ncclAllGather failed: %s", who, R.GetErrorString(e));
     return CCC_OK;
   }
+  // every stream of the group, whatever the others report (error paths)
+  void drain()
+  {
+    for(int r = 0; r < size(); r++)
+    {
+      DeviceGuard g(devices[r]);
+      (void)hipStreamSynchronize(streams[r]);
+    }
+  }
   int synchronize()
   {
     for(int r = 0; r < size(); r++)
@@ -160,6 +169,16 @@ __global__ void first_step_kernel(long n, int N, int M, const double * u, double
   u0[id] = u[(id / M) * N * M + id % M];
 }
 } // namespace
+
+// An entry documented as synchronous must not return while kernels it enqueued on other devices still write the
+// caller's buffers: on any error after the first launch, drain the group's streams, keep the error.
+static int fail_after_launch(ShardGroup & grp, int rc)
+{
+  const std::string keep = last_error();
+  grp.drain();
+  last_error() = keep;
+  return rc;
+}
 
 struct ccc_zmp_sharded
 {
@@ -275,10 +294,10 @@ extern "C" int ccc_zmp_sharded_plan_batch_device_ordered(ccc_zmp_sharded_t * h, 
   {
     rc = ccc_zmp_plan_batch_device(h->handles[r], n_per_device, x0[r], zlim[r], control_dt, zmp_all[r] + r * cnt, nullptr,
                                    status ? status[r] : nullptr, h->grp.streams[r]);
-    if(rc != CCC_OK) return rc;
+    if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
   }
   rc = h->grp.all_gather(zmp_all, cnt, who);
-  if(rc != CCC_OK) return rc;
+  if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
   return h->grp.synchronize();
 }
 
@@ -341,19 +360,21 @@ extern "C" int ccc_xy_sharded_plan_batch_device(ccc_xy_sharded_t * h, int64_t n_
   int rc = ccc_xy_get_params(h->handles[0], &prm, nullptr);
   if(rc != CCC_OK) return rc;
   const size_t cnt = static_cast<size_t>(n_per_device) * (prm.max_ridges ? prm.max_ridges : CCC_XY_MAX_RIDGES);
+  // (every per-device pointer is checked BEFORE anything is enqueued)
+  for(int r = 0; r < D; r++)
+    if(!dim[r] || !vertex[r] || !ridge[r] || !com_z[r] || !total_force_z[r] || !ref_out[r] || !x0[r] || !u0_all[r])
+      return fail(CCC_ERR_INVALID_ARGUMENT, "%s: NULL array for device %d", who, h->grp.devices[r]);
   rc = h->grp.order_after_caller(caller_streams);
   if(rc != CCC_OK) return rc;
   for(int r = 0; r < D; r++)
   {
-    if(!dim[r] || !vertex[r] || !ridge[r] || !com_z[r] || !total_force_z[r] || !ref_out[r] || !x0[r] || !u0_all[r])
-      return fail(CCC_ERR_INVALID_ARGUMENT, "%s: NULL array for device %d", who, h->grp.devices[r]);
     rc = ccc_xy_plan_batch_device(h->handles[r], n_per_device, dim[r], vertex[r], ridge[r], com_z[r], total_force_z[r],
                                   ref_out[r], x0[r], u0_all[r] + r * cnt, nullptr, status ? status[r] : nullptr,
                                   h->grp.streams[r]);
-    if(rc != CCC_OK) return rc;
+    if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
   }
   rc = h->grp.all_gather(u0_all, cnt, who);
-  if(rc != CCC_OK) return rc;
+  if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
   return h->grp.synchronize();
 }
 
@@ -431,26 +452,29 @@ extern "C" int ccc_ddp_sharded_plan_batch_device(ccc_ddp_sharded_t * h, int64_t 
     return fail(CCC_ERR_INVALID_ARGUMENT, "%s: NULL array list", who);
   const int D = h->grp.size();
   const size_t cnt = static_cast<size_t>(n_per_device) * h->M;
+  for(int r = 0; r < D; r++)
+    if(!phase_dim[r] || !phase_vertex[r] || !phase_ridge[r] || !step_phase[r] || !ref_pos[r] || !x0[r] || !u_out[r]
+       || !u0_all[r])
+      return fail(CCC_ERR_INVALID_ARGUMENT, "%s: NULL array for device %d", who, h->grp.devices[r]);
   int rc = h->grp.order_after_caller(caller_streams);
   if(rc != CCC_OK) return rc;
   for(int r = 0; r < D; r++)
   {
-    if(!phase_dim[r] || !phase_vertex[r] || !phase_ridge[r] || !step_phase[r] || !ref_pos[r] || !x0[r] || !u_out[r]
-       || !u0_all[r])
-      return fail(CCC_ERR_INVALID_ARGUMENT, "%s: NULL array for device %d", who, h->grp.devices[r]);
     rc = ccc_ddp_plan_batch_device(h->handles[r], n_per_device, phase_dim[r], phase_vertex[r], phase_ridge[r],
                                    step_phase[r], ref_pos[r], ref_ori ? ref_ori[r] : nullptr,
                                    inertia ? inertia[r] : nullptr, x0[r], u_init ? u_init[r] : nullptr, u_out[r], nullptr,
                                    iters ? iters[r] : nullptr, status ? status[r] : nullptr, cost ? cost[r] : nullptr,
                                    h->grp.streams[r]);
-    if(rc != CCC_OK) return rc;
+    if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
     DeviceGuard g(h->grp.devices[r]);
     const long total = static_cast<long>(cnt);
     hipLaunchKernelGGL(first_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->grp.streams[r],
                        (long)n_per_device, h->N, h->M, u_out[r], u0_all[r] + r * cnt);
-    CCC_HIP_CHECK(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if(le != hipSuccess)
+      return fail_after_launch(h->grp, fail(CCC_ERR_HIP, "%s: first_step_kernel: %s", who, hipGetErrorString(le)));
   }
   rc = h->grp.all_gather(u0_all, cnt, who);
-  if(rc != CCC_OK) return rc;
+  if(rc != CCC_OK) return fail_after_launch(h->grp, rc);
   return h->grp.synchronize();
 }

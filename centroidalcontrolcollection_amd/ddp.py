@@ -30,7 +30,8 @@ class Config(ctypes.Structure):
                 ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
                 ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double),
                 ("cost_update_ratio_thre", ctypes.c_double), ("cost_update_thre", ctypes.c_double),
-                ("alpha_list", ctypes.c_double * 11), ("reg_type", ctypes.c_int), ("precision", ctypes.c_int)]
+                ("alpha_list", ctypes.c_double * 11), ("reg_type", ctypes.c_int), ("precision", ctypes.c_int),
+                ("warm_start_guard", ctypes.c_int)]
 
 
 def _bind(L):

@@ -182,6 +182,12 @@ typedef struct
                   * derivatives, Q blocks, Cholesky factor, gains -- STORED in single precision, operated on in double;
                   * trajectories, rollouts, costs and all line-search and termination decisions stay in double.
                   * Not a nmpc_ddp option. */
+  int warm_start_guard; /* 1 (default): a warm start u_init whose open-loop rollout from x0 costs more than the rollout
+                  * of zero inputs -- the start planOnce() itself uses when InitialParam::u_list is empty,
+                  * src/DdpCentroidal.cpp:221-229 -- or is not finite, is replaced by zero inputs.  It fires on 1 to 7 of
+                  * the 601 control cycles of TestDdpSingleRigidBody.cpp:106-153 (one iteration per cycle on an unshifted
+                  * warm start) and is what makes that loop pass under perturbations.  0: the
+                  * recalled nmpc_ddp behaviour.  Not a nmpc_ddp option; ignored by CCC::DdpZmp. */
 } ccc_ddp_config_t;
 
 void ccc_ddp_default_config(ccc_ddp_config_t * cfg);
@@ -195,9 +201,11 @@ int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params);
 int ccc_ddp_get_config(const ccc_ddp_t * h, ccc_ddp_config_t * cfg);
 int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
 /* Which frozen ORDER OF THE LONG SUMS the handle's current configuration computes in (nmpc_ddp forms them with Eigen,
- * whose order is not pinned): 1 = the tile arithmetic (oracle/ddp_tile.c: trees, fma chains, LDL') of the default kernel
- * for max_ridges = 16, reg_type 1, precision 64; 0 = left-to-right sums (oracle/ddp.c: max_ridges = 32, reg_type 2,
- * precision 32).  Results of the two agree to rounding; bit-for-bit parity tests ask which one applies.  New. */
+ * whose order is not pinned): 1 = the tile arithmetic (oracle/ddp_tile.c: trees, fma chains, LDL') -- the default kernel at
+ * EVERY ridge stride (max_ridges 16, 32 and 64) when reg_type = 1 and precision = 64, and always at max_ridges = 64;
+ * 0 = left-to-right sums (oracle/ddp.c) -- the row-per-lane kernels that reg_type = 2, precision = 32 or the environment
+ * switch CCC_DDP_LEGACY (read ONCE, in ccc_ddp_create: it changes the answer's last bits) select; those exist for
+ * max_ridges = 16 only.  Results of the two agree to rounding; bit-for-bit parity tests ask which one applies.  New. */
 int ccc_ddp_arithmetic(const ccc_ddp_t * h);
 
 /* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,

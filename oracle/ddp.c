@@ -28,6 +28,8 @@
  *     (src/DdpCentroidal.cpp:199), which only matters when lambda is added to Quu.
  *     k = boxQP(Quu_F, Qu, lo - u, hi - u, warm start k_{i+1}); K_free = -Quu_F,ff^-1 Qxu_reg,f'; clamped rows of K = 0;
  *     dV += [k'Qu, 1/2 k'Quu k]; Vx = Qx + K'Quu k + K'Qu + Qxu k; Vxx = sym(Qxx + K'Quu K + K'Qxu' + Qxu K)
+ *   warm-start guard (config warm_start_guard, NOT nmpc_ddp -- this repository's addition, round 4): a warm start whose
+ *     open-loop rollout costs more than the rollout of zero inputs, or is not finite, is replaced by zero inputs.
  *   boxQP: projected Newton (Tassa's boxQP.m) with nmpc_ddp's BoxQP::Configuration: max_iter 500, grad_thre 1e-8,
  *     rel_improve_thre 1e-8, step_factor 0.6, min_step 1e-22, armijo_param 0.1.
  */
@@ -52,6 +54,7 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
   c->cost_update_thre = 1e-7;
   c->reg_type = 1;
   c->arith = 0;
+  c->warm_start_guard = 0;
   for(int i = 0; i < 11; i++) c->alpha_list[i] = pow(10.0, -3.0 * i / 10.0);
 }
 
@@ -550,6 +553,22 @@ int oracle_ddp_solve(const oracle_ddp_problem_t * p, const oracle_ddp_config_t *
     p->state_eq(p->user, i, d.x + (size_t)i * S, d.u + (size_t)i * M, d.x + (size_t)(i + 1) * S);
   }
   d.cost = rollout_cost(&d, d.x, d.u);
+  if(c->warm_start_guard && u_init)
+  {
+    /* warm-start guard (not nmpc_ddp; ccc_oracle.h): keep the warm start only if its rollout is no worse than the
+     * rollout of zero inputs, the cold start of src/DdpCentroidal.cpp:221-229 */
+    memcpy(d.xc, x0, sizeof(double) * S);
+    memset(d.uc, 0, sizeof(double) * nu);
+    for(int i = 0; i < N; i++)
+      p->state_eq(p->user, i, d.xc + (size_t)i * S, d.uc + (size_t)i * M, d.xc + (size_t)(i + 1) * S);
+    const double cold = rollout_cost(&d, d.xc, d.uc);
+    if(!(d.cost <= cold))
+    {
+      memcpy(d.x, d.xc, sizeof(double) * nx);
+      memcpy(d.u, d.uc, sizeof(double) * nu);
+      d.cost = cold;
+    }
+  }
   double initial_cost = d.cost;
 
   int iter = 0, status = 0, need_deriv = 1, n_accept = 0;

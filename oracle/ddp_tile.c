@@ -686,6 +686,29 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
     state_eq(m, &T, d.x + (size_t)i * S, d.x + (size_t)(i + 1) * S);
   }
   d.cost = d.cost + terminal_cost(m, d.x + (size_t)N * S);
+  if(c->warm_start_guard && u_init)
+  {
+    /* warm-start guard (ccc_oracle.h): the rollout of zero inputs, same arithmetic, into the first candidate slot */
+    double * xz = d.xc[0], * uz = d.uc[0];
+    memcpy(xz, x0, sizeof(double) * S);
+    double cold = 0;
+    for(int i = 0; i < N; i++)
+    {
+      double * ui = uz + (size_t)i * M_;
+      for(int r = 0; r < M_; r++) ui[r] = 0.0;
+      cold = cold + running_cost(m, i, xz + (size_t)i * S, ui);
+      terms_t T;
+      terms_of(m, i, xz + (size_t)i * S, ui, &T);
+      state_eq(m, &T, xz + (size_t)i * S, xz + (size_t)(i + 1) * S);
+    }
+    cold = cold + terminal_cost(m, xz + (size_t)N * S);
+    if(!(d.cost <= cold))
+    {
+      memcpy(d.x, xz, sizeof(double) * nx);
+      memcpy(d.u, uz, sizeof(double) * nu);
+      d.cost = cold;
+    }
+  }
   const double initial_cost = d.cost;
 
   int iter = 0, status = 0, n_accept = 0;

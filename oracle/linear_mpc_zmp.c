@@ -164,8 +164,18 @@ int oracle_zmp_proc_once(oracle_zmp_t * o, const double * zmin, const double * z
                          double control_dt, double * zmp, double * jerk_seq, int * iters)
 {
   int N = o->N;
-  double * ineq_vec = (double *)malloc((size_t)2 * N * sizeof(double));
-  double * sol = (double *)malloc((size_t)N * sizeof(double));
+  /* (per-thread scratch: no allocation per solve) */
+  static _Thread_local double * scratch = NULL;
+  static _Thread_local int scratch_n = 0;
+  if(N > scratch_n)
+  {
+    free(scratch);
+    scratch = (double *)malloc((size_t)3 * N * sizeof(double));
+    scratch_n = scratch ? N : 0;
+    if(!scratch) return 3;
+  }
+  double * ineq_vec = scratch;
+  double * sol = scratch + 2 * N;
   /* :54-55 */
   for(int i = 0; i < N; i++)
   {
@@ -190,8 +200,6 @@ int oracle_zmp_proc_once(oracle_zmp_t * o, const double * zmin, const double * z
   double com_pos = x0[0] + control_dt * x0[1] + 0.5 * pow(control_dt, 2) * x0[2];
   *zmp = clampd(com_pos + o->C[2] * com_acc, zmin[0], zmax[0]);
   if(jerk_seq) memcpy(jerk_seq, sol, (size_t)N * sizeof(double));
-  free(ineq_vec);
-  free(sol);
   return rc;
 }
 
@@ -203,7 +211,7 @@ int oracle_zmp_plan_batch(oracle_zmp_t * o, long n, const double * x0, const dou
   int N = o->N;
   int worst = 0;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 1 ? nthreads : 1) reduction(max : worst)
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 1 ? nthreads : 1) reduction(max : worst)
 #endif
   for(long b = 0; b < n; b++)
   {

