@@ -68,11 +68,27 @@ def host_cores():
         phys = psutil.cpu_count(logical=False) or threads
     except Exception:
         phys = threads
-    # a container may see fewer CPUs than the machine has
+    # a container may see fewer CPUs than the machine has: affinity mask and cgroup CPU quota
     try:
         threads = min(threads, len(os.sched_getaffinity(0)))
     except Exception:
         pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        threads = max(1, min(threads, int(quota + 0.5)))
     return threads, max(1, min(phys, threads))
 
 
@@ -105,7 +121,18 @@ def cpu_baseline(batch, seconds_budget=20.0):
         r = o.plan_batch(batch["x0"][:n_mt], batch["zlim"][:n_mt], 0.005, want_jerk=False, nthreads=cores)
         best = min(best, time.perf_counter() - t0)
         reps += 1
+    # where this host stops scaling (a cgroup may cap CPU time without saying so): rate at 1, 2, 4, ... threads, one
+    # repetition of a quarter batch each
+    curve = {}
+    t_ = 2
+    while t_ < cores:
+        nq = max(4096, n_all // 4)
+        t0 = time.perf_counter()
+        o.plan_batch(batch["x0"][:nq], batch["zlim"][:nq], 0.005, want_jerk=False, nthreads=t_)
+        curve[str(t_)] = round(nq / (time.perf_counter() - t0))
+        t_ *= 4
     return dict(value=n_mt / best, unit="solves/s", cores=cores, threads=cores, host_hardware_threads=threads, kind="port",
+                scaling_curve=curve,
                 sample="the %d-instance rank-0 batch, best of %d repetitions, OpenMP over instances, one thread per "
                        "physical core (%d); C restatement of the reference path (oracle/), not QLD" % (n_mt, reps, cores),
                 value_1thread=rate1, parallel_efficiency=(n_mt / best) / (rate1 * cores)), r["zmp"], n_mt

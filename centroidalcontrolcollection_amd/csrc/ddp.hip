@@ -69,8 +69,9 @@ struct ccc_ddp
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
   bool env_legacy = false;    // CCC_DDP_LEGACY: the row-per-lane kernels of csrc/ddp_core.h instead of the tile kernel
   bool fits_fast = false;     // the tables of the row-per-lane fast builds hold this handle's problems
-  int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip), grown on demand
+  int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip): one slot per resident workgroup
   double * ws_t = nullptr;
+  unsigned * ticket = nullptr; // its work-queue counter
   int num_cu = 0;
   // device workspace (grown on demand)
   int64_t cap = 0;
@@ -152,6 +153,7 @@ extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   free_ws(h);
   if(h->ws_t) (void)hipFree(h->ws_t);
+  if(h->ticket) (void)hipFree(h->ticket);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -188,11 +190,11 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   P.warm_guard = h->cfg.warm_start_guard ? 1 : 0;
 }
 
-// the tile kernel takes: every ridge stride (any number of phases and steps), the default regularisation, fp64
+// the tile kernel takes: every ridge stride (any number of phases and steps), both regularisations, fp64
 static bool use_tile(const ccc_ddp * h)
 {
-  if(h->M == CCC_DDP_MAX_RIDGES_MULTI) return true; // (the only build for 64 ridges: other configurations are refused)
-  return !h->env_legacy && h->cfg.reg_type == 1 && h->cfg.precision == 64;
+  if(h->M != CCC_DDP_MAX_RIDGES) return true; // (the only build for 32 and 64 ridges: other configurations are refused)
+  return !h->env_legacy && h->cfg.precision == 64;
 }
 
 extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
@@ -270,29 +272,36 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
-  if(h->M == CCC_DDP_MAX_RIDGES_MULTI && (h->cfg.reg_type != 1 || h->cfg.precision != 64))
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: max_ridges = %d is built for reg_type 1, precision 64",
-                CCC_DDP_MAX_RIDGES_MULTI);
+  if(h->M != CCC_DDP_MAX_RIDGES && h->cfg.precision != 64)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: max_ridges = %d is built for precision 64", h->M);
   if(use_tile(h))
   {
-    if(n > h->tcap)
+    const int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
+    if(grid > h->tcap)
     {
       CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
       if(h->ws_t) (void)hipFree(h->ws_t);
       h->ws_t = nullptr;
       h->tcap = 0;
-      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)n * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
-      h->tcap = n;
+      // (sized for a full resident set at once: later, larger batches do not allocate again)
+      const int full = ddp_tile_grid(1L << 40, h->M, h->num_cu);
+      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)full * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
+      h->tcap = full;
+    }
+    if(!h->ticket)
+    {
+      CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
+      CCC_HIP_CHECK(hipMalloc(&h->ticket, sizeof(unsigned)));
     }
     ddp_common::Params P;
     fill_params(h, P);
     DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
                x_out, nullptr, nullptr, nullptr, nullptr, iters, status, cost};
-    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
+    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, h->ticket, grid, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
     return CCC_OK;
   }
   if(!h->fits_fast)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: reg_type 2, precision 32 and CCC_DDP_LEGACY are built for "
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 and CCC_DDP_LEGACY are built for "
                 "max_ridges = %d, max_phases <= %d, horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
   // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip)
   const bool lean32 = h->cfg.reg_type == 1 && h->cfg.precision == 32;

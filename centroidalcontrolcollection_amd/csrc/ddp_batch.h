@@ -34,9 +34,11 @@ struct DdpBatch
 hipError_t launch_ddp_lean32(const ddp_common::Params & P, const DdpBatch & B, long n, int S, hipStream_t stream);
 
 // csrc/ddp_tile.hip: the tile build (csrc/ddp_tile.h), S in {9, 12}, M in {16, 32, 64} (ridge stride of the arrays = the
-// handle's max_ridges), any number of contact phases and horizon steps, reg_type 1; ws = n x
-// ddp_tile_ws_doubles(N, S, M) doubles of workspace
+// handle's max_ridges), any number of contact phases and horizon steps, reg_type 1 and 2.  One resident set of workgroups
+// (ddp_tile_grid) pulls instances from a ticket counter; ws = grid x ddp_tile_ws_doubles(N, S, M) doubles of workspace,
+// ticket = one unsigned in device memory (reset by the launch)
 size_t ddp_tile_ws_doubles(int N, int S, int M);
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, int M,
-                           hipStream_t stream);
+int ddp_tile_grid(long n, int M, int num_cu);
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, unsigned * ticket, int grid, long n,
+                           int S, int M, hipStream_t stream);
 } // namespace ccc_amd

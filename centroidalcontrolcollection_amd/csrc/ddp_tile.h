@@ -132,15 +132,17 @@ template<int S, int B>
 struct alignas(16) Mem
 {
   static constexpr int M = 16 * B;
-  static constexpr int LT = M + 1; // row stride of the M-wide tables read with a per-lane ROW index (bank-conflict free)
+  static constexpr int LS = 16;        // row stride of the 6 x S matrices
   alignas(16) double Vxx[S * S];
   alignas(16) double Fx[S * S];        // [b][c]
   alignas(16) double T1[S * S];        // Vxx Fx, then Qxx
-  alignas(16) double T2[S * LT];       // Vxx Fu [a*M + c]; later K' [a*LT + c]
-  alignas(16) double Zl[S * LT];       // Quu K + 2 Qux, [a*LT + c]
-  alignas(16) double L[M * LT];        // unit lower factor of H~ = L D L', zeros on and above the diagonal
-  alignas(16) double cb[2][M];         // column / vector broadcast buffers
-  alignas(16) double Vx[16], Qx[16], vxn[16];
+  alignas(16) double W[6 * LS];        // (Vxx Fx)[rows6, :]            [j * LS + a]
+  alignas(16) double Y[6 * LS];        // M_f^-1 Wr
+  alignas(16) double D[6 * LS];        // C_f Y
+  alignas(16) double E[6 * LS];        // w_force Y - 2 W + V6 D
+  alignas(16) double Gl[6 * M];        // the six non-zero rows of Fu    [j * M + r]
+  alignas(16) double Cf[36], Mf[36], Minv[36];
+  alignas(16) double Vx[16], Qx[16];
   double wrun[16], wterm[16];
   double alpha[12];
   double inertia[9];
@@ -197,7 +199,7 @@ struct Solver
 {
   static_assert(B == 1 || B == 2 || B == 4, "16, 32 or 64 ridges per step");
   static constexpr int M = 16 * B;
-  static constexpr int LT = Mem<S, B>::LT;
+  static constexpr int LS = Mem<S, B>::LS;
   static constexpr int FU0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (its six non-zero rows are FU0 .. FU0+5)
   static constexpr int NP = S * (S + 1) / 2;   // entries of the upper triangle of Vxx
   static constexpr int NPASS = (NP + 63) / 64;
@@ -221,6 +223,7 @@ struct Solver
 
   // lane coordinates
   vi lane, c, g;
+  vi j6;             // min(lane, 5): the row of the 6 x 6 matrices this lane works on
   vb inS;            // c < S
   vi arow[3];        // rows of the S x M matrices this lane holds: g, g + 4, g + 8 (clamped to S - 1 when not valid)
   vb aval[3];
@@ -270,6 +273,7 @@ struct Solver
     lane = lane_id();
     c = lane & 15;
     g = lane >> 4;
+    j6 = seli(lane < 6, lane, spl(5));
     inS = c < S;
     for(int t = 0; t < 3; t++)
     {
@@ -515,189 +519,193 @@ struct Solver
     wave_sync();
   }
 
-  // ------------------------------------------------------------------------------------------------ linear algebra
-  // y on every row -> the entries 16 bc + 4g .. 16 bc + 4g+3 this lane's column blocks need (through LDS buffer `slot`)
+  // ------------------------------------------------------------------------------------------------ structured box-QP
+  // oracle/ddp_tile.c (round 4): no M x M object is formed.  With G = the six non-zero rows of Fu, V6r = Vxx[rows6,
+  // rows6] (+ lambda I for reg_type 2), P = V6r G and alpha = w_force (+ lambda for reg_type 1):
+  //   Quu_F = alpha I + G' V6r G = alpha I + P' G,   Quu_F,ff^-1 b = (b - G_f' M_f^-1 (P_f b)) / alpha,
+  //   M_f = alpha I + V6r C_f,  C_f = sum_{r free} g_r g_r'  (6 x 6).
+  // Per lane (ridge c + 16 b): g_r and p_r in registers (six doubles each); the sums over the ridges of the six
+  // components run as TWO trees: row g of the wavefront reduces component g (tree A) and component 4 + (g & 1) (tree B).
+  struct Qp
+  {
+    int m;
+    double alpha, inv_alpha, ratio, lv; // ratio = w_force / alpha
+    vf G[B][6];
+    vf Ga[B], Gb[B];                    // the rows' own components of g_r: [g] and [4 + (g & 1)]
+    vf u[B];                            // the step's nominal inputs (Qu = w_force u + G' Vx6)
+    vb in[B];
+  };
+  static W64_FN vf pick4(vi g, const vf (&v)[6]) { return sel(g == 0, v[0], sel(g == 1, v[1], sel(g == 2, v[2], v[3]))); }
+  // the six ridge sums sum_r G[j][r] y_r.  SPEC: t_r = G[j][r] y_r; treeM
   template<int AB>
-  W64_FN void block_of(const vf (&y)[B], int slot, vf (&yb)[B][4])
+  W64_FN void six_sums(const Qp & Q, const vf (&y)[B], double (&out)[6]) const
   {
-    for(int b = 0; b < AB; b++) st(mem.cb[slot], c + 16 * b, y[b], g == 0);
-    wave_sync();
-    for(int bc = 0; bc < AB; bc++)
-      for(int s = 0; s < 4; s++) yb[bc][s] = ld(mem.cb[slot], g * 4 + s + 16 * bc);
+    vf t[B];
+    for(int b = 0; b < AB; b++) t[b] = Q.Ga[b] * y[b];
+    const vf sa = sumM<AB>(t);
+    for(int b = 0; b < AB; b++) t[b] = Q.Gb[b] * y[b];
+    const vf sb = sumM<AB>(t);
+    out[0] = read_lane(sa, 0);
+    out[1] = read_lane(sa, 16);
+    out[2] = read_lane(sa, 32);
+    out[3] = read_lane(sa, 48);
+    out[4] = read_lane(sb, 0);
+    out[5] = read_lane(sb, 16);
   }
-  // one row block of H times the gathered vector.  SPEC (row r, the four chains g = 0 .. 3 over the columns
-  // k = 16 bc + 4g + s, bc ascending, s = 0 .. 3 inside): p_g = H[r][4g] y_4g; p_g = fma(H[r][k], y_k, p_g) for the
-  // following k; (H y)_r = (p_0 + p_1) + (p_2 + p_3).   elem(bc, s): the lane's entry of the row block.
-  template<int AB, class E>
-  static W64_FN vf row_dot(E elem, const vf (&yb)[B][4])
+  // row j (on lane j < 6) of a 6 x 6 matrix in LDS: elem(l) = A[j][l].  SPEC (apply6): out_j = A[j][0] v_0;
+  // fma(A[j][l], v_l, .), l = 1 .. 5 -- every lane computes "its" row, the six results come back as scalars
+  template<class E>
+  W64_FN void apply6(E elem, const double (&v)[6], double (&out)[6], const double * init = nullptr) const
   {
-    vf p = elem(0, 0) * yb[0][0];
-    for(int s = 1; s < 4; s++) p = vfma(elem(0, s), yb[0][s], p);
-    for(int bc = 1; bc < AB; bc++)
-      for(int s = 0; s < 4; s++) p = vfma(elem(bc, s), yb[bc][s], p);
-    return sum_rows(p);
+    vf s = init ? vfma(elem(0), splat(v[0]), ld(init, j6)) : elem(0) * v[0];
+    for(int l = 1; l < 6; l++) s = vfma(elem(l), splat(v[l]), s);
+    for(int j = 0; j < 6; j++) out[j] = read_lane(s, j);
   }
-  // out = H y for H in row blocks
+  // V6r[j6][l] = Vxx[FU0 + j6][FU0 + l] (+ lv on the diagonal)
+  W64_FN vf v6r_elem(int l, double lv) const
+  {
+    const vf v = ld(mem.Vxx, (j6 + FU0) * S + FU0 + l);
+    return sel(j6 == l, v + lv, v);
+  }
+  // hy = Quu_F y.  SPEC: gy = G y (six sums); vy = V6r gy (apply6); hy_r = alpha y_r; hy_r = fma(G[j][r], vy_j, hy_r)
   template<int AB>
-  W64_FN void matvec(const vf (&H)[B][B][4], const vf (&y)[B], int slot, vf (&out)[B])
+  W64_FN void qp_matvec(const Qp & Q, const vf (&y)[B], vf (&hy)[B]) const
   {
-    vf yb[B][4];
-    block_of<AB>(y, slot, yb);
-    for(int br = 0; br < AB; br++) out[br] = row_dot<AB>([&](int bc, int s) { return H[br][bc][s]; }, yb);
-  }
-  // the same with the diagonal blocks taken from Hd (the unregularised Quu: HF with lambda taken off the diagonal)
-  template<int AB>
-  W64_FN void matvec_u(const vf (&H)[B][B][4], const vf (&Hd)[B][4], const vf (&y)[B], int slot, vf (&out)[B])
-  {
-    vf yb[B][4];
-    block_of<AB>(y, slot, yb);
-    for(int br = 0; br < AB; br++)
-      out[br] = row_dot<AB>([&](int bc, int s) { return bc == br ? Hd[br][s] : H[br][bc][s]; }, yb);
-  }
-
-  // L D L' of H~ (H with the rows and columns of `skip` -- clamped or beyond the step's dimension -- replaced by
-  // identity): unit lower L -> mem.L (zeros on and above the diagonal), 1 / D -> rdv.  SPEC, column j = 0 .. M-1, not skipped:
-  //   d = a[j][j]; fail unless d > 0; r = 1 / d; L[c][j] = a[c][j] r (c > j);
-  //   a[c][k] = fma(-(a[c][j] a[k][j]), r, a[c][k])       (the product of the two column entries first: symmetric)
-  // (entries with a row or column index below the first ridge of j's block of 16 are never read again and are left
-  //  alone.)  Returns false when a pivot is not positive.
-  template<int AB>
-  CCC_TILE_PIECE bool factorize(const vf (&HF)[B][B][4], mask_t skip, vf (&rdv)[B])
-  {
-    vf a[B][B][4];
-    for(int br = 0; br < AB; br++)
+    double gy[6], vy[6];
+    six_sums<AB>(Q, y, gy);
+    apply6([&](int l) { return v6r_elem(l, Q.lv); }, gy, vy);
+    for(int b = 0; b < AB; b++)
     {
-      const vb rskip = row_in(skip, br);
-      for(int bc = 0; bc < AB; bc++)
-        for(int s = 0; s < 4; s++)
-        {
-          const vb cskip = col_in(skip, bc, s);
-          const vf ident = (br == bc) ? sel(c == g * 4 + s, 1.0, 0.0) : splat(0.0);
-          a[br][bc][s] = sel(rskip || cskip, ident, HF[br][bc][s]);
-        }
-      rdv[br] = splat(1.0);
+      vf s = Q.alpha * y[b];
+      for(int j = 0; j < 6; j++) s = vfma(Q.G[b][j], splat(vy[j]), s);
+      hy[b] = s;
+    }
+  }
+  // C_f, M_f = alpha I + V6r C_f, Minv = M_f^-1 by Gauss-Jordan elimination with partial pivoting -> mem.Cf, mem.Minv;
+  // false when a pivot is zero or not finite.  SPEC: oracle/ddp_tile.c s_factor
+  template<int AB>
+  CCC_TILE_PIECE bool qp_factor(const Qp & Q, mask_t freemask)
+  {
+    // entry n = 6 j + l of the 6 x 6 matrices on the lanes n < 36
+    const vb live = lane < 36;
+    const vi n = seli(live, lane, spl(0));
+    const vi j = (n * 43) >> 8, l = n - 6 * j;
+    {
+      vf acc = splat(0.0);
+      for(int r = 0; r < 16 * AB; r++)
+        if((freemask >> r) & 1u) acc = vfma(ld(mem.Gl, j * M + r), ld(mem.Gl, l * M + r), acc);
+      st(mem.Cf, n, acc, live);
+    }
+    wave_sync();
+    {
+      vf acc = sel(j == l, splat(Q.alpha), 0.0);
+      for(int t = 0; t < 6; t++)
+      {
+        const vf v6 = ld(mem.Vxx, (j + FU0) * S + FU0 + t);
+        const vf v6r = sel(j == t, v6 + Q.lv, v6);
+        acc = vfma(v6r, ld(mem.Cf, l + 6 * t), acc);
+      }
+      st(mem.Mf, n, acc, live);
+    }
+    wave_sync();
+    // column `lane` of [M_f | I] in registers (lanes 0 .. 11; the others carry zeros along)
+    vf a[6];
+    {
+      const vb mcol = lane < 6, icol = lane >= 6 && lane < 12;
+      const vi col = seli(mcol, lane, spl(0));
+      for(int i = 0; i < 6; i++) a[i] = sel(mcol, ld(mem.Mf, col + 6 * i), sel(icol && (lane == 6 + i), 1.0, 0.0));
     }
     bool ok = true;
-    factor_col<AB, 0>(a, skip, rdv, ok);
+    gj_step<0>(a, ok);
+    for(int i = 0; i < 6; i++) st(mem.Minv, seli(lane >= 6 && lane < 12, lane - 6 + 6 * i, spl(0)), a[i], lane >= 6 && lane < 12);
     wave_sync();
     return ok;
   }
-
-  // one column of the factorisation (a compile-time column index: the entries of `a` stay in their registers)
-  template<int AB, int J>
-  W64_FN void factor_col(vf (&a)[B][B][4], mask_t skip, vf (&rdv)[B], bool & ok)
+  template<int K>
+  W64_FN void gj_step(vf (&a)[6], bool & ok)
   {
-    if constexpr(J < 16 * AB)
+    if constexpr(K < 6)
     {
-      constexpr int jb = J >> 4, jc = J & 15, gj = jc >> 2, sj = jc & 3;
-      if((skip >> J) & 1u)
-      {
-        for(int br = jb; br < AB; br++) st(mem.L, (c + 16 * br) * LT + J, splat(0.0), g == 0);
-      }
-      else
-      {
-        // (source order = issue order wanted: the column goes to LDS and its reads are in flight while the pivot's
-        //  reciprocal -- an IEEE division, the longest dependent chain of the step -- is computed)
-        for(int br = jb; br < AB; br++) st(mem.cb[J & 1], c + 16 * br, a[br][jb][sj], g == gj);
-        wave_sync();
-        vf uc[B], uk[B][4];
-        for(int br = jb; br < AB; br++) uc[br] = ld(mem.cb[J & 1], c + 16 * br);
-        for(int bc = jb; bc < AB; bc++)
-          for(int s = 0; s < 4; s++) uk[bc][s] = ld(mem.cb[J & 1], g * 4 + s + 16 * bc);
-        const double d = read_lane(a[jb][jb][sj], 16 * gj + jc);
-        if(!(d > 0.0)) ok = false;
-        const double r = 1.0 / d;
-        vf pk[B][B][4];
-        for(int br = jb; br < AB; br++)
-          for(int bc = jb; bc < AB; bc++)
-            for(int s = 0; s < 4; s++) pk[br][bc][s] = uc[br] * uk[bc][s];
-        for(int br = jb; br < AB; br++)
-          st(mem.L, (c + 16 * br) * LT + J, sel(c + 16 * br > J, uc[br] * r, 0.0), g == 0);
-        rdv[jb] = sel(c == jc, splat(r), rdv[jb]);
-        for(int br = jb; br < AB; br++)
-          for(int bc = jb; bc < AB; bc++)
-            for(int s = 0; s < 4; s++) a[br][bc][s] = vfma(-pk[br][bc][s], splat(r), a[br][bc][s]);
-      }
-      factor_col<AB, J + 1>(a, skip, rdv, ok);
+      double pc[6];
+      for(int i = K; i < 6; i++) pc[i] = read_lane(a[i], K);
+      int p = K;
+      double best = std::fabs(pc[K]);
+      for(int i = K + 1; i < 6; i++)
+        if(std::fabs(pc[i]) > best)
+        {
+          best = std::fabs(pc[i]);
+          p = i;
+        }
+      if(!(best > 0.0) || !(best <= 1.7976931348623157e308)) ok = false;
+      for(int i = K + 1; i < 6; i++)
+        if(p == i)
+        {
+          const vf tmp = a[K];
+          a[K] = a[i];
+          a[i] = tmp;
+        }
+      const double rp = 1.0 / read_lane(a[K], K);
+      double mult[6];
+      for(int i = 0; i < 6; i++) mult[i] = read_lane(a[i], K) * rp;
+      const vf akj = a[K];
+      for(int i = 0; i < 6; i++)
+        if(i != K) a[i] = vfma(splat(-mult[i]), akj, a[i]);
+      a[K] = akj * rp;
+      gj_step<K + 1>(a, ok);
     }
   }
-
-  // b <- H~^-1 b for NR right-hand sides held one entry per lane and block (rows may hold different ones), zero on the
-  // skipped rows.  SPEC: forward, k = 0 .. M-1: b_c = fma(-L[c][k], b_k, b_c) for the rows c from the first ridge of k's
-  // block of 16 on (L is zero on and above the diagonal); b_c = b_c rd_c; backward, k = M-1 .. 0: b_c = fma(-L[k][c], b_k, b_c)
-  // for the rows c up to the last ridge of k's block.  Skipped columns are identity columns: nothing to do.
-  template<int AB, int NR>
-  W64_FN void solve(vf (&b)[B][NR], mask_t skip, const vf (&rdv)[B])
+  // sol = Quu_F,ff^-1 (q + Quu_F xcl) on the free rows in the cancellation-free form of oracle/ddp_tile.c s_direction:
+  //   beta = Vx6 + V6r (G xcl); delta = beta - ratio V6r (G_f u_f); gamma = Minv delta; sol_r = ratio u_r + g_r' gamma
+  template<int AB>
+  W64_FN void qp_direction(const Qp & Q, const vb (&fr)[B], const vf (&xcl)[B], vf (&sol)[B]) const
   {
-    solve_fwd<AB, 0>(b, skip);
-    for(int br = 0; br < AB; br++)
-      for(int t = 0; t < NR; t++) b[br][t] = b[br][t] * rdv[br];
-    solve_bwd<AB, 16 * AB - 1>(b, skip);
-  }
-  template<int AB, int K, int NR>
-  W64_FN void solve_fwd(vf (&b)[B][NR], mask_t skip)
-  {
-    if constexpr(K < 16 * AB)
+    double gxc[6], gfu[6], beta[6], tv[6], delta[6], gamma[6];
+    six_sums<AB>(Q, xcl, gxc);
     {
-      constexpr int kb = K >> 4, kc = K & 15;
-      if(!((skip >> K) & 1u))
-      {
-        vf bk[NR];
-        for(int t = 0; t < NR; t++) bk[t] = row_bcast<kc>(b[kb][t]);
-        for(int br = kb; br < AB; br++)
-        {
-          const vf lk = ld(mem.L, (c + 16 * br) * LT + K);
-          for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
-        }
-      }
-      solve_fwd<AB, K + 1>(b, skip);
+      vf uf[B];
+      for(int b = 0; b < AB; b++) uf[b] = sel(fr[b], Q.u[b], 0.0);
+      six_sums<AB>(Q, uf, gfu);
     }
-  }
-  template<int AB, int K, int NR>
-  W64_FN void solve_bwd(vf (&b)[B][NR], mask_t skip)
-  {
-    if constexpr(K >= 0)
+    // SPEC: beta_j = Vx6_j; fma(V6r[j][l], gxc_l, .), l = 0 .. 5
     {
-      constexpr int kb = K >> 4, kc = K & 15;
-      if(!((skip >> K) & 1u))
-      {
-        vf bk[NR];
-        for(int t = 0; t < NR; t++) bk[t] = row_bcast<kc>(b[kb][t]);
-        for(int br = 0; br <= kb; br++)
-        {
-          const vf lk = ld(mem.L, c + 16 * br + K * LT);
-          for(int t = 0; t < NR; t++) b[br][t] = vfma(-lk, bk[t], b[br][t]);
-        }
-      }
-      solve_bwd<AB, K - 1>(b, skip);
+      vf sb = ld(mem.Vx, j6 + FU0);
+      for(int l = 0; l < 6; l++) sb = vfma(v6r_elem(l, Q.lv), splat(gxc[l]), sb);
+      for(int j = 0; j < 6; j++) beta[j] = read_lane(sb, j);
+    }
+    apply6([&](int l) { return v6r_elem(l, Q.lv); }, gfu, tv);
+    for(int j = 0; j < 6; j++) delta[j] = std::fma(-Q.ratio, tv[j], beta[j]);
+    apply6([&](int l) { return ld(mem.Minv, j6 * 6 + l); }, delta, gamma);
+    for(int b = 0; b < AB; b++)
+    {
+      vf s = Q.ratio * Q.u[b];
+      for(int j = 0; j < 6; j++) s = vfma(Q.G[b][j], splat(gamma[j]), s);
+      sol[b] = sel(fr[b], s, 0.0);
     }
   }
 
   // Box-QP (Tassa's boxQP.m, nmpc_ddp's parameters): min 1/2 x'Hx + q'x, lo <= x <= hi over the first m ridges,
-  // H = HF (row blocks, lambda on the diagonal).  x enters as the warm start.  On success (result >= 1) x is the
-  // minimiser, skip the clamped-or-unused rows as a bit mask, and mem.L / rdv hold the factor of H~ for that set.
+  // H = Quu_F in the structured form above.  x enters as the warm start.  On success (result >= 1) x is the minimiser,
+  // freemask the free ridges (empty when everything is clamped) and mem.Cf / mem.Minv belong to that set.
   template<int AB>
-  CCC_TILE_PIECE int box_qp(int m, const vf (&HF)[B][B][4], const vf (&q)[B], const vf (&lo)[B], const vf (&hi)[B],
-                            vf (&x)[B], mask_t & skip, vf (&rdv)[B])
+  CCC_TILE_PIECE int box_qp(const Qp & Q, const vf (&q)[B], const vf (&lo)[B], const vf (&hi)[B], vf (&x)[B], mask_t & freemask)
   {
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
-    vb in[B], cl[B];
+    const int m = Q.m;
+    vb cl[B], fr[B];
     for(int b = 0; b < AB; b++)
     {
-      in[b] = c + 16 * b < m;
       cl[b] = lane < 0; // all false
-      x[b] = sel(in[b], vmin(vmax(x[b], lo[b]), hi[b]), 0.0);
-      rdv[b] = splat(1.0);
+      fr[b] = lane < 0;
+      x[b] = sel(Q.in[b], vmin(vmax(x[b], lo[b]), hi[b]), 0.0);
     }
     const mask_t inmask = (m >= M) ? kAll : static_cast<mask_t>((static_cast<mask_t>(1) << m) - 1u);
     // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); sumM
-    // (H y is kept: the gradient of the next iteration is q + H x at the x the last value was taken at -- the same
-    //  product, not formed twice)
+    // (H y is kept: the gradient of the next iteration is q + H x at the x the last value was taken at)
     vf hy[B];
     auto value_of = [&](const vf (&y)[B]) {
       vf t[B];
-      matvec<AB>(HF, y, 0, hy);
+      qp_matvec<AB>(Q, y, hy);
       for(int b = 0; b < AB; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
       return read_lane(sumM<AB>(t), 0);
     };
@@ -705,7 +713,7 @@ struct Solver
     TILE_PROF_COUNT(TP_QP_CALLS);
     double value = value_of(x), oldvalue = 0.0;
     TILE_PROF_ADD(TP_QP_VALUE);
-    skip = ~inmask & kAll;
+    freemask = 0;
     int result = 0, iter;
     for(iter = 1; iter <= max_iter; iter++)
     {
@@ -723,7 +731,7 @@ struct Solver
       {
         grad[b] = q[b] + hy[b];
         const vb oldc = cl[b];
-        cl[b] = in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
+        cl[b] = Q.in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
         diff[b] = cl[b] != oldc;
       }
       const mask_t clmask = ballotM<AB>(cl) & inmask;
@@ -737,21 +745,17 @@ struct Solver
       if(changed)
       {
         TILE_PROF_COUNT(TP_QP_FACTORS);
-        skip = clmask | (~inmask & kAll);
-        if(!factorize<AB>(HF, skip, rdv))
+        freemask = inmask & ~clmask;
+        for(int b = 0; b < AB; b++) fr[b] = Q.in[b] && !cl[b];
+        if(!qp_factor<AB>(Q, freemask))
         {
           result = -1;
           break;
         }
       }
       TILE_PROF_ADD(TP_QP_FACTOR);
-      vb fr[B];
       vf t[B];
-      for(int b = 0; b < AB; b++)
-      {
-        fr[b] = in[b] && !cl[b];
-        t[b] = sel(fr[b], grad[b] * grad[b], 0.0);
-      }
+      for(int b = 0; b < AB; b++) t[b] = sel(fr[b], grad[b] * grad[b], 0.0);
       // |grad| on the free rows.  SPEC: sqrt(sumM(free ? grad^2 : 0))
       const double gn = std::sqrt(read_lane(sumM<AB>(t), 0));
       if(gn < min_grad)
@@ -759,15 +763,13 @@ struct Solver
         result = 5;
         break;
       }
-      // grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x
-      vf xcl[B], hx[B], rhs[B][1], srch[B];
+      // search = -H_ff^-1 (q + H (x .* clamped))_f - x_f
+      vf xcl[B], rhs[B], srch[B];
       for(int b = 0; b < AB; b++) xcl[b] = sel(cl[b], x[b], 0.0);
-      matvec<AB>(HF, xcl, 0, hx);
-      for(int b = 0; b < AB; b++) rhs[b][0] = sel(fr[b], q[b] + hx[b], 0.0);
-      solve<AB, 1>(rhs, skip, rdv);
+      qp_direction<AB>(Q, fr, xcl, rhs);
       for(int b = 0; b < AB; b++)
       {
-        srch[b] = sel(fr[b], -rhs[b][0] - x[b], 0.0);
+        srch[b] = sel(fr[b], -rhs[b] - x[b], 0.0);
         t[b] = srch[b] * grad[b];
       }
       const double sdotg = read_lane(sumM<AB>(t), 0);
@@ -777,7 +779,7 @@ struct Solver
       vf xc[B];
       for(;;)
       {
-        for(int b = 0; b < AB; b++) xc[b] = sel(in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
+        for(int b = 0; b < AB; b++) xc[b] = sel(Q.in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
         vc = value_of(xc);
         if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
         step *= step_dec;
@@ -792,7 +794,7 @@ struct Solver
       TILE_PROF_ADD(TP_QP_SEARCH);
     }
     if(iter > max_iter && result == 0) result = 1;
-    skip = (ballotM<AB>(cl) & inmask) | (~inmask & kAll);
+    freemask = (result == 6) ? static_cast<mask_t>(0) : (inmask & ~(ballotM<AB>(cl) & inmask));
     return result;
   }
 
@@ -800,24 +802,30 @@ struct Solver
   W64_FN const double * xcur() const { return I.xbuf + static_cast<long>(cur) * (P.N + 1) * S; }
   W64_FN const double * ucur() const { return I.ubuf + static_cast<long>(cur) * P.N * M; }
 
-  // oracle/ddp_tile.c backward_pass; returns false when a box-QP fails.  gnorm: sum_i max_c |k_c| / (|u_c| + 1)
-  // one step of the backward pass with the first AB <= B blocks of 16 ridges live (m <= 16 AB: the further blocks are
-  // exact zeros in every sum of the specification and are left out); returns false when the box-QP fails
+  // oracle/ddp_tile.c backward_pass_struct: one step with the first AB <= B blocks of 16 ridges live (m <= 16 AB: the
+  // further blocks are exact zeros in every sum of the specification and are left out); false when the box-QP fails.
+  // gsum: sum_i max_c |k_c| / (|u_c| + 1)
   template<int AB>
   CCC_TILE_PIECE bool backward_step(int i, int m, int ph, vf x, const vf (&u)[B], vf (&kprev)[B], int mprev, double & gsum)
   {
-    vb in[B];
-    for(int b = 0; b < AB; b++) in[b] = c + 16 * b < m;
+    Qp Q;
+    Q.m = m;
+    const double lq = P.reg_type == 2 ? 0.0 : lambda, lv = P.reg_type == 2 ? lambda : 0.0;
+    Q.alpha = P.w_force + lq;
+    Q.inv_alpha = 1.0 / Q.alpha;
+    Q.ratio = P.w_force * Q.inv_alpha;
+    Q.lv = lv;
+    for(int b = 0; b < AB; b++) Q.in[b] = c + 16 * b < m;
     TILE_PROF_START();
     Terms T;
     terms_of<AB>(ph, m, x, u, T);
     vf Fu[B][6];
     state_eq_deriv<AB>(T, x, Fu);
     TILE_PROF_ADD(TP_DERIV);
+    const vi col = seli(inS, c, spl(0));
     // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
     {
       vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
-      const vi col = seli(inS, c, spl(0));
       for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
       st(mem.Qx, c, s, inS && (g == 0));
     }
@@ -827,29 +835,21 @@ struct Solver
     {
       vf s = P.w_force * u[b];
       for(int bb = 0; bb < 6; bb++) s = vfma(Fu[b][bb], splat(mem.Vx[FU0 + bb]), s);
-      Qu[b] = sel(in[b], s, 0.0);
+      Qu[b] = sel(Q.in[b], s, 0.0);
     }
-    // T2 = Vxx Fu (rows a_t of the columns c + 16 b).  SPEC: s = Vxx[a][FU0] Fu[FU0][c]; s = fma(Vxx[a][b], Fu[b][c], s), b ascending
-    // (loops over the state index run with the three rows inside and a bounded unroll: fully unrolled, the scheduler
-    //  hoists every LDS load of a product and the registers of 3 x S x 2 operands do not fit four wavefronts per SIMD)
+    // the ridge vectors g_r (zero beyond the step's dimension), also in LDS for the C_f sums
+    for(int b = 0; b < AB; b++)
     {
-      vf s3[B][3];
-      for(int t = 0; t < 3; t++)
+      for(int j = 0; j < 6; j++)
       {
-        const vf v = ld(mem.Vxx, arow[t] * S + FU0);
-        for(int b = 0; b < AB; b++) s3[b][t] = v * Fu[b][0];
+        Q.G[b][j] = sel(Q.in[b], Fu[b][j], 0.0);
+        st(mem.Gl, j * M + c + 16 * b, Q.G[b][j], g == 0);
       }
-      for(int bb = 1; bb < 6; bb++)
-        for(int t = 0; t < 3; t++)
-        {
-          const vf v = ld(mem.Vxx, arow[t] * S + (FU0 + bb));
-          for(int b = 0; b < AB; b++) s3[b][t] = vfma(v, Fu[b][bb], s3[b][t]);
-        }
-      for(int b = 0; b < AB; b++)
-        for(int t = 0; t < 3; t++) st(mem.T2, arow[t] * M + c + 16 * b, s3[b][t], aval[t]);
+      Q.Ga[b] = pick4(g, Q.G[b]);
+      Q.Gb[b] = sel((g & 1) == 0, Q.G[b][4], Q.G[b][5]);
+      Q.u[b] = u[b];
     }
     // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
-    const vi col = seli(inS, c, spl(0));
     {
       vf s3[3];
       const vf f0 = ld(mem.Fx, col);
@@ -863,58 +863,8 @@ struct Solver
       for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
     }
     wave_sync();
-    // Quu = Luu + Fu' T2 (rows c + 16 br, columns 16 bc + 4g + s).  SPEC: s = (r == k) w_force; s = fma(Fu[b][r], T2[b][k], s), b ascending
-    // HF: lambda on the diagonal; Hd: the diagonal blocks with the unregularised diagonal entry
-    vf HF[B][B][4], Hd[B][4];
-    for(int bc = 0; bc < AB; bc++)
-    {
-      vf s4v[B][4];
-      for(int br = 0; br < AB; br++)
-        for(int s4 = 0; s4 < 4; s4++)
-          s4v[br][s4] = (br == bc) ? sel(c == g * 4 + s4, splat(P.w_force), 0.0) : splat(0.0);
-      for(int bb = 0; bb < 6; bb++)
-        for(int s4 = 0; s4 < 4; s4++)
-        {
-          const vf t2 = ld(mem.T2, g * 4 + s4 + 16 * bc + (FU0 + bb) * M);
-          for(int br = 0; br < AB; br++) s4v[br][s4] = vfma(Fu[br][bb], t2, s4v[br][s4]);
-        }
-      for(int br = 0; br < AB; br++)
-        for(int s4 = 0; s4 < 4; s4++)
-        {
-          const vi k = g * 4 + s4 + 16 * bc;
-          const vb live = in[br] && (k < m);
-          if(br == bc)
-          {
-            const vb dg = live && (c == g * 4 + s4);
-            Hd[br][s4] = sel(live, s4v[br][s4], 0.0);
-            HF[br][bc][s4] = sel(dg, s4v[br][s4] + lambda, Hd[br][s4]);
-          }
-          else
-            HF[br][bc][s4] = sel(live, s4v[br][s4], 0.0);
-        }
-    }
-    // Qxu = Fx' T2 (rows a_t of the columns c + 16 b).  SPEC: s = Fx[0][a] T2[0][c]; s = fma(Fx[b][a], T2[b][c], s), b = 1 .. S-1
-    vf Qxu[B][3];
-    {
-      for(int t = 0; t < 3; t++)
-      {
-        const vf f = ld(mem.Fx, arow[t]);
-        for(int b = 0; b < AB; b++) Qxu[b][t] = f * ld(mem.T2, c + 16 * b);
-      }
-      W64_UNROLL(CCC_TILE_U_PROD)
-      for(int bb = 1; bb < S; bb++)
-      {
-        vf tb[B];
-        for(int b = 0; b < AB; b++) tb[b] = ld(mem.T2, c + 16 * b + bb * M);
-        for(int t = 0; t < 3; t++)
-        {
-          const vf f = ld(mem.Fx, arow[t] + bb * S);
-          for(int b = 0; b < AB; b++) Qxu[b][t] = vfma(f, tb[b], Qxu[b][t]);
-        }
-      }
-      for(int b = 0; b < AB; b++)
-        for(int t = 0; t < 3; t++) Qxu[b][t] = sel(in[b] && aval[t], Qxu[b][t], 0.0);
-    }
+    // W = T1[rows6, :] -> mem.W (T1's place takes Qxx below)
+    for(int j = 0; j < 6; j++) st(mem.W, j * LS + c, ld(mem.T1, (FU0 + j) * S + col), inS && (g == 0));
     // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
     vf Qxx[3];
     {
@@ -927,69 +877,87 @@ struct Solver
       }
     }
     wave_sync();
-    for(int t = 0; t < 3; t++)
-    {
-      st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
-      for(int b = 0; b < AB; b++)
-        st(mem.Zl, arow[t] * LT + c + 16 * b, Qxu[b][t], aval[t]); // (Qxu waits in Z's place while the box-QP runs)
-    }
+    for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
+    wave_sync();
     TILE_PROF_ADD(TP_PRODUCTS);
     // box-QP and gains
     vf k[B], K[B][3];
+    vb fr[B];
     for(int b = 0; b < AB; b++)
     {
       k[b] = splat(0.0);
+      fr[b] = lane < 0;
       for(int t = 0; t < 3; t++) K[b][t] = splat(0.0);
     }
+    mask_t freemask = 0;
     if(m > 0)
     {
       vf lo[B], hi[B];
       for(int b = 0; b < AB; b++)
       {
-        lo[b] = sel(in[b], P.flo - u[b], 0.0);
-        hi[b] = sel(in[b], P.fhi - u[b], 0.0);
+        lo[b] = sel(Q.in[b], P.flo - u[b], 0.0);
+        hi[b] = sel(Q.in[b], P.fhi - u[b], 0.0);
         // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
         k[b] = (mprev == m) ? kprev[b] : splat(0.0);
       }
-      mask_t skip;
-      vf rdv[B];
-      const int rc = box_qp<AB>(m, HF, Qu, lo, hi, k, skip, rdv);
+      const int rc = box_qp<AB>(Q, Qu, lo, hi, k, freemask);
       if(rc < 1) return false;
       TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
-      // K_f = -H_ff^-1 Qxu_f' (three right-hand sides per row of the wavefront), clamped rows of K = 0
-      vb fr[B];
-      vf rhs[B][3];
+      for(int b = 0; b < AB; b++) fr[b] = row_in(freemask, b);
+    }
+    // Y = M_f^-1 Wr (lanes a < S).  SPEC: s = Minv[j][0] Wr[0][a]; fma(Minv[j][t], Wr[t][a], .), t = 1 .. 5;
+    // Wr[t][a] = fma(lv, Fx[FU0 + t][a], W[t][a]).  Nothing free (or no contact): Y = 0, C_f = 0
+    {
+      vf wr[6], y6[6];
+      for(int t = 0; t < 6; t++) wr[t] = vfma(splat(lv), ld(mem.Fx, (FU0 + t) * S + col), ld(mem.W, t * LS + col));
+      for(int j = 0; j < 6; j++)
+      {
+        vf s = ld(mem.Minv, spl(6 * j)) * wr[0];
+        for(int t = 1; t < 6; t++) s = vfma(ld(mem.Minv, spl(6 * j + t)), wr[t], s);
+        y6[j] = (freemask != 0) ? s : splat(0.0);
+        st(mem.Y, j * LS + c, y6[j], inS && (g == 0));
+      }
+      if(freemask == 0) st(mem.Cf, seli(lane < 36, lane, spl(0)), splat(0.0), lane < 36);
+    }
+    wave_sync();
+    // K = -G_f' Y (rows a_t of the columns c + 16 b), clamped rows = 0.
+    // SPEC: s = G[0][r] Y[0][a]; fma(G[j][r], Y[j][a], .), j = 1 .. 5; K[r][a] = free ? -s : 0
+    for(int t = 0; t < 3; t++)
+    {
+      vf ya[6];
+      for(int j = 0; j < 6; j++) ya[j] = ld(mem.Y, j * LS + arow[t]);
       for(int b = 0; b < AB; b++)
       {
-        fr[b] = !row_in(skip, b);
-        for(int t = 0; t < 3; t++) rhs[b][t] = sel(fr[b], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+        vf s = Q.G[b][0] * ya[0];
+        for(int j = 1; j < 6; j++) s = vfma(Q.G[b][j], ya[j], s);
+        K[b][t] = sel(fr[b] && aval[t], -s, 0.0);
       }
-      solve<AB, 3>(rhs, skip, rdv);
-      for(int b = 0; b < AB; b++)
-        for(int t = 0; t < 3; t++) K[b][t] = sel(fr[b] && aval[t], -rhs[b][t], 0.0);
     }
-    // gains -> global memory (the forward passes read them) and K' -> LDS
+    // gains -> global memory (the forward passes read them)
     for(int b = 0; b < AB; b++)
     {
       st(I.ks + static_cast<long>(i) * M, c + 16 * b, k[b], g == 0);
-      for(int t = 0; t < 3; t++)
-      {
-        st(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + arow[t], K[b][t], aval[t]);
-        st(mem.T2, arow[t] * LT + c + 16 * b, K[b][t], aval[t]);
-      }
+      for(int t = 0; t < 3; t++) st(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + arow[t], K[b][t], aval[t]);
     }
     TILE_PROF_ADD(TP_GAINS);
     // termination measure: max_c |k_c| / (|u_c| + 1)
     {
-      vf mx = sel(in[0], vabs(k[0]) / (vabs(u[0]) + 1.0), 0.0);
-      for(int b = 1; b < AB; b++) mx = vmax(mx, sel(in[b], vabs(k[b]) / (vabs(u[b]) + 1.0), 0.0));
+      vf mx = sel(Q.in[0], vabs(k[0]) / (vabs(u[0]) + 1.0), 0.0);
+      for(int b = 1; b < AB; b++) mx = vmax(mx, sel(Q.in[b], vabs(k[b]) / (vabs(u[b]) + 1.0), 0.0));
       gsum += read_lane(max16(mx), 0);
     }
-    // dV += [k'Qu, 1/2 k'Quu k].  SPEC: sumM(k_c Qu_c), 0.5 sumM(k_c (Quu k)_c)
-    for(int b = 0; b < AB; b++)
-      for(int t = 0; t < 3; t++) Qxu[b][t] = sel(aval[t], ld(mem.Zl, arow[t] * LT + c + 16 * b), 0.0);
+    // gk = G k; vk = V6 gk (unregularised); t4 = Quu k.  SPEC: t4_r = w_force k_r; fma(G[j][r], vk_j, .), j = 0 .. 5
+    double gk[6], vk[6], gfv[6];
+    six_sums<AB>(Q, k, gk);
+    apply6([&](int l) { return ld(mem.Vxx, (j6 + FU0) * S + FU0 + l); }, gk, vk);
     vf t4[B];
-    matvec_u<AB>(HF, Hd, k, 0, t4);
+    for(int b = 0; b < AB; b++)
+    {
+      vf s = P.w_force * k[b];
+      for(int j = 0; j < 6; j++) s = vfma(Q.G[b][j], splat(vk[j]), s);
+      t4[b] = s;
+    }
+    // dV += [k'Qu, 1/2 k'Quu k].  SPEC: sumM(k_c Qu_c), 0.5 sumM(k_c (Quu k)_c)
     {
       vf t[B];
       for(int b = 0; b < AB; b++) t[b] = k[b] * Qu[b];
@@ -997,56 +965,54 @@ struct Solver
       for(int b = 0; b < AB; b++) t[b] = k[b] * t4[b];
       dV1 += 0.5 * read_lane(sumM<AB>(t), 0);
     }
-    // Vx = Qx + K'(Quu k + Qu) + Qxu k.  SPEC: term_c = fma(Qxu[a][c], k_c, K[c][a] (t4_c + Qu_c)); Vx[a] = Qx[a] + sumM
+    // gfv = G_f (Quu k + Qu).  SPEC: treeM(free ? G[j][r] (t4_r + Qu_r) : 0)
     {
-      vf q2[B];
-      for(int b = 0; b < AB; b++) q2[b] = t4[b] + Qu[b];
-      for(int t = 0; t < 3; t++)
+      vf v[B];
+      for(int b = 0; b < AB; b++) v[b] = sel(fr[b], t4[b] + Qu[b], 0.0);
+      six_sums<AB>(Q, v, gfv);
+    }
+    // Vx = Qx + W' gk - Y' gfv; D = C_f Y; E = w_force Y - 2 W + V6 D   (lanes a < S)
+    {
+      vf w6[6], y6[6], d6[6];
+      for(int j = 0; j < 6; j++)
       {
-        vf w[B];
-        for(int b = 0; b < AB; b++) w[b] = vfma(Qxu[b][t], k[b], K[b][t] * q2[b]);
-        const vf v = sumM<AB>(w);
-        st(mem.vxn, arow[t], v, aval[t] && (c == 0));
+        w6[j] = ld(mem.W, j * LS + col);
+        y6[j] = ld(mem.Y, j * LS + col);
+      }
+      vf s = ld(mem.Qx, col);
+      for(int j = 0; j < 6; j++) s = vfma(w6[j], splat(gk[j]), s);
+      for(int j = 0; j < 6; j++) s = vfma(-y6[j], splat(gfv[j]), s);
+      st(mem.Vx, c, s, inS && (g == 0));
+      for(int j = 0; j < 6; j++)
+      {
+        vf dd = ld(mem.Cf, spl(6 * j)) * y6[0];
+        for(int t = 1; t < 6; t++) dd = vfma(ld(mem.Cf, spl(6 * j + t)), y6[t], dd);
+        d6[j] = dd;
+        st(mem.D, j * LS + c, dd, inS && (g == 0));
+      }
+      for(int j = 0; j < 6; j++)
+      {
+        vf e = P.w_force * y6[j] - 2.0 * w6[j];
+        for(int t = 0; t < 6; t++) e = vfma(ld(mem.Vxx, spl((FU0 + j) * S + FU0 + t)), d6[t], e);
+        st(mem.E, j * LS + c, e, inS && (g == 0));
       }
     }
     wave_sync();
-    // Z = Quu K + 2 Qux (column a of K through LDS).  SPEC: Z[c][a] = (Quu K[:, a])_c [row_dot] + 2 Qxu[a][c]
-    wave_sync(); // (every lane has its Qxu back before Z overwrites the place)
-    for(int t = 0; t < 3; t++)
-    {
-      W64_UNROLL_T(kUnrollZ)
-      for(int gg = 0; gg < 4; gg++)
-      {
-        const int a = gg + 4 * t;
-        if(a >= S) break;
-        vf yb[B][4];
-        for(int bc = 0; bc < AB; bc++)
-          for(int s4 = 0; s4 < 4; s4++) yb[bc][s4] = ld(mem.T2, g * 4 + s4 + 16 * bc + a * LT);
-        for(int br = 0; br < AB; br++)
-        {
-          const vf z = row_dot<AB>([&](int bc, int s) { return bc == br ? Hd[br][s] : HF[br][bc][s]; }, yb) + 2.0 * Qxu[br][t];
-          st(mem.Zl, c + 16 * br + a * LT, z, g == gg);
-        }
-      }
-    }
-    st(mem.Vx, c, ld(mem.Qx, seli(inS, c, spl(0))) + ld(mem.vxn, seli(inS, c, spl(0))), inS && (g == 0));
-    wave_sync();
-    // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + sum_c (K[c][a] Z[c][b] + K[c][b] Z[c][a]))
-    // SPEC: acc = 0; for c = 0 .. M-1: acc = fma(K[c][a], Z[c][b], acc); acc = fma(K[c][b], Z[c][a], acc)
+    // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + (T(a,b) + T(b,a))), T = D'E
+    // SPEC: tab = D[0][a] E[0][b]; fma(D[j][a], E[j][b], .), j = 1 .. 5; tba likewise
     for(int q = 0; q < NPASS; q++)
     {
       const vi pidx = lane + 64 * q;
       const vb pv = pidx < NP;
       const vi ab = ldb(mem.pair, seli(pv, pidx, spl(0)));
       const vi pa = ab & 15, pb = ab >> 4;
-      vf acc = splat(0.0);
-      W64_UNROLL(CCC_TILE_U_PAIR)
-      for(int r = 0; r < 16 * AB; r++)
+      vf tab = ld(mem.D, pa) * ld(mem.E, pb), tba = ld(mem.D, pb) * ld(mem.E, pa);
+      for(int j = 1; j < 6; j++)
       {
-        acc = vfma(ld(mem.T2, pa * LT + r), ld(mem.Zl, pb * LT + r), acc);
-        acc = vfma(ld(mem.T2, pb * LT + r), ld(mem.Zl, pa * LT + r), acc);
+        tab = vfma(ld(mem.D, j * LS + pa), ld(mem.E, j * LS + pb), tab);
+        tba = vfma(ld(mem.D, j * LS + pb), ld(mem.E, j * LS + pa), tba);
       }
-      const vf v = 0.5 * ((ld(mem.T1, pa * S + pb) + ld(mem.T1, pb * S + pa)) + acc);
+      const vf v = 0.5 * ((ld(mem.T1, pa * S + pb) + ld(mem.T1, pb * S + pa)) + (tab + tba));
       st(mem.Vxx, pa * S + pb, v, pv);
       st(mem.Vxx, pb * S + pa, v, pv);
     }

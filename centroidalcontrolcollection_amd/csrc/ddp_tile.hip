@@ -23,14 +23,23 @@ size_t ddp_tile_ws_doubles(int N, int S, int M)
 #  define CCC_TILE_WAVES 4
 #endif
 template<int S, int NB>
-__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? 2 : 1))) void ddp_tile_kernel(
-    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n)
+__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : 2)) void ddp_tile_kernel(
+    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, unsigned * ticket)
 {
   __shared__ ddp_tile::Mem<S, NB> mem;
+  __shared__ long next_b;
   constexpr int M = 16 * NB;
   const int N = P.N;
-  for(long b = blockIdx.x; b < n; b += gridDim.x)
+  // Work queue (round 4): the grid is one resident set of workgroups; each takes the next instance from a ticket counter
+  // when it finishes one (DDP solves differ severalfold in length: the hardware dispatcher used to be the queue, at the
+  // price of one workspace per INSTANCE -- now one per resident workgroup).
+  for(;;)
   {
+    if(threadIdx.x == 0) next_b = (long)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const long b = next_b;
+    __syncthreads();
+    if(b >= n) break;
     ddp_tile::Instance I;
     I.phase_dim = B.phase_dim + b * P.P;
     I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
@@ -41,7 +50,7 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? 2 : 1)))
     I.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
     I.x0 = B.x0 + b * S;
     I.u_init = B.u_init ? B.u_init + b * N * M : nullptr;
-    double * w = ws + (size_t)b * ws_stride;
+    double * w = ws + (size_t)blockIdx.x * ws_stride;
     I.xbuf = w;
     w += (size_t)ddp_tile::kSlots * (N + 1) * S;
     I.ubuf = w;
@@ -60,12 +69,21 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? 2 : 1)))
   }
 }
 
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, long n, int S, int M,
-                           hipStream_t stream)
+// workgroups of one resident set: wavefronts per SIMD (launch bounds above) x 4 SIMDs x CUs
+int ddp_tile_grid(long n, int M, int num_cu)
 {
-  const int grid = (int)(n < (1L << 22) ? n : (1L << 22)); // one workgroup per instance: the dispatcher balances
+  const int per_cu = 4 * (M == 16 ? CCC_TILE_WAVES : 2);
+  const long resident = (long)per_cu * (num_cu > 0 ? num_cu : 256);
+  return (int)(n < resident ? n : resident);
+}
+
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, unsigned * ticket, int grid, long n,
+                           int S, int M, hipStream_t stream)
+{
   const size_t stride = ddp_tile_ws_doubles(P.N, S, M);
-#define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n)
+  hipError_t e = hipMemsetAsync(ticket, 0, sizeof(unsigned), stream);
+  if(e != hipSuccess) return e;
+#define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, ticket)
   if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
   else if(S == 12 && M == 16) CCC_TILE_LAUNCH(12, 1);
   else if(S == 9 && M == 32) CCC_TILE_LAUNCH(9, 2);

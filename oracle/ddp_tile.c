@@ -3,25 +3,22 @@
  *
  * Same algorithm, same reference lines (nmpc_ddp::DDPSolver::solve at /root/reference/src/DdpCentroidal.cpp:229,233 and
  * src/DdpSingleRigidBody.cpp:299,303; the problem callbacks src/DdpCentroidal.cpp:32-177 and
- * src/DdpSingleRigidBody.cpp:26-243): every statement below has its counterpart in ddp.c / ddp_models.c.  What changes
- * is the ORDER in which the long sums are formed -- nmpc_ddp forms them with Eigen, whose order is not pinned either, so
- * no order is more faithful than another (parity unpinned at this boundary).  Round 1-2 froze plain
- * left-to-right sums (arith = 0, still what the 32-ridge "wide" kernels run); this file freezes the orders a 64-lane
- * wavefront produces without serialising:
+ * src/DdpSingleRigidBody.cpp:26-243): every quantity below has its counterpart in ddp.c / ddp_models.c.  What changes
+ * is the ORDER -- and, since round 4, the FORM -- in which the sums are taken: nmpc_ddp forms them with Eigen, whose
+ * order is not pinned either, so no order is more faithful than another (parity unpinned at this
+ * boundary).  ddp.c keeps plain left-to-right sums and dense matrices (arith = 0: the independent cross-check); this
+ * file freezes what a 64-lane wavefront computes without serialising:
  *   tree16   sums over 16 terms:  ((t0+t1)+(t2+t3)) + ((t4+t5)+(t6+t7)) + the same of t8..t15
  *   treeM    sums over the M = 16 B ridges of a step (B = 1, 2, 4 blocks of 16: one, two, up to four surface contacts):
  *            w_c = t_c | t_c + t_{c+16} | (t_c + t_{c+16}) + (t_{c+32} + t_{c+48}), then tree16(w)
- *   rows4    M-term dot products with a row of Quu: four fma chains, chain g over the columns 16 b + 4g .. 16 b + 4g+3
- *            of the blocks b = 0 .. B-1 in increasing order, then (p0+p1)+(p2+p3)
- *   chains   products over the state dimension: one fma chain in increasing index
- *   LDL'     the box-QP factorisation without square roots: d_j = a_jj, r_j = 1/d_j, l_cj = a_cj r_j,
- *            a_ck <- fma(-(a_cj a_kj), r_j, a_ck); substitutions column by column with fma, over the rows from the first
- *            ridge of the column's block of 16 on (forward) / up to the last ridge of its block (backward)
- *   value    Vxx = sym(Qxx) + 1/2 (K'Z + Z'K) with Z = Quu K + 2 Qux (algebraically the Vxx of ddp.c)
- * Inputs beyond a step's dimension are exact zeros and take part in the sums (x + 0 = x).  Ridge strides
- * M = 16, 32, 64 and reg_type 1 exist in this arithmetic.  All elementwise formulas (cross products, Euler-angle kinematics,
- * the 3x3 inertia solves, cost terms) are those of ddp_models.c, unfused; fma() appears exactly where written.
- * The two arithmetics agree to rounding (tests/test_oracle_ddp_tile.py) and the HIP kernel csrc/ddp_tile.h reproduces
+ *   chains   products over the state dimension and over the six force / moment rows: one fma chain in increasing index
+ *   the backward step in STRUCTURED form (round 4): Fu has six non-zero rows G, so Quu = w_force I + G' V6 G is the
+ *            identity plus a matrix of rank 6 and Qux = G' W; the box-QP, the gains and the value update run on 6 x 6 and
+ *            6 x S objects and per-ridge 6-vectors -- no M x M matrix is ever formed (see backward_pass_struct)
+ * Inputs beyond a step's dimension are exact zeros and take part in the sums (x + 0 = x).  Ridge strides M = 16, 32, 64,
+ * reg_type 1 and 2.  All elementwise formulas (cross products, Euler-angle kinematics, the 3x3 inertia solves, cost
+ * terms) are those of ddp_models.c, unfused; fma() appears exactly where written.
+ * The two arithmetics agree to rounding (tests/test_ddp_tile_emu.py) and the HIP kernel csrc/ddp_tile.h reproduces
  * this file bit for bit.
  */
 #include "ccc_oracle.h"
@@ -49,22 +46,6 @@ static double treeM(const double * t, int M_)
   for(int c = 0; c < 16; c++)
     w[c] = M_ == 16 ? t[c] : (M_ == 32 ? t[c] + t[c + 16] : (t[c] + t[c + 16]) + (t[c + 32] + t[c + 48]));
   return tree16(w);
-}
-
-/* (H y)_c for a row of an M x M row-major H: four fma chains (chain g: the columns 16 b + 4g .. 16 b + 4g+3, b ascending),
- * then (p0 + p1) + (p2 + p3) */
-static double rows4(const double * Hrow, const double * y, int M_)
-{
-  double p[4];
-  for(int g = 0; g < 4; g++)
-  {
-    double s = Hrow[4 * g] * y[4 * g];
-    for(int k = 1; k < 4; k++) s = fma(Hrow[4 * g + k], y[4 * g + k], s);
-    for(int b = 1; b < M_ / 16; b++)
-      for(int k = 0; k < 4; k++) s = fma(Hrow[16 * b + 4 * g + k], y[16 * b + 4 * g + k], s);
-    p[g] = s;
-  }
-  return (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 static void cross3(const double * a, const double * b, double * c)
@@ -303,151 +284,7 @@ static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, cons
   for(int a = 0; a < S; a++) Fx[a * S + a] = Fx[a * S + a] + 1.0;
 }
 
-/* ------------------------------------------------------------------------------------------- box QP (LDL')
- * H: M x M row-major, zero outside the leading m x m block; skip: bit i set = row / column i is clamped or unused.
- * L: M x M, unit lower factor of H~ (zeros on and above the diagonal); rd: 1 / D. */
 typedef unsigned long long mask_t;
-static int factorize(int M_, const double * H, mask_t skip, double * L, double * rd)
-{
-  double a[MMAX][MMAX];
-  int ok = 1;
-  for(int c = 0; c < M_; c++)
-    for(int k = 0; k < M_; k++)
-      a[c][k] = (((skip >> c) & 1u) || ((skip >> k) & 1u)) ? (c == k ? 1.0 : 0.0) : H[c * M_ + k];
-  for(int c = 0; c < M_; c++) rd[c] = 1.0;
-  for(int j = 0; j < M_; j++)
-  {
-    if((skip >> j) & 1u)
-    {
-      for(int c = 0; c < M_; c++) L[c * M_ + j] = 0.0;
-      continue;
-    }
-    const double d = a[j][j];
-    if(!(d > 0.0)) ok = 0;
-    const double r = 1.0 / d;
-    double col[MMAX];
-    for(int c = 0; c < M_; c++) col[c] = a[c][j];
-    for(int c = 0; c < M_; c++) L[c * M_ + j] = c > j ? col[c] * r : 0.0;
-    rd[j] = r;
-    for(int c = 0; c < M_; c++)
-      for(int k = 0; k < M_; k++) a[c][k] = fma(-(col[c] * col[k]), r, a[c][k]);
-  }
-  return ok;
-}
-
-/* b <- H~^-1 b (b zero on the skipped rows) */
-static void solve_ldl(int M_, const double * L, const double * rd, mask_t skip, double * b)
-{
-  for(int k = 0; k < M_; k++)
-  {
-    if((skip >> k) & 1u) continue;
-    const double bk = b[k];
-    for(int c = 16 * (k / 16); c < M_; c++) b[c] = fma(-L[c * M_ + k], bk, b[c]); /* from the first ridge of k's block on */
-  }
-  for(int c = 0; c < M_; c++) b[c] = b[c] * rd[c];
-  for(int k = M_ - 1; k >= 0; k--)
-  {
-    if((skip >> k) & 1u) continue;
-    const double bk = b[k];
-    for(int c = 0; c < 16 * (k / 16) + 16; c++) b[c] = fma(-L[k * M_ + c], bk, b[c]); /* up to the last ridge of k's block */
-  }
-}
-
-static double qp_value(int M_, const double * H, const double * q, const double * y)
-{
-  double t[MMAX];
-  for(int c = 0; c < M_; c++) t[c] = fma(0.5 * y[c], rows4(H + c * M_, y, M_), y[c] * q[c]);
-  return treeM(t, M_);
-}
-
-/* Tassa's boxQP.m with nmpc_ddp's parameters (oracle/ddp.c oracle_box_qp), in the tile arithmetic */
-static int box_qp_tile(int M_, int m, const double * H, const double * q, const double * lo, const double * hi, double * x,
-                       mask_t * skip_out, double * L, double * rd)
-{
-  const mask_t all = M_ >= 64 ? ~(mask_t)0 : (((mask_t)1 << M_) - 1u);
-  const int max_iter = 500;
-  const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
-  const mask_t inmask = m >= M_ ? all : (((mask_t)1 << m) - 1u);
-  int cl[MMAX] = {0}, oldc[MMAX];
-  mask_t skip = ~inmask & all;
-  for(int c = 0; c < M_; c++) x[c] = c < m ? fmin(fmax(x[c], lo[c]), hi[c]) : 0.0;
-  for(int c = 0; c < M_; c++) rd[c] = 1.0;
-  double value = qp_value(M_, H, q, x), oldvalue = 0.0;
-  int result = 0, iter;
-  for(iter = 1; iter <= max_iter; iter++)
-  {
-    if(result != 0) break;
-    if(iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
-    {
-      result = 4;
-      break;
-    }
-    oldvalue = value;
-    double grad[MMAX];
-    for(int c = 0; c < M_; c++) grad[c] = q[c] + rows4(H + c * M_, x, M_);
-    mask_t clmask = 0;
-    int changed = (iter == 1);
-    for(int c = 0; c < M_; c++)
-    {
-      oldc[c] = cl[c];
-      cl[c] = (c < m && ((x[c] == lo[c] && grad[c] > 0) || (x[c] == hi[c] && grad[c] < 0))) ? 1 : 0;
-      if(c < m && cl[c] != oldc[c]) changed = 1;
-      if(c < m && cl[c]) clmask |= (mask_t)1 << c;
-    }
-    if(clmask == inmask)
-    {
-      result = 6;
-      break;
-    }
-    if(changed)
-    {
-      skip = clmask | (~inmask & all);
-      if(!factorize(M_, H, skip, L, rd))
-      {
-        result = -1;
-        break;
-      }
-    }
-    double t[MMAX];
-    for(int c = 0; c < M_; c++) t[c] = (c < m && !cl[c]) ? grad[c] * grad[c] : 0.0;
-    const double gn = sqrt(treeM(t, M_));
-    if(gn < min_grad)
-    {
-      result = 5;
-      break;
-    }
-    /* grad_clamped = q + H (x .* clamped) on the free rows; search = -H_ff^-1 grad_clamped - x */
-    double xcl[MMAX], rhs[MMAX], srch[MMAX];
-    for(int c = 0; c < M_; c++) xcl[c] = cl[c] ? x[c] : 0.0;
-    for(int c = 0; c < M_; c++) rhs[c] = (c < m && !cl[c]) ? q[c] + rows4(H + c * M_, xcl, M_) : 0.0;
-    solve_ldl(M_, L, rd, skip, rhs);
-    for(int c = 0; c < M_; c++) srch[c] = (c < m && !cl[c]) ? -rhs[c] - x[c] : 0.0;
-    for(int c = 0; c < M_; c++) t[c] = srch[c] * grad[c];
-    const double sdotg = treeM(t, M_);
-    if(sdotg >= 0) break; /* no descent direction: result stays 0 */
-    double step = 1.0, vc = 0, xc[MMAX];
-    for(;;)
-    {
-      for(int c = 0; c < M_; c++) xc[c] = c < m ? fmin(fmax(x[c] + step * srch[c], lo[c]), hi[c]) : 0.0;
-      vc = qp_value(M_, H, q, xc);
-      if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
-      step *= step_dec;
-      if(step < min_step)
-      {
-        result = 2;
-        break;
-      }
-    }
-    for(int c = 0; c < M_; c++) x[c] = xc[c];
-    value = vc;
-  }
-  if(iter > max_iter && result == 0) result = 1;
-  mask_t clmask = 0;
-  for(int c = 0; c < m; c++)
-    if(cl[c]) clmask |= (mask_t)1 << c;
-  *skip_out = clmask | (~inmask & all);
-  return result;
-}
 
 /* ------------------------------------------------------------------------------------------- DDP */
 static void increase_lambda(tile_t * d)
@@ -461,11 +298,242 @@ static void decrease_lambda(tile_t * d)
   d->lambda = d->lambda * d->dlambda * (d->lambda > d->c->lambda_min ? 1.0 : 0.0);
 }
 
-/* oracle/ddp.c backward_pass in the tile arithmetic; gsum = sum_i max_r |k_r| / (|u_r| + 1) */
-static int backward_pass(tile_t * d, double * gsum)
+/* ------------------------------------------------------------------------------------------- STRUCTURED backward pass
+ * (round 4; replaces the dense backward pass of round 3).  Same algorithm, same quantities as backward_pass() above, formed WITHOUT
+ * any M x M object.  With G = the six non-zero rows of Fu (6 x M), rows6 = FU0 .. FU0+5, V6 = Vxx[rows6, rows6],
+ * W = (Vxx Fx)[rows6, :] (6 x S), lq / lv = lambda on Quu (reg_type 1) / on Vxx (reg_type 2), alpha = w_force + lq,
+ * V6r = V6 + lv I, Wr = W + lv Fx[rows6, :]:
+ *     Quu   = w_force I + G' V6 G           Quu_F   = alpha I + G' V6r G          (identity plus rank 6)
+ *     Qux   = G' W                          Qux_reg = G' Wr
+ * so for a free set f, with C_f = sum_{r in f} g_r g_r' (6 x 6) and M_f = alpha I + V6r C_f (6 x 6):
+ *     Quu_F,ff^-1 b = (b - G_f' M_f^-1 V6r G_f b) / alpha                          (Woodbury; see s_direction)
+ *     K_f = -Quu_F,ff^-1 Qux_reg,f = -G_f' Y,   Y = M_f^-1 Wr   (6 x S; exact: I - M_f^-1 V6r C_f = alpha M_f^-1)
+ *     K'Z = D'E,  D = C_f Y,  E = w_force Y - 2 W + V6 D                            (Z = Quu K + 2 Qux)
+ * M_f^-1 by Gauss-Jordan elimination with partial pivoting on [M_f | I].  Order of every sum: as written below.
+ * The box-QP is Tassa's projected Newton, statement by statement as box_qp_tile(), with H y = alpha y + G'(V6r (G y)).  A failed factorisation = a pivot that is zero or not finite; an indefinite Quu_F (Vxx is positive
+ * semi-definite in exact arithmetic, so this takes NaN / overflow) shows up as "no descent direction" as before. */
+typedef struct
+{
+  int M_, m;
+  double alpha, inv_alpha, ratio; /* ratio = w_force / alpha */
+  double G[6][MMAX];
+  double V6r[6][6], Vx6[6];
+  const double * u;               /* the step's nominal inputs (Qu = w_force u + G' Vx6) */
+  double Cf[6][6], Minv[6][6];
+} sqp_t;
+
+/* out = A v for a 6 x 6 A.  SPEC: out_j = A[j][0] v_0; fma(A[j][l], v_l, .), l = 1 .. 5 */
+static void apply6(const double (*A)[6], const double * v, double * out)
+{
+  for(int j = 0; j < 6; j++)
+  {
+    double s = A[j][0] * v[0];
+    for(int l = 1; l < 6; l++) s = fma(A[j][l], v[l], s);
+    out[j] = s;
+  }
+}
+
+/* out_j = treeM(G[j][r] y_r) */
+static void six_sums(const sqp_t * q, const double * y, double * out)
+{
+  double t[MMAX];
+  for(int j = 0; j < 6; j++)
+  {
+    for(int r = 0; r < q->M_; r++) t[r] = q->G[j][r] * y[r];
+    out[j] = treeM(t, q->M_);
+  }
+}
+
+/* hy = Quu_F y = alpha y + G' (V6r (G y)) */
+static void s_matvec(const sqp_t * q, const double * y, double * hy)
+{
+  double gy[6], vy[6];
+  six_sums(q, y, gy);
+  apply6(q->V6r, gy, vy);
+  for(int r = 0; r < q->M_; r++)
+  {
+    double s = q->alpha * y[r];
+    for(int j = 0; j < 6; j++) s = fma(q->G[j][r], vy[j], s);
+    hy[r] = s;
+  }
+}
+
+static double s_value(const sqp_t * q, const double * lin, const double * y, double * hy)
+{
+  double t[MMAX];
+  s_matvec(q, y, hy);
+  for(int r = 0; r < q->M_; r++) t[r] = fma(0.5 * y[r], hy[r], y[r] * lin[r]);
+  return treeM(t, q->M_);
+}
+
+/* C_f, M_f = alpha I + V6r C_f, Minv = M_f^-1 (Gauss-Jordan, partial pivoting); 0 when a pivot is zero or not finite */
+static int s_factor(sqp_t * q, const int * fr)
+{
+  for(int j = 0; j < 6; j++)
+    for(int l = 0; l < 6; l++)
+    {
+      double s = 0.0;
+      for(int r = 0; r < q->M_; r++)
+        if(fr[r]) s = fma(q->G[j][r], q->G[l][r], s);
+      q->Cf[j][l] = s;
+    }
+  double A[6][12];
+  for(int j = 0; j < 6; j++)
+    for(int l = 0; l < 6; l++)
+    {
+      double s = j == l ? q->alpha : 0.0;
+      for(int t = 0; t < 6; t++) s = fma(q->V6r[j][t], q->Cf[t][l], s);
+      A[j][l] = s;
+      A[j][6 + l] = j == l ? 1.0 : 0.0;
+    }
+  for(int k = 0; k < 6; k++)
+  {
+    int p = k;
+    double best = fabs(A[k][k]);
+    for(int i = k + 1; i < 6; i++)
+      if(fabs(A[i][k]) > best)
+      {
+        best = fabs(A[i][k]);
+        p = i;
+      }
+    if(!(best > 0.0) || !(best <= 1.7976931348623157e308)) return 0;
+    if(p != k)
+      for(int j = 0; j < 12; j++)
+      {
+        const double tmp = A[k][j];
+        A[k][j] = A[p][j];
+        A[p][j] = tmp;
+      }
+    const double rp = 1.0 / A[k][k];
+    double mult[6];
+    for(int i = 0; i < 6; i++) mult[i] = A[i][k] * rp;
+    for(int j = 0; j < 12; j++)
+    {
+      const double akj = A[k][j];
+      for(int i = 0; i < 6; i++)
+        if(i != k) A[i][j] = fma(-mult[i], akj, A[i][j]);
+      A[k][j] = akj * rp;
+    }
+  }
+  for(int j = 0; j < 6; j++)
+    for(int t = 0; t < 6; t++) q->Minv[j][t] = A[j][6 + t];
+  return 1;
+}
+
+/* sol = Quu_F,ff^-1 (q + Quu_F xcl)_f on the free rows, WITHOUT the cancellation of the plain Woodbury formula:
+ * with q = w_force u + G' Vx6 the right-hand side is w_force u_f + G_f' beta, beta = Vx6 + V6r (G xcl), and
+ *   Quu_F,ff^-1 G_f' beta = G_f' M_f^-1 beta              (push-through identity: exact, nothing subtracted)
+ *   Quu_F,ff^-1 u_f       = (u_f - G_f' M_f^-1 V6r G_f u_f) / alpha
+ * so  sol_r = ratio u_r + g_r' gamma,  gamma = M_f^-1 (beta - ratio V6r (G_f u_f)),  ratio = w_force / alpha:
+ * the error is at rounding level relative to |u|, whatever mu / alpha (round 4; with lambda on Vxx -- reg_type 2 -- or a
+ * large Vxx the subtracting form loses mu / alpha digits). */
+static void s_direction(const sqp_t * q, const int * fr, const double * xcl, double * sol)
+{
+  double gxc[6], gfu[6], uf[MMAX], beta[6], tv[6], delta[6], gamma[6];
+  six_sums(q, xcl, gxc);
+  for(int r = 0; r < q->M_; r++) uf[r] = fr[r] ? q->u[r] : 0.0;
+  six_sums(q, uf, gfu);
+  for(int j = 0; j < 6; j++)
+  {
+    double b = q->Vx6[j];
+    for(int l = 0; l < 6; l++) b = fma(q->V6r[j][l], gxc[l], b);
+    beta[j] = b;
+  }
+  apply6(q->V6r, gfu, tv);
+  for(int j = 0; j < 6; j++) delta[j] = fma(-q->ratio, tv[j], beta[j]);
+  apply6(q->Minv, delta, gamma);
+  for(int r = 0; r < q->M_; r++)
+  {
+    double s = q->ratio * q->u[r];
+    for(int j = 0; j < 6; j++) s = fma(q->G[j][r], gamma[j], s);
+    sol[r] = fr[r] ? s : 0.0;
+  }
+}
+
+/* box_qp_tile() on the structured Hessian; fr_out: the free set the factor in q belongs to (empty: nothing is free) */
+static int box_qp_struct(sqp_t * q, const double * lin, const double * lo, const double * hi, double * x, int * fr_out)
+{
+  const int M_ = q->M_, m = q->m, max_iter = 500;
+  const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
+  int cl[MMAX] = {0}, oldc[MMAX], fr[MMAX] = {0};
+  double hy[MMAX];
+  for(int c = 0; c < M_; c++) x[c] = c < m ? fmin(fmax(x[c], lo[c]), hi[c]) : 0.0;
+  double value = s_value(q, lin, x, hy), oldvalue = 0.0;
+  int result = 0, iter;
+  for(iter = 1; iter <= max_iter; iter++)
+  {
+    if(result != 0) break;
+    if(iter > 1 && (oldvalue - value) < min_rel_improve * fabs(oldvalue))
+    {
+      result = 4;
+      break;
+    }
+    oldvalue = value;
+    double grad[MMAX];
+    for(int c = 0; c < M_; c++) grad[c] = lin[c] + hy[c]; /* hy = H x of the last value taken at x */
+    int changed = (iter == 1), nclamped = 0;
+    for(int c = 0; c < M_; c++)
+    {
+      oldc[c] = cl[c];
+      cl[c] = (c < m && ((x[c] == lo[c] && grad[c] > 0) || (x[c] == hi[c] && grad[c] < 0))) ? 1 : 0;
+      if(c < m && cl[c] != oldc[c]) changed = 1;
+      nclamped += cl[c];
+    }
+    if(nclamped == m)
+    {
+      result = 6;
+      break;
+    }
+    if(changed)
+    {
+      for(int c = 0; c < M_; c++) fr[c] = c < m && !cl[c];
+      if(!s_factor(q, fr))
+      {
+        result = -1;
+        break;
+      }
+    }
+    double t[MMAX];
+    for(int c = 0; c < M_; c++) t[c] = fr[c] ? grad[c] * grad[c] : 0.0;
+    const double gn = sqrt(treeM(t, M_));
+    if(gn < min_grad)
+    {
+      result = 5;
+      break;
+    }
+    double xcl[MMAX], rhs[MMAX], srch[MMAX];
+    for(int c = 0; c < M_; c++) xcl[c] = cl[c] ? x[c] : 0.0;
+    s_direction(q, fr, xcl, rhs);
+    for(int c = 0; c < M_; c++) srch[c] = fr[c] ? -rhs[c] - x[c] : 0.0;
+    for(int c = 0; c < M_; c++) t[c] = srch[c] * grad[c];
+    const double sdotg = treeM(t, M_);
+    if(sdotg >= 0) break; /* no descent direction: result stays 0 */
+    double step = 1.0, vc = 0, xc[MMAX];
+    for(;;)
+    {
+      for(int c = 0; c < M_; c++) xc[c] = c < m ? fmin(fmax(x[c] + step * srch[c], lo[c]), hi[c]) : 0.0;
+      vc = s_value(q, lin, xc, hy);
+      if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
+      step *= step_dec;
+      if(step < min_step)
+      {
+        result = 2;
+        break;
+      }
+    }
+    for(int c = 0; c < M_; c++) x[c] = xc[c];
+    value = vc;
+  }
+  if(iter > max_iter && result == 0) result = 1;
+  for(int c = 0; c < M_; c++) fr_out[c] = (result == 6) ? 0 : (c < m && !cl[c]);
+  return result;
+}
+
+static int backward_pass_struct(tile_t * d, double * gsum)
 {
   const oracle_ddp_model_t * m = d->m;
   const int S = d->S, N = d->N, FU0 = S == 9 ? 3 : 6, M_ = m->M;
+  const double lq = d->c->reg_type == 2 ? 0.0 : d->lambda, lv = d->c->reg_type == 2 ? d->lambda : 0.0;
   double Vxx[144], Vx[12], ref[12];
   memset(Vxx, 0, sizeof(Vxx));
   ref_of(m, N, ref);
@@ -478,6 +546,7 @@ static int backward_pass(tile_t * d, double * gsum)
   *gsum = 0;
   double kprev[MMAX] = {0};
   int mprev = -1;
+  sqp_t * q = (sqp_t *)malloc(sizeof(sqp_t));
   for(int i = N - 1; i >= 0; i--)
   {
     const int dim = dim_of(m, i);
@@ -488,7 +557,7 @@ static int backward_pass(tile_t * d, double * gsum)
     terms_of(m, i, x, u, &T);
     double Fx[144], Fu[6][MMAX];
     state_eq_deriv(m, &T, x, Fx, Fu);
-    /* Qx = Lx + Fx' Vx ; Qu = Lu + Fu' Vx */
+    /* Qx, Qu as in backward_pass() */
     double Qx[12], Qu[MMAX];
     ref_of(m, i, ref);
     for(int a = 0; a < S; a++)
@@ -503,41 +572,14 @@ static int backward_pass(tile_t * d, double * gsum)
       for(int b = 0; b < 6; b++) s = fma(Fu[b][r], Vx[FU0 + b], s);
       Qu[r] = r < dim ? s : 0.0;
     }
-    /* T2 = Vxx Fu ; T1 = Vxx Fx */
-    double T2[12][MMAX], T1[144];
-    for(int a = 0; a < S; a++)
-      for(int r = 0; r < M_; r++)
-      {
-        double s = Vxx[a * S + FU0] * Fu[0][r];
-        for(int b = 1; b < 6; b++) s = fma(Vxx[a * S + FU0 + b], Fu[b][r], s);
-        T2[a][r] = s;
-      }
+    /* T1 = Vxx Fx ; Qxx = Lxx + Fx' T1 */
+    double T1[144], Qxx[144];
     for(int a = 0; a < S; a++)
       for(int b2 = 0; b2 < S; b2++)
       {
         double s = Vxx[a * S] * Fx[b2];
         for(int b = 1; b < S; b++) s = fma(Vxx[a * S + b], Fx[b * S + b2], s);
         T1[a * S + b2] = s;
-      }
-    /* Quu = Luu + Fu' T2 (H: unregularised, HF: lambda on the diagonal, both zero outside dim x dim) */
-    double H[MMAX * MMAX], HF[MMAX * MMAX];
-    for(int r = 0; r < M_; r++)
-      for(int q = 0; q < M_; q++)
-      {
-        double s = r == q ? m->w_force : 0.0;
-        for(int b = 0; b < 6; b++) s = fma(Fu[b][r], T2[FU0 + b][q], s);
-        const int live = r < dim && q < dim;
-        H[r * M_ + q] = live ? s : 0.0;
-        HF[r * M_ + q] = (live && r == q) ? s + d->lambda : H[r * M_ + q];
-      }
-    /* Qxu = Fx' T2 ; Qxx = Lxx + Fx' T1 */
-    double Qxu[12][MMAX], Qxx[144];
-    for(int a = 0; a < S; a++)
-      for(int r = 0; r < M_; r++)
-      {
-        double s = Fx[a] * T2[0][r];
-        for(int b = 1; b < S; b++) s = fma(Fx[b * S + a], T2[b][r], s);
-        Qxu[a][r] = r < dim ? s : 0.0;
       }
     for(int a = 0; a < S; a++)
       for(int b2 = 0; b2 < S; b2++)
@@ -546,29 +588,69 @@ static int backward_pass(tile_t * d, double * gsum)
         for(int b = 0; b < S; b++) s = fma(Fx[b * S + a], T1[b * S + b2], s);
         Qxx[a * S + b2] = s;
       }
+    /* the six-dimensional pieces */
+    double V6[6][6], W[6][12], Wr[6][12];
+    q->M_ = M_;
+    q->m = dim;
+    q->alpha = m->w_force + lq;
+    q->inv_alpha = 1.0 / q->alpha;
+    q->ratio = m->w_force * q->inv_alpha;
+    q->u = u;
+    for(int j = 0; j < 6; j++)
+    {
+      q->Vx6[j] = Vx[FU0 + j];
+      for(int l = 0; l < 6; l++)
+      {
+        V6[j][l] = Vxx[(FU0 + j) * S + FU0 + l];
+        q->V6r[j][l] = j == l ? V6[j][l] + lv : V6[j][l];
+      }
+      for(int a = 0; a < S; a++)
+      {
+        W[j][a] = T1[(FU0 + j) * S + a];
+        Wr[j][a] = fma(lv, Fx[(FU0 + j) * S + a], W[j][a]);
+      }
+      for(int r = 0; r < M_; r++) q->G[j][r] = r < dim ? Fu[j][r] : 0.0;
+    }
     /* box-QP and gains */
-    double k[MMAX] = {0}, K[MMAX][12];
+    double k[MMAX] = {0}, K[MMAX][12], Y[6][12];
+    int fr[MMAX] = {0};
     memset(K, 0, sizeof(K));
+    memset(Y, 0, sizeof(Y));
+    memset(q->Cf, 0, sizeof(q->Cf));
     if(dim > 0)
     {
-      double lo[MMAX], hi[MMAX], L[MMAX * MMAX], rd[MMAX];
+      double lo[MMAX], hi[MMAX];
       for(int r = 0; r < M_; r++)
       {
         lo[r] = r < dim ? m->force_lo - u[r] : 0.0;
         hi[r] = r < dim ? m->force_hi - u[r] : 0.0;
-        k[r] = (mprev == dim) ? kprev[r] : 0.0; /* warm start: step i + 1 of this pass */
+        k[r] = (mprev == dim) ? kprev[r] : 0.0;
       }
-      mask_t skip;
-      const int rc = box_qp_tile(M_, dim, HF, Qu, lo, hi, k, &skip, L, rd);
-      if(rc < 1) return 0;
-      /* K_f = -H_ff^-1 Qxu_f' */
-      for(int a = 0; a < S; a++)
+      const int rc = box_qp_struct(q, Qu, lo, hi, k, fr);
+      if(rc < 1)
       {
-        double rhs[MMAX];
-        for(int r = 0; r < M_; r++) rhs[r] = ((skip >> r) & 1u) ? 0.0 : Qxu[a][r];
-        solve_ldl(M_, L, rd, skip, rhs);
-        for(int r = 0; r < M_; r++) K[r][a] = ((skip >> r) & 1u) ? 0.0 : -rhs[r];
+        free(q);
+        return 0;
       }
+      int nfree = 0;
+      for(int r = 0; r < M_; r++) nfree += fr[r];
+      if(nfree == 0)
+        memset(q->Cf, 0, sizeof(q->Cf)); /* everything clamped: no feedback (the factor in q is of an older set) */
+      else
+        for(int j = 0; j < 6; j++)
+          for(int a = 0; a < S; a++)
+          {
+            double s = q->Minv[j][0] * Wr[0][a];
+            for(int t = 1; t < 6; t++) s = fma(q->Minv[j][t], Wr[t][a], s);
+            Y[j][a] = s;
+          }
+      for(int r = 0; r < M_; r++)
+        for(int a = 0; a < S; a++)
+        {
+          double s = q->G[0][r] * Y[0][a];
+          for(int j = 1; j < 6; j++) s = fma(q->G[j][r], Y[j][a], s);
+          K[r][a] = fr[r] ? -s : 0.0;
+        }
     }
     for(int r = 0; r < M_; r++)
     {
@@ -581,36 +663,54 @@ static int backward_pass(tile_t * d, double * gsum)
       *gsum += mx;
     }
     /* dV, Vx, Vxx */
-    double t4[MMAX], t[MMAX];
-    for(int r = 0; r < M_; r++) t4[r] = rows4(H + r * M_, k, M_);
+    double gk[6], vk[6], gfv[6], t4[MMAX], t[MMAX];
+    six_sums(q, k, gk);
+    apply6(V6, gk, vk);
+    for(int r = 0; r < M_; r++)
+    {
+      double s = m->w_force * k[r];
+      for(int j = 0; j < 6; j++) s = fma(q->G[j][r], vk[j], s);
+      t4[r] = s; /* (Quu k)_r = w_force k_r + g_r' V6 (G k) */
+    }
     for(int r = 0; r < M_; r++) t[r] = k[r] * Qu[r];
     d->dV[0] += treeM(t, M_);
     for(int r = 0; r < M_; r++) t[r] = k[r] * t4[r];
     d->dV[1] += 0.5 * treeM(t, M_);
+    for(int r = 0; r < M_; r++) t[r] = fr[r] ? t4[r] + Qu[r] : 0.0;
+    six_sums(q, t, gfv);
     double vxn[12];
     for(int a = 0; a < S; a++)
     {
-      for(int r = 0; r < M_; r++) t[r] = fma(Qxu[a][r], k[r], K[r][a] * (t4[r] + Qu[r]));
-      vxn[a] = Qx[a] + treeM(t, M_);
+      double s = Qx[a];
+      for(int j = 0; j < 6; j++) s = fma(W[j][a], gk[j], s);
+      for(int j = 0; j < 6; j++) s = fma(-Y[j][a], gfv[j], s);
+      vxn[a] = s;
     }
-    /* Z = Quu K + 2 Qux */
-    double Z[MMAX][12];
-    for(int a = 0; a < S; a++)
-    {
-      double col[MMAX];
-      for(int r = 0; r < M_; r++) col[r] = K[r][a];
-      for(int r = 0; r < M_; r++) Z[r][a] = rows4(H + r * M_, col, M_) + 2.0 * Qxu[a][r];
-    }
+    double D[6][12], E[6][12];
+    for(int j = 0; j < 6; j++)
+      for(int a = 0; a < S; a++)
+      {
+        double s = q->Cf[j][0] * Y[0][a];
+        for(int t2 = 1; t2 < 6; t2++) s = fma(q->Cf[j][t2], Y[t2][a], s);
+        D[j][a] = s;
+      }
+    for(int j = 0; j < 6; j++)
+      for(int a = 0; a < S; a++)
+      {
+        double s = m->w_force * Y[j][a] - 2.0 * W[j][a];
+        for(int t2 = 0; t2 < 6; t2++) s = fma(V6[j][t2], D[t2][a], s);
+        E[j][a] = s;
+      }
     for(int a = 0; a < S; a++)
       for(int b = a; b < S; b++)
       {
-        double acc = 0.0;
-        for(int r = 0; r < M_; r++)
+        double tab = D[0][a] * E[0][b], tba = D[0][b] * E[0][a];
+        for(int j = 1; j < 6; j++)
         {
-          acc = fma(K[r][a], Z[r][b], acc);
-          acc = fma(K[r][b], Z[r][a], acc);
+          tab = fma(D[j][a], E[j][b], tab);
+          tba = fma(D[j][b], E[j][a], tba);
         }
-        const double v = 0.5 * ((Qxx[a * S + b] + Qxx[b * S + a]) + acc);
+        const double v = 0.5 * ((Qxx[a * S + b] + Qxx[b * S + a]) + (tab + tba));
         Vxx[a * S + b] = v;
         Vxx[b * S + a] = v;
       }
@@ -618,6 +718,7 @@ static int backward_pass(tile_t * d, double * gsum)
     memcpy(kprev, k, sizeof(k));
     mprev = dim;
   }
+  free(q);
   return 1;
 }
 
@@ -655,7 +756,7 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
   tile_t d;
   memset(&d, 0, sizeof(d));
   const int S = m->model == 0 ? 9 : 12, N = m->N, M_ = m->M;
-  if((M_ != 16 && M_ != 32 && M_ != 64) || c->reg_type != 1 || !c->with_input_constraint) return -100; /* not in this arithmetic */
+  if((M_ != 16 && M_ != 32 && M_ != 64) || !c->with_input_constraint) return -100; /* not in this arithmetic */
   d.m = m;
   d.c = c;
   d.S = S;
@@ -718,7 +819,7 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
     double gsum = 0;
     for(;;)
     {
-      if(backward_pass(&d, &gsum))
+      if(backward_pass_struct(&d, &gsum))
       {
         bp_ok = 1;
         break;

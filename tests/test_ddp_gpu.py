@@ -56,16 +56,23 @@ def test_centroidal_parity_with_oracle(max_iter):
     _assert_bitwise(r, o, ("u", "x", "cost", "iters", "status"))
 
 
-def test_parity_with_the_other_regularisation():
-    """ccc_ddp_config_t::reg_type = 2 (lambda added to Vxx instead of Quu): both branches of the kernel are bit-identical
-    to the oracle's."""
-    N, dt = 60, 0.03
-    prob, x0 = fd.make_centroidal_batch(64, N, dt, seed=11)
-    o = _oracle().Ddp(0, 100.0, dt, N, fd.centroidal_weights(), max_iter=12)
-    o.cfg.reg_type = 2
-    d = _cen(N, dt, 12)
+@pytest.mark.parametrize("M", [16, 32])
+def test_parity_with_the_other_regularisation(M):
+    """ccc_ddp_config_t::reg_type = 2 (lambda added to Vxx instead of Quu), since round 4 in the tile arithmetic at every
+    ridge stride (a double-support step no longer refuses it): bit-identical to the oracle's."""
+    N, dt = (60, 0.03) if M == 16 else (40, 0.05)
+    if M == 16:
+        prob, x0 = fd.make_centroidal_batch(64, N, dt, seed=11)
+    else:
+        prob, x0 = fd.make_walking_batch(48, N, dt, seed=11)
+    P = prob["phase_dim"].shape[1]
+    w = DdpCentroidal.WeightParam(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0))
+    d = DdpCentroidal(100.0, dt, N, w, max_phases=P, max_ridges=M)
+    d.ddp_solver_.config().max_iter = 12
     d.ddp_solver_.config().reg_type = 2
-    assert d.arithmetic() == 0  # (the tile arithmetic exists for the default regularisation only)
+    assert d.arithmetic() == 1
+    o = _oracle().Ddp(0, 100.0, dt, N, fd.centroidal_weights(), max_iter=12, arith=1, P=P, M=M)
+    o.cfg.reg_type = 2
     _assert_bitwise(d.planOnceBatch(prob, x0), o.plan_batch(prob, x0, nthreads=8))
 
 
