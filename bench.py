@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
                          "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
-    ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "srb32", "ddp32", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
+    ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
     args = ap.parse_args()

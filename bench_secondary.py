@@ -84,7 +84,7 @@ def _xy(n, dev, rank, walking=False):
                 kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0), mfma=XY_MFMA)
 
 
-def _ddp(n, dev, rank, srb, precision=64, walking=False):
+def _ddp(n, dev, rank, srb, walking=False):
     from centroidalcontrolcollection_amd import DdpCentroidal, DdpSingleRigidBody, fixtures_ddp as fd
     N, dt, base = (50, 0.03, min(n, 4096)) if srb else (100, 0.03, min(n, 4096))
     kw, M, P = {}, 16, 4
@@ -112,7 +112,6 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
         d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
                           device=dev.index, **kw)
     d.ddp_solver_.config().max_iter = 20
-    d.ddp_solver_.config().precision = precision
     tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
     out = torch.zeros((n, N, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -126,57 +125,49 @@ def _ddp(n, dev, rank, srb, precision=64, walking=False):
         ns = min(n, 2048)
         sub = {a: v[:ns] for a, v in prob.items()}
         o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20,
-                       P=P, M=M, arith=d.arithmetic() if precision == 64 else 0)
+                       P=P, M=M, arith=d.arithmetic())
         t0 = time.perf_counter()
         r = o.plan_batch(sub, x0[:ns], nthreads=cores)
         t = time.perf_counter() - t0
         same = bool(np.array_equal(out.cpu().numpy()[:ns], r["u"]))
-        if precision == 32:
-            # single-precision storage: a tolerance, not bits -- share of the sample whose first-step force scales agree
-            # with the fp64 oracle to 1e-3 of the largest one (the rest sit on another branch of the chaotic cold solve,
-            # as the oracle itself does under a 1e-10 perturbation: tests/test_ddp_gpu.py)
-            g = out.cpu().numpy()[:ns, 0, :]
-            e = np.abs(g - r["u"][:, 0, :]).max(axis=1) / (np.abs(r["u"][:, 0, :]).max(axis=1) + 1.0)
-            return ns / t, ns, float((e <= 1e-3).mean()), "share of instances with |d u0| <= 1e-3 (1 + max u0) vs the fp64 oracle"
         return ns / t, ns, 0.0 if same else float(np.abs(out.cpu().numpy()[:ns] - r["u"]).max()), \
             "max |d force scale| over the whole planned sequence (0.0 = bit-identical)"
 
     S = 12 if srb else 9
     return dict(name="%s planOnce() solves/sec (horizon %d, <= 20 DDP iterations, %s, inputs resident in HBM)"
                 % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N,
-                   "fp64" if precision == 64 else "fp32 storage / fp64 arithmetic in the backward pass"),
-                step=step, out=out, status=st, iters=it, dtype="f64" if precision == 64 else "f64 (f32 storage)",  # (the arithmetic type of the path, not its storage format)
+                   "fp64"),
+                step=step, out=out, status=st, iters=it, dtype="f64",
                 workload=("%s horizon=%d @ %d ms, max_iter=20, batch=%d per GPU (%s)"
                           % ("DdpSingleRigidBody" if srb else "DdpCentroidal", N, round(dt * 1e3), n,
                              ("feet + hands multi-contact, 32 / 48 / 64 ridges per step, %d contact phases: beyond BASELINE's configs, "
                               "src/DdpCentroidal.cpp:49-60" % P) if walking == "multi" else
                              "walking with 32-ridge double support, %d contact phases: beyond BASELINE's configs, "
                              "src/DdpCentroidal.cpp:49-60" % P if walking else
-                             "BASELINE config %s" % (("5" if precision == 32 else "5 shape, fp64") if srb else "3"))),
+                             "BASELINE config %s" % ("5 (fp64: its fp32 request runs this kernel, DESIGN.md 7.5)" if srb else "3"))),
                 algo_bytes=P * 4 + 2 * P * M * 3 * 8 + N * 4 + (N + 1) * 24 * (2 if srb else 1) + (72 if srb else 0)
                 + S * 8 + N * M * 8,
-                kernel=(("ddp_tile_kernel<%d, %d>" % (S, M // 16)) if precision == 64
-                        else ("ddp_lean32_kernel<%d,16>" % S)), cpu=cpu,
-                valu=lambda iters: _ddp_valu(S, M, N, iters, walking, precision),
+                kernel="ddp_tile_kernel<%d, %d>" % (S, M // 16), cpu=cpu,
+                valu=lambda iters: _ddp_valu(S, M, N, iters, walking),
                 keep=(d, tp, tx0))
 
 
-def _ddp_valu(S, M, N, iters, walking, precision):
-    """Useful flop per solve: SURVEY.md 8(d)'s count per backward step (Quu 2(S^2 m + S m^2), Qxu / Qxx 2(S^3 + S^2 m),
+def _ddp_valu(S, M, N, iters, walking):
+    """Algorithmic flop per solve (the DENSE formulation's count, what the reference's solver performs; the structured
+    backward step of round 4 gets the same result with fewer operations): SURVEY.md 8(d)'s count per backward step (Quu 2(S^2 m + S m^2), Qxu / Qxx 2(S^3 + S^2 m),
     Cholesky m^3 / 3, gains 2 m^2 S, value update 6 k at S = 9, m = 16: ~25 kflop) scaled to (S, m) x horizon x the
     iterations the run executed; the issue share comes from the committed PMC pass of the same kernel."""
     m = M
     per_step = 2 * (S * S * m + S * m * m) + 2 * (S ** 3 + S * S * m) + m ** 3 / 3 + 2 * m * m * S + 6e3 * (S / 9.0) ** 2
     pmc = None
-    if precision == 64:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_ddp_valu_counters.json")
-        if os.path.exists(path):
-            with open(path) as f:
-                pmc = json.load(f).get("S%d" % S if M == 16 else "S%dM%d" % (S, M))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_ddp_valu_counters.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pmc = json.load(f).get("S%d" % S if M == 16 else "S%dM%d" % (S, M))
     return dict(flop_per_solve=per_step * N * iters, flop_per_backward_step=per_step,
                 issue_frac=None if pmc is None else pmc["valu_issue_frac"],
                 wait_frac=None if pmc is None else pmc["wait_any_frac"],
-                counters_source="profiles/r03_ddp_valu_counters.json" if pmc else None,
+                counters_source="profiles/r04_ddp_valu_counters.json" if pmc else None,
                 what="useful fp64 flop of the backward passes over the kernel time against the vector-fp64 peak; "
                      "issue_frac = SQ_INSTS_VALU x 4 clk / (SIMDs x kernel clocks), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
 
@@ -278,9 +269,9 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, srb32=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, multi=2048, xywalk=32768, ddp32=4096)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), srb32=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
-                     walk=(3, 1), multi=(3, 1), xywalk=(3, 1), ddp32=(3, 1))
+DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, multi=2048, xywalk=32768)
+DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
+                     walk=(3, 1), multi=(3, 1), xywalk=(3, 1))
 
 
 def run(args, rank, world, local_rank, dist):
@@ -288,7 +279,7 @@ def run(args, rank, world, local_rank, dist):
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
-                srb32=lambda a, b, c: _ddp(a, b, c, True, 32), walk=lambda a, b, c: _ddp(a, b, c, False, 64, True), multi=lambda a, b, c: _ddp(a, b, c, False, 64, "multi"), ddp32=lambda a, b, c: _ddp(a, b, c, False, 32))
+                walk=lambda a, b, c: _ddp(a, b, c, False, True), multi=lambda a, b, c: _ddp(a, b, c, False, "multi"))
     w = make[args.workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)

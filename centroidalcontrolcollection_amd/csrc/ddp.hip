@@ -1,62 +1,20 @@
-// ddp.hip -- batched CCC::DdpCentroidal / CCC::DdpSingleRigidBody planOnce() on MI355X: kernel + C-ABI.
+// ddp.hip -- batched CCC::DdpCentroidal / CCC::DdpSingleRigidBody planOnce() on MI355X: the C-ABI around the tile kernel.
 //
 // One problem instance per wavefront (one 64-thread workgroup), the whole solve -- forward rollouts, analytic
-// derivatives, backward Riccati sweep with box-QP, line search -- on the device (csrc/ddp_core.h).  The small
-// per-step matrices live in LDS (struct Mem, ~20 KB per wavefront); trajectories, candidate trajectories and the
-// feedback gains K (N x 16 x S doubles = 115 KB at N = 100) live in an HBM workspace owned by the handle, laid out
-// per instance so that a wavefront streams through contiguous memory.
-//
-// The builds of csrc/ddp_core.h behind one entry (dispatch in ccc_ddp_plan_batch_device):
-//   tile   ddp_tile_kernel (csrc/ddp_tile.hip, csrc/ddp_tile.h)  THE DEFAULT (max_ridges 16, 32, 64; reg_type 1; fp64):
-//                                                         matrices distributed over the lanes, 16 instances per CU at 16
-//                                                         ridges; arithmetic = the tile specification (oracle/ddp_tile.c,
-//                                                         ccc_ddp_arithmetic = 1)
-//   full   ddp_plan_kernel (this file, csrc/ddp_core.h)   the row-per-lane solver in the left-to-right arithmetic: <= 16 ridges
-//                                                         per step, <= 4 contact phases, <= 128 steps (reg_type 2, CCC_DDP_LEGACY)
-//   lean32 ddp_lean32_kernel (csrc/ddp_lean32.hip)        the lean build with single-precision storage: precision 32
-//                                                         (BASELINE configs[4])
+// derivatives, backward Riccati sweep with box-QP, line search -- on the device (csrc/ddp_tile.h, launched by
+// csrc/ddp_tile.hip): every ridge stride (16, 32, 64), both regularisations, fp64; arithmetic = the tile specification
+// (oracle/ddp_tile.c, ccc_ddp_arithmetic = 1).  Trajectories, the four line-search candidates and the feedback gains
+// live in an HBM workspace owned by the handle, one slot per RESIDENT workgroup (a work queue hands out the instances).
+// Removed in round 4: the row-per-lane kernels of rounds 1-2 (left-to-right arithmetic: CCC_DDP_LEGACY, reg_type 2) and
+// the fp32-storage build (precision 32) -- the tile kernel takes reg_type 2 itself and is three times as fast as the
+// fp32-storage build was.
 #include "common.h"
 #include "ddp_batch.h"
-#include "ddp_core.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-
-namespace ccc_amd
-{
-template<int S, int M>
-__global__ __launch_bounds__(64, 2) void ddp_plan_kernel(ddp::Params P, DdpBatch B, long n)
-{
-  __shared__ ddp::Mem<S, M> mem;
-  const int N = P.N;
-  for(long b = blockIdx.x; b < n; b += gridDim.x)
-  {
-    ddp::Instance I;
-    I.phase_dim = B.phase_dim + b * P.P;
-    I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
-    I.phase_ridge = B.phase_ridge + b * P.P * M * 3;
-    I.step_phase = B.step_phase + b * N;
-    I.ref_pos = B.ref_pos + b * (N + 1) * 3;
-    I.ref_ori = B.ref_ori ? B.ref_ori + b * (N + 1) * 3 : nullptr;
-    I.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
-    I.x0 = B.x0 + b * S;
-    I.u_init = B.u_init ? B.u_init + b * N * M : nullptr;
-    I.xs = B.x_out + b * (N + 1) * S;
-    I.us = B.u_out + b * N * M;
-    I.xc = B.xc + b * (N + 1) * S;
-    I.uc = B.uc + b * N * M;
-    I.ks = B.ks + b * N * M;
-    I.Ks = B.Ks + b * N * M * S;
-    I.out_iters = B.iters ? B.iters + b : nullptr;
-    I.out_status = B.status ? B.status + b : nullptr;
-    I.out_cost = B.cost ? B.cost + b : nullptr;
-    ddp::Solver<S, M> solver(P, I, mem);
-    solver.solve();
-    __syncthreads();
-  }
-}
-} // namespace ccc_amd
 
 using namespace ccc_amd;
 
@@ -67,15 +25,10 @@ struct ccc_ddp
   ccc_ddp_config_t cfg{};
   int S = 9;
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
-  bool env_legacy = false;    // CCC_DDP_LEGACY: the row-per-lane kernels of csrc/ddp_core.h instead of the tile kernel
-  bool fits_fast = false;     // the tables of the row-per-lane fast builds hold this handle's problems
   int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip): one slot per resident workgroup
   double * ws_t = nullptr;
   unsigned * ticket = nullptr; // its work-queue counter
   int num_cu = 0;
-  // device workspace (grown on demand)
-  int64_t cap = 0;
-  double *ws_x = nullptr, *ws_xc = nullptr, *ws_uc = nullptr, *ws_k = nullptr, *ws_K = nullptr;
   // staging for the host entry
   int64_t hcap = 0;
   void * d_stage = nullptr;
@@ -121,8 +74,6 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   h->prm = *p;
   h->M = p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES;
   h->prm.max_ridges = h->M;
-  h->fits_fast = h->M == CCC_DDP_MAX_RIDGES && p->max_phases <= ddp::kMaxPhases && p->horizon_steps <= ddp::kMaxSteps;
-  h->env_legacy = std::getenv("CCC_DDP_LEGACY") != nullptr;
   h->S = p->model == CCC_DDP_CENTROIDAL ? 9 : 12;
   ccc_ddp_default_config(&h->cfg);
   hipDeviceProp_t prop;
@@ -137,21 +88,10 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   return CCC_OK;
 }
 
-static void free_ws(ccc_ddp * h)
-{
-  for(double ** p : {&h->ws_x, &h->ws_xc, &h->ws_uc, &h->ws_k, &h->ws_K})
-  {
-    if(*p) (void)hipFree(*p);
-    *p = nullptr;
-  }
-  h->cap = 0;
-}
-
 extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
 {
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
-  free_ws(h);
   if(h->ws_t) (void)hipFree(h->ws_t);
   if(h->ticket) (void)hipFree(h->ticket);
   if(h->d_stage) (void)hipFree(h->d_stage);
@@ -190,17 +130,9 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   P.warm_guard = h->cfg.warm_start_guard ? 1 : 0;
 }
 
-// the tile kernel takes: every ridge stride (any number of phases and steps), both regularisations, fp64
-static bool use_tile(const ccc_ddp * h)
-{
-  if(h->M != CCC_DDP_MAX_RIDGES) return true; // (the only build for 32 and 64 ridges: other configurations are refused)
-  return !h->env_legacy && h->cfg.precision == 64;
-}
-
 extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
 {
-  if(!h) return -1;
-  return use_tile(h) ? 1 : 0;
+  return h ? 1 : -1; // (one kernel, one arithmetic: oracle/ddp_tile.c)
 }
 
 extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
@@ -210,8 +142,6 @@ extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
   if(cfg->reg_type != 1 && cfg->reg_type != 2) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: reg_type must be 1 or 2");
   if(cfg->precision != 64 && cfg->precision != 32)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: precision must be 64 or 32");
-  if(cfg->precision == 32 && cfg->reg_type != 1)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_set_config: precision 32 is built for reg_type 1 only");
   h->cfg = *cfg;
   return CCC_OK;
 }
@@ -242,21 +172,6 @@ extern "C" int ccc_ddp_get_device(const ccc_ddp_t * h, int * device)
   return CCC_OK;
 }
 
-static int ensure_ws(ccc_ddp * h, int64_t n, void * stream)
-{
-  if(n <= h->cap) return CCC_OK;
-  CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
-  free_ws(h);
-  const size_t N = h->prm.horizon_steps, S = h->S, M = h->M;
-  CCC_HIP_CHECK(hipMalloc(&h->ws_x, (size_t)n * (N + 1) * S * sizeof(double)));
-  CCC_HIP_CHECK(hipMalloc(&h->ws_xc, (size_t)n * (N + 1) * S * sizeof(double)));
-  CCC_HIP_CHECK(hipMalloc(&h->ws_uc, (size_t)n * N * M * sizeof(double)));
-  CCC_HIP_CHECK(hipMalloc(&h->ws_k, (size_t)n * N * M * sizeof(double)));
-  CCC_HIP_CHECK(hipMalloc(&h->ws_K, (size_t)n * N * M * S * sizeof(double)));
-  h->cap = n;
-  return CCC_OK;
-}
-
 extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim,
                                          const double * phase_vertex, const double * phase_ridge,
                                          const int32_t * step_phase, const double * ref_pos, const double * ref_ori,
@@ -272,59 +187,28 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   if(h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && (!ref_ori || !inertia))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
-  if(h->M != CCC_DDP_MAX_RIDGES && h->cfg.precision != 64)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: max_ridges = %d is built for precision 64", h->M);
-  if(use_tile(h))
+  // (precision = 32 runs this same fp64 kernel: ccc_amd.h)
+  const int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
+  if(grid > h->tcap)
   {
-    const int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
-    if(grid > h->tcap)
-    {
-      CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
-      if(h->ws_t) (void)hipFree(h->ws_t);
-      h->ws_t = nullptr;
-      h->tcap = 0;
-      // (sized for a full resident set at once: later, larger batches do not allocate again)
-      const int full = ddp_tile_grid(1L << 40, h->M, h->num_cu);
-      CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)full * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
-      h->tcap = full;
-    }
-    if(!h->ticket)
-    {
-      CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
-      CCC_HIP_CHECK(hipMalloc(&h->ticket, sizeof(unsigned)));
-    }
-    ddp_common::Params P;
-    fill_params(h, P);
-    DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
-               x_out, nullptr, nullptr, nullptr, nullptr, iters, status, cost};
-    CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, h->ticket, grid, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
-    return CCC_OK;
+    CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
+    if(h->ws_t) (void)hipFree(h->ws_t);
+    h->ws_t = nullptr;
+    h->tcap = 0;
+    // (sized for a full resident set at once: later, larger batches do not allocate again)
+    const int full = ddp_tile_grid(1L << 40, h->M, h->num_cu);
+    CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)full * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
+    h->tcap = full;
   }
-  if(!h->fits_fast)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_ddp_plan_batch_device: precision 32 and CCC_DDP_LEGACY are built for "
-                "max_ridges = %d, max_phases <= %d, horizon_steps <= %d", CCC_DDP_MAX_RIDGES, ddp::kMaxPhases, ddp::kMaxSteps);
-  // precision 32 (BASELINE configs[4]): the lean build with single-precision storage (csrc/ddp_lean32.hip)
-  const bool lean32 = h->cfg.reg_type == 1 && h->cfg.precision == 32;
-  int rc = ensure_ws(h, n, stream);
-  if(rc != CCC_OK) return rc;
+  if(!h->ticket)
+  {
+    CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
+    CCC_HIP_CHECK(hipMalloc(&h->ticket, sizeof(unsigned)));
+  }
   ddp_common::Params P;
   fill_params(h, P);
-  DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out,
-             x_out ? x_out : h->ws_x, h->ws_xc, h->ws_uc, h->ws_k, h->ws_K, iters, status, cost};
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // the gains of the last horizon step are read as a box-QP warm start before they are first written
-  CCC_HIP_CHECK(hipMemsetAsync(h->ws_k, 0, (size_t)n * P.N * h->M * sizeof(double), s));
-  if(lean32)
-  {
-    CCC_HIP_CHECK(launch_ddp_lean32(P, B, (long)n, h->S, s));
-    return CCC_OK;
-  }
-  const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22); // one workgroup per instance: the dispatcher balances
-  if(h->S == 9)
-    hipLaunchKernelGGL((ddp_plan_kernel<9, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
-  else
-    hipLaunchKernelGGL((ddp_plan_kernel<12, CCC_DDP_MAX_RIDGES>), dim3(grid), dim3(64), 0, s, P, B, (long)n);
-  CCC_HIP_CHECK(hipGetLastError());
+  DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out, x_out, iters, status, cost};
+  CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, h->ticket, grid, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
   return CCC_OK;
 }
 

@@ -1,26 +1,27 @@
 // ddp_tile.h -- control-limited DDP for CCC::DdpCentroidal (S = 9) and CCC::DdpSingleRigidBody (S = 12), M = 16 B ridges
 // per step (B = 1, 2, 4 blocks of 16: one, two, up to four surface contacts): one instance per wavefront, every matrix
-// DISTRIBUTED over the 64 lanes (round 3; replaces the row-per-lane kernels of csrc/ddp_core.h as the default).
+// DISTRIBUTED over the 64 lanes (round 3), the backward step in STRUCTURED form (round 4: no M x M object).
 //
 // Replaces (reference file:line under /root/reference):
 //   src/DdpCentroidal.cpp:32-64, :66-83, :85-121, :123-177          problem callbacks (S = 9)
 //   src/DdpSingleRigidBody.cpp:26-38, :52-91, :93-112, :114-243     problem callbacks (S = 12)
 //   src/DdpCentroidal.cpp:229,233 / src/DdpSingleRigidBody.cpp:299,303   the external nmpc_ddp::DDPSolver::solve
-// Algorithm: the one frozen in oracle/ddp.c (Tassa's control-limited DDP, reg_type 1).  ARITHMETIC: the "tile"
-// specification of oracle/ddp_tile.c -- the same operations as oracle/ddp.c with every long sum re-associated into a
-// fixed tree or fma chain that maps onto the CDNA4 cross-lane paths.  Kernel and oracle
-// implement that specification independently and agree bit for bit.
+// Algorithm: the one frozen in oracle/ddp.c (Tassa's control-limited DDP, reg_type 1 and 2, the warm-start guard).
+// ARITHMETIC: the "tile" specification of oracle/ddp_tile.c -- every long sum a fixed tree or fma chain that maps onto the
+// CDNA4 cross-lane paths, the backward step in structured form.  Kernel and oracle implement that specification
+// independently and agree bit for bit.
 //
-// Lane = 16 g + c (g = row of the wavefront, c = lane in the row).  Layouts (b, br, bc = 0 .. B-1 index blocks of 16):
+// Lane = 16 g + c (g = row of the wavefront, c = lane in the row).  Layouts (b = 0 .. B-1 indexes the blocks of 16 ridges):
 //   vectors over the M ridges        lane (g, c) holds v[c + 16 b] in v[b]        (replicated in the four rows)
 //   state vectors                    lane (g, a), a < S, holds x[a]               (replicated)
-//   M x M matrices (Quu, its factor) lane (g, c) holds H[c + 16 br][16 bc + 4g .. 16 bc + 4g+3] in H[br][bc][0..3]
-//   S x M matrices (T2, Qxu, K')     lane (g, c) holds rows a = g, g+4, g+8 of the columns c + 16 b
-//   S x S matrices                   the same on lanes c < S; Vxx itself lives in LDS
-// Sums over ridges add the blocks lane by lane, then run one 16-lane DPP tree (w64::sum16); sums over the columns of a
-// row are four fma chains (one per row of the wavefront) crossed with v_permlane16/32_swap (w64::sum_rows); broadcasts
-// inside a row are DPP row_newbcast; LDS (B = 1: <= 10 KB per wavefront, sixteen wavefronts per CU) carries what changes
-// layout: Vxx, Fx, T1/Qxx, T2/K', Z, the factor L.
+//   per-ridge 6-vectors g_r          lane (g, c) holds the six non-zero entries of column c + 16 b of Fu
+//   S x M matrices (K')              lane (g, c) holds rows a = g, g+4, g+8 of the columns c + 16 b
+//   S x S and 6 x S, 6 x 6 matrices  LDS (Vxx, Fx, T1/Qxx; W, Y, D, E; C_f, M_f, M_f^-1)
+// The backward step never forms an M x M object (round 4): Fu has six non-zero rows G, so Quu = w_force I + G' V6 G is
+// the identity plus rank 6; the box-QP's products are two packed 16-lane DPP trees (row g of the wavefront reduces
+// components g and 4 + (g & 1) of G y) and a 6 x 6 product; its "factorisation" is a 6 x 6 Gauss-Jordan inverse, one
+// column per lane, pivot choices passed on by DPP row broadcasts; gains and value update are 6 x S algebra.  LDS is
+// ~7.5 / 9 KB per wavefront (S = 9 / 12) at EVERY ridge stride.
 // The line search runs FOUR step sizes at once, one per row (nmpc_ddp tries them in order and takes the first that is
 // accepted; evaluating four side by side and taking the first accepted gives the same answer).
 //
@@ -28,7 +29,7 @@
 // CPU suite checks this kernel bit for bit against the oracle without a GPU.
 #pragma once
 
-#include "ddp_core.h" // ddp_common::Params, kGravity
+#include "ddp_batch.h" // ddp_common::Params
 #include "w64.h"
 
 #include <type_traits>
@@ -56,6 +57,9 @@ using ddp_common::Params;
 #  define CCC_TILE_U_PROD 3
 #endif
 // (the Z loop: per model, see Solver::kUnrollZ)
+#ifndef CCC_TILE_U_CF
+#  define CCC_TILE_U_CF 8
+#endif
 #ifndef CCC_TILE_U_PAIR
 #  define CCC_TILE_U_PAIR 4
 #endif
@@ -80,6 +84,9 @@ enum
   TP_QP_ITERS,
   TP_QP_FACTORS,
   TP_FORWARDS,
+  TP_F_CF,
+  TP_F_MF,
+  TP_F_GJ,
   TP_N
 };
 #if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -152,7 +159,7 @@ struct alignas(16) Mem
 #endif
 };
 
-// Deterministic sin / cos on every lane (the restatement csrc/ddp_core.h and the oracle share: Cody-Waite reduction by
+// Deterministic sin / cos on every lane (the restatement the oracle shares: Cody-Waite reduction by
 // pi/2 + the fdlibm minimax kernels; <= 1 ulp for |x| < 1e3)
 W64_FN void vsincos(vf x, vf & s, vf & c)
 {
@@ -178,7 +185,7 @@ W64_FN void vsincos(vf x, vf & s, vf & c)
   c = sel(q == 0, cs, sel(q == 1, -sn, sel(q == 2, -cs, sn)));
 }
 
-// Eigen::LLT<Matrix3d>::solve on every lane (src/DdpSingleRigidBody.cpp:88,122-123): the statements of csrc/ddp_core.h
+// Eigen::LLT<Matrix3d>::solve on every lane (src/DdpSingleRigidBody.cpp:88,122-123): the statements of oracle/ddp_models.c
 W64_FN void vllt3(const double * I, const vf (&b)[3], vf (&x)[3])
 {
   const double l00 = std::sqrt(I[0]);
@@ -555,9 +562,9 @@ struct Solver
   // row j (on lane j < 6) of a 6 x 6 matrix in LDS: elem(l) = A[j][l].  SPEC (apply6): out_j = A[j][0] v_0;
   // fma(A[j][l], v_l, .), l = 1 .. 5 -- every lane computes "its" row, the six results come back as scalars
   template<class E>
-  W64_FN void apply6(E elem, const double (&v)[6], double (&out)[6], const double * init = nullptr) const
+  W64_FN void apply6(E elem, const double (&v)[6], double (&out)[6]) const
   {
-    vf s = init ? vfma(elem(0), splat(v[0]), ld(init, j6)) : elem(0) * v[0];
+    vf s = elem(0) * v[0];
     for(int l = 1; l < 6; l++) s = vfma(elem(l), splat(v[l]), s);
     for(int j = 0; j < 6; j++) out[j] = read_lane(s, j);
   }
@@ -582,7 +589,7 @@ struct Solver
     }
   }
   // C_f, M_f = alpha I + V6r C_f, Minv = M_f^-1 by Gauss-Jordan elimination with partial pivoting -> mem.Cf, mem.Minv;
-  // false when a pivot is zero or not finite.  SPEC: oracle/ddp_tile.c s_factor
+  // false when the inverse is not finite.  SPEC: oracle/ddp_tile.c s_factor
   template<int AB>
   CCC_TILE_PIECE bool qp_factor(const Qp & Q, mask_t freemask)
   {
@@ -590,13 +597,20 @@ struct Solver
     const vb live = lane < 36;
     const vi n = seli(live, lane, spl(0));
     const vi j = (n * 43) >> 8, l = n - 6 * j;
+    TILE_PROF_START();
     {
+      // (branch-free: the LDS reads of all ridges are in flight together; a ridge that is not free leaves acc alone)
       vf acc = splat(0.0);
+      W64_UNROLL(CCC_TILE_U_CF)
       for(int r = 0; r < 16 * AB; r++)
-        if((freemask >> r) & 1u) acc = vfma(ld(mem.Gl, j * M + r), ld(mem.Gl, l * M + r), acc);
+      {
+        const vf nx = vfma(ld(mem.Gl, j * M + r), ld(mem.Gl, l * M + r), acc);
+        acc = ((freemask >> r) & 1u) ? nx : acc;
+      }
       st(mem.Cf, n, acc, live);
     }
     wave_sync();
+    TILE_PROF_ADD(TP_F_CF);
     {
       vf acc = sel(j == l, splat(Q.alpha), 0.0);
       for(int t = 0; t < 6; t++)
@@ -608,6 +622,7 @@ struct Solver
       st(mem.Mf, n, acc, live);
     }
     wave_sync();
+    TILE_PROF_ADD(TP_F_MF);
     // column `lane` of [M_f | I] in registers (lanes 0 .. 11; the others carry zeros along)
     vf a[6];
     {
@@ -615,43 +630,59 @@ struct Solver
       const vi col = seli(mcol, lane, spl(0));
       for(int i = 0; i < 6; i++) a[i] = sel(mcol, ld(mem.Mf, col + 6 * i), sel(icol && (lane == 6 + i), 1.0, 0.0));
     }
-    bool ok = true;
-    gj_step<0>(a, ok);
-    for(int i = 0; i < 6; i++) st(mem.Minv, seli(lane >= 6 && lane < 12, lane - 6 + 6 * i, spl(0)), a[i], lane >= 6 && lane < 12);
+    gj_step<0>(a);
+    // failure = an entry of the inverse that is not finite (a zero pivot leaves inf / NaN behind)
+    vb bad = lane < 0;
+    for(int i = 0; i < 6; i++)
+    {
+      st(mem.Minv, seli(lane >= 6 && lane < 12, lane - 6 + 6 * i, spl(0)), a[i], lane >= 6 && lane < 12);
+      bad = bad || !(vabs(a[i]) <= 1.7976931348623157e308);
+    }
+    const bool ok = (ballot(bad) & 0xfc0ull) == 0ull;
     wave_sync();
+    TILE_PROF_ADD(TP_F_GJ);
     return ok;
   }
+  // Every lane works on its own column; the pivot column's choices (pivot row, reciprocal, multipliers) reach the
+  // others by DPP row broadcasts -- the twelve live columns sit in the first row of the wavefront -- so a pivot is a
+  // straight run of vector instructions: no scalar registers, no branches.
   template<int K>
-  W64_FN void gj_step(vf (&a)[6], bool & ok)
+  W64_FN void gj_step(vf (&a)[6])
   {
     if constexpr(K < 6)
     {
-      double pc[6];
-      for(int i = K; i < 6; i++) pc[i] = read_lane(a[i], K);
-      int p = K;
-      double best = std::fabs(pc[K]);
+      vi pl = spl(K);
+      vf best = vabs(a[K]);
       for(int i = K + 1; i < 6; i++)
-        if(std::fabs(pc[i]) > best)
+      {
+        const vf ai = vabs(a[i]);
+        const vb gt = ai > best;
+        best = sel(gt, ai, best);
+        pl = seli(gt, spl(i), pl);
+      }
+      const vi p = row_bcast_i<K>(pl);
+      // rows p and K change places
+      {
+        vf ak = a[K];
+        for(int i = K + 1; i < 6; i++)
         {
-          best = std::fabs(pc[i]);
-          p = i;
+          const vb is = p == i;
+          const vf ai = a[i];
+          a[i] = sel(is, a[K], ai);
+          ak = sel(is, ai, ak);
         }
-      if(!(best > 0.0) || !(best <= 1.7976931348623157e308)) ok = false;
-      for(int i = K + 1; i < 6; i++)
-        if(p == i)
-        {
-          const vf tmp = a[K];
-          a[K] = a[i];
-          a[i] = tmp;
-        }
-      const double rp = 1.0 / read_lane(a[K], K);
-      double mult[6];
-      for(int i = 0; i < 6; i++) mult[i] = read_lane(a[i], K) * rp;
+        a[K] = ak;
+      }
+      const vf rpl = 1.0 / a[K];
+      vf mb[6];
+      for(int i = 0; i < 6; i++)
+        if(i != K) mb[i] = row_bcast<K>(a[i] * rpl);
+      const vf rp = row_bcast<K>(rpl);
       const vf akj = a[K];
       for(int i = 0; i < 6; i++)
-        if(i != K) a[i] = vfma(splat(-mult[i]), akj, a[i]);
+        if(i != K) a[i] = vfma(-mb[i], akj, a[i]);
       a[K] = akj * rp;
-      gj_step<K + 1>(a, ok);
+      gj_step<K + 1>(a);
     }
   }
   // sol = Quu_F,ff^-1 (q + Quu_F xcl) on the free rows in the cancellation-free form of oracle/ddp_tile.c s_direction:
@@ -905,19 +936,28 @@ struct Solver
       TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
       for(int b = 0; b < AB; b++) fr[b] = row_in(freemask, b);
     }
-    // Y = M_f^-1 Wr (lanes a < S).  SPEC: s = Minv[j][0] Wr[0][a]; fma(Minv[j][t], Wr[t][a], .), t = 1 .. 5;
-    // Wr[t][a] = fma(lv, Fx[FU0 + t][a], W[t][a]).  Nothing free (or no contact): Y = 0, C_f = 0
+    // Y = M_f^-1 Wr: lane (g, a), a < S, forms the rows j = g and j = 4 + g (g < 2).  SPEC: s = Minv[j][0] Wr[0][a];
+    // fma(Minv[j][t], Wr[t][a], .), t = 1 .. 5; Wr[t][a] = fma(lv, Fx[FU0 + t][a], W[t][a]).  Nothing free (or no
+    // contact): Y = 0, C_f = 0
+    const vi jA = g, jB = seli(g < 2, g + 4, spl(5));
+    const vb hasB = g < 2;
     {
-      vf wr[6], y6[6];
+      vf wr[6];
       for(int t = 0; t < 6; t++) wr[t] = vfma(splat(lv), ld(mem.Fx, (FU0 + t) * S + col), ld(mem.W, t * LS + col));
-      for(int j = 0; j < 6; j++)
+      vf sA = ld(mem.Minv, jA * 6) * wr[0], sB = ld(mem.Minv, jB * 6) * wr[0];
+      for(int t = 1; t < 6; t++)
       {
-        vf s = ld(mem.Minv, spl(6 * j)) * wr[0];
-        for(int t = 1; t < 6; t++) s = vfma(ld(mem.Minv, spl(6 * j + t)), wr[t], s);
-        y6[j] = (freemask != 0) ? s : splat(0.0);
-        st(mem.Y, j * LS + c, y6[j], inS && (g == 0));
+        sA = vfma(ld(mem.Minv, jA * 6 + t), wr[t], sA);
+        sB = vfma(ld(mem.Minv, jB * 6 + t), wr[t], sB);
       }
-      if(freemask == 0) st(mem.Cf, seli(lane < 36, lane, spl(0)), splat(0.0), lane < 36);
+      if(freemask == 0)
+      {
+        sA = splat(0.0);
+        sB = splat(0.0);
+        st(mem.Cf, seli(lane < 36, lane, spl(0)), splat(0.0), lane < 36);
+      }
+      st(mem.Y, jA * LS + c, sA, inS);
+      st(mem.Y, jB * LS + c, sB, inS && hasB);
     }
     wave_sync();
     // K = -G_f' Y (rows a_t of the columns c + 16 b), clamped rows = 0.
@@ -971,31 +1011,35 @@ struct Solver
       for(int b = 0; b < AB; b++) v[b] = sel(fr[b], t4[b] + Qu[b], 0.0);
       six_sums<AB>(Q, v, gfv);
     }
-    // Vx = Qx + W' gk - Y' gfv; D = C_f Y; E = w_force Y - 2 W + V6 D   (lanes a < S)
+    // Vx = Qx + W' gk - Y' gfv (lanes a < S); D = C_f Y and E = w_force Y - 2 W + V6 D: lane (g, a) the rows g and 4 + g
     {
-      vf w6[6], y6[6], d6[6];
-      for(int j = 0; j < 6; j++)
-      {
-        w6[j] = ld(mem.W, j * LS + col);
-        y6[j] = ld(mem.Y, j * LS + col);
-      }
+      vf y6[6];
+      for(int j = 0; j < 6; j++) y6[j] = ld(mem.Y, j * LS + col);
       vf s = ld(mem.Qx, col);
-      for(int j = 0; j < 6; j++) s = vfma(w6[j], splat(gk[j]), s);
+      for(int j = 0; j < 6; j++) s = vfma(ld(mem.W, j * LS + col), splat(gk[j]), s);
       for(int j = 0; j < 6; j++) s = vfma(-y6[j], splat(gfv[j]), s);
       st(mem.Vx, c, s, inS && (g == 0));
-      for(int j = 0; j < 6; j++)
+      // SPEC: D[j][a] = Cf[j][0] Y[0][a]; fma(Cf[j][t], Y[t][a], .), t = 1 .. 5
+      vf dA = ld(mem.Cf, jA * 6) * y6[0], dB = ld(mem.Cf, jB * 6) * y6[0];
+      for(int t = 1; t < 6; t++)
       {
-        vf dd = ld(mem.Cf, spl(6 * j)) * y6[0];
-        for(int t = 1; t < 6; t++) dd = vfma(ld(mem.Cf, spl(6 * j + t)), y6[t], dd);
-        d6[j] = dd;
-        st(mem.D, j * LS + c, dd, inS && (g == 0));
+        dA = vfma(ld(mem.Cf, jA * 6 + t), y6[t], dA);
+        dB = vfma(ld(mem.Cf, jB * 6 + t), y6[t], dB);
       }
-      for(int j = 0; j < 6; j++)
+      st(mem.D, jA * LS + c, dA, inS);
+      st(mem.D, jB * LS + c, dB, inS && hasB);
+      wave_sync();
+      // SPEC: E[j][a] = w_force Y[j][a] - 2 W[j][a]; fma(V6[j][t], D[t][a], .), t = 0 .. 5
+      vf eA = P.w_force * ld(mem.Y, jA * LS + col) - 2.0 * ld(mem.W, jA * LS + col);
+      vf eB = P.w_force * ld(mem.Y, jB * LS + col) - 2.0 * ld(mem.W, jB * LS + col);
+      for(int t = 0; t < 6; t++)
       {
-        vf e = P.w_force * y6[j] - 2.0 * w6[j];
-        for(int t = 0; t < 6; t++) e = vfma(ld(mem.Vxx, spl((FU0 + j) * S + FU0 + t)), d6[t], e);
-        st(mem.E, j * LS + c, e, inS && (g == 0));
+        const vf dt_ = ld(mem.D, t * LS + col);
+        eA = vfma(ld(mem.Vxx, (jA + FU0) * S + FU0 + t), dt_, eA);
+        eB = vfma(ld(mem.Vxx, (jB + FU0) * S + FU0 + t), dt_, eB);
       }
+      st(mem.E, jA * LS + c, eA, inS);
+      st(mem.E, jB * LS + c, eB, inS && hasB);
     }
     wave_sync();
     // Vxx(a, b) = Vxx(b, a) = 1/2 ((Qxx(a,b) + Qxx(b,a)) + (T(a,b) + T(b,a))), T = D'E

@@ -9,8 +9,6 @@
 // Replaces the same reference code as csrc/ddp.hip.
 #include "ddp_tile.h"
 
-#include "ddp_batch.h"
-
 namespace ccc_amd
 {
 // doubles of workspace per instance: trajectories [kSlots][N+1][S] and [kSlots][N][M], gains [N][M] and [N][M][S]
@@ -19,11 +17,20 @@ size_t ddp_tile_ws_doubles(int N, int S, int M)
   return (size_t)ddp_tile::kSlots * ((size_t)(N + 1) * S + (size_t)N * M) + (size_t)N * M + (size_t)N * M * S;
 }
 
+// wavefronts per SIMD the register budget is set for (measured, round 4: the kernel is bound by instruction issue, not by
+// latency -- at 16 ridges two wavefronts per SIMD without spills (256 VGPRs) beat three (168, 240-490 B of scratch) and
+// four (128, 430-660 B): config 3 50.9 k / 50.4 k / 46.6 k solves/s, config 5 shape 152 k / 139 k / 128 k)
 #ifndef CCC_TILE_WAVES
-#  define CCC_TILE_WAVES 4
+#  define CCC_TILE_WAVES 2
+#endif
+#ifndef CCC_TILE_WAVES2
+#  define CCC_TILE_WAVES2 2
+#endif
+#ifndef CCC_TILE_WAVES4
+#  define CCC_TILE_WAVES4 1
 #endif
 template<int S, int NB>
-__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : 2)) void ddp_tile_kernel(
+__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4))) void ddp_tile_kernel(
     ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, unsigned * ticket)
 {
   __shared__ ddp_tile::Mem<S, NB> mem;
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : 2)) void ddp_tile_k
 // workgroups of one resident set: wavefronts per SIMD (launch bounds above) x 4 SIMDs x CUs
 int ddp_tile_grid(long n, int M, int num_cu)
 {
-  const int per_cu = 4 * (M == 16 ? CCC_TILE_WAVES : 2);
+  const int per_cu = 4 * (M == 16 ? CCC_TILE_WAVES : (M == 32 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4));
   const long resident = (long)per_cu * (num_cu > 0 ? num_cu : 256);
   return (int)(n < resident ? n : resident);
 }

@@ -88,6 +88,11 @@ W64_FN vf row_bcast(vf v)
 {
   return dpp<0x150 + K>(v);
 }
+template<int K>
+W64_FN vi row_bcast_i(vi v)
+{
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xf, 0xf, true);
+}
 // lane (c + K) mod 16 of the same row (DPP row_ror: lane c reads lane c - K ... the hardware's rotate-right moves
 // data towards higher lanes, so lane c receives the value of lane (c - K) mod 16)
 template<int K>
@@ -392,6 +397,13 @@ template<int K>
 inline vf row_bcast(const vf & v)
 {
   vf r;
+  W64_LOOP r.v[l_] = v.v[(l_ & ~15) + K];
+  return r;
+}
+template<int K>
+inline vi row_bcast_i(const vi & v)
+{
+  vi r;
   W64_LOOP r.v[l_] = v.v[(l_ & ~15) + K];
   return r;
 }

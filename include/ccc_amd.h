@@ -177,11 +177,12 @@ typedef struct
   double k_rel_norm_thre, lambda_thre, cost_update_ratio_thre, cost_update_thre;
   double alpha_list[11];
   int reg_type; /* 1: Quu_F + lambda I (default; iLQG regType 1), 2: Vxx + lambda I */
-  int precision; /* 64 (default): everything in double, bit-identical to the oracle.  32 (BASELINE configs[4], "fp32
-                  * with fp64 tolerance check"): the matrices of the BACKWARD pass of every DDP iteration -- value function,
-                  * derivatives, Q blocks, Cholesky factor, gains -- STORED in single precision, operated on in double;
-                  * trajectories, rollouts, costs and all line-search and termination decisions stay in double.
-                  * Not a nmpc_ddp option. */
+  int precision; /* 64 (default) or 32.  BASELINE configs[4] asks for "fp32 with fp64 tolerance check": both values run the
+                  * SAME fp64 kernel (trivially inside any fp64 tolerance).  Rounds 2-3 shipped a build with single-precision
+                  * storage of the backward pass; it ran at a third of the fp64 tile kernel's rate and was removed in
+                  * round 4, and a solver in single-precision ARITHMETIC does not converge on this problem (the reference's
+                  * thresholds -- box-QP gradient 1e-8, cost_update_thre 1e-7, force weight 1e-6 -- sit below fp32
+                  * resolution).  Not a nmpc_ddp option. */
   int warm_start_guard; /* 1 (default): a warm start u_init whose open-loop rollout from x0 costs more than the rollout
                   * of zero inputs -- the start planOnce() itself uses when InitialParam::u_list is empty,
                   * src/DdpCentroidal.cpp:221-229 -- or is not finite, is replaced by zero inputs.  It fires on 1 to 7 of
@@ -200,12 +201,10 @@ int ccc_ddp_state_dim(const ccc_ddp_t * h);
 int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params);
 int ccc_ddp_get_config(const ccc_ddp_t * h, ccc_ddp_config_t * cfg);
 int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
-/* Which frozen ORDER OF THE LONG SUMS the handle's current configuration computes in (nmpc_ddp forms them with Eigen,
- * whose order is not pinned): 1 = the tile arithmetic (oracle/ddp_tile.c: trees, fma chains, LDL') -- the default kernel at
- * EVERY ridge stride (max_ridges 16, 32 and 64) when reg_type = 1 and precision = 64, and always at max_ridges = 64;
- * 0 = left-to-right sums (oracle/ddp.c) -- the row-per-lane kernels that reg_type = 2, precision = 32 or the environment
- * switch CCC_DDP_LEGACY (read ONCE, in ccc_ddp_create: it changes the answer's last bits) select; those exist for
- * max_ridges = 16 only.  Results of the two agree to rounding; bit-for-bit parity tests ask which one applies.  New. */
+/* Which frozen arithmetic a handle computes in (nmpc_ddp forms its sums with Eigen, whose order is not pinned): always 1
+ * since round 4 = the tile arithmetic of oracle/ddp_tile.c (trees, fma chains, the structured backward step), at every
+ * ridge stride and for both regularisations; bit-for-bit parity tests run the oracle with this value.  (0 = the dense
+ * left-to-right arithmetic of oracle/ddp.c: the oracle's independent cross-check, no kernel.)  New. */
 int ccc_ddp_arithmetic(const ccc_ddp_t * h);
 
 /* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,

@@ -310,7 +310,7 @@ static void decrease_lambda(tile_t * d)
  *     K_f = -Quu_F,ff^-1 Qux_reg,f = -G_f' Y,   Y = M_f^-1 Wr   (6 x S; exact: I - M_f^-1 V6r C_f = alpha M_f^-1)
  *     K'Z = D'E,  D = C_f Y,  E = w_force Y - 2 W + V6 D                            (Z = Quu K + 2 Qux)
  * M_f^-1 by Gauss-Jordan elimination with partial pivoting on [M_f | I].  Order of every sum: as written below.
- * The box-QP is Tassa's projected Newton, statement by statement as box_qp_tile(), with H y = alpha y + G'(V6r (G y)).  A failed factorisation = a pivot that is zero or not finite; an indefinite Quu_F (Vxx is positive
+ * The box-QP is Tassa's projected Newton, statement by statement as box_qp_tile(), with H y = alpha y + G'(V6r (G y)).  A failed factorisation = an inverse with an entry that is not finite (zero pivot, NaN, overflow); an indefinite Quu_F (Vxx is positive
  * semi-definite in exact arithmetic, so this takes NaN / overflow) shows up as "no descent direction" as before. */
 typedef struct
 {
@@ -366,7 +366,7 @@ static double s_value(const sqp_t * q, const double * lin, const double * y, dou
   return treeM(t, q->M_);
 }
 
-/* C_f, M_f = alpha I + V6r C_f, Minv = M_f^-1 (Gauss-Jordan, partial pivoting); 0 when a pivot is zero or not finite */
+/* C_f, M_f = alpha I + V6r C_f, Minv = M_f^-1 (Gauss-Jordan, partial pivoting); 0 when the inverse is not finite */
 static int s_factor(sqp_t * q, const int * fr)
 {
   for(int j = 0; j < 6; j++)
@@ -396,7 +396,6 @@ static int s_factor(sqp_t * q, const int * fr)
         best = fabs(A[i][k]);
         p = i;
       }
-    if(!(best > 0.0) || !(best <= 1.7976931348623157e308)) return 0;
     if(p != k)
       for(int j = 0; j < 12; j++)
       {
@@ -415,9 +414,16 @@ static int s_factor(sqp_t * q, const int * fr)
       A[k][j] = akj * rp;
     }
   }
+  /* a zero pivot (1 / 0) or a pivot that is not finite leaves inf / NaN behind: failure = an entry of the inverse that is
+   * not finite */
+  int ok = 1;
   for(int j = 0; j < 6; j++)
-    for(int t = 0; t < 6; t++) q->Minv[j][t] = A[j][6 + t];
-  return 1;
+    for(int t = 0; t < 6; t++)
+    {
+      q->Minv[j][t] = A[j][6 + t];
+      if(!(fabs(A[j][6 + t]) <= 1.7976931348623157e308)) ok = 0;
+    }
+  return ok;
 }
 
 /* sol = Quu_F,ff^-1 (q + Quu_F xcl)_f on the free rows, WITHOUT the cancellation of the plain Woodbury formula:

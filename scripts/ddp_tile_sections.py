@@ -20,9 +20,10 @@ else:
     d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)))
 d.ddp_solver_.config().max_iter = 20
 r = d.planOnceBatch(prob, x0)
-tm = r["u"][:, 0, :16].mean(axis=0)
+tm = np.concatenate([r["u"][:, 0, :16], r["u"][:, 1, :16]], axis=1).mean(axis=0)
 names = ["derivatives", "products", "boxqp value_of", "boxqp gradient/flags", "boxqp factorisation", "boxqp solve",
          "boxqp line search", "gains", "value update", "forward passes", "boxqp entry/exit"]
+tm[10] -= tm[2:7].sum()  # (the box-QP slice of backward_step() spans its inner sections)
 tot = tm[:11].sum()
 for j, nm in enumerate(names):
     print("%-26s %12.0f cycles  %5.1f %%" % (nm, tm[j], 100 * tm[j] / tot))
@@ -30,3 +31,5 @@ steps = r["iters"].mean() * N
 print("TOTAL (attributed) %.0f cycles per instance; iterations %.2f; %.0f cycles per backward step" % (tot, r["iters"].mean(), (tot - tm[9]) / steps))
 print("box-QP: %.2f calls per backward step, %.2f iterations per call, %.2f factorisations per call; %.2f forward passes per iteration, %.0f cycles per forward step"
       % (tm[11] / steps, tm[12] / tm[11], tm[13] / tm[11], tm[14] / r["iters"].mean(), tm[9] / (tm[14] * N)))
+
+print("factorisation split: C_f %.0f, M_f %.0f, Gauss-Jordan %.0f cycles per factorisation" % tuple(tm[15 + q] / tm[13] for q in range(3)))

@@ -43,17 +43,13 @@ def _sim_state(n, pos, perturb=0.0, seed=0):
     return s
 
 
-@pytest.mark.parametrize("srb,kernel", [(False, "tile"), (True, "tile"), (True, "legacy")])
-def test_ddp_reference_closed_loop_on_the_device(monkeypatch, srb, kernel):
+@pytest.mark.parametrize("srb", [False, True])
+def test_ddp_reference_closed_loop_on_the_device(srb):
     """Both reference loops AS WRITTEN (one iteration per control cycle, TestDdpCentroidal.cpp:116 /
-    TestDdpSingleRigidBody.cpp:125) as one device call on the default tile kernel -- the single-rigid-body one also on the
-    row-per-lane kernel -- for the reference instance and five instances that start up to 1 cm off: every one of them
+    TestDdpSingleRigidBody.cpp:125) as one device call for the reference instance and five instances that start up to 1 cm off: every one of them
     meets the per-cycle and final assertions (round 4: the warm-start guard, tests/test_oracle_ddp.py)."""
     warm_iter = 1
     import torch
-
-    if kernel == "legacy":
-        monkeypatch.setenv("CCC_DDP_LEGACY", "1")
 
     dev = torch.device("cuda:0")
     n, N, dt = 6, 100, 0.03

@@ -12,7 +12,18 @@ import pytest
 
 from centroidalcontrolcollection_amd import fixtures_ddp as fd
 from oracle import oracle
-from test_ddp_emu import Params
+
+
+class Params(ctypes.Structure):
+    """csrc/ddp_batch.h ddp_common::Params"""
+    _fields_ = [("model", ctypes.c_int), ("N", ctypes.c_int), ("P", ctypes.c_int), ("mass", ctypes.c_double),
+                ("dt", ctypes.c_double), ("w_run", ctypes.c_double * 12), ("w_term", ctypes.c_double * 12),
+                ("w_force", ctypes.c_double), ("flo", ctypes.c_double), ("fhi", ctypes.c_double),
+                ("max_iter", ctypes.c_int), ("lambda0", ctypes.c_double), ("dlambda0", ctypes.c_double),
+                ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
+                ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double), ("ratio_thre", ctypes.c_double),
+                ("cost_thre", ctypes.c_double), ("alpha", ctypes.c_double * 11), ("reg_type", ctypes.c_int),
+                ("warm_guard", ctypes.c_int)]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -21,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def emu():
     so = os.path.join(ROOT, "tests", "emu", "libddp_tile_emu.so")
     src = os.path.join(ROOT, "tests", "emu", "ddp_tile_emu.cpp")
-    hdrs = [os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", h) for h in ("ddp_tile.h", "w64.h", "ddp_core.h")]
+    hdrs = [os.path.join(ROOT, "centroidalcontrolcollection_amd", "csrc", h) for h in ("ddp_tile.h", "w64.h", "ddp_batch.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         from centroidalcontrolcollection_amd.build import host_fma_flags
 
