@@ -138,6 +138,25 @@ def cpu_baseline(batch, seconds_budget=20.0):
                 value_1thread=rate1, parallel_efficiency=(n_mt / best) / (rate1 * cores)), r["zmp"], n_mt
 
 
+def distributed_info(dist, dev, world):
+    """What the SCALE record can be checked against: the backend, the world size torch.distributed reports, the number of
+    DISTINCT GPUs the ranks sit on (PCI bus ids all-gathered through the job's own process group) and RCCL's version."""
+    import torch
+
+    if world <= 1 or dist is None:
+        return {"backend": None, "world_size": 1, "distinct_gpus": 1}
+    prop = torch.cuda.get_device_properties(dev)
+    ident = "%s/%s/%s" % (os.uname().nodename, getattr(prop, "pci_bus_id", dev.index), getattr(prop, "uuid", ""))
+    ids = [None] * world
+    dist.all_gather_object(ids, ident)
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "distinct_gpus": len(set(ids))}
+    try:
+        info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,8 +204,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    dinfo = distributed_info(dist, dev, world)
     if args.workload != "zmp":
         import bench_secondary
+
+        args.distributed_info = dinfo
 
         bench_secondary.run(args, rank, world, local_rank, dist)
         if world > 1:
@@ -413,6 +435,7 @@ def main():
             "pivots_per_solve": pivots_per_solve,
             "unsolved": n_bad,
         }
+        out["distributed"] = dinfo
         if strong is not None:
             out["strong_scaling"] = strong
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle meanwhile)

@@ -277,6 +277,12 @@ DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), 
 def run(args, rank, world, local_rank, dist):
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
+    strong = getattr(args, "scaling", "weak") == "strong" and world > 1
+    if strong:
+        # BASELINE's literal configurations (config 4: 65536 in total over 8 GPUs, config 5: 32768): contiguous shards
+        if n % world:
+            raise SystemExit("--scaling strong needs the batch divisible by the number of GPUs")
+        n //= world
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
                 walk=lambda a, b, c: _ddp(a, b, c, False, True), multi=lambda a, b, c: _ddp(a, b, c, False, "multi"))
@@ -326,8 +332,10 @@ def run(args, rank, world, local_rank, dist):
     achieved = w["algo_bytes"] * n / kavg / 1e9
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
-           "config": {"workload": w["workload"], "batch_per_gpu": n, "parallelism": "batch-sharded x%d" % world,
+           "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
+           "distributed": getattr(args, "distributed_info", None),
+           "config": {"workload": w["workload"], "batch_per_gpu": n, "total_batch": world * n,
+                      "parallelism": "batch-sharded x%d" % world,
                       "collective": "all_gather(planned outputs)" if world > 1 else "none"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": w["algo_bytes"] * n,
@@ -358,10 +366,13 @@ def run(args, rank, world, local_rank, dist):
         out["roofline"]["valu"] = dict(achieved=tfl, peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s",
                                        frac=tfl / FP64_VECTOR_PEAK_TFLOPS, **v)
     if not args.no_cpu_baseline and world == 1:
-        cores = os.cpu_count() or 1
+        import bench  # (host_cores: physical cores within the affinity mask and the cgroup CPU quota)
+
+        hw_threads, cores = bench.host_cores()
         rate, ns, err, what = w["cpu"](cores)
-        out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": cores, "kind": "port",
-                               "sample": "first %d instances of the rank-0 batch, OpenMP over instances, %d threads; C "
-                                         "restatement of the reference path (oracle/)" % (ns, cores)}
+        out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": cores, "threads": cores,
+                               "host_hardware_threads": hw_threads, "kind": "port",
+                               "sample": "first %d instances of the rank-0 batch, OpenMP over instances, one thread per "
+                                         "physical core (%d); C restatement of the reference path (oracle/)" % (ns, cores)}
         out["parity"] = {"value": err, "what": what}
     print(json.dumps(out))

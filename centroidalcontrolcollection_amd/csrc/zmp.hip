@@ -22,7 +22,7 @@
 // Mapping: N <= 32 (K1, zmp_plan_kernel): the two axes of one instance are the two 32-lane halves of ONE wavefront
 // (one planOnce() per wavefront), the tableau in registers.  32 < N <= 200 (K2, zmp_plan_sym_kernel): one QP per
 // workgroup, the tableau packed (lower triangle, sym_tableau.h) in LDS.  200 < N <= 256 (K3, zmp_plan_block_kernel):
-// the full tableau in an HBM workspace.
+// the full tableau in an HBM workspace; 256 < N <= 512: the same kernel at 512 rows (1024 threads per workgroup).
 #include "common.h"
 #include "sym_tableau.h"
 #include "wave_group.h"
@@ -356,7 +356,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
 // coalesced).  Slow (every pivot streams 2 x 512 KB through L2) -- there for completeness of the drop-in surface.
 // Same dual active-set iteration and closing refinement as zmp_plan_kernel.
 // ---------------------------------------------------------------------------------------------
-constexpr int kBigNP = 256;
+constexpr int kBigNP = 256;  // 200 < N <= 256
+constexpr int kHugeNP = 512; // 256 < N <= 512 (round 4: BASELINE config 1 as worded at a 5 ms step is 400 steps)
 
 // -DCCC_ZMP_PROF (development builds only, scripts/zprof.py): the LDS-tableau kernels time the phases of a pivot with
 // s_memtime (ZPROF(k) closes phase k: 0 selection, 1 ratio test, 2 pivot-column staging, 3 tile update, 4 row rewrite +
@@ -364,14 +365,14 @@ constexpr int kBigNP = 256;
 // wall-clock span and start time of the QP: that is how the idle tail of grid-stride scheduling was found).
 struct BlockRed
 {
-  double val[4];
-  int idx[4];
+  double val[8];
+  int idx[8];
 };
 
 struct SelRed
 {
-  double val[4], sig[4];
-  int idx[4];
+  double val[8], sig[8];
+  int idx[8];
 };
 
 __device__ __forceinline__ double wave_lane_value(double v, int k) // k uniform: two v_readlane_b32, no LDS round trip
@@ -1077,16 +1078,21 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   h->last_kernel = h->N > 200 ? "zmp_plan_block_kernel" : "zmp_plan_sym_kernel";
   if(h->N > 200) // beyond the LDS: the tableau in HBM
   {
+    const int NPb = h->NP; // kBigNP or kHugeNP
     const int blocks = h->num_cu * 2;
     if(!h->ws_big)
     {
       CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
-      CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * kBigNP * kBigNP * sizeof(double)));
+      CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * NPb * NPb * sizeof(double)));
     }
-    const size_t lds = (size_t)kBigNP * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
+    const size_t lds = (size_t)NPb * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     const int grid = (int)std::min<int64_t>(nqp, blocks);
-    hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
-                       x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
+    if(NPb == kBigNP)
+      hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
+                         x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
+    else
+      hipLaunchKernelGGL((zmp_plan_block_kernel<kHugeNP, true, 2>), dim3(grid), dim3(kHugeNP * 2), lds, stream, P, (long)nqp,
+                         x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
@@ -1146,15 +1152,15 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(!(com_height > 0) || !(horizon_duration > 0) || !(horizon_dt > 0))
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_zmp_create: com_height, horizon_duration, horizon_dt must be > 0");
   const int N = (int)std::ceil(horizon_duration / horizon_dt); // src/LinearMpcZmp.cpp:13
-  if(N > kBigNP)
-    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > %d is not built into this library", N, kBigNP);
+  if(N > kHugeNP)
+    return fail(CCC_ERR_UNSUPPORTED, "ccc_zmp_create: horizon_steps %d > %d is not built into this library", N, kHugeNP);
   int rc = select_device(device);
   if(rc != CCC_OK) return rc;
   CCC_DEVICE_GUARD(device);
   ccc_zmp * h = new ccc_zmp();
   h->device = device;
   h->N = N;
-  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 96 ? 96 : (N <= 128 ? 128 : kBigNP)));
+  h->NP = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 96 ? 96 : (N <= 128 ? 128 : (N <= kBigNP ? kBigNP : kHugeNP))));
   h->com_height = com_height;
   h->horizon_duration = horizon_duration;
   h->horizon_dt = horizon_dt;

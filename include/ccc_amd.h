@@ -58,7 +58,7 @@ typedef struct ccc_zmp ccc_zmp_t;
  * (src/LinearMpcZmp.cpp:9-28): builds the jerk-input CoM-ZMP model, its ZOH discretisation, the
  * output-condensed sequence matrices and the batch-constant QP data, and uploads them to `device`.
  * qp_solver_type has no equivalent: the QP is solved by this library's own exact active-set kernel.
- * horizon_steps = ceil(horizon_duration / horizon_dt) must be <= 256 (CCC_ERR_UNSUPPORTED beyond). */
+ * horizon_steps = ceil(horizon_duration / horizon_dt) must be <= 512 (CCC_ERR_UNSUPPORTED beyond). */
 int ccc_zmp_create(double com_height, double horizon_duration, double horizon_dt, int device, ccc_zmp_t ** out);
 void ccc_zmp_destroy(ccc_zmp_t * h);
 /* horizon_steps_ = ceil(horizon_duration / horizon_dt)      src/LinearMpcZmp.cpp:13 */

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(port, extra):
-    env = dict(os.environ, CCC_BENCH_BACKEND="gloo")
+def _run(port, extra, backend="gloo"):
+    env = dict(os.environ, CCC_BENCH_BACKEND=backend)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -54,3 +54,22 @@ def test_ddpzmp_workload_two_ranks():
     d = _run(29613, ["--workload", "ddpzmp", "--steps", "3", "--warmup", "1", "--batch", "1024"])
     assert d["n_gpus"] == 2 and d["unsolved"] == 0 and d["value"] > 0 and d["mean_iterations"] == 3.0
     assert d["config"]["collective"].startswith("all_gather")
+
+
+def test_secondary_workload_strong_scaling_flag():
+    d = _run(29615, ["--workload", "srb", "--steps", "1", "--warmup", "1", "--batch", "512", "--scaling", "strong"])
+    assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 256 and d["config"]["total_batch"] == 512
+    assert d["distributed"]["world_size"] == 2 and d["distributed"]["backend"] == "gloo"
+    assert d["distributed"]["distinct_gpus"] == 1  # (two ranks share the one GPU of this box)
+
+
+def test_rccl_backend_two_gpus():
+    """The driver's own launch (backend nccl = RCCL, one rank per GPU) at world size 2: needs two GPUs, skips on the
+    single-GPU box.  Checks the line's `distributed` object: two ranks on two DISTINCT devices."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the RCCL path needs two")
+    d = _run(29616, ["--steps", "4", "--warmup", "1", "--batch", "8192"], backend="nccl")
+    assert d["n_gpus"] == 2 and d["unsolved"] == 0
+    assert d["distributed"] == dict(d["distributed"], backend="nccl", world_size=2, distinct_gpus=2)

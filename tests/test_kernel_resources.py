@@ -20,13 +20,14 @@ EXPECT = {
     "void ccc_amd::zmp_plan_kernel_dyn<32, 2>": ("zmp", 168, 3, 0, None),      # K1, work queue (headline)
     "void ccc_amd::zmp_plan_sym_kernel<40, 4, 2>": ("zmp", 128, 4, 0, None),   # K2 at 40 rows: 16 workgroups per CU
     "void ccc_amd::zmp_plan_sym_kernel<104, 4, 2>": ("zmp", 168, 3, 0, None),  # K2 at the reference test's horizon
-    # DDP default kernel (round 4: structured backward step -- no M x M object, LDS independent of the ridge stride)
-    "void ccc_amd::ddp_tile_kernel<9, 1>": ("ddp_tile", 128, 4, 450, 10240),    # sixteen wavefronts per CU
-    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 128, 4, 700, 10240),
-    "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 400, 10240),    # 32 ridges: eight wavefronts per CU
+    # DDP kernel (round 4: structured backward step -- no M x M object, LDS independent of the ridge stride; bound by
+    # instruction issue, so the register budget is set for NO spills rather than for occupancy: csrc/ddp_tile.hip)
+    "void ccc_amd::ddp_tile_kernel<9, 1>": ("ddp_tile", 256, 2, 0, 10240),
+    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 160, 10240),
+    "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 400, 10240),    # 32 ridges
     "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 400, 10240),
-    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 256, 2, 128, 12288),    # 64 ridges: eight wavefronts per CU
-    "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 256, 2, 128, 12288),
+    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 160, 12288),    # 64 ridges: one wavefront per SIMD
+    "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 512, 1, 160, 12288),
     "ccc_amd::z_plan_stream_kernel": ("z", 168, 3, 0, None),
     "void ccc_amd::z_plan_kernel<40, 1>": ("z", 168, 3, 0, 14336),             # eleven workgroups per CU
     "ccc_amd::ism_plan_pcr_kernel": ("ism", 128, 4, 0, 24576),

@@ -198,8 +198,22 @@ def test_n200_packed_lds_tableau():
     log, fin = fx.run_closed_loop(mpc.planOnce, end_time=3.0)
     for rec in log:
         assert np.all(rec["zmp"] - rec["zmin"] >= 0) and np.all(rec["zmax"] - rec["zmp"] >= 0)
+
+
+def test_n400_config1_at_5_ms_and_the_horizon_limit():
+    """BASELINE.json configs[0] as worded with the reference's control period as horizon step: 2 s @ 5 ms = 400 steps (the
+    HBM-resident tableau at 512 rows, round 4 -- VERDICT r3 item 7).  Parity with the oracle; beyond 512 steps the
+    constructor refuses (CCC_ERR_UNSUPPORTED), never a silent truncation."""
+    mpc = LinearMpcZmp(1.0, 2.0, 0.005)
+    assert mpc.horizon_steps_ == 400
+    b = fx.make_zmp_batch(12, 400, 0.005, seed=41)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.005).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
     with pytest.raises(_lib.CccError):
-        LinearMpcZmp(1.0, 2.0, 0.005)  # 400 steps: not built
+        LinearMpcZmp(1.0, 2.0, 0.0025)  # 800 steps: not built
 
 
 @pytest.mark.parametrize("N", [36, 47, 64, 72, 90, 112, 128, 150, 180, 230])
