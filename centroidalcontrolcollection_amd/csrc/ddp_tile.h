@@ -540,6 +540,7 @@ struct Solver
     vf G[B][6];
     vf Ga[B], Gb[B];                    // the rows' own components of g_r: [g] and [4 + (g & 1)]
     vf u[B];                            // the step's nominal inputs (Qu = w_force u + G' Vx6)
+    vf v6r[6];                          // lane j < 6: row j of V6r = Vxx[rows6, rows6] (+ lv on the diagonal)
     vb in[B];
   };
   static W64_FN vf pick4(vi g, const vf (&v)[6]) { return sel(g == 0, v[0], sel(g == 1, v[1], sel(g == 2, v[2], v[3]))); }
@@ -580,7 +581,7 @@ struct Solver
   {
     double gy[6], vy[6];
     six_sums<AB>(Q, y, gy);
-    apply6([&](int l) { return v6r_elem(l, Q.lv); }, gy, vy);
+    apply6([&](int l) { return Q.v6r[l]; }, gy, vy);
     for(int b = 0; b < AB; b++)
     {
       vf s = Q.alpha * y[b];
@@ -700,10 +701,10 @@ struct Solver
     // SPEC: beta_j = Vx6_j; fma(V6r[j][l], gxc_l, .), l = 0 .. 5
     {
       vf sb = ld(mem.Vx, j6 + FU0);
-      for(int l = 0; l < 6; l++) sb = vfma(v6r_elem(l, Q.lv), splat(gxc[l]), sb);
+      for(int l = 0; l < 6; l++) sb = vfma(Q.v6r[l], splat(gxc[l]), sb);
       for(int j = 0; j < 6; j++) beta[j] = read_lane(sb, j);
     }
-    apply6([&](int l) { return v6r_elem(l, Q.lv); }, gfu, tv);
+    apply6([&](int l) { return Q.v6r[l]; }, gfu, tv);
     for(int j = 0; j < 6; j++) delta[j] = std::fma(-Q.ratio, tv[j], beta[j]);
     apply6([&](int l) { return ld(mem.Minv, j6 * 6 + l); }, delta, gamma);
     for(int b = 0; b < AB; b++)
@@ -880,6 +881,7 @@ struct Solver
       Q.Gb[b] = sel((g & 1) == 0, Q.G[b][4], Q.G[b][5]);
       Q.u[b] = u[b];
     }
+    for(int l = 0; l < 6; l++) Q.v6r[l] = v6r_elem(l, lv);
     // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
     {
       vf s3[3];

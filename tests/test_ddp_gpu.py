@@ -436,20 +436,24 @@ def test_unused_entries_of_the_phase_table_do_not_change_the_plan():
 
 
 def test_wide_limits_are_reported():
-    """max_ridges other than 16 / 32 / 64 and precision 32 on a wide handle: CCC_ERR_UNSUPPORTED, as documented."""
+    """The one limit the DDP planners keep: a ridge stride other than 16 / 32 / 64 is CCC_ERR_UNSUPPORTED, as documented
+    (more than four 4-vertex surface contacts in one contact_list).  Every configuration -- reg_type 2, a precision-32
+    request -- runs at every stride since round 4."""
     from centroidalcontrolcollection_amd import _lib
 
     w = DdpCentroidal.WeightParam()
-    with pytest.raises(_lib.CccError) as e:
-        DdpCentroidal(100.0, 0.05, 20, w, max_ridges=48)
-    assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
+    for bad in (48, 80, 128):
+        with pytest.raises(_lib.CccError) as e:
+            DdpCentroidal(100.0, 0.05, 20, w, max_ridges=bad)
+        assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
     prob, x0 = fd.make_walking_batch(2, 20, 0.05, seed=1)
     P = prob["phase_dim"].shape[1]
     d2 = DdpCentroidal(100.0, 0.05, 20, w, max_phases=P, max_ridges=32)
+    r64 = d2.planOnceBatch(prob, x0)
     d2.ddp_solver_.config().precision = 32
-    with pytest.raises(_lib.CccError) as e:
-        d2.planOnceBatch(prob, x0)
-    assert e.value.code == _lib.CCC_ERR_UNSUPPORTED
+    d2.ddp_solver_.config().reg_type = 2
+    r = d2.planOnceBatch(prob, x0)
+    assert np.all(r["status"] >= 0) and np.all(np.isfinite(r["u"])) and not np.array_equal(r["u"], r64["u"])
 
 
 # ------------------------------------------------------------------------------------------ independent known answers
