@@ -53,9 +53,6 @@ using namespace w64;
 using ddp_common::Params;
 
 // unroll factors of the loops whose full unrolling costs more registers than four wavefronts per SIMD leave (measured)
-#ifndef CCC_TILE_U_PROD
-#  define CCC_TILE_U_PROD 3
-#endif
 // (the Z loop: per model, see Solver::kUnrollZ)
 #ifndef CCC_TILE_U_CF
 #  define CCC_TILE_U_CF 8
@@ -216,6 +213,13 @@ struct Solver
   static constexpr int kUnrollZ = CCC_TILE_U_Z;
 #else
   static constexpr int kUnrollZ = (S == 9) ? 4 : 2;
+#endif
+  // unroll factor of the S-term products T1 = Vxx Fx, Qxx = Fx' T1 (measured, round 4, 16 ridges at 256 VGPRs: fully
+  // unrolled + 1.5 % for 100-200 B of scratch -- not taken; fully unrolled at 128 VGPRs: - 25 %)
+#ifdef CCC_TILE_U_PROD
+  static constexpr int kUnrollProd = CCC_TILE_U_PROD;
+#else
+  static constexpr int kUnrollProd = 3;
 #endif
   // one bit per ridge: clamped-or-unused sets
   using mask_t = std::conditional_t<(B <= 2), unsigned, unsigned long long>;
@@ -887,7 +891,7 @@ struct Solver
       vf s3[3];
       const vf f0 = ld(mem.Fx, col);
       for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
-      W64_UNROLL(CCC_TILE_U_PROD)
+      W64_UNROLL_T(kUnrollProd)
       for(int b = 1; b < S; b++)
       {
         const vf fb = ld(mem.Fx, col + b * S);
@@ -902,7 +906,7 @@ struct Solver
     vf Qxx[3];
     {
       for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
-      W64_UNROLL(CCC_TILE_U_PROD)
+      W64_UNROLL_T(kUnrollProd)
       for(int b = 0; b < S; b++)
       {
         const vf tb = ld(mem.T1, col + b * S);
