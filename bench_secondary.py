@@ -330,6 +330,19 @@ def run(args, rank, world, local_rank, dist):
     if callable(sb):
         sb = sb(st)
     achieved = w["algo_bytes"] * n / kavg / 1e9
+    # measured HBM bytes per launch / per step of THIS workload at THIS batch, from the round's PMC passes (rocprofv3
+    # FETCH_SIZE x 2 + WRITE_SIZE, separate runs: scripts/prof_round.sh + scripts/summarize_round.py -> profiles/); null
+    # when the passes were not collected for this configuration.  A counter needs rocprofv3 around the process, so the
+    # figure is read back from the committed summary of the same command, not measured inside this run.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_hbm_traffic.json")) as f:
+            tr = json.load(f).get(args.workload)
+        if tr and tr.get("batch") == n:
+            traffic = tr.get("hbm_bytes_per_launch", tr.get("hbm_bytes_per_step"))
+            traffic_src = "profiles/r04_hbm_traffic.json"
+    except Exception:
+        pass
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
@@ -338,7 +351,8 @@ def run(args, rank, world, local_rank, dist):
                       "parallelism": "batch-sharded x%d" % world,
                       "collective": "all_gather(planned outputs)" if world > 1 else "none"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": w["algo_bytes"] * n,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                        "algorithmic_bytes": w["algo_bytes"] * n,
                         "kernel": w["kernel"], "kernel_avg_ms": kavg * 1e3,
                         "workspace": None if sb is None else {
                             "modelled_bytes": sb * n, "achieved": sb * n / kavg / 1e9, "unit": "GB/s",

@@ -144,7 +144,8 @@ struct alignas(16) Mem
   alignas(16) double Y[6 * LS];        // M_f^-1 Wr
   alignas(16) double D[6 * LS];        // C_f Y
   alignas(16) double E[6 * LS];        // w_force Y - 2 W + V6 D
-  alignas(16) double Gl[6 * M];        // the six non-zero rows of Fu    [j * M + r]
+  static constexpr int LG = M + 1;     // row stride of the g_r table: odd, so that its six rows start in different banks
+  alignas(16) double Gl[6 * LG];       // the six non-zero rows of Fu    [j * LG + r]
   alignas(16) double Cf[36], Mf[36], Minv[36];
   alignas(16) double Vx[16], Qx[16];
   double wrun[16], wterm[16];
@@ -204,6 +205,7 @@ struct Solver
   static_assert(B == 1 || B == 2 || B == 4, "16, 32 or 64 ridges per step");
   static constexpr int M = 16 * B;
   static constexpr int LS = Mem<S, B>::LS;
+  static constexpr int LG = Mem<S, B>::LG;
   static constexpr int FU0 = (S == 9) ? 3 : 6; // first non-zero row of Fu (its six non-zero rows are FU0 .. FU0+5)
   static constexpr int NP = S * (S + 1) / 2;   // entries of the upper triangle of Vxx
   static constexpr int NPASS = (NP + 63) / 64;
@@ -609,7 +611,7 @@ struct Solver
       W64_UNROLL(CCC_TILE_U_CF)
       for(int r = 0; r < 16 * AB; r++)
       {
-        const vf nx = vfma(ld(mem.Gl, j * M + r), ld(mem.Gl, l * M + r), acc);
+        const vf nx = vfma(ld(mem.Gl, j * LG + r), ld(mem.Gl, l * LG + r), acc);
         acc = ((freemask >> r) & 1u) ? nx : acc;
       }
       st(mem.Cf, n, acc, live);
@@ -879,7 +881,7 @@ struct Solver
       for(int j = 0; j < 6; j++)
       {
         Q.G[b][j] = sel(Q.in[b], Fu[b][j], 0.0);
-        st(mem.Gl, j * M + c + 16 * b, Q.G[b][j], g == 0);
+        st(mem.Gl, j * LG + c + 16 * b, Q.G[b][j], g == 0);
       }
       Q.Ga[b] = pick4(g, Q.G[b]);
       Q.Gb[b] = sel((g & 1) == 0, Q.G[b][4], Q.G[b][5]);
