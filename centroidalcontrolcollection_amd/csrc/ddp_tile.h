@@ -1129,7 +1129,11 @@ struct Solver
 
   // ------------------------------------------------------------------------------------------------ forward passes
   // Four candidates at once: row g rolls out alpha[first + g] into slot cand[g].  Returns the costs per row.
+#ifdef CCC_TILE_NO_PREFETCH_K
+  static constexpr bool kPrefetchK = false;
+#else
   static constexpr bool kPrefetchK = (B == 1); // the gain rows of the next step fetched a step ahead (registers permitting)
+#endif
   // one step of the rollouts with the first AB <= B blocks of 16 ridges live (the further ones are written as zeros)
   template<int AB>
   W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, const vf (&ui)[B], const vf (&ki)[B],

@@ -22,11 +22,18 @@ __global__ __launch_bounds__(64) void probe(const double * __restrict__ Bv, cons
                                             int N, long n)
 {
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  __shared__ double T[8 * 16]; // T = P B_s' (6 x 16), rows 6, 7 zero (the K padding of the MFMA path)
+  __shared__ double T[8 * 16];  // T = P B_s' (6 x 16), rows 6, 7 zero (the K padding of the MFMA path)
+  __shared__ double Bl[20 * 8 * 16]; // the instance's ridge vectors, [stage][k (6, padded to 8 with zeros)][ridge]
   for(long b = blockIdx.x; b < n; b += gridDim.x)
   {
     const double * Bi = Bv + b * N * 96; // [stage][6][16]
     const double * Pi = Pm + b * N * 36; // [stage][6][6]  (P_{s,s'} stands in as P_{s'}: the probe times the contraction)
+    __syncthreads();
+    for(int e = lane; e < N * 128; e += 64)
+    {
+      const int st = e >> 7, k = (e >> 4) & 7, r = e & 15;
+      Bl[e] = k < 6 ? Bi[st * 96 + k * 16 + r] : 0.0;
+    }
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     for(int sp = 0; sp < N; sp++)
     {
@@ -37,32 +44,32 @@ __global__ __launch_bounds__(64) void probe(const double * __restrict__ Bv, cons
         const int j = g + 4 * jj;
         double t = 0.0;
         if(j < 6)
-          for(int l = 0; l < 6; l++) t = fma(Pi[sp * 36 + j * 6 + l], Bi[sp * 96 + l * 16 + c], t);
+          for(int l = 0; l < 6; l++) t = fma(Pi[sp * 36 + j * 6 + l], Bl[sp * 128 + l * 16 + c], t);
         T[j * 16 + c] = t;
       }
       __syncthreads();
+      const double t0 = T[g * 16 + c], t1 = T[(g + 4) * 16 + c];
       for(int s = 0; s <= sp; s++)
       {
         if(MFMA)
         {
-          // A = B_s' (16 x K): lane (g, c) supplies A[c][k = g] of each K chunk; B = T (K x 16): lane supplies T[k = g][c]
-          const double a0 = Bi[s * 96 + g * 16 + c];
-          const double a1 = (g + 4 < 6) ? Bi[s * 96 + (g + 4) * 16 + c] : 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, T[g * 16 + c], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, T[(g + 4) * 16 + c], acc, 0, 0, 0);
+          // A = B_s' (16 x K): lane (g, c) supplies A[i = c][k = g] of each K chunk; B = T (K x 16): lane supplies T[k = g][j = c]
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[s * 128 + g * 16 + c], t0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Bl[s * 128 + (g + 4) * 16 + c], t1, acc, 0, 0, 0);
         }
         else
         {
-          // rows 4g .. 4g+3 of column c: H[r][c] = sum_k B_s[k][r] T[k][c]
+          // rows 4g .. 4g+3 of column c: H[r][c] = sum_k B_s[k][r] T[k][c]   (operands from LDS: B_s rows as b128 pairs)
           for(int k = 0; k < 6; k++)
           {
             const double tk = T[k * 16 + c];
-            for(int q = 0; q < 4; q++) acc[q] = fma(Bi[s * 96 + k * 16 + 4 * g + q], tk, acc[q]);
+            for(int q = 0; q < 4; q++) acc[q] = fma(Bl[s * 128 + k * 16 + 4 * g + q], tk, acc[q]);
           }
         }
       }
     }
-    for(int q = 0; q < 4; q++) out[b * 256 + (4 * g + q) * 16 + c] = acc[q];
+    // (output layout of v_mfma_f64_16x16x4_f64, measured on gfx950: register q of lane (g, c) is D[4 q + g][c])
+    for(int q = 0; q < 4; q++) out[b * 256 + (MFMA ? 4 * q + g : 4 * g + q) * 16 + c] = acc[q];
   }
 }
 
