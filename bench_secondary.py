@@ -167,9 +167,12 @@ def _ddp_valu(S, M, N, iters, walking):
     return dict(flop_per_solve=per_step * N * iters, flop_per_backward_step=per_step,
                 issue_frac=None if pmc is None else pmc["valu_issue_frac"],
                 wait_frac=None if pmc is None else pmc["wait_any_frac"],
+                simd_valu_busy_frac=None if pmc is None else pmc.get("simd_valu_busy_frac"),
                 counters_source="profiles/r04_ddp_valu_counters.json" if pmc else None,
                 what="useful fp64 flop of the backward passes over the kernel time against the vector-fp64 peak; "
-                     "issue_frac = SQ_INSTS_VALU x 4 clk / (SIMDs x kernel clocks), wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
+                     "issue_frac = SQ_INSTS_VALU x 4 clk / (SIMDs x kernel clocks at the 2.4 GHz PEAK clock), wait_frac = SQ_WAIT_ANY / "
+                     "SQ_WAVE_CYCLES, simd_valu_busy_frac = SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES (clock-independent: "
+                     "what says the kernel is bound by VALU instruction throughput)")
 
 
 def _ism(n, dev, rank):

@@ -39,6 +39,14 @@ for name, match in MATCH.items():
     ms = kernel_ms(name, match)
     valu[KEY[name]] = dict(valu_issue_frac=c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * ms * 1e6 * 2.4),
                            wait_any_frac=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
+                           # share of a wavefront's resident time in which it executes a VALU instruction, and -- x the
+                           # wavefronts that share a SIMD (persistent grid: SQ_WAVES / 1024 SIMDs) -- how busy the SIMD's
+                           # one VALU is.  Independent of the clock (the 2.4 GHz in valu_issue_frac is the PEAK clock; these
+                           # kernels run at ~1.3 GHz: SQ_WAVE_CYCLES x 4 / waves / kernel time)
+                           valu_active_frac_of_wave=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"],
+                           waves_per_simd=c["SQ_WAVES"] / 1024.0,
+                           simd_valu_busy_frac=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * c["SQ_WAVES"] / 1024.0,
+                           effective_clock_ghz=c["SQ_WAVE_CYCLES"] * 4.0 / c["SQ_WAVES"] / (ms * 1e6),
                            valu_insts_per_instance=c["SQ_INSTS_VALU"] / BATCH[name],
                            salu_insts_per_instance=c["SQ_INSTS_SALU"] / BATCH[name],
                            lds_insts_per_instance=c["SQ_INSTS_LDS"] / BATCH[name],

@@ -512,9 +512,13 @@ def _full_size_properties(model, n, N, dt, max_iter, seed, make=None):
     assert np.all(u[~Pn.mask] == 0.0)  # no force without a contact (flight steps, ridges beyond the contact's)
     with np.errstate(all="ignore"):
         J, grad, x = Pn.cost_and_gradient(x0, u)
-    # (a plan that has not converged may tumble through the Euler-angle singularity of the single-rigid-body model, where
-    #  a rollout amplifies the last bit of sin / cos by many orders of magnitude: the consistency checks are made on the
-    #  plans whose states stay bounded -- nearly all, asserted)
+    # (a plan may tumble through the Euler-angle singularity of the single-rigid-body model, where a rollout amplifies the
+    #  last bit of sin / cos by many orders of magnitude: the consistency checks are made on the plans whose states stay
+    #  bounded.  Why some do not, measured with the oracle on 1024 instances of this workload: after the
+    #  20 iterations config 5 allows 92.3 % are bounded, after 60 iterations 96.8 %, after 200 98.1 %; the remaining 1.9 %
+    #  CONVERGE to a tumbling local minimum of this non-convex problem (cost ~100 against ~2.3), as 5 % do for the
+    #  unconstrained solver of the dense oracle.  test_config5_full_size_properties checks that the kernel's unbounded
+    #  plans are, bit for bit, the oracle's.)
     sane = np.abs(r["x"][:, :, 0:3]).max(axis=(1, 2)) < 10.0
     if srb:
         sane &= np.abs(r["x"][:, :, 3:6]).max(axis=(1, 2)) < 1.0  # (pitch well away from +-pi/2, where 1 / cos blows up)
@@ -526,7 +530,8 @@ def _full_size_properties(model, n, N, dt, max_iter, seed, make=None):
     assert np.all(r["cost"] <= J0 * (1 + 1e-12))
     conv = (r["status"] >= 1) & sane
     pg = np.abs(Pn.projected_gradient(u, grad)).reshape(n, -1).max(axis=1)
-    return dict(conv=conv, pg=pg, J=J, J0=J0, iters=r["iters"], status=r["status"])
+    return dict(conv=conv, pg=pg, J=J, J0=J0, iters=r["iters"], status=r["status"], sane=sane, prob=prob, x0=x0, u=u,
+                arith=d.arithmetic())
 
 
 def test_config3_full_size_properties():
@@ -570,3 +575,12 @@ def test_config5_full_size_properties():
     assert (s["status"] < 0).mean() <= 0.005  # (the chaotic cold solve of the 12-state model: a handful in 32768)
     assert s["conv"].mean() >= 0.85
     assert s["pg"][s["conv"]].max() <= 5e-3 and np.median(s["pg"][s["conv"]]) <= 1e-5
+    # the plans left out of the consistency checks (unbounded states): the share the oracle measures on this workload
+    # (0.077 at 20 iterations), and -- on a sample of them -- the oracle's plans bit for bit: the algorithm on this
+    # workload, not the kernel
+    bad = np.flatnonzero(~s["sane"])
+    assert 0.04 <= len(bad) / len(s["sane"]) <= 0.10, len(bad) / len(s["sane"])
+    pick = bad[:: max(1, len(bad) // 48)][:48]
+    sub = {k: v[pick] for k, v in s["prob"].items()}
+    o = _oracle().Ddp(1, 100.0, 0.03, 50, fd.srb_weights(), max_iter=20, arith=s["arith"]).plan_batch(sub, s["x0"][pick], nthreads=8)
+    assert np.array_equal(o["u"], s["u"][pick])
