@@ -1296,6 +1296,9 @@ struct Solver
   // oracle/ddp.c oracle_ddp_solve
   W64_FN void solve_instance()
   {
+#if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    const long long timing_t0 = (long long)wall_clock64(); // (development aid: 100 MHz ticks)
+#endif
     init();
     lambda = P.lambda0;
     dlambda = P.dlambda0;
@@ -1403,6 +1406,10 @@ struct Solver
       if(I.out_iters) I.out_iters[0] = iter;
       if(I.out_status) I.out_status[0] = status;
       if(I.out_cost) I.out_cost[0] = cost;
+#if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+      // (development aid, scripts/ddp_sched_probe.py: the cost output carries start tick * 2^24 + duration in ticks)
+      if(I.out_cost) I.out_cost[0] = (double)(timing_t0 & 0xffffffll) * 16777216.0 + (double)((long long)wall_clock64() - timing_t0);
+#endif
     }
   }
 };

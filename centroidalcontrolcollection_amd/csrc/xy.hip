@@ -149,19 +149,20 @@ __device__ __forceinline__ void xy_block_argmin(double v, XyRed * red, double & 
     red->idx[w] = kXyNT;
   }
   __syncthreads();
-  double best = red->val[0];
-  int bi = red->idx[0];
-#pragma unroll
-  for(int k = 1; k < kXyWaves; ++k)
-  {
-    const double a = red->val[k];
-    const int ia = red->idx[k];
-    const bool take = (ia < kXyNT) && (bi >= kXyNT || a < best);
-    best = take ? a : best;
-    bi = take ? ia : bi;
-  }
-  vmin = best;
-  imin = bi;
+  // the seven per-wavefront results, one per lane, reduced inside the first eight lanes (round 4: every lane used to
+  // scan the seven entries itself -- 14 LDS reads and ~35 selects per argmin, two argmins per pivot, on all seven
+  // wavefronts); same choice: the smallest value, the lowest wavefront on a tie, kXyNT when no wavefront has a candidate
+  const int l = tid & 63;
+  const int ia = l < kXyWaves ? red->idx[l < kXyWaves ? l : 0] : kXyNT;
+  const double a = (l < kXyWaves && ia < kXyNT) ? red->val[l < kXyWaves ? l : 0] : kXyInf;
+  double m = -a;
+  m = max_raw(m, dpp_f64<kDppQuadXor1>(m));
+  m = max_raw(m, dpp_f64<kDppQuadXor2>(m));
+  m = max_raw(m, dpp_f64<kDppRowHalfMirror>(m));
+  const unsigned long long hit = __ballot(ia < kXyNT && -a == m) & 0x7full;
+  const int k = hit ? (int)__ffsll((long long)hit) - 1 : 0;
+  vmin = -__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 0), __builtin_amdgcn_readlane(__double2loint(m), 0));
+  imin = hit ? __builtin_amdgcn_readlane(ia, k) : kXyNT;
 }
 
 // Half of one 7x7 block of the lower block triangle of Qt: rows a0 .. a0+3 (a0 = 0: rows 0-3, a0 = 4: rows 4-6 plus
@@ -726,11 +727,12 @@ constexpr int kXsMaxIt = 16;
 constexpr int kXsE = 0, kXsF = 36, kXsPt = 42, kXsPv = 63, kXsT = 69, kXsAl = 75, kXsDp = 76, kXsDim = 77, kXsFz = 78,
               kXsRef = 79, kXsS = 85, kXsC = 106, kXsSt = 112, kXsSt2 = 113, // (ridges 0-15 / 16-31: each exact in a double)
               kXsPin = 114, // (6) the linear term of the value function ENTERING the stage, beside its matrix in kXsPt
-              kXsFields = 120, // (120 + 16 x 8 fields x 512 B: stages start on 4 KB boundaries)
+              kXsFields = 120, // (120 + 16 x 6 fields x 512 B: stages start on 4 KB boundaries)
               kXsSt3 = 120, kXsSt4 = 121, // (64 ridge slots only: ridges 32-47 / 48-63)
               kXsFields64 = 128;
 // fields of a stage before its ridge vectors, and 64-bit words of a saved clamped set, by ridge slots per step
 constexpr int xs_fields(int M) { return M > 32 ? kXsFields64 : kXsFields; }
+constexpr int kXsRidge = 6; // doubles of a ridge in the workspace (see RB in the kernel)
 constexpr int xs_st_words(int M) { return M > 32 ? 2 : 1; }
 // the clamped set of a stage: 2 bits per ridge
 template<int M> struct XsBits { using type = unsigned long long; };
@@ -818,17 +820,20 @@ __device__ __forceinline__ void xs_accumulate(unsigned state, double val, const 
   }
 }
 
+constexpr int kXsLanes = 64; // instances per wavefront
 constexpr int kXsRounds = 4;
 constexpr const char * kXsRoundsDefault = "6,10";
-constexpr int kXsLanes = 64; // instances per wavefront (see DESIGN.md 7b)
 // M: ridge slots per step; SINGLE: the single-change rounds (a separate instantiation: the block iteration, which nearly
 // every instance finishes in, does not carry their registers)
+// (Round 4, measured and dropped: half-filled wavefronts -- 32 instances per wavefront, 2048 wavefronts for config 4, two per
+//  SIMD at 255 VGPRs -- run the first round in 6.16 ms against 6.00 ms: the block rounds of a full batch are bound by
+//  the ~3.7 TB/s of mixed read / write workspace traffic they sustain, not by the latency of a sweep's dependent chain.)
 template<int M, bool SINGLE>
 __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch B, XyWork W, long n, int it_begin, int max_it)
 {
   static_assert(M == 16 || M == 32 || M == 64, "ridge slots per step");
   constexpr int kF = xs_fields(M), kStW = xs_st_words(M);
-  constexpr int kXsStage = kF + M * 8; // fields of a stage + M ridges x (7 + 1 pad)
+  constexpr int kXsStage = kF + M * kXsRidge; // fields of a stage + M ridges x (5 + 1 pad)
   using Bits = typename XsBits<M>::type; // 2 bits per ridge
   const long slot = (long)blockIdx.x * kXsLanes + threadIdx.x;
   if(slot >= (W.in_list ? (long)*W.in_count : n)) return;
@@ -845,7 +850,25 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     return W.ws[blk * W.ws_stride + (size_t)((s * kXsStage + (g & ~1)) * kXsLanes) + ln * 2 + (g & 1)];
   };
   auto WS = [&](int s, int f) -> double & { return FLD(s, f); };
-  auto RB = [&](int s, int r, int f) -> double & { return FLD(s, kF + r * 8 + f); };
+  // a ridge in the workspace: (b1, b3), (b4, b5), (rho_z, -) -- three 16-byte pairs.  The two position entries of its
+  // impulse vector are not stored: b0 = rd0 dt dt / 2 = (b1 dt) / 2 and b2 = (b3 dt) / 2 are the very operations
+  // xs_ridge forms them with (round 4: 6 instead of 8 doubles per ridge and sweep, a quarter of the ridge traffic)
+  auto RB = [&](int s, int r, int f) -> double & { return FLD(s, kF + r * kXsRidge + f); };
+  auto ridge_of = [&](const double (&v)[5], double (&bb)[6], double & az) {
+    bb[1] = v[0];
+    bb[3] = v[1];
+    bb[0] = v[0] * dt / 2;
+    bb[2] = v[1] * dt / 2;
+    bb[4] = v[2];
+    bb[5] = v[3];
+    az = v[4];
+  };
+  auto load_ridge = [&](int s, int r, double (&bb)[6], double & az) {
+    double v[5];
+#pragma unroll
+    for(int a = 0; a < 5; a++) v[a] = RB(s, r, a);
+    ridge_of(v, bb, az);
+  };
   // the clamped set of a stage in the workspace: 32 bits (16 ridges) per field, each exact in a double
   auto load_bits = [&](int s) -> Bits {
     Bits bits = (Bits)(unsigned)WS(s, kXsSt);
@@ -898,9 +921,11 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     {
       double bb[6], az;
       xs_ridge(P, B.vertex + ((size_t)(b * N + s) * M + r) * 3, B.ridge + ((size_t)(b * N + s) * M + r) * 3, cz, kap, bb, az);
-#pragma unroll
-      for(int a = 0; a < 6; a++) RB(s, r, a) = bb[a];
-      RB(s, r, 6) = az;
+      RB(s, r, 0) = bb[1];
+      RB(s, r, 1) = bb[3];
+      RB(s, r, 2) = bb[4];
+      RB(s, r, 3) = bb[5];
+      RB(s, r, 4) = az;
       const unsigned st0 = (unsigned)(bits0 >> (2 * r)) & 3u;
       xs_accumulate(st0, st0 == 1u ? P.flo : P.fhi, bb, az, S, t, cc, alpha, dprime);
     }
@@ -943,11 +968,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     for(int a = 0; a < 6; a++) nt[a] = nc[a] = 0.0;
     for(int q = 0; q < m; q++)
     {
-      double bb[6];
-#pragma unroll
-      for(int a = 0; a < 6; a++) bb[a] = RB(s, q, a);
+      double bb[6], azq;
+      load_ridge(s, q, bb, azq);
       const unsigned st = (unsigned)(bits >> (2 * q)) & 3u;
-      xs_accumulate(st, st == 1u ? P.flo : P.fhi, bb, RB(s, q, 6), nS, nt, nc, nal, ndp);
+      xs_accumulate(st, st == 1u ? P.flo : P.fhi, bb, azq, nS, nt, nc, nal, ndp);
     }
 #pragma unroll
     for(int a = 0; a < 21; a++) WS(s, kXsS + a) = nS[a];
@@ -1236,20 +1260,18 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
         const bool may_clamp = nfree > 1 || m > nfree;
         for(int r0 = 0; r0 < m; r0 += 8) // eight ridges at a time: their 56 operands are in flight together
         {
-          double rbv[8][7];
+          double rbv[8][5];
 #pragma unroll
           for(int u = 0; u < 8; u++)
 #pragma unroll
-            for(int a = 0; a < 7; a++) rbv[u][a] = RB(s, r0 + u, a); // (all M slots exist; those past m are not used)
+            for(int a = 0; a < 5; a++) rbv[u][a] = RB(s, r0 + u, a); // (all M slots exist; those past m are not used)
 #pragma unroll
           for(int u = 0; u < 8; u++)
           {
             const int r = r0 + u;
             if(r >= m) break;
-            double bb[6];
-#pragma unroll
-            for(int a = 0; a < 6; a++) bb[a] = rbv[u][a];
-            const double az = rbv[u][6];
+            double bb[6], az;
+            ridge_of(rbv[u], bb, az);
             double bpi = nu * az;
 #pragma unroll
             for(int a = 0; a < 6; a++) bpi += bb[a] * pi[a];
@@ -1376,11 +1398,10 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             ndp = fz;
             for(int r = 0; r < m; r++)
             {
-              double bb[6];
-#pragma unroll
-              for(int a = 0; a < 6; a++) bb[a] = RB(s, r, a);
+              double bb[6], azr;
+              load_ridge(s, r, bb, azr);
               const unsigned ns = (unsigned)(nb >> (2 * r)) & 3u;
-              xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, RB(s, r, 6), nS, nt, nc, nal, ndp);
+              xs_accumulate(ns, ns == 1u ? P.flo : P.fhi, bb, azr, nS, nt, nc, nal, ndp);
             }
           }
           if(nb != bits) // (a stage whose set stays has its sums in the workspace already: the same values, not rewritten)
@@ -1587,11 +1608,11 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const size_t N = (size_t)P.N;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  const size_t n64 = ((size_t)n + kXsLanes - 1) / kXsLanes * kXsLanes; // whole wavefronts
+  const size_t n64 = ((size_t)n + 63) / 64 * 64; // whole wavefronts
   // one region per wavefront: [stage][fields | 16 ridges x 7][lane] -- what a stage touches is one contiguous run
-  const size_t kXsStage = (size_t)xs_fields(h->M) + (size_t)h->M * 8;
-  const size_t nwave = n64 / kXsLanes, ws_stride = N * kXsStage * kXsLanes, rb_stride = ws_stride;
-  const size_t o_ws = 0, o_rb = o_ws + (size_t)xs_fields(h->M) * kXsLanes * 8, o_st = o_ws + up(nwave * ws_stride * 8),
+  const size_t kXsStage = (size_t)xs_fields(h->M) + (size_t)h->M * kXsRidge;
+  // (a wavefront's region is N stages x kXsStage fields x its L instances: n64 instances take the same room whatever L)
+  const size_t o_ws = 0, o_rb = 0, o_st = o_ws + up(n64 * N * kXsStage * 8),
                o_li = o_st + up(N * n64 * 8 * (size_t)xs_st_words(h->M)), o_l1 = o_li + up((size_t)n * 4), o_l2 = o_l1 + up((size_t)n * 4),
                o_l3 = o_l2 + up((size_t)n * 4), o_cn = o_l3 + (kXsRounds - 1) * up((size_t)n * 4), total = o_cn + 256;
   if(n > h->ws_cap) // (synchronous: not inside a captured stream)
@@ -1605,7 +1626,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   }
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned long long *>(h->ws + o_st),
-           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), ws_stride, rb_stride, n64,
+           reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), 0, 0, n64,
            nullptr, nullptr, nullptr, nullptr, 0};
   int * const round_list[2] = {reinterpret_cast<int *>(h->ws + o_l1), reinterpret_cast<int *>(h->ws + o_l2)};
   int * const round_count = reinterpret_cast<int *>(h->ws + o_cn) + 1; // [kXsRounds], after the redo count
@@ -1622,7 +1643,9 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   // CCC_XY_SAFEGUARD (development switch): the single-change rounds instead of the dual kernel where both apply
   const bool safeguard = h->wide || h->env_safeguard;
   const bool dual_only = !safeguard && (h->env_dual || (n < 4096 && !h->env_stream && h->env_pdas_iters < 0));
-  auto launch_stream = [&](const XyWork & Wk, int it_begin, int it_end) {
+  auto launch_stream = [&](const XyWork & Wk0, int it_begin, int it_end) {
+    XyWork Wk = Wk0;
+    Wk.ws_stride = Wk.rb_stride = N * kXsStage * (size_t)kXsLanes;
     const dim3 g((unsigned)((n + kXsLanes - 1) / kXsLanes)), b(kXsLanes);
     if(h->M == 16 && !Wk.single)
       hipLaunchKernelGGL((xy_plan_stream_kernel<16, false>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
