@@ -11,6 +11,7 @@
 #include "common.h"
 #include "ddp_batch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +28,10 @@ struct ccc_ddp
   int M = CCC_DDP_MAX_RIDGES; // ridge stride of the per-phase / per-step arrays (params.max_ridges)
   int64_t tcap = 0;           // workspace of the tile kernel (csrc/ddp_tile.hip): one slot per resident workgroup
   double * ws_t = nullptr;
-  unsigned * ticket = nullptr; // its work-queue counter
+  void * sched = nullptr;      // its scheduling state (csrc/ddp_batch.h DdpSched), sized for scap instances
+  int64_t scap = -1;           // (-1: not allocated; 0: counters only)
+  int slice = 2, slice_next = 4; // iterations of an instance's first / later slices (CCC_DDP_SLICE="a,b", development switch; 0: plain queue)
+  int slots = 0;               // CCC_DDP_SLOTS (development switch): resident workgroups to launch, 0 = what fits
   int num_cu = 0;
   // staging for the host entry
   int64_t hcap = 0;
@@ -84,6 +88,13 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
     return fail(CCC_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
   }
   h->num_cu = prop.multiProcessorCount;
+  // development switches, read once here
+  if(const char * v = std::getenv("CCC_DDP_SLICE"))
+  {
+    h->slice = std::max(0, std::atoi(v));
+    if(const char * c2 = std::strchr(v, ',')) h->slice_next = std::max(1, std::atoi(c2 + 1));
+  }
+  if(const char * v = std::getenv("CCC_DDP_SLOTS")) h->slots = std::max(0, std::atoi(v));
   *out = h;
   return CCC_OK;
 }
@@ -93,7 +104,7 @@ extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->ws_t) (void)hipFree(h->ws_t);
-  if(h->ticket) (void)hipFree(h->ticket);
+  if(h->sched) (void)hipFree(h->sched);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -188,7 +199,8 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
   // (precision = 32 runs this same fp64 kernel: ccc_amd.h)
-  const int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
+  int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
+  if(h->slots > 0 && h->slots < grid) grid = h->slots;
   if(grid > h->tcap)
   {
     CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
@@ -200,15 +212,25 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)full * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
     h->tcap = full;
   }
-  if(!h->ticket)
+  // longest-first scheduling (csrc/ddp_batch.h) when the batch does not fit one resident set; its lists are per instance
+  const bool sliced = h->slice > 0 && n > grid;
+  const int64_t need = sliced ? n : 0;
+  if(need > h->scap)
   {
     CCC_NO_CAPTURE(stream, "ccc_ddp_plan_batch_device");
-    CCC_HIP_CHECK(hipMalloc(&h->ticket, sizeof(unsigned)));
+    if(h->sched) (void)hipFree(h->sched);
+    h->sched = nullptr;
+    h->scap = -1;
+    CCC_HIP_CHECK(hipMalloc(&h->sched, ddp_sched_bytes((long)need, h->prm.horizon_steps, h->S)));
+    h->scap = need;
   }
+  DdpSched sched = ddp_sched_carve(h->sched, (long)h->scap, h->prm.horizon_steps, h->S);
+  sched.slice = sliced ? h->slice : 0;
+  sched.slice_next = h->slice_next;
   ddp_common::Params P;
   fill_params(h, P);
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out, x_out, iters, status, cost};
-  CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, h->ticket, grid, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
+  CCC_HIP_CHECK(launch_ddp_tile(P, B, h->ws_t, sched, grid, (long)n, h->S, h->M, reinterpret_cast<hipStream_t>(stream)));
   return CCC_OK;
 }
 

@@ -47,14 +47,41 @@ struct DdpBatch
   double * cost;
 };
 
+// Scheduling state of one launch (device memory owned by the handle; csrc/ddp_tile.hip).  A batch larger than one resident
+// set of wavefronts is scheduled LONGEST-FIRST: DDP solves of one batch differ tenfold in length (iterations needed x
+// regularisation retries x line-search rounds; measured), and with a plain work queue the long ones that
+// happen to start late set the makespan (config 5's shape: 218 ms against 144 ms of work per slot).  Every instance
+// runs in slices of a few iterations; after a slice its remaining work is estimated (pace of the slice x iterations it may
+// still take) and, when fresh instances or suspended ones that look as long are waiting, it is suspended
+// (Solver::suspend) into the bucket of that estimate.  Wavefronts take fresh instances while there are any, then the
+// suspended ones from the highest bucket down: longest remaining first, re-estimated every slice.  A suspended solve
+// continues bit for bit (tests/test_ddp_tile_emu.py).  Each list can hold every instance once per slice at most:
+constexpr int kDdpSchedBuckets = 64;
+struct DdpSched
+{
+  unsigned * ticket;   // next fresh instance
+  unsigned * finished; // instances completed
+  int * head;          // [kDdpSchedBuckets] next entry to resume
+  int * tail;          // [kDdpSchedBuckets] entries reserved
+  int * slot;          // [kDdpSchedBuckets][cap] instance ids (-1: reserved, not written yet)
+  double * save_x;     // [cap][(N + 1) S] states of the suspended solves (their inputs wait in u_out)
+  double * save_s;     // [cap][4] cost, lambda, dlambda, iterations done
+  long cap;
+  int slice;           // iterations of an instance's first slice; 0 = no slicing (the batch fits one resident set)
+  int slice_next;      // iterations of the later slices
+};
+// bytes of device memory behind a DdpSched for `cap` instances, and its carving
+size_t ddp_sched_bytes(long cap, int N, int S);
+
 #if defined(__HIPCC__)
 // csrc/ddp_tile.hip: the tile build (csrc/ddp_tile.h), S in {9, 12}, M in {16, 32, 64} (ridge stride of the arrays = the
 // handle's max_ridges), any number of contact phases and horizon steps, reg_type 1 and 2.  One resident set of workgroups
 // (ddp_tile_grid) pulls instances from a ticket counter; ws = grid x ddp_tile_ws_doubles(N, S, M) doubles of workspace,
-// ticket = one unsigned in device memory (reset by the launch)
+// sched = the launch's scheduling state (reset by the launch; slice > 0 needs its lists sized for cap >= n)
 size_t ddp_tile_ws_doubles(int N, int S, int M);
 int ddp_tile_grid(long n, int M, int num_cu);
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, unsigned * ticket, int grid, long n,
+DdpSched ddp_sched_carve(void * mem, long cap, int N, int S);
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, const DdpSched & sched, int grid, long n,
                            int S, int M, hipStream_t stream);
 #endif
 } // namespace ccc_amd

@@ -1293,11 +1293,22 @@ struct Solver
     lambda = lambda * dlambda * (lambda > P.lambda_min ? 1.0 : 0.0);
   }
 
-  // oracle/ddp.c oracle_ddp_solve
+  // oracle/ddp.c oracle_ddp_solve, in three pieces so that the launch code can run an instance in SLICES of iterations
+  // (csrc/ddp_tile.hip: a batch larger than one resident set is scheduled longest-first from the time its first
+  // iterations took): begin() = start-up, iterate(budget) = up to `budget` iterations (false: the solve goes on),
+  // finish() = outputs; suspend() / resume() carry the complete state of the iteration across slices -- the current
+  // trajectory, its cost, the regularisation and the iteration count -- so a sliced solve is the unsliced one bit for bit.
+  int iters_done, exit_status;
   W64_FN void solve_instance()
   {
+    begin();
+    (void)iterate(-1);
+    finish();
+  }
+  W64_FN void begin()
+  {
 #if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    const long long timing_t0 = (long long)wall_clock64(); // (development aid: 100 MHz ticks)
+    timing_t0 = (long long)wall_clock64(); // (development aid: 100 MHz ticks)
 #endif
     init();
     lambda = P.lambda0;
@@ -1315,9 +1326,51 @@ struct Solver
         cost = cold;
       }
     }
-    int iter = 0, status = 0;
-    for(iter = 1; iter <= P.max_iter; iter++)
+    iters_done = 0;
+    exit_status = 0;
+  }
+  // the state of a suspended solve: inputs -> I.u_out (overwritten by the result in the end), states -> sx [(N+1) S],
+  // scalars -> ss [4]
+  W64_FN void suspend(double * sx, double * ss)
+  {
+    mem_sync();
+    const int N = P.N;
+    const double * xs = xcur();
+    const double * us = ucur();
+    for(int e = 0; e < N * M; e += 64) st(I.u_out, lane + e, ldm(us, lane + e, lane + e < N * M), lane + e < N * M);
+    for(int e = 0; e < (N + 1) * S; e += 64) st(sx, lane + e, ldm(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
+    const vf sc = sel(lane == 0, splat(cost), sel(lane == 1, splat(lambda), sel(lane == 2, splat(dlambda), splat((double)iters_done))));
+    st(ss, lane, sc, lane < 4);
+    mem_sync();
+  }
+  W64_FN void resume(const double * sx, const double * ss)
+  {
+    init();
+    const int N = P.N;
+    cur = 0;
+    for(int e = 0; e < N * M; e += 64) st(I.ubuf, lane + e, ldm(I.u_out, lane + e, lane + e < N * M), lane + e < N * M);
+    for(int e = 0; e < (N + 1) * S; e += 64) st(I.xbuf, lane + e, ldm(sx, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
+    cost = ss[0];
+    lambda = ss[1];
+    dlambda = ss[2];
+    iters_done = (int)ss[3];
+    exit_status = 0;
+    mem_sync();
+  }
+#if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+  long long timing_t0;
+#endif
+  W64_FN bool iterate(int budget)
+  {
+    int iter = 0, status = 0, used = 0;
+    for(iter = iters_done + 1; iter <= P.max_iter; iter++)
     {
+      if(budget >= 0 && used == budget)
+      {
+        iters_done = iter - 1; // (iterations completed; none of them ended the solve)
+        return false;
+      }
+      used++;
       bool bp_ok = false;
       double gsum = 0.0;
       for(;;)
@@ -1388,6 +1441,13 @@ struct Solver
       }
     }
     if(iter > P.max_iter) iter = P.max_iter;
+    iters_done = iter;
+    exit_status = status;
+    return true;
+  }
+  W64_FN void finish()
+  {
+    const int iter = iters_done, status = exit_status;
     mem_sync();
     // results
     {

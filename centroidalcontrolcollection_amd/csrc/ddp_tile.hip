@@ -29,24 +29,92 @@ size_t ddp_tile_ws_doubles(int N, int S, int M)
 #ifndef CCC_TILE_WAVES4
 #  define CCC_TILE_WAVES4 1
 #endif
+__global__ void ddp_sched_reset_kernel(int * counters, size_t words, int * slot, size_t fill)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if(i < words)
+    counters[i] = 0;
+  else if(i - words < fill)
+    slot[i - words] = -1;
+}
+
+// device-scope loads / stores of the scheduling words (other wavefronts, possibly on another XCD, write them)
+__device__ __forceinline__ int sched_load(const int * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned sched_load(const unsigned * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bucket of an estimate of `ticks` (100 MHz) of remaining work: four per octave from 2^8 ticks up -- monotone in the
+// estimate, which is all the order needs
+__device__ __forceinline__ int sched_bucket(long long ticks)
+{
+  const float f = (float)(ticks > 1 ? ticks : 1);
+  const int key = (int)(__float_as_uint(f) >> 21) - ((127 + 8) << 2);
+  return key < 0 ? 0 : (key >= kDdpSchedBuckets ? kDdpSchedBuckets - 1 : key);
+}
+
 template<int S, int NB>
 __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4))) void ddp_tile_kernel(
-    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, unsigned * ticket)
+    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, DdpSched Sc)
 {
   __shared__ ddp_tile::Mem<S, NB> mem;
-  __shared__ long next_b;
   constexpr int M = 16 * NB;
   const int N = P.N;
-  // Work queue (round 4): the grid is one resident set of workgroups; each takes the next instance from a ticket counter
-  // when it finishes one (DDP solves differ severalfold in length: the hardware dispatcher used to be the queue, at the
-  // price of one workspace per INSTANCE -- now one per resident workgroup).
+  const int lane = threadIdx.x;
+  const size_t sx_stride = (size_t)(N + 1) * S;
+  // Work queue: the grid is one resident set of workgroups (one workspace per resident workgroup).  Each
+  // takes the next FRESH instance from a ticket counter; when those are handed out, the suspended ones, slowest first.
+  bool fresh_left = true;
   for(;;)
   {
-    if(threadIdx.x == 0) next_b = (long)atomicAdd(ticket, 1u);
-    __syncthreads();
-    const long b = next_b;
-    __syncthreads();
-    if(b >= n) break;
+    long b = -1;
+    bool resumed = false;
+    if(fresh_left)
+    {
+      unsigned t = 0;
+      if(lane == 0) t = atomicAdd(Sc.ticket, 1u);
+      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      if((long)t < n)
+        b = (long)t;
+      else
+        fresh_left = false;
+    }
+    if(b < 0 && Sc.slice > 0)
+    {
+      for(;;)
+      {
+        // lane k looks at bucket k; the highest non-empty one is taken from (compare-and-swap on its head: a head never
+        // passes its tail)
+        const int hd = sched_load(Sc.head + lane), tl = sched_load(Sc.tail + lane);
+        const unsigned long long ne = __ballot(hd < tl);
+        if(ne != 0ull)
+        {
+          const int k = 63 - __builtin_clzll(ne);
+          const int hk = __builtin_amdgcn_readlane(hd, k);
+          int ok = 0;
+          if(lane == 0) ok = atomicCAS(Sc.head + k, hk, hk + 1) == hk ? 1 : 0;
+          ok = __builtin_amdgcn_readfirstlane(ok);
+          if(!ok) continue;
+          int id;
+          for(;;) // (the entry was reserved before the tail moved; its writer is a few instructions behind at most)
+          {
+            id = lane == 0 ? sched_load(Sc.slot + (size_t)k * Sc.cap + hk % Sc.cap) : 0;
+            id = __builtin_amdgcn_readfirstlane(id);
+            if(id >= 0) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+          // (the lists are rings: an instance is in one list at a time, so at most n <= cap entries are outstanding and
+          //  the entry is free again for the push that comes round to it)
+          if(lane == 0) __hip_atomic_store(Sc.slot + (size_t)k * Sc.cap + hk % Sc.cap, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          b = id;
+          resumed = true;
+          break;
+        }
+        unsigned f = lane == 0 ? sched_load(Sc.finished) : 0u;
+        f = (unsigned)__builtin_amdgcn_readfirstlane((int)f);
+        if((long)f >= n) break; // every instance is complete
+        __builtin_amdgcn_s_sleep(64); // (an instance still in its first slice may yet be suspended)
+      }
+    }
+    if(b < 0) break;
     ddp_tile::Instance I;
     I.phase_dim = B.phase_dim + b * P.P;
     I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
@@ -71,7 +139,43 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
     I.out_status = B.status ? B.status + b : nullptr;
     I.out_cost = B.cost ? B.cost + b : nullptr;
     ddp_tile::Solver<S, NB> solver(P, I, mem);
-    solver.solve_instance();
+    if(resumed)
+    {
+      __threadfence(); // (acquire: the state below was written by the wavefront that suspended the instance)
+      solver.resume(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 4);
+    }
+    else
+      solver.begin();
+    for(int budget = Sc.slice > 0 ? (resumed ? Sc.slice_next : Sc.slice) : -1;; budget = Sc.slice_next)
+    {
+      const long long t0 = (long long)wall_clock64();
+      const int it0 = solver.iters_done;
+      if(solver.iterate(budget))
+      {
+        solver.finish();
+        __syncthreads();
+        if(Sc.slice > 0 && lane == 0) atomicAdd(Sc.finished, 1u);
+        break;
+      }
+      // what is left of this solve, as far as one can tell: the pace of the slice x the iterations it may still take
+      const long long per = ((long long)wall_clock64() - t0) / (solver.iters_done > it0 ? solver.iters_done - it0 : 1);
+      const int k = sched_bucket(per * (P.max_iter - solver.iters_done));
+      // longest remaining first: the instance steps aside for fresh ones (nobody knows yet how long those are) and for
+      // suspended ones that look about as long or longer; when only shorter ones wait, it keeps its wavefront
+      const unsigned tk = lane == 0 ? sched_load(Sc.ticket) : 0u;
+      const bool fresh_waiting = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk) < n;
+      const unsigned long long ne = __ballot(sched_load(Sc.head + lane) < sched_load(Sc.tail + lane));
+      const int lowest = k > 0 ? k - 1 : 0;
+      if(!fresh_waiting && (ne >> lowest) == 0ull) continue;
+      solver.suspend(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 4);
+      __threadfence(); // (release: the state is out before the entry is)
+      if(lane == 0)
+      {
+        const int e = atomicAdd(Sc.tail + k, 1);
+        __hip_atomic_store(Sc.slot + (size_t)k * Sc.cap + e % Sc.cap, (int)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      break;
+    }
     __syncthreads();
   }
 }
@@ -84,13 +188,40 @@ int ddp_tile_grid(long n, int M, int num_cu)
   return (int)(n < resident ? n : resident);
 }
 
-hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, unsigned * ticket, int grid, long n,
+// layout behind a DdpSched: [ticket, finished, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 4][save_x cap x (N+1) S]
+static size_t sched_off_slot() { return (size_t)(64 + 2 * kDdpSchedBuckets) * 4; }
+static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 4 + 255) / 256 * 256; }
+static size_t sched_off_x(long cap) { return sched_off_s(cap) + (size_t)cap * 4 * 8; }
+size_t ddp_sched_bytes(long cap, int N, int S) { return sched_off_x(cap) + (size_t)cap * (size_t)(N + 1) * S * 8; }
+DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
+{
+  char * base = static_cast<char *>(mem);
+  DdpSched sc;
+  sc.ticket = reinterpret_cast<unsigned *>(base);
+  sc.finished = sc.ticket + 1;
+  sc.head = reinterpret_cast<int *>(base) + 64;
+  sc.tail = sc.head + kDdpSchedBuckets;
+  sc.slot = reinterpret_cast<int *>(base + sched_off_slot());
+  sc.save_s = reinterpret_cast<double *>(base + sched_off_s(cap));
+  sc.save_x = reinterpret_cast<double *>(base + sched_off_x(cap));
+  sc.cap = cap;
+  sc.slice = 0;
+  return sc;
+}
+
+hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, const DdpSched & sched, int grid, long n,
                            int S, int M, hipStream_t stream)
 {
   const size_t stride = ddp_tile_ws_doubles(P.N, S, M);
-  hipError_t e = hipMemsetAsync(ticket, 0, sizeof(unsigned), stream);
-  if(e != hipSuccess) return e;
-#define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, ticket)
+  // counters and list ends to zero; with slicing, the entries of the lists to -1 ("reserved, not written").  (A kernel of
+  // the library's own, not hipMemsetAsync: see zero_words in csrc/common.h.)
+  {
+    const size_t words = sched_off_slot() / 4, fill = sched.slice > 0 ? (size_t)kDdpSchedBuckets * (size_t)sched.cap : 0;
+    const size_t total = words + fill;
+    hipLaunchKernelGGL(ddp_sched_reset_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<int *>(sched.ticket), words, sched.slot, fill);
+  }
+#define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, sched)
   if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
   else if(S == 12 && M == 16) CCC_TILE_LAUNCH(12, 1);
   else if(S == 9 && M == 32) CCC_TILE_LAUNCH(9, 2);

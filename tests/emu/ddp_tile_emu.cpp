@@ -5,6 +5,7 @@
 #include "../../centroidalcontrolcollection_amd/csrc/ddp_tile.h"
 
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 using namespace ccc_amd;
@@ -16,6 +17,35 @@ static void run_one(const Params & P, const ddp_tile::Instance & I)
   static ddp_tile::Mem<S, B> mem;
   ddp_tile::Solver<S, B> solver(P, I, mem);
   solver.solve_instance();
+}
+
+// the same solve in slices of `slice` iterations: between two slices the state goes through suspend() / resume() and
+// everything else a wavefront owns (LDS, trajectory slots, gains) is overwritten, as if another instance had used it
+template<int S, int B>
+static void run_sliced(const Params & P, const ddp_tile::Instance & I, int slice, std::vector<double> & xbuf, std::vector<double> & ubuf,
+                       std::vector<double> & ks, std::vector<double> & Ks)
+{
+  static ddp_tile::Mem<S, B> mem;
+  std::vector<double> sx((size_t)(P.N + 1) * S), ss(4);
+  bool fresh = true;
+  for(;;)
+  {
+    ddp_tile::Solver<S, B> solver(P, I, mem);
+    if(fresh)
+      solver.begin();
+    else
+      solver.resume(sx.data(), ss.data());
+    fresh = false;
+    if(solver.iterate(slice))
+    {
+      solver.finish();
+      return;
+    }
+    solver.suspend(sx.data(), ss.data());
+    std::memset(static_cast<void *>(&mem), 0xa5, sizeof(mem));
+    for(auto * v : {&xbuf, &ubuf, &ks, &Ks})
+      for(double & e : *v) e = -1.2345e300;
+  }
 }
 
 extern "C" int ccc_ddp_tile_emu_lds_bytes(int S, int M)
@@ -30,7 +60,7 @@ extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, int M, long n, cons
                                             const double * phase_ridge, const int * step_phase, const double * ref_pos,
                                             const double * ref_ori, const double * inertia, const double * x0,
                                             const double * u_init, double * u_out, double * x_out, int * iters,
-                                            int * status, double * cost)
+                                            int * status, double * cost, int slice)
 {
   const int S = P->model == 0 ? 9 : 12, N = P->N, Pn = P->P;
   if(M != 16 && M != 32 && M != 64) return -1;
@@ -57,7 +87,16 @@ extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, int M, long n, cons
     I.out_iters = iters ? iters + b : nullptr;
     I.out_status = status ? status + b : nullptr;
     I.out_cost = cost ? cost + b : nullptr;
-    if(S == 9 && M == 16) run_one<9, 1>(*P, I);
+    if(slice > 0)
+    {
+      if(S == 9 && M == 16) run_sliced<9, 1>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      else if(S == 12 && M == 16) run_sliced<12, 1>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      else if(S == 9 && M == 32) run_sliced<9, 2>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      else if(S == 12 && M == 32) run_sliced<12, 2>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      else if(S == 9) run_sliced<9, 4>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      else run_sliced<12, 4>(*P, I, slice, xbuf, ubuf, ks, Ks);
+    }
+    else if(S == 9 && M == 16) run_one<9, 1>(*P, I);
     else if(S == 12 && M == 16) run_one<12, 1>(*P, I);
     else if(S == 9 && M == 32) run_one<9, 2>(*P, I);
     else if(S == 12 && M == 32) run_one<12, 2>(*P, I);

@@ -41,7 +41,7 @@ def emu():
     L = ctypes.CDLL(so)
     L.ccc_ddp_tile_emu_lds_bytes.restype = ctypes.c_int
 
-    def run(model, N, dt, w, prob, x0, max_iter, u_init=None, reg_type=1):
+    def run(model, N, dt, w, prob, x0, max_iter, u_init=None, reg_type=1, slice=0):
         P = Params()
         P.model, P.N, P.P, P.mass, P.dt = model, N, prob["phase_dim"].shape[1], 100.0, dt
         S = 9 if model == 0 else 12
@@ -63,7 +63,7 @@ def emu():
         it, st, cost = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n)
         p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)  # noqa: E731
         rc = L.ccc_ddp_tile_emu_plan_batch(ctypes.byref(P), ctypes.c_int(M), ctypes.c_long(n), *[p(a) for a in arr], p(u), p(x), p(it),
-                                           p(st), p(cost))
+                                           p(st), p(cost), ctypes.c_int(slice))
         assert rc == 0
         return dict(u=u, x=x, iters=it, status=st, cost=cost)
 
@@ -93,6 +93,19 @@ def test_kernel_source_reproduces_the_tile_specification_bit_for_bit(emu, model,
     w = fd.srb_weights() if model else fd.centroidal_weights()
     prob, x0 = fd.make_centroidal_batch(10, N, 0.03, seed=5 + N, srb=bool(model))
     _same(emu(model, N, 0.03, w, prob, x0, max_iter), _ora(model, N, 0.03, w, max_iter, 1).plan_batch(prob, x0, nthreads=8))
+
+
+@pytest.mark.parametrize("model,N,max_iter,slice", [(0, 24, 7, 2), (1, 20, 9, 1), (1, 20, 9, 4)])
+def test_a_solve_suspended_and_resumed_every_few_iterations_is_the_same_solve_bit_for_bit(emu, model, N, max_iter, slice):
+    """csrc/ddp_tile.hip schedules batches larger than a resident set in slices of iterations (suspend() / resume());
+    here: every `slice` iterations, with everything a wavefront owns overwritten in between."""
+    prob, x0 = fd.make_centroidal_batch(12, N, 0.03, seed=21 + model, srb=model == 1)
+    w = fd.srb_weights() if model else fd.centroidal_weights()
+    whole = emu(model, N, 0.03, w, prob, x0, max_iter)
+    _same(emu(model, N, 0.03, w, prob, x0, max_iter, slice=slice), whole)
+    assert whole["iters"].max() > slice  # (the slices were needed)
+    warm = emu(model, N, 0.03, w, prob, x0 + 0.01, 3, u_init=whole["u"])
+    _same(emu(model, N, 0.03, w, prob, x0 + 0.01, 3, u_init=whole["u"], slice=1), warm)
 
 
 @pytest.mark.parametrize("model", [0, 1])
