@@ -236,7 +236,7 @@ struct Solver
 
   // lane coordinates
   vi lane, c, g;
-  vi j6;             // min(lane, 5): the row of the 6 x 6 matrices this lane works on
+  vi j6;             // min(c, 5): the row of the 6 x 6 matrices this lane works on (the results are taken from lanes 0 .. 5)
   vb inS;            // c < S
   vi arow[3];        // rows of the S x M matrices this lane holds: g, g + 4, g + 8 (clamped to S - 1 when not valid)
   vb aval[3];
@@ -286,7 +286,7 @@ struct Solver
     lane = lane_id();
     c = lane & 15;
     g = lane >> 4;
-    j6 = seli(lane < 6, lane, spl(5));
+    j6 = seli(c < 6, c, spl(5));
     inS = c < S;
     for(int t = 0; t < 3; t++)
     {
@@ -738,15 +738,45 @@ struct Solver
       x[b] = sel(Q.in[b], vmin(vmax(x[b], lo[b]), hi[b]), 0.0);
     }
     const mask_t inmask = (m >= M) ? kAll : static_cast<mask_t>((static_cast<mask_t>(1) << m) - 1u);
-    // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: t_c = fma(0.5 y_c, (H y)_c, y_c q_c); sumM
+    // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: gy = G y (six sums, treeM); vy = V6r gy (apply6); (H y)_r =
+    // alpha y_r, then fma(G[j][r], vy_j, .); t_c = fma(0.5 y_c, (H y)_c, y_c q_c); sumM.
+    // Evaluated for FOUR vectors at once, one per row of the wavefront (round 4: the Armijo search of Tassa's box-QP tries
+    // step, 0.6 step, 0.36 step, ... in order; the instances that set a batch's makespan backtrack eight to ten times per
+    // search, one dependent evaluation after the other): every row forms all six ridge sums of ITS vector with the same
+    // trees, the 6 x 6 product on its lanes c < 6, and hands the six results round by DPP row broadcasts -- the same
+    // operations in the same order as the one-vector form, so each row's value is that form's value bit for bit, with no
+    // scalar round trip.  Returns the values (replicated in each row) and H y per row.
     // (H y is kept: the gradient of the next iteration is q + H x at the x the last value was taken at)
     vf hy[B];
-    auto value_of = [&](const vf (&y)[B]) {
+    auto value_of4 = [&](const vf (&y)[B], vf (&hy4)[B]) {
+      vf gy[6];
+      for(int j = 0; j < 6; j++)
+      {
+        vf t[B];
+        for(int b = 0; b < AB; b++) t[b] = Q.G[b][j] * y[b];
+        gy[j] = sumM<AB>(t);
+      }
+      vf sv = Q.v6r[0] * gy[0];
+      for(int l = 1; l < 6; l++) sv = vfma(Q.v6r[l], gy[l], sv);
+      const vf vy[6] = {row_bcast<0>(sv), row_bcast<1>(sv), row_bcast<2>(sv), row_bcast<3>(sv), row_bcast<4>(sv), row_bcast<5>(sv)};
       vf t[B];
-      qp_matvec<AB>(Q, y, hy);
-      for(int b = 0; b < AB; b++) t[b] = vfma(0.5 * y[b], hy[b], y[b] * q[b]);
-      return read_lane(sumM<AB>(t), 0);
+      for(int b = 0; b < AB; b++)
+      {
+        vf h = Q.alpha * y[b];
+        for(int j = 0; j < 6; j++) h = vfma(Q.G[b][j], vy[j], h);
+        hy4[b] = h;
+        t[b] = vfma(0.5 * y[b], h, y[b] * q[b]);
+      }
+      return sumM<AB>(t);
     };
+    // row w (wave-uniform) of v on every row
+    auto pick_row = [&](vf v, int w) {
+      vf a, b2, lo2, hi2;
+      rows_pair(v, a, b2);
+      halves_pair((w & 1) ? b2 : a, lo2, hi2);
+      return (w & 2) ? hi2 : lo2;
+    };
+    auto value_of = [&](const vf (&y)[B]) { return read_lane(value_of4(y, hy), 0); }; // (the same vector on every row)
     TILE_PROF_START();
     TILE_PROF_COUNT(TP_QP_CALLS);
     double value = value_of(x), oldvalue = 0.0;
@@ -813,19 +843,35 @@ struct Solver
       const double sdotg = read_lane(sumM<AB>(t), 0);
       TILE_PROF_ADD(TP_QP_SOLVE);
       if(sdotg >= 0) break; // no descent direction: result stays 0
-      double step = 1.0, vc;
+      double step = 1.0, vc = 0.0;
       vf xc[B];
       for(;;)
       {
-        for(int b = 0; b < AB; b++) xc[b] = sel(Q.in[b], vmin(vmax(x[b] + step * srch[b], lo[b]), hi[b]), 0.0);
-        vc = value_of(xc);
-        if(!((vc - oldvalue) / (step * sdotg) < armijo)) break;
-        step *= step_dec;
-        if(step < min_step)
+        // the next four step sizes of the list, one per row; candidate k is the last one tried when it passes the Armijo
+        // test or when the step after it would be below min_step (result 2) -- the first such row is where the
+        // one-at-a-time loop stops
+        const double s1 = step * step_dec, s2 = s1 * step_dec, s3 = s2 * step_dec;
+        const vf stepv = sel(g == 0, splat(step), sel(g == 1, splat(s1), sel(g == 2, splat(s2), splat(s3))));
+        vf xc4[B], hy4[B];
+        for(int b = 0; b < AB; b++) xc4[b] = sel(Q.in[b], vmin(vmax(x[b] + stepv * srch[b], lo[b]), hi[b]), 0.0);
+        const vf vc4 = value_of4(xc4, hy4);
+        const vb pass = !(((vc4 - oldvalue) / (stepv * sdotg)) < armijo);
+        const vb stop = pass || ((stepv * step_dec) < min_step);
+        const unsigned long long sm = ballot(stop);
+        if(sm == 0ull)
         {
-          result = 2;
-          break;
+          step = s3 * step_dec;
+          continue;
         }
+        const int w = (sm & 0xffffull) ? 0 : ((sm & 0xffff0000ull) ? 1 : ((sm & 0xffff00000000ull) ? 2 : 3));
+        if(((ballot(pass) >> (16 * w)) & 1ull) == 0ull) result = 2;
+        vc = read_lane(vc4, 16 * w);
+        for(int b = 0; b < AB; b++)
+        {
+          xc[b] = pick_row(xc4[b], w);
+          hy[b] = pick_row(hy4[b], w);
+        }
+        break;
       }
       for(int b = 0; b < AB; b++) x[b] = xc[b];
       value = vc;
@@ -1307,9 +1353,6 @@ struct Solver
   }
   W64_FN void begin()
   {
-#if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    timing_t0 = (long long)wall_clock64(); // (development aid: 100 MHz ticks)
-#endif
     init();
     lambda = P.lambda0;
     dlambda = P.dlambda0;
@@ -1357,8 +1400,9 @@ struct Solver
     exit_status = 0;
     mem_sync();
   }
-#if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-  long long timing_t0;
+#if defined(CCC_TILE_TIMING)
+  double timing_busy, timing_first; // (development aid, set by the launch code: 100 MHz ticks)
+  long long timing_slice0;
 #endif
   W64_FN bool iterate(int budget)
   {
@@ -1467,8 +1511,15 @@ struct Solver
       if(I.out_status) I.out_status[0] = status;
       if(I.out_cost) I.out_cost[0] = cost;
 #if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-      // (development aid, scripts/ddp_sched_probe.py: the cost output carries start tick * 2^24 + duration in ticks)
-      if(I.out_cost) I.out_cost[0] = (double)(timing_t0 & 0xffffffll) * 16777216.0 + (double)((long long)wall_clock64() - timing_t0);
+      // (development aid, scripts/ddp_sched_probe.py: the cost output carries the busy ticks, the first planned input the
+      //  first start tick and the second the finish tick)
+      const long long timing_now = (long long)wall_clock64();
+      if(I.out_cost) I.out_cost[0] = timing_busy + (double)(timing_now - timing_slice0);
+      if((threadIdx.x & 63) == 0)
+      {
+        I.u_out[0] = timing_first;
+        I.u_out[1] = (double)timing_now;
+      }
 #endif
     }
   }

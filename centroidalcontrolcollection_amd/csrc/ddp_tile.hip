@@ -142,10 +142,23 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
     if(resumed)
     {
       __threadfence(); // (acquire: the state below was written by the wavefront that suspended the instance)
-      solver.resume(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 4);
+      solver.resume(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 8);
     }
     else
       solver.begin();
+#if defined(CCC_TILE_TIMING)
+    // (development aid, scripts/ddp_sched_probe.py: busy ticks and first start of the instance travel in save_s[4..5])
+    const long long tt0 = (long long)wall_clock64();
+    double * const tsv = Sc.save_s + (size_t)b * 8;
+    if(!resumed && Sc.slice > 0 && lane == 0)
+    {
+      tsv[4] = 0.0;
+      tsv[5] = (double)tt0;
+    }
+    solver.timing_busy = (Sc.slice > 0 && resumed) ? tsv[4] : 0.0;
+    solver.timing_first = (Sc.slice > 0 && resumed) ? tsv[5] : (double)tt0;
+    solver.timing_slice0 = tt0;
+#endif
     for(int budget = Sc.slice > 0 ? (resumed ? Sc.slice_next : Sc.slice) : -1;; budget = Sc.slice_next)
     {
       const long long t0 = (long long)wall_clock64();
@@ -167,7 +180,10 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
       const unsigned long long ne = __ballot(sched_load(Sc.head + lane) < sched_load(Sc.tail + lane));
       const int lowest = k > 0 ? k - 1 : 0;
       if(!fresh_waiting && (ne >> lowest) == 0ull) continue;
-      solver.suspend(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 4);
+      solver.suspend(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 8);
+#if defined(CCC_TILE_TIMING)
+      if(lane == 0) tsv[4] = solver.timing_busy + (double)((long long)wall_clock64() - tt0);
+#endif
       __threadfence(); // (release: the state is out before the entry is)
       if(lane == 0)
       {
@@ -188,10 +204,10 @@ int ddp_tile_grid(long n, int M, int num_cu)
   return (int)(n < resident ? n : resident);
 }
 
-// layout behind a DdpSched: [ticket, finished, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 4][save_x cap x (N+1) S]
+// layout behind a DdpSched: [ticket, finished, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8][save_x cap x (N+1) S]
 static size_t sched_off_slot() { return (size_t)(64 + 2 * kDdpSchedBuckets) * 4; }
 static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 4 + 255) / 256 * 256; }
-static size_t sched_off_x(long cap) { return sched_off_s(cap) + (size_t)cap * 4 * 8; }
+static size_t sched_off_x(long cap) { return sched_off_s(cap) + (size_t)cap * 8 * 8; }
 size_t ddp_sched_bytes(long cap, int N, int S) { return sched_off_x(cap) + (size_t)cap * (size_t)(N + 1) * S * 8; }
 DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
 {

@@ -26,7 +26,7 @@ EXPECT = {
     "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 160, 10240),
     "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 416, 10240),    # 32 ridges
     "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 416, 10240),
-    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 160, 12288),    # 64 ridges: one wavefront per SIMD
+    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 176, 12288),    # 64 ridges: one wavefront per SIMD
     "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 512, 1, 160, 12288),
     "ccc_amd::z_plan_stream_kernel": ("z", 168, 3, 0, None),
     "void ccc_amd::z_plan_kernel<40, 1>": ("z", 168, 3, 0, 14336),             # eleven workgroups per CU
