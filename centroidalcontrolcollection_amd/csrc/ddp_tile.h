@@ -151,6 +151,7 @@ struct alignas(16) Mem
   double wrun[16], wterm[16];
   double alpha[12];
   double inertia[9];
+  double llt[6];                       // Cholesky factor of the inertia matrix (vllt3_factor)
   unsigned char pair[80];              // (a, b), a <= b, of the entries of Vxx's upper triangle: a | b << 4
 #if defined(CCC_TILE_PROF)
   double prof[TP_N];
@@ -183,14 +184,26 @@ W64_FN void vsincos(vf x, vf & s, vf & c)
   c = sel(q == 0, cs, sel(q == 1, -sn, sel(q == 2, -cs, sn)));
 }
 
-// Eigen::LLT<Matrix3d>::solve on every lane (src/DdpSingleRigidBody.cpp:88,122-123): the statements of oracle/ddp_models.c
-W64_FN void vllt3(const double * I, const vf (&b)[3], vf (&x)[3])
+// Eigen::LLT<Matrix3d>::solve on every lane (src/DdpSingleRigidBody.cpp:88,122-123): the statements of oracle/ddp_models.c.
+// The factor of the inertia matrix is the same for every solve of an instance: vllt3_factor() forms it once (init()) with
+// the statements the oracle forms it with at every call -- the same six numbers, so every solve is bit for bit the same
+W64_FN void vllt3_factor(const double * I, double * L)
 {
   const double l00 = std::sqrt(I[0]);
   const double l10 = I[3] / l00, l20 = I[6] / l00;
   const double l11 = std::sqrt(I[4] - l10 * l10);
   const double l21 = (I[7] - l20 * l10) / l11;
   const double l22 = std::sqrt(I[8] - l20 * l20 - l21 * l21);
+  L[0] = l00;
+  L[1] = l10;
+  L[2] = l20;
+  L[3] = l11;
+  L[4] = l21;
+  L[5] = l22;
+}
+W64_FN void vllt3(const double * L, const vf (&b)[3], vf (&x)[3])
+{
+  const double l00 = L[0], l10 = L[1], l20 = L[2], l11 = L[3], l21 = L[4], l22 = L[5];
   const vf y0 = b[0] / l00;
   const vf y1 = (b[1] - l10 * y0) / l11;
   const vf y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
@@ -309,6 +322,12 @@ struct Solver
     }
     for(int e = 0; e < 12; e++) mem.alpha[e] = e < 11 ? P.alpha[e] : 0.0;
     for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12) ? I.inertia[e] : 0.0;
+    if(S == 12)
+    {
+      double lf[6];
+      vllt3_factor(I.inertia, lf);
+      for(int e = 0; e < 6; e++) mem.llt[e] = lf[e];
+    }
 #if defined(CCC_TILE_PROF)
     for(int e = 0; e < TP_N; e++) mem.prof[e] = 0.0;
 #endif
@@ -418,7 +437,7 @@ struct Solver
       const vf cw0 = w1 * Iw2 - w2 * Iw1, cw1 = w2 * Iw0 - w0 * Iw2, cw2 = w0 * Iw1 - w1 * Iw0;
       const vf wd[3] = {-1 * cw0 + T.moment[0], -1 * cw1 + T.moment[1], -1 * cw2 + T.moment[2]};
       vf sol[3];
-      vllt3(In, wd, sol);
+      vllt3(mem.llt, wd, sol);
       const vf az = -1 * kGravity + T.accel[2];
       const vf vshift = sel(c == 0, row_bcast<6>(x), sel(c == 1, row_bcast<7>(x), row_bcast<8>(x)));
       xd = sel(c < 3, vshift,
@@ -478,7 +497,7 @@ struct Solver
       for(int b = 0; b < AB; b++)
       {
         vf sol[3];
-        vllt3(In, T.cr[b], sol);
+        vllt3(mem.llt, T.cr[b], sol);
         for(int k = 0; k < 3; k++)
         {
           Fu[b][k] = (Rc[b][k] / P.mass) * dt;
@@ -504,8 +523,8 @@ struct Solver
         // column b of I^-1 d(-w x I w)/dw -> block (9, 9); column b of I^-1 crossMat(totalForce) -> block (9, 0)
         const vf colD[3] = {D[b], D[3 + b], D[6 + b]}, colC[3] = {CM[b], CM[3 + b], CM[6 + b]};
         vf sD[3], sC[3];
-        vllt3(In, colD, sD);
-        vllt3(In, colC, sC);
+        vllt3(mem.llt, colD, sD);
+        vllt3(mem.llt, colC, sC);
         for(int a = 0; a < 3; a++)
         {
           st(mem.Fx, spl((9 + a) * S + 9 + b), sD[a] * dt, first);

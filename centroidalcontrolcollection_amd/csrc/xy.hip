@@ -755,6 +755,7 @@ struct XyWork
   int * out_list;
   int * out_count;
   int single; // 1: single-change mode from the saved sets (the safeguard round)
+  int wander; // > 0: hand an instance over when its last forward pass changed more ridges than this (see the kernel's end)
 };
 
 // index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
     return bits;
   };
   unsigned long long h1 = 0, h2 = 0, h3 = 0, h4 = 0; // hashes of the clamped sets of the last iterations
+  int nchg = 0; // ridges that changed sides in the last forward pass of the block iteration
   // The value function of a stage depends on the sets of the LATER stages only: when the last forward pass changed
   // nothing beyond stage smax, the backward recursion resumes there, from the value function it stored on its way in
   // (kXsPt / kXsPin then hold it as it ENTERED the stage: the very numbers a full recursion would produce again).
@@ -1206,6 +1208,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       //  found the set unchanged computes exactly the values an extra pass would: that pass is only run for lambda_all)
       if(emit && !single && !B.lambda_all) break;
       bool changed = false;
+      if(!emit && !single) nchg = 0;
       unsigned long long hh = 1469598103934665603ull;
       double x[6];
 #pragma unroll
@@ -1419,6 +1422,13 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
             store_bits(s, nb);
             changed = true;
             smax_new = s;
+            // ridges of the stage that changed sides (2 bits each)
+            const Bits df = nb ^ bits;
+            const Bits any = (df | (df >> 1)) & (~Bits(0) / 3);
+            if constexpr(M > 32)
+              nchg += __popcll((unsigned long long)any) + __popcll((unsigned long long)(any >> 64));
+            else
+              nchg += __popcll((unsigned long long)any);
           }
           hh = (hh ^ fold(nb)) * 1099511628211ull;
         }
@@ -1473,7 +1483,12 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       W.st[((size_t)s * kStW) * W.st_stride + b] = (unsigned long long)bits;
       if constexpr(M > 32) W.st[((size_t)s * kStW + 1) * W.st_stride + b] = (unsigned long long)(bits >> 64);
     }
-    if(!cycling && W.out_list)
+    // Round 4: an instance that still moves an eighth of its variables per iteration this late does not settle (prototype,
+    // 300 bench instances: after ten iterations more than 30 of the 320 variables changed on 13 instances, all 13 among
+    // the 16 that never settle, none among the 28 that do) -- it goes to the dual kernel now, beside the next round,
+    // instead of after it (config 4: 15.3 -> 14.0 ms, 16384 instances: 7.1 -> 5.9 ms)
+    const bool wandering = W.wander > 0 && nchg > W.wander;
+    if(!cycling && !wandering && W.out_list)
     {
       const int q = atomicAdd(W.out_count, 1);
       W.out_list[q] = (int)b;
@@ -1509,6 +1524,7 @@ struct ccc_xy
   bool env_safeguard = false, env_dual = false, env_stream = false;
   int env_pdas_iters = -1; // CCC_XY_PDAS_ITERS (< 0: the default cap)
   std::string env_rounds;  // CCC_XY_ROUNDS ("": the default round boundaries)
+  int wander = 0;          // changed ridges per iteration beyond which a late instance counts as wandering (CCC_XY_WANDER; 0: off)
 };
 
 extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** out)
@@ -1537,6 +1553,8 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   h->env_stream = std::getenv("CCC_XY_STREAM") != nullptr;
   if(const char * mi = std::getenv("CCC_XY_PDAS_ITERS")) h->env_pdas_iters = std::atoi(mi);
   if(const char * rs = std::getenv("CCC_XY_ROUNDS")) h->env_rounds = rs;
+  h->wander = std::max(8, p->horizon_steps * h->M / 8);
+  if(const char * wv = std::getenv("CCC_XY_WANDER")) h->wander = std::max(0, std::atoi(wv));
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
   if(e != hipSuccess)
@@ -1627,7 +1645,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned long long *>(h->ws + o_st),
            reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), 0, 0, n64,
-           nullptr, nullptr, nullptr, nullptr, 0};
+           nullptr, nullptr, nullptr, nullptr, 0, 0};
   int * const round_list[2] = {reinterpret_cast<int *>(h->ws + o_l1), reinterpret_cast<int *>(h->ws + o_l2)};
   int * const round_count = reinterpret_cast<int *>(h->ws + o_cn) + 1; // [kXsRounds], after the redo count
   // hand-overs to the dual kernel: a list per round (the first round's is W.redo_list)
@@ -1691,6 +1709,8 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       // (safeguard: every round hands over to ONE list, worked off by the single-change round after the last)
       Wk.redo_list = redo_list_of(safeguard ? 0 : k);
       Wk.redo_count = redo_count_of(safeguard ? 0 : k);
+      // (from the second round on, and only where the dual kernel takes the hand-overs)
+      Wk.wander = (!safeguard && k >= 1 && k + 1 < nr) ? h->wander : 0;
       launch_stream(Wk, k ? ends[k - 1] : 0, ends[k]);
       if(k + 1 < nr && !safeguard)
       {

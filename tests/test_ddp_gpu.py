@@ -87,6 +87,36 @@ def test_srb_parity_with_oracle_config5_shape():
     _assert_bitwise(r, o)
 
 
+@pytest.mark.parametrize("srb", [False, True])
+def test_longest_first_schedule_gives_the_plain_queues_answers_bit_for_bit(srb, monkeypatch):
+    """csrc/ddp_tile.hip: a batch larger than one resident set of wavefronts runs in slices of iterations, suspended and
+    resumed longest-remaining-first.  The answers must be those of the plain work queue bit for bit: a batch
+    of 2100 (more than the 2048 resident wavefronts of an MI355X), and small batches on a grid cut to 24 workgroups with
+    slices of 1 iteration -- cold, warm-started, with one iteration allowed, with and without the state output."""
+    N, dt = 12, 0.05
+    mk = _srb if srb else _cen
+    prob, x0 = fd.make_centroidal_batch(2100, N, dt, seed=77, srb=srb)
+    monkeypatch.setenv("CCC_DDP_SLICE", "0")  # (development switches are read when a handle is created)
+    plain = mk(N, dt, 8).planOnceBatch(prob, x0, want_x=True)
+    monkeypatch.delenv("CCC_DDP_SLICE")
+    _assert_bitwise(mk(N, dt, 8).planOnceBatch(prob, x0, want_x=True), plain, ("u", "x", "cost", "iters", "status"))
+    assert plain["iters"].max() > 2 and plain["iters"].min() < plain["iters"].max()
+    sub = {a: v[:200] for a, v in prob.items()}
+    monkeypatch.setenv("CCC_DDP_SLOTS", "24")
+    monkeypatch.setenv("CCC_DDP_SLICE", "1,1")
+    d = mk(N, dt, 8)
+    r = d.planOnceBatch(sub, x0[:200])
+    for k in ("u", "cost", "iters", "status"):
+        assert np.array_equal(r[k], plain[k][:200]), k
+    monkeypatch.setenv("CCC_DDP_SLICE", "0")
+    for max_iter in (1, 3):
+        ref = mk(N, dt, max_iter).planOnceBatch(sub, x0[:200] + 0.01, u_init=plain["u"][:200])
+        monkeypatch.setenv("CCC_DDP_SLICE", "2,1")
+        got = mk(N, dt, max_iter).planOnceBatch(sub, x0[:200] + 0.01, u_init=plain["u"][:200])
+        monkeypatch.setenv("CCC_DDP_SLICE", "0")
+        _assert_bitwise(got, ref)
+
+
 def test_warm_start_and_limits():
     N, dt = 100, 0.03
     prob, x0 = fd.make_centroidal_batch(64, N, dt, seed=3)
