@@ -117,6 +117,13 @@ def solve_structured(prob, k, x0, verbose=False, LD=np.float64):
         v = np.maximum(viol_lo, viol_hi)
         p = int(np.argmax(v))
         if v[p] <= 1e-9: break
+        if RULE:
+            # entering variable by the dual objective's gain of a full step, violation^2 / curvature (curvature of variable
+            # i: (1 - bt_i' Q[s_i, s_i] bt_i) / w_f): RULE 1 with the current operator, RULE 2 with the one after the set-up
+            Qd = Q if RULE == 1 else Q_SETUP
+            curv = np.array([1.0 - bt[i] @ Qd[7 * step[i]:7 * step[i] + 7, 7 * step[i]:7 * step[i] + 7] @ bt[i] if v[i] > 1e-9 else 1.0 for i in range(nv)])
+            key = np.where(v > 1e-9, v * v / np.maximum(curv, 1e-12), -np.inf)
+            p = int(np.argmax(key))
         sg = 1.0 if viol_lo[p] >= viol_hi[p] else -1.0      # constraint normal n = sg e_p  (sg=+1 lower bound)
         while True:
             npiv += 1
@@ -147,7 +154,7 @@ def solve_structured(prob, k, x0, verbose=False, LD=np.float64):
         l2 = refine(lam); hist.append(np.abs(l2 - lam).max()); lam = l2
     global HIST; HIST = hist
     return lam, lam_pre, npiv, stat
-REBUILD = True; NREF = 4; ETA = True
+REBUILD = True; NREF = 4; ETA = True; RULE = 0
 
 if __name__ == "__main__":
     n = 6
