@@ -1680,13 +1680,18 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   };
   if(!dual_only)
   {
-    const int cap = h->env_pdas_iters >= 0 ? h->env_pdas_iters : kXsMaxIt; // (small values exercise the work list)
+    // iterations of the block iteration before what is left goes to the dual kernel (safeguard rounds: always 16).  A small
+    // batch runs at the latency of its sweeps (0.33 ms each) while the dual kernel has room: fewer sweeps, more hand-overs
+    // (measured, round 4: 8192 instances 5.7 -> 4.9 ms with 12, 16384 6.0 -> 5.6 ms with 14, 65536 14.0 ms with 16 against
+    // 14.5 / 16.3 ms with 14 / 12).  CCC_XY_PDAS_ITERS overrides (small values exercise the work list)
+    const bool small = !safeguard && n < 12288, medium = !safeguard && n < 32768;
+    const int cap = h->env_pdas_iters >= 0 ? h->env_pdas_iters : (small ? 12 : (medium ? 14 : kXsMaxIt));
     // rounds of iterations (development switch CCC_XY_ROUNDS="a,b": the iteration counts at which the instances still
     // going are repacked; the instances of a wavefront need very different numbers of iterations, and a wavefront is as
     // slow as its slowest lane)
     int ends[kXsRounds], nr = 0;
     {
-      std::string spec = h->env_rounds.empty() ? std::string(kXsRoundsDefault) : h->env_rounds;
+      std::string spec = h->env_rounds.empty() ? std::string(small && h->env_pdas_iters < 0 ? "6,9" : kXsRoundsDefault) : h->env_rounds;
       size_t pos = 0;
       while(pos < spec.size() && nr < kXsRounds - 1)
       {
