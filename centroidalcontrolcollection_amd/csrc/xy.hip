@@ -1654,13 +1654,13 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   auto ticket_of = [&](int k) { return W.redo_count + 2 * kXsRounds + k; };
   const int lgrid = (int)std::min<int64_t>(n, (int64_t)h->num_cu * 4); // (two workgroups are resident per CU)
   // one instance per lane needs a batch to fill the device and has a latency floor of ~7 ms (16 dependent iterations, then
-  // the dual kernel on what is left): below 4096 instances the dual active-set kernel alone, one 448-thread workgroup
-  // per instance, is faster (measured: 4.2 against 7.3 ms at 2048, 7.6 / 7.3 at 4096, 14.5 / 8.1 at 8192, 28 / 9.4 at
-  // 16384); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
+  // the dual kernel on what is left): below ~3300 instances the dual active-set kernel alone, one 448-thread workgroup
+  // per instance, is faster (measured, end of round 4: 1.7 against 4.4 ms at 1024, 3.0 / 4.5 at 2048, 4.3 / 4.5 at 3072,
+  // 5.6 / 4.6 at 4096); CCC_XY_DUAL / CCC_XY_STREAM force either path (development switches)
   const int grid = (int)std::min<int64_t>(n, (int64_t)1 << 22);
   // CCC_XY_SAFEGUARD (development switch): the single-change rounds instead of the dual kernel where both apply
   const bool safeguard = h->wide || h->env_safeguard;
-  const bool dual_only = !safeguard && (h->env_dual || (n < 4096 && !h->env_stream && h->env_pdas_iters < 0));
+  const bool dual_only = !safeguard && (h->env_dual || (n < 3328 && !h->env_stream && h->env_pdas_iters < 0));
   auto launch_stream = [&](const XyWork & Wk0, int it_begin, int it_end) {
     XyWork Wk = Wk0;
     Wk.ws_stride = Wk.rb_stride = N * kXsStage * (size_t)kXsLanes;
