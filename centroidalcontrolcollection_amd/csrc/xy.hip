@@ -1021,9 +1021,41 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
 #pragma unroll
       for(int c = 0; c < 6; c++) Pm[a][c] = 0.0;
     }
+    // (round 4) the fields a stage of the backward recursion reads are loaded one stage AHEAD: a sweep is a chain of
+    // load -> 6 x 6 algebra -> store per stage, and the loads of stage s - 1 do not depend on what stage s computes
+    // (8192 instances 4.8 -> 4.7 ms; the same for the 80 fields of a forward stage costs 232 B of scratch: 4.9 ms, not kept)
+    struct BwIn
+    {
+      double dim, fz, ref[6], al, dp, t[6], c[6], S[21];
+    };
+    auto load_bw = [&](int s, BwIn & in) {
+      in.dim = WS(s, kXsDim);
+      in.fz = WS(s, kXsFz);
+      in.al = WS(s, kXsAl);
+      in.dp = WS(s, kXsDp);
+#pragma unroll
+      for(int a = 0; a < 6; a++)
+      {
+        in.ref[a] = WS(s, kXsRef + a);
+        in.t[a] = WS(s, kXsT + a);
+        in.c[a] = WS(s, kXsC + a);
+      }
+#pragma unroll
+      for(int a = 0; a < 21; a++) in.S[a] = WS(s, kXsS + a);
+    };
+    BwIn nxt;
+    if(!kResume) load_bw(N - 1, nxt);
     for(int s = N - 1; s >= 0; s--)
     {
       if(kResume && s > smax) continue;
+      BwIn cur;
+      if(kResume)
+        load_bw(s, cur);
+      else
+      {
+        cur = nxt;
+        if(s > 0) load_bw(s - 1, nxt);
+      }
       if(kResume && s == smax && s < N - 1)
       {
 #pragma unroll
@@ -1034,27 +1066,27 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
           for(int c = 0; c < 6; c++) Pm[a][c] = WS(s, kXsPt + (c >= a ? xs_tri(a, c) : xs_tri(c, a)));
         }
       }
-      const int m = (int)WS(s, kXsDim);
-      const double fz = WS(s, kXsFz);
+      const int m = (int)cur.dim;
+      const double fz = cur.fz;
       const double kap = fz / P.mass, k2 = kap * dt, k3 = kap * dt * dt / 2;
       double Pt[6][6], pt[6];
 #pragma unroll
       for(int a = 0; a < 6; a++)
       {
-        pt[a] = pv[a] - P.w[a] * WS(s, kXsRef + a);
+        pt[a] = pv[a] - P.w[a] * cur.ref[a];
 #pragma unroll
         for(int c = 0; c < 6; c++) Pt[a][c] = Pm[a][c] + (a == c ? P.w[a] : 0.0);
       }
       // the clamped set's sums, as the setup / the last forward pass left them
       double S[6][6], t[6], cc[6];
-      const double alpha = WS(s, kXsAl), dprime = WS(s, kXsDp);
+      const double alpha = cur.al, dprime = cur.dp;
 #pragma unroll
       for(int a = 0; a < 6; a++)
       {
-        t[a] = WS(s, kXsT + a);
-        cc[a] = WS(s, kXsC + a);
+        t[a] = cur.t[a];
+        cc[a] = cur.c[a];
 #pragma unroll
-        for(int c = 0; c < 6; c++) S[a][c] = WS(s, kXsS + (c >= a ? xs_tri(a, c) : xs_tri(c, a)));
+        for(int c = 0; c < 6; c++) S[a][c] = cur.S[c >= a ? xs_tri(a, c) : xs_tri(c, a)];
       }
       if(m > 0 && alpha > 0.0)
       {
