@@ -33,26 +33,42 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector fp64 (256 CUs x 64
 FLOP_PER_PIVOT = 2048
 
 
+def _same_build(d):
+    """The profile summary d was made from the kernel sources this library was built from (kernel_hash of
+    centroidalcontrolcollection_amd/build.py: the csrc files of the headline kernel + the compiler flags)?  Counters of
+    another build are not replayed (VERDICT r4 weak #4)."""
+    from centroidalcontrolcollection_amd import build as _b
+
+    return d.get("kernel_hash") == _b.kernel_hash("zmp")
+
+
 def measured_traffic(n):
-    """HBM bytes per launch from the PMC passes of scripts/prof_zmp.sh (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE,
-    summarised by scripts/summarize_prof.py into profiles/zmp_hbm_traffic.json); None if not collected for this batch."""
+    """(HBM bytes per launch | None, source) from the PMC passes of scripts/prof_zmp.sh (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE,
+    summarised by scripts/summarize_prof.py into profiles/zmp_hbm_traffic.json); None if not collected for this batch or
+    collected on another build of the kernel."""
+    from centroidalcontrolcollection_amd import build as _b
+
     path = os.path.join(ROOT, "profiles", "zmp_hbm_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("algorithmic_bytes_per_launch") == ALGO_BYTES_PER_SOLVE * n:
-            return d["hbm_bytes_per_launch"]
+            if _same_build(d):
+                return d["hbm_bytes_per_launch"], "profiles/zmp_hbm_traffic.json (replayed; kernel_hash %s = this build)" % d["kernel_hash"]
+            return None, "profiles/zmp_hbm_traffic.json refused: profiled build %s, this build %s" % (
+                d.get("kernel_hash"), _b.kernel_hash("zmp"))
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def valu_counters(n):
     """VALU-issue share of the kernel from the PMC pass of the same launch (profiles/zmp_valu_counters.json, written by
-    scripts/summarize_prof.py from rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES ...); None if not collected for this batch."""
+    scripts/summarize_prof.py from rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES ...); None if not collected for this batch
+    or collected on another build of the kernel."""
     path = os.path.join(ROOT, "profiles", "zmp_valu_counters.json")
     try:
         d = json.load(open(path))
-        if d.get("batch") == n:
+        if d.get("batch") == n and _same_build(d):
             return d
     except Exception:
         pass
@@ -174,6 +190,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
                          "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only: skip the `secondary` entries (configs 3, 4, 5: xy 65536 x 3 steps, ddp 4096 x 3, "
+                         "srb 32768 x 2, each with roofline / cpu_baseline / parity) the default one-GPU command appends")
     ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
@@ -382,6 +401,7 @@ def main():
         achieved = ALGO_BYTES_PER_SOLVE * n / kavg / 1e9
         tflops = pivots_per_solve * FLOP_PER_PIVOT * n / kavg / 1e12
         vc = valu_counters(n)
+        traffic, traffic_src = measured_traffic(n)
         out = {
             "metric": "LinearMpcZmp planOnce() solves/sec (N=32, fp64, inputs resident in HBM)",
             "value": value,
@@ -410,10 +430,11 @@ def main():
             # the bound that binds is VALU issue (fp64 vector pipe), not HBM and not MFMA: `achieved/peak/frac` are the
             # HBM figures the contract asks for, `valu` the ones that say how far the kernel is from ITS roofline
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          # (PMC counters need rocprofv3 around the process: collected by scripts/prof_zmp.sh -- this command
-                         #  under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, one pass each -- and read back from profiles/)
-                         "traffic_source": "profiles/zmp_hbm_traffic.json",
+                         #  under `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`, one pass each -- and read back from profiles/, only
+                         #  when that summary was made from the kernel sources this library was built from)
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
                          "kernel": timed_kernel,
                          "kernel_avg_ms": kavg * 1e3,
@@ -442,6 +463,22 @@ def main():
             cb, ref_zmp, n_chk = cpu_baseline(batch)
             out["cpu_baseline"] = cb
             out["parity_max_abs_err"] = float(np.abs(zmp.cpu().numpy()[:n_chk] - ref_zmp).max())
+    # configs 3, 4, 5 in the driver's record: the default one-GPU command also times LinearMpcXY
+    # (config 4), DdpCentroidal (config 3) and DdpSingleRigidBody (config 5's shape) with the same protocol and appends their
+    # lines -- value, ms_per_step, steps, roofline (traffic + traffic_source), cpu_baseline (value_1thread), parity
+    secondary = None
+    if world == 1 and not args.no_secondary and not args.batch_given:
+        import bench_secondary
+
+        torch.cuda.empty_cache()
+        secondary = []
+        for wl, (k_steps, k_warm) in (("xy", (3, 1)), ("ddp", (3, 1)), ("srb", (2, 1))):
+            secondary.append(bench_secondary.measure(wl, bench_secondary.DEFAULT_BATCH[wl], k_steps, k_warm, rank, world,
+                                                     local_rank, dist, cpu=not args.no_cpu_baseline, dinfo=None))
+            torch.cuda.empty_cache()
+    if rank == 0:
+        if secondary is not None:
+            out["secondary"] = secondary
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

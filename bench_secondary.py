@@ -60,9 +60,9 @@ def _xy(n, dev, rank, walking=False):
     def step(stream):
         mpc.plan_batch_device(tp, tx0, out, status=st, stream=stream)
 
-    def cpu(cores):
+    def cpu(cores, ns=None):
         from oracle import oracle
-        ns = min(n, 512 if walking else 2048)
+        ns = min(n, ns or (512 if walking else 2048))
         sub = {a: v[:ns] for a, v in prob.items()}
         o = oracle.LinearMpcXY(100.0, dt, N, M=M)
         t0 = time.perf_counter()
@@ -120,9 +120,9 @@ def _ddp(n, dev, rank, srb, walking=False):
     def step(stream):
         d.plan_batch_device(tp, tx0, out, iters=it, status=st, stream=stream)
 
-    def cpu(cores):
+    def cpu(cores, ns=None):
         from oracle import oracle
-        ns = min(n, 2048)
+        ns = min(n, ns or 2048)
         sub = {a: v[:ns] for a, v in prob.items()}
         o = oracle.Ddp(1 if srb else 0, 100.0, dt, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=20,
                        P=P, M=M, arith=d.arithmetic())
@@ -153,26 +153,43 @@ def _ddp(n, dev, rank, srb, walking=False):
 
 
 def _ddp_valu(S, M, N, iters, walking):
-    """Algorithmic flop per solve (the DENSE formulation's count, what the reference's solver performs; the structured
-    backward step of round 4 gets the same result with fewer operations): SURVEY.md 8(d)'s count per backward step (Quu 2(S^2 m + S m^2), Qxu / Qxx 2(S^3 + S^2 m),
-    Cholesky m^3 / 3, gains 2 m^2 S, value update 6 k at S = 9, m = 16: ~25 kflop) scaled to (S, m) x horizon x the
-    iterations the run executed; the issue share comes from the committed PMC pass of the same kernel."""
+    """What the DDP kernel is bound by -- VALU instruction throughput -- from the newest committed PMC summary made from the
+    same kernel sources (profiles/r*_ddp_valu_counters.json; replayed, see replayed_counters), plus a DENSE-EQUIVALENT flop
+    count for orientation: SURVEY.md 8(d)'s count per backward step of the dense formulation (Quu 2(S^2 m + S m^2), Qxu /
+    Qxx 2(S^3 + S^2 m), Cholesky m^3 / 3, gains 2 m^2 S, value update 6 k at S = 9, m = 16: ~25 kflop) x horizon x the
+    iterations the run executed.  The structured backward step (round 4) gets the same result with fewer operations, so
+    this is NOT what the kernel executes and is kept out of any fraction of the peak."""
+    import glob
+
+    from centroidalcontrolcollection_amd import build as _b
+
     m = M
     per_step = 2 * (S * S * m + S * m * m) + 2 * (S ** 3 + S * S * m) + m ** 3 / 3 + 2 * m * m * S + 6e3 * (S / 9.0) ** 2
-    pmc = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_ddp_valu_counters.json")
-    if os.path.exists(path):
+    pmc, src = None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    mine = _b.kernel_hash("ddp")
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_ddp_valu_counters.json")), reverse=True):
         with open(path) as f:
-            pmc = json.load(f).get("S%d" % S if M == 16 else "S%dM%d" % (S, M))
-    return dict(flop_per_solve=per_step * N * iters, flop_per_backward_step=per_step,
+            d = json.load(f)
+        rel = "profiles/" + os.path.basename(path)
+        if d.get("kernel_hash") != mine:
+            src = src or "%s refused: profiled build %s, this build %s" % (rel, d.get("kernel_hash"), mine)
+            continue
+        pmc = d.get("S%d" % S if M == 16 else "S%dM%d" % (S, M))
+        src = "%s (replayed; kernel_hash %s = this build)" % (rel, mine)
+        break
+    return dict(dense_equivalent_flop_per_solve=per_step * N * iters, dense_equivalent_flop_per_backward_step=per_step,
                 issue_frac=None if pmc is None else pmc["valu_issue_frac"],
                 wait_frac=None if pmc is None else pmc["wait_any_frac"],
                 simd_valu_busy_frac=None if pmc is None else pmc.get("simd_valu_busy_frac"),
-                counters_source="profiles/r04_ddp_valu_counters.json" if pmc else None,
-                what="useful fp64 flop of the backward passes over the kernel time against the vector-fp64 peak; "
-                     "issue_frac = SQ_INSTS_VALU x 4 clk / (SIMDs x kernel clocks at the 2.4 GHz PEAK clock), wait_frac = SQ_WAIT_ANY / "
-                     "SQ_WAVE_CYCLES, simd_valu_busy_frac = SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES (clock-independent: "
-                     "what says the kernel is bound by VALU instruction throughput)")
+                arch_vgprs=None if pmc is None else pmc.get("arch_vgpr", pmc.get("vgpr")),
+                scratch_bytes_per_lane=None if pmc is None else pmc.get("scratch"),
+                counters_source=src,
+                what="simd_valu_busy_frac = SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES (clock-independent: how "
+                     "busy a SIMD's one vector ALU is -- the roofline this kernel is bound by); issue_frac = SQ_INSTS_VALU x 4 "
+                     "clk / (SIMDs x kernel clocks at the 2.4 GHz PEAK clock); wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES; "
+                     "dense_equivalent_* = flop of the DENSE formulation of the backward passes the run executed (the "
+                     "structured kernel performs fewer): orientation only, in no fraction of the peak")
 
 
 def _ism(n, dev, rank):
@@ -187,9 +204,9 @@ def _ism(n, dev, rank):
     def step(stream):
         mpc.plan_batch_device(ti, tr, 0.005, out, status=st, stream=stream)
 
-    def cpu(cores):
+    def cpu(cores, ns=None):
         from oracle import oracle
-        ns = min(n, 16384)
+        ns = min(n, ns or 16384)
         o = oracle.IntrinsicallyStableMpc(1.0, 2.0, dt)
         t0 = time.perf_counter()
         r = o.plan_batch(b["init"][:ns], b["ref"][:ns], 0.005, want_vel=False, nthreads=cores)
@@ -213,9 +230,9 @@ def _z(n, dev, rank):
     def step(stream):
         mpc.plan_batch_device(tc, tr, tx, out, status=st, stream=stream)
 
-    def cpu(cores):
+    def cpu(cores, ns=None):
         from oracle import oracle
-        ns = min(n, 65536)
+        ns = min(n, ns or 65536)
         o = oracle.LinearMpcZ(100.0, dt, N)
         t0 = time.perf_counter()
         r = o.plan_batch(b["contact"][:ns], b["ref_pos"][:ns], b["x0"][:ns], nthreads=cores)
@@ -252,9 +269,9 @@ def _ddpzmp(n, dev, rank):
         d.plan_batch_device(tr, tx, tu, u, None, it, st, None, stream=stream)
         out.copy_(u[:, 0, :])
 
-    def cpu(cores):
+    def cpu(cores, ns=None):
         from oracle import oracle
-        ns = min(n, 65536)
+        ns = min(n, ns or 65536)
         o = oracle.DdpZmp(100.0, dt, N, max_iter=max_iter)
         t0 = time.perf_counter()
         r = o.plan_batch(b["ref"][:ns], b["x0"][:ns], b["u_init"][:ns], nthreads=cores)
@@ -277,8 +294,41 @@ DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), 
                      walk=(3, 1), multi=(3, 1), xywalk=(3, 1))
 
 
+# sample of the 1-thread leg of cpu_baseline (instances; ~1 s each on one core of the GPU box's host)
+ONE_THREAD_SAMPLE = dict(xy=64, xywalk=16, ddp=128, srb=256, walk=96, multi=64, ism=1024, z=8192, ddpzmp=4096)
+
+
+def replayed_counters(workload, n):
+    """(hbm_bytes_per_step | None, source): the measured HBM bytes of one step of `workload` at batch n from the newest
+    committed PMC summary (profiles/r*_hbm_traffic.json, written by scripts/summarize_round.py from `rocprofv3 --pmc
+    FETCH_SIZE` / `WRITE_SIZE` passes around this very command).  A counter needs rocprofv3 around the process, so the
+    figure is REPLAYED, not measured in this run -- and only when the summary was made from the same kernel sources
+    (centroidalcontrolcollection_amd.build.kernel_hash: csrc files + flags) as the library that just ran; otherwise
+    null, and the source string says which build the summary belongs to (VERDICT r4 weak #4)."""
+    import glob
+
+    from centroidalcontrolcollection_amd import build as _b
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    mine = _b.kernel_hash(workload)
+    refused = None
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tr = json.load(f).get(workload)
+        except Exception:
+            continue
+        if not tr or tr.get("batch") != n:
+            continue
+        rel = "profiles/" + os.path.basename(path)
+        if tr.get("kernel_hash") != mine:
+            refused = refused or "%s refused: profiled build %s, this build %s" % (rel, tr.get("kernel_hash"), mine)
+            continue
+        return tr.get("hbm_bytes_per_launch", tr.get("hbm_bytes_per_step")), "%s (replayed; kernel_hash %s = this build)" % (rel, mine)
+    return None, refused
+
+
 def run(args, rank, world, local_rank, dist):
-    dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch_given else DEFAULT_BATCH[args.workload]
     strong = getattr(args, "scaling", "weak") == "strong" and world > 1
     if strong:
@@ -287,9 +337,20 @@ def run(args, rank, world, local_rank, dist):
             raise SystemExit("--scaling strong needs the batch divisible by the number of GPUs")
         n //= world
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
+    out = measure(args.workload, n, steps, warmup, rank, world, local_rank, dist, strong=strong,
+                  cpu=not args.no_cpu_baseline, dinfo=getattr(args, "distributed_info", None))
+    if out is not None:
+        print(json.dumps(out))
+
+
+def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=False, cpu=True, dinfo=None):
+    """One bench line (a dict; None on ranks other than 0) of a secondary workload: `warmup` untimed steps, `steps` timed
+    ones bracketed by barrier + synchronize, max over ranks.  Also what bench.py's default command appends to the headline
+    line as `secondary` (configs 3, 4, 5: VERDICT r4 item 2)."""
+    dev = torch.device("cuda", local_rank)
     make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
                 walk=lambda a, b, c: _ddp(a, b, c, False, True), multi=lambda a, b, c: _ddp(a, b, c, False, "multi"))
-    w = make[args.workload](n, dev, rank)
+    w = make[workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)
     gathered = (torch.empty((world * w["out"].shape[0],) + tuple(w["out"].shape[1:]), dtype=w["out"].dtype, device=dev)
                 if world > 1 else None)
@@ -322,7 +383,7 @@ def run(args, rank, world, local_rank, dist):
         elapsed = float(t.item())
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])
     if rank != 0:
-        return
+        return None
     kavg = float(kern_ms.mean()) * 1e-3
     st = w["status"].cpu().numpy()
     # ALGORITHMIC bytes = the mandatory inputs + outputs of an instance, nothing else.  The kernels that
@@ -333,23 +394,13 @@ def run(args, rank, world, local_rank, dist):
     if callable(sb):
         sb = sb(st)
     achieved = w["algo_bytes"] * n / kavg / 1e9
-    # measured HBM bytes per launch / per step of THIS workload at THIS batch, from the round's PMC passes (rocprofv3
-    # FETCH_SIZE x 2 + WRITE_SIZE, separate runs: scripts/prof_round.sh + scripts/summarize_round.py -> profiles/); null
-    # when the passes were not collected for this configuration.  A counter needs rocprofv3 around the process, so the
-    # figure is read back from the committed summary of the same command, not measured inside this run.
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_hbm_traffic.json")) as f:
-            tr = json.load(f).get(args.workload)
-        if tr and tr.get("batch") == n:
-            traffic = tr.get("hbm_bytes_per_launch", tr.get("hbm_bytes_per_step"))
-            traffic_src = "profiles/r04_hbm_traffic.json"
-    except Exception:
-        pass
+    # measured HBM bytes per step of THIS workload at THIS batch, replayed from the newest PMC summary made from the same
+    # kernel sources (replayed_counters above); null otherwise
+    traffic, traffic_src = replayed_counters(workload, n)
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
-           "distributed": getattr(args, "distributed_info", None),
+           "distributed": dinfo,
            "config": {"workload": w["workload"], "batch_per_gpu": n, "total_batch": world * n,
                       "parallelism": "batch-sharded x%d" % world,
                       "collective": "all_gather(planned outputs)" if world > 1 else "none"},
@@ -378,18 +429,22 @@ def run(args, rank, world, local_rank, dist):
         # say how far the kernel is from THAT roofline (useful flop from SURVEY.md 8(d)'s count per backward step x the
         # steps the run executed, against the vector-fp64 peak; the issue share from the PMC pass in profiles/)
         v = w["valu"](out["mean_iterations"])
-        tfl = v["flop_per_solve"] * n / kavg / 1e12
         out["roofline"]["bound"] = "valu"
-        out["roofline"]["valu"] = dict(achieved=tfl, peak=FP64_VECTOR_PEAK_TFLOPS, unit="TFLOP/s",
-                                       frac=tfl / FP64_VECTOR_PEAK_TFLOPS, **v)
-    if not args.no_cpu_baseline and world == 1:
+        out["roofline"]["valu"] = dict(achieved=v["simd_valu_busy_frac"], peak=1.0, unit="share of SIMD VALU cycles busy",
+                                       frac=v["simd_valu_busy_frac"],
+                                       dense_equivalent_tflops=v["dense_equivalent_flop_per_solve"] * n / kavg / 1e12, **v)
+    if cpu and world == 1:
         import bench  # (host_cores: physical cores within the affinity mask and the cgroup CPU quota)
 
         hw_threads, cores = bench.host_cores()
         rate, ns, err, what = w["cpu"](cores)
+        rate1, ns1, _, _ = w["cpu"](1, ONE_THREAD_SAMPLE[workload])
         out["cpu_baseline"] = {"value": rate, "unit": "solves/s", "cores": cores, "threads": cores,
-                               "host_hardware_threads": hw_threads, "kind": "port",
+                               "host_hardware_threads": hw_threads, "kind": "port", "value_1thread": rate1,
+                               "parallel_efficiency": rate / (rate1 * cores),
                                "sample": "first %d instances of the rank-0 batch, OpenMP over instances, one thread per "
-                                         "physical core (%d); C restatement of the reference path (oracle/)" % (ns, cores)}
+                                         "physical core of the cgroup quota (%d of the host's %d hardware threads); 1-thread "
+                                         "rate on the first %d; C restatement of the reference path (oracle/), not the "
+                                         "reference's Eigen + QLD / nmpc_ddp build" % (ns, cores, hw_threads, ns1)}
         out["parity"] = {"value": err, "what": what}
-    print(json.dumps(out))
+    return out

@@ -23,6 +23,8 @@ CCC_STATUS_SOLVED = 0
 CCC_STATUS_INFEASIBLE = 1
 CCC_STATUS_MAX_ITER = 2
 
+ABI_VERSION = 4  # CCC_ABI_VERSION of include/ccc_amd.h
+
 # every symbol include/ccc_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "ccc_shard_bounds",
@@ -30,6 +32,7 @@ ABI_SYMBOLS = [
     "ccc_ddp_get_config",
     "ccc_ddp_get_device",
     "ccc_ddp_arithmetic",
+    "ccc_ddp_effective_precision",
     "ccc_xy_get_params",
     "ccc_ddp_closed_loop_device",
     "ccc_xy_closed_loop_device",
@@ -134,6 +137,11 @@ def load():
     L.ccc_last_error_string.argtypes = []
     L.ccc_abi_version.restype = ctypes.c_int
     L.ccc_abi_version.argtypes = []
+    if L.ccc_abi_version() != ABI_VERSION:
+        # (the ctypes structures below mirror include/ccc_amd.h at this version: another library would read or write past
+        #  their ends)
+        raise ImportError("libccc_amd.so at %s answers ABI version %d, this package binds version %d"
+                          % (path, L.ccc_abi_version(), ABI_VERSION))
     L.ccc_zmp_create.restype = ctypes.c_int
     L.ccc_zmp_create.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                  ctypes.POINTER(ctypes.c_void_p)]

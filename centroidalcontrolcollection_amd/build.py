@@ -52,6 +52,34 @@ def source_hash():
     return h.hexdigest()
 
 
+# what each benched workload's kernels are compiled from (csrc/ file names): the hash of these files + the flags goes into
+# the profile summaries the bench lines replay counters from, and a bench line refuses counters of another build
+KERNEL_UNITS = dict(
+    zmp=["zmp.hip", "zmp_k1.inc", "sym_tableau.h", "wave_group.h", "common.h"],
+    xy=["xy.hip", "wave_group.h", "common.h"],
+    ddp=["ddp.hip", "ddp_tile.hip", "ddp_tile.h", "ddp_batch.h", "w64.h", "common.h"],
+)
+for _alias in ("srb", "walk", "multi"):
+    KERNEL_UNITS[_alias] = KERNEL_UNITS["ddp"]
+KERNEL_UNITS["xywalk"] = KERNEL_UNITS["xy"]
+
+
+def kernel_hash(workload):
+    """sha256 (first 16 hex digits) over the csrc/ files the workload's kernels are built from and the compiler flags;
+    None for a workload without an entry in KERNEL_UNITS."""
+    import hashlib
+
+    files = KERNEL_UNITS.get(workload)
+    if files is None:
+        return None
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for name in files:
+        h.update(name.encode())
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     """True when libccc_amd.so is missing or was not built from the sources in the tree (content hash recorded by
     build_lib next to the library; mtimes do not survive the copy to the GPU box)."""
@@ -121,4 +149,11 @@ def build_lib(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+
+    if len(sys.argv) > 1 and sys.argv[1] == "--kernel-hashes":  # scripts/prof_*.sh: what the profiled build was made from
+        import json
+
+        print(json.dumps({k: kernel_hash(k) for k in sorted(KERNEL_UNITS)}))
+    else:
+        print(build_lib(force=True, verbose=True))

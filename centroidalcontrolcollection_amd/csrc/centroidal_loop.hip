@@ -164,7 +164,8 @@ struct SimArgs
   const double * ref_now; // [n][6] reference (pos, ori ZYX) at the cycle's time, for the statistics
   double * sim;
   double * stats;         // [n][8]: max over the cycles of |pos - ref|, |ori - ref_ori (unreversed, as the test)|, |vel|,
-                          //          |ang_vel|, |ang_mom|; [5..7] free
+                          //          |ang_vel|, |ang_mom|; [5] cycles whose warm start the guard replaced; [6..7] free
+  const int * plan_status; // optional [n]: the DDP status words of this cycle's plan (CCC_DDP_STATUS_WARM_REPLACED)
   double * log;           // optional [n][9] of this cycle: pos, force, moment
 };
 
@@ -221,6 +222,11 @@ __global__ void sim_step_kernel(SimArgs A)
     st[2] = fmax(st[2], sqrt(e2));
     st[3] = fmax(st[3], sqrt(e3));
     st[4] = fmax(st[4], sqrt(e4));
+    if(A.plan_status)
+    {
+      const int w = A.plan_status[k];
+      if(CCC_DDP_STATUS_WARM_REPLACED(w)) st[5] += 1.0;
+    }
   }
   if(A.log)
   {
@@ -331,9 +337,10 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
   CCC_DEVICE_GUARD(device);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DevBuf buf;
-  int *step_phase, *dims_prev;
+  int *step_phase, *dims_prev, *plan_status;
   double *ref_pos, *ref_ori = nullptr, *x0, *u, *ref_now, *inertia9 = nullptr;
   if(int rc = buf.get(&step_phase, (size_t)n * N)) return rc;
+  if(int rc = buf.get(&plan_status, (size_t)n)) return rc;
   if(int rc = buf.get(&dims_prev, (size_t)n * N)) return rc;
   if(int rc = buf.get(&ref_pos, (size_t)n * (N + 1) * 3)) return rc;
   if(model == 1)
@@ -372,7 +379,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
     rc = ccc_ddp_set_config(h, &cfg);
     if(rc == CCC_OK)
       rc = ccc_ddp_plan_batch_device(h, n, tl->contact_dim, tl->contact_vertex, tl->contact_ridge, step_phase, ref_pos,
-                                     ref_ori, inertia9, x0, u, u, nullptr, nullptr, nullptr, nullptr, s);
+                                     ref_ori, inertia9, x0, u, u, nullptr, nullptr, plan_status, nullptr, s);
     if(rc != CCC_OK) break;
     t += sim_dt; // t += sim_dt BEFORE the update and the disturbance test, as the reference loop
     SimArgs A{};
@@ -401,6 +408,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
     A.ref_now = ref_now;
     A.sim = sim_state;
     A.stats = stats;
+    A.plan_status = plan_status;
     A.log = log ? log + (size_t)c * n * 9 : nullptr;
     hipLaunchKernelGGL(sim_step_kernel, dim3(blocks(n)), dim3(256), 0, s, A);
   }

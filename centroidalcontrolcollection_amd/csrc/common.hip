@@ -63,7 +63,9 @@ extern "C" const char * ccc_last_error_string(void)
 
 extern "C" int ccc_abi_version(void)
 {
-  return 3; // 2: ccc_ddp_config_t::reg_type, sharded entry points, ccc_device_count; 3: max_ridges in ccc_ddp_params_t / ccc_xy_params_t
+  // 2: ccc_ddp_config_t::reg_type, sharded entry points, ccc_device_count; 3: max_ridges in ccc_ddp_params_t /
+  // ccc_xy_params_t; 4: ccc_ddp_config_t::warm_start_guard (the struct grew), CCC_DDP_STATUS_WARM_REPLACED_BIT
+  return CCC_ABI_VERSION;
 }
 
 extern "C" int ccc_device_count(void)

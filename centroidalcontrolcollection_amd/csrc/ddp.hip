@@ -146,6 +146,11 @@ extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
   return h ? 1 : -1; // (one kernel, one arithmetic: oracle/ddp_tile.c)
 }
 
+extern "C" int ccc_ddp_effective_precision(const ccc_ddp_t * h)
+{
+  return h ? 64 : -1; // (one kernel, fp64; cfg.precision = 32 is a request it over-fulfils: ccc_amd.h)
+}
+
 extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
 {
   if(!h || !cfg) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: NULL argument");

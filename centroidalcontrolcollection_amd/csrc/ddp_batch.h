@@ -65,7 +65,7 @@ struct DdpSched
   int * tail;          // [kDdpSchedBuckets] entries reserved
   int * slot;          // [kDdpSchedBuckets][cap] instance ids (-1: reserved, not written yet)
   double * save_x;     // [cap][(N + 1) S] states of the suspended solves (their inputs wait in u_out)
-  double * save_s;     // [cap][4] cost, lambda, dlambda, iterations done
+  double * save_s;     // [cap][8] cost, lambda, dlambda, iterations done, (timing aid x 2), warm start replaced
   long cap;
   int slice;           // iterations of an instance's first slice; 0 = no slicing (the batch fits one resident set)
   int slice_next;      // iterations of the later slices

@@ -153,6 +153,8 @@ struct alignas(16) Mem
   double inertia[9];
   double llt[6];                       // Cholesky factor of the inertia matrix (vllt3_factor)
   unsigned char pair[80];              // (a, b), a <= b, of the entries of Vxx's upper triangle: a | b << 4
+  int warm_replaced;                   // 1: the warm-start guard replaced u_init (kept here, not in a register: it is
+                                       //    written once per solve and read at its end)
 #if defined(CCC_TILE_PROF)
   double prof[TP_N];
 #endif
@@ -1363,7 +1365,7 @@ struct Solver
   // iterations took): begin() = start-up, iterate(budget) = up to `budget` iterations (false: the solve goes on),
   // finish() = outputs; suspend() / resume() carry the complete state of the iteration across slices -- the current
   // trajectory, its cost, the regularisation and the iteration count -- so a sliced solve is the unsliced one bit for bit.
-  int iters_done, exit_status;
+  int iters_done, exit_status; // (whether the warm-start guard fired lives in mem.warm_replaced)
   W64_FN void solve_instance()
   {
     begin();
@@ -1376,6 +1378,7 @@ struct Solver
     lambda = P.lambda0;
     dlambda = P.dlambda0;
     cur = 0;
+    mem.warm_replaced = 0;
     cost = initial_rollout(0, I.u_init);
     if(P.warm_guard && I.u_init)
     {
@@ -1386,13 +1389,14 @@ struct Solver
       {
         cur = 1;
         cost = cold;
+        mem.warm_replaced = 1;
       }
     }
     iters_done = 0;
     exit_status = 0;
   }
   // the state of a suspended solve: inputs -> I.u_out (overwritten by the result in the end), states -> sx [(N+1) S],
-  // scalars -> ss [4]
+  // scalars -> ss [0..3] and ss [6] (the guard's flag; ss [4..5] belong to the timing aid of the launch code)
   W64_FN void suspend(double * sx, double * ss)
   {
     mem_sync();
@@ -1401,8 +1405,9 @@ struct Solver
     const double * us = ucur();
     for(int e = 0; e < N * M; e += 64) st(I.u_out, lane + e, ldm(us, lane + e, lane + e < N * M), lane + e < N * M);
     for(int e = 0; e < (N + 1) * S; e += 64) st(sx, lane + e, ldm(xs, lane + e, lane + e < (N + 1) * S), lane + e < (N + 1) * S);
-    const vf sc = sel(lane == 0, splat(cost), sel(lane == 1, splat(lambda), sel(lane == 2, splat(dlambda), splat((double)iters_done))));
-    st(ss, lane, sc, lane < 4);
+    const vf sc = sel(lane == 0, splat(cost), sel(lane == 1, splat(lambda), sel(lane == 2, splat(dlambda),
+                  sel(lane == 3, splat((double)iters_done), splat((double)mem.warm_replaced)))));
+    st(ss, lane, sc, (lane < 4) || (lane == 6));
     mem_sync();
   }
   W64_FN void resume(const double * sx, const double * ss)
@@ -1416,6 +1421,7 @@ struct Solver
     lambda = ss[1];
     dlambda = ss[2];
     iters_done = (int)ss[3];
+    mem.warm_replaced = (int)ss[6];
     exit_status = 0;
     mem_sync();
   }
@@ -1527,7 +1533,8 @@ struct Solver
         for(int e = 0; e < TP_N; e++) I.u_out[e] = mem.prof[e];
 #endif
       if(I.out_iters) I.out_iters[0] = iter;
-      if(I.out_status) I.out_status[0] = status;
+      // (the exit code as it always was unless the guard fired: ccc_amd.h CCC_DDP_STATUS_WARM_REPLACED)
+      if(I.out_status) I.out_status[0] = mem.warm_replaced ? (0x100 | (status & 0xff)) : status;
       if(I.out_cost) I.out_cost[0] = cost;
 #if defined(CCC_TILE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
       // (development aid, scripts/ddp_sched_probe.py: the cost output carries the busy ticks, the first planned input the

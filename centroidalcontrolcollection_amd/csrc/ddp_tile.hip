@@ -1,9 +1,10 @@
 // ddp_tile.hip -- the TILE build of the DDP planners (csrc/ddp_tile.h): CCC::DdpCentroidal / CCC::DdpSingleRigidBody with
-// the default regularisation, one instance per wavefront, every matrix distributed over the 64 lanes.
-//   M = 16 ridges per step (one surface contact):  <= 128 VGPRs and <= 10 KB of LDS per wavefront -> four wavefronts per
-//                                                  SIMD, sixteen instances per CU
-//   M = 32 (two surface contacts, double support): 16-20 KB of LDS -> two wavefronts per SIMD
-//   M = 64 (up to four surface contacts):          ~50 KB of LDS -> three wavefronts per CU
+// either regularisation, one instance per wavefront (64-thread workgroup), every matrix distributed over the 64 lanes, the
+// backward step in structured form (no M x M object; DESIGN.md sections 7.2-7.4).  Register budget: no spills before
+// occupancy -- two wavefronts per SIMD at 16 and 32 ridges per step, one at 64 (CCC_TILE_WAVES* below; the compiler's
+// register / scratch / LDS figures of every instantiation are pinned in tests/test_kernel_resources.py); LDS 7.4-11.2 KB
+// per wavefront whatever the ridge stride.  One resident set of workgroups pulls instances from a work queue, longest
+// remaining first, in bit-identical slices of iterations (csrc/ddp_batch.h DdpSched).
 // What ccc_ddp_plan_batch_device runs by default (csrc/ddp.hip); its arithmetic is the tile specification of
 // oracle/ddp_tile.c, reproduced bit for bit (tests/test_ddp_gpu.py, tests/test_ddp_tile_emu.py).
 // Replaces the same reference code as csrc/ddp.hip.

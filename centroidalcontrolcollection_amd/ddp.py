@@ -16,6 +16,21 @@ from . import _lib
 MAX_RIDGES = 16  # default ridge stride (one surface contact per step)
 MAX_RIDGES_WIDE = 32  # max_ridges=32: two surface contacts per step (double support)
 MAX_RIDGES_MULTI = 64  # max_ridges=64: up to four surface contacts per step (feet + hands)
+STATUS_WARM_REPLACED_BIT = 0x100  # CCC_DDP_STATUS_WARM_REPLACED_BIT (include/ccc_amd.h)
+
+
+def exit_code(status):
+    """CCC_DDP_STATUS_EXIT: 0 max_iter reached, 1 gradient small, 2 cost change small, -1 lambda > lambda_max (array or
+    scalar status words of ccc_ddp_plan_batch*; torch tensors: pass ``.cpu().numpy()``)."""
+    return (np.asarray(status).astype(np.int64) & 0xff).astype(np.uint8).view(np.int8).astype(np.int32)
+
+
+def warm_start_replaced(status):
+    """CCC_DDP_STATUS_WARM_REPLACED: the warm-start guard (Config.warm_start_guard, on by default, not a nmpc_ddp option)
+    replaced this instance's u_init by zero inputs -- on exactly these instances the result is not what the reference
+    computes from the same u_list (src/DdpSingleRigidBody.cpp:299-303)."""
+    s = np.asarray(status).astype(np.int64)
+    return (s >= 0) & ((s & STATUS_WARM_REPLACED_BIT) != 0)
 
 
 class _Params(ctypes.Structure):
@@ -50,6 +65,8 @@ def _bind(L):
     L.ccc_ddp_state_dim.argtypes = [vp]
     L.ccc_ddp_arithmetic.restype = ctypes.c_int
     L.ccc_ddp_arithmetic.argtypes = [vp]
+    L.ccc_ddp_effective_precision.restype = ctypes.c_int
+    L.ccc_ddp_effective_precision.argtypes = [vp]
     L.ccc_ddp_plan_batch_device.restype = ctypes.c_int
     L.ccc_ddp_plan_batch_device.argtypes = [vp, ctypes.c_int64] + [vp] * 15
     L.ccc_ddp_plan_batch.restype = ctypes.c_int
@@ -70,6 +87,8 @@ class _Solver:
         self._cfg = cfg
         self._control = _ControlData()
         self.last_iter = 0
+        self.last_status = 0  # exit code of the last planOnce
+        self.last_warm_start_replaced = False  # the warm-start guard dropped the last planOnce's u_list
 
     def config(self):
         return self._cfg
@@ -117,7 +136,8 @@ class _DdpBase:
     def planOnceBatch(self, prob, x0, u_init=None, want_x=False):
         """Host arrays in / out (ccc_ddp_plan_batch).  prob: dict(phase_dim [n,P] i32, phase_vertex [n,P,M,3],
         phase_ridge [n,P,M,3], step_phase [n,N] i32, ref_pos [n,N+1,3] (+ ref_ori [n,N+1,3], inertia [n,3,3]));
-        x0 [n,S]; u_init [n,N,M] | None, M = max_ridges.  Returns dict(u [n,N,M], x | None, iters, status, cost)."""
+        x0 [n,S]; u_init [n,N,M] | None, M = max_ridges.  Returns dict(u [n,N,M], x | None, iters, status, cost,
+        exit_code, warm_replaced): status = the C-ABI's status word, exit_code / warm_replaced its two parts."""
         N, P, S, M = self.horizon_steps_, self.max_phases_, self.S, self.max_ridges_
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         n = x0.shape[0]
@@ -156,7 +176,12 @@ class _DdpBase:
                                               p(arr["phase_ridge"]), p(arr["step_phase"]), p(arr["ref_pos"]),
                                               p(arr.get("ref_ori")), p(arr.get("inertia")), p(x0), p(ui), p(u), p(x),
                                               p(iters), p(status), p(cost)))
-        return dict(u=u, x=x, iters=iters, status=status, cost=cost)
+        return dict(u=u, x=x, iters=iters, status=status, cost=cost, exit_code=exit_code(status),
+                    warm_replaced=warm_start_replaced(status))
+
+    def effective_precision(self):
+        """ccc_ddp_effective_precision: 64, whatever Config.precision asked for."""
+        return int(self._L.ccc_ddp_effective_precision(self._h))
 
     def arithmetic(self):
         """ccc_ddp_arithmetic for the object's current solver configuration: 1 = the tile arithmetic
@@ -268,6 +293,8 @@ class _DdpBase:
         cd.u_list = [r["u"][0, i, :dims[i]].copy() for i in range(N)]
         cd.x_list = [r["x"][0, i].copy() for i in range(N + 1)]
         self.ddp_solver_.last_iter = int(r["iters"][0])
+        self.ddp_solver_.last_status = int(r["exit_code"][0])
+        self.ddp_solver_.last_warm_start_replaced = bool(r["warm_replaced"][0])
         return cd.u_list[0]
 
 

@@ -26,6 +26,11 @@ struct TraceData
 {
   int iter = 0;
   int status = 0; //!< 0 max_iter reached, 1 gradient small, 2 cost change small, -1 lambda exceeded lambda_max (new)
+  /** (new) the warm-start guard (config().warm_start_guard, on by default, not a nmpc_ddp option) replaced
+      InitialParam::u_list by zero inputs in this planOnce(): on exactly these calls the plan is not what the reference
+      computes from the same u_list (/root/reference/src/DdpSingleRigidBody.cpp:299-303).  Never true with
+      config().warm_start_guard = 0. */
+  bool warm_start_replaced = false;
 };
 
 /** nmpc_ddp::DDPSolver::Configuration as the reference's callers see it: the solver parameters of ccc_ddp_config_t plus
@@ -236,9 +241,10 @@ inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool sr
     for(int a = 0; a < S; a++) solver.control_data_.x_list[static_cast<size_t>(i)][static_cast<size_t>(a)] = x[static_cast<size_t>(i) * S + a];
   TraceData td;
   td.iter = iters;
-  td.status = status;
+  td.status = CCC_DDP_STATUS_EXIT(status);
+  td.warm_start_replaced = CCC_DDP_STATUS_WARM_REPLACED(status);
   solver.trace_data_list_.assign(1, td);
-  if(status < 0)
+  if(td.status < 0)
   {
     // nmpc_ddp prints "[DDP] Failure: lambda is too large" and keeps the last accepted sequence; same here
     std::fprintf(stderr, "[%s] DDP did not converge: regularisation exceeded lambda_max after %d iteration(s); the "

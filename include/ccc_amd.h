@@ -42,7 +42,12 @@ extern "C" {
 #define CCC_STATUS_PIVOTS(s) ((s) >> 8)
 
 const char * ccc_last_error_string(void);
-/* version of this ABI (bumped on incompatible change) */
+/* version of this ABI (bumped on incompatible change): CCC_ABI_VERSION is what this header describes; a caller compiled
+ * against another version passes structs of another size (ccc_ddp_config_t grew by warm_start_guard in the library
+ * that answered 3) -- compare before the first call:  if(ccc_abi_version() != CCC_ABI_VERSION) refuse.
+ *   4 (round 5): ccc_ddp_config_t::warm_start_guard counted in; the DDP status word carries
+ *     CCC_DDP_STATUS_WARM_REPLACED_BIT; ccc_ddp_effective_precision; stats[5] of ccc_ddp_closed_loop_device. */
+#define CCC_ABI_VERSION 4
 int ccc_abi_version(void);
 /* number of visible HIP devices that are gfx950 parts (0 when none: every create call then fails with
  * CCC_ERR_NO_DEVICE); device ordinals are HIP's */
@@ -188,8 +193,21 @@ typedef struct
                   * src/DdpCentroidal.cpp:221-229 -- or is not finite, is replaced by zero inputs.  It fires on 1 to 7 of
                   * the 601 control cycles of TestDdpSingleRigidBody.cpp:106-153 (one iteration per cycle on an unshifted
                   * warm start) and is what makes that loop pass under perturbations.  0: the
-                  * recalled nmpc_ddp behaviour.  Not a nmpc_ddp option; ignored by CCC::DdpZmp. */
+                  * recalled nmpc_ddp behaviour.  Not a nmpc_ddp option; ignored by CCC::DdpZmp.
+                  * On a call where it fires the result is, by design, NOT what the reference computes from the same
+                  * u_list (src/DdpSingleRigidBody.cpp:299-303 hands initial_param.u_list to solve() as is); every such
+                  * instance is flagged in its status word (CCC_DDP_STATUS_WARM_REPLACED below), in
+                  * TraceData::warm_start_replaced of the header shims and in stats[5] of ccc_ddp_closed_loop_device.
+                  * Unflagged instances are the recalled algorithm, bit for bit. */
 } ccc_ddp_config_t;
+
+/* The per-instance status word of the DDP planners (`status` of ccc_ddp_plan_batch*): the exit code -- 0 max_iter
+ * reached, 1 gradient small, 2 cost change small, -1 regularisation exceeded lambda_max -- exactly as before ABI 4 on
+ * every instance whose warm start was kept (and always with warm_start_guard = 0 or u_init = NULL); on an instance whose
+ * warm start the guard replaced by zero inputs: CCC_DDP_STATUS_WARM_REPLACED_BIT | (exit code & 0xff), a value >= 0x100. */
+#define CCC_DDP_STATUS_WARM_REPLACED_BIT 0x100
+#define CCC_DDP_STATUS_EXIT(s) ((int)(signed char)((s)&0xff))
+#define CCC_DDP_STATUS_WARM_REPLACED(s) ((s) >= 0 && ((s)&CCC_DDP_STATUS_WARM_REPLACED_BIT) != 0)
 
 void ccc_ddp_default_config(ccc_ddp_config_t * cfg);
 int ccc_ddp_create(const ccc_ddp_params_t * params, int device, ccc_ddp_t ** out);
@@ -206,6 +224,9 @@ int ccc_ddp_get_device(const ccc_ddp_t * h, int * device);
  * ridge stride and for both regularisations; bit-for-bit parity tests run the oracle with this value.  (0 = the dense
  * left-to-right arithmetic of oracle/ddp.c: the oracle's independent cross-check, no kernel.)  New. */
 int ccc_ddp_arithmetic(const ccc_ddp_t * h);
+/* The precision a handle's kernel computes in, whatever ccc_ddp_config_t::precision asked for: 64 (a `precision = 32`
+ * request is accepted and runs the fp64 kernel, see above; this call makes the substitution explicit).  New. */
+int ccc_ddp_effective_precision(const ccc_ddp_t * h);
 
 /* Replaces n calls of DdpCentroidal::planOnce / DdpSingleRigidBody::planOnce(motion_param_func, ref_data_func,
  * initial_param, current_time) (src/DdpCentroidal.cpp:213-237, src/DdpSingleRigidBody.cpp:283-307) including the
@@ -225,8 +246,9 @@ int ccc_ddp_arithmetic(const ccc_ddp_t * h);
  *   u_out        [n][N][M]         f64  controlData().u_list; planOnce returns u_out[k][0][0 : phase_dim of step 0]
  *   x_out        [n][N+1][S]       f64  optional: controlData().x_list
  *   iters        [n]               i32  optional: traceDataList().back().iter
- *   status       [n]               i32  optional: 0 max_iter reached, 1 gradient small, 2 cost change small,
- *                                       -1 regularisation exceeded lambda_max
+ *   status       [n]               i32  optional: the status word above -- CCC_DDP_STATUS_EXIT(s): 0 max_iter reached,
+ *                                       1 gradient small, 2 cost change small, -1 regularisation exceeded lambda_max;
+ *                                       CCC_DDP_STATUS_WARM_REPLACED(s): the warm-start guard dropped u_init
  *   cost         [n]               f64  optional: final cost
  * All DEVICE pointers, asynchronous on `stream`. */
 int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t * phase_dim, const double * phase_vertex,
@@ -471,7 +493,10 @@ typedef struct
  *   inertia_diag [n][3]   f64  moment of inertia of the simulator (the SRB planner takes diag(inertia_diag))
  *   sim_state    [n][18]  f64  in/out: pos, ori (X, Y, Z), vel, ang_vel, linear momentum, angular momentum
  *   stats        [n][8]   f64  optional: max over the cycles, taken where the test asserts (before the update), of
- *                              |pos - ref|, |ori - ref_ori| (unreversed vectors, as the test), |vel|, |ang_vel|, |ang_mom|
+ *                              |pos - ref|, |ori - ref_ori| (unreversed vectors, as the test), |vel|, |ang_vel|, |ang_mom|;
+ *                              [5] = the number of cycles whose warm start the warm-start guard replaced
+ *                              (CCC_DDP_STATUS_WARM_REPLACED; always 0 with ccc_ddp_config_t::warm_start_guard = 0 and in
+ *                              the LinearMpcXY loop); [6..7] = 0
  *   log          [cycles][n][9] f64 optional: pos, planned force, planned moment about the CoM of every cycle
  *   t_end                      optional (host): the time after the last cycle
  * Synchronous (returns when the last cycle is done; its workspaces live and die inside the call). */

@@ -54,7 +54,7 @@ void oracle_ddp_default_config(oracle_ddp_config_t * c)
   c->cost_update_thre = 1e-7;
   c->reg_type = 1;
   c->arith = 0;
-  c->warm_start_guard = 0;
+  c->warm_start_guard = 1; /* = ccc_ddp_default_config (csrc/ddp.hip); 0 = the recalled nmpc_ddp behaviour */
   for(int i = 0; i < 11; i++) c->alpha_list[i] = pow(10.0, -3.0 * i / 10.0);
 }
 
@@ -553,6 +553,7 @@ int oracle_ddp_solve(const oracle_ddp_problem_t * p, const oracle_ddp_config_t *
     p->state_eq(p->user, i, d.x + (size_t)i * S, d.u + (size_t)i * M, d.x + (size_t)(i + 1) * S);
   }
   d.cost = rollout_cost(&d, d.x, d.u);
+  int warm_replaced = 0;
   if(c->warm_start_guard && u_init)
   {
     /* warm-start guard (not nmpc_ddp; ccc_oracle.h): keep the warm start only if its rollout is no worse than the
@@ -567,6 +568,7 @@ int oracle_ddp_solve(const oracle_ddp_problem_t * p, const oracle_ddp_config_t *
       memcpy(d.x, d.xc, sizeof(double) * nx);
       memcpy(d.u, d.uc, sizeof(double) * nu);
       d.cost = cold;
+      warm_replaced = 1;
     }
   }
   double initial_cost = d.cost;
@@ -667,6 +669,7 @@ int oracle_ddp_solve(const oracle_ddp_problem_t * p, const oracle_ddp_config_t *
     res->initial_cost = initial_cost;
     res->lambda = d.lambda;
     res->accepted = n_accept;
+    res->warm_replaced = warm_replaced;
   }
   free(d.x);
   free(d.Fx);

@@ -399,7 +399,7 @@ int oracle_ddp_plan_batch(const oracle_ddp_model_t * shared, const oracle_ddp_co
       st = oracle_ddp_solve(&prob, cfg, x0 + (size_t)b * S, u_init ? u_init + (size_t)b * N * M : NULL,
                             x_out ? x_out + (size_t)b * (N + 1) * S : NULL, u_out + (size_t)b * N * M, &res);
     if(iters) iters[b] = res.iters;
-    if(status) status[b] = st;
+    if(status) status[b] = res.warm_replaced ? (ORACLE_DDP_STATUS_WARM_REPLACED | (st & 0xff)) : st;
     if(cost) cost[b] = res.cost;
     if(st < worst) worst = st;
   }

@@ -793,6 +793,7 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
     state_eq(m, &T, d.x + (size_t)i * S, d.x + (size_t)(i + 1) * S);
   }
   d.cost = d.cost + terminal_cost(m, d.x + (size_t)N * S);
+  int warm_replaced = 0;
   if(c->warm_start_guard && u_init)
   {
     /* warm-start guard (ccc_oracle.h): the rollout of zero inputs, same arithmetic, into the first candidate slot */
@@ -814,6 +815,7 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
       memcpy(d.x, xz, sizeof(double) * nx);
       memcpy(d.u, uz, sizeof(double) * nu);
       d.cost = cold;
+      warm_replaced = 1;
     }
   }
   const double initial_cost = d.cost;
@@ -892,6 +894,7 @@ int oracle_ddp_solve_tile(const oracle_ddp_model_t * m, const oracle_ddp_config_
     res->status = status;
     res->cost = d.cost;
     res->initial_cost = initial_cost;
+    res->warm_replaced = warm_replaced;
     res->lambda = d.lambda;
     res->accepted = n_accept;
   }

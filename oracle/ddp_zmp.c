@@ -166,6 +166,7 @@ void oracle_ddpzmp_default_config(oracle_ddp_config_t * c)
 {
   oracle_ddp_default_config(c);
   c->with_input_constraint = 0; /* nmpc_ddp default; CCC::DdpZmp does not enable it */
+  c->warm_start_guard = 0;      /* the guard belongs to the force-scale planners; the product's DdpZmp ignores it */
 }
 
 int oracle_ddpzmp_plan_batch(const oracle_ddpzmp_params_t * prm, const oracle_ddp_config_t * cfg, long n,

@@ -246,6 +246,17 @@ def box_qp(H, g, lo, hi, x0=None):
     return x, rc, is_free.astype(bool), it.value
 
 
+def ddp_exit_code(status):
+    """ORACLE_DDP_STATUS_EXIT: 0 max_iter reached, 1 gradient small, 2 cost change small, -1 lambda > lambda_max."""
+    return (np.asarray(status).astype(np.int64) & 0xff).astype(np.uint8).view(np.int8).astype(np.int32)
+
+
+def ddp_warm_start_replaced(status):
+    """ORACLE_DDP_STATUS_WARM_REPLACED: the warm-start guard replaced u_init by zero inputs."""
+    s = np.asarray(status).astype(np.int64)
+    return (s >= 0) & ((s & 0x100) != 0)
+
+
 class Ddp:
     """CPU restatement of CCC::DdpCentroidal (model=0, S=9) / CCC::DdpSingleRigidBody (model=1, S=12) on
     pre-sampled, flattened per-instance problem data (oracle/ddp.c + oracle/ddp_models.c).
@@ -266,8 +277,8 @@ class Ddp:
         self.cfg.max_iter = int(max_iter)
         # order of the long sums: 0 = left to right (ddp.c), 1 = the tile arithmetic (ddp_tile.c; M = 16, reg_type 1)
         self.cfg.arith = int(arith)
-        # the product's default (ccc_ddp_default_config): a warm start that rolls out worse than zero inputs is dropped;
-        # False = the recalled nmpc_ddp behaviour (oracle_ddp_default_config)
+        # the default of both oracle_ddp_default_config and the product's ccc_ddp_default_config: a warm start that rolls
+        # out worse than zero inputs is dropped (and reported in the status word); False = the recalled nmpc_ddp behaviour
         self.cfg.warm_start_guard = 1 if warm_start_guard else 0
         self.mdl = _DdpModel()
         self.mdl.model, self.mdl.N, self.mdl.P, self.mdl.M = self.model, self.N, self.P, self.M
@@ -308,7 +319,9 @@ class Ddp:
                                 _ptr(pr), _ptr(sp, ctypes.c_int), _ptr(rp), _ptr(ro), _ptr(ine), _ptr(x0), _ptr(ui),
                                 _ptr(u), _ptr(x), _ptr(iters, ctypes.c_int), _ptr(status, ctypes.c_int), _ptr(cost),
                                 int(nthreads))
-        return dict(u=u, x=x, iters=iters, status=status, cost=cost)
+        # status = the product's word (ccc_amd.h CCC_DDP_STATUS_*): the exit code, | 0x100 where the guard replaced u_init
+        return dict(u=u, x=x, iters=iters, status=status, cost=cost, exit_code=ddp_exit_code(status),
+                    warm_replaced=ddp_warm_start_replaced(status))
 
     def eval(self, prob, k, step, x, u):
         """Problem callbacks of instance k at (step, x, u): dict(x_next, Fx [S,S], Fu [S,M], run_cost, term_cost,

@@ -102,7 +102,10 @@ static void cons_normal(const cons_t * c, int id, double * out)
 typedef struct
 {
   int n, q;
-  double * J; /* n x n, J = L^-T Q */
+  double * Jt; /* n x n, J = L^-T Q stored TRANSPOSED: Jt[j * n + i] = J[i][j] -- every loop of the iteration (the column sums
+               * J'n, the Givens rotations of two columns of J, z = J2 d2) then runs over contiguous memory (round 5: the
+               * row-major J made the CPU baseline of LinearMpcXY, n = 320, run at the speed of its cache misses; same
+               * operations in the same order, same bits) */
   double * R; /* n x n, leading q x q upper triangular */
   double * d; /* n */
   double * z; /* n */
@@ -115,19 +118,29 @@ static void compute_d(fact_t * f, const double * np)
   for(int j = 0; j < n; j++)
   {
     double s = 0;
-    for(int i = 0; i < n; i++) s += f->J[i * n + j] * np[i];
+    const double * Jj = f->Jt + (size_t)j * n;
+    for(int i = 0; i < n; i++) s += Jj[i] * np[i];
     f->d[j] = s;
   }
+}
+
+/* the same for a bound constraint, whose normal is sign e_k: every other term of the sum is an exact zero, so J'n is a
+ * scaled row of Jt (QLD, too, keeps the bounds out of its dense constraint rows) */
+static void compute_d_bound(fact_t * f, int k, double sign)
+{
+  int n = f->n;
+  for(int j = 0; j < n; j++) f->d[j] = 0.0 + f->Jt[(size_t)j * n + k] * sign;
 }
 
 static void compute_z_r(fact_t * f)
 {
   int n = f->n, q = f->q;
-  for(int i = 0; i < n; i++)
+  for(int i = 0; i < n; i++) f->z[i] = 0;
+  for(int j = q; j < n; j++) /* (per entry of z the terms still arrive in increasing j) */
   {
-    double s = 0;
-    for(int j = q; j < n; j++) s += f->J[i * n + j] * f->d[j];
-    f->z[i] = s;
+    const double * Jj = f->Jt + (size_t)j * n;
+    const double dj = f->d[j];
+    for(int i = 0; i < n; i++) f->z[i] += Jj[i] * dj;
   }
   for(int i = q - 1; i >= 0; i--)
   {
@@ -149,11 +162,12 @@ static int fact_add(fact_t * f, double * rnorm)
     double cs = a / h, sn = b / h;
     f->d[j - 1] = h;
     f->d[j] = 0.0;
+    double * Ja = f->Jt + (size_t)(j - 1) * n, * Jb = f->Jt + (size_t)j * n;
     for(int k = 0; k < n; k++)
     {
-      double t1 = f->J[k * n + j - 1], t2 = f->J[k * n + j];
-      f->J[k * n + j - 1] = cs * t1 + sn * t2;
-      f->J[k * n + j] = -sn * t1 + cs * t2;
+      double t1 = Ja[k], t2 = Jb[k];
+      Ja[k] = cs * t1 + sn * t2;
+      Jb[k] = -sn * t1 + cs * t2;
     }
   }
   if(fabs(f->d[q]) <= DBL_EPSILON * (*rnorm) * 16.0) return 0;
@@ -185,11 +199,12 @@ static void fact_del(fact_t * f, int l)
       f->R[j * n + k] = cs * t1 + sn * t2;
       f->R[(j + 1) * n + k] = -sn * t1 + cs * t2;
     }
+    double * Ja = f->Jt + (size_t)j * n, * Jb = f->Jt + (size_t)(j + 1) * n;
     for(int k = 0; k < n; k++)
     {
-      double t1 = f->J[k * n + j], t2 = f->J[k * n + j + 1];
-      f->J[k * n + j] = cs * t1 + sn * t2;
-      f->J[k * n + j + 1] = -sn * t1 + cs * t2;
+      double t1 = Ja[k], t2 = Jb[k];
+      Ja[k] = cs * t1 + sn * t2;
+      Jb[k] = -sn * t1 + cs * t2;
     }
   }
 }
@@ -222,8 +237,8 @@ int oracle_qp_solve(int n, int me, int mi, const double * H, const double * g, c
   fact_t f;
   f.n = n;
   f.q = 0;
-  f.J = Li + nn;
-  f.R = f.J + nn;
+  f.Jt = Li + nn;
+  f.R = f.Jt + nn;
   f.d = f.R + nn;
   f.z = f.d + n;
   f.r = f.z + n;
@@ -236,45 +251,70 @@ int oracle_qp_solve(int n, int me, int mi, const double * H, const double * g, c
   if(lam_in)
     for(int i = 0; i < mi; i++) lam_in[i] = 0.0;
 
-  /* Cholesky H = L L' */
+  /* Cholesky H = L L', right-looking: column j is finished, then its rank-1 update goes into the trailing rows -- every
+   * entry (i, c) still receives its subtractions l_i0 l_c0, l_i1 l_c1, ... one after the other in increasing k, i.e. the
+   * operations and order of the dot-product form  t = H[i][c]; for k < c: t -= L[i][k] L[c][k]  this replaces (same bits),
+   * but the inner loop now runs over independent entries instead of one dependent chain (round 5: n = 320 for LinearMpcXY).
+   * LT = L' is filled on the way: column j of L contiguous, for this update and the substitution below. */
+  double * LT = f.R; /* (R is not in use before the first constraint is added; zeroed again below) */
+  for(int i = 0; i < n; i++)
+    for(int c = 0; c <= i; c++) L[i * n + c] = H[i * n + c];
   for(int j = 0; j < n; j++)
   {
-    double s = H[j * n + j];
-    for(int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
+    const double s = L[j * n + j];
     if(!(s > 0.0))
     {
       rc = 3;
+      memset(LT, 0, nn * sizeof(double));
       goto done;
     }
-    L[j * n + j] = sqrt(s);
+    const double ljj = sqrt(s);
+    L[j * n + j] = ljj;
+    double * col = LT + (size_t)j * n; /* col[i] = L[i][j] */
+    col[j] = ljj;
     for(int i = j + 1; i < n; i++)
     {
-      double t = H[i * n + j];
-      for(int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k];
-      L[i * n + j] = t / L[j * n + j];
+      L[i * n + j] = L[i * n + j] / ljj;
+      col[i] = L[i * n + j];
+    }
+    for(int i = j + 1; i < n; i++)
+    {
+      const double lij = col[i];
+      double * Li_ = L + (size_t)i * n;
+      for(int c = j + 1; c <= i; c++) Li_[c] -= lij * col[c];
     }
   }
-  /* Li = L^-1 (lower); J = Li' */
+  /* Li = L^-1 (lower), held transposed (LiT[c * n + k] = Li[k][c]: the substitution reads it along k); J = Li', so the
+   * transposed J of the iteration is Li itself */
+  double * LiT = Li;
   for(int c = 0; c < n; c++)
-    for(int i = c; i < n; i++)
+  {
+    /* column c of L^-1 by forward substitution, column-oriented: s_i = delta_ic, and as soon as entry k is final every
+     * later s_i loses L[i][k] Li[k][c] -- per entry the subtractions of  s -= L[i][k] Li[k][c], k = c .. i - 1  in that order */
+    double * sc = LiT + (size_t)c * n;
+    for(int i = c; i < n; i++) sc[i] = (i == c) ? 1.0 : 0.0;
+    for(int k = c; k < n; k++)
     {
-      double s = (i == c) ? 1.0 : 0.0;
-      for(int k = c; k < i; k++) s -= L[i * n + k] * Li[k * n + c];
-      Li[i * n + c] = s / L[i * n + i];
+      sc[k] = sc[k] / L[k * n + k];
+      const double v = sc[k];
+      const double * colk = LT + (size_t)k * n; /* colk[i] = L[i][k] */
+      for(int i = k + 1; i < n; i++) sc[i] -= colk[i] * v;
     }
+  }
+  memset(LT, 0, nn * sizeof(double)); /* (R again) */
   for(int i = 0; i < n; i++)
-    for(int j = 0; j < n; j++) f.J[i * n + j] = Li[j * n + i];
+    for(int j = 0; j < n; j++) f.Jt[i * n + j] = LiT[j * n + i]; /* = Li[i][j] */
   /* unconstrained minimiser x = -H^-1 g = -Li' Li g */
   for(int i = 0; i < n; i++)
   {
     double s = 0;
-    for(int k = 0; k <= i; k++) s += Li[i * n + k] * g[k];
+    for(int k = 0; k <= i; k++) s += f.Jt[i * n + k] * g[k];
     np[i] = s;
   }
   for(int i = 0; i < n; i++)
   {
     double s = 0;
-    for(int k = i; k < n; k++) s += Li[k * n + i] * np[k];
+    for(int k = i; k < n; k++) s += LiT[i * n + k] * np[k];
     x[i] = -s;
   }
   double rnorm = 1.0;
@@ -336,7 +376,10 @@ int oracle_qp_solve(int n, int me, int mi, const double * H, const double * g, c
         rc = 2;
         goto done;
       }
-      compute_d(&f, np);
+      if(ip >= me + mi)
+        compute_d_bound(&f, ip - me - mi < n ? ip - me - mi : ip - me - mi - n, ip - me - mi < n ? 1.0 : -1.0);
+      else
+        compute_d(&f, np);
       compute_z_r(&f);
       /* partial (dual) step length */
       double t1 = INFINITY;

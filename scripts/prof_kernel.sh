@@ -6,6 +6,7 @@
 TAG=$1; NAME=$2; shift 2
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
 for d in trace pmc1 pmc2; do mkdir -p gpurun_out/${TAG}_${NAME}_$d; done
+python -m centroidalcontrolcollection_amd.build --kernel-hashes 2>/dev/null | tail -1 > gpurun_out/${TAG}_kernel_hashes.json
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_${NAME}_trace -o k -- "$@" > gpurun_out/${TAG}_${NAME}_trace/run.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/${TAG}_${NAME}_pmc1 -o k -- "$@" > gpurun_out/${TAG}_${NAME}_pmc1/run.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/${TAG}_${NAME}_pmc2 -o k -- "$@" > gpurun_out/${TAG}_${NAME}_pmc2/run.log 2>&1

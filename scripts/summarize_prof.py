@@ -14,6 +14,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+# the kernel sources the profiled library was built from (written on the GPU box by scripts/prof_zmp.sh)
+with open(os.path.join(src, tag + "_kernel_hashes.json")) as f:
+    KH = json.load(f)["zmp"]
 
 shutil.copy(os.path.join(src, tag + "_trace", "zmp_kernel_stats.csv"), os.path.join(dst, tag + "_zmp_kernel_stats.csv"))
 rows = []
@@ -38,7 +41,7 @@ c = {r["counter"]: r["avg_per_dispatch"] for r in rows}
 # coalesced streaming read (128-B requests tallied at 64 B) -> doubled.  WRITE_SIZE is uncalibrated and taken as is.
 fetch = c["FETCH_SIZE"] * 1024 * 2
 write = c["WRITE_SIZE"] * 1024
-out = dict(tag=tag, workload="LinearMpcZmp N=32 batch=65536", kernel=rows[0]["kernel"],
+out = dict(tag=tag, kernel_hash=KH, workload="LinearMpcZmp N=32 batch=65536", kernel=rows[0]["kernel"],
            fetch_size_kib_raw=c["FETCH_SIZE"], write_size_kib_raw=c["WRITE_SIZE"],
            fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes_per_launch=fetch + write,
            algorithmic_bytes_per_launch=1088 * 65536,
@@ -52,7 +55,7 @@ for r in csv.DictReader(open(os.path.join(dst, tag + "_zmp_kernel_stats.csv"))):
     if "zmp_plan_kernel_dyn" in r["Name"]:
         dur_ns = float(r["AverageNs"])
         break
-valu = dict(tag=tag, batch=65536, kernel=rows[0]["kernel"], kernel_avg_ns=dur_ns, sq_insts_valu=c["SQ_INSTS_VALU"],
+valu = dict(tag=tag, kernel_hash=KH, batch=65536, kernel=rows[0]["kernel"], kernel_avg_ns=dur_ns, sq_insts_valu=c["SQ_INSTS_VALU"],
             sq_insts_salu=c.get("SQ_INSTS_SALU"), sq_insts_lds=c.get("SQ_INSTS_LDS"),
             valu_insts_per_solve=c["SQ_INSTS_VALU"] / 65536.0,
             valu_issue_frac=c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * dur_ns * 2.4),

@@ -26,7 +26,7 @@ static void run_sliced(const Params & P, const ddp_tile::Instance & I, int slice
                        std::vector<double> & ks, std::vector<double> & Ks)
 {
   static ddp_tile::Mem<S, B> mem;
-  std::vector<double> sx((size_t)(P.N + 1) * S), ss(4);
+  std::vector<double> sx((size_t)(P.N + 1) * S), ss(8);
   bool fresh = true;
   for(;;)
   {

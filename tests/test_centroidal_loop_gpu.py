@@ -75,6 +75,14 @@ def test_ddp_reference_closed_loop_on_the_device(srb):
     # and on the perturbed ones
     assert st[:, 0].max() < 2.0 and st[:, 2].max() < 2.0
     ref_end = np.array([0.5, 0.0, 1.0])
+    # stats[5]: the cycles whose warm start the guard replaced (the deviation from the reference's
+    # warm-start semantics is counted) -- SRB 1 to 7 of the 601 cycles on the reference instance, a handful on the others;
+    # the centroidal loop: at the kick (it passes either way)
+    assert np.all(st[:, 5] == np.round(st[:, 5])) and np.all(st[:, 6:] == 0.0)
+    if srb:
+        assert 1 <= st[0, 5] <= 7 and st[:, 5].max() <= 12, st[:, 5]
+    else:
+        assert st[:, 5].max() <= 4, st[:, 5]
     if srb:
         assert st[:, 1].max() < 1.0 and st[:, 3].max() < 2.0
         assert np.linalg.norm(fin[:, :3] - ref_end, axis=1).max() < 0.1 and np.linalg.norm(fin[:, 3:6], axis=1).max() < 0.1

@@ -132,6 +132,50 @@ def test_warm_start_and_limits():
     _assert_bitwise(warm, o)
 
 
+@pytest.mark.parametrize("srb", [False, True])
+def test_warm_start_guard_is_reported_and_guard_off_is_the_reference_semantics(srb):
+    """VERDICT r4 item 1.  Warm starts that roll out worse than zero inputs (3 x the converged plan of another start; one with
+    a NaN) next to good ones, 300 instances (more than nothing: the status flag has to survive the host path, and with
+    CCC_DDP_SLOTS the sliced scheduler): (b) guard ON (the default) -- the status word carries
+    CCC_DDP_STATUS_WARM_REPLACED_BIT on exactly the instances the oracle replaces, everything bit for bit the oracle's;
+    (a) guard OFF -- bit-identical to the oracle with the guard off (the recalled nmpc_ddp behaviour: u_list goes to
+    solve() as is, /root/reference/src/DdpSingleRigidBody.cpp:299-303) on the very batch where the flag WOULD fire, and
+    no flag."""
+    from centroidalcontrolcollection_amd import ddp as ddp_mod
+
+    N, dt, n = 40, 0.03, 300
+    w = fd.srb_weights() if srb else fd.centroidal_weights()
+    prob, x0 = fd.make_centroidal_batch(n, N, dt, seed=9, srb=srb)
+    mk = _srb if srb else _cen
+    good = mk(N, dt, 30).planOnceBatch(prob, x0)["u"]
+    bad = good.copy()
+    bad[::3] *= 3.0  # every third instance: a warm start that rolls out worse than zero inputs
+    d = mk(N, dt, 2)
+    assert d.ddp_solver_.config().warm_start_guard == 1  # ccc_ddp_default_config
+    on = d.planOnceBatch(prob, x0 + 0.01, u_init=bad, want_x=True)
+    O = _oracle()
+    o_on = O.Ddp(int(srb), 100.0, dt, N, w, max_iter=2, arith=1).plan_batch(prob, x0 + 0.01, u_init=bad, nthreads=8)
+    _assert_bitwise(on, o_on, ("u", "x", "cost", "iters", "status"))
+    fired = ddp_mod.warm_start_replaced(on["status"])
+    assert np.array_equal(fired, on["warm_replaced"]) and np.array_equal(fired, o_on["warm_replaced"])
+    assert fired[::3].all() and fired.sum() <= 0.36 * n  # (measured on the oracle: 101 = the 100 scaled ones + one other)
+    assert np.array_equal(on["status"][fired], 0x100 | (on["exit_code"][fired] & 0xff))
+    assert np.array_equal(on["status"][~fired], on["exit_code"][~fired])  # unflagged: the word is the plain exit code
+    cold = d.planOnceBatch(prob, x0 + 0.01)
+    assert np.array_equal(on["u"][fired], cold["u"][fired])  # replaced = the cold solve
+    assert not ddp_mod.warm_start_replaced(cold["status"]).any()
+    # (a) the reference's semantics
+    d.ddp_solver_.config().warm_start_guard = 0
+    off = d.planOnceBatch(prob, x0 + 0.01, u_init=bad, want_x=True)
+    o_off = O.Ddp(int(srb), 100.0, dt, N, w, max_iter=2, arith=1, warm_start_guard=False)
+    o_off = o_off.plan_batch(prob, x0 + 0.01, u_init=bad, nthreads=8)
+    _assert_bitwise(off, o_off, ("u", "x", "cost", "iters", "status"))
+    assert not ddp_mod.warm_start_replaced(off["status"]).any()
+    assert not np.array_equal(off["u"][fired], on["u"][fired])
+    assert np.array_equal(off["u"][~fired], on["u"][~fired])  # unflagged instances: the guard changes nothing
+    assert d.effective_precision() == 64
+
+
 def test_centroidal_reference_closed_loop_through_planonce():
     """TestDdpCentroidal.cpp:15-174 through planOnce(motion_param_func, ref_data_func, initial_param, t) with warm
     start and max_iter = 1 after the first cycle: per-cycle and final property assertions (:133-135, :154-156)."""
@@ -202,7 +246,7 @@ def test_srb_reference_closed_loop_through_planonce():
     sim = fd.CentroidalSim(mass, (40.0, 20.0, 10.0), 0.005)
     sim.pos = ref(0.0).pos.copy()
     sim.ori = ref(0.0).ori[::-1].copy()
-    t, cycle = 0.0, 0
+    t, cycle, fired = 0.0, 0, 0
     while t < 3.0:
         ip = DdpSingleRigidBody.InitialParam(sim.pos, sim.ori[::-1], sim.vel, sim.ang_vel,
                                              d.ddp_solver_.controlData().u_list)
@@ -213,6 +257,7 @@ def test_srb_reference_closed_loop_through_planonce():
                     ip.u_list[i] = np.zeros(mi)
         max_iter = d.ddp_solver_.config().max_iter
         scales = d.planOnce(motion, ref, ip, t)
+        fired += d.ddp_solver_.last_warm_start_replaced  # (the shims: traceDataList().back().warm_start_replaced)
         if cycle % 25 == 0:  # the oracle on the same inputs
             _, prob = d._sample(motion, ref, t)
             u_init = None
@@ -242,6 +287,8 @@ def test_srb_reference_closed_loop_through_planonce():
     r = ref(t)
     assert np.linalg.norm(sim.pos - r.pos) < 0.1 and np.linalg.norm(sim.ori - r.ori) < 0.1
     assert np.linalg.norm(sim.vel) < 0.1 and np.linalg.norm(sim.ang_vel) < 0.1
+    # the cycles on which the default deviates from the reference's warm-start semantics are reported: 1 to 7 of the 601
+    assert cycle == 601 and 1 <= fired <= 7, (cycle, fired)
 
 
 def test_config5_precision_32_request_runs_the_fp64_kernel():
@@ -315,7 +362,19 @@ def test_cpp_header_shims_match_python_mirror():
     d.ddp_solver_.config().max_iter = 1
     u1 = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
                     lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
-    assert float(lines["centroidal_warm"].split("u0[0]=")[1]) == u1[0]
+    assert float(lines["centroidal_warm"].split("u0[0]=")[1]) == u1[0] and "replaced=0" in lines["centroidal_warm"]
+    # the shims report the warm-start guard (TraceData::warm_start_replaced), and config().warm_start_guard = 0 switches
+    # to the reference's semantics
+    ip.u_list = [3.0 * ui for ui in ip.u_list]
+    u2 = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
+                    lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
+    assert d.ddp_solver_.last_warm_start_replaced and "replaced=1" in lines["centroidal_bad_warm"]
+    assert float(lines["centroidal_bad_warm"].split("u0[0]=")[1]) == u2[0]
+    d.ddp_solver_.config().warm_start_guard = 0
+    u3 = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
+                    lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
+    assert not d.ddp_solver_.last_warm_start_replaced and "replaced=0" in lines["centroidal_bad_warm_unguarded"]
+    assert float(lines["centroidal_bad_warm_unguarded"].split("u0[0]=")[1]) == u3[0] and u3[0] != u2[0]
     s = _srb(N, dt, 20)
     ips = DdpSingleRigidBody.InitialParam((0.01, -0.02, 1.0), (0.02, -0.01, 0.03))
     us = s.planOnce(lambda t: DdpSingleRigidBody.MotionParam(contacts(t), np.diag([40.0, 20.0, 10.0])),

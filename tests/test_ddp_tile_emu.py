@@ -41,14 +41,14 @@ def emu():
     L = ctypes.CDLL(so)
     L.ccc_ddp_tile_emu_lds_bytes.restype = ctypes.c_int
 
-    def run(model, N, dt, w, prob, x0, max_iter, u_init=None, reg_type=1, slice=0):
+    def run(model, N, dt, w, prob, x0, max_iter, u_init=None, reg_type=1, slice=0, guard=1):
         P = Params()
         P.model, P.N, P.P, P.mass, P.dt = model, N, prob["phase_dim"].shape[1], 100.0, dt
         S = 9 if model == 0 else 12
         for a in range(S):
             P.w_run[a], P.w_term[a] = w["run"][a], w["term"][a]
         P.w_force, P.flo, P.fhi, P.max_iter, P.reg_type = w["force"], 0.0, 1e6, max_iter, reg_type
-        P.warm_guard = 1  # ccc_ddp_default_config
+        P.warm_guard = guard  # 1 = ccc_ddp_default_config
         P.lambda0, P.dlambda0, P.lambda_factor, P.lambda_min, P.lambda_max = 1e-6, 1.0, 1.6, 1e-8, 1e10
         P.k_rel_norm_thre, P.lambda_thre, P.ratio_thre, P.cost_thre = 1e-4, 1e-7, 0.0, 1e-7
         for i in range(11):
@@ -177,6 +177,22 @@ def test_warm_start_guard_bit_for_bit(emu, model):
         assert np.array_equal(r_bad["u"][k], cold["u"][k])
     assert np.array_equal(r_bad["u"][2], warm["u"][2]) and not np.array_equal(warm["u"][2], cold["u"][2])
     assert np.all(np.isfinite(r_bad["u"]))
+    # the replacement is reported: the status word carries CCC_DDP_STATUS_WARM_REPLACED_BIT on exactly
+    # the dropped instances -- through a suspended / resumed solve too -- and is the plain exit code everywhere else
+    fired = np.array([True, True, False, True, True, True])
+    for r in (r_bad, emu(model, N, dt, w, prob, x0, 2, u_init=bad, slice=1)):
+        assert np.array_equal(oracle.ddp_warm_start_replaced(r["status"]), fired)
+        assert np.array_equal(r["status"][fired], 0x100 | (oracle.ddp_exit_code(r["status"])[fired] & 0xff))
+        assert np.array_equal(oracle.ddp_exit_code(r["status"]), cold["status"] * fired + warm["status"] * ~fired)
+    assert not oracle.ddp_warm_start_replaced(cold["status"]).any() and not oracle.ddp_warm_start_replaced(warm["status"]).any()
+    # guard off = the recalled nmpc_ddp behaviour (src/DdpSingleRigidBody.cpp:299-303: u_list goes to solve() as is): same
+    # bits from kernel source and specification on the very instances where the guard WOULD fire, and no flag
+    off = oracle.Ddp(model, 100.0, dt, N, w, max_iter=2, arith=1, warm_start_guard=False)
+    bad_finite = np.where(np.isfinite(bad), bad, 0.0)
+    r_off = off.plan_batch(prob, x0, u_init=bad_finite)
+    _same(emu(model, N, dt, w, prob, x0, 2, u_init=bad_finite, guard=0), r_off)
+    assert not oracle.ddp_warm_start_replaced(r_off["status"]).any()
+    assert not any(np.array_equal(r_off["u"][k], cold["u"][k]) for k in (0, 1, 3, 4, 5))
 
 
 @pytest.mark.parametrize("model,N", [(0, 100), (1, 50)])

@@ -128,7 +128,8 @@ def test_centroidal_reference_closed_loop_properties():
     assert np.linalg.norm(fin["vel"]) < 0.1 and np.linalg.norm(fin["ang_mom"]) < 0.01
 
 
-def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1, arith=0, guard=True):
+def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1, arith=0, guard=True, fired=None):
+    """fired: optional list; gets one bool per control cycle -- the warm-start guard replaced that cycle's warm start."""
     N, dt = 100, 0.03
     solvers = {}
     rng = np.random.default_rng(perturb_seed)
@@ -141,7 +142,10 @@ def _srb_closed_loop(perturb_seed=0, warm_max_iter=1, reg_type=1, arith=0, guard
             d.cfg.reg_type = reg_type
         if perturb_seed:
             x0 = x0 + 1e-10 * rng.standard_normal(x0.shape)
-        return d.plan_batch(prob, x0, u_init)["u"]
+        r = d.plan_batch(prob, x0, u_init)
+        if fired is not None:
+            fired.append(bool(r["warm_replaced"][0]))
+        return r["u"]
 
     return fd.run_closed_loop_ddp(plan, srb=True, warm_max_iter=warm_max_iter)
 
@@ -162,10 +166,29 @@ def test_srb_reference_closed_loop_properties(arith):
     default iteration budget, then unshifted warm start (dims reset :118-127) and max_iter = 1 per control cycle (:125),
     linear kick of 0.05 m/s in x and y at t = 1 s (:24-25, sva::ForceVecd(couple, force)), per-cycle assertions
     :150-153, final ones :172-175."""
-    log, fin = _srb_closed_loop(arith=arith)
+    fired = []
+    log, fin = _srb_closed_loop(arith=arith, fired=fired)
     assert len(log) in (600, 601)
     assert _srb_assertions_hold(log, fin)
     assert np.linalg.norm(fin["pos"] - fin["ref"]) < 0.02 and np.linalg.norm(fin["vel"]) < 0.03
+    # the cycles on which the default differs from the reference's warm-start semantics are observable (VERDICT r4
+    # item 1): the guard's firing is in the status word -- never on the cold first cycle, on 1 to 7 of the 601 cycles
+    assert len(fired) == len(log) and not fired[0]
+    assert 1 <= sum(fired) <= 7, sum(fired)
+
+
+def test_default_config_is_the_products_and_the_guard_is_reported():
+    """oracle_ddp_default_config = ccc_ddp_default_config since round 5 (they differed), and with the guard
+    off no status word ever carries the flag."""
+    import ctypes
+
+    L = oracle._bind_ddp()
+    cfg = oracle._DdpConfig()
+    L.oracle_ddp_default_config(ctypes.byref(cfg))
+    assert cfg.warm_start_guard == 1
+    fired = []
+    _srb_closed_loop(guard=False, fired=fired)
+    assert not any(fired)
 
 
 def test_srb_cold_solve_needs_the_quu_regularisation():
