@@ -32,6 +32,11 @@ struct ccc_ddp
   int64_t scap = -1;           // (-1: not allocated; 0: counters only)
   int slice = 2, slice_next = 4; // iterations of an instance's first / later slices (CCC_DDP_SLICE="a,b", development switch; 0: plain queue)
   int slots = 0;               // CCC_DDP_SLOTS (development switch): resident workgroups to launch, 0 = what fits
+  int update_kmax = 4;         // CCC_DDP_UPDATE_KMAX (development switch; the specification's S_UPDATE_KMAX is 4)
+  int64_t hist_n = -1;         // batch size of the last sliced launch: its per-instance busy times (DdpSched::prev) order the
+                               // next launch of the same size, longest first (closed-loop callers repeat the batch)
+  int hist_runs = 0;           // consecutive sliced launches of that size so far
+  int history = 1;             // CCC_DDP_HISTORY=0 (development switch) turns the history off
   int num_cu = 0;
   // staging for the host entry
   int64_t hcap = 0;
@@ -95,6 +100,8 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
     if(const char * c2 = std::strchr(v, ',')) h->slice_next = std::max(1, std::atoi(c2 + 1));
   }
   if(const char * v = std::getenv("CCC_DDP_SLOTS")) h->slots = std::max(0, std::atoi(v));
+  if(const char * v = std::getenv("CCC_DDP_UPDATE_KMAX")) h->update_kmax = std::max(0, std::atoi(v));
+  if(const char * v = std::getenv("CCC_DDP_HISTORY")) h->history = std::atoi(v);
   *out = h;
   return CCC_OK;
 }
@@ -139,6 +146,7 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
   P.reg_type = h->cfg.reg_type;
   P.warm_guard = h->cfg.warm_start_guard ? 1 : 0;
+  P.update_kmax = h->update_kmax;
 }
 
 extern "C" int ccc_ddp_arithmetic(const ccc_ddp_t * h)
@@ -228,10 +236,18 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     h->scap = -1;
     CCC_HIP_CHECK(hipMalloc(&h->sched, ddp_sched_bytes((long)need, h->prm.horizon_steps, h->S)));
     h->scap = need;
+    h->hist_n = -1; // (the busy times went with the old allocation)
+    h->hist_runs = 0;
   }
   DdpSched sched = ddp_sched_carve(h->sched, (long)h->scap, h->prm.horizon_steps, h->S);
   sched.slice = sliced ? h->slice : 0;
   sched.slice_next = h->slice_next;
+  if(sliced)
+  {
+    h->hist_runs = (h->hist_n == n) ? h->hist_runs + 1 : 0; // launches of this size before this one
+    h->hist_n = n;                                          // (this launch leaves its busy times for the next one)
+  }
+  sched.use_history = (sliced && h->history && h->hist_runs >= 1) ? (h->hist_runs >= 2 ? 2 : 1) : 0;
   ddp_common::Params P;
   fill_params(h, P);
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out, x_out, iters, status, cost};

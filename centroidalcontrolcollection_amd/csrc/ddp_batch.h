@@ -26,6 +26,8 @@ struct Params
   double alpha[11];
   int reg_type;   // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
   int warm_guard; // ccc_ddp_config_t::warm_start_guard
+  int update_kmax; // changed ridges a refactorisation of the box-QP absorbs by rank-one updates (oracle/ddp_tile.c
+                   // S_UPDATE_KMAX = 4; CCC_DDP_UPDATE_KMAX overrides it for timing experiments: 0 = always afresh)
 };
 } // namespace ddp_common
 
@@ -69,6 +71,21 @@ struct DdpSched
   long cap;
   int slice;           // iterations of an instance's first slice; 0 = no slicing (the batch fits one resident set)
   int slice_next;      // iterations of the later slices
+  // Round 5: what the handle's PREVIOUS call of the same batch size measured.  Closed-loop callers
+  // repeat the batch, and an instance that was long last time is long again: with every instance's busy time known, the
+  // launch is plain LONGEST-PROCESSING-TIME-FIRST list scheduling -- fresh instances are handed out in the order of their
+  // previous busy time and every solve runs to completion on the wavefront that took it, no slices, no suspensions
+  // (measured: config 3 62.6 -> 56.1 ms, config 5's shape 158.5 -> 144.3 ms).  Whether the history predicts anything is
+  // checked on the device: every finishing instance compares its busy time with the previous call's, and a launch whose
+  // predecessor agreed on fewer than 70 % of the instances (a caller whose batches are unrelated) falls back to the
+  // estimate-driven slices above.  Answers do not depend on the schedule (bit-identical, tested).
+  float * prev;        // [cap] busy ticks (100 MHz) of instance b in this launch, written when it finishes; read as the
+                       //       previous call's while it runs
+  int * order;         // [cap] instance handed out with fresh ticket t (ddp_order_kernel)
+  int * trust;         // [2]   trust[0]: 1 = this launch follows the history (set by ddp_order_kernel); trust[1]: instances
+                       //       of the running launch whose busy time fell within one bucket of the previous call's
+  int use_history;     // 0: no history for this batch size; 1: the previous call had the same size; 2: ... and the one before
+                       //    (so trust[1] is a verdict on the history, and the order kernel asks for 70 %)
 };
 // bytes of device memory behind a DdpSched for `cap` instances, and its carving
 size_t ddp_sched_bytes(long cap, int N, int S);

@@ -84,6 +84,8 @@ enum
   TP_F_CF,
   TP_F_MF,
   TP_F_GJ,
+  TP_F_UPD,   // cycles in rank-one updates (qp_update), and their number
+  TP_F_UPDS,
   TP_N
 };
 #if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -147,6 +149,8 @@ struct alignas(16) Mem
   static constexpr int LG = M + 1;     // row stride of the g_r table: odd, so that its six rows start in different banks
   alignas(16) double Gl[6 * LG];       // the six non-zero rows of Fu    [j * LG + r]
   alignas(16) double Cf[36], Mf[36], Minv[36];
+  alignas(16) double u6[3][8];         // p, a, b of a rank-one update of Minv (qp_update)
+  alignas(16) double cvr[6 * M];       // vertex (rows 0 .. 2) and ridge (3 .. 5) of the ridges of the cached contact phase
   alignas(16) double Vx[16], Qx[16];
   double wrun[16], wterm[16];
   double alpha[12];
@@ -262,7 +266,9 @@ struct Solver
   // vertex and ridge of the ridges c + 16 b in the contact phase `ph_cached` (zero beyond its dimension): reloaded only
   // when a step is in another phase than the one before -- a horizon has a handful of phases
   int ph_cached;
-  vf Vc[B][3], Rc[B][3];
+  // (round 5: in LDS, mem.cvr, not in registers -- twelve VGPRs per block of ridges that were live through the whole solve)
+  W64_FN vf Vc(int b, int k) const { return ld(mem.cvr, k * M + c + 16 * b); }
+  W64_FN vf Rc(int b, int k) const { return ld(mem.cvr, (3 + k) * M + c + 16 * b); }
 
   W64_FN Solver(const Params & p, const Instance & i, Mem<S, B> & m) : P(p), I(i), mem(m) {}
 
@@ -360,10 +366,11 @@ struct Solver
       const vb in = r < dim;
       for(int k = 0; k < 3; k++)
       {
-        Vc[b][k] = ldm(I.phase_vertex + base, r * 3 + k, in);
-        Rc[b][k] = ldm(I.phase_ridge + base, r * 3 + k, in);
+        st(mem.cvr, k * M + r, ldm(I.phase_vertex + base, r * 3 + k, in), g == 0);
+        st(mem.cvr, (3 + k) * M + r, ldm(I.phase_ridge + base, r * 3 + k, in), g == 0);
       }
     }
+    wave_sync();
   }
   // reference of the weighted state entries (Cen: [pos, 0, 0]; SRB: [pos, ori, 0, 0]) on the lanes a < S
   W64_FN vf ref_of(int step) const
@@ -390,21 +397,21 @@ struct Solver
     const vf p0 = row_bcast<0>(x), p1 = row_bcast<1>(x), p2 = row_bcast<2>(x);
     for(int b = 0; b < AB; b++)
     {
-      const vf d0 = Vc[b][0] - p0, d1 = Vc[b][1] - p1, d2 = Vc[b][2] - p2;
-      T.cr[b][0] = d1 * Rc[b][2] - d2 * Rc[b][1];
-      T.cr[b][1] = d2 * Rc[b][0] - d0 * Rc[b][2];
-      T.cr[b][2] = d0 * Rc[b][1] - d1 * Rc[b][0];
+      const vf d0 = Vc(b, 0) - p0, d1 = Vc(b, 1) - p1, d2 = Vc(b, 2) - p2;
+      T.cr[b][0] = d1 * Rc(b, 2) - d2 * Rc(b, 1);
+      T.cr[b][1] = d2 * Rc(b, 0) - d0 * Rc(b, 2);
+      T.cr[b][2] = d0 * Rc(b, 1) - d1 * Rc(b, 0);
     }
     for(int k = 0; k < 3; k++)
     {
       vf t[B];
-      for(int b = 0; b < AB; b++) t[b] = u[b] * Rc[b][k];
+      for(int b = 0; b < AB; b++) t[b] = u[b] * Rc(b, k);
       T.force[k] = sumM<AB>(t);
       for(int b = 0; b < AB; b++) t[b] = u[b] * T.cr[b][k];
       T.moment[k] = sumM<AB>(t);
       if(S == 12)
       {
-        for(int b = 0; b < AB; b++) t[b] = (u[b] * Rc[b][k]) / P.mass;
+        for(int b = 0; b < AB; b++) t[b] = (u[b] * Rc(b, k)) / P.mass;
         T.accel[k] = sumM<AB>(t);
       }
     }
@@ -480,7 +487,7 @@ struct Solver
       for(int b = 0; b < AB; b++)
         for(int k = 0; k < 3; k++)
         {
-          Fu[b][k] = Rc[b][k] * dt;
+          Fu[b][k] = Rc(b, k) * dt;
           Fu[b][3 + k] = T.cr[b][k] * dt;
         }
       // (the scalars are the same on every lane: lane 0 stores them)
@@ -502,7 +509,7 @@ struct Solver
         vllt3(mem.llt, T.cr[b], sol);
         for(int k = 0; k < 3; k++)
         {
-          Fu[b][k] = (Rc[b][k] / P.mass) * dt;
+          Fu[b][k] = (Rc(b, k) / P.mass) * dt;
           Fu[b][3 + k] = sol[k] * dt;
         }
       }
@@ -713,6 +720,53 @@ struct Solver
       gj_step<K + 1>(a);
     }
   }
+  // Round 5 -- the free set changes by ONE ridge r (sigma = +1: it becomes free, -1: clamped): C_f += sigma g g',
+  // M_f += sigma p g', p = V6r g, so Minv -= (sigma / den) (Minv p)(g' Minv), den = 1 + sigma g' Minv p (Sherman-Morrison):
+  // a dozen 6-term sums and one division instead of C_f's 16 B-term sums and a Gauss-Jordan inverse.  false = declined
+  // (den small or not finite, or an updated entry not finite): the caller factorises afresh.  SPEC: oracle/ddp_tile.c
+  // s_update, statement by statement: p and a by apply6 (row j on lane j), b with column l on lane l, the three vectors
+  // handed to the 36 entry lanes through LDS.
+  static constexpr int kUpdateKmax = 4;   // S_UPDATE_KMAX (the default of Params::update_kmax)
+  static constexpr int kUpdateUmax = 12;  // S_UPDATE_UMAX
+  W64_FN bool qp_update(const Qp & Q, int r, double sigma)
+  {
+    const vb row6 = lane < 6;
+    // (g_t is re-read where it is used -- broadcast LDS reads -- rather than held: the box-QP is where the kernel's
+    //  register pressure peaks)
+    auto gt = [&](int t) { return ld(mem.Gl, spl(t * LG + r)); };
+    {
+      vf ps = Q.v6r[0] * gt(0);
+      for(int l = 1; l < 6; l++) ps = vfma(Q.v6r[l], gt(l), ps);
+      st(mem.u6[0], j6, ps, row6);
+    }
+    wave_sync();
+    {
+      vf as = ld(mem.Minv, j6 * 6) * ld(mem.u6[0], spl(0));
+      for(int l = 1; l < 6; l++) as = vfma(ld(mem.Minv, j6 * 6 + l), ld(mem.u6[0], spl(l)), as);
+      st(mem.u6[1], j6, as, row6);
+      vf bs = gt(0) * ld(mem.Minv, j6);
+      for(int t = 1; t < 6; t++) bs = vfma(gt(t), ld(mem.Minv, t * 6 + j6), bs);
+      st(mem.u6[2], j6, bs, row6);
+    }
+    wave_sync();
+    vf gam = gt(0) * ld(mem.u6[1], spl(0));
+    for(int t = 1; t < 6; t++) gam = vfma(gt(t), ld(mem.u6[1], spl(t)), gam);
+    const vf den = vfma(splat(sigma), gam, splat(1.0));
+    const double d0 = read_lane(den, 0);
+    if(!(std::fabs(d0) >= 0.01) || !(std::fabs(d0) <= 1.7976931348623157e308)) return false; // S_UPDATE_DEN_MIN
+    const vf scale = splat(sigma) / den;
+    const vb live = lane < 36;
+    const vi n = seli(live, lane, spl(0));
+    const vi j = (n * 43) >> 8, l = n - 6 * j;
+    const vf as = ld(mem.u6[1], j) * scale, sg = sigma * ld(mem.Gl, j * LG + r);
+    const vf mi = vfma(-as, ld(mem.u6[2], l), ld(mem.Minv, n));
+    const vf cf = vfma(sg, ld(mem.Gl, l * LG + r), ld(mem.Cf, n));
+    const bool ok = (ballot(!(vabs(mi) <= 1.7976931348623157e308)) & 0xfffffffffull) == 0ull;
+    st(mem.Minv, n, mi, live);
+    st(mem.Cf, n, cf, live);
+    wave_sync();
+    return ok;
+  }
   // sol = Quu_F,ff^-1 (q + Quu_F xcl) on the free rows in the cancellation-free form of oracle/ddp_tile.c s_direction:
   //   beta = Vx6 + V6r (G xcl); delta = beta - ratio V6r (G_f u_f); gamma = Minv delta; sol_r = ratio u_r + g_r' gamma
   template<int AB>
@@ -803,6 +857,8 @@ struct Solver
     double value = value_of(x), oldvalue = 0.0;
     TILE_PROF_ADD(TP_QP_VALUE);
     freemask = 0;
+    mask_t factmask = 0; // the free set the factor in mem.Cf / mem.Minv belongs to
+    int nupd = 0;        // rank-one updates since it was formed afresh
     int result = 0, iter;
     for(iter = 1; iter <= max_iter; iter++)
     {
@@ -836,11 +892,35 @@ struct Solver
         TILE_PROF_COUNT(TP_QP_FACTORS);
         freemask = inmask & ~clmask;
         for(int b = 0; b < AB; b++) fr[b] = Q.in[b] && !cl[b];
-        if(!qp_factor<AB>(Q, freemask))
+        // round 5: a set a few ridges from the factorised one is reached by rank-one updates, ridge by ridge in increasing
+        // index (oracle/ddp_tile.c box_qp_struct); afresh in the first iteration, beyond kUpdateKmax changes, after
+        // kUpdateUmax updates in a row, and whenever an update declines
+        unsigned long long dm = static_cast<unsigned long long>((freemask ^ factmask) & inmask);
+        const int nch = __builtin_popcountll(dm);
+        bool fresh = (iter == 1) || nch > P.update_kmax || nupd + nch > kUpdateUmax;
+        while(!fresh && dm != 0ull)
         {
-          result = -1;
-          break;
+          const int r = __builtin_ctzll(dm);
+          dm &= dm - 1ull;
+          TILE_PROF_COUNT(TP_F_UPDS);
+          if(qp_update(Q, r, ((freemask >> r) & 1u) ? 1.0 : -1.0))
+            nupd++;
+          else
+            fresh = true;
         }
+#if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+        if(!fresh && (threadIdx.x & 63) == 0) mem.prof[TP_F_UPD] += (double)((long long)__builtin_readcyclecounter() - prof_t_);
+#endif
+        if(fresh)
+        {
+          if(!qp_factor<AB>(Q, freemask))
+          {
+            result = -1;
+            break;
+          }
+          nupd = 0;
+        }
+        factmask = freemask;
       }
       TILE_PROF_ADD(TP_QP_FACTOR);
       vf t[B];

@@ -34,7 +34,9 @@ __global__ void ddp_sched_reset_kernel(int * counters, size_t words, int * slot,
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(i < words)
-    counters[i] = 0;
+  {
+    if(i < 2 || i >= 8) counters[i] = 0; // (words 2 .. 7 carry the verdict on the history from launch to launch: DdpSched::trust)
+  }
   else if(i - words < fill)
     slot[i - words] = -1;
 }
@@ -52,6 +54,37 @@ __device__ __forceinline__ int sched_bucket(long long ticks)
   return key < 0 ? 0 : (key >= kDdpSchedBuckets ? kDdpSchedBuckets - 1 : key);
 }
 
+// Fresh tickets -> instances, longest previous busy time first (csrc/ddp_batch.h DdpSched::prev): a counting sort over the
+// same four-per-octave buckets, one workgroup; also the decision whether this launch follows the history at all
+// (DdpSched::trust).  The order inside a bucket is whatever the atomics make it: the answers do not depend on it.
+__global__ __launch_bounds__(1024) void ddp_order_kernel(const float * prev, long n, int * order, int * trust, int check)
+{
+  __shared__ unsigned hist[kDdpSchedBuckets], base[kDdpSchedBuckets];
+  const int t = threadIdx.x;
+  if(t < kDdpSchedBuckets) hist[t] = 0u;
+  __syncthreads();
+  for(long i = t; i < n; i += 1024) atomicAdd(&hist[sched_bucket((long long)prev[i])], 1u);
+  __syncthreads();
+  if(t == 0)
+  {
+    // follow the history unless the previous launch, which could check it, found it wrong (check = 0: nothing to go by yet)
+    trust[0] = (!check || 10L * trust[1] >= 7L * n) ? 1 : 0;
+    trust[1] = 0;
+    unsigned acc = 0u;
+    for(int k = kDdpSchedBuckets - 1; k >= 0; k--) // descending: the highest bucket gets the first tickets
+    {
+      base[k] = acc;
+      acc += hist[k];
+    }
+  }
+  __syncthreads();
+  for(long i = t; i < n; i += 1024)
+  {
+    const unsigned at = atomicAdd(&base[sched_bucket((long long)prev[i])], 1u);
+    order[at] = (int)i;
+  }
+}
+
 template<int S, int NB>
 __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4))) void ddp_tile_kernel(
     ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, DdpSched Sc)
@@ -64,6 +97,8 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
   // Work queue: the grid is one resident set of workgroups (one workspace per resident workgroup).  Each
   // takes the next FRESH instance from a ticket counter; when those are handed out, the suspended ones, slowest first.
   bool fresh_left = true;
+  // longest-processing-time-first from the previous call's busy times (csrc/ddp_batch.h), when they are there and held
+  const bool follow = Sc.use_history != 0 && __hip_atomic_load(Sc.trust, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   for(;;)
   {
     long b = -1;
@@ -74,7 +109,7 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
       if(lane == 0) t = atomicAdd(Sc.ticket, 1u);
       t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
       if((long)t < n)
-        b = (long)t;
+        b = follow ? (long)Sc.order[t] : (long)t;
       else
         fresh_left = false;
     }
@@ -147,15 +182,18 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
     }
     else
       solver.begin();
-#if defined(CCC_TILE_TIMING)
-    // (development aid, scripts/ddp_sched_probe.py: busy ticks and first start of the instance travel in save_s[4..5])
+    // busy ticks of the instance so far travel in save_s[4] (the history of the next call; with -DCCC_TILE_TIMING also the
+    // first start in save_s[5], scripts/ddp_sched_probe.py)
     const long long tt0 = (long long)wall_clock64();
-    double * const tsv = Sc.save_s + (size_t)b * 8;
+    double * const tsv = Sc.slice > 0 ? Sc.save_s + (size_t)b * 8 : nullptr;
     if(!resumed && Sc.slice > 0 && lane == 0)
     {
       tsv[4] = 0.0;
+#if defined(CCC_TILE_TIMING)
       tsv[5] = (double)tt0;
+#endif
     }
+#if defined(CCC_TILE_TIMING)
     solver.timing_busy = (Sc.slice > 0 && resumed) ? tsv[4] : 0.0;
     solver.timing_first = (Sc.slice > 0 && resumed) ? tsv[5] : (double)tt0;
     solver.timing_slice0 = tt0;
@@ -168,7 +206,17 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
       {
         solver.finish();
         __syncthreads();
-        if(Sc.slice > 0 && lane == 0) atomicAdd(Sc.finished, 1u);
+        if(Sc.slice > 0 && lane == 0)
+        {
+          const float busy = (float)(tsv[4] + (double)((long long)wall_clock64() - tt0));
+          if(Sc.use_history != 0)
+          {
+            const int d = sched_bucket((long long)busy) - sched_bucket((long long)Sc.prev[b]);
+            if(d >= -1 && d <= 1) atomicAdd(Sc.trust + 1, 1);
+          }
+          Sc.prev[b] = busy;
+          atomicAdd(Sc.finished, 1u);
+        }
         break;
       }
       // what is left of this solve, as far as one can tell: the pace of the slice x the iterations it may still take
@@ -181,10 +229,9 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
       const unsigned long long ne = __ballot(sched_load(Sc.head + lane) < sched_load(Sc.tail + lane));
       const int lowest = k > 0 ? k - 1 : 0;
       if(!fresh_waiting && (ne >> lowest) == 0ull) continue;
+      if(follow) continue; // (list scheduling: the order was settled at the hand-out, every solve runs to completion)
       solver.suspend(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 8);
-#if defined(CCC_TILE_TIMING)
-      if(lane == 0) tsv[4] = solver.timing_busy + (double)((long long)wall_clock64() - tt0);
-#endif
+      if(lane == 0) tsv[4] = tsv[4] + (double)((long long)wall_clock64() - tt0);
       __threadfence(); // (release: the state is out before the entry is)
       if(lane == 0)
       {
@@ -205,11 +252,13 @@ int ddp_tile_grid(long n, int M, int num_cu)
   return (int)(n < resident ? n : resident);
 }
 
-// layout behind a DdpSched: [ticket, finished, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8][save_x cap x (N+1) S]
+// layout behind a DdpSched: [ticket, finished, trust x 2, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8]
+// [save_x cap x (N+1) S][prev cap][order cap]
 static size_t sched_off_slot() { return (size_t)(64 + 2 * kDdpSchedBuckets) * 4; }
 static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 4 + 255) / 256 * 256; }
 static size_t sched_off_x(long cap) { return sched_off_s(cap) + (size_t)cap * 8 * 8; }
-size_t ddp_sched_bytes(long cap, int N, int S) { return sched_off_x(cap) + (size_t)cap * (size_t)(N + 1) * S * 8; }
+static size_t sched_off_prev(long cap, int N, int S) { return sched_off_x(cap) + (size_t)cap * (size_t)(N + 1) * S * 8; }
+size_t ddp_sched_bytes(long cap, int N, int S) { return sched_off_prev(cap, N, S) + (size_t)cap * 8 + 256; }
 DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
 {
   char * base = static_cast<char *>(mem);
@@ -221,8 +270,13 @@ DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
   sc.slot = reinterpret_cast<int *>(base + sched_off_slot());
   sc.save_s = reinterpret_cast<double *>(base + sched_off_s(cap));
   sc.save_x = reinterpret_cast<double *>(base + sched_off_x(cap));
+  sc.prev = reinterpret_cast<float *>(base + sched_off_prev(cap, N, S));
+  sc.order = reinterpret_cast<int *>(sc.prev + cap);
+  sc.trust = reinterpret_cast<int *>(base) + 2; // (words 2, 3 of the header: NOT reset with the counters)
   sc.cap = cap;
   sc.slice = 0;
+  sc.slice_next = 0;
+  sc.use_history = 0;
   return sc;
 }
 
@@ -238,6 +292,9 @@ hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, dou
     hipLaunchKernelGGL(ddp_sched_reset_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<int *>(sched.ticket), words, sched.slot, fill);
   }
+  if(sched.use_history)
+    hipLaunchKernelGGL(ddp_order_kernel, dim3(1), dim3(1024), 0, stream, sched.prev, n, sched.order, sched.trust,
+                       sched.use_history > 1 ? 1 : 0);
 #define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, sched)
   if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
   else if(S == 12 && M == 16) CCC_TILE_LAUNCH(12, 1);

@@ -34,4 +34,8 @@ print("correlation of cycles with: qp iters %.3f, forwards %.3f, iters %.3f" % (
 names = ["derivatives", "products", "qp value_of", "qp gradient", "qp factor", "qp solve", "qp search", "gains", "value update", "forward", "qp entry/exit"]
 for lab, idx in (("slowest 20", order[:20]), ("middle 200", order[n // 2 - 100:n // 2 + 100])):
     m = tm[idx].mean(axis=0); m[10] -= m[2:7].sum()
+    fresh = m[13] - (m[13] - m[11])  # (first-iteration factorisations = box-QP calls)
+    print(lab, "factor detail: Cf %.0f Mf %.0f GJ %.0f cycles per fresh factorisation (sum over the instance %.1f M); rank-one updates: %.0f per instance, "
+          "%.0f cycles each (%.1f M)" % (m[15] / max(m[13], 1), m[16] / max(m[13], 1), m[17] / max(m[13], 1), (m[15] + m[16] + m[17]) / 1e6,
+                                            m[19], m[18] / max(m[19], 1), m[18] / 1e6))
     print(lab, " ".join("%s %.1f%%" % (nm, 100 * m[j] / m[:11].sum()) for j, nm in enumerate(names)))

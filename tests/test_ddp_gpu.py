@@ -117,6 +117,29 @@ def test_longest_first_schedule_gives_the_plain_queues_answers_bit_for_bit(srb, 
         _assert_bitwise(got, ref)
 
 
+@pytest.mark.parametrize("srb", [False, True])
+def test_history_schedule_gives_the_same_answers_whatever_the_caller_repeats(srb, monkeypatch):
+    """csrc/ddp_batch.h DdpSched::prev (round 5): a handle that sees the same batch size again hands its instances out
+    longest-previous-busy-time first and runs every solve to completion; the device checks whether the history predicted
+    anything and falls back to the estimate-driven slices when it did not.  Whatever the schedule, the answers are those
+    of a fresh handle bit for bit: batch A three times (no history, history taken on trust, history confirmed), then an
+    unrelated batch B of the same size twice (history followed and found wrong, then distrusted), then A again -- on a
+    full-size batch and on a grid cut to 24 workgroups."""
+    N, dt = 12, 0.05
+    mk = _srb if srb else _cen
+    for n, slots in ((2100, None), (160, "24")):
+        if slots:
+            monkeypatch.setenv("CCC_DDP_SLOTS", slots)
+        pa, xa = fd.make_centroidal_batch(n, N, dt, seed=5, srb=srb)
+        pb, xb = fd.make_centroidal_batch(n, N, dt, seed=6, srb=srb)
+        monkeypatch.setenv("CCC_DDP_HISTORY", "0")
+        ra, rb = mk(N, dt, 8).planOnceBatch(pa, xa, want_x=True), mk(N, dt, 8).planOnceBatch(pb, xb, want_x=True)
+        monkeypatch.delenv("CCC_DDP_HISTORY")
+        d = mk(N, dt, 8)
+        for prob, x0, ref in ((pa, xa, ra), (pa, xa, ra), (pa, xa, ra), (pb, xb, rb), (pb, xb, rb), (pa, xa, ra)):
+            _assert_bitwise(d.planOnceBatch(prob, x0, want_x=True), ref, ("u", "x", "cost", "iters", "status"))
+
+
 def test_warm_start_and_limits():
     N, dt = 100, 0.03
     prob, x0 = fd.make_centroidal_batch(64, N, dt, seed=3)

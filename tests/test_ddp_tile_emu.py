@@ -23,7 +23,7 @@ class Params(ctypes.Structure):
                 ("lambda_factor", ctypes.c_double), ("lambda_min", ctypes.c_double), ("lambda_max", ctypes.c_double),
                 ("k_rel_norm_thre", ctypes.c_double), ("lambda_thre", ctypes.c_double), ("ratio_thre", ctypes.c_double),
                 ("cost_thre", ctypes.c_double), ("alpha", ctypes.c_double * 11), ("reg_type", ctypes.c_int),
-                ("warm_guard", ctypes.c_int)]
+                ("warm_guard", ctypes.c_int), ("update_kmax", ctypes.c_int)]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,6 +49,7 @@ def emu():
             P.w_run[a], P.w_term[a] = w["run"][a], w["term"][a]
         P.w_force, P.flo, P.fhi, P.max_iter, P.reg_type = w["force"], 0.0, 1e6, max_iter, reg_type
         P.warm_guard = guard  # 1 = ccc_ddp_default_config
+        P.update_kmax = 4  # S_UPDATE_KMAX of the specification
         P.lambda0, P.dlambda0, P.lambda_factor, P.lambda_min, P.lambda_max = 1e-6, 1.0, 1.6, 1e-8, 1e10
         P.k_rel_norm_thre, P.lambda_thre, P.ratio_thre, P.cost_thre = 1e-4, 1e-7, 0.0, 1e-7
         for i in range(11):

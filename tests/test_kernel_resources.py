@@ -23,11 +23,13 @@ EXPECT = {
     # DDP kernel (round 4: structured backward step -- no M x M object, LDS independent of the ridge stride; bound by
     # instruction issue, so the register budget is set for NO spills rather than for occupancy: csrc/ddp_tile.hip)
     "void ccc_amd::ddp_tile_kernel<9, 1>": ("ddp_tile", 256, 2, 0, 10240),
-    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 160, 10240),
-    "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 416, 10240),    # 32 ridges
-    "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 416, 10240),
-    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 176, 12288),    # 64 ridges: one wavefront per SIMD
-    "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 512, 1, 160, 12288),
+    # (round 5: the cached contact vertices / ridges moved from registers to LDS -- scratch 140 -> 20 B at S = 12, 416 -> 156 /
+    #  172 B at 32 ridges, 176 / 160 -> 0 at 64, with the rank-one updates of the box-QP's factor added on top)
+    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 24, 10240),
+    "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 160, 10240),    # 32 ridges
+    "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 176, 12288),
+    "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 0, 14336),      # 64 ridges: one wavefront per SIMD
+    "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 512, 1, 0, 15360),
     "ccc_amd::z_plan_stream_kernel": ("z", 168, 3, 0, None),
     "void ccc_amd::z_plan_kernel<40, 1>": ("z", 168, 3, 0, 14336),             # eleven workgroups per CU
     "ccc_amd::ism_plan_pcr_kernel": ("ism", 128, 4, 0, 24576),
