@@ -916,6 +916,8 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
   }
 }
 
+#include "zmp_k2r.inc"
+
 } // namespace ccc_amd
 
 // =============================================================================================
@@ -947,6 +949,9 @@ struct ccc_zmp
   int64_t env_queue_min = -1;   // CCC_ZMP_QUEUE_MIN: QPs from which the work-queue kernel runs (< 0: the measured default)
   bool env_static = false;      // CCC_ZMP_STATIC: never the work-queue kernel
   bool env_debug = false;       // CCC_ZMP_DEBUG: print the occupancy of the LDS-tableau kernels
+  int env_k2 = -1;              // CCC_ZMP_K2: 0 = the LDS tableau (K2) for every 32 < N <= 200, 1 = the register tiles (K2r)
+                                //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
+                                //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
   const char * last_kernel = "none"; // the kernel the last plan call launched (ccc_zmp_last_kernel)
 };
@@ -1096,6 +1101,62 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
+  // K2r: the packed tableau in registers (csrc/zmp_k2r.inc), up to 128 rows
+  auto go_reg = [&](auto kernel, auto rt) -> int {
+    using RT = decltype(rt);
+    const size_t lds = RT::lds_bytes();
+    const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    if(h->env_debug)
+    {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, RT::NT, lds);
+      std::fprintf(stderr, "zmp reg kernel: rows %d threads %d tiles/thread %d lds %zu B -> %d workgroups per CU (grid %d)\n",
+                   RT::NB * 4, RT::NT, RT::TPT, lds, nb, grid);
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT::NT), lds, stream, P, h->NP, (long)nqp, x0, zlim, control_dt, zmp, jerk,
+                       status);
+    h->last_kernel = "zmp_plan_reg_kernel";
+    return CCC_OK;
+  };
+  // measured (round 5, batch 32768, one MI355X; solves/s K2 -> K2r with two | three tiles per thread): N = 40 29.9 -> 27.6 M
+  // and 48 17.3 -> 16.9 M (the LDS tableau stays), 56 14.6 -> 15.7 | 13.7 M, 64 8.0 -> 7.9 | 9.6 M, 72 6.47 -> 6.55 | 4.75 M,
+  // 80 4.85 -> 5.69 | 4.14 M, 96 3.13 -> 3.19 | 3.12 M, 100 2.27 -> 3.05 | 2.91 M (one tile per thread: 1.63 M), 112 2.01 ->
+  // 2.15 | 1.37 M, 128 1.11 -> 0.67 | 1.15 M.  What a pivot costs at these sizes is the per-wavefront selection / staging /
+  // ratio-test code around the update (~300 vector and ~280 scalar instructions per pivot and wavefront for 16 FMAs per
+  // tile), so fewer, fatter wavefronts per QP win until the registers run out.
+  const bool use_reg = h->env_k2 > 0 || (h->env_k2 < 0 && h->N > 48);
+  if(use_reg && h->N <= 128)
+  {
+    int rcr;
+    const bool three = h->env_k2 == 13 || (h->env_k2 != 12 && ((h->N > 56 && h->N <= 64) || h->N > 112));
+#define CCC_ZMP_REG(NR, TPT) rcr = go_reg(&zmp_plan_reg_kernel<NR, TPT>, RegTab<NR, TPT>{})
+#define CCC_ZMP_REG23(NR) \
+  do                      \
+  {                       \
+    if(three)             \
+      CCC_ZMP_REG(NR, 3); \
+    else                  \
+      CCC_ZMP_REG(NR, 2); \
+  } while(0)
+    const int Nr = h->N;
+    if(Nr <= 40) CCC_ZMP_REG(40, 1);
+    else if(Nr <= 48) CCC_ZMP_REG(48, 2);
+    else if(Nr <= 56) CCC_ZMP_REG23(56);
+    else if(Nr <= 64) CCC_ZMP_REG23(64);
+    else if(Nr <= 72) CCC_ZMP_REG23(72);
+    else if(Nr <= 80) CCC_ZMP_REG23(80);
+    else if(Nr <= 96) CCC_ZMP_REG23(96);
+    else if(Nr <= 104) CCC_ZMP_REG23(104);
+    else if(Nr <= 112) CCC_ZMP_REG23(112);
+    else CCC_ZMP_REG23(128);
+#undef CCC_ZMP_REG23
+#undef CCC_ZMP_REG
+    if(rcr != CCC_OK) return rcr;
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  }
   // packed LDS tableau sized to the horizon (rows rounded up to a tile boundary the instantiations cover)
   auto go = [&](auto kernel, auto st) -> int {
     using ST = decltype(st);
@@ -1167,6 +1228,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) h->env_queue_min = std::atoll(qm);
   h->env_static = std::getenv("CCC_ZMP_STATIC") != nullptr;
   h->env_debug = std::getenv("CCC_ZMP_DEBUG") != nullptr;
+  if(const char * k2 = std::getenv("CCC_ZMP_K2")) h->env_k2 = std::atoi(k2);
   if(const char * ce = std::getenv("CCC_ZMP_HOST_CHUNK")) h->env_host_chunk = std::atoll(ce);
   build_model(h);
   hipDeviceProp_t prop;

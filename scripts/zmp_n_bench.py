@@ -20,4 +20,8 @@ ts = []
 for _ in range(reps):
     t0 = time.perf_counter(); mpc.plan_batch_device(x0, zl, 0.005, z, None, st); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 t = min(ts); s = st.cpu().numpy()
+if os.environ.get("CCC_ZMP_BENCH_CHECK"):  # (development aid) the first 256 instances against the CPU oracle
+    from oracle import oracle
+    ref = oracle.LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"][:256], b["zlim"][:256], 0.005, want_jerk=False, nthreads=8)
+    print("  max |dZMP| vs the oracle on 256 instances: %.3g (%s)" % (np.abs(z.cpu().numpy()[:256] - ref["zmp"]).max(), mpc.last_kernel()))
 print("LinearMpcZmp n=%d N=%d: %.2f ms -> %.0f solves/s (mean pivots/axis %.1f, non-ok %d)" % (n, N, t * 1e3, n / t, (s >> 8).mean(), int(((s & 0xff) != 0).sum())))

@@ -183,6 +183,35 @@ def test_golden_vectors_n100_block_kernel(golden_zmp):
     assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
 
 
+@pytest.mark.parametrize("N", [40, 56, 64, 80, 100, 112, 128])
+def test_register_tile_kernel_against_the_oracle_and_the_lds_tableau(N, monkeypatch):
+    """csrc/zmp_k2r.inc (round 5): the packed symmetric tableau of K2 kept in registers across pivots, the default for
+    48 < N <= 128.  Every size it is built for, with two and with three tiles per thread: solved, planned ZMP and jerk
+    sequence within the parity tolerances of the oracle, and the same pivot counts as the LDS tableau (the iteration is K2's
+    statement by statement; only the closing refinement adds its partial sums in another order) with ZMPs within 1e-12."""
+    dt = 2.0 / N
+    b = fx.make_zmp_batch(384, N, dt, seed=41 + N)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    monkeypatch.setenv("CCC_ZMP_K2", "0")  # (development switches are read when a handle is created)
+    lds = LinearMpcZmp(1.0, 2.0, dt)
+    assert lds.horizon_steps_ == N
+    r0 = lds.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert lds.last_kernel() == "zmp_plan_sym_kernel"
+    for k2 in ("12", "13") if N > 48 else ("1",):
+        monkeypatch.setenv("CCC_ZMP_K2", k2)
+        mpc = LinearMpcZmp(1.0, 2.0, dt)
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+        assert mpc.last_kernel() == "zmp_plan_reg_kernel"
+        assert np.all(r["status"] == 0)
+        assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+        assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+        assert np.array_equal(r["pivots"], r0["pivots"]) and np.abs(r["zmp"] - r0["zmp"]).max() <= 1e-12
+    monkeypatch.delenv("CCC_ZMP_K2")
+    d = LinearMpcZmp(1.0, 2.0, dt)
+    d.planOnceBatch(b["x0"][:8], b["zlim"][:8], 0.005)
+    assert d.last_kernel() == ("zmp_plan_reg_kernel" if N > 48 else "zmp_plan_sym_kernel")
+
+
 def test_n200_packed_lds_tableau():
     """BASELINE.json configs[0] as worded (2 s horizon @ dt = 10 ms = 200 steps): the largest horizon whose packed
     symmetric tableau (2 x 2 tiles) fits the 160 KB of LDS.  Parity with the oracle, and a short stretch of the reference
