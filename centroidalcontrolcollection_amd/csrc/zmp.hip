@@ -67,12 +67,23 @@ struct RowRegs
   // element `u` of the row, u uniform across the wavefront (held in an SGPR)
   __device__ __forceinline__ double at_uniform(int u) const
   {
+    // (written out, not a loop over the tuples: a loop that is still rolled when the optimiser first looks keeps the whole
+    //  struct in memory -- measured at three and four tuples: the row in scratch)
     double r = t[0][u & 15];
-#pragma unroll
-    for(int k = 1; k < NP / 16; ++k)
+    if constexpr(NP / 16 > 1)
     {
-      const double e = t[k][u & 15];
-      r = ((u >> 4) == k) ? e : r;
+      const double e = t[1][u & 15];
+      r = ((u >> 4) == 1) ? e : r;
+    }
+    if constexpr(NP / 16 > 2)
+    {
+      const double e = t[2][u & 15];
+      r = ((u >> 4) == 2) ? e : r;
+    }
+    if constexpr(NP / 16 > 3)
+    {
+      const double e = t[3][u & 15];
+      r = ((u >> 4) == 3) ? e : r;
     }
     return r;
   }
@@ -89,6 +100,11 @@ __device__ __forceinline__ double row_at_group_uniform(const RowRegs<NP> & T, in
   const double c1 = T.at_uniform(u1);
   return (threadIdx.x & 32) ? c1 : c0;
 }
+
+// the row accessors of csrc/zmp_k1.inc for the kernels that keep the row in a RowRegs struct `T`
+#define K1_TGET(j) T.t[(j) / 16][(j) % 16]
+#define K1_TSET(j, v) T.t[(j) / 16][(j) % 16] = (v)
+#define K1_TCOL(u) row_at_group_uniform<LG, NP>(T, (u))
 
 // K1, static pairing: QP (instance, axis) = (qp / 2, qp % 2), the two axes of an instance in the two halves of a
 // wavefront.  The steps of the iteration are the sections of csrc/zmp_k1.inc, shared with zmp_plan_kernel_dyn.
@@ -109,7 +125,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
   double * bs = smem + NP * NP; // [NP]
   double * As = bs + NP;        // [NP][3]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & (LG - 1), grp = lane / LG;
+  const int li = lane & (LG - 1), grp = lane / LG, lic = li;
   double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
   const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
@@ -176,6 +192,132 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
   }
 }
 
+#undef K1_TGET
+#undef K1_TSET
+#undef K1_TCOL
+// ... and for K1w below, which keeps it in SEPARATE sixteen-double tuples Tq0 .. Tq3: as members of one struct three or four
+// tuples stay in memory whatever the code looks like (measured on a twenty-line kernel: 512 / 640 B of scratch; separate
+// variables: none at three tuples)
+#define K1_TGET(j) (((j) / 16 == 0) ? Tq0[(j) % 16] : (((j) / 16 == 1) ? Tq1[(j) % 16] : (((j) / 16 == 2) ? Tq2[(j) % 16] : Tq3[(j) % 16])))
+#define K1_TSET(j, v)                                  \
+  do                                                   \
+  {                                                    \
+    if((j) / 16 == 0) Tq0[(j) % 16] = (v);             \
+    else if((j) / 16 == 1) Tq1[(j) % 16] = (v);        \
+    else if((j) / 16 == 2) Tq2[(j) % 16] = (v);        \
+    else Tq3[(j) % 16] = (v);                          \
+  } while(0)
+#define K1_TCOL(u) tq_col(Tq0, Tq1, Tq2, Tq3, __builtin_amdgcn_readfirstlane(u), NP)
+__device__ __forceinline__ double tq_col(const v16d & a, const v16d & b, const v16d & c, const v16d & d, int u, int np)
+{
+  double r = a[u & 15];
+  if(np > 16)
+  {
+    const double e = b[u & 15];
+    r = ((u >> 4) == 1) ? e : r;
+  }
+  if(np > 32)
+  {
+    const double e = c[u & 15];
+    r = ((u >> 4) == 2) ? e : r;
+  }
+  if(np > 48)
+  {
+    const double e = d[u & 15];
+    r = ((u >> 4) == 3) ? e : r;
+  }
+  return r;
+}
+
+// K1w.  32 < N <= NPC <= 64: ONE QP per wavefront, lane li < NPC holds row li of an NPC-column tableau in NPC / 16
+// indexable register tuples (the lanes beyond NPC idle along).  Round 5: the step from K1 to the
+// LDS tableau cost a factor of three at N = 33 (105 M -> 38 M solves/s); K1's trip is per wavefront, so a wavefront that
+// carries one 48-row QP instead of two 32-row ones should lose a factor of two and a bit, not three.  Same sections of
+// csrc/zmp_k1.inc, same arithmetic; a QP per wavefront needs no pairing, so the static schedule is all there is.
+// (Round 3 tried the 64-lane, 64-column instantiation under K1's three-wavefronts-per-SIMD register cap: the row went to
+//  scratch, 6.7 M solves/s.  Here the cap follows the row: MINW = 3 at 48 columns, 2 at 64.)
+template<int NPC, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void zmp_plan_kernel_w(ZmpDev P, int GS, long nqp, const double * __restrict__ x0,
+                                                                     const double * __restrict__ zlim, double control_dt,
+                                                                     double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                     int * __restrict__ status)
+{
+  constexpr int LG = 64, NP = NPC;
+  static_assert(NP % 16 == 0 && NP <= 64, "the row lives in 16-wide register tuples");
+  using Grp = WaveGroup<LG>;
+  using Scr = ZmpScratch<LG>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double * Gs = smem;           // [NP][NP]
+  double * bs = smem + NP * NP; // [NP]
+  double * As = bs + NP;        // [NP][3]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane, lic = li < NP ? li : NP - 1;
+  double * scr = As + 3 * NP + wave * Scr::kSize; // this wavefront's scratch
+  const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
+
+  for(int k = tid; k < NP * NP; k += WAVES * 64) Gs[k] = P.G[(size_t)(k / NP) * GS + (k % NP)];
+  for(int k = tid; k < NP; k += WAVES * 64) bs[k] = P.b[k];
+  for(int k = tid; k < 3 * NP; k += WAVES * 64) As[k] = P.A[k];
+  __syncthreads();
+
+  const int N = P.N;
+  const int maxpass = 20 * N + 100;
+  for(long qp = (long)blockIdx.x * WAVES + wave; qp < nqp; qp += (long)gridDim.x * WAVES)
+  {
+    const bool valid = true;
+    const bool row = li < N;
+    double lo, hi;
+    v16d Tq0, Tq1, Tq2, Tq3;
+    Tq0 = Tq1 = Tq2 = Tq3 = 0.0;
+    double dg, dgm;
+    double z, mu;
+    bool inW, side;
+    int p;
+    double sig;
+    int passes;
+#define K1_LOAD
+#include "zmp_k1.inc"
+#undef K1_LOAD
+    if(li >= NP) dg = dgm = 1.0; // (idle lanes: a harmless curvature for the selection key)
+    int st = CCC_STATUS_SOLVED;
+    if(Grp::any(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
+    bool done = st != CCC_STATUS_SOLVED;
+    bool need_select = true;
+#define K1_SELECT
+#include "zmp_k1.inc"
+#undef K1_SELECT
+    for(int round = 0; round < 3; ++round)
+    {
+      select_entering();
+      if(__ballot(!done) != 0ull) do
+        {
+#define K1_PIVOT
+#include "zmp_k1.inc"
+#undef K1_PIVOT
+        } while(__ballot(!done) != 0ull);
+      const bool fin = true;
+#define K1_REFINE
+#include "zmp_k1.inc"
+#undef K1_REFINE
+      done = !reopen;
+      need_select = true;
+      __builtin_amdgcn_wave_barrier();
+      if(__ballot(reopen) == 0ull) break;
+    }
+    const bool emit = true;
+#define K1_WRITE
+#include "zmp_k1.inc"
+#undef K1_WRITE
+  }
+}
+
+#undef K1_TGET
+#undef K1_TSET
+#undef K1_TCOL
+#define K1_TGET(j) T.t[(j) / 16][(j) % 16]
+#define K1_TSET(j, v) T.t[(j) / 16][(j) % 16] = (v)
+#define K1_TCOL(u) row_at_group_uniform<LG, NP>(T, (u))
+
 // K1 with a work queue per 32-lane group ("dyn").  In zmp_plan_kernel the two axes of an instance run in lock-step: a
 // wavefront spends max(pivots_x, pivots_y) trips on a pair (measured: 24.7 against a mean of 17.9 per QP).  Here every group
 // takes its QPs from a global queue on its own: when one group finishes (refinement, outputs) it fetches and sets up the
@@ -204,7 +346,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
   double * bs = smem + NP * NP; // [NP]
   double * As = bs + NP;        // [NP][3]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & (LG - 1), grp = lane / LG;
+  const int li = lane & (LG - 1), grp = lane / LG, lic = li;
   double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
   const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
@@ -949,6 +1091,10 @@ struct ccc_zmp
   int64_t env_queue_min = -1;   // CCC_ZMP_QUEUE_MIN: QPs from which the work-queue kernel runs (< 0: the measured default)
   bool env_static = false;      // CCC_ZMP_STATIC: never the work-queue kernel
   bool env_debug = false;       // CCC_ZMP_DEBUG: print the occupancy of the LDS-tableau kernels
+  int env_kw = -1;              // CCC_ZMP_KW: 0 = never the one-QP-per-wavefront register kernel (K1w) for 32 < N <= 64 (the
+                                //             default there: 39.2 / 34.1 / 28.9 / 19.2 / 17.5 M solves/s at N = 33 / 40 / 48 /
+                                //             56 / 64 against 38.6 / 33.5 / 18.9 / 16.3 / 9.7 M for K2 / K2r, batch 65536);
+                                //             2 = its 48-column build at two wavefronts per SIMD without spills (slower)
   int env_k2 = -1;              // CCC_ZMP_K2: 0 = the LDS tableau (K2) for every 32 < N <= 200, 1 = the register tiles (K2r)
                                 //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
                                 //             measured default per size
@@ -1101,6 +1247,28 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   }
+  // K1w: one QP per wavefront, the rows in register tuples (zmp_plan_kernel_w), 32 < N <= 64
+  auto go_w = [&](auto kernel, int npc, int waves) -> int {
+    const size_t lds = ((size_t)npc * npc + 4 * (size_t)npc + (size_t)waves * ZmpScratch<64>::kSize) * sizeof(double);
+    CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    int nb = 0;
+    if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, waves * 64, lds) != hipSuccess || nb < 1) nb = 2;
+    // a few workgroups per resident slot: the hardware dispatcher evens out the data-dependent pivot counts
+    const int64_t want = (nqp + waves - 1) / waves;
+    const int grid = (int)std::min<int64_t>(want, (int64_t)h->num_cu * nb * 8);
+    if(h->env_debug) std::fprintf(stderr, "zmp w kernel: %d columns, lds %zu B -> %d workgroups per CU (grid %d)\n", npc, lds, nb, grid);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(waves * 64), lds, stream, P, h->NP, (long)nqp, x0, zlim, control_dt, zmp, jerk,
+                       status);
+    h->last_kernel = "zmp_plan_kernel_w";
+    CCC_HIP_CHECK(hipGetLastError());
+    return CCC_OK;
+  };
+  if(h->N <= 64 && h->env_kw != 0)
+  {
+    if(h->N <= 48) return h->env_kw == 2 ? go_w(&zmp_plan_kernel_w<48, 4, 2>, 48, 4) : go_w(&zmp_plan_kernel_w<48, 4, 3>, 48, 4);
+    return go_w(&zmp_plan_kernel_w<64, 4, 2>, 64, 4);
+  }
   // K2r: the packed tableau in registers (csrc/zmp_k2r.inc), up to 128 rows
   auto go_reg = [&](auto kernel, auto rt) -> int {
     using RT = decltype(rt);
@@ -1229,6 +1397,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   h->env_static = std::getenv("CCC_ZMP_STATIC") != nullptr;
   h->env_debug = std::getenv("CCC_ZMP_DEBUG") != nullptr;
   if(const char * k2 = std::getenv("CCC_ZMP_K2")) h->env_k2 = std::atoi(k2);
+  if(const char * kw = std::getenv("CCC_ZMP_KW")) h->env_kw = std::atoi(kw);
   if(const char * ce = std::getenv("CCC_ZMP_HOST_CHUNK")) h->env_host_chunk = std::atoll(ce);
   build_model(h);
   hipDeviceProp_t prop;

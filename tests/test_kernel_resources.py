@@ -20,6 +20,11 @@ EXPECT = {
     "void ccc_amd::zmp_plan_kernel_dyn<32, 2>": ("zmp", 168, 3, 0, None),      # K1, work queue (headline)
     "void ccc_amd::zmp_plan_sym_kernel<40, 4, 2>": ("zmp", 128, 4, 0, None),   # K2 at 40 rows: 16 workgroups per CU
     "void ccc_amd::zmp_plan_sym_kernel<104, 4, 2>": ("zmp", 168, 3, 0, None),  # K2 at the reference test's horizon
+    # round 5: one QP per wavefront, rows in register tuples (32 < N <= 64), and the packed tableau in registers (N = 100)
+    "void ccc_amd::zmp_plan_kernel_w<64, 4, 2>": ("zmp", 256, 2, 0, None),
+    "void ccc_amd::zmp_plan_kernel_w<48, 4, 3>": ("zmp", 168, 3, 128, None),   # (28 spilled dwords at three waves per SIMD:
+    #                                                                             faster than two waves without, measured)
+    "void ccc_amd::zmp_plan_reg_kernel<104, 2>": ("zmp", 168, 3, 160, None),
     # DDP kernel (round 4: structured backward step -- no M x M object, LDS independent of the ridge stride; bound by
     # instruction issue, so the register budget is set for NO spills rather than for occupancy: csrc/ddp_tile.hip)
     "void ccc_amd::ddp_tile_kernel<9, 1>": ("ddp_tile", 256, 2, 0, 10240),

@@ -146,7 +146,8 @@ def test_device_entry_full_size_properties(mpc32):
 
 
 def test_n50_one_axis_per_wavefront_path():
-    """32 < N <= 200 runs the packed-tableau kernel (one QP per workgroup; at N = 50 a workgroup is one wavefront)."""
+    """32 < N <= 64: one QP per wavefront, the rows in registers (zmp_plan_kernel_w since round 5; before: the packed LDS
+    tableau with a one-wavefront workgroup)."""
     dt = 0.04
     mpc = LinearMpcZmp(1.0, 2.0, dt)
     assert mpc.horizon_steps_ == 50
@@ -193,6 +194,7 @@ def test_register_tile_kernel_against_the_oracle_and_the_lds_tableau(N, monkeypa
     b = fx.make_zmp_batch(384, N, dt, seed=41 + N)
     ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
     monkeypatch.setenv("CCC_ZMP_K2", "0")  # (development switches are read when a handle is created)
+    monkeypatch.setenv("CCC_ZMP_KW", "0")  # (32 < N <= 64 would otherwise run the one-QP-per-wavefront register kernel)
     lds = LinearMpcZmp(1.0, 2.0, dt)
     assert lds.horizon_steps_ == N
     r0 = lds.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
@@ -207,9 +209,29 @@ def test_register_tile_kernel_against_the_oracle_and_the_lds_tableau(N, monkeypa
         assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
         assert np.array_equal(r["pivots"], r0["pivots"]) and np.abs(r["zmp"] - r0["zmp"]).max() <= 1e-12
     monkeypatch.delenv("CCC_ZMP_K2")
+    monkeypatch.delenv("CCC_ZMP_KW")
     d = LinearMpcZmp(1.0, 2.0, dt)
     d.planOnceBatch(b["x0"][:8], b["zlim"][:8], 0.005)
-    assert d.last_kernel() == ("zmp_plan_reg_kernel" if N > 48 else "zmp_plan_sym_kernel")
+    assert d.last_kernel() == ("zmp_plan_reg_kernel" if N > 64 else "zmp_plan_kernel_w")
+
+
+@pytest.mark.parametrize("N", [33, 40, 48, 50, 56, 64])
+def test_one_qp_per_wavefront_register_kernel(N):
+    """zmp_plan_kernel_w (round 5): K1's iteration -- the sections of csrc/zmp_k1.inc -- with ONE QP per wavefront and the
+    rows in three or four sixteen-double register tuples, the default for 32 < N <= 64 (48 columns up to N = 48, 64 beyond).
+    Solved everywhere, planned ZMP and jerk sequence within the parity tolerances of the oracle, deterministic."""
+    dt = 2.0 / N
+    b = fx.make_zmp_batch(1024, N, dt, seed=7 + N)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    mpc = LinearMpcZmp(1.0, 2.0, dt)
+    assert mpc.horizon_steps_ == N
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert mpc.last_kernel() == "zmp_plan_kernel_w"
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+    r2 = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.array_equal(r2["zmp"], r["zmp"]) and np.array_equal(r2["jerk"], r["jerk"])
 
 
 def test_n200_packed_lds_tableau():
