@@ -156,6 +156,7 @@ struct alignas(16) Mem
   double alpha[12];
   double inertia[9];
   double llt[6];                       // Cholesky factor of the inertia matrix (vllt3_factor)
+  double rll[4];                       // 1 / l00, 1 / l11, 1 / l22 of that factor; 1 / mass (round 5: the solves multiply)
   unsigned char pair[80];              // (a, b), a <= b, of the entries of Vxx's upper triangle: a | b << 4
   int warm_replaced;                   // 1: the warm-start guard replaced u_init (kept here, not in a register: it is
                                        //    written once per solve and read at its end)
@@ -207,15 +208,18 @@ W64_FN void vllt3_factor(const double * I, double * L)
   L[4] = l21;
   L[5] = l22;
 }
-W64_FN void vllt3(const double * L, const vf (&b)[3], vf (&x)[3])
+// (round 5: R = the reciprocals of the factor's diagonal, formed once per instance -- the substitutions multiply; SPEC:
+//  oracle/ddp_tile.c llt3_solve)
+W64_FN void vllt3(const double * L, const double * R, const vf (&b)[3], vf (&x)[3])
 {
-  const double l00 = L[0], l10 = L[1], l20 = L[2], l11 = L[3], l21 = L[4], l22 = L[5];
-  const vf y0 = b[0] / l00;
-  const vf y1 = (b[1] - l10 * y0) / l11;
-  const vf y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
-  x[2] = y2 / l22;
-  x[1] = (y1 - l21 * x[2]) / l11;
-  x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+  const double l10 = L[1], l20 = L[2], l21 = L[4];
+  const double r00 = R[0], r11 = R[1], r22 = R[2];
+  const vf y0 = b[0] * r00;
+  const vf y1 = (b[1] - l10 * y0) * r11;
+  const vf y2 = (b[2] - l20 * y0 - l21 * y1) * r22;
+  x[2] = y2 * r22;
+  x[1] = (y1 - l21 * x[2]) * r11;
+  x[0] = (y0 - l10 * x[1] - l20 * x[2]) * r00;
 }
 
 template<int S, int B>
@@ -330,12 +334,17 @@ struct Solver
     }
     for(int e = 0; e < 12; e++) mem.alpha[e] = e < 11 ? P.alpha[e] : 0.0;
     for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12) ? I.inertia[e] : 0.0;
+    for(int e = 0; e < 3; e++) mem.rll[e] = 0.0;
     if(S == 12)
     {
       double lf[6];
       vllt3_factor(I.inertia, lf);
       for(int e = 0; e < 6; e++) mem.llt[e] = lf[e];
+      mem.rll[0] = 1.0 / lf[0];
+      mem.rll[1] = 1.0 / lf[3];
+      mem.rll[2] = 1.0 / lf[5];
     }
+    mem.rll[3] = 1.0 / P.mass;
 #if defined(CCC_TILE_PROF)
     for(int e = 0; e < TP_N; e++) mem.prof[e] = 0.0;
 #endif
@@ -411,7 +420,7 @@ struct Solver
       T.moment[k] = sumM<AB>(t);
       if(S == 12)
       {
-        for(int b = 0; b < AB; b++) t[b] = (u[b] * Rc(b, k)) / P.mass;
+        for(int b = 0; b < AB; b++) t[b] = (u[b] * Rc(b, k)) * mem.rll[3];
         T.accel[k] = sumM<AB>(t);
       }
     }
@@ -425,7 +434,7 @@ struct Solver
       // pos' = P / m, P' = -m g e_z + force, L' = moment
       const vf shifted = sel(c == 0, row_bcast<3>(x), sel(c == 1, row_bcast<4>(x), row_bcast<5>(x)));
       const vf fz = -1 * P.mass * kGravity + T.force[2];
-      xd = sel(c < 3, shifted / P.mass,
+      xd = sel(c < 3, shifted * mem.rll[3],
                sel(c == 3, T.force[0], sel(c == 4, T.force[1], sel(c == 5, fz,
                sel(c == 6, T.moment[0], sel(c == 7, T.moment[1], T.moment[2]))))));
     }
@@ -436,9 +445,10 @@ struct Solver
       vsincos(row_bcast<3>(x), sa, ca);
       vsincos(row_bcast<4>(x), sb, cb);
       // matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72
-      const vf e0 = ((ca * sb) / cb) * w0 + ((sb * sa) / cb) * w1 + 1.0 * w2;
+      const vf rcb = 1.0 / cb; // (round 5: one reciprocal, the divisions by cos(beta) multiply; SPEC: oracle/ddp_tile.c state_eq)
+      const vf e0 = ((ca * sb) * rcb) * w0 + ((sb * sa) * rcb) * w1 + 1.0 * w2;
       const vf e1 = (-1 * sa) * w0 + ca * w1 + 0.0 * w2;
-      const vf e2 = (ca / cb) * w0 + (sa / cb) * w1 + 0.0 * w2;
+      const vf e2 = (ca * rcb) * w0 + (sa * rcb) * w1 + 0.0 * w2;
       const double * In = mem.inertia;
       const vf Iw0 = In[0] * w0 + In[1] * w1 + In[2] * w2;
       const vf Iw1 = In[3] * w0 + In[4] * w1 + In[5] * w2;
@@ -446,7 +456,7 @@ struct Solver
       const vf cw0 = w1 * Iw2 - w2 * Iw1, cw1 = w2 * Iw0 - w0 * Iw2, cw2 = w0 * Iw1 - w1 * Iw0;
       const vf wd[3] = {-1 * cw0 + T.moment[0], -1 * cw1 + T.moment[1], -1 * cw2 + T.moment[2]};
       vf sol[3];
-      vllt3(mem.llt, wd, sol);
+      vllt3(mem.llt, mem.rll, wd, sol);
       const vf az = -1 * kGravity + T.accel[2];
       const vf vshift = sel(c == 0, row_bcast<6>(x), sel(c == 1, row_bcast<7>(x), row_bcast<8>(x)));
       xd = sel(c < 3, vshift,
@@ -506,10 +516,10 @@ struct Solver
       for(int b = 0; b < AB; b++)
       {
         vf sol[3];
-        vllt3(mem.llt, T.cr[b], sol);
+        vllt3(mem.llt, mem.rll, T.cr[b], sol);
         for(int k = 0; k < 3; k++)
         {
-          Fu[b][k] = (Rc(b, k) / P.mass) * dt;
+          Fu[b][k] = (Rc(b, k) * mem.rll[3]) * dt;
           Fu[b][3 + k] = sol[k] * dt;
         }
       }
@@ -532,8 +542,8 @@ struct Solver
         // column b of I^-1 d(-w x I w)/dw -> block (9, 9); column b of I^-1 crossMat(totalForce) -> block (9, 0)
         const vf colD[3] = {D[b], D[3 + b], D[6 + b]}, colC[3] = {CM[b], CM[3 + b], CM[6 + b]};
         vf sD[3], sC[3];
-        vllt3(mem.llt, colD, sD);
-        vllt3(mem.llt, colC, sC);
+        vllt3(mem.llt, mem.rll, colD, sD);
+        vllt3(mem.llt, mem.rll, colC, sC);
         for(int a = 0; a < 3; a++)
         {
           st(mem.Fx, spl((9 + a) * S + 9 + b), sD[a] * dt, first);
@@ -543,16 +553,16 @@ struct Solver
       vf sa, ca, sb, cb;
       vsincos(row_bcast<3>(x), sa, ca);
       vsincos(row_bcast<4>(x), sb, cb);
-      const vf cb2 = cb * cb, sb2 = sb * sb;
+      const vf sb2 = sb * sb, rcb = 1.0 / cb, rcb2 = rcb * rcb; // (round 5: SPEC oracle/ddp_tile.c state_eq_deriv)
       for(int a = 0; a < 3; a++) st(mem.Fx, spl(a * S + 6 + a), splat(1.0 * dt), first);
-      const vf K[9] = {(ca * sb) / cb, (sb * sa) / cb, splat(1.0), -1 * sa, ca, zero, ca / cb, sa / cb, zero};
+      const vf K[9] = {(ca * sb) * rcb, (sb * sa) * rcb, splat(1.0), -1 * sa, ca, zero, ca * rcb, sa * rcb, zero};
       for(int a = 0; a < 3; a++)
         for(int b = 0; b < 3; b++) st(mem.Fx, spl((3 + a) * S + 9 + b), K[a * 3 + b] * dt, first);
-      st(mem.Fx, spl(3 * S + 3), (-w1 * sa * sb / cb + w2 * sb * ca / cb) * dt, first);
+      st(mem.Fx, spl(3 * S + 3), (-w1 * sa * sb * rcb + w2 * sb * ca * rcb) * dt, first);
       st(mem.Fx, spl(4 * S + 3), (-w1 * ca - w2 * sa) * dt, first);
-      st(mem.Fx, spl(5 * S + 3), (-w1 * sa / cb + w2 * ca / cb) * dt, first);
-      st(mem.Fx, spl(3 * S + 4), (w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa) * dt, first);
-      st(mem.Fx, spl(5 * S + 4), (w1 * sb * ca / cb2 + w2 * sa * sb / cb2) * dt, first);
+      st(mem.Fx, spl(5 * S + 3), (-w1 * sa * rcb + w2 * ca * rcb) * dt, first);
+      st(mem.Fx, spl(3 * S + 4), (w1 * sb2 * ca * rcb2 + w1 * ca + w2 * sa * sb2 * rcb2 + w2 * sa) * dt, first);
+      st(mem.Fx, spl(5 * S + 4), (w1 * sb * ca * rcb2 + w2 * sa * sb * rcb2) * dt, first);
     }
     wave_sync();
     // diagonal: entry * dt + 1
@@ -800,8 +810,13 @@ struct Solver
   // H = Quu_F in the structured form above.  x enters as the warm start.  On success (result >= 1) x is the minimiser,
   // freemask the free ridges (empty when everything is clamped) and mem.Cf / mem.Minv belong to that set.
   template<int AB>
-  CCC_TILE_PIECE int box_qp(const Qp & Q, const vf (&q)[B], const vf (&lo)[B], const vf (&hi)[B], vf (&x)[B], mask_t & freemask)
+  CCC_TILE_PIECE int box_qp(const Qp & Q, const vf (&q)[B], vf (&x)[B], mask_t & freemask)
   {
+    // (the bounds lo = flo - u, hi = fhi - u of the ridges in range are formed where they are used, from Q.u, instead of
+    //  being held through the iteration -- two or four registers per block of ridges at the point where the kernel's register
+    //  pressure peaks; every use is masked by Q.in, beyond the step's dimension the values do not matter)
+    auto lo_of = [&](int b) { return P.flo - Q.u[b]; };
+    auto hi_of = [&](int b) { return P.fhi - Q.u[b]; };
     const double min_grad = 1e-8, min_rel_improve = 1e-8, step_dec = 0.6, min_step = 1e-22, armijo = 0.1;
     const int max_iter = 500; // nmpc_ddp BoxQP::Configuration::max_iter
     const int m = Q.m;
@@ -810,7 +825,7 @@ struct Solver
     {
       cl[b] = lane < 0; // all false
       fr[b] = lane < 0;
-      x[b] = sel(Q.in[b], vmin(vmax(x[b], lo[b]), hi[b]), 0.0);
+      x[b] = sel(Q.in[b], vmin(vmax(x[b], lo_of(b)), hi_of(b)), 0.0);
     }
     const mask_t inmask = (m >= M) ? kAll : static_cast<mask_t>((static_cast<mask_t>(1) << m) - 1u);
     // value(y) = sum_c y_c q_c + 1/2 y_c (H y)_c.  SPEC: gy = G y (six sums, treeM); vy = V6r gy (apply6); (H y)_r =
@@ -876,7 +891,7 @@ struct Solver
       {
         grad[b] = q[b] + hy[b];
         const vb oldc = cl[b];
-        cl[b] = Q.in[b] && (((x[b] == lo[b]) && (grad[b] > 0.0)) || ((x[b] == hi[b]) && (grad[b] < 0.0)));
+        cl[b] = Q.in[b] && (((x[b] == lo_of(b)) && (grad[b] > 0.0)) || ((x[b] == hi_of(b)) && (grad[b] < 0.0)));
         diff[b] = cl[b] != oldc;
       }
       const mask_t clmask = ballotM<AB>(cl) & inmask;
@@ -954,7 +969,7 @@ struct Solver
         const double s1 = step * step_dec, s2 = s1 * step_dec, s3 = s2 * step_dec;
         const vf stepv = sel(g == 0, splat(step), sel(g == 1, splat(s1), sel(g == 2, splat(s2), splat(s3))));
         vf xc4[B], hy4[B];
-        for(int b = 0; b < AB; b++) xc4[b] = sel(Q.in[b], vmin(vmax(x[b] + stepv * srch[b], lo[b]), hi[b]), 0.0);
+        for(int b = 0; b < AB; b++) xc4[b] = sel(Q.in[b], vmin(vmax(x[b] + stepv * srch[b], lo_of(b)), hi_of(b)), 0.0);
         const vf vc4 = value_of4(xc4, hy4);
         const vb pass = !(((vc4 - oldvalue) / (stepv * sdotg)) < armijo);
         const vb stop = pass || ((stepv * step_dec) < min_step);
@@ -1078,15 +1093,10 @@ struct Solver
     mask_t freemask = 0;
     if(m > 0)
     {
-      vf lo[B], hi[B];
-      for(int b = 0; b < AB; b++)
-      {
-        lo[b] = sel(Q.in[b], P.flo - u[b], 0.0);
-        hi[b] = sel(Q.in[b], P.fhi - u[b], 0.0);
-        // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change)
-        k[b] = (mprev == m) ? kprev[b] : splat(0.0);
-      }
-      const int rc = box_qp<AB>(Q, Qu, lo, hi, k, freemask);
+      // warm start: the feed-forward of step i + 1 of this pass (zeros for the last step or on a dimension change); the
+      // bounds force_lo - u, force_hi - u are formed inside from Q.u
+      for(int b = 0; b < AB; b++) k[b] = (mprev == m) ? kprev[b] : splat(0.0);
+      const int rc = box_qp<AB>(Q, Qu, k, freemask);
       if(rc < 1) return false;
       TILE_PROF_ADD(TP_OTHER); // (the box-QP accounts for itself: this slice is its entry and exit)
       for(int b = 0; b < AB; b++) fr[b] = row_in(freemask, b);

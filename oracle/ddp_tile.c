@@ -55,7 +55,12 @@ static void cross3(const double * a, const double * b, double * c)
   c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-/* Eigen::LLT<Matrix3d>::solve, src/DdpSingleRigidBody.cpp:88,122-123 (as ddp_models.c) */
+/* Eigen::LLT<Matrix3d>::solve, src/DdpSingleRigidBody.cpp:88,122-123: the factor as ddp_models.c forms it; the six
+ * divisions of the two substitutions are MULTIPLICATIONS by the reciprocals of the factor's diagonal (round 5: the
+ * single-rigid-body derivatives solve with this factor nine times per backward step, on the device 57 IEEE divisions of
+ * ~28 instructions each -- a fifth of a median solve's time; the inertia matrix is constant over an instance, so the
+ * three reciprocals are formed once).  SPEC: r_kk = 1 / l_kk; y0 = b0 r00; y1 = (b1 - l10 y0) r11; y2 = (b2 - l20 y0 - l21
+ * y1) r22; x2 = y2 r22; x1 = (y1 - l21 x2) r11; x0 = (y0 - l10 x1 - l20 x2) r00. */
 static void llt3_solve(const double * I, const double * b, double * x)
 {
   const double l00 = sqrt(I[0]);
@@ -63,12 +68,13 @@ static void llt3_solve(const double * I, const double * b, double * x)
   const double l11 = sqrt(I[4] - l10 * l10);
   const double l21 = (I[7] - l20 * l10) / l11;
   const double l22 = sqrt(I[8] - l20 * l20 - l21 * l21);
-  const double y0 = b[0] / l00;
-  const double y1 = (b[1] - l10 * y0) / l11;
-  const double y2 = (b[2] - l20 * y0 - l21 * y1) / l22;
-  x[2] = y2 / l22;
-  x[1] = (y1 - l21 * x[2]) / l11;
-  x[0] = (y0 - l10 * x[1] - l20 * x[2]) / l00;
+  const double r00 = 1.0 / l00, r11 = 1.0 / l11, r22 = 1.0 / l22;
+  const double y0 = b[0] * r00;
+  const double y1 = (b[1] - l10 * y0) * r11;
+  const double y2 = (b[2] - l20 * y0 - l21 * y1) * r22;
+  x[2] = y2 * r22;
+  x[1] = (y1 - l21 * x[2]) * r11;
+  x[0] = (y0 - l10 * x[1] - l20 * x[2]) * r00;
 }
 
 typedef struct
@@ -127,6 +133,7 @@ static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, c
     const double d[3] = {T->V[r][0] - x[0], T->V[r][1] - x[1], T->V[r][2] - x[2]};
     cross3(d, T->R[r], T->cr[r]);
   }
+  const double inv_mass = 1.0 / m->mass;
   for(int k = 0; k < 3; k++)
   {
     double t[MMAX];
@@ -134,7 +141,7 @@ static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, c
     T->force[k] = treeM(t, M_);
     for(int r = 0; r < M_; r++) t[r] = u[r] * T->cr[r][k];
     T->moment[k] = treeM(t, M_);
-    for(int r = 0; r < M_; r++) t[r] = (u[r] * T->R[r][k]) / m->mass;
+    for(int r = 0; r < M_; r++) t[r] = (u[r] * T->R[r][k]) * inv_mass; /* (round 5: x (1 / mass), not / mass) */
     T->accel[k] = treeM(t, M_);
   }
 }
@@ -145,7 +152,8 @@ static void state_eq(const oracle_ddp_model_t * m, const terms_t * T, const doub
   if(m->model == 0)
   {
     double xd[9];
-    for(int a = 0; a < 3; a++) xd[a] = x[3 + a] / m->mass;
+    const double inv_mass = 1.0 / m->mass;
+    for(int a = 0; a < 3; a++) xd[a] = x[3 + a] * inv_mass;
     xd[3] = T->force[0];
     xd[4] = T->force[1];
     xd[5] = -1 * m->mass * G_ + T->force[2];
@@ -160,10 +168,12 @@ static void state_eq(const oracle_ddp_model_t * m, const terms_t * T, const doub
     for(int a = 0; a < 3; a++) xd[a] = x[6 + a];
     oracle_det_sincos(x[3], &sa, &ca);
     oracle_det_sincos(x[4], &sb, &cb);
-    /* matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72 */
-    xd[3] = ((ca * sb) / cb) * w[0] + ((sb * sa) / cb) * w[1] + 1.0 * w[2];
+    /* matAngularVelToEulerDot(ori) * angular_vel, src/DdpSingleRigidBody.cpp:26-38,72; the divisions by cos(beta) as
+     * multiplications by ONE reciprocal (round 5) */
+    const double rcb = 1.0 / cb;
+    xd[3] = ((ca * sb) * rcb) * w[0] + ((sb * sa) * rcb) * w[1] + 1.0 * w[2];
     xd[4] = (-1 * sa) * w[0] + ca * w[1] + 0.0 * w[2];
-    xd[5] = (ca / cb) * w[0] + (sa / cb) * w[1] + 0.0 * w[2];
+    xd[5] = (ca * rcb) * w[0] + (sa * rcb) * w[1] + 0.0 * w[2];
     xd[6] = T->accel[0];
     xd[7] = T->accel[1];
     xd[8] = -1 * G_ + T->accel[2];
@@ -233,13 +243,14 @@ static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, cons
   else
   {
     const double * I = m->inertia;
+    const double inv_mass = 1.0 / m->mass;
     for(int r = 0; r < M_; r++)
     {
       double sol[3];
       llt3_solve(I, T->cr[r], sol);
       for(int k = 0; k < 3; k++)
       {
-        Fu[k][r] = (T->R[r][k] / m->mass) * dt;
+        Fu[k][r] = (T->R[r][k] * inv_mass) * dt;
         Fu[3 + k][r] = sol[k] * dt;
       }
     }
@@ -270,16 +281,18 @@ static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, cons
     double sa, ca, sb, cb;
     oracle_det_sincos(x[3], &sa, &ca);
     oracle_det_sincos(x[4], &sb, &cb);
-    const double cb2 = cb * cb, sb2 = sb * sb;
+    /* (round 5: rcb = 1 / cos(beta) once, rcb2 = rcb rcb; every "/ cb" and "/ cb2" of src/DdpSingleRigidBody.cpp:140-185 a
+     *  multiplication, the products otherwise left to right as written there) */
+    const double sb2 = sb * sb, rcb = 1.0 / cb, rcb2 = rcb * rcb;
     for(int a = 0; a < 3; a++) Fx[a * S + 6 + a] = 1.0 * dt;
-    const double K[9] = {(ca * sb) / cb, (sb * sa) / cb, 1.0, -1 * sa, ca, 0.0, ca / cb, sa / cb, 0.0};
+    const double K[9] = {(ca * sb) * rcb, (sb * sa) * rcb, 1.0, -1 * sa, ca, 0.0, ca * rcb, sa * rcb, 0.0};
     for(int a = 0; a < 3; a++)
       for(int b = 0; b < 3; b++) Fx[(3 + a) * S + 9 + b] = K[a * 3 + b] * dt;
-    Fx[3 * S + 3] = (-w1 * sa * sb / cb + w2 * sb * ca / cb) * dt;
+    Fx[3 * S + 3] = (-w1 * sa * sb * rcb + w2 * sb * ca * rcb) * dt;
     Fx[4 * S + 3] = (-w1 * ca - w2 * sa) * dt;
-    Fx[5 * S + 3] = (-w1 * sa / cb + w2 * ca / cb) * dt;
-    Fx[3 * S + 4] = (w1 * sb2 * ca / cb2 + w1 * ca + w2 * sa * sb2 / cb2 + w2 * sa) * dt;
-    Fx[5 * S + 4] = (w1 * sb * ca / cb2 + w2 * sa * sb / cb2) * dt;
+    Fx[5 * S + 3] = (-w1 * sa * rcb + w2 * ca * rcb) * dt;
+    Fx[3 * S + 4] = (w1 * sb2 * ca * rcb2 + w1 * ca + w2 * sa * sb2 * rcb2 + w2 * sa) * dt;
+    Fx[5 * S + 4] = (w1 * sb * ca * rcb2 + w2 * sa * sb * rcb2) * dt;
   }
   for(int a = 0; a < S; a++) Fx[a * S + a] = Fx[a * S + a] + 1.0;
 }
