@@ -77,15 +77,16 @@ struct DdpSched
   // previous busy time and every solve runs to completion on the wavefront that took it, no slices, no suspensions
   // (measured: config 3 62.6 -> 56.1 ms, config 5's shape 158.5 -> 144.3 ms).  Whether the history predicts anything is
   // checked on the device: every finishing instance compares its busy time with the previous call's, and a launch whose
-  // predecessor agreed on fewer than 70 % of the instances (a caller whose batches are unrelated) falls back to the
-  // estimate-driven slices above.  Answers do not depend on the schedule (bit-identical, tested).
+  // predecessor saw fewer than half of its predicted-longest tenth come in long again (a caller whose batches are
+  // unrelated) falls back to the estimate-driven slices above.  Answers do not depend on the schedule (bit-identical, tested).
   float * prev;        // [cap] busy ticks (100 MHz) of instance b in this launch, written when it finishes; read as the
                        //       previous call's while it runs
   int * order;         // [cap] instance handed out with fresh ticket t (ddp_order_kernel)
-  int * trust;         // [2]   trust[0]: 1 = this launch follows the history (set by ddp_order_kernel); trust[1]: instances
-                       //       of the running launch whose busy time fell within one bucket of the previous call's
+  int * trust;         // [4]   [0]: 1 = this launch follows the history (set by ddp_order_kernel); [1] / [2]: instances of the
+                       //       running launch that the history put in the longest tenth / that came in long again; [3]: the
+                       //       bucket where that tenth begins
   int use_history;     // 0: no history for this batch size; 1: the previous call had the same size; 2: ... and the one before
-                       //    (so trust[1] is a verdict on the history, and the order kernel asks for 70 %)
+                       //    (so trust[1 .. 2] are a verdict on the history)
 };
 // bytes of device memory behind a DdpSched for `cap` instances, and its carving
 size_t ddp_sched_bytes(long cap, int N, int S);

@@ -67,15 +67,25 @@ __global__ __launch_bounds__(1024) void ddp_order_kernel(const float * prev, lon
   __syncthreads();
   if(t == 0)
   {
-    // follow the history unless the previous launch, which could check it, found it wrong (check = 0: nothing to go by yet)
-    trust[0] = (!check || 10L * trust[1] >= 7L * n) ? 1 : 0;
+    // Follow the history unless the previous launch, which could check it, found it wrong (check = 0: nothing to go by
+    // yet).  What the order needs from the history is the TAIL: an instance that was among the longest tenth is long
+    // again.  The previous launch counted, of the instances its own history put in that tenth (trust[1]), how many came in
+    // within two buckets (a factor 1.4) below the tenth's threshold or above (trust[2]); a repeated batch scores ~1, an
+    // unrelated one the tail's share of the distribution (~0.2).  (The bulk says nothing either way: most solves of a batch
+    // lie within a factor two of its median whatever the batch, and the busy time of a median solve moves by a bucket with
+    // the company it keeps on its SIMD.)
+    trust[0] = (!check || 2 * trust[2] >= trust[1]) ? 1 : 0;
     trust[1] = 0;
+    trust[2] = 0;
     unsigned acc = 0u;
+    int tail = kDdpSchedBuckets - 1;
     for(int k = kDdpSchedBuckets - 1; k >= 0; k--) // descending: the highest bucket gets the first tickets
     {
       base[k] = acc;
       acc += hist[k];
+      if(10L * acc <= n) tail = k; // (the lowest bucket with at most a tenth of the instances at or above it)
     }
+    trust[3] = tail;
   }
   __syncthreads();
   for(long i = t; i < n; i += 1024)
@@ -211,8 +221,12 @@ __global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE
           const float busy = (float)(tsv[4] + (double)((long long)wall_clock64() - tt0));
           if(Sc.use_history != 0)
           {
-            const int d = sched_bucket((long long)busy) - sched_bucket((long long)Sc.prev[b]);
-            if(d >= -1 && d <= 1) atomicAdd(Sc.trust + 1, 1);
+            const int tail = Sc.trust[3];
+            if(sched_bucket((long long)Sc.prev[b]) >= tail)
+            {
+              atomicAdd(Sc.trust + 1, 1);
+              if(sched_bucket((long long)busy) >= tail - 2) atomicAdd(Sc.trust + 2, 1);
+            }
           }
           Sc.prev[b] = busy;
           atomicAdd(Sc.finished, 1u);
@@ -252,7 +266,7 @@ int ddp_tile_grid(long n, int M, int num_cu)
   return (int)(n < resident ? n : resident);
 }
 
-// layout behind a DdpSched: [ticket, finished, trust x 2, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8]
+// layout behind a DdpSched: [ticket, finished, trust x 4, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8]
 // [save_x cap x (N+1) S][prev cap][order cap]
 static size_t sched_off_slot() { return (size_t)(64 + 2 * kDdpSchedBuckets) * 4; }
 static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 4 + 255) / 256 * 256; }
@@ -272,7 +286,7 @@ DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
   sc.save_x = reinterpret_cast<double *>(base + sched_off_x(cap));
   sc.prev = reinterpret_cast<float *>(base + sched_off_prev(cap, N, S));
   sc.order = reinterpret_cast<int *>(sc.prev + cap);
-  sc.trust = reinterpret_cast<int *>(base) + 2; // (words 2, 3 of the header: NOT reset with the counters)
+  sc.trust = reinterpret_cast<int *>(base) + 2; // (words 2 .. 5 of the header: NOT reset with the counters)
   sc.cap = cap;
   sc.slice = 0;
   sc.slice_next = 0;
