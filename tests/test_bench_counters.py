@@ -1,0 +1,63 @@
+"""CPU tests of the counter replay of the bench lines (bench.py / bench_secondary.py): a counter
+needs rocprofv3 around the process, so `roofline.traffic` and the VALU shares are REPLAYED from the committed summaries in
+profiles/ -- and only when the summary was made from the kernel sources the running library was built from
+(centroidalcontrolcollection_amd.build.kernel_hash).  No GPU, no oracle."""
+import json
+import os
+
+import pytest
+
+from centroidalcontrolcollection_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernel_hash_follows_the_sources_of_its_workload_only(tmp_path, monkeypatch):
+    h = {w: build.kernel_hash(w) for w in ("zmp", "xy", "ddp", "srb", "walk", "multi")}
+    assert all(isinstance(v, str) and len(v) == 16 for v in h.values())
+    assert h["ddp"] == h["srb"] == h["walk"] == h["multi"] and len({h["zmp"], h["xy"], h["ddp"]}) == 3
+    assert build.kernel_hash("no-such-workload") is None
+    # a copy of csrc/ with one byte more in zmp_k1.inc: the headline's hash moves, the others stay
+    import shutil
+
+    csrc = tmp_path / "csrc"
+    shutil.copytree(build.CSRC, csrc)
+    with open(csrc / "zmp_k1.inc", "a") as f:
+        f.write("\n")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    assert build.kernel_hash("zmp") != h["zmp"] and build.kernel_hash("xy") == h["xy"] and build.kernel_hash("ddp") == h["ddp"]
+
+
+def test_committed_summaries_belong_to_the_tree():
+    """The summaries the bench lines replay from were collected on THIS tree's kernels (a round that changes a kernel after
+    profiling it must profile again, or its lines report null)."""
+    for name, keys in (("zmp_hbm_traffic.json", None), ("zmp_valu_counters.json", None)):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d.get("kernel_hash") == build.kernel_hash("zmp"), name
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")))
+    for w in ("xy", "ddp", "srb", "walk", "multi"):
+        assert tr[w]["kernel_hash"] == build.kernel_hash(w), w
+    assert json.load(open(os.path.join(ROOT, "profiles", "r05_ddp_valu_counters.json")))["kernel_hash"] == build.kernel_hash("ddp")
+
+
+def test_counters_of_another_build_are_refused(monkeypatch):
+    torch = pytest.importorskip("torch")  # (bench_secondary imports it at module level; nothing here touches a device)
+    del torch
+    import bench
+    import bench_secondary
+
+    got, src = bench_secondary.replayed_counters("xy", 65536)
+    assert got is not None and got > 1e10 and "replayed" in src and build.kernel_hash("xy") in src
+    assert bench_secondary.replayed_counters("xy", 12345) == (None, None)  # (no summary for that batch size)
+    t, tsrc = bench.measured_traffic(65536)
+    assert t is not None and "replayed" in tsrc
+    assert bench.valu_counters(65536) is not None
+    # the same questions asked by a library built from other sources
+    monkeypatch.setattr(build, "kernel_hash", lambda w: "0123456789abcdef")
+    got, src = bench_secondary.replayed_counters("xy", 65536)
+    assert got is None and "refused" in src and "0123456789abcdef" in src
+    t, tsrc = bench.measured_traffic(65536)
+    assert t is None and "refused" in tsrc
+    assert bench.valu_counters(65536) is None
+    v = bench_secondary._ddp_valu(9, 16, 100, 16.8, False)
+    assert v["simd_valu_busy_frac"] is None and "refused" in v["counters_source"]
