@@ -1289,8 +1289,22 @@ struct Solver
 #ifdef CCC_TILE_NO_PREFETCH_K
   static constexpr bool kPrefetchK = false;
 #else
-  static constexpr bool kPrefetchK = (B == 1); // the gain rows of the next step fetched a step ahead (registers permitting)
+  static constexpr bool kPrefetchK = (B == 1); // the gain rows are fetched ahead with the step's other operands (at 32 and
+                                                // 64 ridges per step they are loaded in the step: fetched ahead, 36 / 72
+                                                // more registers cost more than the wait -- measured, 64 ridges 46.9 -> 49.8 ms)
 #endif
+  // steps the forward pass fetches ahead (see forward_pass)
+#ifdef CCC_TILE_FWD_DEPTH
+  static constexpr int kFwdDepth = CCC_TILE_FWD_DEPTH;
+#else
+  static constexpr int kFwdDepth = (B == 1 && S == 9) ? 2 : 1; // (S = 12: a second buffer spills 42 dwords for no gain, measured)
+#endif
+  struct FwdOps
+  {
+    int ph, m;
+    vf xi, ui[B], ki[B];
+    vf Kr[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
+  };
   // one step of the rollouts with the first AB <= B blocks of 16 ridges live (the further ones are written as zeros)
   template<int AB>
   W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, const vf (&ui)[B], const vf (&ki)[B],
@@ -1337,63 +1351,57 @@ struct Solver
     vf x = ldm(I.x0, c, inS);
     vf costc = splat(0.0);
     st(I.xbuf, xoff + c, x, inS);
-    // the operands of step i + 1 are fetched while step i computes
-    int ph_n = phase_of(0), m_n = dim_of_phase(ph_n);
-    vf xi_n = ldm(xs, c, inS), ui_n[B], ki_n[B];
-    vf Kr_n[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
-    for(int b = 0; b < B; b++)
-    {
-      const vb inn = c + 16 * b < m_n;
-      ui_n[b] = ldm(us, c + 16 * b, inn);
-      ki_n[b] = ldm(I.ks, c + 16 * b, inn);
-      if constexpr(kPrefetchK)
-        for(int a = 0; a < S; a++) Kr_n[b][a] = ldm(I.Ks, (c + 16 * b) * S + a, inn);
-    }
-    for(int i = 0; i < N; i++)
-    {
-      const int m = m_n, ph = ph_n;
-      vf ui[B], ki[B];
-      vf Krp[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
-      const vf xi = xi_n;
+    // The operands of step i + kFwdDepth are fetched while step i computes: the gains of an instance (115 KB at 100 steps
+    // of 16 ridges) were written by the backward pass and come back from HBM.  Round 5: two steps ahead instead of one at 16
+    // ridges (config 3 52.2 -> 51.2 ms; three steps ahead: 54.7 ms, the third buffer spills).  Explicit buffers o0 .. o2
+    // taken in turn by a loop unrolled by the depth: indexed by a constant, registers.  Same loads, same arithmetic, same
+    // order: the same bits.
+    FwdOps o0, o1, o2;
+    auto fetch = [&](int i, FwdOps & o) {
+      o.ph = phase_of(i);
+      o.m = dim_of_phase(o.ph);
+      o.xi = ldm(xs + static_cast<long>(i) * S, c, inS);
       for(int b = 0; b < B; b++)
       {
-        ui[b] = ui_n[b];
-        ki[b] = ki_n[b];
+        const vb inn = c + 16 * b < o.m;
+        o.ui[b] = ldm(us + static_cast<long>(i) * M, c + 16 * b, inn);
+        o.ki[b] = ldm(I.ks + static_cast<long>(i) * M, c + 16 * b, inn);
         if constexpr(kPrefetchK)
-          for(int a = 0; a < S; a++) Krp[b][a] = Kr_n[b][a];
+          for(int a = 0; a < S; a++) o.Kr[b][a] = ldm(I.Ks + static_cast<long>(i) * M * S, (c + 16 * b) * S + a, inn);
       }
-      if(i + 1 < N)
-      {
-        ph_n = phase_of(i + 1);
-        m_n = dim_of_phase(ph_n);
-        xi_n = ldm(xs + static_cast<long>(i + 1) * S, c, inS);
-        for(int b = 0; b < B; b++)
-        {
-          const vb inn = c + 16 * b < m_n;
-          ui_n[b] = ldm(us + static_cast<long>(i + 1) * M, c + 16 * b, inn);
-          ki_n[b] = ldm(I.ks + static_cast<long>(i + 1) * M, c + 16 * b, inn);
-          if constexpr(kPrefetchK)
-            for(int a = 0; a < S; a++) Kr_n[b][a] = ldm(I.Ks + static_cast<long>(i + 1) * M * S, (c + 16 * b) * S + a, inn);
-        }
-      }
+    };
+    auto run = [&](int i, FwdOps & o) {
+      // (the step's operands by value, then the buffer is free for the fetch of step i + kFwdDepth)
+      const FwdOps cur = o;
+      if(i + kFwdDepth < N) fetch(i + kFwdDepth, o);
+      const int m = cur.m, ph = cur.ph;
       if constexpr(B == 1)
-        forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+        forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
       else if constexpr(B == 2)
       {
         if(m <= 16)
-          forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
         else
-          forward_step<2>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
       }
       else
       {
         if(m <= 16)
-          forward_step<1>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
         else if(m <= 32)
-          forward_step<2>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
         else
-          forward_step<4>(i, m, ph, alpha, xoff, uoff, xi, ui, ki, Krp, x, costc);
+          forward_step<4>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
       }
+    };
+    fetch(0, o0);
+    if(kFwdDepth > 1 && 1 < N) fetch(1, o1);
+    if(kFwdDepth > 2 && 2 < N) fetch(2, o2);
+    for(int i = 0; i < N; i += kFwdDepth)
+    {
+      run(i, o0);
+      if(kFwdDepth > 1 && i + 1 < N) run(i + 1, o1);
+      if(kFwdDepth > 2 && i + 2 < N) run(i + 2, o2);
     }
     const vf total = costc + terminal_cost(x);
     TILE_PROF_ADD(TP_FORWARD);
