@@ -86,6 +86,11 @@ enum
   TP_F_GJ,
   TP_F_UPD,   // cycles in rank-one updates (qp_update), and their number
   TP_F_UPDS,
+  TP_FW_FETCH, // forward step (development aid): issue of the fetches, feedback + input store, running cost, terms, state
+  TP_FW_FEED,
+  TP_FW_COST,
+  TP_FW_TERMS,
+  TP_FW_STATE,
   TP_N
 };
 #if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -157,6 +162,8 @@ struct alignas(16) Mem
   double inertia[9];
   double llt[6];                       // Cholesky factor of the inertia matrix (vllt3_factor)
   double rll[4];                       // 1 / l00, 1 / l11, 1 / l22 of that factor; 1 / mass (round 5: the solves multiply)
+  static constexpr int kStepTable = 256;
+  unsigned short stepinfo[kStepTable]; // (phase << 7) | ridges of the horizon's steps (round 5: see Solver::step_info)
   unsigned char pair[80];              // (a, b), a <= b, of the entries of Vxx's upper triangle: a | b << 4
   int warm_replaced;                   // 1: the warm-start guard replaced u_init (kept here, not in a register: it is
                                        //    written once per solve and read at its end)
@@ -345,6 +352,17 @@ struct Solver
       mem.rll[2] = 1.0 / lf[5];
     }
     mem.rll[3] = 1.0 / P.mass;
+    // the steps' phases and ridge counts (step_info): lane l looks up the steps l, l + 64, ...
+    for(int e = 0; e < P.N && e < Mem<S, B>::kStepTable; e += 64)
+    {
+      const vb ok = (lane + e < P.N) && (lane + e < Mem<S, B>::kStepTable);
+      const vi st_ = seli(ok, lane + e, spl(0));
+      vi ph = ldi(I.step_phase, st_);
+      ph = seli(ph < 0, spl(0), seli(ph >= P.P, spl(P.P - 1), ph));
+      vi dm = ldi(I.phase_dim, ph);
+      dm = seli(dm < 0, spl(0), seli(dm > M, spl(M), dm));
+      sth(mem.stepinfo, st_, (ph << 7) | dm, ok);
+    }
 #if defined(CCC_TILE_PROF)
     for(int e = 0; e < TP_N; e++) mem.prof[e] = 0.0;
 #endif
@@ -352,6 +370,24 @@ struct Solver
     wave_sync();
   }
 
+  // Phase and ridge count of a step.  Round 5: from an LDS table filled once per solve (init()) -- the two look-ups are
+  // DEPENDENT scalar loads from global memory (step_phase[step], then phase_dim[phase]), and the operand fetches of the
+  // forward and backward passes cannot be issued before both have returned: measured, 1.4-1.9 k of the 3.3-4.0 k cycles of a
+  // forward step on a lone wavefront were the issue of its prefetch.  Horizons beyond the table take the loads.
+  W64_FN void step_info(int step, int & ph, int & m) const
+  {
+    if(step < Mem<S, B>::kStepTable && P.P <= 512)
+    {
+      const int pm = uniform_i(static_cast<int>(mem.stepinfo[step]));
+      ph = pm >> 7;
+      m = pm & 0x7f;
+    }
+    else
+    {
+      ph = phase_of(step);
+      m = dim_of_phase(ph);
+    }
+  }
   W64_FN int phase_of(int step) const
   {
     const int p = I.step_phase[step];
@@ -1253,7 +1289,8 @@ struct Solver
     for(int b = 0; b < B; b++) kprev[b] = splat(0.0);
     int mprev = -1;
     // the operands of step i - 1 are fetched while step i computes
-    int ph_n = phase_of(N - 1), m_n = dim_of_phase(ph_n);
+    int ph_n, m_n;
+    step_info(N - 1, ph_n, m_n);
     vf x_n = ldm(xs + static_cast<long>(N - 1) * S, c, inS);
     vf u_n[B];
     for(int b = 0; b < B; b++) u_n[b] = ldm(us + static_cast<long>(N - 1) * M, c + 16 * b, c + 16 * b < m_n);
@@ -1265,8 +1302,7 @@ struct Solver
       const vf x = x_n;
       if(i > 0)
       {
-        ph_n = phase_of(i - 1);
-        m_n = dim_of_phase(ph_n);
+        step_info(i - 1, ph_n, m_n);
         x_n = ldm(xs + static_cast<long>(i - 1) * S, c, inS);
         for(int b = 0; b < B; b++) u_n[b] = ldm(us + static_cast<long>(i - 1) * M, c + 16 * b, c + 16 * b < m_n);
       }
@@ -1310,6 +1346,7 @@ struct Solver
   W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, const vf (&ui)[B], const vf (&ki)[B],
                            const vf (&Krp)[kPrefetchK ? B : 1][kPrefetchK ? S : 1], vf & x, vf & costc)
   {
+    TILE_PROF_START();
     const vf dx = x - xi;
     // SPEC: s = u_c + alpha k_c; s = fma(K[c][a], dx_a, s), a = 0 .. S-1; clamp
     vf un[B];
@@ -1330,11 +1367,15 @@ struct Solver
       st(I.ubuf, uoff + i * M + c + 16 * b, un[b], c < 16);
     }
     for(int b = AB; b < B; b++) st(I.ubuf, uoff + i * M + c + 16 * b, splat(0.0), c < 16);
+    TILE_PROF_ADD(TP_FW_FEED);
     costc = costc + running_cost<AB>(i, x, un);
+    TILE_PROF_ADD(TP_FW_COST);
     Terms T;
     terms_of<AB>(ph, m, x, un, T);
+    TILE_PROF_ADD(TP_FW_TERMS);
     x = state_eq(T, x);
     st(I.xbuf, xoff + (i + 1) * S + c, x, inS);
+    TILE_PROF_ADD(TP_FW_STATE);
   }
 
   CCC_TILE_PIECE vf forward_pass(int first, const int (&cand)[4])
@@ -1358,8 +1399,7 @@ struct Solver
     // order: the same bits.
     FwdOps o0, o1, o2;
     auto fetch = [&](int i, FwdOps & o) {
-      o.ph = phase_of(i);
-      o.m = dim_of_phase(o.ph);
+      step_info(i, o.ph, o.m);
       o.xi = ldm(xs + static_cast<long>(i) * S, c, inS);
       for(int b = 0; b < B; b++)
       {
@@ -1373,7 +1413,13 @@ struct Solver
     auto run = [&](int i, FwdOps & o) {
       // (the step's operands by value, then the buffer is free for the fetch of step i + kFwdDepth)
       const FwdOps cur = o;
+#if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+      const long long fw_t0 = (long long)__builtin_readcyclecounter();
+#endif
       if(i + kFwdDepth < N) fetch(i + kFwdDepth, o);
+#if defined(CCC_TILE_PROF) && defined(__HIP_DEVICE_COMPILE__)
+      if((threadIdx.x & 63) == 0) mem.prof[TP_FW_FETCH] += (double)((long long)__builtin_readcyclecounter() - fw_t0);
+#endif
       const int m = cur.m, ph = cur.ph;
       if constexpr(B == 1)
         forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
@@ -1429,7 +1475,8 @@ struct Solver
     st(I.xbuf + xo, c, x, inS && (g == 0));
     for(int i = 0; i < N; i++)
     {
-      const int ph = phase_of(i), m = dim_of_phase(ph);
+      int ph, m;
+      step_info(i, ph, m);
       vf u[B];
       for(int b = 0; b < B; b++)
       {

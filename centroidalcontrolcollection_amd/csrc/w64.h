@@ -150,6 +150,12 @@ W64_FN void st(double * p, vi idx, vf v, vb m)
   if(m) p[idx] = v;
 }
 W64_FN vi ldi(const int * p, vi idx) { return p[idx]; }
+W64_FN void sth(unsigned short * p, vi idx, vi v, vb m)
+{
+  if(m) p[idx] = static_cast<unsigned short>(v);
+}
+// a value that is the same on every lane, as a scalar
+W64_FN int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 W64_FN vi ldb(const unsigned char * p, vi idx) { return static_cast<int>(p[idx]); }
 // Orders this wavefront's LDS traffic: the LDS executes one wavefront's operations in order, so all that is needed is that
 // the COMPILER keeps the accesses on their side of this point (a wavefront-scope fence + scheduling barrier: no
@@ -276,6 +282,7 @@ W64_BIN_I(*)
 W64_BIN_I(&)
 W64_BIN_I(>>)
 W64_BIN_I(<<)
+W64_BIN_I(|)
 #  undef W64_BIN_I
 #  define W64_CMP_I(op)                                   \
     inline vb operator op(const vi & a, const vi & b)     \
@@ -490,6 +497,11 @@ inline vi ldb(const unsigned char * p, const vi & idx)
   W64_LOOP r.v[l_] = static_cast<int>(p[idx.v[l_]]);
   return r;
 }
+inline void sth(unsigned short * p, const vi & idx, const vi & v, const vb & m)
+{
+  W64_LOOP if(m.v[l_]) p[idx.v[l_]] = static_cast<unsigned short>(v.v[l_]);
+}
+inline int uniform_i(int v) { return v; }
 inline void wave_sync() {}
 inline void mem_sync() {}
 #endif

@@ -39,3 +39,6 @@ for lab, idx in (("slowest 20", order[:20]), ("middle 200", order[n // 2 - 100:n
           "%.0f cycles each (%.1f M)" % (m[15] / max(m[13], 1), m[16] / max(m[13], 1), m[17] / max(m[13], 1), (m[15] + m[16] + m[17]) / 1e6,
                                             m[19], m[18] / max(m[19], 1), m[18] / 1e6))
     print(lab, " ".join("%s %.1f%%" % (nm, 100 * m[j] / m[:11].sum()) for j, nm in enumerate(names)))
+    steps = max(m[14], 1) * N  # forward passes x steps
+    print(lab, "forward step, cycles: fetch issue %.0f, feedback + store %.0f, running cost %.0f, terms %.0f, state + store %.0f (sum %.0f; forward total / steps %.0f)"
+          % (m[20] / steps, m[21] / steps, m[22] / steps, m[23] / steps, m[24] / steps, m[20:25].sum() / steps, m[9] / steps))
