@@ -503,10 +503,12 @@ struct Solver
     return sel(inS, x + P.dt * xd, 0.0);
   }
   // running / terminal cost of (x, u) per row: src/DdpCentroidal.cpp:66-83
+  // (ref = ref_of(step): fetched ahead by the callers with the step's other operands -- round 5: asked for here, the load was
+  //  consumed on the spot, a trip to L2 exposed in every step of every rollout)
   template<int AB>
-  W64_FN vf running_cost(int step, vf x, const vf (&u)[B]) const
+  W64_FN vf running_cost(vf ref, vf x, const vf (&u)[B]) const
   {
-    const vf e = x - ref_of(step);
+    const vf e = x - ref;
     const vf cx = sum16(sel(inS, 0.5 * ld(mem.wrun, c) * e * e, 0.0));
     vf t[B];
     for(int b = 0; b < AB; b++) t[b] = u[b] * u[b];
@@ -1053,6 +1055,7 @@ struct Solver
     Q.lv = lv;
     for(int b = 0; b < AB; b++) Q.in[b] = c + 16 * b < m;
     TILE_PROF_START();
+    const vf ref = ref_of(i); // (asked for here, used after the derivatives: the trip to memory runs beside them)
     Terms T;
     terms_of<AB>(ph, m, x, u, T);
     vf Fu[B][6];
@@ -1061,7 +1064,7 @@ struct Solver
     const vi col = seli(inS, c, spl(0));
     // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
     {
-      vf s = sel(inS, ld(mem.wrun, c) * (x - ref_of(i)), 0.0);
+      vf s = sel(inS, ld(mem.wrun, c) * (x - ref), 0.0);
       for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
       st(mem.Qx, c, s, inS && (g == 0));
     }
@@ -1338,12 +1341,12 @@ struct Solver
   struct FwdOps
   {
     int ph, m;
-    vf xi, ui[B], ki[B];
+    vf xi, ref, ui[B], ki[B];
     vf Kr[kPrefetchK ? B : 1][kPrefetchK ? S : 1];
   };
   // one step of the rollouts with the first AB <= B blocks of 16 ridges live (the further ones are written as zeros)
   template<int AB>
-  W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, const vf (&ui)[B], const vf (&ki)[B],
+  W64_FN void forward_step(int i, int m, int ph, vf alpha, vi xoff, vi uoff, vf xi, vf ref, const vf (&ui)[B], const vf (&ki)[B],
                            const vf (&Krp)[kPrefetchK ? B : 1][kPrefetchK ? S : 1], vf & x, vf & costc)
   {
     TILE_PROF_START();
@@ -1368,7 +1371,7 @@ struct Solver
     }
     for(int b = AB; b < B; b++) st(I.ubuf, uoff + i * M + c + 16 * b, splat(0.0), c < 16);
     TILE_PROF_ADD(TP_FW_FEED);
-    costc = costc + running_cost<AB>(i, x, un);
+    costc = costc + running_cost<AB>(ref, x, un);
     TILE_PROF_ADD(TP_FW_COST);
     Terms T;
     terms_of<AB>(ph, m, x, un, T);
@@ -1401,6 +1404,7 @@ struct Solver
     auto fetch = [&](int i, FwdOps & o) {
       step_info(i, o.ph, o.m);
       o.xi = ldm(xs + static_cast<long>(i) * S, c, inS);
+      o.ref = ref_of(i);
       for(int b = 0; b < B; b++)
       {
         const vb inn = c + 16 * b < o.m;
@@ -1422,22 +1426,22 @@ struct Solver
 #endif
       const int m = cur.m, ph = cur.ph;
       if constexpr(B == 1)
-        forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+        forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
       else if constexpr(B == 2)
       {
         if(m <= 16)
-          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
         else
-          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
       }
       else
       {
         if(m <= 16)
-          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+          forward_step<1>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
         else if(m <= 32)
-          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+          forward_step<2>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
         else
-          forward_step<4>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ui, cur.ki, cur.Kr, x, costc);
+          forward_step<4>(i, m, ph, alpha, xoff, uoff, cur.xi, cur.ref, cur.ui, cur.ki, cur.Kr, x, costc);
       }
     };
     fetch(0, o0);
@@ -1473,10 +1477,13 @@ struct Solver
     vf x = ldm(I.x0, c, inS);
     vf cc = splat(0.0);
     st(I.xbuf + xo, c, x, inS && (g == 0));
+    vf ref_n = ref_of(0); // (the reference a step ahead, as in the forward passes)
     for(int i = 0; i < N; i++)
     {
       int ph, m;
       step_info(i, ph, m);
+      const vf ref = ref_n;
+      if(i + 1 < N) ref_n = ref_of(i + 1);
       vf u[B];
       for(int b = 0; b < B; b++)
       {
@@ -1484,7 +1491,7 @@ struct Solver
         u[b] = u_init ? ldm(u_init + static_cast<long>(i) * M, c + 16 * b, in) : splat(0.0);
         st(I.ubuf + uo, i * M + c + 16 * b, u[b], g == 0);
       }
-      cc = cc + running_cost<B>(i, x, u);
+      cc = cc + running_cost<B>(ref, x, u);
       Terms T;
       terms_of<B>(ph, m, x, u, T);
       x = state_eq(T, x);
