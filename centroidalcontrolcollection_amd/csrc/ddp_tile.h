@@ -246,6 +246,19 @@ struct Solver
 #else
   static constexpr int kUnrollZ = (S == 9) ? 4 : 2;
 #endif
+  // oracle/ddp_tile.c FX_NZ9 / FX_NZ12: the rows of Fx's column c that enter the products, kNzLen per column; entry k of
+  // every column as sixteen 4-bit values (column c in bits 4c .. 4c+3)
+  static constexpr int kNzLen = S == 9 ? 3 : 6;
+  static W64_FN constexpr unsigned long long fx_nz_table(int k)
+  {
+    constexpr unsigned char t9[9][3] = {{0, 7, 8}, {1, 6, 8}, {2, 6, 7}, {0, 3, 6}, {1, 4, 6}, {2, 5, 6}, {6, 0, 1}, {7, 0, 1}, {8, 0, 1}};
+    constexpr unsigned char t12[12][6] = {{0, 9, 10, 11, 3, 4}, {1, 9, 10, 11, 3, 4}, {2, 9, 10, 11, 3, 4}, {3, 4, 5, 0, 1, 2},
+                                          {3, 4, 5, 0, 1, 2},   {5, 0, 1, 2, 3, 4},   {0, 6, 3, 4, 5, 9},   {1, 7, 3, 4, 5, 9},
+                                          {2, 8, 3, 4, 5, 9},   {3, 4, 5, 9, 10, 11}, {3, 4, 5, 9, 10, 11}, {3, 4, 5, 9, 10, 11}};
+    unsigned long long r = 0;
+    for(int cc = 0; cc < S; cc++) r |= static_cast<unsigned long long>(S == 9 ? t9[cc][k % 3] : t12[cc % 12][k]) << (4 * cc);
+    return r;
+  }
   // unroll factor of the S-term products T1 = Vxx Fx, Qxx = Fx' T1 (measured, round 4, 16 ridges at 256 VGPRs: fully
   // unrolled + 1.5 % for 100-200 B of scratch -- not taken; fully unrolled at 128 VGPRs: - 25 %)
 #ifdef CCC_TILE_U_PROD
@@ -1063,11 +1076,44 @@ struct Solver
     TILE_PROF_ADD(TP_DERIV);
     const vi col = seli(inS, c, spl(0));
     // Qx = Lx + Fx' Vx (lanes a < S).  SPEC: s = Lx_a; s = fma(Fx[b][a], Vx[b], s), b = 0 .. S-1
+    // (round 5: over the rows Fx's structure leaves -- oracle/ddp_tile.c FX_NZ; nz[k] = row b_k of this lane's column,
+    //  fk[k] = Fx[b_k][c], shared by the three products)
+    vi nz[kNzLen];
+    const vi colo = opaque(col); // (the row numbers are a few operations: made here, every step, not kept across the solver)
+    for(int k = 0; k < kNzLen; k++) nz[k] = tbl4(fx_nz_table(k), colo);
     {
       vf s = sel(inS, ld(mem.wrun, c) * (x - ref), 0.0);
-      for(int b = 0; b < S; b++) s = vfma(ld(mem.Fx, col + b * S), splat(mem.Vx[b]), s);
+      for(int k = 0; k < kNzLen; k++) s = vfma(ld(mem.Fx, nz[k] * S + col), ld(mem.Vx, nz[k]), s);
       st(mem.Qx, c, s, inS && (g == 0));
     }
+    // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][b_0] Fx[b_0][c]; s = fma(Vxx[a][b_k], Fx[b_k][c], s), k = 1 .. L-1
+    {
+      vf s3[3];
+      const vf f0 = ld(mem.Fx, nz[0] * S + col);
+      for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S + nz[0]) * f0;
+      for(int k = 1; k < kNzLen; k++)
+      {
+        const vf fk = ld(mem.Fx, nz[k] * S + col);
+        for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + nz[k]), fk, s3[t]);
+      }
+      for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
+    }
+    wave_sync();
+    // W = T1[rows6, :] -> mem.W (T1's place takes Qxx below)
+    for(int j = 0; j < 6; j++) st(mem.W, j * LS + c, ld(mem.T1, (FU0 + j) * S + col), inS && (g == 0));
+    // Qxx = Lxx + Fx' T1; this lane: Qxx[c][r], r = its rows.  SPEC: s = (c == r) w_run[c]; s = fma(Fx[b_k][c], T1[b_k][r], s)
+    vf Qxx[3];
+    {
+      for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
+      for(int k = 0; k < kNzLen; k++)
+      {
+        const vf fk = ld(mem.Fx, nz[k] * S + col);
+        for(int t = 0; t < 3; t++) Qxx[t] = vfma(fk, ld(mem.T1, nz[k] * S + arow[t]), Qxx[t]);
+      }
+    }
+    wave_sync();
+    for(int t = 0; t < 3; t++) st(mem.T1, col * S + arow[t], Qxx[t], aval[t] && inS); // T1 <- Qxx
+    wave_sync();
     // Qu = Lu + Fu' Vx.  SPEC: s = w_force u_c; s = fma(Fu[b][c], Vx[b], s), b = FU0 .. FU0+5
     vf Qu[B];
     for(int b = 0; b < AB; b++)
@@ -1089,36 +1135,6 @@ struct Solver
       Q.u[b] = u[b];
     }
     for(int l = 0; l < 6; l++) Q.v6r[l] = v6r_elem(l, lv);
-    // T1 = Vxx Fx (lanes c < S).  SPEC: s = Vxx[a][0] Fx[0][c]; s = fma(Vxx[a][b], Fx[b][c], s), b = 1 .. S-1
-    {
-      vf s3[3];
-      const vf f0 = ld(mem.Fx, col);
-      for(int t = 0; t < 3; t++) s3[t] = ld(mem.Vxx, arow[t] * S) * f0;
-      W64_UNROLL_T(kUnrollProd)
-      for(int b = 1; b < S; b++)
-      {
-        const vf fb = ld(mem.Fx, col + b * S);
-        for(int t = 0; t < 3; t++) s3[t] = vfma(ld(mem.Vxx, arow[t] * S + b), fb, s3[t]);
-      }
-      for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, s3[t], aval[t] && inS);
-    }
-    wave_sync();
-    // W = T1[rows6, :] -> mem.W (T1's place takes Qxx below)
-    for(int j = 0; j < 6; j++) st(mem.W, j * LS + c, ld(mem.T1, (FU0 + j) * S + col), inS && (g == 0));
-    // Qxx = Lxx + Fx' T1 (lanes c < S).  SPEC: s = (a == c) w_run[a]; s = fma(Fx[b][a], T1[b][c], s), b = 0 .. S-1
-    vf Qxx[3];
-    {
-      for(int t = 0; t < 3; t++) Qxx[t] = sel(arow[t] == c, ld(mem.wrun, arow[t]), 0.0);
-      W64_UNROLL_T(kUnrollProd)
-      for(int b = 0; b < S; b++)
-      {
-        const vf tb = ld(mem.T1, col + b * S);
-        for(int t = 0; t < 3; t++) Qxx[t] = vfma(ld(mem.Fx, arow[t] + b * S), tb, Qxx[t]);
-      }
-    }
-    wave_sync();
-    for(int t = 0; t < 3; t++) st(mem.T1, arow[t] * S + col, Qxx[t], aval[t] && inS); // T1 <- Qxx
-    wave_sync();
     TILE_PROF_ADD(TP_PRODUCTS);
     // box-QP and gains
     vf k[B], K[B][3];

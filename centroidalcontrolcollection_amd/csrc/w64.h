@@ -157,6 +157,15 @@ W64_FN void sth(unsigned short * p, vi idx, vi v, vb m)
 // a value that is the same on every lane, as a scalar
 W64_FN int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 W64_FN vi ldb(const unsigned char * p, vi idx) { return static_cast<int>(p[idx]); }
+// the same value, but one the compiler cannot trace: what is computed from it is computed HERE, not hoisted out of the
+// enclosing loops into registers that live (or spill) across them
+W64_FN vi opaque(vi v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// entry idx (0 .. 15) of a table of sixteen 4-bit values held in one 64-bit constant
+W64_FN vi tbl4(unsigned long long t, vi idx) { return static_cast<int>((t >> (4 * idx)) & 15ull); }
 // Orders this wavefront's LDS traffic: the LDS executes one wavefront's operations in order, so all that is needed is that
 // the COMPILER keeps the accesses on their side of this point (a wavefront-scope fence + scheduling barrier: no
 // s_barrier, and above all no s_waitcnt vmcnt(0) -- __syncthreads() would drain every global load in flight here).
@@ -502,6 +511,13 @@ inline void sth(unsigned short * p, const vi & idx, const vi & v, const vb & m)
   W64_LOOP if(m.v[l_]) p[idx.v[l_]] = static_cast<unsigned short>(v.v[l_]);
 }
 inline int uniform_i(int v) { return v; }
+inline vi opaque(const vi & v) { return v; }
+inline vi tbl4(unsigned long long t, const vi & idx)
+{
+  vi r;
+  W64_LOOP r.v[l_] = static_cast<int>((t >> (4 * idx.v[l_])) & 15ull);
+  return r;
+}
 inline void wave_sync() {}
 inline void mem_sync() {}
 #endif

@@ -615,6 +615,23 @@ static int box_qp_struct(sqp_t * q, const double * lin, const double * lo, const
   return result;
 }
 
+/* Round 5: the products with Fx = df/dx use its STRUCTURE.  Fx = I + dt A, and A of either model has a handful of entries
+ * per column (src/DdpCentroidal.cpp:85-121: d pos / d momentum and d moment / d pos; src/DdpSingleRigidBody.cpp:114-185: d pos /
+ * d vel, the Euler-rate block, the angular-acceleration blocks).  Column c of Fx can be non-zero only in the leading rows of
+ * FX_NZ[c]; every list is filled to one length per model (3 / 6) with rows whose entry in that column is an exact zero, so
+ * that each sum has the same number of terms on every lane of the kernel.  T1 = Vxx Fx, Qxx = Lxx + Fx' T1 and Qx = Lx + Fx' Vx
+ * add the terms of the listed rows in the listed order: what the dense chains add, minus exact zeros -- the same values
+ * wherever Vxx is finite, a third (9 states) or half (12 states) of the operations.
+ * SPEC (L = 3 / 6, b_k = FX_NZ[c][k]):
+ *   T1[a][c] = Vxx[a][b_0] Fx[b_0][c]; then fma(Vxx[a][b_k], Fx[b_k][c], .), k = 1 .. L-1
+ *   Qxx[c][r] = (c == r) w_run[c]; then fma(Fx[b_k][c], T1[b_k][r], .), k = 0 .. L-1
+ *   Qx[c] = Lx[c]; then fma(Fx[b_k][c], Vx[b_k], .), k = 0 .. L-1 */
+#define FX_NZ_MAX 6
+static const signed char FX_NZ9[9][FX_NZ_MAX] = {{0, 7, 8}, {1, 6, 8}, {2, 6, 7}, {0, 3, 6}, {1, 4, 6}, {2, 5, 6}, {6, 0, 1}, {7, 0, 1}, {8, 0, 1}};
+static const signed char FX_NZ12[12][FX_NZ_MAX] = {{0, 9, 10, 11, 3, 4},  {1, 9, 10, 11, 3, 4},  {2, 9, 10, 11, 3, 4},  {3, 4, 5, 0, 1, 2},
+                                                   {3, 4, 5, 0, 1, 2},    {5, 0, 1, 2, 3, 4},    {0, 6, 3, 4, 5, 9},    {1, 7, 3, 4, 5, 9},
+                                                   {2, 8, 3, 4, 5, 9},    {3, 4, 5, 9, 10, 11},  {3, 4, 5, 9, 10, 11},  {3, 4, 5, 9, 10, 11}};
+
 static int backward_pass_struct(tile_t * d, double * gsum)
 {
   const oracle_ddp_model_t * m = d->m;
@@ -646,10 +663,12 @@ static int backward_pass_struct(tile_t * d, double * gsum)
     /* Qx, Qu as in backward_pass() */
     double Qx[12], Qu[MMAX];
     ref_of(m, i, ref);
+    const signed char (*NZ)[FX_NZ_MAX] = S == 9 ? FX_NZ9 : FX_NZ12;
+    const int NL = S == 9 ? 3 : 6;
     for(int a = 0; a < S; a++)
     {
       double s = m->w_run[a] * (x[a] - ref[a]);
-      for(int b = 0; b < S; b++) s = fma(Fx[b * S + a], Vx[b], s);
+      for(int k = 0; k < NL; k++) s = fma(Fx[NZ[a][k] * S + a], Vx[NZ[a][k]], s);
       Qx[a] = s;
     }
     for(int r = 0; r < M_; r++)
@@ -658,20 +677,20 @@ static int backward_pass_struct(tile_t * d, double * gsum)
       for(int b = 0; b < 6; b++) s = fma(Fu[b][r], Vx[FU0 + b], s);
       Qu[r] = r < dim ? s : 0.0;
     }
-    /* T1 = Vxx Fx ; Qxx = Lxx + Fx' T1 */
+    /* T1 = Vxx Fx ; Qxx = Lxx + Fx' T1, over the rows Fx's structure leaves (FX_NZ above) */
     double T1[144], Qxx[144];
     for(int a = 0; a < S; a++)
       for(int b2 = 0; b2 < S; b2++)
       {
-        double s = Vxx[a * S] * Fx[b2];
-        for(int b = 1; b < S; b++) s = fma(Vxx[a * S + b], Fx[b * S + b2], s);
+        double s = Vxx[a * S + NZ[b2][0]] * Fx[NZ[b2][0] * S + b2];
+        for(int k = 1; k < NL; k++) s = fma(Vxx[a * S + NZ[b2][k]], Fx[NZ[b2][k] * S + b2], s);
         T1[a * S + b2] = s;
       }
     for(int a = 0; a < S; a++)
       for(int b2 = 0; b2 < S; b2++)
       {
         double s = a == b2 ? m->w_run[a] : 0.0;
-        for(int b = 0; b < S; b++) s = fma(Fx[b * S + a], T1[b * S + b2], s);
+        for(int k = 0; k < NL; k++) s = fma(Fx[NZ[a][k] * S + a], T1[NZ[a][k] * S + b2], s);
         Qxx[a * S + b2] = s;
       }
     /* the six-dimensional pieces */

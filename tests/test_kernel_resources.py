@@ -34,9 +34,9 @@ EXPECT = {
     #  172 B at 32 ridges, 176 / 160 -> 0 at 64, with the rank-one updates of the box-QP's factor added on top)
     # (<12, 1>: four values of the kernel's prologue, stored once and reloaded in its cold corners -- none in the box-QP loop)
     # (LDS: + 512 B for the table of the steps' phases and ridge counts; two wavefronts per SIMD = eight per CU leave 20 KB each)
-    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 40, 10752),
+    "void ccc_amd::ddp_tile_kernel<12, 1>": ("ddp_tile", 256, 2, 48, 10752),
     "void ccc_amd::ddp_tile_kernel<9, 2>": ("ddp_tile", 256, 2, 136, 10752),    # 32 ridges
-    "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 208, 12288),
+    "void ccc_amd::ddp_tile_kernel<12, 2>": ("ddp_tile", 256, 2, 224, 12288),
     "void ccc_amd::ddp_tile_kernel<9, 4>": ("ddp_tile", 512, 1, 0, 14336),      # 64 ridges: one wavefront per SIMD
     "void ccc_amd::ddp_tile_kernel<12, 4>": ("ddp_tile", 512, 1, 0, 15360),
     "ccc_amd::z_plan_stream_kernel": ("z", 168, 3, 0, None),
