@@ -43,6 +43,10 @@ struct ZmpDev
   const double * b; // [NP]     first column of B_seq (B_seq[i][j] = b[i-j])
   double c2;        // C(0,2) = -com_height / g
   double dt;        // horizon_dt
+  // K1 only (round 5): the pivot trips of every QP of this call -> hist (when given); order (when given) = the QPs sorted by
+  // the trips the PREVIOUS call of the same size spent on them, longest first: slot s of the schedule solves QP order[s]
+  const int * order;
+  int * hist;
 };
 
 constexpr double kInf = __builtin_huge_val();
@@ -140,8 +144,11 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
   const long ntask = (nqp + QPW - 1) / QPW;
   for(long task = (long)blockIdx.x * WAVES + wave; task < ntask; task += (long)gridDim.x * WAVES)
   {
-    const long qp = task * QPW + grp; // (instance, axis) = (qp / 2, qp % 2)
-    const bool valid = qp < nqp;
+    // (instance, axis) = (qp / 2, qp % 2); without a history the two axes of an instance share a wavefront, with one the
+    // two QPs of a wavefront are neighbours in the order of their last pivot counts -- the lock-step pair wastes little
+    const long slot = task * QPW + grp;
+    const bool valid = slot < nqp;
+    const long qp = valid ? (P.order ? (long)P.order[slot] : slot) : 0;
     const bool row = valid && li < N;
     double lo, hi;
     // tableau T = G (W empty): lane li holds row li = column li of the symmetric G.  The diagonal lives in dg: the
@@ -326,10 +333,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void zmp_plan_kernel_w(ZmpDev P, 
 constexpr int kQueues = 64;      // ticket counters of zmp_plan_kernel_dyn
 constexpr int kQueueStride = 16; // in counters: one 128-byte line each
 
-#ifndef CCC_ZMP_BATCH
-#define CCC_ZMP_BATCH 1
-#endif
-
 template<int LG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                                  const double * __restrict__ zlim, double control_dt,
@@ -360,7 +363,6 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
 
   // group state (uniform inside a group)
   enum { kNeed = 0, kActive = 1, kIdle = 2 };
-  constexpr int kBatch = CCC_ZMP_BATCH;
   int phase = kNeed, left = 0;
   long qp = 0, next = 0;
   int myq = (int)((blockIdx.x * (WAVES * QPW) + wave * QPW + grp) % kQueues);
@@ -391,7 +393,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
       // the next ones when that is exhausted
       if(__ballot(phase == kNeed && left == 0) != 0ull)
       {
-        const long share = (nqp + kQueues - 1) / kQueues;
+        // (ticket t of queue k = slot t kQueues + k of the schedule: every queue holds the same mix of the slots, so that
+        //  with an order by the last call's pivot counts -- P.order -- the long QPs are taken first by everybody)
         for(int tries = 0; tries < kQueues; ++tries) // (wave-uniform trip count; groups that found work idle along)
         {
           const bool want = phase == kNeed && left == 0;
@@ -399,8 +402,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
           long q = -1;
           if(want && li == 0)
           {
-            const long t = (long)atomicAdd(queue + (size_t)myq * kQueueStride, (unsigned long long)kBatch);
-            q = (t < share && myq * share + t < nqp) ? myq * share + t : -1;
+            const long t = (long)atomicAdd(queue + (size_t)myq * kQueueStride, 1ull);
+            q = (t * kQueues + myq < nqp) ? t * kQueues + myq : -1;
           }
           q = __shfl(q, lane & ~(LG - 1)); // the group leader's ticket
           if(want)
@@ -408,8 +411,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
             if(q >= 0)
             {
               next = q;
-              const long end = (myq + 1) * share < nqp ? (myq + 1) * share : nqp;
-              left = (int)(end - q < kBatch ? end - q : kBatch);
+              left = 1;
             }
             else
               myq = (myq + 1) % kQueues;
@@ -420,12 +422,8 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
       if(phase == kNeed)
       {
         valid = left > 0;
-        qp = valid ? next : 0;
-        if(valid)
-        {
-          ++next;
-          --left;
-        }
+        qp = valid ? (P.order ? (long)P.order[next] : next) : 0;
+        if(valid) --left;
         if(!valid)
         {
           phase = kIdle;
@@ -1076,6 +1074,10 @@ struct ccc_zmp
   std::vector<double> A_seq, B_seq; // host copies, N x 3 and N x N
   double *dG = nullptr, *dA = nullptr, *db = nullptr;
   unsigned long long * queue = nullptr; // work-queue ticket counter of zmp_plan_kernel_dyn
+  int *hist = nullptr, *order = nullptr; // K1: pivot trips per QP of the last call, and the schedule made from them
+  int64_t hist_cap = 0, hist_n = -1;     // (hist_n: the QPs of the call the counts belong to, -1 = none yet)
+  bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
+                                         //  about the next)
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
   int num_cu = 0;
   // per-handle (= per-device) launch state: function attributes set, resident workgroups per CU of the queue kernel
@@ -1090,6 +1092,7 @@ struct ccc_zmp
   // development switches, read ONCE in ccc_zmp_create (never per launch)
   int64_t env_queue_min = -1;   // CCC_ZMP_QUEUE_MIN: QPs from which the work-queue kernel runs (< 0: the measured default)
   bool env_static = false;      // CCC_ZMP_STATIC: never the work-queue kernel
+  bool env_history = true;      // CCC_ZMP_HISTORY=0: never order a call by the last call's pivot counts
   bool env_debug = false;       // CCC_ZMP_DEBUG: print the occupancy of the LDS-tableau kernels
   int env_kw = -1;              // CCC_ZMP_KW: 0 = never the one-QP-per-wavefront register kernel (K1w) for 32 < N <= 64 (the
                                 //             default there: 39.2 / 34.1 / 28.9 / 19.2 / 17.5 M solves/s at N = 33 / 40 / 48 /
@@ -1160,6 +1163,54 @@ int upload_model(ccc_zmp * h)
   return CCC_OK;
 }
 
+// The schedule of the next call from the pivot counts of the last one: a counting sort of the QPs by trips, longest first
+// (one workgroup; within a count the order is whatever the atomics give -- the answers do not depend on it).  Also zeroes
+// the ticket counters of zmp_plan_kernel_dyn, which need a launch of their own otherwise.
+__global__ __launch_bounds__(1024) void zmp_order_kernel(const int * __restrict__ hist, int n, int * __restrict__ order,
+                                                         unsigned * __restrict__ queue_words, int nwords)
+{
+  constexpr int kB = 256;
+  __shared__ int cnt[kB];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x;
+  if(tid < kB) cnt[tid] = 0;
+  for(int k = tid; k < nwords; k += 1024) queue_words[k] = 0u;
+  __syncthreads();
+  for(int i = tid; i < n; i += 1024)
+  {
+    const int t = hist[i];
+    atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the kB buckets (four wavefronts)
+  int v = 0, incl = 0;
+  if(tid < kB)
+  {
+    v = cnt[tid];
+    incl = v;
+    for(int d = 1; d < 64; d <<= 1)
+    {
+      const int o = __shfl_up(incl, d);
+      if((tid & 63) >= d) incl += o;
+    }
+    if((tid & 63) == 63) wsum[tid >> 6] = incl;
+  }
+  __syncthreads();
+  if(tid < kB)
+  {
+    int base = 0;
+    for(int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    cnt[tid] = base + incl - v;
+  }
+  __syncthreads();
+  for(int i = tid; i < n; i += 1024)
+  {
+    const int t = hist[i];
+    const int pos = atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
+    order[pos] = i;
+  }
+}
+
 template<int LG, int WAVES>
 int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
            double * jerk, int32_t * status, hipStream_t stream)
@@ -1179,12 +1230,39 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   const int64_t resident = (int64_t)h->num_cu * (16 / WAVES);
   const int grid = (int)std::min<int64_t>(want, resident * 8);
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  // round 5: a handle remembers the pivot trips of every QP of its last call; a call of the same size runs them longest
+  // first (and, in the static kernel, pairs QPs of like counts in a wavefront).  Closed-loop callers repeat their batch
+  // from cycle to cycle; for anybody else the order is as good as any other -- the answers never depend on it.
+  // (inside a stream capture the buffers are not grown: the call runs unordered and keeps no counts)
+  bool ordered = false;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if(h->env_history && !h->skip_history && nqp < (int64_t)1 << 30 && !(capturing && h->hist_cap < nqp))
+  {
+    if(h->hist_cap < nqp)
+    {
+      if(h->hist) (void)hipFree(h->hist);
+      if(h->order) (void)hipFree(h->order);
+      h->hist = h->order = nullptr;
+      h->hist_cap = 0;
+      h->hist_n = -1;
+      CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
+      CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
+      h->hist_cap = nqp;
+    }
+    ordered = h->hist_n == nqp;
+    P.hist = h->hist;
+    P.order = ordered ? h->order : nullptr;
+  }
   // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~18 QPs per resident group the static
   // pairing (one instance per wavefront, more workgroups than fit: the hardware dispatcher balances) is faster -- measured
   // static / queue in M solves/s: 83.7 / 65.4 at 16384 instances, 90.3 / 83.3 at 32768, 95.1 / 93.2 at 49152,
   // 96.2 / 96.5 at 57344, 94.4 / 98.3 at 65536
   const int64_t queue_min = h->env_queue_min >= 0 ? h->env_queue_min : (int64_t)18 * h->num_cu * 12 * QPW;
-  const bool use_queue = !h->env_static && nqp >= queue_min;
+  // (round 5: with an order from the last call the static kernel is the faster one at every size -- the wavefront's two QPs
+  //  have like pivot counts, which is what the queue was for, without its divergent set-up: 127 against 96 M at 65536, 106
+  //  against 78 M at 8192 instances, the batch repeated; the queue stays for calls without a history)
+  const bool use_queue = !h->env_static && nqp >= queue_min && !ordered;
   h->last_kernel = use_queue ? (LG == 32 ? "zmp_plan_kernel_dyn<32,2>" : "zmp_plan_kernel_dyn")
                              : (LG == 32 ? "zmp_plan_kernel<32,2>" : "zmp_plan_kernel");
   if(use_queue)
@@ -1201,7 +1279,11 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
       CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
       CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
     }
-    if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream)) return zrc;
+    if(ordered)
+      hipLaunchKernelGGL(zmp_order_kernel, dim3(1), dim3(1024), 0, stream, h->hist, (int)nqp, h->order,
+                         reinterpret_cast<unsigned *>(h->queue), (int)(qbytes / 4));
+    else if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream))
+      return zrc;
     int & per_cu = h->per_cu; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
     if(per_cu == 0)
     {
@@ -1214,11 +1296,16 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     hipLaunchKernelGGL((zmp_plan_kernel_dyn<LG, WAVES>), dim3(gdyn), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                        control_dt, zmp, jerk, status, h->queue);
     CCC_HIP_CHECK(hipGetLastError());
+    if(P.hist) h->hist_n = nqp;
     return CCC_OK;
   }
+  if(ordered)
+    hipLaunchKernelGGL(zmp_order_kernel, dim3(1), dim3(1024), 0, stream, h->hist, (int)nqp, h->order,
+                       static_cast<unsigned *>(nullptr), 0);
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
   CCC_HIP_CHECK(hipGetLastError());
+  if(P.hist) h->hist_n = nqp;
   return CCC_OK;
 }
 int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
@@ -1395,6 +1482,7 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   h->horizon_dt = horizon_dt;
   if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) h->env_queue_min = std::atoll(qm);
   h->env_static = std::getenv("CCC_ZMP_STATIC") != nullptr;
+  if(const char * e = std::getenv("CCC_ZMP_HISTORY")) h->env_history = std::atoi(e) != 0;
   h->env_debug = std::getenv("CCC_ZMP_DEBUG") != nullptr;
   if(const char * k2 = std::getenv("CCC_ZMP_K2")) h->env_k2 = std::atoi(k2);
   if(const char * kw = std::getenv("CCC_ZMP_KW")) h->env_kw = std::atoi(kw);
@@ -1423,6 +1511,8 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->queue) (void)hipFree(h->queue);
+  if(h->hist) (void)hipFree(h->hist);
+  if(h->order) (void)hipFree(h->order);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);
@@ -1601,6 +1691,7 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
     }
     int64_t chunk = in_pinned ? n : 8192;
     if(h->env_host_chunk > 0) chunk = std::max<int64_t>(256, std::min<int64_t>(h->env_host_chunk, n));
+    h->skip_history = chunk < n;
     for(int64_t b = 0; b < n; b += chunk)
     {
       const size_t m = (size_t)std::min<int64_t>(chunk, n - b), o = (size_t)b;
@@ -1612,8 +1703,13 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
       const double * k_x0 = (in_pinned ? v_x0 : k_in) + o * 6, * k_zl = (in_pinned ? v_zl : k_in + nx) + o * 4 * N;
       rc = ccc_zmp_plan_batch_device(h, (int64_t)m, k_x0, k_zl, control_dt, o_z + o * 2, o_j ? o_j + o * 2 * N : nullptr,
                                      o_st + o * 2, h->stream);
-      if(rc != CCC_OK) return rc;
+      if(rc != CCC_OK)
+      {
+        h->skip_history = false;
+        return rc;
+      }
     }
+    h->skip_history = false;
   }
   CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
   if(!out_pinned)

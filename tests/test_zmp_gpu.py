@@ -349,6 +349,50 @@ def test_work_queue_kernel_equals_static_pairing(mpc32):
         assert np.array_equal(part["pivots"], full["pivots"][a:a + 4096])
 
 
+def test_history_schedule_gives_the_same_answers_whatever_the_caller_repeats(monkeypatch):
+    """Round 5: a handle keeps the pivot counts of its last call and runs a call of the same size longest-first, the two QPs
+    of a wavefront neighbours in that order (csrc/zmp.hip launch, zmp_order_kernel).  The order is a schedule, never an
+    input of the arithmetic: repeating a batch, handing over ANOTHER batch of the same size (a history that predicts
+    nothing), changing the size and coming back must all give, bit for bit, what a handle without a history gives -- from
+    the static kernel and from the work-queue kernel alike (CCC_ZMP_QUEUE_MIN=0 puts the first, unordered call on it)."""
+    import torch
+
+    n = 6000
+    bA = fx.make_zmp_batch(n, 32, 0.0625, seed=5)
+    bB = fx.make_zmp_batch(n, 32, 0.0625, seed=6)
+    dev = torch.device("cuda:0")
+
+    def run(m, b, k=None):
+        k = n if k is None else k
+        x0 = torch.from_numpy(b["x0"][:k]).to(dev)
+        zl = torch.from_numpy(b["zlim"][:k]).to(dev)
+        z = torch.empty((k, 2), dtype=torch.float64, device=dev)
+        j = torch.empty((k, 2, 32), dtype=torch.float64, device=dev)
+        st = torch.empty((k, 2), dtype=torch.int32, device=dev)
+        m.plan_batch_device(x0, zl, 0.005, z, j, st)
+        torch.cuda.synchronize()
+        return z.cpu().numpy(), j.cpu().numpy(), st.cpu().numpy(), m.last_kernel()
+
+    monkeypatch.setenv("CCC_ZMP_HISTORY", "0")
+    ref = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_HISTORY")
+    rA, rB, rC = run(ref, bA), run(ref, bB), run(ref, bB, n - 7)
+    assert np.all((rA[2] & 0xff) == 0) and rA[2].max() >> 8 > 20  # (solved; pivot counts spread: there is something to order)
+    for qmin in (None, "0"):
+        if qmin is not None:
+            monkeypatch.setenv("CCC_ZMP_QUEUE_MIN", qmin)
+        m = LinearMpcZmp(1.0, 2.0, 0.0625)
+        if qmin is not None:
+            monkeypatch.delenv("CCC_ZMP_QUEUE_MIN")
+        first = run(m, bA)
+        assert first[3] == ("zmp_plan_kernel_dyn<32,2>" if qmin is not None else "zmp_plan_kernel<32,2>")
+        calls = [(first, rA), (run(m, bA), rA), (run(m, bB), rB), (run(m, bB, n - 7), rC), (run(m, bA), rA), (run(m, bA), rA)]
+        for got, want in calls:
+            for a, b in zip(got[:3], want[:3]):
+                assert np.array_equal(a, b)
+        assert calls[1][0][3] == calls[2][0][3] == calls[5][0][3] == "zmp_plan_kernel<32,2>"  # (ordered calls: the static kernel)
+
+
 def test_random_horizons_sweep():
     """Thirty random (horizon, com_height, seed) combinations across the packed-tableau range: ZMP and jerk parity
     with the oracle (guards the tile bookkeeping at row counts that are not multiples of the tile size)."""
