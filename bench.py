@@ -42,7 +42,12 @@ def _same_build(d):
     return d.get("kernel_hash") == _b.kernel_hash("zmp")
 
 
-def measured_traffic(n):
+def _same_kernel(d, kernel):
+    """The summary is of the kernel the timed launches ran (names as the library / rocprofv3 spell them)."""
+    return kernel is None or kernel.replace(" ", "") in d.get("kernel", "").replace(" ", "")
+
+
+def measured_traffic(n, kernel=None):
     """(HBM bytes per launch | None, source) from the PMC passes of scripts/prof_zmp.sh (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE,
     summarised by scripts/summarize_prof.py into profiles/zmp_hbm_traffic.json); None if not collected for this batch or
     collected on another build of the kernel."""
@@ -52,6 +57,8 @@ def measured_traffic(n):
     try:
         d = json.load(open(path))
         if d.get("algorithmic_bytes_per_launch") == ALGO_BYTES_PER_SOLVE * n:
+            if not _same_kernel(d, kernel):
+                return None, "profiles/zmp_hbm_traffic.json refused: it profiled %s, the timed launches ran %s" % (d.get("kernel"), kernel)
             if _same_build(d):
                 return d["hbm_bytes_per_launch"], "profiles/zmp_hbm_traffic.json (replayed; kernel_hash %s = this build)" % d["kernel_hash"]
             return None, "profiles/zmp_hbm_traffic.json refused: profiled build %s, this build %s" % (
@@ -61,14 +68,14 @@ def measured_traffic(n):
     return None, None
 
 
-def valu_counters(n):
+def valu_counters(n, kernel=None):
     """VALU-issue share of the kernel from the PMC pass of the same launch (profiles/zmp_valu_counters.json, written by
     scripts/summarize_prof.py from rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES ...); None if not collected for this batch
     or collected on another build of the kernel."""
     path = os.path.join(ROOT, "profiles", "zmp_valu_counters.json")
     try:
         d = json.load(open(path))
-        if d.get("batch") == n and _same_build(d):
+        if d.get("batch") == n and _same_build(d) and _same_kernel(d, kernel):
             return d
     except Exception:
         pass
@@ -318,6 +325,34 @@ def main():
     if os.environ.get("CCC_BENCH_DEBUG") and rank == 0:
         print("kern_ms", np.round(kern_ms[:24], 3).tolist(), "wall_ms", 1e3 * elapsed,
               "span_ms", evs[0][0].elapsed_time(evs[-1][1]), file=sys.stderr)
+    # The timed steps above repeat ONE batch on a handle that has seen it: the library orders a call by the pivot counts of
+    # the handle's last call of that size (csrc/zmp.hip, DESIGN.md section 4 -- what a closed-loop caller gets from cycle
+    # to cycle).  The same steps on a handle that keeps no history (CCC_ZMP_HISTORY=0, read at creation) are timed beside
+    # it and reported as `history.value_without_history`: what a caller whose batches have nothing to do with each
+    # other gets.
+    no_hist = None
+    if world == 1:
+        os.environ["CCC_ZMP_HISTORY"] = "0"
+        try:
+            mpc0 = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
+        finally:
+            del os.environ["CCC_ZMP_HISTORY"]
+        for _ in range(args.warmup + 20):
+            mpc0.plan_batch_device(x0, zlim, 0.005, zbuf[0], None, None, stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mpc0.plan_batch_device(x0, zlim, 0.005, zbuf[0], None, None, stream)
+        torch.cuda.synchronize(dev)
+        e0 = time.perf_counter() - t1
+        no_hist = {"value_without_history": n * args.steps / e0, "ms_per_step_without_history": 1e3 * e0 / args.steps,
+                   "kernel_without_history": mpc0.last_kernel(),
+                   "what": "`value` is measured on a handle that has seen the batch: its calls run longest-first by the "
+                           "previous call's pivot counts, QPs of like counts paired in a wavefront (the answers do not "
+                           "depend on the order: tests/test_zmp_gpu.py); value_without_history = the same steps on a "
+                           "handle created with CCC_ZMP_HISTORY=0.  The device-side closed loop of TestLinearMpcZmp.cpp "
+                           "(every cycle a new problem) gains 16-27 % from the order: DESIGN.md section 4"}
+        del mpc0
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
     # ccc_zmp_plan_batch; PCIe-inclusive, never the `value` above
     # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the kernel reads the inputs
@@ -400,8 +435,8 @@ def main():
         kavg = float(kern_ms.mean()) * 1e-3
         achieved = ALGO_BYTES_PER_SOLVE * n / kavg / 1e9
         tflops = pivots_per_solve * FLOP_PER_PIVOT * n / kavg / 1e12
-        vc = valu_counters(n)
-        traffic, traffic_src = measured_traffic(n)
+        vc = valu_counters(n, timed_kernel)
+        traffic, traffic_src = measured_traffic(n, timed_kernel)
         out = {
             "metric": "LinearMpcZmp planOnce() solves/sec (N=32, fp64, inputs resident in HBM)",
             "value": value,
@@ -438,6 +473,9 @@ def main():
                          "algorithmic_bytes": ALGO_BYTES_PER_SOLVE * n,
                          "kernel": timed_kernel,
                          "kernel_avg_ms": kavg * 1e3,
+                         "kernel_avg_ms_what": "HIP events round the library call on its stream: the solve kernel plus, on a "
+                                               "handle with a history, zmp_order_kernel (one workgroup: counting sort of the "
+                                               "last call's pivot counts) in front of it -- both in profiles/*_zmp_kernel_stats.csv",
                          "valu": {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,
                                   "flop_per_solve": pivots_per_solve * FLOP_PER_PIVOT,
@@ -456,6 +494,8 @@ def main():
             "pivots_per_solve": pivots_per_solve,
             "unsolved": n_bad,
         }
+        if no_hist is not None:
+            out["history"] = no_hist
         out["distributed"] = dinfo
         if strong is not None:
             out["strong_scaling"] = strong

@@ -26,6 +26,64 @@ int zero_words(void * p, int words, void * stream)
   return CCC_OK;
 }
 
+// Schedules from the last call's counts (round 5; csrc/zmp.hip: pivot trips per QP, csrc/xy.hip: sweeps per instance): a
+// counting sort of the n items by count, largest first (one workgroup; within a count the order is whatever the atomics
+// give -- the answers never depend on it).  Optionally zeroes `nwords` words and stores n in *count_out, so that a caller
+// that needs those done in-stream as well does not pay a launch for each.
+__global__ __launch_bounds__(1024) void order_by_count_kernel(const int * __restrict__ hist, int n, int * __restrict__ order,
+                                                              unsigned * __restrict__ zero, int nwords, int * count_out)
+{
+  constexpr int kB = 256;
+  __shared__ int cnt[kB];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x;
+  if(tid < kB) cnt[tid] = 0;
+  for(int k = tid; k < nwords; k += 1024) zero[k] = 0u;
+  __syncthreads();
+  for(int i = tid; i < n; i += 1024)
+  {
+    const int t = hist[i];
+    atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the kB buckets (four wavefronts)
+  int v = 0, incl = 0;
+  if(tid < kB)
+  {
+    v = cnt[tid];
+    incl = v;
+    for(int d = 1; d < 64; d <<= 1)
+    {
+      const int o = __shfl_up(incl, d);
+      if((tid & 63) >= d) incl += o;
+    }
+    if((tid & 63) == 63) wsum[tid >> 6] = incl;
+  }
+  __syncthreads();
+  if(tid < kB)
+  {
+    int base = 0;
+    for(int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    cnt[tid] = base + incl - v;
+  }
+  __syncthreads();
+  for(int i = tid; i < n; i += 1024)
+  {
+    const int t = hist[i];
+    const int pos = atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
+    order[pos] = i;
+  }
+  if(tid == 0 && count_out) *count_out = n;
+}
+
+int order_by_count(const int * hist, int n, int * order, void * zero, int nwords, int * count_out, void * stream)
+{
+  hipLaunchKernelGGL(order_by_count_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), hist, n, order,
+                     static_cast<unsigned *>(zero), nwords, count_out);
+  if(hipGetLastError() != hipSuccess) return fail(CCC_ERR_HIP, "order_by_count: launch failed");
+  return CCC_OK;
+}
+
 int refuse_growth_in_capture(void * stream, const char * who)
 {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -769,6 +769,10 @@ struct XyWork
   int * out_count;
   int single; // 1: single-change mode from the saved sets (the safeguard round)
   int wander; // > 0: hand an instance over when its last forward pass changed more ridges than this (see the kernel's end)
+  // round 5: in_list of the FIRST round = the batch in the order of the sweeps the handle's last call spent on each instance
+  // (longest first: the lanes of a wavefront stop together); resume = the listed instances bring a saved set (later rounds)
+  int resume;
+  int * hist; // sweeps of this call, per instance (255: handed to the dual kernel); nullptr: not kept
 };
 
 // index of (a, c), a <= c, in the row-wise packed upper triangle of a 6 x 6 matrix
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   // the impulse vectors of all ridges, once, into the coalesced layout (the instance-major inputs are read here only)
   for(int s = 0; s < N; s++)
   {
-    const Bits bits0 = W.in_list ? saved_bits(s) : Bits(0); // (a resumed instance: the set it had)
+    const Bits bits0 = W.resume ? saved_bits(s) : Bits(0); // (a resumed instance: the set it had)
     store_bits(s, bits0);
     const int m = B.dim[b * N + s] < M ? (B.dim[b * N + s] > 0 ? B.dim[b * N + s] : 0) : M; // (0..M: the slots there are)
     const double fz0 = B.total_force_z[b * N + s];
@@ -1517,6 +1521,7 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
   {
     // (converged or out of budget: the outputs are written either way)
     if(B.status) B.status[b] = ((it - 1) << 8) | (converged ? CCC_STATUS_SOLVED : CCC_STATUS_MAX_ITER);
+    if(W.hist) W.hist[b] = 255;
     return;
   }
   if(!converged)
@@ -1539,11 +1544,13 @@ __global__ __launch_bounds__(64) void xy_plan_stream_kernel(XyParams P, XyBatch 
       W.out_list[q] = (int)b;
       return;
     }
+    if(W.hist) W.hist[b] = 255;
     const int q = atomicAdd(W.redo_count, 1);
     W.redo_list[q] = (int)b;
     return;
   }
   if(B.status) B.status[b] = ((it - 1) << 8) | CCC_STATUS_SOLVED; // changes of the clamped set before it repeated
+  if(W.hist) W.hist[b] = it;
 }
 } // namespace ccc_amd
 
@@ -1570,6 +1577,11 @@ struct ccc_xy
   int env_pdas_iters = -1; // CCC_XY_PDAS_ITERS (< 0: the default cap)
   std::string env_rounds;  // CCC_XY_ROUNDS ("": the default round boundaries)
   int wander = 0;          // changed ridges per iteration beyond which a late instance counts as wandering (CCC_XY_WANDER; 0: off)
+  // round 5: the sweeps every instance of the last call took, and the order of the next call of the same size made from
+  // them (CCC_XY_HISTORY=0: never)
+  int *hist = nullptr, *order = nullptr;
+  int64_t hist_cap = 0, hist_n = -1;
+  bool env_history = true;
 };
 
 extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** out)
@@ -1598,6 +1610,7 @@ extern "C" int ccc_xy_create(const ccc_xy_params_t * p, int device, ccc_xy_t ** 
   h->env_stream = std::getenv("CCC_XY_STREAM") != nullptr;
   if(const char * mi = std::getenv("CCC_XY_PDAS_ITERS")) h->env_pdas_iters = std::atoi(mi);
   if(const char * rs = std::getenv("CCC_XY_ROUNDS")) h->env_rounds = rs;
+  if(const char * e = std::getenv("CCC_XY_HISTORY")) h->env_history = std::atoi(e) != 0;
   h->wander = std::max(8, p->horizon_steps * h->M / 8);
   if(const char * wv = std::getenv("CCC_XY_WANDER")) h->wander = std::max(0, std::atoi(wv));
   hipDeviceProp_t prop;
@@ -1634,6 +1647,8 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
   if(!h) return;
   ccc_amd::DeviceGuard ccc_device_guard__(h->device);
   if(h->ws) (void)hipFree(h->ws);
+  if(h->hist) (void)hipFree(h->hist);
+  if(h->order) (void)hipFree(h->order);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->side) (void)hipStreamDestroy(h->side);
@@ -1690,7 +1705,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
   XyWork W{reinterpret_cast<double *>(h->ws + o_ws), reinterpret_cast<double *>(h->ws + o_rb),
            reinterpret_cast<unsigned long long *>(h->ws + o_st),
            reinterpret_cast<int *>(h->ws + o_li), reinterpret_cast<int *>(h->ws + o_cn), 0, 0, n64,
-           nullptr, nullptr, nullptr, nullptr, 0, 0};
+           nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
   int * const round_list[2] = {reinterpret_cast<int *>(h->ws + o_l1), reinterpret_cast<int *>(h->ws + o_l2)};
   int * const round_count = reinterpret_cast<int *>(h->ws + o_cn) + 1; // [kXsRounds], after the redo count
   // hand-overs to the dual kernel: a list per round (the first round's is W.redo_list)
@@ -1723,6 +1738,34 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
     else
       hipLaunchKernelGGL((xy_plan_stream_kernel<64, true>), g, b, 0, s, P, B, Wk, (long)n, it_begin, it_end);
   };
+  // round 5: the lanes of a wavefront run in lock-step and a wavefront sweeps until its last lane's set repeats -- 2 to 7
+  // sweeps on nineteen instances in twenty, so every wavefront of a batch in the caller's order runs the first round's seven.
+  // A handle keeps the sweeps of its last call per instance; a call of the same size takes the instances in that order,
+  // longest first: the wavefronts stop after the sweeps their instances need (4.5 on average at config 4).  A schedule
+  // only: the arithmetic of an instance does not depend on its lane.
+  bool ordered = false;
+  int * n_word = W.redo_count + 3 * kXsRounds + 1; // (holds n for the first round's in_count when it runs from the order)
+  if(!dual_only && h->env_history)
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    if(!(capturing && h->hist_cap < n))
+    {
+      if(h->hist_cap < n)
+      {
+        if(h->hist) (void)hipFree(h->hist);
+        if(h->order) (void)hipFree(h->order);
+        h->hist = h->order = nullptr;
+        h->hist_cap = 0;
+        h->hist_n = -1;
+        CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)n * sizeof(int)));
+        CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)n * sizeof(int)));
+        h->hist_cap = n;
+      }
+      ordered = h->hist_n == n;
+      W.hist = h->hist;
+    }
+  }
   if(!dual_only)
   {
     // iterations of the block iteration before what is left goes to the dual kernel (safeguard rounds: always 16).  A small
@@ -1748,12 +1791,19 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       }
       ends[nr++] = cap;
     }
-    if(int zrc = zero_words(W.redo_count, 3 * kXsRounds, s)) return zrc;
+    if(ordered)
+    {
+      if(int orc = order_by_count(h->hist, (int)n, h->order, W.redo_count, 3 * kXsRounds, n_word, s)) return orc;
+    }
+    else if(int zrc = zero_words(W.redo_count, 3 * kXsRounds, s))
+      return zrc;
+    if(W.hist) h->hist_n = n;
     for(int k = 0; k < nr; k++)
     {
       XyWork Wk = W;
-      Wk.in_list = k ? round_list[(k - 1) & 1] : nullptr;
-      Wk.in_count = k ? round_count + (k - 1) : nullptr;
+      Wk.in_list = k ? round_list[(k - 1) & 1] : (ordered ? h->order : nullptr);
+      Wk.in_count = k ? round_count + (k - 1) : (ordered ? n_word : nullptr);
+      Wk.resume = k > 0;
       Wk.out_list = k + 1 < nr ? round_list[k & 1] : nullptr;
       Wk.out_count = k + 1 < nr ? round_count + k : nullptr;
       // (safeguard: every round hands over to ONE list, worked off by the single-change round after the last)
@@ -1781,6 +1831,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
       XyWork Ws = W;
       Ws.in_list = redo_list_of(0);
       Ws.in_count = redo_count_of(0);
+      Ws.resume = 1;
       Ws.single = 1;
       const int budget = 200 + 4 * P.N * (h->M / 16) * 8;
       launch_stream(Ws, ends[nr - 1], ends[nr - 1] + budget);

@@ -1163,54 +1163,6 @@ int upload_model(ccc_zmp * h)
   return CCC_OK;
 }
 
-// The schedule of the next call from the pivot counts of the last one: a counting sort of the QPs by trips, longest first
-// (one workgroup; within a count the order is whatever the atomics give -- the answers do not depend on it).  Also zeroes
-// the ticket counters of zmp_plan_kernel_dyn, which need a launch of their own otherwise.
-__global__ __launch_bounds__(1024) void zmp_order_kernel(const int * __restrict__ hist, int n, int * __restrict__ order,
-                                                         unsigned * __restrict__ queue_words, int nwords)
-{
-  constexpr int kB = 256;
-  __shared__ int cnt[kB];
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x;
-  if(tid < kB) cnt[tid] = 0;
-  for(int k = tid; k < nwords; k += 1024) queue_words[k] = 0u;
-  __syncthreads();
-  for(int i = tid; i < n; i += 1024)
-  {
-    const int t = hist[i];
-    atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
-  }
-  __syncthreads();
-  // exclusive prefix sum over the kB buckets (four wavefronts)
-  int v = 0, incl = 0;
-  if(tid < kB)
-  {
-    v = cnt[tid];
-    incl = v;
-    for(int d = 1; d < 64; d <<= 1)
-    {
-      const int o = __shfl_up(incl, d);
-      if((tid & 63) >= d) incl += o;
-    }
-    if((tid & 63) == 63) wsum[tid >> 6] = incl;
-  }
-  __syncthreads();
-  if(tid < kB)
-  {
-    int base = 0;
-    for(int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-    cnt[tid] = base + incl - v;
-  }
-  __syncthreads();
-  for(int i = tid; i < n; i += 1024)
-  {
-    const int t = hist[i];
-    const int pos = atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
-    order[pos] = i;
-  }
-}
-
 template<int LG, int WAVES>
 int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
            double * jerk, int32_t * status, hipStream_t stream)
@@ -1279,11 +1231,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
       CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
       CCC_HIP_CHECK(hipMalloc(&h->queue, qbytes));
     }
-    if(ordered)
-      hipLaunchKernelGGL(zmp_order_kernel, dim3(1), dim3(1024), 0, stream, h->hist, (int)nqp, h->order,
-                         reinterpret_cast<unsigned *>(h->queue), (int)(qbytes / 4));
-    else if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream))
-      return zrc;
+    if(int zrc = zero_words(h->queue, (int)(qbytes / 4), stream)) return zrc;
     int & per_cu = h->per_cu; // resident workgroups per CU (the kernel loops on the queue: one grid-full is all it needs)
     if(per_cu == 0)
     {
@@ -1299,9 +1247,9 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     if(P.hist) h->hist_n = nqp;
     return CCC_OK;
   }
+  // the schedule of this call from the pivot counts of the last one: a counting sort, longest first (common.hip)
   if(ordered)
-    hipLaunchKernelGGL(zmp_order_kernel, dim3(1), dim3(1024), 0, stream, h->hist, (int)nqp, h->order,
-                       static_cast<unsigned *>(nullptr), 0);
+    if(int orc = order_by_count(h->hist, (int)nqp, h->order, nullptr, 0, nullptr, stream)) return orc;
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
   CCC_HIP_CHECK(hipGetLastError());

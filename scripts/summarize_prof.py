@@ -25,8 +25,11 @@ for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     meta = {}
     path = os.path.join(src, "%s_%s" % (tag, d), "zmp_counter_collection.csv")
     for r in csv.DictReader(open(path)):
-        if "zmp_plan_kernel_dyn" not in r["Kernel_Name"]:  # the headline launches (the pinned-host p50 loop of bench.py
-            continue                                         # also runs the static kernel on 8192-instance chunks)
+        # the headline launches: the static-pairing kernel on a handle with a history (round 5; bench.py's leg without a
+        # history runs zmp_plan_kernel_dyn, the ordering itself is zmp_order_kernel -- both have lines of their own in the
+        # kernel statistics)
+        if "zmp_plan_kernel<" not in r["Kernel_Name"]:
+            continue
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta = dict(kernel=r["Kernel_Name"].split("(")[0], grid=r["Grid_Size"], wg=r["Workgroup_Size"],
                     lds=r["LDS_Block_Size"], vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], scratch=r["Scratch_Size"])
@@ -52,7 +55,7 @@ print(json.dumps(out, indent=1))
 # (fp64 FMA at full rate); 256 CUs x 4 SIMDs; clock from the kernel trace's average duration at 2.4 GHz
 dur_ns = None
 for r in csv.DictReader(open(os.path.join(dst, tag + "_zmp_kernel_stats.csv"))):
-    if "zmp_plan_kernel_dyn" in r["Name"]:
+    if "zmp_plan_kernel<" in r["Name"]:
         dur_ns = float(r["AverageNs"])
         break
 valu = dict(tag=tag, kernel_hash=KH, batch=65536, kernel=rows[0]["kernel"], kernel_avg_ns=dur_ns, sq_insts_valu=c["SQ_INSTS_VALU"],

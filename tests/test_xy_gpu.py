@@ -315,6 +315,45 @@ def test_rounds_of_the_stage_recursion_kernel_are_bit_identical(monkeypatch):
     assert np.abs(early["lam"] - res[0]["lam"]).max() <= 1e-7 * scale
 
 
+def test_history_order_of_the_first_round_is_a_schedule_only(monkeypatch):
+    """Round 5: a handle keeps the sweeps every instance of its last call took and runs the first round of a call of the
+    same size in that order, longest first, so that the lanes of a wavefront stop together (csrc/xy.hip
+    ccc_xy_plan_batch_device, common.hip order_by_count).  An instance's arithmetic does not depend on its lane: the
+    repeated batch, another batch of the same size (a history that predicts nothing), another size and the way back all
+    give what a handle without a history gives, bit for bit -- inputs, multipliers and iteration counts."""
+    import torch
+
+    monkeypatch.delenv("CCC_XY_DUAL", raising=False)
+    N, dt, mass, n = 20, 0.1, 100.0, 5000
+    pA, xA = fd.make_xy_batch(n, N, dt, mass, seed=31)
+    xB = xA * 1.05 + 0.01
+    dev = torch.device("cuda:0")
+    tp = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in pA.items()}
+
+    def run(m, x, k=n):
+        tk = {a: v[:k].contiguous() for a, v in tp.items()}
+        tx = torch.from_numpy(np.ascontiguousarray(x[:k])).to(dev)
+        u = torch.zeros((k, 16), dtype=torch.float64, device=dev)
+        lam = torch.zeros((k, N, 16), dtype=torch.float64, device=dev)
+        st = torch.zeros(k, dtype=torch.int32, device=dev)
+        m.plan_batch_device(tk, tx, u, lambda_all=lam, status=st)
+        torch.cuda.synchronize()
+        return u.cpu().numpy(), lam.cpu().numpy(), st.cpu().numpy()
+
+    monkeypatch.setenv("CCC_XY_HISTORY", "0")
+    ref = LinearMpcXY(mass, dt, N)
+    monkeypatch.delenv("CCC_XY_HISTORY")
+    rA, rB, rC = run(ref, xA), run(ref, xB), run(ref, xA, n - 129)
+    assert np.all((rA[2] & 0xff) == 0)
+    sweeps = rA[2] >> 8
+    assert sweeps.min() <= 2 and np.percentile(sweeps, 90) >= 6  # (there is something to order)
+    m = LinearMpcXY(mass, dt, N)
+    for got, want in ((run(m, xA), rA), (run(m, xA), rA), (run(m, xB), rB), (run(m, xA, n - 129), rC), (run(m, xA), rA),
+                      (run(m, xA), rA)):
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("env", [{"CCC_XY_DUAL": "1"}, {"CCC_XY_PDAS_ITERS": "1"}, {"CCC_XY_PDAS_ITERS": "3"},
                                  {"CCC_XY_STREAM": "1", "CCC_XY_ROUNDS": "2,5,9"}])
 def test_dual_kernel_and_fallback_list(env):
