@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
                          "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
+    ap.add_argument("--no-history-leg", action="store_true",
+                    help="skip the second measurement on a handle without a history (profiling runs: one kind of launch)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the `secondary` entries (configs 3, 4, 5: xy 65536 x 3 steps, ddp 4096 x 3, "
                          "srb 32768 x 2, each with roofline / cpu_baseline / parity) the default one-GPU command appends")
@@ -331,7 +333,7 @@ def main():
     # it and reported as `history.value_without_history`: what a caller whose batches have nothing to do with each
     # other gets.
     no_hist = None
-    if world == 1:
+    if world == 1 and not args.no_history_leg:
         os.environ["CCC_ZMP_HISTORY"] = "0"
         try:
             mpc0 = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
@@ -474,7 +476,7 @@ def main():
                          "kernel": timed_kernel,
                          "kernel_avg_ms": kavg * 1e3,
                          "kernel_avg_ms_what": "HIP events round the library call on its stream: the solve kernel plus, on a "
-                                               "handle with a history, zmp_order_kernel (one workgroup: counting sort of the "
+                                               "handle with a history, the two order_by_count kernels (counting sort of the "
                                                "last call's pivot counts) in front of it -- both in profiles/*_zmp_kernel_stats.csv",
                          "valu": {"achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": tflops / FP64_VECTOR_PEAK_TFLOPS,

@@ -23,6 +23,19 @@ def _tile(d, n, base):
     return {a: np.concatenate([v] * k)[:n] for a, v in d.items()}
 
 
+def _without_history(env, make):
+    """A handle created with the library's history switch `env` off (the switches are read when a handle is created)."""
+    old = os.environ.get(env)
+    os.environ[env] = "0"
+    try:
+        return make()
+    finally:
+        if old is None:
+            del os.environ[env]
+        else:
+            os.environ[env] = old
+
+
 def _xy_algo(status):
     """Bytes a lane must move (csrc/xy.hip, stage-recursion kernel): inputs and outputs once, the ridge vectors into the
     workspace once (7 doubles per ridge), then per iteration and stage: the backward sweep reads 43 doubles (the clamped
@@ -60,6 +73,11 @@ def _xy(n, dev, rank, walking=False):
     def step(stream):
         mpc.plan_batch_device(tp, tx0, out, status=st, stream=stream)
 
+    def nohist():
+        m0 = _without_history("CCC_XY_HISTORY", lambda: LinearMpcXY(100.0, dt, N, device=dev.index, max_ridges=M))
+        o0 = torch.zeros_like(out)
+        return (lambda stream: m0.plan_batch_device(tp, tx0, o0, stream=stream)), (m0, o0)
+
     def cpu(cores, ns=None):
         from oracle import oracle
         ns = min(n, ns or (512 if walking else 2048))
@@ -81,7 +99,9 @@ def _xy(n, dev, rank, walking=False):
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
                 algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, stream_bytes=_xy_algo,
-                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0), mfma=XY_MFMA)
+                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0), mfma=XY_MFMA, nohist=nohist,
+                history_what="the first round of the block iteration takes the instances in the order of the sweeps the "
+                             "handle's last call of this size spent on each (DESIGN.md section 8)")
 
 
 def _ddp(n, dev, rank, srb, walking=False):
@@ -104,14 +124,18 @@ def _ddp(n, dev, rank, srb, walking=False):
         prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
     prob = _tile(prob, n, base)
     x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
-    if srb:
-        w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0),
-                                           terminal_ori=(0.5,) * 3)
-        d = DdpSingleRigidBody(100.0, dt, N, w, device=dev.index, **kw)
-    else:
-        d = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
-                          device=dev.index, **kw)
-    d.ddp_solver_.config().max_iter = 20
+    def handle():
+        if srb:
+            w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0),
+                                               terminal_ori=(0.5,) * 3)
+            h = DdpSingleRigidBody(100.0, dt, N, w, device=dev.index, **kw)
+        else:
+            h = DdpCentroidal(100.0, dt, N, DdpCentroidal.WeightParam(running_pos=(1, 1, 10), terminal_pos=(1, 1, 10)),
+                              device=dev.index, **kw)
+        h.ddp_solver_.config().max_iter = 20
+        return h
+
+    d = handle()
     tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
     out = torch.zeros((n, N, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -119,6 +143,11 @@ def _ddp(n, dev, rank, srb, walking=False):
 
     def step(stream):
         d.plan_batch_device(tp, tx0, out, iters=it, status=st, stream=stream)
+
+    def nohist():
+        d0 = _without_history("CCC_DDP_HISTORY", handle)
+        o0 = torch.zeros_like(out)
+        return (lambda stream: d0.plan_batch_device(tp, tx0, o0, stream=stream)), (d0, o0)
 
     def cpu(cores, ns=None):
         from oracle import oracle
@@ -149,7 +178,9 @@ def _ddp(n, dev, rank, srb, walking=False):
                 + S * 8 + N * M * 8,
                 kernel="ddp_tile_kernel<%d, %d>" % (S, M // 16), cpu=cpu,
                 valu=lambda iters: _ddp_valu(S, M, N, iters, walking),
-                keep=(d, tp, tx0))
+                keep=(d, tp, tx0), nohist=nohist,
+                history_what="fresh instances are handed out longest-first from the busy times of the handle's last call of "
+                             "this size, and none is suspended (DESIGN.md section 7.4)")
 
 
 def _ddp_valu(S, M, N, iters, walking):
@@ -338,12 +369,13 @@ def run(args, rank, world, local_rank, dist):
         n //= world
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     out = measure(args.workload, n, steps, warmup, rank, world, local_rank, dist, strong=strong,
-                  cpu=not args.no_cpu_baseline, dinfo=getattr(args, "distributed_info", None))
+                  cpu=not args.no_cpu_baseline, dinfo=getattr(args, "distributed_info", None),
+                  history_leg=not getattr(args, "no_history_leg", False))
     if out is not None:
         print(json.dumps(out))
 
 
-def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=False, cpu=True, dinfo=None):
+def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=False, cpu=True, dinfo=None, history_leg=True):
     """One bench line (a dict; None on ranks other than 0) of a secondary workload: `warmup` untimed steps, `steps` timed
     ones bracketed by barrier + synchronize, max over ranks.  Also what bench.py's default command appends to the headline
     line as `secondary` (configs 3, 4, 5: VERDICT r4 item 2)."""
@@ -433,6 +465,23 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
         out["roofline"]["valu"] = dict(achieved=v["simd_valu_busy_frac"], peak=1.0, unit="share of SIMD VALU cycles busy",
                                        frac=v["simd_valu_busy_frac"],
                                        dense_equivalent_tflops=v["dense_equivalent_flop_per_solve"] * n / kavg / 1e12, **v)
+    if world == 1 and history_leg and "nohist" in w:
+        # `value` is of a handle that has seen the batch (the timed steps repeat it): the same steps on a handle that keeps no
+        # history, for a caller whose batches have nothing to do with each other
+        step0, keep0 = w["nohist"]()
+        for _ in range(max(1, warmup)):
+            step0(stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step0(stream)
+        torch.cuda.synchronize(dev)
+        e0 = time.perf_counter() - t1
+        out["history"] = {"value_without_history": n * steps / e0, "ms_per_step_without_history": 1e3 * e0 / steps,
+                          "what": "`value`: a handle that has seen this batch -- " + w["history_what"]
+                                  + "; value_without_history: the same steps on a handle created with the history switched "
+                                    "off.  The answers are the same bits either way (tests/)"}
+        del step0, keep0
     if cpu and world == 1:
         import bench  # (host_cores: physical cores within the affinity mask and the cgroup CPU quota)
 

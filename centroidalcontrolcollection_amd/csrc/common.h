@@ -52,9 +52,11 @@ struct DeviceGuard
 // lengths, tickets) are reset with this rather than hipMemsetAsync: captured in a hipGraph, a 4-byte memset node
 // followed a foreign kernel with a memory access fault on replay (ROCm 7.2; tests/test_graph_capture_gpu.py).
 int zero_words(void * p, int words, void * stream);
-// order[0 .. n) = the items sorted by hist[], largest first (in-stream; see common.hip); optionally zeroes nwords words at
-// `zero` and stores n in *count_out in the same launch
-int order_by_count(const int * hist, int n, int * order, void * zero, int nwords, int * count_out, void * stream);
+// order[0 .. n) = the items sorted by hist[], largest first (in-stream, two launches; see common.hip); `scratch`:
+// kOrderScratchInts ints of the caller's; optionally zeroes nwords words at `zero` and stores n in *count_out on the way
+constexpr int kOrderBlocks = 128;
+constexpr int kOrderScratchInts = kOrderBlocks * 256;
+int order_by_count(const int * hist, int n, int * order, int * scratch, void * zero, int nwords, int * count_out, void * stream);
 
 // The `_device` entry points are asynchronous and graph-capturable EXCEPT when a handle's workspace has to grow (a batch
 // larger than any seen before): hipMalloc / hipFree synchronise the device and invalidate an active capture.  Growth

@@ -1,6 +1,8 @@
 // common.hip -- error reporting and device selection of libccc_amd.
 #include "common.h"
 
+#include <algorithm>
+
 #include <cstring>
 
 namespace ccc_amd
@@ -27,59 +29,72 @@ int zero_words(void * p, int words, void * stream)
 }
 
 // Schedules from the last call's counts (round 5; csrc/zmp.hip: pivot trips per QP, csrc/xy.hip: sweeps per instance): a
-// counting sort of the n items by count, largest first (one workgroup; within a count the order is whatever the atomics
-// give -- the answers never depend on it).  Optionally zeroes `nwords` words and stores n in *count_out, so that a caller
-// that needs those done in-stream as well does not pay a launch for each.
-__global__ __launch_bounds__(1024) void order_by_count_kernel(const int * __restrict__ hist, int n, int * __restrict__ order,
-                                                              unsigned * __restrict__ zero, int nwords, int * count_out)
+// counting sort of the n items by count, largest first; within a count the order is whatever the atomics give -- the
+// answers never depend on it.  Two launches over kOrderBlocks chunks of the items (one workgroup doing all of it took
+// 85 us for the headline's 131072 QPs, a sixth of the solve): (1) every workgroup counts its chunk into a row of
+// `scratch` [blocks][256]; (2) every workgroup finds where its items of each count start -- the items of larger counts of
+// all chunks, then the same count of the chunks before it -- and places them.  Optionally zeroes `nwords` words and stores
+// n in *count_out, so that a caller that needs those done in-stream as well does not pay a launch for each.
+constexpr int kOrderBuckets = 256;
+__device__ __forceinline__ int order_bucket(int t) { return kOrderBuckets - 1 - (t < 0 ? 0 : (t > kOrderBuckets - 1 ? kOrderBuckets - 1 : t)); }
+
+__global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict__ hist, int n, int chunk, int * __restrict__ scratch,
+                                                          unsigned * __restrict__ zero, int nwords, int * count_out)
 {
-  constexpr int kB = 256;
-  __shared__ int cnt[kB];
-  __shared__ int wsum[4];
-  const int tid = threadIdx.x;
-  if(tid < kB) cnt[tid] = 0;
-  for(int k = tid; k < nwords; k += 1024) zero[k] = 0u;
-  __syncthreads();
-  for(int i = tid; i < n; i += 1024)
+  __shared__ int cnt[kOrderBuckets];
+  const int tid = threadIdx.x, blk = blockIdx.x;
+  cnt[tid] = 0;
+  if(blk == 0)
   {
-    const int t = hist[i];
-    atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
+    for(int k = tid; k < nwords; k += 256) zero[k] = 0u;
+    if(tid == 0 && count_out) *count_out = n;
   }
   __syncthreads();
-  // exclusive prefix sum over the kB buckets (four wavefronts)
-  int v = 0, incl = 0;
-  if(tid < kB)
-  {
-    v = cnt[tid];
-    incl = v;
-    for(int d = 1; d < 64; d <<= 1)
-    {
-      const int o = __shfl_up(incl, d);
-      if((tid & 63) >= d) incl += o;
-    }
-    if((tid & 63) == 63) wsum[tid >> 6] = incl;
-  }
+  const int lo = blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for(int i = lo + tid; i < hi; i += 256) atomicAdd(&cnt[order_bucket(hist[i])], 1);
   __syncthreads();
-  if(tid < kB)
-  {
-    int base = 0;
-    for(int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-    cnt[tid] = base + incl - v;
-  }
-  __syncthreads();
-  for(int i = tid; i < n; i += 1024)
-  {
-    const int t = hist[i];
-    const int pos = atomicAdd(&cnt[kB - 1 - (t < 0 ? 0 : (t > kB - 1 ? kB - 1 : t))], 1);
-    order[pos] = i;
-  }
-  if(tid == 0 && count_out) *count_out = n;
+  scratch[blk * kOrderBuckets + tid] = cnt[tid];
 }
 
-int order_by_count(const int * hist, int n, int * order, void * zero, int nwords, int * count_out, void * stream)
+__global__ __launch_bounds__(256) void order_place_kernel(const int * __restrict__ hist, int n, int chunk, const int * __restrict__ scratch,
+                                                          int * __restrict__ order)
 {
-  hipLaunchKernelGGL(order_by_count_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), hist, n, order,
-                     static_cast<unsigned *>(zero), nwords, count_out);
+  __shared__ int pos[kOrderBuckets];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
+  // bucket tid: items of it in all chunks, and in the chunks before this one
+  int total = 0, before = 0;
+  for(int b = 0; b < nblk; b++)
+  {
+    const int c = scratch[b * kOrderBuckets + tid];
+    total += c;
+    before += b < blk ? c : 0;
+  }
+  // exclusive prefix of `total` over the buckets (four wavefronts)
+  int incl = total;
+  for(int d = 1; d < 64; d <<= 1)
+  {
+    const int o = __shfl_up(incl, d);
+    if((tid & 63) >= d) incl += o;
+  }
+  if((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for(int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  pos[tid] = base + incl - total + before;
+  __syncthreads();
+  const int lo = blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for(int i = lo + tid; i < hi; i += 256) order[atomicAdd(&pos[order_bucket(hist[i])], 1)] = i;
+}
+
+int order_by_count(const int * hist, int n, int * order, int * scratch, void * zero, int nwords, int * count_out, void * stream)
+{
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int blocks = std::max(1, std::min(kOrderBlocks, (n + 1023) / 1024));
+  const int chunk = (n + blocks - 1) / blocks;
+  hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, s, hist, n, chunk, scratch, static_cast<unsigned *>(zero),
+                     nwords, count_out);
+  hipLaunchKernelGGL(order_place_kernel, dim3(blocks), dim3(256), 0, s, hist, n, chunk, scratch, order);
   if(hipGetLastError() != hipSuccess) return fail(CCC_ERR_HIP, "order_by_count: launch failed");
   return CCC_OK;
 }

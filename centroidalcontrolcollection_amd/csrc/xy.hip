@@ -1579,7 +1579,7 @@ struct ccc_xy
   int wander = 0;          // changed ridges per iteration beyond which a late instance counts as wandering (CCC_XY_WANDER; 0: off)
   // round 5: the sweeps every instance of the last call took, and the order of the next call of the same size made from
   // them (CCC_XY_HISTORY=0: never)
-  int *hist = nullptr, *order = nullptr;
+  int *hist = nullptr, *order = nullptr, *order_scratch = nullptr;
   int64_t hist_cap = 0, hist_n = -1;
   bool env_history = true;
 };
@@ -1649,6 +1649,7 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
   if(h->ws) (void)hipFree(h->ws);
   if(h->hist) (void)hipFree(h->hist);
   if(h->order) (void)hipFree(h->order);
+  if(h->order_scratch) (void)hipFree(h->order_scratch);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   if(h->side) (void)hipStreamDestroy(h->side);
@@ -1760,6 +1761,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
         h->hist_n = -1;
         CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)n * sizeof(int)));
         CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)n * sizeof(int)));
+        if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
         h->hist_cap = n;
       }
       ordered = h->hist_n == n;
@@ -1793,7 +1795,7 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
     }
     if(ordered)
     {
-      if(int orc = order_by_count(h->hist, (int)n, h->order, W.redo_count, 3 * kXsRounds, n_word, s)) return orc;
+      if(int orc = order_by_count(h->hist, (int)n, h->order, h->order_scratch, W.redo_count, 3 * kXsRounds, n_word, s)) return orc;
     }
     else if(int zrc = zero_words(W.redo_count, 3 * kXsRounds, s))
       return zrc;

@@ -1075,6 +1075,7 @@ struct ccc_zmp
   double *dG = nullptr, *dA = nullptr, *db = nullptr;
   unsigned long long * queue = nullptr; // work-queue ticket counter of zmp_plan_kernel_dyn
   int *hist = nullptr, *order = nullptr; // K1: pivot trips per QP of the last call, and the schedule made from them
+  int * order_scratch = nullptr;         // (order_by_count's table)
   int64_t hist_cap = 0, hist_n = -1;     // (hist_n: the QPs of the call the counts belong to, -1 = none yet)
   bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
                                          //  about the next)
@@ -1195,11 +1196,13 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     {
       if(h->hist) (void)hipFree(h->hist);
       if(h->order) (void)hipFree(h->order);
+  if(h->order_scratch) (void)hipFree(h->order_scratch);
       h->hist = h->order = nullptr;
       h->hist_cap = 0;
       h->hist_n = -1;
       CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
       CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
+      if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
       h->hist_cap = nqp;
     }
     ordered = h->hist_n == nqp;
@@ -1249,7 +1252,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   }
   // the schedule of this call from the pivot counts of the last one: a counting sort, longest first (common.hip)
   if(ordered)
-    if(int orc = order_by_count(h->hist, (int)nqp, h->order, nullptr, 0, nullptr, stream)) return orc;
+    if(int orc = order_by_count(h->hist, (int)nqp, h->order, h->order_scratch, nullptr, 0, nullptr, stream)) return orc;
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
   CCC_HIP_CHECK(hipGetLastError());

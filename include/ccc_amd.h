@@ -89,7 +89,12 @@ const char * ccc_zmp_last_kernel(const ccc_zmp_t * h);
  *   status  [n][2]        optional, per axis: (pivots << 8) | CCC_STATUS_*  -- low byte = solver status,
  *                         upper bits = active-set pivots spent on that axis' QP
  *
- * All pointers are DEVICE pointers; the call is asynchronous on `stream`. */
+ * All pointers are DEVICE pointers; the call is asynchronous on `stream`.
+ *
+ * Scheduling (N <= 32; round 5): a handle remembers the pivots every QP of its last call took; a call with the same n runs
+ * the QPs longest first, QPs of like counts sharing a wavefront (closed-loop callers hand over nearly the same batch cycle
+ * after cycle).  The answers never depend on it -- bit-identical to a handle created with CCC_ZMP_HISTORY=0 in the
+ * environment.  A handle holds per-call state (this order, the work-queue tickets): use one handle per stream at a time. */
 int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double * x0, const double * zlim, double control_dt,
                               double * zmp, double * jerk, int32_t * status, void * stream);
 
@@ -306,7 +311,10 @@ int ccc_xy_get_params(const ccc_xy_t * h, ccc_xy_params_t * params, int * device
  *   u0             [n][M]          f64  planned force scales of step 0 (first dim[.][0] entries = the return value)
  *   lambda_all     [n][N][M]       f64  optional: every QP variable, per step
  *   status         [n]             i32  optional: CCC_STATUS_*
- * All DEVICE pointers, asynchronous on `stream`. */
+ * All DEVICE pointers, asynchronous on `stream`.
+ * Scheduling (round 5): a call with the n of the handle's last call takes the instances in the order of the sweeps that call
+ * spent on each (the lanes of a wavefront then stop together); the answers do not depend on it (CCC_XY_HISTORY=0 in the
+ * environment when the handle is created: never).  One handle per stream at a time. */
 int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t * dim, const double * vertex, const double * ridge,
                              const double * com_z, const double * total_force_z, const double * ref_out,
                              const double * x0, double * u0, double * lambda_all, int32_t * status, void * stream);

@@ -83,7 +83,7 @@ for short in ("xystream", "xydual"):
 if xy:
     # dispatches per step: count from the kernel stats (calls of the profiled run / launches of a step)
     traffic["xy"] = dict(batch=65536, kernel_hash=KH["xy"], kernels=xy, total_bytes_in_the_profiled_run=tot,
-                         note="divide by the batched calls of the profiled run (bench.py --workload xy --steps 3 --warmup 1: "
+                         note="divide by the batched calls of the profiled run (bench.py --workload xy --steps 5 --warmup 1: the first call without an order: "
                               "see <tag>_xy_kernel_stats.csv for the calls per kernel) for bytes per 65536-instance step")
     calls = None
     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_xy_kernel_stats.csv" % tag))):
