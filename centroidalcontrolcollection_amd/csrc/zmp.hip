@@ -1196,7 +1196,6 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     {
       if(h->hist) (void)hipFree(h->hist);
       if(h->order) (void)hipFree(h->order);
-  if(h->order_scratch) (void)hipFree(h->order_scratch);
       h->hist = h->order = nullptr;
       h->hist_cap = 0;
       h->hist_n = -1;
@@ -1464,6 +1463,7 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->queue) (void)hipFree(h->queue);
   if(h->hist) (void)hipFree(h->hist);
   if(h->order) (void)hipFree(h->order);
+  if(h->order_scratch) (void)hipFree(h->order_scratch);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);
