@@ -63,12 +63,19 @@ __global__ __launch_bounds__(256) void order_place_kernel(const int * __restrict
   __shared__ int wsum[4];
   const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
   // bucket tid: items of it in all chunks, and in the chunks before this one
+  // (the loads of sixteen chunks in flight at a time: one after the other this loop was most of the sort's 20 us)
   int total = 0, before = 0;
-  for(int b = 0; b < nblk; b++)
+  for(int b0 = 0; b0 < nblk; b0 += 16)
   {
-    const int c = scratch[b * kOrderBuckets + tid];
-    total += c;
-    before += b < blk ? c : 0;
+    int c[16];
+#pragma unroll
+    for(int k = 0; k < 16; k++) c[k] = b0 + k < nblk ? scratch[(b0 + k) * kOrderBuckets + tid] : 0;
+#pragma unroll
+    for(int k = 0; k < 16; k++)
+    {
+      total += c[k];
+      before += b0 + k < blk ? c[k] : 0;
+    }
   }
   // exclusive prefix of `total` over the buckets (four wavefronts)
   int incl = total;
