@@ -8,10 +8,11 @@ env "$@" rocprofv3 --kernel-trace --output-format csv -d $d -o k -- python scrip
 python - "$d" <<'PY'
 import sys, csv, glob
 f = glob.glob(sys.argv[1] + "/**/k_kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "xy_plan" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "xy_" in r["Kernel_Name"] or "order_" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-n = len(rows) // 3          # three calls (warm-up + 2 timed)
-last = rows[-n:]
+# the last call: from the last launch of the first kernel a call with a history starts with (or a third of the rows)
+marks = [i for i, r in enumerate(rows) if "order_count" in r["Kernel_Name"]]
+last = rows[marks[-1]:] if marks else rows[-(len(rows) // 3):]
 t0 = int(last[0]["Start_Timestamp"])
 for r in last:
     print("%-24s start %8.3f  end %8.3f  dur %7.3f ms  grid %s queue %s" % (r["Kernel_Name"].replace("ccc_amd::", "").replace("void ", "")[:24], (int(r["Start_Timestamp"]) - t0) / 1e6,
