@@ -334,13 +334,19 @@ def test_cpp_header_shim_reference_scenario():
     assert np.abs(np.array(fin_cpp) - np.array([0.64215196, -0.05244137])).max() < 1e-6
 
 
-def test_work_queue_kernel_equals_static_pairing(mpc32):
-    """Large batches run zmp_plan_kernel_dyn (a work queue per 32-lane group), small ones the static pairing: the
-    arithmetic of a QP is the same, so an odd-sized large batch must reproduce, bit for bit, what chunks of 4096 give
-    (ZMP, jerk and pivot counts), and the queue must hand out every QP exactly once."""
-    n = 20001  # 40002 QPs: above the dispatch threshold, not a multiple of anything
+def test_work_queue_kernel_equals_static_pairing(mpc32, monkeypatch):
+    """Large first calls run zmp_plan_kernel_dyn (a work queue per 32-lane group), small ones the static pairing: the
+    arithmetic of a QP is the same, so an odd-sized batch on the queue kernel must reproduce, bit for bit, what chunks of
+    4096 on the static kernel give (ZMP, jerk and pivot counts), and the queue must hand out every QP exactly once."""
+    n = 20001  # 40002 QPs: not a multiple of anything (CCC_ZMP_QUEUE_MIN=0: the queue kernel whatever the size)
     b = fx.make_zmp_batch(n, 32, 0.0625, seed=77)
-    full = mpc32.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    monkeypatch.setenv("CCC_ZMP_QUEUE_MIN", "0")
+    monkeypatch.setenv("CCC_ZMP_HOST_CHUNK", "1000000")  # (one launch for the whole batch)
+    mq = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_QUEUE_MIN")
+    monkeypatch.delenv("CCC_ZMP_HOST_CHUNK")
+    full = mq.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert mq.last_kernel() == "zmp_plan_kernel_dyn<32,2>"
     assert np.all(full["status"] == 0)
     for a in range(0, n, 4096):
         part = mpc32.planOnceBatch(b["x0"][a:a + 4096], b["zlim"][a:a + 4096], 0.005, want_jerk=True)
