@@ -353,7 +353,8 @@ def main():
                            "previous call's pivot counts, QPs of like counts paired in a wavefront (the answers do not "
                            "depend on the order: tests/test_zmp_gpu.py); value_without_history = the same steps on a "
                            "handle created with CCC_ZMP_HISTORY=0.  The device-side closed loop of TestLinearMpcZmp.cpp "
-                           "(every cycle a new problem) gains 16-27 % from the order: DESIGN.md section 4"}
+                           "(every cycle a new problem) gains 30-35 % from the order; unrelated batches of one size make "
+                           "the handle drop it (106 against 108 M solves/s without a history): DESIGN.md section 4"}
         del mpc0
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
     # ccc_zmp_plan_batch; PCIe-inclusive, never the `value` above

@@ -38,12 +38,43 @@ int zero_words(void * p, int words, void * stream)
 constexpr int kOrderBuckets = 256;
 __device__ __forceinline__ int order_bucket(int t) { return kOrderBuckets - 1 - (t < 0 ? 0 : (t > kOrderBuckets - 1 ? kOrderBuckets - 1 : t)); }
 
+// Does the history predict?  A kernel that keeps per-item counts can also keep, per item, |count now - count of the call
+// before| (`diff`); the counting pass adds them up beside the counts themselves (two more words per chunk behind the table),
+// and the verdict -- independent draws of a batch's counts differ by about a third of their sum, the consecutive cycles of
+// a closed loop by a few per cent: the history is trusted below a tenth -- goes to *flag: page-locked host memory that the
+// launching code reads, without waiting, a call or two later.
+__device__ void order_verdict(const int * __restrict__ scratch, int nblk, int * flag, int tid)
+{
+  if(tid < 64)
+  {
+    long long a = 0, sum = 0;
+    for(int b = tid; b < nblk; b += 64)
+    {
+      a += scratch[kOrderBlocks * kOrderBuckets + 2 * b];
+      sum += scratch[kOrderBlocks * kOrderBuckets + 2 * b + 1];
+    }
+    for(int d = 32; d >= 1; d >>= 1)
+    {
+      a += __shfl_xor(a, d);
+      sum += __shfl_xor(sum, d);
+    }
+    if(tid == 0 && sum > 0) __hip_atomic_store(flag, 10 * a < 2 * sum ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+__global__ __launch_bounds__(64) void order_verdict_kernel(const int * __restrict__ scratch, int nblk, int * flag)
+{
+  order_verdict(scratch, nblk, flag, threadIdx.x);
+}
+
 __global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict__ hist, int n, int chunk, int * __restrict__ scratch,
-                                                          unsigned * __restrict__ zero, int nwords, int * count_out)
+                                                          unsigned * __restrict__ zero, int nwords, int * count_out,
+                                                          const int * __restrict__ diff)
 {
   __shared__ int cnt[kOrderBuckets];
+  __shared__ int agree[2];
   const int tid = threadIdx.x, blk = blockIdx.x;
   cnt[tid] = 0;
+  if(tid < 2) agree[tid] = 0;
   if(blk == 0)
   {
     for(int k = tid; k < nwords; k += 256) zero[k] = 0u;
@@ -51,17 +82,42 @@ __global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict
   }
   __syncthreads();
   const int lo = blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  for(int i = lo + tid; i < hi; i += 256) atomicAdd(&cnt[order_bucket(hist[i])], 1);
+  int da = 0, ds = 0;
+  for(int i = lo + tid; i < hi; i += 256)
+  {
+    const int t = hist[i];
+    atomicAdd(&cnt[order_bucket(t)], 1);
+    if(diff)
+    {
+      da += diff[i];
+      ds += t;
+    }
+  }
+  if(diff)
+  {
+    for(int d = 32; d >= 1; d >>= 1)
+    {
+      da += __shfl_xor(da, d);
+      ds += __shfl_xor(ds, d);
+    }
+    if((tid & 63) == 0)
+    {
+      atomicAdd(&agree[0], da);
+      atomicAdd(&agree[1], ds);
+    }
+  }
   __syncthreads();
   scratch[blk * kOrderBuckets + tid] = cnt[tid];
+  if(diff && tid < 2) scratch[kOrderBlocks * kOrderBuckets + 2 * blk + tid] = agree[tid];
 }
 
 __global__ __launch_bounds__(256) void order_place_kernel(const int * __restrict__ hist, int n, int chunk, const int * __restrict__ scratch,
-                                                          int * __restrict__ order)
+                                                          int * __restrict__ order, int * flag)
 {
   __shared__ int pos[kOrderBuckets];
   __shared__ int wsum[4];
   const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
+  if(flag && blk == 0) order_verdict(scratch, nblk, flag, tid);
   // bucket tid: items of it in all chunks, and in the chunks before this one
   // (the loads of sixteen chunks in flight at a time: one after the other this loop was most of the sort's 20 us)
   int total = 0, before = 0;
@@ -94,14 +150,18 @@ __global__ __launch_bounds__(256) void order_place_kernel(const int * __restrict
   for(int i = lo + tid; i < hi; i += 256) order[atomicAdd(&pos[order_bucket(hist[i])], 1)] = i;
 }
 
-int order_by_count(const int * hist, int n, int * order, int * scratch, void * zero, int nwords, int * count_out, void * stream)
+int order_by_count(const int * hist, int n, int * order, int * scratch, void * zero, int nwords, int * count_out, void * stream,
+                   const int * diff, int * flag)
 {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int blocks = std::max(1, std::min(kOrderBlocks, (n + 1023) / 1024));
   const int chunk = (n + blocks - 1) / blocks;
   hipLaunchKernelGGL(order_count_kernel, dim3(blocks), dim3(256), 0, s, hist, n, chunk, scratch, static_cast<unsigned *>(zero),
-                     nwords, count_out);
-  hipLaunchKernelGGL(order_place_kernel, dim3(blocks), dim3(256), 0, s, hist, n, chunk, scratch, order);
+                     nwords, count_out, diff);
+  if(!order) // (the verdict alone: a history that is not followed is still watched)
+    hipLaunchKernelGGL(order_verdict_kernel, dim3(1), dim3(64), 0, s, scratch, blocks, flag);
+  else
+    hipLaunchKernelGGL(order_place_kernel, dim3(blocks), dim3(256), 0, s, hist, n, chunk, scratch, order, diff ? flag : nullptr);
   if(hipGetLastError() != hipSuccess) return fail(CCC_ERR_HIP, "order_by_count: launch failed");
   return CCC_OK;
 }

@@ -47,6 +47,7 @@ struct ZmpDev
   // the trips the PREVIOUS call of the same size spent on them, longest first: slot s of the schedule solves QP order[s]
   const int * order;
   int * hist;
+  int * diff; // (when given: |trips now - trips of the last call| per QP -> order_by_count's verdict on the history)
 };
 
 constexpr double kInf = __builtin_huge_val();
@@ -1076,7 +1077,11 @@ struct ccc_zmp
   unsigned long long * queue = nullptr; // work-queue ticket counter of zmp_plan_kernel_dyn
   int *hist = nullptr, *order = nullptr; // K1: pivot trips per QP of the last call, and the schedule made from them
   int * order_scratch = nullptr;         // (order_by_count's table)
+  int * diff = nullptr;                  // |trips - trips of the call before| per QP, and the verdict it leads to:
+  int *trust_host = nullptr, *trust_dev = nullptr; // page-locked host memory, read without waiting (0: do not follow)
   int64_t hist_cap = 0, hist_n = -1;     // (hist_n: the QPs of the call the counts belong to, -1 = none yet)
+  int64_t diff_n = -1;                   // (... and of the call the differences belong to)
+  unsigned watch = 0;
   bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
                                          //  about the next)
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
@@ -1187,7 +1192,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   // first (and, in the static kernel, pairs QPs of like counts in a wavefront).  Closed-loop callers repeat their batch
   // from cycle to cycle; for anybody else the order is as good as any other -- the answers never depend on it.
   // (inside a stream capture the buffers are not grown: the call runs unordered and keeps no counts)
-  bool ordered = false;
+  bool ordered = false, hist_verdict = false;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   if(h->env_history && !h->skip_history && nqp < (int64_t)1 << 30 && !(capturing && h->hist_cap < nqp))
@@ -1196,17 +1201,38 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     {
       if(h->hist) (void)hipFree(h->hist);
       if(h->order) (void)hipFree(h->order);
-      h->hist = h->order = nullptr;
+      if(h->diff) (void)hipFree(h->diff);
+      h->hist = h->order = h->diff = nullptr;
       h->hist_cap = 0;
       h->hist_n = -1;
       CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
       CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
+      CCC_HIP_CHECK(hipMalloc(&h->diff, (size_t)nqp * sizeof(int)));
       if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
+      if(!h->trust_host)
+      {
+        CCC_HIP_CHECK(hipHostMalloc(&h->trust_host, 64, hipHostMallocMapped));
+        *h->trust_host = 1;
+        CCC_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->trust_dev), h->trust_host, 0));
+      }
       h->hist_cap = nqp;
     }
-    ordered = h->hist_n == nqp;
+    // (a history that does not predict -- unrelated batches of one size, call after call -- is worse than none: the two
+    //  axes of an instance are better company for each other than two QPs picked by a wrong guess, 101 against 110 M
+    //  solves/s at 65536.  A call that has counts to compare with keeps the differences; the sort of the next call, or a
+    //  pass of its own when the history is not followed, turns them into a verdict that is read here a call or two late)
+    const bool comparable = h->hist_n == nqp, verdict = comparable && h->diff_n == nqp;
+    const bool trusted = *static_cast<volatile int *>(h->trust_host) != 0;
+    ordered = comparable && trusted;
     P.hist = h->hist;
     P.order = ordered ? h->order : nullptr;
+    P.diff = comparable ? h->diff : nullptr;
+    // (not followed: watched every fourth call -- the pass costs 7 us, a call of 8192 instances 97)
+    if(verdict && !ordered && (h->watch++ & 3) == 0)
+      if(int arc = order_by_count(h->hist, (int)nqp, nullptr, h->order_scratch, nullptr, 0, nullptr, stream, h->diff, h->trust_dev))
+        return arc;
+    hist_verdict = verdict;
+    h->diff_n = comparable ? nqp : -1;
   }
   // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~18 QPs per resident group the static
   // pairing (one instance per wavefront, more workgroups than fit: the hardware dispatcher balances) is faster -- measured
@@ -1251,7 +1277,8 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   }
   // the schedule of this call from the pivot counts of the last one: a counting sort, longest first (common.hip)
   if(ordered)
-    if(int orc = order_by_count(h->hist, (int)nqp, h->order, h->order_scratch, nullptr, 0, nullptr, stream)) return orc;
+    if(int orc = order_by_count(h->hist, (int)nqp, h->order, h->order_scratch, nullptr, 0, nullptr, stream, hist_verdict ? h->diff : nullptr,
+                                 h->trust_dev)) return orc;
   hipLaunchKernelGGL((zmp_plan_kernel<LG, WAVES>), dim3(grid), dim3(WAVES * 64), lds, stream, P, (long)nqp, x0, zlim,
                      control_dt, zmp, jerk, status);
   CCC_HIP_CHECK(hipGetLastError());
@@ -1464,6 +1491,8 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->hist) (void)hipFree(h->hist);
   if(h->order) (void)hipFree(h->order);
   if(h->order_scratch) (void)hipFree(h->order_scratch);
+  if(h->diff) (void)hipFree(h->diff);
+  if(h->trust_host) (void)hipHostFree(h->trust_host);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);

@@ -93,8 +93,9 @@ const char * ccc_zmp_last_kernel(const ccc_zmp_t * h);
  *
  * Scheduling (N <= 32; round 5): a handle remembers the pivots every QP of its last call took; a call with the same n runs
  * the QPs longest first, QPs of like counts sharing a wavefront (closed-loop callers hand over nearly the same batch cycle
- * after cycle).  The answers never depend on it -- bit-identical to a handle created with CCC_ZMP_HISTORY=0 in the
- * environment.  A handle holds per-call state (this order, the work-queue tickets): use one handle per stream at a time. */
+ * after cycle); when the counts of consecutive calls stop agreeing -- unrelated batches of one size -- the handle goes back
+ * to the plain dispatch until they agree again.  The answers never depend on it -- bit-identical to a handle created with
+ * CCC_ZMP_HISTORY=0 in the environment.  A handle holds per-call state (this order, the work-queue tickets): use one handle per stream at a time. */
 int ccc_zmp_plan_batch_device(ccc_zmp_t * h, int64_t n, const double * x0, const double * zlim, double control_dt,
                               double * zmp, double * jerk, int32_t * status, void * stream);
 

@@ -399,6 +399,45 @@ def test_history_schedule_gives_the_same_answers_whatever_the_caller_repeats(mon
         assert calls[1][0][3] == calls[2][0][3] == calls[5][0][3] == "zmp_plan_kernel<32,2>"  # (ordered calls: the static kernel)
 
 
+def test_a_history_that_does_not_predict_is_dropped_and_taken_up_again(monkeypatch):
+    """The order is only worth following when the last call's pivot counts say something about this call's: with unrelated
+    batches of one size, call after call, two QPs picked by a wrong guess are worse company in a wavefront than the two axes
+    of an instance.  The kernels keep |count - last count| per QP, the next call's sort adds them up, and the handle stops
+    following (and goes on watching) when they are a fifth of the counts themselves -- read from page-locked memory a call
+    or two late.  With CCC_ZMP_QUEUE_MIN=0 the kernel's name tells which way a call went; the answers never change."""
+    import torch
+
+    n = 5000
+    dev = torch.device("cuda:0")
+    bs = [fx.make_zmp_batch(n, 32, 0.0625, seed=40 + k) for k in range(4)]
+    monkeypatch.setenv("CCC_ZMP_HISTORY", "0")
+    ref = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_HISTORY")
+    monkeypatch.setenv("CCC_ZMP_QUEUE_MIN", "0")
+    m = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_QUEUE_MIN")
+
+    def run(h, b):
+        x0 = torch.from_numpy(b["x0"]).to(dev)
+        zl = torch.from_numpy(b["zlim"]).to(dev)
+        z = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        st = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        h.plan_batch_device(x0, zl, 0.005, z, None, st)
+        torch.cuda.synchronize()
+        return z.cpu().numpy(), st.cpu().numpy(), h.last_kernel()
+
+    want = [run(ref, b)[:2] for b in bs]
+    kernels = []
+    for k in [0] * 5 + [1, 2, 3] * 5 + [0] * 10:
+        z, st, name = run(m, bs[k])
+        assert np.array_equal(z, want[k][0]) and np.array_equal(st, want[k][1])
+        kernels.append(name)
+    static, queue = "zmp_plan_kernel<32,2>", "zmp_plan_kernel_dyn<32,2>"
+    assert kernels[0] == queue and kernels[1:5] == [static] * 4  # (first call: no counts yet; then the repeated batch)
+    assert kernels[14:20] == [queue] * 6                         # (unrelated batches: dropped within a few calls)
+    assert kernels[-3:] == [static] * 3                          # (the repeated batch again: taken up again)
+
+
 def test_random_horizons_sweep():
     """Thirty random (horizon, com_height, seed) combinations across the packed-tableau range: ZMP and jerk parity
     with the oracle (guards the tile bookkeeping at row counts that are not multiples of the tile size)."""
