@@ -31,6 +31,7 @@ struct ccc_ddp
   void * sched = nullptr;      // its scheduling state (csrc/ddp_batch.h DdpSched), sized for scap instances
   int64_t scap = -1;           // (-1: not allocated; 0: counters only)
   int slice = 2, slice_next = 4; // iterations of an instance's first / later slices (CCC_DDP_SLICE="a,b", development switch; 0: plain queue)
+  bool slice_env = false;      // (CCC_DDP_SLICE given: no choice by batch size)
   int slots = 0;               // CCC_DDP_SLOTS (development switch): resident workgroups to launch, 0 = what fits
   int update_kmax = 4;         // CCC_DDP_UPDATE_KMAX (development switch; the specification's S_UPDATE_KMAX is 4)
   int64_t hist_n = -1;         // batch size of the last sliced launch: its per-instance busy times (DdpSched::prev) order the
@@ -96,6 +97,7 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   // development switches, read once here
   if(const char * v = std::getenv("CCC_DDP_SLICE"))
   {
+    h->slice_env = true;
     h->slice = std::max(0, std::atoi(v));
     if(const char * c2 = std::strchr(v, ',')) h->slice_next = std::max(1, std::atoi(c2 + 1));
   }
@@ -242,6 +244,24 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
   DdpSched sched = ddp_sched_carve(h->sched, (long)h->scap, h->prm.horizon_steps, h->S);
   sched.slice = sliced ? h->slice : 0;
   sched.slice_next = h->slice_next;
+  if(sliced && !h->slice_env)
+  {
+    // (a suspension and the resumption after it write and read an instance's trajectories and rebuild its LDS tables -- more of
+    //  them since round 5: with many instances per slot, each suspended several times, short slices cost more than they
+    //  balance.  Measured without a history, SRB N = 50, slices 2,4 / 3,6 / 5,10: 32768 instances 197 / 141 / 133 ms,
+    //  16384 105 / 89 / 91 ms, 8192 72.5 / 72.2 / 74.5 ms; DdpCentroidal N = 100, 4096 instances 54.5 / - / 57.5 ms)
+    const int64_t per_slot = n / grid;
+    if(per_slot >= 16)
+    {
+      sched.slice = 5;
+      sched.slice_next = 10;
+    }
+    else if(per_slot >= 6)
+    {
+      sched.slice = 3;
+      sched.slice_next = 6;
+    }
+  }
   if(sliced)
   {
     h->hist_runs = (h->hist_n == n) ? h->hist_runs + 1 : 0; // launches of this size before this one
