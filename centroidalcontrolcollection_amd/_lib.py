@@ -23,7 +23,7 @@ CCC_STATUS_SOLVED = 0
 CCC_STATUS_INFEASIBLE = 1
 CCC_STATUS_MAX_ITER = 2
 
-ABI_VERSION = 4  # CCC_ABI_VERSION of include/ccc_amd.h
+ABI_VERSION = 5  # CCC_ABI_VERSION of include/ccc_amd.h
 
 # every symbol include/ccc_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -32,6 +32,9 @@ ABI_SYMBOLS = [
     "ccc_ddp_get_config",
     "ccc_ddp_get_device",
     "ccc_ddp_arithmetic",
+    "ccc_ddp_set_limits",
+    "ccc_ddp_last_call_aborted",
+    "ccc_ddp_set_inertia_per_phase",
     "ccc_ddp_effective_precision",
     "ccc_xy_get_params",
     "ccc_ddp_closed_loop_device",
@@ -51,6 +54,7 @@ ABI_SYMBOLS = [
     "ccc_ddp_sharded_destroy",
     "ccc_ddp_sharded_num_devices",
     "ccc_ddp_sharded_set_config",
+    "ccc_ddp_sharded_set_limits",
     "ccc_ddp_sharded_plan_batch_device",
     "ccc_last_error_string",
     "ccc_abi_version",

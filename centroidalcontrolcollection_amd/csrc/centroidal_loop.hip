@@ -365,6 +365,9 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
   const Timeline T = to_dev(tl, kLoopM);
   double t = t0;
   int rc = CCC_OK;
+  // (the loop's simulator has ONE inertia per instance, diag(inertia_diag): the planner takes it in the one-matrix layout
+  //  whatever layout the handle was created for)
+  if(prm.inertia_per_phase) (void)ccc_ddp_set_inertia_per_phase(h, 0);
   for(int c = 0; c < cycles && rc == CCC_OK; c++)
   {
     hipLaunchKernelGGL(sample_ddp_kernel, dim3(blocks(n * (N + 1))), dim3(256), 0, s, T, (long)n, N, t, prm.horizon_dt,
@@ -413,6 +416,7 @@ extern "C" int ccc_ddp_closed_loop_device(ccc_ddp_t * h, int64_t n, const ccc_co
     hipLaunchKernelGGL(sim_step_kernel, dim3(blocks(n)), dim3(256), 0, s, A);
   }
   (void)ccc_ddp_set_config(h, &cfg0);
+  if(prm.inertia_per_phase) (void)ccc_ddp_set_inertia_per_phase(h, 1);
   if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
   CCC_HIP_CHECK(hipStreamSynchronize(s)); // the workspaces die with this call

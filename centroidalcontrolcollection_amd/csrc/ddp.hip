@@ -39,6 +39,12 @@ struct ccc_ddp
   int hist_runs = 0;           // consecutive sliced launches of that size so far
   int history = 1;             // CCC_DDP_HISTORY=0 (development switch) turns the history off
   int num_cu = 0;
+  int per_cu[2] = {0, 0};      // resident workgroups per CU of this handle's kernel, one matrix per instance / per phase
+                               // (ddp_tile_blocks_per_cu: launch bounds capped by the runtime's occupancy query)
+  int * abort_host = nullptr;  // page-locked word a launch's waits raise when they give up (DdpSched::abort_host)
+  long long spin_budget_ms = 10000; // budget of a scheduler wait without progress (CCC_DDP_SPIN_BUDGET_MS, development
+                               // switch; 0 = wait for ever); handed to the kernel as a number of looks of ~4 us
+  int test_drop = -1;          // CCC_DDP_TEST_DROP (tests only): this instance of every sliced launch is lost
   // staging for the host entry
   int64_t hcap = 0;
   void * d_stage = nullptr;
@@ -104,6 +110,31 @@ extern "C" int ccc_ddp_create(const ccc_ddp_params_t * p, int device, ccc_ddp_t 
   if(const char * v = std::getenv("CCC_DDP_SLOTS")) h->slots = std::max(0, std::atoi(v));
   if(const char * v = std::getenv("CCC_DDP_UPDATE_KMAX")) h->update_kmax = std::max(0, std::atoi(v));
   if(const char * v = std::getenv("CCC_DDP_HISTORY")) h->history = std::atoi(v);
+  if(const char * v = std::getenv("CCC_DDP_SPIN_BUDGET_MS")) h->spin_budget_ms = std::max(0LL, std::atoll(v));
+  if(const char * v = std::getenv("CCC_DDP_TEST_DROP")) h->test_drop = std::atoi(v);
+  // the resident set the work queue is launched as: what the launch bounds ask for, checked against the runtime's occupancy
+  // figure for this kernel on this device (no assumption about co-residency is left unchecked)
+  for(int ipp = 0; ipp < (h->S == 12 ? 2 : 1); ipp++)
+  {
+    h->per_cu[ipp] = ddp_tile_blocks_per_cu(h->S, h->M, ipp != 0);
+    if(h->per_cu[ipp] <= 0)
+    {
+      delete h;
+      return fail(CCC_ERR_HIP, "ccc_ddp_create: the occupancy query for the DDP kernel (S = %d, M = %d) failed: %s", p->model == 0 ? 9 : 12,
+                  p->max_ridges ? p->max_ridges : CCC_DDP_MAX_RIDGES, hipGetErrorString(hipGetLastError()));
+    }
+  }
+  {
+    void * w = nullptr;
+    e = hipHostMalloc(&w, 64, hipHostMallocMapped);
+    if(e != hipSuccess)
+    {
+      delete h;
+      return fail(CCC_ERR_HIP, "ccc_ddp_create: hipHostMalloc: %s", hipGetErrorString(e));
+    }
+    h->abort_host = static_cast<int *>(w);
+    *h->abort_host = 0;
+  }
   *out = h;
   return CCC_OK;
 }
@@ -115,6 +146,7 @@ extern "C" void ccc_ddp_destroy(ccc_ddp_t * h)
   if(h->ws_t) (void)hipFree(h->ws_t);
   if(h->sched) (void)hipFree(h->sched);
   if(h->d_stage) (void)hipFree(h->d_stage);
+  if(h->abort_host) (void)hipHostFree(h->abort_host);
   if(h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -148,6 +180,7 @@ static void fill_params(const ccc_ddp * h, ddp_common::Params & P)
   for(int i = 0; i < 11; i++) P.alpha[i] = h->cfg.alpha_list[i];
   P.reg_type = h->cfg.reg_type;
   P.warm_guard = h->cfg.warm_start_guard ? 1 : 0;
+  P.inertia_per_phase = (h->prm.model == CCC_DDP_SINGLE_RIGID_BODY && h->prm.inertia_per_phase) ? 1 : 0;
   P.update_kmax = h->update_kmax;
 }
 
@@ -169,6 +202,25 @@ extern "C" int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg)
   if(cfg->precision != 64 && cfg->precision != 32)
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_config: precision must be 64 or 32");
   h->cfg = *cfg;
+  return CCC_OK;
+}
+
+// force_scale_limits_ is a live public member of the reference classes, read at every solve
+// (src/DdpCentroidal.cpp:202-210, src/DdpSingleRigidBody.cpp:272-280)
+extern "C" int ccc_ddp_set_limits(ccc_ddp_t * h, double lo, double hi)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_limits: NULL handle");
+  if(std::isnan(lo) || std::isnan(hi) || lo > hi)
+    return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_limits: need lo <= hi, got [%g, %g]", lo, hi);
+  h->prm.force_scale_limits[0] = lo;
+  h->prm.force_scale_limits[1] = hi;
+  return CCC_OK;
+}
+
+extern "C" int ccc_ddp_set_inertia_per_phase(ccc_ddp_t * h, int per_phase)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_set_inertia_per_phase: NULL handle");
+  h->prm.inertia_per_phase = per_phase ? 1 : 0;
   return CCC_OK;
 }
 
@@ -214,7 +266,8 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_plan_batch_device: the single-rigid-body model needs ref_ori and inertia");
   CCC_DEVICE_GUARD(h->device);
   // (precision = 32 runs this same fp64 kernel: ccc_amd.h)
-  int grid = ddp_tile_grid((long)n, h->M, h->num_cu);
+  const int per_cu = h->per_cu[(h->S == 12 && h->prm.inertia_per_phase) ? 1 : 0];
+  int grid = ddp_tile_grid((long)n, per_cu, h->num_cu);
   if(h->slots > 0 && h->slots < grid) grid = h->slots;
   if(grid > h->tcap)
   {
@@ -223,7 +276,7 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     h->ws_t = nullptr;
     h->tcap = 0;
     // (sized for a full resident set at once: later, larger batches do not allocate again)
-    const int full = ddp_tile_grid(1L << 40, h->M, h->num_cu);
+    const int full = ddp_tile_grid(1L << 40, std::max(h->per_cu[0], h->per_cu[1]), h->num_cu);
     CCC_HIP_CHECK(hipMalloc(&h->ws_t, (size_t)full * ddp_tile_ws_doubles(h->prm.horizon_steps, h->S, h->M) * sizeof(double)));
     h->tcap = full;
   }
@@ -268,6 +321,10 @@ extern "C" int ccc_ddp_plan_batch_device(ccc_ddp_t * h, int64_t n, const int32_t
     h->hist_n = n;                                          // (this launch leaves its busy times for the next one)
   }
   sched.use_history = (sliced && h->history && h->hist_runs >= 1) ? (h->hist_runs >= 2 ? 2 : 1) : 0;
+  sched.abort_host = h->abort_host;
+  sched.spin_limit = (unsigned)std::min(4000000000LL, h->spin_budget_ms * 250LL); // (a look of the long wait: ~4 us)
+  sched.test_drop = sliced ? h->test_drop : -1;
+  __atomic_store_n(h->abort_host, 0, __ATOMIC_RELAXED); // (raised again by this launch's waits if they give up)
   ddp_common::Params P;
   fill_params(h, P);
   DdpBatch B{phase_dim, phase_vertex, phase_ridge, step_phase, ref_pos, ref_ori, inertia, x0, u_init, u_out, x_out, iters, status, cost};
@@ -299,7 +356,7 @@ extern "C" int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phas
   };
   std::vector<Seg> in = {{phase_vertex, nullptr, n * Pn * M * 3 * 8, 0}, {phase_ridge, nullptr, n * Pn * M * 3 * 8, 0},
                          {ref_pos, nullptr, n * (N + 1) * 3 * 8, 0},     {ref_ori, nullptr, n * (N + 1) * 3 * 8, 0},
-                         {inertia, nullptr, (size_t)n * 9 * 8, 0},        {x0, nullptr, n * S * 8, 0},
+                         {inertia, nullptr, (size_t)n * 9 * 8 * (h->prm.inertia_per_phase ? Pn : 1), 0}, {x0, nullptr, n * S * 8, 0},
                          {u_init, nullptr, n * N * M * 8, 0},             {phase_dim, nullptr, n * Pn * 4, 0},
                          {step_phase, nullptr, n * N * 4, 0}};
   std::vector<Seg> outv = {{nullptr, u_out, n * N * M * 8, 0},
@@ -341,5 +398,15 @@ extern "C" int ccc_ddp_plan_batch(ccc_ddp_t * h, int64_t n, const int32_t * phas
   for(auto & s : outv)
     if(s.dst_host) CCC_HIP_CHECK(hipMemcpyAsync(s.dst_host, base + s.off, s.bytes, hipMemcpyDeviceToHost, h->stream));
   CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  if(ccc_ddp_last_call_aborted(h) == 1)
+    return fail(CCC_ERR_HIP, "ccc_ddp_plan_batch: the scheduler of the DDP kernel gave up a wait that saw no progress for about %.1f s; the "
+                             "instances it did not complete carry status CCC_DDP_STATUS_ABORTED", (double)h->spin_budget_ms * 1e-3);
   return CCC_OK;
+}
+
+// 1: a wait of the most recent launch's scheduler gave up (DdpSched: bounded waits); valid once that launch has completed
+extern "C" int ccc_ddp_last_call_aborted(const ccc_ddp_t * h)
+{
+  if(!h) return -1;
+  return h->abort_host && __atomic_load_n(h->abort_host, __ATOMIC_RELAXED) != 0 ? 1 : 0;
 }

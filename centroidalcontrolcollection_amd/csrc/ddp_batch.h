@@ -26,6 +26,7 @@ struct Params
   double alpha[11];
   int reg_type;   // 1: Quu_F + lambda I, 2: Vxx + lambda I (oracle/ddp.c)
   int warm_guard; // ccc_ddp_config_t::warm_start_guard
+  int inertia_per_phase; // ccc_ddp_params_t::inertia_per_phase: inertia is [n][P][3][3], one matrix per contact phase
   int update_kmax; // changed ridges a refactorisation of the box-QP absorbs by rank-one updates (oracle/ddp_tile.c
                    // S_UPDATE_KMAX = 4; CCC_DDP_UPDATE_KMAX overrides it for timing experiments: 0 = always afresh)
 };
@@ -65,7 +66,10 @@ struct DdpSched
   unsigned * finished; // instances completed
   int * head;          // [kDdpSchedBuckets] next entry to resume
   int * tail;          // [kDdpSchedBuckets] entries reserved
-  int * slot;          // [kDdpSchedBuckets][cap] instance ids (-1: reserved, not written yet)
+  unsigned long long * slot; // [kDdpSchedBuckets][cap] ring entries, SEQUENCE-TAGGED (round 6, ADVICE r4 / VERDICT r5 item 8): entry
+                       //       e of a list lives in slot e % cap as ((e + 1) << 32) | instance; 0 = free.  A popper that took
+                       //       index e waits for THAT tag, a pusher waits for the slot to be free -- an entry can neither be
+                       //       read before it is written nor overwritten before it is read, whatever the interleaving
   double * save_x;     // [cap][(N + 1) S] states of the suspended solves (their inputs wait in u_out)
   double * save_s;     // [cap][8] cost, lambda, dlambda, iterations done, (timing aid x 2), warm start replaced
   long cap;
@@ -87,6 +91,20 @@ struct DdpSched
                        //       bucket where that tenth begins
   int use_history;     // 0: no history for this batch size; 1: the previous call had the same size; 2: ... and the one before
                        //    (so trust[1 .. 2] are a verdict on the history)
+  // Bounded waits (round 6).  Every wait of the scheduler -- for a ring entry's writer, for a free ring slot, for the
+  // instances still in someone else's slice -- watches the launch's progress (instances finished + slices ended); a wait
+  // that sees none for spin_limit looks in a row (~4 us each in the long wait; 0 = wait for ever) sets `abort`, and every wavefront leaves at its next
+  // look at the scheduler: the kernel EXITS, the instances that were not completed keep the status CCC_DDP_STATUS_ABORTED
+  // they were given at launch, and the host learns of it through abort_host (page-locked memory).  Progress does not need
+  // the whole grid to be resident (a waiting wavefront holds no instance: whatever is unfinished is being solved by a
+  // wavefront that runs, or sits in a list any wavefront may take it from), so a CU mask or a shared GPU slows a launch
+  // down but cannot stall it; what the budget catches is a wavefront that is lost with an instance (a fault, a debugger).
+  unsigned * beat;     // slices ended so far in this launch
+  int * abort;         // != 0: a wait gave up
+  int * abort_host;    // the same word for the host (page-locked, written with system scope), or nullptr
+  unsigned spin_limit;
+  int test_drop;       // >= 0 (tests only, CCC_DDP_TEST_DROP): the wavefront that takes this fresh instance drops it -- an
+                       //      injected "lost" instance, to exercise the budget
 };
 // bytes of device memory behind a DdpSched for `cap` instances, and its carving
 size_t ddp_sched_bytes(long cap, int N, int S);
@@ -97,7 +115,10 @@ size_t ddp_sched_bytes(long cap, int N, int S);
 // (ddp_tile_grid) pulls instances from a ticket counter; ws = grid x ddp_tile_ws_doubles(N, S, M) doubles of workspace,
 // sched = the launch's scheduling state (reset by the launch; slice > 0 needs its lists sized for cap >= n)
 size_t ddp_tile_ws_doubles(int N, int S, int M);
-int ddp_tile_grid(long n, int M, int num_cu);
+// workgroups per CU that are resident at once: what the launch bounds ask for, capped by what the runtime's occupancy
+// query grants this kernel on this device (checked when a handle is created; <= 0: the query failed)
+int ddp_tile_blocks_per_cu(int S, int M, bool inertia_per_phase);
+int ddp_tile_grid(long n, int per_cu, int num_cu);
 DdpSched ddp_sched_carve(void * mem, long cap, int N, int S);
 hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, double * ws, const DdpSched & sched, int grid, long n,
                            int S, int M, hipStream_t stream);

@@ -125,7 +125,7 @@ struct Instance
   const int * step_phase;      // [N]
   const double * ref_pos;      // [N+1][3]
   const double * ref_ori;      // [N+1][3]  (SRB)
-  const double * inertia;      // [9]       (SRB)
+  const double * inertia;      // [9] or, in the IPP builds (Params::inertia_per_phase), [P][9]   (SRB)
   const double * x0;           // [S]
   const double * u_init;       // [N][M] or nullptr
   double * xbuf;               // [kSlots][N+1][S]
@@ -229,9 +229,12 @@ W64_FN void vllt3(const double * L, const double * R, const vf (&b)[3], vf (&x)[
   x[0] = (y0 - l10 * x[1] - l20 * x[2]) * r00;
 }
 
-template<int S, int B>
+// IPP (single-rigid-body model only): MotionParam::inertia_mat per contact phase (Params::inertia_per_phase) -- a build of
+// its own, so that the register allocation of the one-matrix-per-instance kernels (config 5) is what it was
+template<int S, int B, bool IPP = false>
 struct Solver
 {
+  static_assert(!IPP || S == 12, "the centroidal model has no inertia matrix");
   static_assert(B == 1 || B == 2 || B == 4, "16, 32 or 64 ridges per step");
   static constexpr int M = 16 * B;
   static constexpr int LS = Mem<S, B>::LS;
@@ -353,9 +356,10 @@ struct Solver
       mem.wterm[e] = e < S ? P.w_term[e] : 0.0;
     }
     for(int e = 0; e < 12; e++) mem.alpha[e] = e < 11 ? P.alpha[e] : 0.0;
-    for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12) ? I.inertia[e] : 0.0;
+    // (one inertia matrix per instance: here; one per contact phase -- IPP -- in contact_of())
+    for(int e = 0; e < 9; e++) mem.inertia[e] = (S == 12 && !IPP) ? I.inertia[e] : 0.0;
     for(int e = 0; e < 3; e++) mem.rll[e] = 0.0;
-    if(S == 12)
+    if(S == 12 && !IPP)
     {
       double lf[6];
       vllt3_factor(I.inertia, lf);
@@ -411,12 +415,30 @@ struct Solver
     const int d = I.phase_dim[ph];
     return d < 0 ? 0 : (d > M ? M : d);
   }
+  // MotionParam::inertia_mat number k of the instance, its Cholesky factor and the reciprocals of the factor's diagonal ->
+  // LDS.  The reference reads motion_param_func_(t).inertia_mat at every step (src/DdpSingleRigidBody.cpp:56-57 in
+  // stateEq, :120-123 in calcStateEqDeriv, where it also factorises it): with IPP a contact phase IS a distinct MotionParam
+  // -- contact list and inertia matrix -- and the matrix is cached with the phase's contact vectors.  The factor's
+  // statements are vllt3_factor's whichever way the matrix is indexed, so a phase's six numbers are the ones the oracle
+  // forms at each of its steps.
+  W64_FN void inertia_of(int k)
+  {
+    const double * In = I.inertia + static_cast<long>(k) * 9;
+    double lf[6];
+    vllt3_factor(In, lf);
+    for(int e = 0; e < 9; e++) mem.inertia[e] = In[e];
+    for(int e = 0; e < 6; e++) mem.llt[e] = lf[e];
+    mem.rll[0] = 1.0 / lf[0];
+    mem.rll[1] = 1.0 / lf[3];
+    mem.rll[2] = 1.0 / lf[5];
+  }
   // the step's contact phase into Vc / Rc
   template<int AB>
   W64_FN void contact_of(int ph, int dim)
   {
     if(ph == ph_cached) return;
     ph_cached = ph;
+    if(IPP) inertia_of(ph);
     const long base = static_cast<long>(ph) * M * 3;
     for(int b = 0; b < AB; b++)
     {

@@ -2,8 +2,8 @@
 // either regularisation, one instance per wavefront (64-thread workgroup), every matrix distributed over the 64 lanes, the
 // backward step in structured form (no M x M object; DESIGN.md sections 7.2-7.4).  Register budget: no spills before
 // occupancy -- two wavefronts per SIMD at 16 and 32 ridges per step, one at 64 (CCC_TILE_WAVES* below; the compiler's
-// register / scratch / LDS figures of every instantiation are pinned in tests/test_kernel_resources.py); LDS 7.4-11.2 KB
-// per wavefront whatever the ridge stride.  One resident set of workgroups pulls instances from a work queue, longest
+// register / scratch / LDS figures of every instantiation are pinned in tests/test_kernel_resources.py); LDS 10.7-15.4 KB
+// per wavefront (pinned with the register figures).  One resident set of workgroups pulls instances from a work queue, longest
 // remaining first, in bit-identical slices of iterations (csrc/ddp_batch.h DdpSched).
 // What ccc_ddp_plan_batch_device runs by default (csrc/ddp.hip); its arithmetic is the tile specification of
 // oracle/ddp_tile.c, reproduced bit for bit (tests/test_ddp_gpu.py, tests/test_ddp_tile_emu.py).
@@ -30,20 +30,63 @@ size_t ddp_tile_ws_doubles(int N, int S, int M)
 #ifndef CCC_TILE_WAVES4
 #  define CCC_TILE_WAVES4 1
 #endif
-__global__ void ddp_sched_reset_kernel(int * counters, size_t words, int * slot, size_t fill)
+// status of an instance the launch did not complete (include/ccc_amd.h CCC_DDP_STATUS_ABORTED): given to every instance at
+// launch, overwritten by the exit code when its solve finishes
+constexpr int kDdpStatusAborted = -2;
+__global__ void ddp_sched_reset_kernel(int * counters, size_t words, unsigned long long * slot, size_t fill, int * status, size_t n)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if(i < words)
   {
-    if(i < 2 || i >= 8) counters[i] = 0; // (words 2 .. 7 carry the verdict on the history from launch to launch: DdpSched::trust)
+    if(i < 2 || i >= 6) counters[i] = 0; // (words 2 .. 5 carry the verdict on the history from launch to launch: DdpSched::trust)
   }
   else if(i - words < fill)
-    slot[i - words] = -1;
+    slot[i - words] = 0ull; // (free)
+  if(status && i < n) status[i] = kDdpStatusAborted;
 }
 
 // device-scope loads / stores of the scheduling words (other wavefronts, possibly on another XCD, write them)
 __device__ __forceinline__ int sched_load(const int * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned sched_load(const unsigned * p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sched_load(const unsigned long long * p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One look of a waiting wavefront at the launch's state (DdpSched: bounded waits).  True = leave: another wait gave up
+// already, or this one has looked spin_limit times in a row without seeing an instance finish or a slice end -- then it
+// raises `abort` itself, for the other wavefronts and (page-locked word) for the host.  `watch` is the wavefront's
+// watch (two words of LDS).  The budget counts LOOKS, not time (a look of the long wait is an s_sleep 64 and two
+// loads, ~4 us: csrc/ddp.hip converts): reading the clock here (s_memrealtime in the wait loops) cost every build of the
+// kernel 200 B of scratch per lane -- the words of DdpSched by value for the same reason.
+__device__ __forceinline__ bool sched_wait_gives_up(int * abort, int * abort_host, const unsigned * finished, const unsigned * beat,
+                                                    unsigned spin_limit, int lane, unsigned * watch)
+{
+  // (lane 0 alone, its watch in LDS -- watch[0]: progress last seen, 0xffffffff starts the watch; watch[1]: looks since:
+  //  carried in scalar registers by the whole wavefront, the same statements cost every build 200 B of scratch per lane)
+  int r = 0;
+  if(lane == 0)
+  {
+    if(sched_load(abort) != 0)
+      r = 1;
+    else
+    {
+      const unsigned pr = (sched_load(finished) + sched_load(beat)) & 0x7fffffffu;
+      if(pr != watch[0])
+      {
+        watch[0] = pr;
+        watch[1] = 0u;
+      }
+      else if(spin_limit != 0u && ++watch[1] > spin_limit)
+      {
+        __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(abort_host) __hip_atomic_store(abort_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r = 1;
+      }
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(r) != 0;
+}
 
 // bucket of an estimate of `ticks` (100 MHz) of remaining work: four per octave from 2^8 ticks up -- monotone in the
 // estimate, which is all the order needs
@@ -95,181 +138,61 @@ __global__ __launch_bounds__(1024) void ddp_order_kernel(const float * prev, lon
   }
 }
 
+#define CCC_TILE_BOUNDS(NB) __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4)))
 template<int S, int NB>
-__global__ __launch_bounds__(64, (NB == 1 ? CCC_TILE_WAVES : (NB == 2 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4))) void ddp_tile_kernel(
-    ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, DdpSched Sc)
+__global__ CCC_TILE_BOUNDS(NB) void ddp_tile_kernel(ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, DdpSched Sc)
 {
-  __shared__ ddp_tile::Mem<S, NB> mem;
-  constexpr int M = 16 * NB;
-  const int N = P.N;
-  const int lane = threadIdx.x;
-  const size_t sx_stride = (size_t)(N + 1) * S;
-  // Work queue: the grid is one resident set of workgroups (one workspace per resident workgroup).  Each
-  // takes the next FRESH instance from a ticket counter; when those are handed out, the suspended ones, slowest first.
-  bool fresh_left = true;
-  // longest-processing-time-first from the previous call's busy times (csrc/ddp_batch.h), when they are there and held
-  const bool follow = Sc.use_history != 0 && __hip_atomic_load(Sc.trust, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-  for(;;)
-  {
-    long b = -1;
-    bool resumed = false;
-    if(fresh_left)
-    {
-      unsigned t = 0;
-      if(lane == 0) t = atomicAdd(Sc.ticket, 1u);
-      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-      if((long)t < n)
-        b = follow ? (long)Sc.order[t] : (long)t;
-      else
-        fresh_left = false;
-    }
-    if(b < 0 && Sc.slice > 0)
-    {
-      for(;;)
-      {
-        // lane k looks at bucket k; the highest non-empty one is taken from (compare-and-swap on its head: a head never
-        // passes its tail)
-        const int hd = sched_load(Sc.head + lane), tl = sched_load(Sc.tail + lane);
-        const unsigned long long ne = __ballot(hd < tl);
-        if(ne != 0ull)
-        {
-          const int k = 63 - __builtin_clzll(ne);
-          const int hk = __builtin_amdgcn_readlane(hd, k);
-          int ok = 0;
-          if(lane == 0) ok = atomicCAS(Sc.head + k, hk, hk + 1) == hk ? 1 : 0;
-          ok = __builtin_amdgcn_readfirstlane(ok);
-          if(!ok) continue;
-          int id;
-          for(;;) // (the entry was reserved before the tail moved; its writer is a few instructions behind at most)
-          {
-            id = lane == 0 ? sched_load(Sc.slot + (size_t)k * Sc.cap + hk % Sc.cap) : 0;
-            id = __builtin_amdgcn_readfirstlane(id);
-            if(id >= 0) break;
-            __builtin_amdgcn_s_sleep(8);
-          }
-          // (the lists are rings: an instance is in one list at a time, so at most n <= cap entries are outstanding and
-          //  the entry is free again for the push that comes round to it)
-          if(lane == 0) __hip_atomic_store(Sc.slot + (size_t)k * Sc.cap + hk % Sc.cap, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          b = id;
-          resumed = true;
-          break;
-        }
-        unsigned f = lane == 0 ? sched_load(Sc.finished) : 0u;
-        f = (unsigned)__builtin_amdgcn_readfirstlane((int)f);
-        if((long)f >= n) break; // every instance is complete
-        __builtin_amdgcn_s_sleep(64); // (an instance still in its first slice may yet be suspended)
-      }
-    }
-    if(b < 0) break;
-    ddp_tile::Instance I;
-    I.phase_dim = B.phase_dim + b * P.P;
-    I.phase_vertex = B.phase_vertex + b * P.P * M * 3;
-    I.phase_ridge = B.phase_ridge + b * P.P * M * 3;
-    I.step_phase = B.step_phase + b * N;
-    I.ref_pos = B.ref_pos + b * (N + 1) * 3;
-    I.ref_ori = B.ref_ori ? B.ref_ori + b * (N + 1) * 3 : nullptr;
-    I.inertia = B.inertia ? B.inertia + b * 9 : nullptr;
-    I.x0 = B.x0 + b * S;
-    I.u_init = B.u_init ? B.u_init + b * N * M : nullptr;
-    double * w = ws + (size_t)blockIdx.x * ws_stride;
-    I.xbuf = w;
-    w += (size_t)ddp_tile::kSlots * (N + 1) * S;
-    I.ubuf = w;
-    w += (size_t)ddp_tile::kSlots * N * M;
-    I.ks = w;
-    w += (size_t)N * M;
-    I.Ks = w;
-    I.u_out = B.u_out + b * N * M;
-    I.x_out = B.x_out ? B.x_out + b * (N + 1) * S : nullptr;
-    I.out_iters = B.iters ? B.iters + b : nullptr;
-    I.out_status = B.status ? B.status + b : nullptr;
-    I.out_cost = B.cost ? B.cost + b : nullptr;
-    ddp_tile::Solver<S, NB> solver(P, I, mem);
-    if(resumed)
-    {
-      __threadfence(); // (acquire: the state below was written by the wavefront that suspended the instance)
-      solver.resume(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 8);
-    }
-    else
-      solver.begin();
-    // busy ticks of the instance so far travel in save_s[4] (the history of the next call; with -DCCC_TILE_TIMING also the
-    // first start in save_s[5], scripts/ddp_sched_probe.py)
-    const long long tt0 = (long long)wall_clock64();
-    double * const tsv = Sc.slice > 0 ? Sc.save_s + (size_t)b * 8 : nullptr;
-    if(!resumed && Sc.slice > 0 && lane == 0)
-    {
-      tsv[4] = 0.0;
-#if defined(CCC_TILE_TIMING)
-      tsv[5] = (double)tt0;
-#endif
-    }
-#if defined(CCC_TILE_TIMING)
-    solver.timing_busy = (Sc.slice > 0 && resumed) ? tsv[4] : 0.0;
-    solver.timing_first = (Sc.slice > 0 && resumed) ? tsv[5] : (double)tt0;
-    solver.timing_slice0 = tt0;
-#endif
-    for(int budget = Sc.slice > 0 ? (resumed ? Sc.slice_next : Sc.slice) : -1;; budget = Sc.slice_next)
-    {
-      const long long t0 = (long long)wall_clock64();
-      const int it0 = solver.iters_done;
-      if(solver.iterate(budget))
-      {
-        solver.finish();
-        __syncthreads();
-        if(Sc.slice > 0 && lane == 0)
-        {
-          const float busy = (float)(tsv[4] + (double)((long long)wall_clock64() - tt0));
-          if(Sc.use_history != 0)
-          {
-            const int tail = Sc.trust[3];
-            if(sched_bucket((long long)Sc.prev[b]) >= tail)
-            {
-              atomicAdd(Sc.trust + 1, 1);
-              if(sched_bucket((long long)busy) >= tail - 2) atomicAdd(Sc.trust + 2, 1);
-            }
-          }
-          Sc.prev[b] = busy;
-          atomicAdd(Sc.finished, 1u);
-        }
-        break;
-      }
-      // what is left of this solve, as far as one can tell: the pace of the slice x the iterations it may still take
-      const long long per = ((long long)wall_clock64() - t0) / (solver.iters_done > it0 ? solver.iters_done - it0 : 1);
-      const int k = sched_bucket(per * (P.max_iter - solver.iters_done));
-      // longest remaining first: the instance steps aside for fresh ones (nobody knows yet how long those are) and for
-      // suspended ones that look about as long or longer; when only shorter ones wait, it keeps its wavefront
-      const unsigned tk = lane == 0 ? sched_load(Sc.ticket) : 0u;
-      const bool fresh_waiting = (long)(unsigned)__builtin_amdgcn_readfirstlane((int)tk) < n;
-      const unsigned long long ne = __ballot(sched_load(Sc.head + lane) < sched_load(Sc.tail + lane));
-      const int lowest = k > 0 ? k - 1 : 0;
-      if(!fresh_waiting && (ne >> lowest) == 0ull) continue;
-      if(follow) continue; // (list scheduling: the order was settled at the hand-out, every solve runs to completion)
-      solver.suspend(Sc.save_x + (size_t)b * sx_stride, Sc.save_s + (size_t)b * 8);
-      if(lane == 0) tsv[4] = tsv[4] + (double)((long long)wall_clock64() - tt0);
-      __threadfence(); // (release: the state is out before the entry is)
-      if(lane == 0)
-      {
-        const int e = atomicAdd(Sc.tail + k, 1);
-        __hip_atomic_store(Sc.slot + (size_t)k * Sc.cap + e % Sc.cap, (int)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      break;
-    }
-    __syncthreads();
-  }
+#define CCC_TILE_IPP false
+#include "ddp_tile_body.inc"
+#undef CCC_TILE_IPP
 }
-
-// workgroups of one resident set: wavefronts per SIMD (launch bounds above) x 4 SIMDs x CUs
-int ddp_tile_grid(long n, int M, int num_cu)
+// one inertia matrix per contact phase (ccc_ddp_params_t::inertia_per_phase; the single-rigid-body model): kernels of their
+// own, so that the one-matrix-per-instance kernels keep their names and their register allocation
+template<int NB>
+__global__ CCC_TILE_BOUNDS(NB) void ddp_tile_ipp_kernel(ddp_common::Params P, DdpBatch B, double * ws, size_t ws_stride, long n, DdpSched Sc)
 {
-  const int per_cu = 4 * (M == 16 ? CCC_TILE_WAVES : (M == 32 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4));
+  constexpr int S = 12;
+#define CCC_TILE_IPP true
+#include "ddp_tile_body.inc"
+#undef CCC_TILE_IPP
+}
+#undef CCC_TILE_BOUNDS
+
+// workgroups per CU of one resident set: wavefronts per SIMD (launch bounds above) x 4 SIMDs, capped by what the runtime
+// grants the kernel on the current device (registers, LDS) -- the scheduler's waits do not NEED the whole grid resident
+// (csrc/ddp_batch.h), but workgroups beyond the resident set would only queue behind it
+int ddp_tile_blocks_per_cu(int S, int M, bool ipp)
+{
+  const int want = 4 * (M == 16 ? CCC_TILE_WAVES : (M == 32 ? CCC_TILE_WAVES2 : CCC_TILE_WAVES4));
+  int got = 0;
+  hipError_t e = hipErrorInvalidValue;
+#define CCC_TILE_OCC(K) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&got, K, 64, 0)
+  if(S == 12 && ipp)
+  {
+    if(M == 16) CCC_TILE_OCC(ddp_tile_ipp_kernel<1>);
+    else if(M == 32) CCC_TILE_OCC(ddp_tile_ipp_kernel<2>);
+    else if(M == 64) CCC_TILE_OCC(ddp_tile_ipp_kernel<4>);
+  }
+  else if(S == 9 && M == 16) CCC_TILE_OCC((ddp_tile_kernel<9, 1>));
+  else if(S == 12 && M == 16) CCC_TILE_OCC((ddp_tile_kernel<12, 1>));
+  else if(S == 9 && M == 32) CCC_TILE_OCC((ddp_tile_kernel<9, 2>));
+  else if(S == 12 && M == 32) CCC_TILE_OCC((ddp_tile_kernel<12, 2>));
+  else if(S == 9 && M == 64) CCC_TILE_OCC((ddp_tile_kernel<9, 4>));
+  else if(S == 12 && M == 64) CCC_TILE_OCC((ddp_tile_kernel<12, 4>));
+#undef CCC_TILE_OCC
+  if(e != hipSuccess || got <= 0) return 0;
+  return got < want ? got : want;
+}
+int ddp_tile_grid(long n, int per_cu, int num_cu)
+{
   const long resident = (long)per_cu * (num_cu > 0 ? num_cu : 256);
   return (int)(n < resident ? n : resident);
 }
 
-// layout behind a DdpSched: [ticket, finished, trust x 4, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8]
+// layout behind a DdpSched: [ticket, finished, trust x 4, beat, abort, pad .. 64 words][head 64][tail 64][slot 64 x cap][save_s cap x 8]
 // [save_x cap x (N+1) S][prev cap][order cap]
 static size_t sched_off_slot() { return (size_t)(64 + 2 * kDdpSchedBuckets) * 4; }
-static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 4 + 255) / 256 * 256; }
+static size_t sched_off_s(long cap) { return (sched_off_slot() + (size_t)kDdpSchedBuckets * (size_t)cap * 8 + 255) / 256 * 256; }
 static size_t sched_off_x(long cap) { return sched_off_s(cap) + (size_t)cap * 8 * 8; }
 static size_t sched_off_prev(long cap, int N, int S) { return sched_off_x(cap) + (size_t)cap * (size_t)(N + 1) * S * 8; }
 size_t ddp_sched_bytes(long cap, int N, int S) { return sched_off_prev(cap, N, S) + (size_t)cap * 8 + 256; }
@@ -281,12 +204,17 @@ DdpSched ddp_sched_carve(void * mem, long cap, int N, int S)
   sc.finished = sc.ticket + 1;
   sc.head = reinterpret_cast<int *>(base) + 64;
   sc.tail = sc.head + kDdpSchedBuckets;
-  sc.slot = reinterpret_cast<int *>(base + sched_off_slot());
+  sc.slot = reinterpret_cast<unsigned long long *>(base + sched_off_slot());
   sc.save_s = reinterpret_cast<double *>(base + sched_off_s(cap));
   sc.save_x = reinterpret_cast<double *>(base + sched_off_x(cap));
   sc.prev = reinterpret_cast<float *>(base + sched_off_prev(cap, N, S));
   sc.order = reinterpret_cast<int *>(sc.prev + cap);
   sc.trust = reinterpret_cast<int *>(base) + 2; // (words 2 .. 5 of the header: NOT reset with the counters)
+  sc.beat = sc.ticket + 6;
+  sc.abort = reinterpret_cast<int *>(base) + 7;
+  sc.abort_host = nullptr;
+  sc.spin_limit = 0u;
+  sc.test_drop = -1;
   sc.cap = cap;
   sc.slice = 0;
   sc.slice_next = 0;
@@ -302,15 +230,23 @@ hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, dou
   // the library's own, not hipMemsetAsync: see zero_words in csrc/common.h.)
   {
     const size_t words = sched_off_slot() / 4, fill = sched.slice > 0 ? (size_t)kDdpSchedBuckets * (size_t)sched.cap : 0;
-    const size_t total = words + fill;
+    const size_t total = words + fill > (size_t)n ? words + fill : (size_t)n;
     hipLaunchKernelGGL(ddp_sched_reset_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       reinterpret_cast<int *>(sched.ticket), words, sched.slot, fill);
+                       reinterpret_cast<int *>(sched.ticket), words, sched.slot, fill, B.status, (size_t)n);
   }
   if(sched.use_history)
     hipLaunchKernelGGL(ddp_order_kernel, dim3(1), dim3(1024), 0, stream, sched.prev, n, sched.order, sched.trust,
                        sched.use_history > 1 ? 1 : 0);
 #define CCC_TILE_LAUNCH(S_, NB_) hipLaunchKernelGGL((ddp_tile_kernel<S_, NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, sched)
-  if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
+#define CCC_TILE_LAUNCH_IPP(NB_) hipLaunchKernelGGL((ddp_tile_ipp_kernel<NB_>), dim3(grid), dim3(64), 0, stream, P, B, ws, stride, n, sched)
+  if(S == 12 && P.inertia_per_phase)
+  {
+    if(M == 16) CCC_TILE_LAUNCH_IPP(1);
+    else if(M == 32) CCC_TILE_LAUNCH_IPP(2);
+    else if(M == 64) CCC_TILE_LAUNCH_IPP(4);
+    else return hipErrorInvalidValue;
+  }
+  else if(S == 9 && M == 16) CCC_TILE_LAUNCH(9, 1);
   else if(S == 12 && M == 16) CCC_TILE_LAUNCH(12, 1);
   else if(S == 9 && M == 32) CCC_TILE_LAUNCH(9, 2);
   else if(S == 12 && M == 32) CCC_TILE_LAUNCH(12, 2);
@@ -318,6 +254,7 @@ hipError_t launch_ddp_tile(const ddp_common::Params & P, const DdpBatch & B, dou
   else if(S == 12 && M == 64) CCC_TILE_LAUNCH(12, 4);
   else return hipErrorInvalidValue;
 #undef CCC_TILE_LAUNCH
+#undef CCC_TILE_LAUNCH_IPP
   return hipGetLastError();
 }
 } // namespace ccc_amd

@@ -435,6 +435,18 @@ extern "C" int ccc_ddp_sharded_set_config(ccc_ddp_sharded_t * h, const ccc_ddp_c
   return CCC_OK;
 }
 
+// force_scale_limits_ of every shard's planner (ccc_ddp_set_limits: the reference reads the member at every solve)
+extern "C" int ccc_ddp_sharded_set_limits(ccc_ddp_sharded_t * h, double lo, double hi)
+{
+  if(!h) return fail(CCC_ERR_INVALID_ARGUMENT, "ccc_ddp_sharded_set_limits: NULL handle");
+  for(ccc_ddp_t * d : h->handles)
+  {
+    int rc = ccc_ddp_set_limits(d, lo, hi);
+    if(rc != CCC_OK) return rc;
+  }
+  return CCC_OK;
+}
+
 extern "C" int ccc_ddp_sharded_plan_batch_device(ccc_ddp_sharded_t * h, int64_t n_per_device,
                                                  const int32_t * const * phase_dim, const double * const * phase_vertex,
                                                  const double * const * phase_ridge, const int32_t * const * step_phase,

@@ -36,7 +36,8 @@ def warm_start_replaced(status):
 class _Params(ctypes.Structure):
     _fields_ = [("model", ctypes.c_int), ("mass", ctypes.c_double), ("horizon_dt", ctypes.c_double),
                 ("horizon_steps", ctypes.c_int), ("w_run", ctypes.c_double * 12), ("w_term", ctypes.c_double * 12),
-                ("w_force", ctypes.c_double), ("force_scale_limits", ctypes.c_double * 2), ("max_phases", ctypes.c_int), ("max_ridges", ctypes.c_int)]
+                ("w_force", ctypes.c_double), ("force_scale_limits", ctypes.c_double * 2), ("max_phases", ctypes.c_int), ("max_ridges", ctypes.c_int),
+                ("inertia_per_phase", ctypes.c_int)]
 
 
 class Config(ctypes.Structure):
@@ -61,6 +62,10 @@ def _bind(L):
     L.ccc_ddp_destroy.argtypes = [vp]
     L.ccc_ddp_set_config.restype = ctypes.c_int
     L.ccc_ddp_set_config.argtypes = [vp, ctypes.POINTER(Config)]
+    L.ccc_ddp_set_limits.restype = ctypes.c_int
+    L.ccc_ddp_set_limits.argtypes = [vp, ctypes.c_double, ctypes.c_double]
+    L.ccc_ddp_set_inertia_per_phase.restype = ctypes.c_int
+    L.ccc_ddp_set_inertia_per_phase.argtypes = [vp, ctypes.c_int]
     L.ccc_ddp_state_dim.restype = ctypes.c_int
     L.ccc_ddp_state_dim.argtypes = [vp]
     L.ccc_ddp_arithmetic.restype = ctypes.c_int
@@ -111,7 +116,10 @@ class _DdpBase:
         for a in range(self.S):
             p.w_run[a], p.w_term[a] = float(w_run[a]), float(w_term[a])
         p.w_force = float(w_force)
-        p.force_scale_limits[0], p.force_scale_limits[1] = 0.0, 1e6  # force_scale_limits_, DdpCentroidal.h:364
+        # force_scale_limits_ (DdpCentroidal.h:364): a public member the reference reads at EVERY solve
+        # (src/DdpCentroidal.cpp:202-210) -- assign to it any time; every plan call pushes its current value (_push_state)
+        self.force_scale_limits_ = [0.0, 1e6]
+        p.force_scale_limits[0], p.force_scale_limits[1] = self.force_scale_limits_
         p.max_phases = int(max_phases)
         max_ridges = int(max_ridges) or MAX_RIDGES  # (the C-ABI reads 0 as the default stride, 16)
         p.max_ridges = max_ridges
@@ -151,7 +159,8 @@ class _DdpBase:
         if self.MODEL == 1:
             arr["ref_ori"] = np.ascontiguousarray(prob["ref_ori"], dtype=np.float64)
             arr["inertia"] = np.ascontiguousarray(prob["inertia"], dtype=np.float64)
-            shapes.update(ref_ori=(n, N + 1, 3), inertia=(n, 3, 3))
+            # [n,3,3]: one matrix per instance; [n,P,3,3]: one per contact phase (MotionParam::inertia_mat of its steps)
+            shapes.update(ref_ori=(n, N + 1, 3), inertia=(n, P, 3, 3) if arr["inertia"].ndim == 4 else (n, 3, 3))
         for k, shp in shapes.items():
             if arr[k].shape != shp:
                 raise ValueError("%s must have shape %s, got %s" % (k, shp, arr[k].shape))
@@ -167,7 +176,7 @@ class _DdpBase:
         iters = np.zeros(n, dtype=np.int32)
         status = np.zeros(n, dtype=np.int32)
         cost = np.zeros(n)
-        _lib.check(self._L.ccc_ddp_set_config(self._h, ctypes.byref(self.ddp_solver_.config())))
+        self._push_state(arr.get("inertia"))
 
         def p(a):
             return None if a is None else ctypes.c_void_p(a.ctypes.data)
@@ -178,6 +187,15 @@ class _DdpBase:
                                               p(iters), p(status), p(cost)))
         return dict(u=u, x=x, iters=iters, status=status, cost=cost, exit_code=exit_code(status),
                     warm_replaced=warm_start_replaced(status))
+
+    def _push_state(self, inertia=None):
+        """What the reference's solve() reads from the object at every call, pushed to the handle: ddp_solver_->config(),
+        force_scale_limits_ (src/DdpCentroidal.cpp:202-210) and the layout of `inertia` (4 dimensions = per phase)."""
+        _lib.check(self._L.ccc_ddp_set_config(self._h, ctypes.byref(self.ddp_solver_.config())))
+        _lib.check(self._L.ccc_ddp_set_limits(self._h, float(self.force_scale_limits_[0]), float(self.force_scale_limits_[1])))
+        if self.MODEL == 1 and inertia is not None:
+            ndim = inertia.dim() if hasattr(inertia, "dim") else np.ndim(inertia)
+            _lib.check(self._L.ccc_ddp_set_inertia_per_phase(self._h, 1 if ndim == 4 else 0))
 
     def effective_precision(self):
         """ccc_ddp_effective_precision: 64, whatever Config.precision asked for."""
@@ -197,7 +215,7 @@ class _DdpBase:
         if stream is None:
             stream = torch.cuda.current_stream(self.device)
         n = x0.shape[0]
-        _lib.check(self._L.ccc_ddp_set_config(self._h, ctypes.byref(self.ddp_solver_.config())))
+        self._push_state(prob.get("inertia"))
 
         def p(t):
             return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -218,7 +236,7 @@ class _DdpBase:
         phase per step if need be) created on first need -- the reference takes any contact_list
         (src/DdpCentroidal.cpp:49-60)."""
         N = self.horizon_steps_
-        ref_pos, ref_ori, inertia = np.zeros((1, N + 1, 3)), np.zeros((1, N + 1, 3)), np.zeros((1, 3, 3))
+        ref_pos, ref_ori = np.zeros((1, N + 1, 3)), np.zeros((1, N + 1, 3))
         step_phase = np.zeros((1, N), dtype=np.int32)
         phases = []
         for i in range(N + 1):
@@ -238,17 +256,18 @@ class _DdpBase:
             if len(V) > MAX_RIDGES_MULTI:
                 raise _lib.CccError(_lib.CCC_ERR_UNSUPPORTED, "%d ridges in one contact list, the kernels are built "
                                     "for %d (four 4-vertex surface contacts)" % (len(V), MAX_RIDGES_MULTI))
-            if self.MODEL == 1 and i == 0:
-                inertia[0] = mp.inertia_mat
-            for k, (Vk, Rk) in enumerate(phases):
-                if Vk.shape == V.shape and np.array_equal(Vk, V) and np.array_equal(Rk, R):
+            # a phase is a distinct MotionParam: contact list and, for the single-rigid-body model, inertia matrix -- the
+            # reference reads motion_param_func_(t).inertia_mat at every step (src/DdpSingleRigidBody.cpp:56-57,120-123)
+            In = np.array(mp.inertia_mat, dtype=np.float64).reshape(3, 3) if self.MODEL == 1 else None
+            for k, (Vk, Rk, Ik) in enumerate(phases):
+                if Vk.shape == V.shape and np.array_equal(Vk, V) and np.array_equal(Rk, R) and (In is None or np.array_equal(Ik, In)):
                     step_phase[0, i] = k
                     break
             else:
-                phases.append((V, R))
+                phases.append((V, R, In))
                 step_phase[0, i] = len(phases) - 1
         planner = self
-        widest = max([len(V) for V, _ in phases] + [0])
+        widest = max([len(ph[0]) for ph in phases] + [0])
         if len(phases) > self.max_phases_ or widest > self.max_ridges_:
             need = MAX_RIDGES if widest <= MAX_RIDGES else (MAX_RIDGES_WIDE if widest <= MAX_RIDGES_WIDE else MAX_RIDGES_MULTI)
             planner = self._twin(need)
@@ -256,11 +275,13 @@ class _DdpBase:
         prob = dict(phase_dim=np.zeros((1, P), dtype=np.int32), phase_vertex=np.zeros((1, P, M, 3)),
                     phase_ridge=np.zeros((1, P, M, 3)), step_phase=step_phase, ref_pos=ref_pos)
         if self.MODEL == 1:
-            prob["ref_ori"], prob["inertia"] = ref_ori, inertia
-        for k, (V, R) in enumerate(phases):
+            prob["ref_ori"], prob["inertia"] = ref_ori, np.tile(np.eye(3), (1, P, 1, 1))
+        for k, (V, R, In) in enumerate(phases):
             prob["phase_dim"][0, k] = len(V)
             prob["phase_vertex"][0, k, :len(V)] = V
             prob["phase_ridge"][0, k, :len(V)] = R
+            if In is not None:
+                prob["inertia"][0, k] = In
         return planner, prob
 
     def _twin(self, max_ridges):
@@ -271,6 +292,7 @@ class _DdpBase:
                               self._w_force, self.device, max_phases=self.horizon_steps_, max_ridges=max_ridges)
             twins[max_ridges] = t
         twins[max_ridges].ddp_solver_ = self.ddp_solver_  # one configuration / control data, as the caller sees one solver
+        twins[max_ridges].force_scale_limits_ = self.force_scale_limits_  # ... and one force_scale_limits_
         return twins[max_ridges]
 
     def _plan_once(self, motion_param_func, ref_data_func, x0, u_list, current_time):

@@ -136,6 +136,26 @@ def srb_weights(running_pos=(1.0, 1.0, 10.0), terminal_pos=(1.0, 1.0, 10.0), run
                 term=list(terminal_pos) + [terminal_ori] * 3 + [0.01] * 6, force=1e-6)
 
 
+def make_varying_inertia_batch(n, N, dt, seed):
+    """A single-rigid-body batch whose MotionParam::inertia_mat changes over the horizon (the reference reads
+    motion_param_func_(t).inertia_mat at every step, src/DdpSingleRigidBody.cpp:56-57,120-123): P = 7 phases -- the three
+    contact phases of make_centroidal_batch, each with its own full (non-diagonal) SPD matrix, plus copies of the first
+    stance phase's contacts with OTHER matrices for some of its steps (same contact list, another inertia: a phase boundary
+    inside a stance).  Returns (prob with inertia [n,3,3], prob with inertia [n,P,3,3], x0)."""
+    prob, x0 = make_centroidal_batch(n, N, dt, seed=seed, srb=True, P=7)
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, 7, 3, 3)) * 2.0
+    I4 = A @ np.swapaxes(A, -1, -2) + np.diag([40.0, 20.0, 10.0])
+    for p in (4, 5):
+        prob["phase_dim"][:, p] = prob["phase_dim"][:, 0]
+        prob["phase_vertex"][:, p], prob["phase_ridge"][:, p] = prob["phase_vertex"][:, 0], prob["phase_ridge"][:, 0]
+    first = prob["step_phase"] == 0
+    idx = np.arange(N)[None, :]
+    prob["step_phase"][first & (idx % 7 >= 3)] = 4
+    prob["step_phase"][first & (idx % 7 >= 5)] = 5
+    return prob, dict(prob, inertia=np.ascontiguousarray(I4)), x0
+
+
 def make_centroidal_batch(n, N=100, dt=0.03, mass=100.0, P=4, M=16, seed=20250928, srb=False):
     """Synthetic DDP workload of SURVEY.md section 8(d): rect 0.2x0.2 contact at the origin, a 0.2 s flight window
     starting at U(0.9, 1.9) s, then the rect shifted by U(0.2, 0.6) in x; reference CoM height 1.0 (1.2 in flight);

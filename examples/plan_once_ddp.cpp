@@ -98,6 +98,36 @@ int main()
       std::printf("srb iter=%d dim=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size());
       for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
       std::printf("\n");
+      // MotionParam::inertia_mat that changes over the horizon: the reference reads motion_param_func_(t).inertia_mat at every
+      // step (src/DdpSingleRigidBody.cpp:56-57,120-123), so does the shim (one contact phase per distinct MotionParam)
+      auto motion_varying = [&](double t) {
+        CCC::DdpSingleRigidBody::MotionParam mp = motion(t);
+        const double s = t / 3.0;
+        mp.inertia_mat(0, 0) += 5.0 * s;
+        mp.inertia_mat(0, 1) = mp.inertia_mat(1, 0) = 1.0 * s;
+        mp.inertia_mat(1, 1) += -3.0 * s;
+        mp.inertia_mat(1, 2) = mp.inertia_mat(2, 1) = 0.5 * s;
+        mp.inertia_mat(2, 2) += 2.0 * s;
+        return mp;
+      };
+      u = ddp.planOnce(motion_varying, ref, ip, 0.0);
+      std::printf("srb_varying_inertia iter=%d dim=%d u0=", ddp.ddp_solver_->traceDataList().back().iter, u.size());
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
+      // force_scale_limits_ is a live public member (include/CCC/DdpSingleRigidBody.h, read by the lambda of
+      // src/DdpSingleRigidBody.cpp:272-280 at every solve): assigned after construction, it bounds the next plan
+      ddp.force_scale_limits_ = {2.0, 60.0};
+      u = ddp.planOnce(motion, ref, ip, 0.0);
+      double lo = 1e300, hi = -1e300;
+      for(const auto & ui : ddp.ddp_solver_->controlData().u_list)
+        for(int r = 0; r < ui.size(); r++)
+        {
+          lo = ui[r] < lo ? ui[r] : lo;
+          hi = ui[r] > hi ? ui[r] : hi;
+        }
+      std::printf("srb_limits iter=%d min=%.17g max=%.17g u0=", ddp.ddp_solver_->traceDataList().back().iter, lo, hi);
+      for(int r = 0; r < u.size(); r++) std::printf(" %.17g", u[r]);
+      std::printf("\n");
     }
     {
       // Walking with double support: a two-element contact_list (32 ridges, src/DdpCentroidal.cpp:49-60) and six

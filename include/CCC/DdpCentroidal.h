@@ -140,7 +140,7 @@ public:
       if(i < horizon_steps_) f.setStepContacts(i, motion_param_func(t).contact_list);
     }
     return ddp_shim::solveOne(handles_.select(f, "DdpCentroidal"), *ddp_solver_, f, false, initial_param.toState(ddp_problem_->mass_),
-                              initial_param.u_list, "DdpCentroidal");
+                              initial_param.u_list, force_scale_limits_, "DdpCentroidal");
   }
 
   /** \brief The C-ABI handle (<= 16 ridges per step, <= max_phases phases), for the flat-array batch entry points of
@@ -159,7 +159,8 @@ public:
   //! DDP solver
   std::shared_ptr<ddp_shim::Solver> ddp_solver_;
 
-  //! Force scale limits (DdpCentroidal.h:364; fixed at construction in this shim)
+  //! Force scale limits (DdpCentroidal.h:364).  Live, as in the reference, whose input-limits lambda reads the member at
+  //! every solve (src/DdpCentroidal.cpp:202-210): planOnce() hands its current value to the handle (ccc_ddp_set_limits)
   std::array<double, 2> force_scale_limits_ = {0.0, 1e6};
 
 protected:

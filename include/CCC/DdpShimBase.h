@@ -7,6 +7,7 @@
 #pragma once
 
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <functional>
@@ -80,7 +81,7 @@ struct Flat
 {
   int N = 0, P = 0, M = 0; // P, M: layout of the packed arrays (set by pack())
   std::vector<int32_t> phase_dim, step_phase;
-  std::vector<double> phase_vertex, phase_ridge, ref_pos, ref_ori, inertia;
+  std::vector<double> phase_vertex, phase_ridge, ref_pos, ref_ori, inertia; // inertia: [P][3][3] (inertia_per_phase)
   std::vector<int> dims; // input dimension per step
 
   void init(int n_steps)
@@ -89,15 +90,19 @@ struct Flat
     step_phase.assign(static_cast<size_t>(N), 0);
     ref_pos.assign(static_cast<size_t>(N + 1) * 3, 0.0);
     ref_ori.assign(static_cast<size_t>(N + 1) * 3, 0.0);
-    inertia.assign(9, 0.0);
+    inertia.clear();
     dims.assign(static_cast<size_t>(N), 0);
     phases_V_.clear();
     phases_R_.clear();
+    phases_I_.clear();
     max_dim_ = 0;
   }
 
-  /** Register the contact list of step i (find or append its contact phase); src/DdpCentroidal.cpp:49-60 order. */
-  void setStepContacts(int i, const std::vector<std::shared_ptr<Contact>> & contact_list)
+  /** Register the MotionParam of step i (find or append its phase): the contact list in src/DdpCentroidal.cpp:49-60 order
+      and, for the single-rigid-body model, MotionParam::inertia_mat (row-major 3 x 3; nullptr for DdpCentroidal).  The
+      reference reads motion_param_func_(t).inertia_mat at every step (src/DdpSingleRigidBody.cpp:56-57,120-123), so two
+      steps share a phase only when contact list AND inertia matrix agree. */
+  void setStepContacts(int i, const std::vector<std::shared_ptr<Contact>> & contact_list, const double * inertia9 = nullptr)
   {
     std::vector<double> V, R;
     for(const auto & contact : contact_list)
@@ -114,14 +119,17 @@ struct Flat
                                + std::to_string(CCC_DDP_MAX_RIDGES_MULTI) + " (four 4-vertex surface contacts)");
     dims[static_cast<size_t>(i)] = m;
     max_dim_ = std::max(max_dim_, m);
+    std::vector<double> In;
+    if(inertia9) In.assign(inertia9, inertia9 + 9);
     for(size_t k = 0; k < phases_V_.size(); k++)
-      if(phases_V_[k] == V && phases_R_[k] == R)
+      if(phases_V_[k] == V && phases_R_[k] == R && phases_I_[k] == In)
       {
         step_phase[static_cast<size_t>(i)] = static_cast<int32_t>(k);
         return;
       }
     phases_V_.push_back(V);
     phases_R_.push_back(R);
+    phases_I_.push_back(In);
     step_phase[static_cast<size_t>(i)] = static_cast<int32_t>(phases_V_.size() - 1);
   }
 
@@ -142,8 +150,11 @@ struct Flat
     phase_dim.assign(static_cast<size_t>(P), 0);
     phase_vertex.assign(static_cast<size_t>(P) * M * 3, 0.0);
     phase_ridge.assign(static_cast<size_t>(P) * M * 3, 0.0);
+    inertia.assign(static_cast<size_t>(P) * 9, 0.0);
+    for(int k = 0; k < P; k++) inertia[static_cast<size_t>(k) * 9] = inertia[static_cast<size_t>(k) * 9 + 4] = inertia[static_cast<size_t>(k) * 9 + 8] = 1.0;
     for(size_t k = 0; k < phases_V_.size(); k++)
     {
+      if(!phases_I_[k].empty()) std::copy(phases_I_[k].begin(), phases_I_[k].end(), inertia.begin() + static_cast<long>(k) * 9);
       phase_dim[k] = static_cast<int32_t>(phases_V_[k].size() / 3);
       std::copy(phases_V_[k].begin(), phases_V_[k].end(), phase_vertex.begin() + static_cast<long>(k) * M * 3);
       std::copy(phases_R_[k].begin(), phases_R_[k].end(), phase_ridge.begin() + static_cast<long>(k) * M * 3);
@@ -151,7 +162,7 @@ struct Flat
   }
 
 private:
-  std::vector<std::vector<double>> phases_V_, phases_R_;
+  std::vector<std::vector<double>> phases_V_, phases_R_, phases_I_;
   int max_dim_ = 0;
 };
 
@@ -205,7 +216,8 @@ struct Handles
 
 /** Run one instance through ccc_ddp_plan_batch and fill the solver stand-in; returns u_list[0]. */
 inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool srb, const std::vector<double> & x0,
-                         const std::vector<VectorXd> & u_init_list, const char * who)
+                         const std::vector<VectorXd> & u_init_list, const std::array<double, 2> & force_scale_limits,
+                         const char * who)
 {
   const int N = f.N, M = f.M, S = static_cast<int>(x0.size());
   std::vector<double> u_init, u(static_cast<size_t>(N) * M, 0.0), x(static_cast<size_t>(N + 1) * S, 0.0);
@@ -224,6 +236,8 @@ inline VectorXd solveOne(ccc_ddp_t * h, Solver & solver, const Flat & f, bool sr
   int32_t iters = 0, status = 0;
   double cost = 0;
   check(ccc_ddp_set_config(h, &solver.config_), who);
+  // force_scale_limits_ is read by the reference at every solve (the lambda of src/DdpCentroidal.cpp:202-210): its value NOW
+  check(ccc_ddp_set_limits(h, force_scale_limits[0], force_scale_limits[1]), who);
   check(ccc_ddp_plan_batch(h, 1, f.phase_dim.data(), f.phase_vertex.data(), f.phase_ridge.data(), f.step_phase.data(),
                            f.ref_pos.data(), srb ? f.ref_ori.data() : nullptr, srb ? f.inertia.data() : nullptr,
                            x0.data(), u_init.empty() ? nullptr : u_init.data(), u.data(), x.data(), &iters, &status,

@@ -121,6 +121,7 @@ public:
     p.force_scale_limits[0] = force_scale_limits_[0];
     p.force_scale_limits[1] = force_scale_limits_[1];
     p.max_phases = max_phases;
+    p.inertia_per_phase = 1; // a phase = a distinct MotionParam: contact list and inertia_mat (ddp_shim::Flat)
     handles_.create(p, device, "DdpSingleRigidBody");
     ddp_solver_->config().horizon_steps = horizon_steps; // src/DdpCentroidal.cpp:198
     ddp_solver_->config().max_iter = 500;
@@ -148,18 +149,21 @@ public:
       }
       if(i < horizon_steps_)
       {
+        // MotionParam::inertia_mat of EVERY step, as stateEq / calcStateEqDeriv read it
+        // (src/DdpSingleRigidBody.cpp:56-57,120-123)
         const MotionParam mp = motion_param_func(t);
-        f.setStepContacts(i, mp.contact_list);
-        if(i == 0)
-          for(int r = 0; r < 3; r++)
-            for(int c = 0; c < 3; c++) f.inertia[static_cast<size_t>(r * 3 + c)] = mp.inertia_mat(r, c);
+        double inertia9[9];
+        for(int r = 0; r < 3; r++)
+          for(int c = 0; c < 3; c++) inertia9[r * 3 + c] = mp.inertia_mat(r, c);
+        f.setStepContacts(i, mp.contact_list, inertia9);
       }
     }
     return ddp_shim::solveOne(handles_.select(f, "DdpSingleRigidBody"), *ddp_solver_, f, true, initial_param.toState(), initial_param.u_list,
-                              "DdpSingleRigidBody");
+                              force_scale_limits_, "DdpSingleRigidBody");
   }
 
-  /** \brief The C-ABI handle of the fast kernel (see DdpCentroidal::handle()). */
+  /** \brief The C-ABI handle of the fast kernel (see DdpCentroidal::handle()); created with inertia_per_phase = 1: its
+      `inertia` argument is [n][max_phases][3][3] (ccc_ddp_set_inertia_per_phase(handle(), 0) for one matrix per instance). */
   ccc_ddp_t * handle() const
   {
     return handles_.fast.get();
@@ -168,6 +172,7 @@ public:
 public:
   std::shared_ptr<DdpProblem> ddp_problem_;
   std::shared_ptr<ddp_shim::Solver> ddp_solver_;
+  //! Force scale limits: live, read at every planOnce() like the reference's (src/DdpSingleRigidBody.cpp:272-280)
   std::array<double, 2> force_scale_limits_ = {0.0, 1e6};
 
 protected:

@@ -47,7 +47,7 @@ const char * ccc_last_error_string(void);
  * that answered 3) -- compare before the first call:  if(ccc_abi_version() != CCC_ABI_VERSION) refuse.
  *   4 (round 5): ccc_ddp_config_t::warm_start_guard counted in; the DDP status word carries
  *     CCC_DDP_STATUS_WARM_REPLACED_BIT; ccc_ddp_effective_precision; stats[5] of ccc_ddp_closed_loop_device. */
-#define CCC_ABI_VERSION 4
+#define CCC_ABI_VERSION 5
 int ccc_abi_version(void);
 /* number of visible HIP devices that are gfx950 parts (0 when none: every create call then fails with
  * CCC_ERR_NO_DEVICE); device ordinals are HIP's */
@@ -176,6 +176,13 @@ typedef struct
                    * over a two-element contact_list), 64 = CCC_DDP_MAX_RIDGES_MULTI (up to four: feet and hands).  A
                    * problem gives the same answer at every stride that holds it; smaller strides run faster.  Other
                    * values: CCC_ERR_UNSUPPORTED. */
+  int inertia_per_phase; /* (ABI 5; single-rigid-body model) 0: `inertia` of ccc_ddp_plan_batch* is [n][3][3], one matrix
+                   * per instance for the whole horizon.  != 0: `inertia` is [n][P][3][3], MotionParam::inertia_mat of the
+                   * steps in contact phase p: the reference reads motion_param_func_(t).inertia_mat at EVERY step
+                   * (src/DdpSingleRigidBody.cpp:56-57 in stateEq, :120-123 in calcStateEqDeriv), so a "contact phase" is
+                   * then a distinct MotionParam -- contact list AND inertia matrix; a horizon whose inertia varies from
+                   * step to step has one phase per step (max_phases = horizon_steps).  ccc_ddp_set_inertia_per_phase
+                   * changes it after construction. */
 } ccc_ddp_params_t;
 
 /* ddp_solver_->config() (nmpc_ddp::DDPSolver::Configuration, external).  ccc_ddp_default_config
@@ -212,6 +219,9 @@ typedef struct
  * every instance whose warm start was kept (and always with warm_start_guard = 0 or u_init = NULL); on an instance whose
  * warm start the guard replaced by zero inputs: CCC_DDP_STATUS_WARM_REPLACED_BIT | (exit code & 0xff), a value >= 0x100. */
 #define CCC_DDP_STATUS_WARM_REPLACED_BIT 0x100
+/* (ABI 5) the status every instance carries from the launch until its solve completes: what is left in `status` for the
+ * instances a launch did NOT complete because a wait of its scheduler gave up (ccc_ddp_last_call_aborted) */
+#define CCC_DDP_STATUS_ABORTED (-2)
 #define CCC_DDP_STATUS_EXIT(s) ((int)(signed char)((s)&0xff))
 #define CCC_DDP_STATUS_WARM_REPLACED(s) ((s) >= 0 && ((s)&CCC_DDP_STATUS_WARM_REPLACED_BIT) != 0)
 
@@ -220,6 +230,23 @@ int ccc_ddp_create(const ccc_ddp_params_t * params, int device, ccc_ddp_t ** out
 void ccc_ddp_destroy(ccc_ddp_t * h);
 /* ddp_solver_->config() = cfg   (e.g. max_iter = 1 after the first control cycle, TestDdpCentroidal.cpp:116) */
 int ccc_ddp_set_config(ccc_ddp_t * h, const ccc_ddp_config_t * cfg);
+/* force_scale_limits_ = {lo, hi}   (ABI 5).  The reference keeps force_scale_limits_ as a public data member
+ * (include/CCC/DdpCentroidal.h:364, include/CCC/DdpSingleRigidBody.h) that the input-limits lambda reads at EVERY solve
+ * (src/DdpCentroidal.cpp:202-210, src/DdpSingleRigidBody.cpp:272-280): assigning to it after construction is how a caller
+ * changes the limits.  The header shims and the Python mirrors push the member's current value through this entry before
+ * every planOnce(); params.force_scale_limits is only the value the handle starts with.  lo <= hi, both finite or
+ * +-infinity; applies from the next plan call on. */
+int ccc_ddp_set_limits(ccc_ddp_t * h, double lo, double hi);
+/* the layout of `inertia` (ccc_ddp_params_t::inertia_per_phase) from the next plan call on   (ABI 5) */
+int ccc_ddp_set_inertia_per_phase(ccc_ddp_t * h, int per_phase);
+/* (ABI 5) Bounded waits.  The DDP kernel is one resident set of workgroups that pull instances from a work queue; each of
+ * its waits (for a queue entry's writer, for the instances still being solved elsewhere) watches the launch's progress
+ * and gives up after 10 s without any (CCC_DDP_SPIN_BUDGET_MS in the environment at create time; 0 = never): the kernel
+ * then EXITS, the instances it did not complete keep status CCC_DDP_STATUS_ABORTED, ccc_ddp_plan_batch returns
+ * CCC_ERR_HIP, and after a ccc_ddp_plan_batch_device call this entry answers 1 once the launch has completed (0 otherwise;
+ * -1: NULL handle).  Progress does not depend on the whole grid being resident; the budget catches a wavefront lost with
+ * an instance.  The resident set itself is checked against the runtime's occupancy figure in ccc_ddp_create. */
+int ccc_ddp_last_call_aborted(const ccc_ddp_t * h);
 int ccc_ddp_state_dim(const ccc_ddp_t * h);
 /* the constructor arguments / the current configuration / the device of a handle */
 int ccc_ddp_get_params(const ccc_ddp_t * h, ccc_ddp_params_t * params);
@@ -245,7 +272,8 @@ int ccc_ddp_effective_precision(const ccc_ddp_t * h);
  *   step_phase   [n][N]            i32  contact phase of horizon step i
  *   ref_pos      [n][N+1][3]       f64  RefData::pos at step i (i = N: terminal cost)
  *   ref_ori      [n][N+1][3]       f64  RefData::ori            (SRB only, else NULL)
- *   inertia      [n][3][3]         f64  MotionParam::inertia_mat (SRB only, else NULL; constant over the horizon)
+ *   inertia      [n][3][3]         f64  MotionParam::inertia_mat (SRB only, else NULL): one matrix per instance, or, with
+ *                [n][P][3][3]           params.inertia_per_phase, one per contact phase (the step's: src/DdpSingleRigidBody.cpp:56-57,120-123)
  *   x0           [n][S]            f64  InitialParam::toState()  (S = 9: [pos, mass*vel, angular_momentum];
  *                                       S = 12: [pos, ori, linear_vel, angular_vel])
  *   u_init       [n][N][M]         f64  InitialParam::u_list (warm start) or NULL (zeros, src/DdpCentroidal.cpp:221-229)
@@ -589,6 +617,8 @@ int ccc_ddp_sharded_create(const ccc_ddp_params_t * params, const ccc_ddp_config
 void ccc_ddp_sharded_destroy(ccc_ddp_sharded_t * h);
 int ccc_ddp_sharded_num_devices(const ccc_ddp_sharded_t * h);
 int ccc_ddp_sharded_set_config(ccc_ddp_sharded_t * h, const ccc_ddp_config_t * config);
+/* ccc_ddp_set_limits on every device's planner (force_scale_limits_ is a live member of the reference classes)   (ABI 5) */
+int ccc_ddp_sharded_set_limits(ccc_ddp_sharded_t * h, double lo, double hi);
 int ccc_ddp_sharded_plan_batch_device(ccc_ddp_sharded_t * h, int64_t n_per_device, const int32_t * const * phase_dim,
                                       const double * const * phase_vertex, const double * const * phase_ridge,
                                       const int32_t * const * step_phase, const double * const * ref_pos,

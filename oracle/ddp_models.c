@@ -151,8 +151,8 @@ static void mdl_state_eq(void * user, int step, const double * x, const double *
   }
   else
   {
-    /* src/DdpSingleRigidBody.cpp:52-91 */
-    const double * I = m->inertia;
+    /* src/DdpSingleRigidBody.cpp:52-91; :56-57: motion_param_func_(t).inertia_mat is the STEP's */
+    const double * I = m->inertia + (m->inertia_per_phase ? (size_t)ph * 9 : 0);
     double xd[12], K[9];
     const double * w = x + 9;
     for(int a = 0; a < 3; a++) xd[a] = x[6 + a];
@@ -249,8 +249,8 @@ static void mdl_state_eq_deriv(void * user, int step, const double * x, const do
   }
   else
   {
-    /* src/DdpSingleRigidBody.cpp:114-185 */
-    const double * I = m->inertia;
+    /* src/DdpSingleRigidBody.cpp:114-185; :120-123: the step's inertia matrix and its factor */
+    const double * I = m->inertia + (m->inertia_per_phase ? (size_t)ph * 9 : 0);
     const double * ori = x + 3;
     for(int a = 0; a < 3; a++) Fx[a * S + 6 + a] = 1.0;
     double K[9];
@@ -387,7 +387,7 @@ int oracle_ddp_plan_batch(const oracle_ddp_model_t * shared, const oracle_ddp_co
     mdl.step_phase = step_phase + (size_t)b * N;
     mdl.ref_pos = ref_pos + (size_t)b * (N + 1) * 3;
     mdl.ref_ori = ref_ori ? ref_ori + (size_t)b * (N + 1) * 3 : NULL;
-    mdl.inertia = inertia ? inertia + (size_t)b * 9 : NULL;
+    mdl.inertia = inertia ? inertia + (size_t)b * 9 * (shared->inertia_per_phase ? P : 1) : NULL;
     oracle_ddp_problem_t prob;
     oracle_ddp_model_problem(&mdl, &prob);
     oracle_ddp_result_t res;

@@ -58,8 +58,8 @@ static void cross3(const double * a, const double * b, double * c)
 /* Eigen::LLT<Matrix3d>::solve, src/DdpSingleRigidBody.cpp:88,122-123: the factor as ddp_models.c forms it; the six
  * divisions of the two substitutions are MULTIPLICATIONS by the reciprocals of the factor's diagonal (round 5: the
  * single-rigid-body derivatives solve with this factor nine times per backward step, on the device 57 IEEE divisions of
- * ~28 instructions each -- a fifth of a median solve's time; the inertia matrix is constant over an instance, so the
- * three reciprocals are formed once).  SPEC: r_kk = 1 / l_kk; y0 = b0 r00; y1 = (b1 - l10 y0) r11; y2 = (b2 - l20 y0 - l21
+ * ~28 instructions each -- a fifth of a median solve's time; the inertia matrix is constant over a contact phase, so
+ * the kernel forms the three reciprocals once per phase change).  SPEC: r_kk = 1 / l_kk; y0 = b0 r00; y1 = (b1 - l10 y0) r11; y2 = (b2 - l20 y0 - l21
  * y1) r22; x2 = y2 r22; x1 = (y1 - l21 x2) r11; x0 = (y0 - l10 x1 - l20 x2) r00. */
 static void llt3_solve(const double * I, const double * b, double * x)
 {
@@ -116,6 +116,8 @@ typedef struct
 {
   double V[MMAX][3], R[MMAX][3], cr[MMAX][3];
   double force[3], moment[3], accel[3];
+  const double * inertia; /* MotionParam::inertia_mat of the STEP (src/DdpSingleRigidBody.cpp:56-57,120-123): the instance's
+                           * one matrix, or its phase's with oracle_ddp_model_t::inertia_per_phase */
 } terms_t;
 
 static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, const double * u, terms_t * T)
@@ -123,6 +125,7 @@ static void terms_of(const oracle_ddp_model_t * m, int step, const double * x, c
   const int dim = dim_of(m, step), ph = phase_of(m, step), M_ = m->M;
   const double * V = m->phase_vertex + (size_t)ph * M_ * 3;
   const double * R = m->phase_ridge + (size_t)ph * M_ * 3;
+  T->inertia = m->inertia ? m->inertia + (m->inertia_per_phase ? (size_t)ph * 9 : 0) : NULL;
   for(int r = 0; r < M_; r++)
   {
     for(int k = 0; k < 3; k++)
@@ -162,7 +165,7 @@ static void state_eq(const oracle_ddp_model_t * m, const terms_t * T, const doub
   }
   else
   {
-    const double * I = m->inertia;
+    const double * I = T->inertia;
     const double * w = x + 9;
     double xd[12], sa, ca, sb, cb;
     for(int a = 0; a < 3; a++) xd[a] = x[6 + a];
@@ -242,7 +245,7 @@ static void state_eq_deriv(const oracle_ddp_model_t * m, const terms_t * T, cons
   }
   else
   {
-    const double * I = m->inertia;
+    const double * I = T->inertia;
     const double inv_mass = 1.0 / m->mass;
     for(int r = 0; r < M_; r++)
     {

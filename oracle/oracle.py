@@ -170,7 +170,7 @@ class _DdpModel(ctypes.Structure):
                 ("force_lo", ctypes.c_double), ("force_hi", ctypes.c_double),
                 ("phase_dim", ctypes.c_void_p), ("phase_vertex", ctypes.c_void_p), ("phase_ridge", ctypes.c_void_p),
                 ("step_phase", ctypes.c_void_p), ("ref_pos", ctypes.c_void_p), ("ref_ori", ctypes.c_void_p),
-                ("inertia", ctypes.c_void_p)]
+                ("inertia", ctypes.c_void_p), ("inertia_per_phase", ctypes.c_int)]
 
 
 class _DdpProblem(ctypes.Structure):
@@ -291,7 +291,8 @@ class Ddp:
 
     def plan_batch(self, prob, x0, u_init=None, nthreads=1):
         """prob: dict(phase_dim [n,P] i32, phase_vertex [n,P,M,3], phase_ridge [n,P,M,3], step_phase [n,N] i32,
-        ref_pos [n,N+1,3], ref_ori [n,N+1,3] (SRB), inertia [n,3,3] (SRB)); x0 [n,S]; u_init [n,N,M] | None.
+        ref_pos [n,N+1,3], ref_ori [n,N+1,3] (SRB), inertia [n,3,3] or [n,P,3,3] (SRB: per instance / per contact phase));
+        x0 [n,S]; u_init [n,N,M] | None.
         Returns dict(u [n,N,M], x [n,N+1,S], iters [n], status [n], cost [n])."""
         L = _bind_ddp()
         N, P, M, S = self.N, self.P, self.M, self.S
@@ -308,7 +309,9 @@ class Ddp:
         if self.model == 1:
             ro = np.ascontiguousarray(prob["ref_ori"], dtype=np.float64)
             ine = np.ascontiguousarray(prob["inertia"], dtype=np.float64)
-            assert ro.shape == (n, N + 1, 3) and ine.shape == (n, 3, 3)
+            # [n,3,3]: one matrix per instance; [n,P,3,3]: one per contact phase (oracle_ddp_model_t::inertia_per_phase)
+            assert ro.shape == (n, N + 1, 3) and ine.shape in ((n, 3, 3), (n, P, 3, 3))
+            self.mdl.inertia_per_phase = 1 if ine.ndim == 4 else 0
         ui = None if u_init is None else np.ascontiguousarray(u_init, dtype=np.float64)
         u = np.zeros((n, N, M))
         x = np.zeros((n, N + 1, S))
@@ -336,6 +339,8 @@ class Ddp:
             if name in prob and prob[name] is not None:
                 arrs[name] = np.ascontiguousarray(prob[name][k], dtype=dtype)
                 setattr(mdl, name, arrs[name].ctypes.data)
+        if "inertia" in arrs:
+            mdl.inertia_per_phase = 1 if arrs["inertia"].ndim == 3 else 0  # [P,3,3] of this instance: one per phase
         x = np.ascontiguousarray(x, dtype=np.float64)
         u = np.ascontiguousarray(np.pad(np.asarray(u, dtype=np.float64), (0, M - len(u))))
         xn, Fx, Fu = np.zeros(S), np.zeros((S, S)), np.zeros((S, M))

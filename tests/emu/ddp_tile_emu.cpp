@@ -11,17 +11,17 @@
 using namespace ccc_amd;
 using ccc_amd::ddp_common::Params;
 
-template<int S, int B>
+template<int S, int B, bool IPP = false>
 static void run_one(const Params & P, const ddp_tile::Instance & I)
 {
   static ddp_tile::Mem<S, B> mem;
-  ddp_tile::Solver<S, B> solver(P, I, mem);
+  ddp_tile::Solver<S, B, IPP> solver(P, I, mem);
   solver.solve_instance();
 }
 
 // the same solve in slices of `slice` iterations: between two slices the state goes through suspend() / resume() and
 // everything else a wavefront owns (LDS, trajectory slots, gains) is overwritten, as if another instance had used it
-template<int S, int B>
+template<int S, int B, bool IPP = false>
 static void run_sliced(const Params & P, const ddp_tile::Instance & I, int slice, std::vector<double> & xbuf, std::vector<double> & ubuf,
                        std::vector<double> & ks, std::vector<double> & Ks)
 {
@@ -30,7 +30,7 @@ static void run_sliced(const Params & P, const ddp_tile::Instance & I, int slice
   bool fresh = true;
   for(;;)
   {
-    ddp_tile::Solver<S, B> solver(P, I, mem);
+    ddp_tile::Solver<S, B, IPP> solver(P, I, mem);
     if(fresh)
       solver.begin();
     else
@@ -75,7 +75,7 @@ extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, int M, long n, cons
     I.step_phase = step_phase + (size_t)b * N;
     I.ref_pos = ref_pos + (size_t)b * (N + 1) * 3;
     I.ref_ori = ref_ori ? ref_ori + (size_t)b * (N + 1) * 3 : nullptr;
-    I.inertia = inertia ? inertia + (size_t)b * 9 : nullptr;
+    I.inertia = inertia ? inertia + (size_t)b * 9 * (P->inertia_per_phase ? Pn : 1) : nullptr;
     I.x0 = x0 + (size_t)b * S;
     I.u_init = u_init ? u_init + (size_t)b * N * M : nullptr;
     I.xbuf = xbuf.data();
@@ -87,7 +87,20 @@ extern "C" int ccc_ddp_tile_emu_plan_batch(const Params * P, int M, long n, cons
     I.out_iters = iters ? iters + b : nullptr;
     I.out_status = status ? status + b : nullptr;
     I.out_cost = cost ? cost + b : nullptr;
-    if(slice > 0)
+    if(S == 12 && P->inertia_per_phase)
+    {
+      // the builds with one inertia matrix per contact phase (ccc_ddp_params_t::inertia_per_phase)
+      if(slice > 0)
+      {
+        if(M == 16) run_sliced<12, 1, true>(*P, I, slice, xbuf, ubuf, ks, Ks);
+        else if(M == 32) run_sliced<12, 2, true>(*P, I, slice, xbuf, ubuf, ks, Ks);
+        else run_sliced<12, 4, true>(*P, I, slice, xbuf, ubuf, ks, Ks);
+      }
+      else if(M == 16) run_one<12, 1, true>(*P, I);
+      else if(M == 32) run_one<12, 2, true>(*P, I);
+      else run_one<12, 4, true>(*P, I);
+    }
+    else if(slice > 0)
     {
       if(S == 9 && M == 16) run_sliced<9, 1>(*P, I, slice, xbuf, ubuf, ks, Ks);
       else if(S == 12 && M == 16) run_sliced<12, 1>(*P, I, slice, xbuf, ubuf, ks, Ks);

@@ -59,6 +59,44 @@ def test_srb_check_derivatives(inertia):
     _fd_check(d, _single_contact_problem(True, inertia), x, np.arange(1.0, 17.0), 12)
 
 
+@pytest.mark.parametrize("arith", [0, 1])
+def test_srb_derivatives_and_rollout_use_the_steps_inertia(arith):
+    """MotionParam::inertia_mat is sampled at EVERY step by the reference (src/DdpSingleRigidBody.cpp:56-57 stateEq,
+    :120-123 calcStateEqDeriv): with one matrix per contact phase ([n,P,3,3]) the finite-difference check of
+    TestDdpSingleRigidBody.cpp:197-308 holds at a step of the second phase with THAT phase's matrix, stateEq there equals
+    stateEq of a one-matrix problem holding it, and the planned rollout x_{i+1} = stateEq(i, x_i, u_i) switches matrices
+    where the phases do."""
+    I_a = np.diag([15.0, 10.0, 5.0])
+    I_b = np.array([[25.0, 1.0, -2.0], [1.0, 8.0, 0.5], [-2.0, 0.5, 12.0]])
+    w = dict(run=[1] * 6 + [0.01] * 6, term=[1] * 6 + [0.01] * 6, force=1e-6)
+    N = 12
+    d = oracle.Ddp(1, 100.0, 0.03, N, w, arith=arith, max_iter=5)
+    prob = _single_contact_problem(True, I_a)
+    prob = {k: (v[:, :N + 1] if k.startswith("ref_") else v[:, :N] if k == "step_phase" else v) for k, v in prob.items()}
+    prob["phase_dim"][0, 1] = 16
+    prob["phase_vertex"][0, 1], prob["phase_ridge"][0, 1] = prob["phase_vertex"][0, 0], prob["phase_ridge"][0, 0]
+    prob["step_phase"][0, 5:] = 1
+    prob["inertia"] = np.ascontiguousarray(np.stack([I_a, I_b, I_a, I_a])[None])  # [1, P = 4, 3, 3]
+    x = np.array([1.0, -2.0, 3.0, 0.1, -0.2, 0.3, -4.0, 5.0, -6.0, 7.0, -8.0, 9.0])
+    u = np.arange(1.0, 17.0)
+    for step, In in ((2, I_a), (7, I_b)):
+        e = d.eval(prob, 0, step, x, u)
+        one = dict(prob, inertia=np.ascontiguousarray(In[None]))
+        assert np.array_equal(e["x_next"], d.eval(one, 0, step, x, u)["x_next"])
+        eps, Fx = 1e-6, np.zeros((12, 12))
+        for i in range(12):
+            dx = np.zeros(12)
+            dx[i] = eps
+            Fx[:, i] = (d.eval(prob, 0, step, x + dx, u)["x_next"] - d.eval(prob, 0, step, x - dx, u)["x_next"]) / (2 * eps)
+        assert np.linalg.norm(e["Fx"] - Fx) < 1e-6
+    assert not np.array_equal(d.eval(prob, 0, 2, x, u)["x_next"], d.eval(prob, 0, 7, x, u)["x_next"])
+    x0 = np.array([[0.02, -0.01, 1.0, 0.05, -0.02, 0.01, 0.1, 0.0, 0.0, 0.2, -0.1, 0.3]])
+    r = d.plan_batch(prob, x0)
+    for i in range(N):
+        xn = d.eval(prob, 0, i, r["x"][0, i], r["u"][0, i])["x_next"]
+        assert np.abs(xn - r["x"][0, i + 1]).max() <= 1e-12 * (1 + np.abs(xn).max())
+
+
 def test_deterministic_sincos_within_two_ulp_of_libm():
     rng = np.random.default_rng(0)
     xs = np.concatenate([rng.uniform(-8, 8, 4000), rng.uniform(-1e-3, 1e-3, 500), [0.0, np.pi / 4, -np.pi / 2, 3.0]])
