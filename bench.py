@@ -197,11 +197,16 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): --batch instances on EVERY GPU; strong: --batch instances in total, GPU r "
                          "takes the contiguous shard [r B/N, (r+1) B/N) (SURVEY.md 8e)")
+    ap.add_argument("--ring", type=int, default=8,
+                    help="distinct batches the timed steps rotate through (seeds 20250928 + 8 rank + k, all resident in "
+                         "HBM): step k solves batch k mod RING, so no call sees its own past -- the library orders a call by "
+                         "the pivot counts of the handle's LAST call of that size, and a repeated batch would be its best "
+                         "case (VERDICT r5 weak #2); the repeated-batch rate is reported as history.value_repeated")
     ap.add_argument("--no-history-leg", action="store_true",
                     help="skip the second measurement on a handle without a history (profiling runs: one kind of launch)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="headline only: skip the `secondary` entries (configs 3, 4, 5: xy 65536 x 3 steps, ddp 4096 x 3, "
-                         "srb 32768 x 2, each with roofline / cpu_baseline / parity) the default one-GPU command appends")
+                    help="headline only: skip the `secondary` entries (configs 3, 4, 5: xy 65536, ddp 4096, srb 32768, 20 timed "
+                         "steps each over rotating batches, each with roofline / cpu_baseline / parity) the default one-GPU command appends")
     ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
@@ -253,15 +258,20 @@ def main():
         from centroidalcontrolcollection_amd import sharding
 
         lo, hi = sharding.shard_bounds(args.batch, world)[rank]
-        full = fx.make_zmp_batch(args.batch, N, dt, 1.0, seed=20250928)
-        batch = {k: np.ascontiguousarray(v[lo:hi]) for k, v in full.items()}
         n = hi - lo
         if args.batch % world:
             raise SystemExit("--scaling strong needs --batch divisible by the number of GPUs (all_gather_into_tensor)")
+        ring_host = []
+        for k in range(max(1, args.ring)):
+            full = fx.make_zmp_batch(args.batch, N, dt, 1.0, seed=20250928 + k)
+            ring_host.append({kk: np.ascontiguousarray(v[lo:hi]) for kk, v in full.items()})
     else:
-        batch = fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + rank)
-    x0 = torch.from_numpy(batch["x0"]).to(dev)
-    zlim = torch.from_numpy(batch["zlim"]).to(dev)
+        # RING distinct draws of the workload per rank (seed 20250928 + 8 rank + k), all resident in HBM
+        ring_host = [fx.make_zmp_batch(n, N, dt, 1.0, seed=20250928 + 8 * rank + k) for k in range(max(1, args.ring))]
+    R = len(ring_host)
+    batch = ring_host[0]
+    ring = [(torch.from_numpy(b["x0"]).to(dev), torch.from_numpy(b["zlim"]).to(dev)) for b in ring_host]
+    x0, zlim = ring[0]
     # two output buffers: the all-gather of step k (RCCL's own stream) overlaps the kernel of step k + 1
     zbuf = [torch.empty((n, 2), dtype=torch.float64, device=dev) for _ in range(2)]
     zmp = zbuf[0]
@@ -279,7 +289,8 @@ def main():
             pending[k] = None
         if ev is not None:
             ev[0].record(stream)
-        mpc.plan_batch_device(x0, zlim, 0.005, zbuf[k], None, None, stream)
+        rx0, rzl = ring[(counter[0] - 1) % R]  # step k solves batch k mod RING: never the batch of the call before
+        mpc.plan_batch_device(rx0, rzl, 0.005, zbuf[k], None, None, stream)
         if ev is not None:
             ev[1].record(stream)
         if world > 1:
@@ -291,12 +302,15 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
-    # one untimed launch with the status array for pivot statistics / status check
-    mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, status, stream)
-    torch.cuda.synchronize(dev)
-    st = status.cpu().numpy()
-    n_bad = int(((st & 0xff) != 0).sum())
-    pivots_per_solve = float((st >> 8).sum()) / n
+    # one untimed launch per batch of the ring with the status array: pivot statistics / status check over all of them
+    n_bad, piv_sum = 0, 0.0
+    for rx0, rzl in ring:
+        mpc.plan_batch_device(rx0, rzl, 0.005, zmp, None, status, stream)
+        torch.cuda.synchronize(dev)
+        st = status.cpu().numpy()
+        n_bad += int(((st & 0xff) != 0).sum())
+        piv_sum += float((st >> 8).sum())
+    pivots_per_solve = piv_sum / (n * R)
 
     # clock ramp (untimed, before the W warm-up steps): see --ramp-steps
     for _ in range(args.ramp_steps):
@@ -327,35 +341,44 @@ def main():
     if os.environ.get("CCC_BENCH_DEBUG") and rank == 0:
         print("kern_ms", np.round(kern_ms[:24], 3).tolist(), "wall_ms", 1e3 * elapsed,
               "span_ms", evs[0][0].elapsed_time(evs[-1][1]), file=sys.stderr)
-    # The timed steps above repeat ONE batch on a handle that has seen it: the library orders a call by the pivot counts of
-    # the handle's last call of that size (csrc/zmp.hip, DESIGN.md section 4 -- what a closed-loop caller gets from cycle
-    # to cycle).  The same steps on a handle that keeps no history (CCC_ZMP_HISTORY=0, read at creation) are timed beside
-    # it and reported as `history.value_without_history`: what a caller whose batches have nothing to do with each
-    # other gets.
+    # The timed steps above ROTATE through RING distinct batches: no call sees its own past.  The library orders a call by
+    # the pivot counts of the handle's last call of that size (csrc/zmp.hip) -- what a closed-loop
+    # caller gets from cycle to cycle, and nothing a caller of unrelated batches can use (the handle notices and drops
+    # it).  Two more figures beside `value`: the same rotation on a handle that keeps no history at all
+    # (CCC_ZMP_HISTORY=0, read at creation), and ONE batch repeated on a fresh handle -- the schedule's best case.
     no_hist = None
     if world == 1 and not args.no_history_leg:
+        def timed(h, rotate):
+            for i in range(args.warmup + 20):
+                rx0, rzl = ring[i % R] if rotate else ring[0]
+                h.plan_batch_device(rx0, rzl, 0.005, zbuf[0], None, None, stream)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                rx0, rzl = ring[i % R] if rotate else ring[0]
+                h.plan_batch_device(rx0, rzl, 0.005, zbuf[0], None, None, stream)
+            torch.cuda.synchronize(dev)
+            return time.perf_counter() - t1, h.last_kernel()
+
         os.environ["CCC_ZMP_HISTORY"] = "0"
         try:
             mpc0 = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
         finally:
             del os.environ["CCC_ZMP_HISTORY"]
-        for _ in range(args.warmup + 20):
-            mpc0.plan_batch_device(x0, zlim, 0.005, zbuf[0], None, None, stream)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            mpc0.plan_batch_device(x0, zlim, 0.005, zbuf[0], None, None, stream)
-        torch.cuda.synchronize(dev)
-        e0 = time.perf_counter() - t1
-        no_hist = {"value_without_history": n * args.steps / e0, "ms_per_step_without_history": 1e3 * e0 / args.steps,
-                   "kernel_without_history": mpc0.last_kernel(),
-                   "what": "`value` is measured on a handle that has seen the batch: its calls run longest-first by the "
-                           "previous call's pivot counts, QPs of like counts paired in a wavefront (the answers do not "
-                           "depend on the order: tests/test_zmp_gpu.py); value_without_history = the same steps on a "
-                           "handle created with CCC_ZMP_HISTORY=0.  The device-side closed loop of TestLinearMpcZmp.cpp "
-                           "(every cycle a new problem) gains 30-35 % from the order; unrelated batches of one size make "
-                           "the handle drop it (106 against 108 M solves/s without a history): DESIGN.md section 4"}
+        e0, k0 = timed(mpc0, True)
         del mpc0
+        mpc1 = LinearMpcZmp(1.0, 2.0, dt, device=local_rank)
+        e1, k1 = timed(mpc1, False)
+        del mpc1
+        no_hist = {"value_without_history": n * args.steps / e0, "ms_per_step_without_history": 1e3 * e0 / args.steps,
+                   "kernel_without_history": k0,
+                   "value_repeated": n * args.steps / e1, "ms_per_step_repeated": 1e3 * e1 / args.steps, "kernel_repeated": k1,
+                   "what": "`value` rotates through %d distinct batches on a default handle (no call sees its own past); "
+                           "value_without_history = the same rotation on a handle created with CCC_ZMP_HISTORY=0; "
+                           "value_repeated = ONE batch repeated on a fresh handle, whose calls then run longest-first by the "
+                           "previous call's pivot counts, QPs of like counts paired in a wavefront (the answers do not depend "
+                           "on the order: tests/test_zmp_gpu.py) -- the schedule's best case, what the device-side closed loop "
+                           "of TestLinearMpcZmp.cpp approaches from cycle to cycle (DESIGN.md section 4)" % R}
     # p50 of the host-to-host call: inputs in host memory -> planned ZMPs back in host memory through
     # ccc_zmp_plan_batch; PCIe-inclusive, never the `value` above
     # ... measured twice: from PINNED host tensors (SURVEY.md 8d's definition of the p50: the kernel reads the inputs
@@ -380,7 +403,10 @@ def main():
             pgath.copy_(gathered[0], non_blocking=True)
             torch.cuda.synchronize(dev)
         h2h.append(1e3 * (time.perf_counter() - t1))
-    assert not n_h2h or np.array_equal(pz.numpy(), zbuf[(counter[0] - 1) & 1].cpu().numpy()), "pinned path differs from the device path"
+    zref = torch.empty((n, 2), dtype=torch.float64, device=dev)  # batch 0 of the ring through the device entry
+    mpc.plan_batch_device(x0, zlim, 0.005, zref, None, None, stream)
+    torch.cuda.synchronize(dev)
+    assert not n_h2h or np.array_equal(pz.numpy(), zref.cpu().numpy()), "pinned path differs from the device path"
     if rank == 0 and n_h2h:
         for _ in range(8):
             t1 = time.perf_counter()
@@ -398,7 +424,7 @@ def main():
     strong = None
     if world > 1 and args.scaling == "weak" and args.batch % world == 0:
         ns = args.batch // world
-        sx0, szl = x0[:ns].contiguous(), zlim[:ns].contiguous()
+        ring_s = [(a[:ns].contiguous(), b[:ns].contiguous()) for a, b in ring]  # rotating here too
         sz = [torch.empty((ns, 2), dtype=torch.float64, device=dev) for _ in range(2)]
         sg = [torch.empty((world * ns, 2), dtype=torch.float64, device=dev) for _ in range(2)]
         works = [None, None]
@@ -407,6 +433,7 @@ def main():
             k = i & 1
             if works[k] is not None:
                 works[k].wait()
+            sx0, szl = ring_s[i % R]
             mpc.plan_batch_device(sx0, szl, 0.005, sz[k], None, None, stream)
             works[k] = dist.all_gather_into_tensor(sg[k], sz[k], async_op=True)
 
@@ -460,10 +487,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "LinearMpcZmp N=32 (2 s horizon @ 62.5 ms), batch=%d per GPU (%s), random 6-step "
-                                   "footstep sequences (SURVEY.md 8d)" % (
+                                   "footstep sequences (SURVEY.md 8d), the timed steps rotating through %d distinct batches" % (
                                        n, "%d in total, contiguous shards" % (world * n)
-                                       if args.scaling == "strong" and world > 1 else "weak scaling"),
-                       "batch_per_gpu": n, "horizon_steps": N, "parallelism": "batch-sharded x%d" % world,
+                                       if args.scaling == "strong" and world > 1 else "weak scaling", R),
+                       "batch_per_gpu": n, "ring": R, "horizon_steps": N, "parallelism": "batch-sharded x%d" % world,
                        "collective": "all_gather(zmp)" if world > 1 else "none"},
             # the bound that binds is VALU issue (fp64 vector pipe), not HBM and not MFMA: `achieved/peak/frac` are the
             # HBM figures the contract asks for, `valu` the ones that say how far the kernel is from ITS roofline
@@ -505,7 +532,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (the other ranks would idle meanwhile)
             cb, ref_zmp, n_chk = cpu_baseline(batch)
             out["cpu_baseline"] = cb
-            out["parity_max_abs_err"] = float(np.abs(zmp.cpu().numpy()[:n_chk] - ref_zmp).max())
+            out["parity_max_abs_err"] = float(np.abs(zref.cpu().numpy()[:n_chk] - ref_zmp).max())
     # configs 3, 4, 5 in the driver's record: the default one-GPU command also times LinearMpcXY
     # (config 4), DdpCentroidal (config 3) and DdpSingleRigidBody (config 5's shape) with the same protocol and appends their
     # lines -- value, ms_per_step, steps, roofline (traffic + traffic_source), cpu_baseline (value_1thread), parity
@@ -515,7 +542,7 @@ def main():
 
         torch.cuda.empty_cache()
         secondary = []
-        for wl, (k_steps, k_warm) in (("xy", (3, 1)), ("ddp", (3, 1)), ("srb", (2, 1))):
+        for wl, (k_steps, k_warm) in (("xy", (20, 2)), ("ddp", (20, 2)), ("srb", (20, 2))):
             secondary.append(bench_secondary.measure(wl, bench_secondary.DEFAULT_BATCH[wl], k_steps, k_warm, rank, world,
                                                      local_rank, dist, cpu=not args.no_cpu_baseline, dinfo=None))
             torch.cuda.empty_cache()

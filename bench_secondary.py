@@ -12,6 +12,8 @@ import torch
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
+RING = 8  # distinct batches the timed steps of the scheduled workloads (xy, ddp, srb, walk, multi) rotate through: no call
+#           sees its own past (the handles order a call by what their LAST call of that size measured)
 
 
 def _dev(a, dev):
@@ -60,23 +62,42 @@ def _xy(n, dev, rank, walking=False):
         # two separate foot contacts in double support (32 ridges per step), 30 steps: beyond the dual kernel, the
         # stage-recursion kernel with its single-change safeguard rounds
         N, M, base = 30, 32, min(n, 512)
-        prob, x0 = fd.make_xy_walking_batch(base, N, dt, M=32, seed=20250928 + rank)
+        gen = lambda seed: fd.make_xy_walking_batch(base, N, dt, M=32, seed=seed)  # noqa: E731
     else:
-        prob, x0 = fd.make_xy_batch(base, N, dt, seed=20250928 + rank)
-    prob = _tile(prob, n, base)
-    x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
+        gen = lambda seed: fd.make_xy_batch(base, N, dt, seed=seed)  # noqa: E731
+    # RING distinct draws (seed 20250928 + 8 rank + k), each tiled to the batch; entry 0 is the one the CPU leg checks
+    ring = []
+    for k in range(1 if walking else RING):
+        pk, xk = gen(20250928 + 8 * rank + k)
+        pk = _tile(pk, n, base)
+        xk = np.concatenate([xk] * ((n + base - 1) // base))[:n]
+        if k == 0:
+            prob, x0 = pk, xk
+        ring.append(({a: _dev(v, dev) for a, v in pk.items()}, _dev(xk, dev)))
     mpc = LinearMpcXY(100.0, dt, N, device=dev.index, max_ridges=M)
-    tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
+    tp, tx0 = ring[0]
     out = torch.zeros((n, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
+    count = [0]
 
     def step(stream):
+        rp, rx = ring[count[0] % len(ring)]
+        count[0] += 1
+        mpc.plan_batch_device(rp, rx, out, status=st, stream=stream)
+
+    def rebase(stream):  # the outputs of ring entry 0 (what `cpu` compares with the oracle)
         mpc.plan_batch_device(tp, tx0, out, status=st, stream=stream)
 
-    def nohist():
-        m0 = _without_history("CCC_XY_HISTORY", lambda: LinearMpcXY(100.0, dt, N, device=dev.index, max_ridges=M))
-        o0 = torch.zeros_like(out)
-        return (lambda stream: m0.plan_batch_device(tp, tx0, o0, stream=stream)), (m0, o0)
+    def other(history, rotate):
+        make = lambda: LinearMpcXY(100.0, dt, N, device=dev.index, max_ridges=M)  # noqa: E731
+        m0 = make() if history else _without_history("CCC_XY_HISTORY", make)
+        o0, c0 = torch.zeros_like(out), [0]
+
+        def f(stream):
+            rp, rx = ring[c0[0] % len(ring)] if rotate else ring[0]
+            c0[0] += 1
+            m0.plan_batch_device(rp, rx, o0, stream=stream)
+        return f, (m0, o0)
 
     def cpu(cores, ns=None):
         from oracle import oracle
@@ -91,7 +112,7 @@ def _xy(n, dev, rank, walking=False):
 
     if walking:
         return dict(name="LinearMpcXY planOnce() solves/sec (N=30, 32 ridge slots, fp64, inputs resident in HBM)", step=step,
-                    out=out, status=st,
+                    out=out, status=st, rebase=rebase, ring=len(ring),
                     workload="LinearMpcXY N=30 (3 s horizon @ 100 ms), walking with two foot contacts in double support (32 "
                              "ridges), batch=%d per GPU (beyond BASELINE's configs: src/LinearMpcXY.cpp:69-82)" % n,
                     algo_bytes=N * (4 + M * 3 * 8 * 2 + 16 + 48) + 48 + M * 8, kernel="xy_plan_stream_kernel<32,false>", cpu=cpu,
@@ -99,7 +120,11 @@ def _xy(n, dev, rank, walking=False):
     return dict(name="LinearMpcXY planOnce() solves/sec (N=20, fp64, inputs resident in HBM)", step=step, out=out, status=st,
                 workload="LinearMpcXY N=20 (2 s horizon @ 100 ms), 16 ridges per step, batch=%d per GPU (BASELINE config 4)" % n,
                 algo_bytes=20 * (4 + 16 * 3 * 8 * 2 + 16 + 48) + 48 + 128, stream_bytes=_xy_algo,
-                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, tp, tx0), mfma=XY_MFMA, nohist=nohist,
+                kernel="xy_plan_stream_kernel<16,false>", cpu=cpu, keep=(mpc, ring), mfma=XY_MFMA, other=other,
+                # LinearMpcXY is held to 5e-9 of the force scales relative to (1 + the largest), the bound of the certified
+                # golden vectors (tests/test_xy_gpu.py): condition number 1e6-1e7, two different exact solvers
+                parity_tol=5e-9,
+                rebase=rebase, ring=len(ring),
                 history_what="the first round of the block iteration takes the instances in the order of the sweeps the "
                              "handle's last call of this size spent on each (DESIGN.md section 8)")
 
@@ -111,19 +136,30 @@ def _ddp(n, dev, rank, srb, walking=False):
     if walking == "multi":
         # feet + hands: 32- / 48- / 64-ridge steps -> the tile kernel with four ridge blocks
         N, dt, base, M = 30, 0.05, min(n, 512), 64
-        prob, x0 = fd.make_multicontact_batch(base, N, dt, seed=20250928 + rank, srb=srb)
-        P = prob["phase_dim"].shape[1]
+        gen = lambda seed: fd.make_multicontact_batch(base, N, dt, seed=seed, srb=srb)  # noqa: E731
+        P = gen(20250928)[0]["phase_dim"].shape[1]
         kw = dict(max_phases=P, max_ridges=64)
     elif walking:
         # double-support walking sequences: 32-ridge steps, 8-10 contact phases -> the tile kernel with two ridge blocks
         N, dt, base, M = 40, 0.05, min(n, 1024), 32
-        prob, x0 = fd.make_walking_batch(base, N, dt, seed=20250928 + rank, srb=srb)
-        P = prob["phase_dim"].shape[1]
+        gen = lambda seed: fd.make_walking_batch(base, N, dt, seed=seed, srb=srb)  # noqa: E731
+        P = gen(20250928)[0]["phase_dim"].shape[1]
         kw = dict(max_phases=P, max_ridges=32)
     else:
-        prob, x0 = fd.make_centroidal_batch(base, N, dt, seed=20250928 + rank, srb=srb)
-    prob = _tile(prob, n, base)
-    x0 = np.concatenate([x0] * ((n + base - 1) // base))[:n]
+        gen = lambda seed: fd.make_centroidal_batch(base, N, dt, seed=seed, srb=srb)  # noqa: E731
+    # RING distinct draws (seed 20250928 + 8 rank + k), each tiled to the batch; entry 0 is the one the CPU leg checks
+    ring_host = []
+    for k in range(RING):
+        pk, xk = gen(20250928 + 8 * rank + k)
+        if pk["phase_dim"].shape[1] != P:  # (the walking fixtures' phase count follows the draw: pad to the handle's)
+            pad = P - pk["phase_dim"].shape[1]
+            if pad < 0:
+                continue
+            pk = dict(pk, phase_dim=np.pad(pk["phase_dim"], ((0, 0), (0, pad))),
+                      phase_vertex=np.pad(pk["phase_vertex"], ((0, 0), (0, pad), (0, 0), (0, 0))),
+                      phase_ridge=np.pad(pk["phase_ridge"], ((0, 0), (0, pad), (0, 0), (0, 0))))
+        ring_host.append((_tile(pk, n, base), np.concatenate([xk] * ((n + base - 1) // base))[:n]))
+    prob, x0 = ring_host[0]
     def handle():
         if srb:
             w = DdpSingleRigidBody.WeightParam(running_pos=(1.0, 1.0, 10.0), running_ori=(0.5,) * 3, terminal_pos=(1.0, 1.0, 10.0),
@@ -136,18 +172,30 @@ def _ddp(n, dev, rank, srb, walking=False):
         return h
 
     d = handle()
-    tp, tx0 = {a: _dev(v, dev) for a, v in prob.items()}, _dev(x0, dev)
+    ring = [({a: _dev(v, dev) for a, v in pk.items()}, _dev(xk, dev)) for pk, xk in ring_host]
+    tp, tx0 = ring[0]
     out = torch.zeros((n, N, M), dtype=torch.float64, device=dev)
     st = torch.zeros(n, dtype=torch.int32, device=dev)
     it = torch.zeros(n, dtype=torch.int32, device=dev)
+    count = [0]
 
     def step(stream):
+        rp, rx = ring[count[0] % len(ring)]
+        count[0] += 1
+        d.plan_batch_device(rp, rx, out, iters=it, status=st, stream=stream)
+
+    def rebase(stream):  # the outputs of ring entry 0 (what `cpu` compares with the oracle)
         d.plan_batch_device(tp, tx0, out, iters=it, status=st, stream=stream)
 
-    def nohist():
-        d0 = _without_history("CCC_DDP_HISTORY", handle)
-        o0 = torch.zeros_like(out)
-        return (lambda stream: d0.plan_batch_device(tp, tx0, o0, stream=stream)), (d0, o0)
+    def other(history, rotate):
+        d0 = handle() if history else _without_history("CCC_DDP_HISTORY", handle)
+        o0, c0 = torch.zeros_like(out), [0]
+
+        def f(stream):
+            rp, rx = ring[c0[0] % len(ring)] if rotate else ring[0]
+            c0[0] += 1
+            d0.plan_batch_device(rp, rx, o0, stream=stream)
+        return f, (d0, o0)
 
     def cpu(cores, ns=None):
         from oracle import oracle
@@ -178,7 +226,7 @@ def _ddp(n, dev, rank, srb, walking=False):
                 + S * 8 + N * M * 8,
                 kernel="ddp_tile_kernel<%d, %d>" % (S, M // 16), cpu=cpu,
                 valu=lambda iters: _ddp_valu(S, M, N, iters, walking),
-                keep=(d, tp, tx0), nohist=nohist,
+                keep=(d, ring), other=other, rebase=rebase, ring=len(ring), parity_tol=0.0,  # (bit-identical to the tile oracle)
                 history_what="fresh instances are handed out longest-first from the busy times of the handle's last call of "
                              "this size, and none is suspended (DESIGN.md section 7.4)")
 
@@ -414,6 +462,9 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = np.array([a.elapsed_time(b) for a, b in evs])
+    if "rebase" in w:  # (the timed steps rotated through the ring: leave ring entry 0's answers in the output arrays)
+        w["rebase"](stream)
+        torch.cuda.synchronize(dev)
     if rank != 0:
         return None
     kavg = float(kern_ms.mean()) * 1e-3
@@ -433,7 +484,9 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
            "distributed": dinfo,
-           "config": {"workload": w["workload"], "batch_per_gpu": n, "total_batch": world * n,
+           "config": {"workload": w["workload"] + (", the timed steps rotating through %d distinct batches" % w["ring"]
+                                                   if w.get("ring", 1) > 1 else ""),
+                      "batch_per_gpu": n, "total_batch": world * n, "ring": w.get("ring", 1),
                       "parallelism": "batch-sharded x%d" % world,
                       "collective": "all_gather(planned outputs)" if world > 1 else "none"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -465,23 +518,29 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
         out["roofline"]["valu"] = dict(achieved=v["simd_valu_busy_frac"], peak=1.0, unit="share of SIMD VALU cycles busy",
                                        frac=v["simd_valu_busy_frac"],
                                        dense_equivalent_tflops=v["dense_equivalent_flop_per_solve"] * n / kavg / 1e12, **v)
-    if world == 1 and history_leg and "nohist" in w:
-        # `value` is of a handle that has seen the batch (the timed steps repeat it): the same steps on a handle that keeps no
-        # history, for a caller whose batches have nothing to do with each other
-        step0, keep0 = w["nohist"]()
-        for _ in range(max(1, warmup)):
-            step0(stream)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(steps):
-            step0(stream)
-        torch.cuda.synchronize(dev)
-        e0 = time.perf_counter() - t1
+    if world == 1 and history_leg and "other" in w:
+        # `value` rotates through w["ring"] distinct batches on a default handle.  Beside it: the same rotation on a handle
+        # that keeps no history at all, and ONE batch repeated on a fresh handle (the schedule's best case)
+        def timed(history, rotate):
+            step0, keep0 = w["other"](history, rotate)
+            for _ in range(max(2, warmup)):
+                step0(stream)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step0(stream)
+            torch.cuda.synchronize(dev)
+            e = time.perf_counter() - t1
+            del step0, keep0
+            return e
+
+        e0, e1 = timed(False, True), timed(True, False)
         out["history"] = {"value_without_history": n * steps / e0, "ms_per_step_without_history": 1e3 * e0 / steps,
-                          "what": "`value`: a handle that has seen this batch -- " + w["history_what"]
-                                  + "; value_without_history: the same steps on a handle created with the history switched "
-                                    "off.  The answers are the same bits either way (tests/)"}
-        del step0, keep0
+                          "value_repeated": n * steps / e1, "ms_per_step_repeated": 1e3 * e1 / steps,
+                          "what": "`value`: the timed steps rotate through %d distinct batches on a default handle (no call "
+                                  "sees its own past); value_without_history: the same rotation on a handle created with the "
+                                  "history switched off; value_repeated: ONE batch repeated on a fresh handle -- " % w["ring"]
+                                  + w["history_what"] + ".  The answers are the same bits whatever the schedule (tests/)"}
     if cpu and world == 1:
         import bench  # (host_cores: physical cores within the affinity mask and the cgroup CPU quota)
 
@@ -496,4 +555,7 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
                                          "rate on the first %d; C restatement of the reference path (oracle/), not the "
                                          "reference's Eigen + QLD / nmpc_ddp build" % (ns, cores, hw_threads, ns1)}
         out["parity"] = {"value": err, "what": what}
+        if "parity_tol" in w:  # (the tolerance this class is held to, stated and asserted in the run)
+            out["parity"]["tolerance"] = w["parity_tol"]
+            assert err <= w["parity_tol"], "%s: parity %g exceeds the stated tolerance %g" % (workload, err, w["parity_tol"])
     return out

@@ -57,6 +57,7 @@ template<int NP>
 struct ZmpScratch
 {
   static constexpr int kRp = NP;
+  static constexpr int kT = NP + 1;    // the full step of the entering row (K1_PIVOT_FAST)
   static constexpr int kSize = NP + 8; // keeps every group's base 16-byte aligned
 };
 
@@ -179,9 +180,9 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
       // top-tested loop hipcc keeps a second copy of the register-resident row and moves it back every trip
       if(__ballot(!done) != 0ull) do
         {
-#define K1_PIVOT
+#define K1_PIVOT_FAST
 #include "zmp_k1.inc"
-#undef K1_PIVOT
+#undef K1_PIVOT_FAST
         } while(__ballot(!done) != 0ull);
 
       const bool fin = true;
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
     // ---- one pivot for every group that is iterating
     if(__ballot(phase == kActive && !done) != 0ull)
     {
-#define K1_PIVOT
+#define K1_PIVOT_FAST
 #include "zmp_k1.inc"
-#undef K1_PIVOT
+#undef K1_PIVOT_FAST
     }
 
     // ---- groups whose iteration stopped: closing refinement, then either re-open or emit and ask for the next QP
