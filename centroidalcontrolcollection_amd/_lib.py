@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "ccc_zmp_horizon_steps",
     "ccc_zmp_get_seq",
     "ccc_zmp_last_kernel",
+    "ccc_zmp_last_schedule",
     "ccc_zmp_plan_batch_device",
     "ccc_zmp_plan_batch",
     "ccc_zmp_get_model",
@@ -155,6 +156,8 @@ def load():
     L.ccc_zmp_horizon_steps.argtypes = [ctypes.c_void_p]
     L.ccc_zmp_last_kernel.restype = ctypes.c_char_p
     L.ccc_zmp_last_kernel.argtypes = [ctypes.c_void_p]
+    L.ccc_zmp_last_schedule.restype = ctypes.c_char_p
+    L.ccc_zmp_last_schedule.argtypes = [ctypes.c_void_p]
     L.ccc_zmp_get_seq.restype = ctypes.c_int
     L.ccc_zmp_get_seq.argtypes = [ctypes.c_void_p, c_double_p, c_double_p]
     L.ccc_zmp_plan_batch_device.restype = ctypes.c_int

@@ -55,7 +55,7 @@ int zero_words(void * p, int words, void * stream);
 // order[0 .. n) = the items sorted by hist[], largest first (in-stream, two launches; see common.hip); `scratch`:
 // kOrderScratchInts ints of the caller's; optionally zeroes nwords words at `zero` and stores n in *count_out on the way
 constexpr int kOrderBlocks = 128;
-constexpr int kOrderScratchInts = kOrderBlocks * 256 + 2 * kOrderBlocks;
+constexpr int kOrderScratchInts = kOrderBlocks * 256 + 4 * kOrderBlocks; // (the table, then two 64-bit sums per chunk)
 // diff / flag (optional): per-item |count - count of the call before| and where the verdict "the history predicts" goes
 // (page-locked host memory; see common.hip); order = nullptr: the verdict alone
 int order_by_count(const int * hist, int n, int * order, int * scratch, void * zero, int nwords, int * count_out, void * stream,

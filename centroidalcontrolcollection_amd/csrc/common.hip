@@ -40,25 +40,29 @@ __device__ __forceinline__ int order_bucket(int t) { return kOrderBuckets - 1 - 
 
 // Does the history predict?  A kernel that keeps per-item counts can also keep, per item, |count now - count of the call
 // before| (`diff`); the counting pass adds them up beside the counts themselves (two more words per chunk behind the table),
-// and the verdict -- independent draws of a batch's counts differ by about a third of their sum, the consecutive cycles of
-// a closed loop by a few per cent: the history is trusted below a tenth -- goes to *flag: page-locked host memory that the
-// launching code reads, without waiting, a call or two later.
+// and the verdict -- independent draws of a batch's counts differ by about 0.6 of their sum, the consecutive cycles of
+// a closed loop by a few per cent: the history is trusted below kTrustNum / kTrustDen = a fifth -- goes to *flag: page-locked
+// host memory that the launching code reads, without waiting, a call or two later.  (The per-chunk sums travel as 64-bit
+// words: a chunk of the largest batch the callers allow, 2^30 items / 128 chunks x several hundred trips, overflows 32.)
+constexpr long long kTrustNum = 1, kTrustDen = 5;
 __device__ void order_verdict(const int * __restrict__ scratch, int nblk, int * flag, int tid)
 {
   if(tid < 64)
   {
     long long a = 0, sum = 0;
+    const long long * agree = reinterpret_cast<const long long *>(scratch + kOrderBlocks * kOrderBuckets);
     for(int b = tid; b < nblk; b += 64)
     {
-      a += scratch[kOrderBlocks * kOrderBuckets + 2 * b];
-      sum += scratch[kOrderBlocks * kOrderBuckets + 2 * b + 1];
+      a += agree[2 * b];
+      sum += agree[2 * b + 1];
     }
     for(int d = 32; d >= 1; d >>= 1)
     {
       a += __shfl_xor(a, d);
       sum += __shfl_xor(sum, d);
     }
-    if(tid == 0 && sum > 0) __hip_atomic_store(flag, 10 * a < 2 * sum ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if(tid == 0 && sum > 0)
+      __hip_atomic_store(flag, kTrustDen * a < kTrustNum * sum ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ __launch_bounds__(64) void order_verdict_kernel(const int * __restrict__ scratch, int nblk, int * flag)
@@ -71,10 +75,10 @@ __global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict
                                                           const int * __restrict__ diff)
 {
   __shared__ int cnt[kOrderBuckets];
-  __shared__ int agree[2];
+  __shared__ unsigned long long agree[2];
   const int tid = threadIdx.x, blk = blockIdx.x;
   cnt[tid] = 0;
-  if(tid < 2) agree[tid] = 0;
+  if(tid < 2) agree[tid] = 0ull;
   if(blk == 0)
   {
     for(int k = tid; k < nwords; k += 256) zero[k] = 0u;
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict
   }
   __syncthreads();
   const int lo = blk * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  int da = 0, ds = 0;
+  long long da = 0, ds = 0;
   for(int i = lo + tid; i < hi; i += 256)
   {
     const int t = hist[i];
@@ -102,13 +106,13 @@ __global__ __launch_bounds__(256) void order_count_kernel(const int * __restrict
     }
     if((tid & 63) == 0)
     {
-      atomicAdd(&agree[0], da);
-      atomicAdd(&agree[1], ds);
+      atomicAdd(&agree[0], (unsigned long long)da);
+      atomicAdd(&agree[1], (unsigned long long)ds);
     }
   }
   __syncthreads();
   scratch[blk * kOrderBuckets + tid] = cnt[tid];
-  if(diff && tid < 2) scratch[kOrderBlocks * kOrderBuckets + 2 * blk + tid] = agree[tid];
+  if(diff && tid < 2) reinterpret_cast<long long *>(scratch + kOrderBlocks * kOrderBuckets)[2 * blk + tid] = (long long)agree[tid];
 }
 
 __global__ __launch_bounds__(256) void order_place_kernel(const int * __restrict__ hist, int n, int chunk, const int * __restrict__ scratch,

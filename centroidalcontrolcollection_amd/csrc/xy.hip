@@ -1580,6 +1580,7 @@ struct ccc_xy
   // round 5: the sweeps every instance of the last call took, and the order of the next call of the same size made from
   // them (CCC_XY_HISTORY=0: never)
   int *hist = nullptr, *order = nullptr, *order_scratch = nullptr;
+  std::vector<void *> retired; // outgrown hist / order buffers (see the launch code)
   int64_t hist_cap = 0, hist_n = -1;
   bool env_history = true;
 };
@@ -1649,6 +1650,7 @@ extern "C" void ccc_xy_destroy(ccc_xy_t * h)
   if(h->ws) (void)hipFree(h->ws);
   if(h->hist) (void)hipFree(h->hist);
   if(h->order) (void)hipFree(h->order);
+  for(void * q : h->retired) (void)hipFree(q);
   if(h->order_scratch) (void)hipFree(h->order_scratch);
   if(h->d_stage) (void)hipFree(h->d_stage);
   if(h->stream) (void)hipStreamDestroy(h->stream);
@@ -1754,8 +1756,10 @@ extern "C" int ccc_xy_plan_batch_device(ccc_xy_t * h, int64_t n, const int32_t *
     {
       if(h->hist_cap < n)
       {
-        if(h->hist) (void)hipFree(h->hist);
-        if(h->order) (void)hipFree(h->order);
+        // (outgrown buffers are RETIRED, not freed: a hipGraph captured at the smaller size still replays launches that
+        //  read and write them -- ADVICE r5; they go with the handle)
+        if(h->hist) h->retired.push_back(h->hist);
+        if(h->order) h->retired.push_back(h->order);
         h->hist = h->order = nullptr;
         h->hist_cap = 0;
         h->hist_n = -1;

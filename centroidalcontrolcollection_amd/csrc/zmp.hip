@@ -107,6 +107,19 @@ __device__ __forceinline__ double row_at_group_uniform(const RowRegs<NP> & T, in
   return (threadIdx.x & 32) ? c1 : c0;
 }
 
+// Block layout of the row (round 6, csrc/zmp_k1.inc K1D_*): TS[k] = T[li][16 rblk + k], TO[k] = T[li][16 (1 - rblk) + k] with rblk
+// the 16-lane DPP row of the lane inside its 32-lane group.  Element idx of the row, idx uniform inside each group:
+__device__ __forceinline__ double row_at_group_uniform_blocks(const v16d & TS, const v16d & TO, int idx, int rblk)
+{
+  const int u0 = __builtin_amdgcn_readlane(idx, 0), u1 = __builtin_amdgcn_readlane(idx, 32);
+  const double a0 = TS[u0 & 15], b0 = TO[u0 & 15];
+  const double a1 = TS[u1 & 15], b1 = TO[u1 & 15];
+  const double c0 = ((u0 >> 4) == rblk) ? a0 : b0;
+  const double c1 = ((u1 >> 4) == rblk) ? a1 : b1;
+  return (threadIdx.x & 32) ? c1 : c0;
+}
+#define K1D_TCOL(u) row_at_group_uniform_blocks(TS, TO, (u), rblk)
+
 // the row accessors of csrc/zmp_k1.inc for the kernels that keep the row in a RowRegs struct `T`
 #define K1_TGET(j) T.t[(j) / 16][(j) % 16]
 #define K1_TSET(j, v) T.t[(j) / 16][(j) % 16] = (v)
@@ -125,6 +138,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
   using Grp = WaveGroup<LG>;
   using Scr = ZmpScratch<LG>;
   constexpr int NP = LG;
+  static_assert(LG == 32, "block layout: two 16-lane DPP rows per group");
   constexpr int QPW = 64 / LG; // QPs per wavefront
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double * Gs = smem;           // [NP][NP]
@@ -132,6 +146,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
   double * As = bs + NP;        // [NP][3]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & (LG - 1), grp = lane / LG, lic = li;
+  const int rblk = (li >> 4) & 1; // the 16-lane DPP row of this lane inside its group
   double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
   const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
@@ -155,16 +170,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
     double lo, hi;
     // tableau T = G (W empty): lane li holds row li = column li of the symmetric G.  The diagonal lives in dg: the
     // in-row copy T[li][li] is never read by its owner (dgm mirrors its bits for the closing refinement).
-    RowRegs<NP> T;
+    v16d TS, TO; // the row in block layout (K1D_LOAD)
     double dg, dgm;
     double z, mu;      // z = (G mu)_li, mu = multiplier of row li
     bool inW, side;    // while in W: side = sits on lo
     int p;             // entering row   (group uniform)
     double sig;        // its side +1/-1 (group uniform)
     int passes;
-#define K1_LOAD
+#define K1D_LOAD
 #include "zmp_k1.inc"
-#undef K1_LOAD
+#undef K1D_LOAD
     int st = CCC_STATUS_SOLVED;
     if(Grp::any(row && lo > hi)) st = CCC_STATUS_INFEASIBLE;
     bool done = !valid || st != CCC_STATUS_SOLVED;
@@ -180,15 +195,15 @@ __global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long 
       // top-tested loop hipcc keeps a second copy of the register-resident row and moves it back every trip
       if(__ballot(!done) != 0ull) do
         {
-#define K1_PIVOT_FAST
+#define K1D_PIVOT
 #include "zmp_k1.inc"
-#undef K1_PIVOT_FAST
+#undef K1D_PIVOT
         } while(__ballot(!done) != 0ull);
 
       const bool fin = true;
-#define K1_REFINE
+#define K1D_REFINE
 #include "zmp_k1.inc"
-#undef K1_REFINE
+#undef K1D_REFINE
       done = !reopen;
       need_select = true;
       __builtin_amdgcn_wave_barrier();
@@ -345,6 +360,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
   using Grp = WaveGroup<LG>;
   using Scr = ZmpScratch<LG>;
   constexpr int NP = LG;
+  static_assert(LG == 32, "block layout: two 16-lane DPP rows per group");
   constexpr int QPW = 64 / LG; // QPs per wavefront
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double * Gs = smem;           // [NP][NP]
@@ -352,6 +368,7 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
   double * As = bs + NP;        // [NP][3]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & (LG - 1), grp = lane / LG, lic = li;
+  const int rblk = (li >> 4) & 1; // the 16-lane DPP row of this lane inside its group
   double * scr = As + 3 * NP + (wave * QPW + grp) * Scr::kSize; // this group's scratch
   const double2 * scr2 = reinterpret_cast<const double2 *>(scr);
 
@@ -371,9 +388,13 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
   bool valid = false, row = false;
   double lo = -kInf, hi = kInf;
   int st = CCC_STATUS_SOLVED;
-  RowRegs<NP> T;
+  v16d TS, TO; // the row in block layout (K1D_LOAD)
 #pragma unroll
-  for(int j = 0; j < NP; ++j) T.t[j / 16][j % 16] = 0.0;
+  for(int j = 0; j < 16; ++j)
+  {
+    TS[j] = 0.0;
+    TO[j] = 0.0;
+  }
   double dg = 1.0, dgm = 1.0;
   double z = 0.0, mu = 0.0;
   bool inW = false, side = false;
@@ -437,9 +458,9 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
         {
           fresh = true;
           row = li < N;
-#define K1_LOAD
+#define K1D_LOAD
 #include "zmp_k1.inc"
-#undef K1_LOAD
+#undef K1D_LOAD
           round = 0;
           need_select = true;
           phase = kActive;
@@ -459,18 +480,18 @@ __global__ __launch_bounds__(WAVES * 64) void zmp_plan_kernel_dyn(ZmpDev P, long
     // ---- one pivot for every group that is iterating
     if(__ballot(phase == kActive && !done) != 0ull)
     {
-#define K1_PIVOT_FAST
+#define K1D_PIVOT
 #include "zmp_k1.inc"
-#undef K1_PIVOT_FAST
+#undef K1D_PIVOT
     }
 
     // ---- groups whose iteration stopped: closing refinement, then either re-open or emit and ask for the next QP
     if(__ballot(phase == kActive && done) != 0ull)
     {
       const bool fin = phase == kActive && done;
-#define K1_REFINE
+#define K1D_REFINE
 #include "zmp_k1.inc"
-#undef K1_REFINE
+#undef K1D_REFINE
       const bool again = fin && reopen && round + 1 < 3;
       if(fin)
       {
@@ -1062,6 +1083,41 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
 
 } // namespace ccc_amd
 
+// ---------------------------------------------------------------------------------------------
+// The schedule of a call WITHOUT a usable history (round 6): a prediction of every QP's pivot trips, fed
+// to the same counting sort the history feeds (csrc/common.hip order_by_count); the static kernel then runs the QPs longest
+// first, like predictions paired in a wavefront.  What predicts: a QP's trips are the rows in its working set at the optimum
+// (15.8 trips for 15.6 rows on the bench workload: rows hardly ever leave), and those are driven by the rows the
+// UNCONSTRAINED optimum u = 0 violates, i.e. where the free response A_seq x0 leaves its limits -- the earlier in the
+// horizon, the more: a violation a few LIPM time constants ahead is absorbed by a handful of active rows, one that is
+// imminent drags its whole neighbourhood onto the bounds.  key = sum_i exp(-t_i / tau) [row i violated], tau = 2.35 sqrt(h / g)
+// (0.75 s at h = 1 m), t_i = i dt: measured on the bench workload (numpy, counts of the kernel itself), the two QPs of a
+// wavefront then spend 1.14 x their own trips in lock-step (the x and y axes of an instance: 1.39, the plain count of
+// violated rows: 1.23, the last call's counts of a repeated batch: 1.00).  One pass over the inputs (HBM-bound, 71 MB at
+// the headline), lane = row as in K1.  A schedule only: the answers do not depend on it.
+// ---------------------------------------------------------------------------------------------
+namespace ccc_amd
+{
+template<int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void zmp_predict_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                                 const double * __restrict__ zlim, int * __restrict__ pred)
+{
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31;
+  const long qp = ((long)blockIdx.x * WAVES + (tid >> 6)) * 2 + (lane >> 5);
+  const int N = P.N;
+  float k = 0.0f;
+  if(qp < nqp && li < N)
+  {
+    const double fr = P.A[li * 3 + 0] * x0[qp * 3 + 0] + P.A[li * 3 + 1] * x0[qp * 3 + 1] + P.A[li * 3 + 2] * x0[qp * 3 + 2];
+    const double lo = zlim[qp * 2 * N + li] - fr, hi = zlim[qp * 2 * N + N + li] - fr;
+    const float tau = 2.35f * sqrtf((float)-P.c2); // c2 = -h / g
+    if(lo > 0.0 || hi < 0.0) k = 16.0f * __expf(-(float)li * (float)P.dt / tau);
+  }
+  for(int d = 16; d >= 1; d >>= 1) k += __shfl_xor(k, d, 32);
+  if(li == 0 && qp < nqp) pred[qp] = (int)(k + 0.5f); // (<= 16 / (1 - exp(-dt / tau)): inside order_by_count's 256 buckets)
+}
+} // namespace ccc_amd
+
 // =============================================================================================
 // host side: model construction and the C-ABI
 // =============================================================================================
@@ -1080,6 +1136,9 @@ struct ccc_zmp
   int * order_scratch = nullptr;         // (order_by_count's table)
   int * diff = nullptr;                  // |trips - trips of the call before| per QP, and the verdict it leads to:
   int *trust_host = nullptr, *trust_dev = nullptr; // page-locked host memory, read without waiting (0: do not follow)
+  int * pred = nullptr;                  // predicted trips per QP of THIS call (zmp_predict_kernel), when no history is followed
+  std::vector<void *> retired;           // scheduling buffers that were outgrown: kept until the handle goes, because a
+                                         // hipGraph captured at the smaller size still holds their addresses
   int64_t hist_cap = 0, hist_n = -1;     // (hist_n: the QPs of the call the counts belong to, -1 = none yet)
   int64_t diff_n = -1;                   // (... and of the call the differences belong to)
   unsigned watch = 0;
@@ -1100,6 +1159,9 @@ struct ccc_zmp
   int64_t env_queue_min = -1;   // CCC_ZMP_QUEUE_MIN: QPs from which the work-queue kernel runs (< 0: the measured default)
   bool env_static = false;      // CCC_ZMP_STATIC: never the work-queue kernel
   bool env_history = true;      // CCC_ZMP_HISTORY=0: never order a call by the last call's pivot counts
+  bool env_predict = true;      // CCC_ZMP_PREDICT=0: never order a call by the predicted pivot counts (zmp_predict_kernel)
+  int64_t env_predict_min = -1; // CCC_ZMP_PREDICT_MIN: QPs from which a call without a followed history is ordered by the
+                                //                      prediction (< 0: the measured default)
   bool env_debug = false;       // CCC_ZMP_DEBUG: print the occupancy of the LDS-tableau kernels
   int env_kw = -1;              // CCC_ZMP_KW: 0 = never the one-QP-per-wavefront register kernel (K1w) for 32 < N <= 64 (the
                                 //             default there: 39.2 / 34.1 / 28.9 / 19.2 / 17.5 M solves/s at N = 33 / 40 / 48 /
@@ -1110,6 +1172,7 @@ struct ccc_zmp
                                 //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
   const char * last_kernel = "none"; // the kernel the last plan call launched (ccc_zmp_last_kernel)
+  const char * last_order = "none";  // ... and what its schedule came from (CCC_ZMP_DEBUG prints it)
 };
 
 namespace
@@ -1196,28 +1259,32 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   bool ordered = false, hist_verdict = false;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-  if(h->env_history && !h->skip_history && nqp < (int64_t)1 << 30 && !(capturing && h->hist_cap < nqp))
+  const bool sched_ok = (h->env_history || h->env_predict) && !h->skip_history && nqp < (int64_t)1 << 30
+                        && !(capturing && h->hist_cap < nqp);
+  if(sched_ok && h->hist_cap < nqp)
   {
-    if(h->hist_cap < nqp)
+    // (the outgrown buffers are RETIRED, not freed: a hipGraph captured at the smaller size replays launches that read and
+    //  write them -- ADVICE r5: freed, that was silent corruption; they go with the handle)
+    for(int * q : {h->hist, h->order, h->diff, h->pred})
+      if(q) h->retired.push_back(q);
+    h->hist = h->order = h->diff = h->pred = nullptr;
+    h->hist_cap = 0;
+    h->hist_n = -1;
+    CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->diff, (size_t)nqp * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->pred, (size_t)nqp * sizeof(int)));
+    if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
+    if(!h->trust_host)
     {
-      if(h->hist) (void)hipFree(h->hist);
-      if(h->order) (void)hipFree(h->order);
-      if(h->diff) (void)hipFree(h->diff);
-      h->hist = h->order = h->diff = nullptr;
-      h->hist_cap = 0;
-      h->hist_n = -1;
-      CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
-      CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
-      CCC_HIP_CHECK(hipMalloc(&h->diff, (size_t)nqp * sizeof(int)));
-      if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
-      if(!h->trust_host)
-      {
-        CCC_HIP_CHECK(hipHostMalloc(&h->trust_host, 64, hipHostMallocMapped));
-        *h->trust_host = 1;
-        CCC_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->trust_dev), h->trust_host, 0));
-      }
-      h->hist_cap = nqp;
+      CCC_HIP_CHECK(hipHostMalloc(&h->trust_host, 64, hipHostMallocMapped));
+      *h->trust_host = 1;
+      CCC_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->trust_dev), h->trust_host, 0));
     }
+    h->hist_cap = nqp;
+  }
+  if(sched_ok && h->env_history)
+  {
     // (a history that does not predict -- unrelated batches of one size, call after call -- is worse than none: the two
     //  axes of an instance are better company for each other than two QPs picked by a wrong guess, 101 against 110 M
     //  solves/s at 65536.  A call that has counts to compare with keeps the differences; the sort of the next call, or a
@@ -1225,15 +1292,20 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     const bool comparable = h->hist_n == nqp, verdict = comparable && h->diff_n == nqp;
     const bool trusted = *static_cast<volatile int *>(h->trust_host) != 0;
     ordered = comparable && trusted;
-    P.hist = h->hist;
+    // (round 6: while the history is NOT followed it is still watched, but only three calls in eight keep counts -- the
+    //  first for the second to compare with, the third to sum the differences up: the twelve bytes per QP a recording call
+    //  writes and the 7 us of the counting pass were 3 % of a call of rotating batches, 15 % at 4096 instances)
+    const unsigned phase = trusted ? 7u : (h->watch++ & 7u);
+    const bool record = trusted || phase >= 5u;
+    P.hist = record ? h->hist : nullptr;
     P.order = ordered ? h->order : nullptr;
-    P.diff = comparable ? h->diff : nullptr;
-    // (not followed: watched every fourth call -- the pass costs 7 us, a call of 8192 instances 97)
-    if(verdict && !ordered && (h->watch++ & 3) == 0)
+    P.diff = (record && comparable) ? h->diff : nullptr;
+    if(verdict && !ordered && phase == 7u)
       if(int arc = order_by_count(h->hist, (int)nqp, nullptr, h->order_scratch, nullptr, 0, nullptr, stream, h->diff, h->trust_dev))
         return arc;
     hist_verdict = verdict;
-    h->diff_n = comparable ? nqp : -1;
+    h->diff_n = (record && comparable) ? nqp : -1;
+    if(!record) h->hist_n = -1; // (the counts in the buffer are not the previous call's any more)
   }
   // large batches: a work queue per 32-lane group (zmp_plan_kernel_dyn); below ~18 QPs per resident group the static
   // pairing (one instance per wavefront, more workgroups than fit: the hardware dispatcher balances) is faster -- measured
@@ -1243,9 +1315,16 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   // (round 5: with an order from the last call the static kernel is the faster one at every size -- the wavefront's two QPs
   //  have like pivot counts, which is what the queue was for, without its divergent set-up: 127 against 96 M at 65536, 106
   //  against 78 M at 8192 instances, the batch repeated; the queue stays for calls without a history)
-  const bool use_queue = !h->env_static && nqp >= queue_min && !ordered;
+  // round 6: a call without a followed history is ordered by the PREDICTED trips (zmp_predict_kernel above) and runs on the
+  // static kernel as well -- measured at 65536 instances, eight unrelated batches in turn: 114.5 (queue kernel) -> 130.2 M
+  // solves/s on a default handle, 118.4 -> 133.0 M on one that keeps no history; 8192 instances: 96.7 M, 4096 (below the
+  // threshold: the prediction's pass costs what it saves): 72 M
+  const int64_t predict_min = h->env_predict_min >= 0 ? h->env_predict_min : 16384;
+  const bool predicted = sched_ok && h->env_predict && !ordered && LG == 32 && nqp >= predict_min;
+  const bool use_queue = !h->env_static && nqp >= queue_min && !ordered && !predicted;
   h->last_kernel = use_queue ? (LG == 32 ? "zmp_plan_kernel_dyn<32,2>" : "zmp_plan_kernel_dyn")
                              : (LG == 32 ? "zmp_plan_kernel<32,2>" : "zmp_plan_kernel");
+  h->last_order = ordered ? "last call's pivot counts" : (predicted ? "predicted pivot counts" : "none");
   if(use_queue)
   {
     if(!h->attr_dyn)
@@ -1276,7 +1355,17 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     if(P.hist) h->hist_n = nqp;
     return CCC_OK;
   }
-  // the schedule of this call from the pivot counts of the last one: a counting sort, longest first (common.hip)
+  // the schedule of this call from a prediction of every QP's trips (no history followed) ...
+  if(predicted)
+  {
+    constexpr int PW = 4;
+    hipLaunchKernelGGL((zmp_predict_kernel<PW>), dim3((unsigned)((nqp + 2 * PW - 1) / (2 * PW))), dim3(PW * 64), 0, stream, P,
+                       (long)nqp, x0, zlim, h->pred);
+    if(int orc = order_by_count(h->pred, (int)nqp, h->order, h->order_scratch, nullptr, 0, nullptr, stream, nullptr, nullptr))
+      return orc;
+    P.order = h->order;
+  }
+  // ... or from the pivot counts of the last one: a counting sort, longest first (common.hip)
   if(ordered)
     if(int orc = order_by_count(h->hist, (int)nqp, h->order, h->order_scratch, nullptr, 0, nullptr, stream, hist_verdict ? h->diff : nullptr,
                                  h->trust_dev)) return orc;
@@ -1438,6 +1527,11 @@ extern "C" const char * ccc_zmp_last_kernel(const ccc_zmp_t * h)
   return h ? h->last_kernel : "none";
 }
 
+extern "C" const char * ccc_zmp_last_schedule(const ccc_zmp_t * h)
+{
+  return h ? h->last_order : "none";
+}
+
 extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double horizon_dt, int device,
                               ccc_zmp_t ** out)
 {
@@ -1461,6 +1555,8 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(const char * qm = std::getenv("CCC_ZMP_QUEUE_MIN")) h->env_queue_min = std::atoll(qm);
   h->env_static = std::getenv("CCC_ZMP_STATIC") != nullptr;
   if(const char * e = std::getenv("CCC_ZMP_HISTORY")) h->env_history = std::atoi(e) != 0;
+  if(const char * e = std::getenv("CCC_ZMP_PREDICT")) h->env_predict = std::atoi(e) != 0;
+  if(const char * e = std::getenv("CCC_ZMP_PREDICT_MIN")) h->env_predict_min = std::atoll(e);
   h->env_debug = std::getenv("CCC_ZMP_DEBUG") != nullptr;
   if(const char * k2 = std::getenv("CCC_ZMP_K2")) h->env_k2 = std::atoi(k2);
   if(const char * kw = std::getenv("CCC_ZMP_KW")) h->env_kw = std::atoi(kw);
@@ -1493,6 +1589,8 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->order) (void)hipFree(h->order);
   if(h->order_scratch) (void)hipFree(h->order_scratch);
   if(h->diff) (void)hipFree(h->diff);
+  if(h->pred) (void)hipFree(h->pred);
+  for(void * q : h->retired) (void)hipFree(q);
   if(h->trust_host) (void)hipHostFree(h->trust_host);
   if(h->dG) (void)hipFree(h->dG);
   if(h->dA) (void)hipFree(h->dA);

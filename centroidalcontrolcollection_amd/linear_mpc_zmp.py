@@ -60,6 +60,11 @@ class LinearMpcZmp:
                                            B.ctypes.data_as(_lib.c_double_p)))
         return A, B
 
+    def last_schedule(self):
+        """What the last plan call's schedule came from (ccc_zmp_last_schedule): "last call's pivot counts", "predicted
+        pivot counts" or "none"."""
+        return self._L.ccc_zmp_last_schedule(self._h).decode()
+
     def last_kernel(self):
         """Name of the kernel the last plan call launched (ccc_zmp_last_kernel): what a profile of that call lists."""
         return self._L.ccc_zmp_last_kernel(self._h).decode()

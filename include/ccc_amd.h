@@ -17,6 +17,10 @@
  * hipGraph: every "_device" call may be captured (hipStreamBeginCapture on the stream it is given) once the handle has
  * run one call of at least that batch size eagerly -- workspaces are allocated, synchronously, when a batch size is
  * first seen; a call enqueues only kernels (and, LinearMpcXY, an event fork/join with a stream the handle owns).
+ * A captured graph holds the addresses of the handle's workspaces: it stays valid until a LATER call with a larger batch
+ * makes a workspace grow (the old one is freed) -- capture at the largest batch the handle will see.  LinearMpcZmp handles
+ * for N <= 32 have no such workspace (their scheduling buffers are retired, not freed, when outgrown): graphs of theirs stay
+ * valid for the life of the handle.
  */
 #ifndef CCC_AMD_H
 #define CCC_AMD_H
@@ -75,6 +79,11 @@ int ccc_zmp_get_seq(const ccc_zmp_t * h, double * A_seq, double * B_seq);
  * "zmp_plan_sym_kernel", "zmp_plan_block_kernel", "none" before the first call): what a profile of that call lists.
  * New -- no reference counterpart; for measurement code (bench.py's roofline object). */
 const char * ccc_zmp_last_kernel(const ccc_zmp_t * h);
+/* What the schedule of the handle's last plan call (N <= 32) came from: "last call's pivot counts" (a handle that sees its
+ * batch again, round 5), "predicted pivot counts" (round 6: no usable history -- one pass over the inputs predicts every
+ * QP's pivot trips from the rows its unconstrained optimum violates, csrc/zmp.hip zmp_predict_kernel) or "none".  The
+ * answers never depend on the schedule.  New (ABI 5); for measurement code and tests. */
+const char * ccc_zmp_last_schedule(const ccc_zmp_t * h);
 
 /* Replaces n calls of CCC::LinearMpcZmp::planOnce(ref_data_func, initial_param, current_time, control_dt)
  * (include/CCC/LinearMpcZmp.h:151-154, src/LinearMpcZmp.cpp:83-112) with the callbacks already

@@ -47,6 +47,36 @@ def test_zmp_graph_replay(n):
         assert np.array_equal(zmp.cpu().numpy(), eager["zmp"]) and np.all((st.cpu().numpy() & 0xff) == 0)
 
 
+def test_a_zmp_graph_survives_a_later_larger_eager_call():
+    """the scheduling buffers of a LinearMpcZmp handle (last call's counts, predicted counts, the order
+    made from them) grow with the batch; a hipGraph captured at a smaller size has their addresses baked into its launches.
+    The N <= 32 path has no other growable buffer, and the outgrown ones are retired, not freed: the graph still replays to
+    the eager answers after larger eager calls on the same handle.  (The classes with a per-batch WORKSPACE -- LinearMpcXY,
+    the DDP planners, DdpZmp -- free and re-allocate it when a larger batch arrives: there a graph is valid until the
+    handle's next larger call, as include/ccc_amd.h says.)"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n, big = 9000, 30000
+    mpc = LinearMpcZmp(1.0, 2.0, 0.0625)
+    a, c = fx.make_zmp_batch(n, 32, 0.0625, seed=3), fx.make_zmp_batch(big, 32, 0.0625, seed=5)
+    x0, zlim = torch.from_numpy(a["x0"]).to(dev), torch.from_numpy(a["zlim"]).to(dev)
+    out = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    mpc.plan_batch_device(x0, zlim, 0.005, out, None, None, torch.cuda.current_stream())  # (a call before: a history exists)
+    g = _capture(lambda s: mpc.plan_batch_device(x0, zlim, 0.005, out, None, None, s))
+    want = mpc.planOnceBatch(a["x0"], a["zlim"], 0.005)["zmp"]
+    bx, bz = torch.from_numpy(c["x0"]).to(dev), torch.from_numpy(c["zlim"]).to(dev)
+    bo = torch.zeros((big, 2), dtype=torch.float64, device=dev)
+    for _ in range(2):
+        mpc.plan_batch_device(bx, bz, 0.005, bo, None, None, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_xy_graph_replay_with_rounds_and_second_stream(monkeypatch):
     import torch
 

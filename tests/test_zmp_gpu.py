@@ -341,9 +341,11 @@ def test_work_queue_kernel_equals_static_pairing(mpc32, monkeypatch):
     n = 20001  # 40002 QPs: not a multiple of anything (CCC_ZMP_QUEUE_MIN=0: the queue kernel whatever the size)
     b = fx.make_zmp_batch(n, 32, 0.0625, seed=77)
     monkeypatch.setenv("CCC_ZMP_QUEUE_MIN", "0")
+    monkeypatch.setenv("CCC_ZMP_PREDICT", "0")  # (round 6: by default a batch this large is ordered by the predicted trips)
     monkeypatch.setenv("CCC_ZMP_HOST_CHUNK", "1000000")  # (one launch for the whole batch)
     mq = LinearMpcZmp(1.0, 2.0, 0.0625)
     monkeypatch.delenv("CCC_ZMP_QUEUE_MIN")
+    monkeypatch.delenv("CCC_ZMP_PREDICT")
     monkeypatch.delenv("CCC_ZMP_HOST_CHUNK")
     full = mq.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
     assert mq.last_kernel() == "zmp_plan_kernel_dyn<32,2>"
@@ -353,6 +355,60 @@ def test_work_queue_kernel_equals_static_pairing(mpc32, monkeypatch):
         assert np.array_equal(part["zmp"], full["zmp"][a:a + 4096])
         assert np.array_equal(part["jerk"], full["jerk"][a:a + 4096])
         assert np.array_equal(part["pivots"], full["pivots"][a:a + 4096])
+
+
+def test_predicted_schedule_gives_the_same_answers(monkeypatch):
+    """Round 6: a call that has no usable history is ordered by a PREDICTION of every QP's pivot trips
+    (csrc/zmp.hip zmp_predict_kernel: the rows the unconstrained optimum violates, weighted towards the start of the
+    horizon) and runs on the static kernel, like predictions paired in a wavefront.  A schedule only: unrelated batches in
+    turn, on a default handle and on one that keeps no history, give bit for bit what a handle without any ordering
+    gives; and the prediction does predict -- the lock-step trips of the pairs it makes are well below those of the
+    (x, y) pairs of an instance."""
+    import torch
+
+    n = 20000
+    dev = torch.device("cuda:0")
+    batches = [fx.make_zmp_batch(n, 32, 0.0625, seed=60 + k) for k in range(3)]
+
+    def run(m, b):
+        x0, zl = torch.from_numpy(b["x0"]).to(dev), torch.from_numpy(b["zlim"]).to(dev)
+        z = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        j = torch.empty((n, 2, 32), dtype=torch.float64, device=dev)
+        st = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        m.plan_batch_device(x0, zl, 0.005, z, j, st)
+        torch.cuda.synchronize()
+        return z.cpu().numpy(), j.cpu().numpy(), st.cpu().numpy()
+
+    monkeypatch.setenv("CCC_ZMP_PREDICT", "0")
+    monkeypatch.setenv("CCC_ZMP_HISTORY", "0")
+    plain = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_PREDICT")
+    nohist = LinearMpcZmp(1.0, 2.0, 0.0625)
+    monkeypatch.delenv("CCC_ZMP_HISTORY")
+    default = LinearMpcZmp(1.0, 2.0, 0.0625)
+    seen = set()
+    for rep in range(3):
+        for b in batches:
+            ref = run(plain, b)
+            assert plain.last_schedule() == "none"
+            for m in (nohist, default):
+                got = run(m, b)
+                seen.add(m.last_schedule())
+                for a, r in zip(got, ref):
+                    assert np.array_equal(a, r)
+            assert nohist.last_schedule() == "predicted pivot counts" and nohist.last_kernel() == "zmp_plan_kernel<32,2>"
+    assert "predicted pivot counts" in seen
+    # the prediction's quality, from the kernel's own counts: the same sort key, computed here
+    b = batches[0]
+    piv = (run(plain, b)[2] >> 8).reshape(-1).astype(np.int64)
+    i = np.arange(32)
+    A = np.stack([np.ones(32), (i + 1) * 0.0625, ((i + 1) * 0.0625) ** 2 / 2 - 1.0 / 9.80665], axis=1)
+    fr = np.einsum("ik,nak->nai", A, b["x0"])
+    viol = ((b["zlim"][:, :, 0, :] - fr > 0) | (b["zlim"][:, :, 1, :] - fr < 0)).reshape(-1, 32)
+    key = np.rint(16.0 * (viol * np.exp(-i * 0.0625 / (2.35 * np.sqrt(1.0 / 9.80665)))).sum(1))
+    paired = piv[np.argsort(-key, kind="stable")].reshape(-1, 2).max(1).sum() * 2.0 / piv.sum()
+    as_is = piv.reshape(-1, 2).max(1).sum() * 2.0 / piv.sum()
+    assert paired < 1.2 < 1.3 < as_is, (paired, as_is)
 
 
 def test_history_schedule_gives_the_same_answers_whatever_the_caller_repeats(monkeypatch):
