@@ -315,9 +315,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void zmp_plan_kernel_w(ZmpDev P, 
       select_entering();
       if(__ballot(!done) != 0ull) do
         {
-#define K1_PIVOT
+#define K1_PIVOT_FAST
 #include "zmp_k1.inc"
-#undef K1_PIVOT
+#undef K1_PIVOT_FAST
         } while(__ballot(!done) != 0ull);
       const bool fin = true;
 #define K1_REFINE
