@@ -530,6 +530,8 @@ struct BlockRed
 {
   double val[8];
   int idx[8];
+  double num;  // K2r: the full step's numerator of the entering row (zmp_k2r.inc)
+  int flag[2]; // K2r: "a multiplier would change sign on this pivot", double-buffered over the pivots
 };
 
 struct SelRed

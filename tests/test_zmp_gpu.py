@@ -188,8 +188,8 @@ def test_golden_vectors_n100_block_kernel(golden_zmp):
 def test_register_tile_kernel_against_the_oracle_and_the_lds_tableau(N, monkeypatch):
     """csrc/zmp_k2r.inc (round 5): the packed symmetric tableau of K2 kept in registers across pivots, the default for
     48 < N <= 128.  Every size it is built for, with two and with three tiles per thread: solved, planned ZMP and jerk
-    sequence within the parity tolerances of the oracle, and the same pivot counts as the LDS tableau (the iteration is K2's
-    statement by statement; only the closing refinement adds its partial sums in another order) with ZMPs within 1e-12."""
+    sequence within the parity tolerances of the oracle, no more pivots than the LDS tableau (the same iteration; since
+    round 6 K2r enters rows by the dual gain and skips the ratio test on the pivots that cannot drop a row) with ZMPs within 1e-12."""
     dt = 2.0 / N
     b = fx.make_zmp_batch(384, N, dt, seed=41 + N)
     ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
@@ -207,7 +207,9 @@ def test_register_tile_kernel_against_the_oracle_and_the_lds_tableau(N, monkeypa
         assert np.all(r["status"] == 0)
         assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
         assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
-        assert np.array_equal(r["pivots"], r0["pivots"]) and np.abs(r["zmp"] - r0["zmp"]).max() <= 1e-12
+        # (round 6: K2r enters rows by the dual objective's gain, K1's rule, instead of by the largest violation: fewer
+        #  pivots than the LDS tableau, the same minimiser)
+        assert r["pivots"].sum() <= r0["pivots"].sum() and np.abs(r["zmp"] - r0["zmp"]).max() <= 1e-12
     monkeypatch.delenv("CCC_ZMP_K2")
     monkeypatch.delenv("CCC_ZMP_KW")
     d = LinearMpcZmp(1.0, 2.0, dt)
