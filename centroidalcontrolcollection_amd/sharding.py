@@ -59,6 +59,21 @@ def plan_sharded(solve_local, x0, zlim, group=None):
     return all_gather_outputs(local, n, group)
 
 
+def plan_sharded_problem(solve_local, prob, x0, group=None):
+    """The same for the classes whose problem is a dict of per-instance arrays (LinearMpcXY: dim / vertex / ridge / ...; the
+    DDP planners: phase tables, references, ...): every tensor of `prob` and `x0` is cut along its first dimension into
+    this rank's contiguous shard, `solve_local(prob_shard, x0_shard) -> out_shard [n_local, ...]` plans it, and the planned
+    outputs (the first-step force scales) are all-gathered: [n, ...] on every rank (configs 4 and 5)."""
+    n = x0.shape[0]
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    s, e = shard_bounds(n, world)[rank]
+    local = solve_local({k: v[s:e] for k, v in prob.items()}, x0[s:e])
+    return all_gather_outputs(local, n, group)
+
+
 class ShardedLinearMpcZmp:
     """The C-ABI's own multi-GPU path (include/ccc_amd.h "One node, several GPUs", csrc/sharded.hip) for a host that is
     ONE process -- what a C++ controller linking libccc_amd.so gets: contiguous shards over a device list, one

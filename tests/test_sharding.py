@@ -69,3 +69,58 @@ def test_two_rank_gloo_shard_and_gather(n):
     for rank, err, shape in res:
         assert shape == (n, 2)
         assert err == 0.0
+
+
+def _worker_problem(rank, world, port, n, cls, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from centroidalcontrolcollection_amd import fixtures_ddp as fd
+        from oracle import oracle
+
+        if cls == "xy":
+            prob, x0 = fd.make_xy_batch(n, 20, 0.1, seed=77)
+            o = oracle.LinearMpcXY(100.0, 0.1, 20)
+            solve = lambda p, x: o.plan_batch(p, x)["u0"]  # noqa: E731
+            width = 16
+        else:
+            srb = cls == "srb"
+            N = 20
+            prob, x0 = fd.make_centroidal_batch(n, N, 0.03, seed=77, srb=srb)
+            o = oracle.Ddp(1 if srb else 0, 100.0, 0.03, N, fd.srb_weights() if srb else fd.centroidal_weights(), max_iter=4, arith=1)
+            solve = lambda p, x: o.plan_batch(p, x)["u"][:, 0]  # noqa: E731  (the first-step force scales: what is gathered)
+            width = 16
+
+        def solve_local(p, x):
+            if x.shape[0] == 0:
+                return torch.empty((0, width), dtype=torch.float64)
+            return torch.from_numpy(np.ascontiguousarray(solve({k: v.numpy() for k, v in p.items()}, x.numpy())))
+
+        tp = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in prob.items()}
+        got = sharding.plan_sharded_problem(solve_local, tp, torch.from_numpy(x0))
+        full = solve(prob, x0)
+        q.put((rank, float(np.abs(got.numpy() - full).max()), tuple(got.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cls", ["xy", "ddp", "srb"])
+@pytest.mark.parametrize("n", [64, 37])
+def test_two_rank_gloo_shard_and_gather_of_the_force_scale_planners(cls, n):
+    """the shard paths of configs 4 and 5 (LinearMpcXY, the DDP planners) at world size 2, even (64) and
+    ragged (37) shards: contiguous shards of every per-instance array, a local solve (the CPU oracle standing in for the
+    GPU kernel), ONE all-gather of the first-step force scales -- the full batch's answers on every rank, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_problem, args=(r, 2, port, n, cls, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, shape in res:
+        assert shape == (n, 16)
+        assert err == 0.0
