@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
 // horizon, the more: a violation a few LIPM time constants ahead is absorbed by a handful of active rows, one that is
 // imminent drags its whole neighbourhood onto the bounds.  key = sum_i exp(-t_i / tau) [row i violated], tau = 2.35 sqrt(h / g)
 // (0.75 s at h = 1 m), t_i = i dt: measured on the bench workload (numpy, counts of the kernel itself), the two QPs of a
-// wavefront then spend 1.14 x their own trips in lock-step (the x and y axes of an instance: 1.39, the plain count of
+// wavefront then spend 1.18 x their own trips in lock-step (the x and y axes of an instance: 1.39, the plain count of
 // violated rows: 1.23, the last call's counts of a repeated batch: 1.00).  One pass over the inputs (HBM-bound, 71 MB at
 // the headline), lane = row as in K1.  A schedule only: the answers do not depend on it.
 // ---------------------------------------------------------------------------------------------

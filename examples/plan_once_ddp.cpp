@@ -52,7 +52,7 @@ int main()
       std::printf("centroidal_warm iter=%d replaced=%d u0[0]=%.17g\n", ddp.ddp_solver_->traceDataList().back().iter,
                   (int)ddp.ddp_solver_->traceDataList().back().warm_start_replaced, u[0]);
       // a warm start that rolls out worse than zero inputs (3 x the plan): the warm-start guard (on by default, NOT a
-      // nmpc_ddp option) replaces it and says so; with the guard off the reference's semantics -- u_list handed to
+      // nmpc_ddp option) replaces it and says so; with the guard off the recalled nmpc_ddp semantics -- u_list handed to
       // solve() as is, src/DdpCentroidal.cpp:229-233 -- apply
       for(auto & ui : ip.u_list)
         for(int r = 0; r < ui.size(); r++) ui[r] = 3.0 * ui[r];

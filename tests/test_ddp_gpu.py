@@ -342,7 +342,7 @@ def test_warm_start_and_limits():
 
 
 @pytest.mark.parametrize("srb", [False, True])
-def test_warm_start_guard_is_reported_and_guard_off_is_the_reference_semantics(srb):
+def test_warm_start_guard_is_reported_and_guard_off_is_the_recalled_nmpc_ddp_semantics(srb):
     """VERDICT r4 item 1.  Warm starts that roll out worse than zero inputs (3 x the converged plan of another start; one with
     a NaN) next to good ones, 300 instances (more than nothing: the status flag has to survive the host path, and with
     CCC_DDP_SLOTS the sliced scheduler): (b) guard ON (the default) -- the status word carries
@@ -373,7 +373,7 @@ def test_warm_start_guard_is_reported_and_guard_off_is_the_reference_semantics(s
     cold = d.planOnceBatch(prob, x0 + 0.01)
     assert np.array_equal(on["u"][fired], cold["u"][fired])  # replaced = the cold solve
     assert not ddp_mod.warm_start_replaced(cold["status"]).any()
-    # (a) the reference's semantics
+    # (a) the recalled nmpc_ddp semantics
     d.ddp_solver_.config().warm_start_guard = 0
     off = d.planOnceBatch(prob, x0 + 0.01, u_init=bad, want_x=True)
     o_off = O.Ddp(int(srb), 100.0, dt, N, w, max_iter=2, arith=1, warm_start_guard=False)
@@ -573,7 +573,7 @@ def test_cpp_header_shims_match_python_mirror():
                     lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
     assert float(lines["centroidal_warm"].split("u0[0]=")[1]) == u1[0] and "replaced=0" in lines["centroidal_warm"]
     # the shims report the warm-start guard (TraceData::warm_start_replaced), and config().warm_start_guard = 0 switches
-    # to the reference's semantics
+    # to the recalled nmpc_ddp semantics
     ip.u_list = [3.0 * ui for ui in ip.u_list]
     u2 = d.planOnce(lambda t: DdpCentroidal.MotionParam(contacts(t)),
                     lambda t: DdpCentroidal.RefData(fd.reference_schedule(t)[1]), ip, 0.0)
