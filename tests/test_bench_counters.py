@@ -34,10 +34,10 @@ def test_committed_summaries_belong_to_the_tree():
     for name, keys in (("zmp_hbm_traffic.json", None), ("zmp_valu_counters.json", None)):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert d.get("kernel_hash") == build.kernel_hash("zmp"), name
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic.json")))
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")))
     for w in ("xy", "ddp", "srb", "walk", "multi"):
         assert tr[w]["kernel_hash"] == build.kernel_hash(w), w
-    assert json.load(open(os.path.join(ROOT, "profiles", "r05_ddp_valu_counters.json")))["kernel_hash"] == build.kernel_hash("ddp")
+    assert json.load(open(os.path.join(ROOT, "profiles", "r06_ddp_valu_counters.json")))["kernel_hash"] == build.kernel_hash("ddp")
 
 
 def test_counters_of_another_build_are_refused(monkeypatch):
