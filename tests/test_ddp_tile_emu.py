@@ -248,7 +248,13 @@ def test_the_two_arithmetics_are_the_same_algorithm_up_to_rounding(model, N):
     # (round 5, the single-rigid-body solves multiply by reciprocals: one of the 48 cold solves of the 12-state model now
     #  wanders off to a tumbling rollout and spends its 500 iterations there -- the chaotic cold solve of DESIGN.md 7.1, on
     #  another instance than before; the dense arithmetic has its own such instances on other seeds)
-    assert np.mean(r1["status"] >= 1) >= 0.97
+    #  -- pinned: exactly instance 4 of the 12-state batch, which spends its 500 iterations at a cost of ~19.5
+    #  against a median of ~2; its plan stays finite and inside the limits.  Every centroidal instance converges.
+    bad = np.nonzero(r1["status"] < 1)[0]
+    assert list(bad) == ([4] if model else []), bad
+    if model:
+        assert r1["iters"][4] == 500 and np.isfinite(r1["cost"][4]) and r1["cost"][4] < 25.0
+        assert np.isfinite(r1["u"][4]).all() and r1["u"][4].min() >= 0.0 and r1["u"][4].max() <= 1e6
 
 
 @pytest.mark.parametrize("model,max_iter", [(0, 4), (1, 4), (0, 200)])
