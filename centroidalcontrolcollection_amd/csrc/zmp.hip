@@ -1144,6 +1144,8 @@ struct ccc_zmp
   int64_t hist_cap = 0, hist_n = -1;     // (hist_n: the QPs of the call the counts belong to, -1 = none yet)
   int64_t diff_n = -1;                   // (... and of the call the differences belong to)
   unsigned watch = 0;
+  bool inputs_in_host = false;           // (set by the host entry while the kernels read the caller's page-locked memory in
+                                         //  place: a prediction pass would fetch the inputs over PCIe a second time)
   bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
                                          //  about the next)
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
@@ -1322,7 +1324,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   // solves/s on a default handle, 118.4 -> 133.0 M on one that keeps no history; 8192 instances: 96.7 M, 4096 (below the
   // threshold: the prediction's pass costs what it saves): 72 M
   const int64_t predict_min = h->env_predict_min >= 0 ? h->env_predict_min : 16384;
-  const bool predicted = sched_ok && h->env_predict && !ordered && LG == 32 && nqp >= predict_min;
+  const bool predicted = sched_ok && h->env_predict && !ordered && LG == 32 && nqp >= predict_min && !h->inputs_in_host;
   const bool use_queue = !h->env_static && nqp >= queue_min && !ordered && !predicted;
   h->last_kernel = use_queue ? (LG == 32 ? "zmp_plan_kernel_dyn<32,2>" : "zmp_plan_kernel_dyn")
                              : (LG == 32 ? "zmp_plan_kernel<32,2>" : "zmp_plan_kernel");
@@ -1773,6 +1775,7 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
     int64_t chunk = in_pinned ? n : 8192;
     if(h->env_host_chunk > 0) chunk = std::max<int64_t>(256, std::min<int64_t>(h->env_host_chunk, n));
     h->skip_history = chunk < n;
+    h->inputs_in_host = true;
     for(int64_t b = 0; b < n; b += chunk)
     {
       const size_t m = (size_t)std::min<int64_t>(chunk, n - b), o = (size_t)b;
@@ -1787,10 +1790,12 @@ extern "C" int ccc_zmp_plan_batch(ccc_zmp_t * h, int64_t n, const double * x0, c
       if(rc != CCC_OK)
       {
         h->skip_history = false;
+        h->inputs_in_host = false;
         return rc;
       }
     }
     h->skip_history = false;
+    h->inputs_in_host = false;
   }
   CCC_HIP_CHECK(hipStreamSynchronize(h->stream));
   if(!out_pinned)
