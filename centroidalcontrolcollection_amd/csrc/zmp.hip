@@ -127,10 +127,15 @@ __device__ __forceinline__ double row_at_group_uniform_blocks(const v16d & TS, c
 
 // K1, static pairing: QP (instance, axis) = (qp / 2, qp % 2), the two axes of an instance in the two halves of a
 // wavefront.  The steps of the iteration are the sections of csrc/zmp_k1.inc, shared with zmp_plan_kernel_dyn.
-// (three wavefronts per SIMD asked for explicitly: left alone hipcc allocates 169 VGPRs, one more than three wavefronts
-//  allow, and the kernel runs a quarter slower -- 67.7 against 84.2 M solves/s at 16384 instances)
+// (the occupancy is asked for explicitly.  Rounds 2-5: three wavefronts per SIMD -- left alone hipcc allocates 169 VGPRs, one
+//  more than three allow, and the kernel ran a quarter slower.  Round 6: FOUR, 128 VGPRs with 20 spilled dwords per lane:
+//  the trip is bound by vector issue at 0.85, and a fourth wavefront fills more of the rest than the spills cost --
+//  130.3 -> 136.0 M solves/s on rotating batches, 164.2 -> 170.5 M on a repeated one, two runs each)
+#ifndef CCC_ZMP_K1_OCC
+#  define CCC_ZMP_K1_OCC 4
+#endif
 template<int LG, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 3) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+__global__ __launch_bounds__(WAVES * 64, CCC_ZMP_K1_OCC) void zmp_plan_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                              const double * __restrict__ zlim, double control_dt,
                                                              double * __restrict__ zmp, double * __restrict__ jerk,
                                                              int * __restrict__ status)

@@ -16,7 +16,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # kernel (demangled prefix) -> (unit, max VGPRs, min waves/SIMD, max scratch bytes/lane, max LDS bytes or None)
 EXPECT = {
-    "void ccc_amd::zmp_plan_kernel<32, 2>": ("zmp", 168, 3, 0, None),          # K1, static pairing (headline, small batches)
+    # K1, static pairing (the headline's kernel since round 6: every schedule runs on it).  Round 6: four wavefronts per
+    # SIMD at 128 VGPRs and 80 B of scratch, measured 4 % faster than three at 160 and none (csrc/zmp.hip)
+    "void ccc_amd::zmp_plan_kernel<32, 2>": ("zmp", 128, 4, 80, None),
     "void ccc_amd::zmp_plan_kernel_dyn<32, 2>": ("zmp", 168, 3, 0, None),      # K1, work queue (headline)
     "void ccc_amd::zmp_plan_sym_kernel<40, 4, 2>": ("zmp", 128, 4, 0, None),   # K2 at 40 rows: 16 workgroups per CU
     "void ccc_amd::zmp_plan_sym_kernel<104, 4, 2>": ("zmp", 168, 3, 0, None),  # K2 at the reference test's horizon
