@@ -413,6 +413,44 @@ def test_predicted_schedule_gives_the_same_answers(monkeypatch):
     assert paired < 1.2 < 1.3 < as_is, (paired, as_is)
 
 
+@pytest.mark.parametrize("N,n", [(24, 9001), (13, 16385), (32, 8192)])
+def test_predicted_schedule_at_shorter_horizons_and_odd_sizes(N, n, monkeypatch):
+    """The prediction pass and the ordered static kernel on horizons below 32 rows (idle lanes in every group), on an odd
+    number of instances and exactly at the threshold (16384 QPs): planned ZMP, jerk and pivot counts bit for bit those of a
+    handle without any ordering, and within the parity tolerance of the oracle."""
+    dt = 2.0 / N
+    b = fx.make_zmp_batch(n, N, dt, seed=90 + N)
+    monkeypatch.setenv("CCC_ZMP_PREDICT", "0")
+    monkeypatch.setenv("CCC_ZMP_HISTORY", "0")
+    plain = LinearMpcZmp(1.0, 2.0, dt)
+    monkeypatch.delenv("CCC_ZMP_PREDICT")
+    monkeypatch.delenv("CCC_ZMP_HISTORY")
+    monkeypatch.setenv("CCC_ZMP_HOST_CHUNK", "1000000")  # (one launch for the whole batch through the host entry)
+    monkeypatch.setenv("CCC_ZMP_PREDICT_MIN", "1")
+    pred = LinearMpcZmp(1.0, 2.0, dt)
+    assert pred.horizon_steps_ == N
+    import torch
+
+    dev = torch.device("cuda:0")
+    x0, zl = torch.from_numpy(b["x0"]).to(dev), torch.from_numpy(b["zlim"]).to(dev)
+
+    def run(m):
+        z = torch.empty((n, 2), dtype=torch.float64, device=dev)
+        j = torch.empty((n, 2, N), dtype=torch.float64, device=dev)
+        st = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        m.plan_batch_device(x0, zl, 0.005, z, j, st)
+        torch.cuda.synchronize()
+        return z.cpu().numpy(), j.cpu().numpy(), st.cpu().numpy()
+
+    ref, got = run(plain), run(pred)
+    assert plain.last_schedule() == "none" and pred.last_schedule() == "predicted pivot counts"
+    for a, r in zip(got, ref):
+        assert np.array_equal(a, r)
+    assert np.all((got[2] & 0xff) == 0)
+    o = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"][:2048], b["zlim"][:2048], 0.005, nthreads=8)
+    assert np.abs(got[0][:2048] - o["zmp"]).max() <= ZMP_TOL
+
+
 def test_history_schedule_gives_the_same_answers_whatever_the_caller_repeats(monkeypatch):
     """Round 5: a handle keeps the pivot counts of its last call and runs a call of the same size longest-first, the two QPs
     of a wavefront neighbours in that order (csrc/zmp.hip launch, zmp_order_kernel).  The order is a schedule, never an
