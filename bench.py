@@ -82,6 +82,70 @@ def valu_counters(n, kernel=None):
     return None
 
 
+def parse_counter_csv(path, kernel):
+    """rocprofv3 `*_counter_collection.csv` -> ({counter: average value per dispatch}, average dispatch duration in ns,
+    dispatches) over the dispatches of `kernel` (names compared without spaces, as the library / rocprofv3 spell them)."""
+    import collections
+    import csv
+
+    want = kernel.replace(" ", "")
+    acc, dur = collections.defaultdict(dict), {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if want not in r["Kernel_Name"].replace(" ", ""):
+                continue
+            d = r["Dispatch_Id"]
+            acc[r["Counter_Name"]][d] = acc[r["Counter_Name"]].get(d, 0.0) + float(r["Counter_Value"])
+            dur[d] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    if not dur:
+        return {}, None, 0
+    return {k: sum(v.values()) / len(v) for k, v in acc.items()}, sum(dur.values()) / len(dur), len(dur)
+
+
+def live_counters(batch, kernel):
+    """the counters of the headline kernel measured IN THIS RUN.  A counter needs rocprofv3 around the
+    process, so rank 0 runs this script again three times under `rocprofv3 --pmc ...` (each --pmc pass in its own run, no
+    trace domain beside it: the guide's HBM recipe) as `--inner`: 2 rotating batches of the same size, ~130 launches of
+    the same kernel (100 of them the clock ramp), nothing else.  Returns (dict | None, source string)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--batch", str(batch), "--steps", "20", "--warmup", "5",
+             "--ramp-steps", "100", "--ring", "2", "--no-cpu-baseline", "--no-host-p50", "--no-history-leg", "--no-secondary"]
+    got, n_disp = {}, 0
+    t_begin = time.perf_counter()
+    for pmc in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]):
+        d = tempfile.mkdtemp(prefix="ccc_live_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc"] + pmc + ["--output-format", "csv", "-d", d, "-o", "live", "--"] + inner, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), timeout=600, check=True, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(d, "**", "live_counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 wrote no counter file for %s" % pmc
+            c, dur, nd = parse_counter_csv(files[0], kernel)
+            if not nd:
+                return None, "no dispatch of %s in the %s pass" % (kernel, pmc[0])
+            got.update(c)
+            n_disp = nd
+            if "SQ_INSTS_VALU" in c:
+                got["dispatch_ns"] = dur
+        except Exception as e:  # noqa: BLE001 -- a profiler that is missing or refuses must not fail the bench line
+            return None, "live counter pass %s failed: %s" % (pmc[0], e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    got["dispatches"] = n_disp
+    got["seconds"] = time.perf_counter() - t_begin
+    return got, ("measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_INSTS_* around `bench.py --inner` (three "
+                 "separate passes, %d dispatches of %s each on 2 rotating batches of %d); traffic = FETCH_SIZE x 2 + WRITE_SIZE "
+                 "KiB (MI355X_MICROARCH.md: gfx950 tallies 128-B requests at 64 B)" % (n_disp, kernel, batch))
+
+
 def host_cores():
     """(hardware threads, physical cores) of this host."""
     threads = os.cpu_count() or 1
@@ -202,6 +266,10 @@ def main():
                          "HBM): step k solves batch k mod RING, so no call sees its own past -- the library orders a call by "
                          "the pivot counts of the handle's LAST call of that size, and a repeated batch would be its best "
                          "case (VERDICT r5 weak #2); the repeated-batch rate is reported as history.value_repeated")
+    ap.add_argument("--inner", action="store_true", help="(internal) the short run rank 0 starts under rocprofv3 for the live counters")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not run the three rocprofv3 --pmc passes of the headline kernel (about 40 s); the line then "
+                         "replays the counters of profiles/ when they belong to this build")
     ap.add_argument("--no-history-leg", action="store_true",
                     help="skip the second measurement on a handle without a history (profiling runs: one kind of launch)")
     ap.add_argument("--no-secondary", action="store_true",
@@ -467,6 +535,16 @@ def main():
         tflops = pivots_per_solve * FLOP_PER_PIVOT * n / kavg / 1e12
         vc = valu_counters(n, timed_kernel)
         traffic, traffic_src = measured_traffic(n, timed_kernel)
+        live = None
+        if world == 1 and not args.inner and not args.no_live_counters:
+            live, live_src = live_counters(n, timed_kernel)
+            if live is not None:
+                traffic = live["FETCH_SIZE"] * 1024 * 2 + live["WRITE_SIZE"] * 1024
+                traffic_src = live_src
+                vc = {"valu_insts_per_solve": live["SQ_INSTS_VALU"] / n,
+                      "valu_issue_frac": live["SQ_INSTS_VALU"] * 4.0 / (1024.0 * live["dispatch_ns"] * 2.4)}
+            else:
+                traffic_src = "%s; live collection: %s" % (traffic_src, live_src)
         out = {
             "metric": "LinearMpcZmp planOnce() solves/sec (N=32, fp64, inputs resident in HBM)",
             "value": value,
@@ -524,6 +602,11 @@ def main():
             "pivots_per_solve": pivots_per_solve,
             "unsolved": n_bad,
         }
+        if live is not None:
+            out["roofline"]["live_counters"] = {k: live[k] for k in sorted(live)}
+            out["roofline"]["live_counters"]["what"] = (
+                "per dispatch of the headline kernel, averaged over the dispatches of the inner runs; dispatch_ns = the "
+                "kernel's duration under counter collection (SQ pass), the clock issue_frac is computed with")
         if no_hist is not None:
             out["history"] = no_hist
         out["distributed"] = dinfo

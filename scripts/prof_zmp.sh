@@ -7,7 +7,7 @@ TAG=${1:-r01}
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
 # --no-host-p50: the p50 loops launch the same kernel on pinned HOST memory (PCIe-bound, 1.3 ms); left in, they are
 # averaged into the kernel's --stats line, which is meant to be compared with bench.py's device-resident kernel_ms
-B="python bench.py --no-cpu-baseline --no-host-p50 --no-secondary --no-history-leg"
+B="python bench.py --no-cpu-baseline --no-host-p50 --no-secondary --no-history-leg --no-live-counters"
 for d in trace pmc_sq1 pmc_sq2 pmc_fetch pmc_write; do mkdir -p gpurun_out/${TAG}_$d; done
 # what the profiled library was built from (bench lines replay counters only for the same kernel sources)
 python -m centroidalcontrolcollection_amd.build --kernel-hashes 2>/dev/null | tail -1 > gpurun_out/${TAG}_kernel_hashes.json

@@ -61,3 +61,27 @@ def test_counters_of_another_build_are_refused(monkeypatch):
     assert bench.valu_counters(65536) is None
     v = bench_secondary._ddp_valu(9, 16, 100, 16.8, False)
     assert v["simd_valu_busy_frac"] is None and "refused" in v["counters_source"]
+
+
+def test_live_counter_csv_is_read_per_dispatch_of_the_timed_kernel(tmp_path):
+    """bench.py collects the headline kernel's counters in its own run (rocprofv3 --pmc around `bench.py --inner`): the CSV
+    reader takes the dispatches of the timed kernel only, sums a counter's rows of one dispatch (one per XCD when rocprofv3
+    splits them) and averages over the dispatches."""
+    pytest.importorskip("torch")
+    import bench
+
+    hdr = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+           '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name",'
+           '"Counter_Value","Start_Timestamp","End_Timestamp"')
+    k = '"void ccc_amd::zmp_plan_kernel<32, 2>(ccc_amd::ZmpDev, long, double const*, double const*, double, double*, double*, int*)"'
+    rows = [hdr,
+            '1,1,"Agent 2",1,7,7,512,8,"__amd_rocclr_copyBuffer",512,0,0,8,0,32,"FETCH_SIZE",6.5,100,200',
+            '2,2,"Agent 2",1,7,7,512,9,%s,128,9856,80,128,0,96,"FETCH_SIZE",1000.0,1000,1500' % k,
+            '2,2,"Agent 2",1,7,7,512,9,%s,128,9856,80,128,0,96,"FETCH_SIZE",500.0,1000,1500' % k,
+            '3,3,"Agent 2",1,7,7,512,9,%s,128,9856,80,128,0,96,"FETCH_SIZE",2500.0,2000,2700' % k,
+            '4,4,"Agent 2",1,7,7,512,10,"void ccc_amd::zmp_plan_kernel_dyn<32, 2>(ccc_amd::ZmpDev)",128,0,0,8,0,32,"FETCH_SIZE",9e9,1,2']
+    f = tmp_path / "live_counter_collection.csv"
+    f.write_text("\n".join(rows) + "\n")
+    c, dur, nd = bench.parse_counter_csv(str(f), "zmp_plan_kernel<32,2>")
+    assert nd == 2 and c == {"FETCH_SIZE": (1500.0 + 2500.0) / 2} and dur == (500.0 + 700.0) / 2
+    assert bench.parse_counter_csv(str(f), "no_such_kernel") == ({}, None, 0)
