@@ -102,6 +102,45 @@ def parse_counter_csv(path, kernel):
     return {k: sum(v.values()) / len(v) for k, v in acc.items()}, sum(dur.values()) / len(dur), len(dur)
 
 
+def pmc_passes(inner, passes, env=None):
+    """Run `inner` (a command list) once per entry of `passes` (lists of counter names) under `rocprofv3 --pmc ...`, each
+    pass its own run with no trace domain beside it.  Returns ({counter: {kernel name: [sum over its dispatches, dispatches,
+    sum of their durations in ns]}}, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    for pmc in passes:
+        d = tempfile.mkdtemp(prefix="ccc_live_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--pmc"] + pmc + ["--output-format", "csv", "-d", d, "-o", "live", "--"] + inner, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp", **(env or {})), timeout=900, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(d, "**", "live_counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 wrote no counter file for %s" % pmc
+            per = collections.defaultdict(lambda: collections.defaultdict(dict))
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    k = per[r["Counter_Name"]][r["Kernel_Name"].split("(")[0]]
+                    e = k.setdefault(r["Dispatch_Id"], [0.0, float(r["End_Timestamp"]) - float(r["Start_Timestamp"])])
+                    e[0] += float(r["Counter_Value"])
+            for c, kernels in per.items():
+                out[c] = {kn: [sum(v[0] for v in dd.values()), len(dd), sum(v[1] for v in dd.values())] for kn, dd in kernels.items()}
+        except Exception as e:  # noqa: BLE001 -- a profiler that is missing or refuses must not fail the bench line
+            return None, "live counter pass %s failed: %s" % (pmc[0], e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, None
+
+
 def live_counters(batch, kernel):
     """the counters of the headline kernel measured IN THIS RUN.  A counter needs rocprofv3 around the
     process, so rank 0 runs this script again three times under `rocprofv3 --pmc ...` (each --pmc pass in its own run, no
@@ -627,7 +666,8 @@ def main():
         secondary = []
         for wl, (k_steps, k_warm) in (("xy", (20, 2)), ("ddp", (20, 2)), ("srb", (20, 2))):
             secondary.append(bench_secondary.measure(wl, bench_secondary.DEFAULT_BATCH[wl], k_steps, k_warm, rank, world,
-                                                     local_rank, dist, cpu=not args.no_cpu_baseline, dinfo=None))
+                                                     local_rank, dist, cpu=not args.no_cpu_baseline, dinfo=None,
+                                                     live=not args.no_live_counters and not args.inner))
             torch.cuda.empty_cache()
     if rank == 0:
         if secondary is not None:

@@ -5,6 +5,7 @@ over one batch of synthetic instances already resident in HBM; weak scaling (eve
 Part of bench.py: the `cpu` callbacks below are its cpu_baseline leg (the only place here that touches oracle/)."""
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -12,7 +13,7 @@ import torch
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
-RING = 8  # distinct batches the timed steps of the scheduled workloads (xy, ddp, srb, walk, multi) rotate through: no call
+RING = int(os.environ.get("CCC_BENCH_RING", "8"))  # distinct batches the timed steps of the scheduled workloads (xy, ddp, srb, walk, multi) rotate through: no call
 #           sees its own past (the handles order a call by what their LAST call of that size measured)
 
 
@@ -418,12 +419,49 @@ def run(args, rank, world, local_rank, dist):
     steps, warmup = (args.steps, args.warmup) if args.steps_given else DEFAULT_STEPS[args.workload]
     out = measure(args.workload, n, steps, warmup, rank, world, local_rank, dist, strong=strong,
                   cpu=not args.no_cpu_baseline, dinfo=getattr(args, "distributed_info", None),
-                  history_leg=not getattr(args, "no_history_leg", False))
+                  history_leg=not getattr(args, "no_history_leg", False),
+                  live=not getattr(args, "no_live_counters", False) and not getattr(args, "inner", False))
     if out is not None:
         print(json.dumps(out))
 
 
-def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=False, cpu=True, dinfo=None, history_leg=True):
+def live_secondary(workload, n, kernel):
+    """The counters of a secondary workload measured in this run: `bench.py --workload W --inner` (one
+    batch, 1 + 3 + 1 calls) under `rocprofv3 --pmc`, FETCH_SIZE and WRITE_SIZE passes and, for the DDP kernels, an SQ pass.
+    HBM bytes per step = (FETCH_SIZE x 2 + WRITE_SIZE) KiB summed over EVERY dispatch of the library's kernels in the run /
+    its calls.  Returns (dict | None, source)."""
+    import bench
+
+    calls = 1 + 3 + 1  # warm-up, timed steps, the closing call that leaves ring entry 0's answers
+    here = os.path.dirname(os.path.abspath(__file__))
+    inner = [sys.executable, os.path.join(here, "bench.py"), "--workload", workload, "--inner", "--batch", str(n), "--steps", "3",
+             "--warmup", "1", "--no-cpu-baseline", "--no-history-leg"]
+    passes = [["FETCH_SIZE"], ["WRITE_SIZE"]]
+    ddp = "ddp_tile" in kernel
+    if ddp:
+        passes.append(["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY"])
+    t0 = time.perf_counter()
+    got, why = bench.pmc_passes(inner, passes, env={"CCC_BENCH_RING": "1"})
+    if got is None:
+        return None, why
+    mine = lambda kn: "ccc_amd::" in kn  # noqa: E731  (not the runtime's copy / fill kernels)
+    tot = {c: sum(v[0] for kn, v in got.get(c, {}).items() if mine(kn)) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    res = {"hbm_bytes_per_step": (tot["FETCH_SIZE"] * 2 + tot["WRITE_SIZE"]) * 1024 / calls, "calls": calls,
+           "seconds": time.perf_counter() - t0}
+    if ddp:
+        want = kernel.replace(" ", "")
+        sq = {c: [v for kn, v in got.get(c, {}).items() if want in kn.replace(" ", "")] for c in passes[2]}
+        if all(len(v) == 1 for v in sq.values()):
+            a = {c: v[0][0] / v[0][1] for c, v in sq.items()}  # per dispatch
+            res.update(simd_valu_busy_frac=a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"] * a["SQ_WAVES"] / 1024.0,
+                       wait_frac=a["SQ_WAIT_ANY"] / a["SQ_WAVE_CYCLES"], valu_insts_per_instance=a["SQ_INSTS_VALU"] / n)
+    return res, ("measured in this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE%s around `bench.py --workload %s --inner` "
+                 "(separate passes, %d calls of one batch of %d); bytes = (FETCH_SIZE x 2 + WRITE_SIZE) KiB over every dispatch of "
+                 "the library's kernels / calls" % (" | SQ_*" if ddp else "", workload, calls, n))
+
+
+def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=False, cpu=True, dinfo=None, history_leg=True,
+            live=False):
     """One bench line (a dict; None on ranks other than 0) of a secondary workload: `warmup` untimed steps, `steps` timed
     ones bracketed by barrier + synchronize, max over ranks.  Also what bench.py's default command appends to the headline
     line as `secondary` (configs 3, 4, 5: VERDICT r4 item 2)."""
@@ -480,6 +518,13 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
     # measured HBM bytes per step of THIS workload at THIS batch, replayed from the newest PMC summary made from the same
     # kernel sources (replayed_counters above); null otherwise
     traffic, traffic_src = replayed_counters(workload, n)
+    live_res = None
+    if live and world == 1 and workload in ("xy", "ddp", "srb"):
+        live_res, live_src = live_secondary(workload, n, w["kernel"])
+        if live_res is not None:
+            traffic, traffic_src = live_res["hbm_bytes_per_step"], live_src
+        else:
+            traffic_src = "%s; live collection: %s" % (traffic_src, live_src)
     out = {"metric": w["name"], "value": world * n * steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "p50_ms": float(np.median(kern_ms)),
            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": w.get("dtype", "f64"), "data": "synthetic",
@@ -515,6 +560,9 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
         # steps the run executed, against the vector-fp64 peak; the issue share from the PMC pass in profiles/)
         v = w["valu"](out["mean_iterations"])
         out["roofline"]["bound"] = "valu"
+        if live_res is not None and "simd_valu_busy_frac" in live_res:  # (this run's SQ pass instead of the replayed summary)
+            v = dict(v, simd_valu_busy_frac=live_res["simd_valu_busy_frac"], wait_frac=live_res["wait_frac"],
+                     valu_insts_per_instance=live_res["valu_insts_per_instance"], counters_source=live_src)
         out["roofline"]["valu"] = dict(achieved=v["simd_valu_busy_frac"], peak=1.0, unit="share of SIMD VALU cycles busy",
                                        frac=v["simd_valu_busy_frac"],
                                        dense_equivalent_tflops=v["dense_equivalent_flop_per_solve"] * n / kavg / 1e12, **v)

@@ -9,6 +9,6 @@ bash scripts/prof_zmp.sh $TAG > gpurun_out/${TAG}_prof_zmp.log 2>&1
 export HBM=1
 bash scripts/prof_kernel.sh $TAG ddp python scripts/ddp_bench.py 4096 2 cen
 bash scripts/prof_kernel.sh $TAG srb python scripts/ddp_bench.py 32768 2 srb
-bash scripts/prof_kernel.sh $TAG walk python bench.py --workload walk --no-cpu-baseline --no-history-leg --steps 2 --warmup 1
-bash scripts/prof_kernel.sh $TAG multi python bench.py --workload multi --no-cpu-baseline --no-history-leg --steps 2 --warmup 1
-bash scripts/prof_kernel.sh $TAG xy python bench.py --workload xy --no-cpu-baseline --no-history-leg --steps 5 --warmup 1
+bash scripts/prof_kernel.sh $TAG walk python bench.py --workload walk --no-cpu-baseline --no-history-leg --no-live-counters --steps 2 --warmup 1
+bash scripts/prof_kernel.sh $TAG multi python bench.py --workload multi --no-cpu-baseline --no-history-leg --no-live-counters --steps 2 --warmup 1
+bash scripts/prof_kernel.sh $TAG xy python bench.py --workload xy --no-cpu-baseline --no-history-leg --no-live-counters --steps 5 --warmup 1

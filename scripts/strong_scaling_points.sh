@@ -4,6 +4,6 @@
 # usage (through gpurun, from the repo root): bash scripts/strong_scaling_points.sh > gpurun_out/strong_points.jsonl
 # (4096 = BASELINE config 2 as quoted: one GPU)
 for b in 4096 8192 16384 32768 65536; do python bench.py --batch $b --steps 50 --warmup 10 --no-cpu-baseline --no-live-counters 2>/dev/null | tail -1; done
-python bench.py --workload xy --batch 8192 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1
-python bench.py --workload srb --batch 4096 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
-python bench.py --workload ddp --batch 512 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1
+python bench.py --workload xy --batch 8192 --steps 10 --warmup 3 --no-cpu-baseline --no-live-counters 2>/dev/null | tail -1
+python bench.py --workload srb --batch 4096 --steps 5 --warmup 2 --no-cpu-baseline --no-live-counters 2>/dev/null | tail -1
+python bench.py --workload ddp --batch 512 --steps 5 --warmup 2 --no-cpu-baseline --no-live-counters 2>/dev/null | tail -1
