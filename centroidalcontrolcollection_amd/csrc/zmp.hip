@@ -1280,13 +1280,16 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
     //  write them -- ADVICE r5: freed, that was silent corruption; they go with the handle)
     for(int * q : {h->hist, h->order, h->diff, h->pred})
       if(q) h->retired.push_back(q);
+    // (capacity grows by at least half, so that a caller whose batches creep upwards retires a geometric series of
+    //  buffers -- at most twice the final size in all -- not one set per call)
+    const int64_t cap = std::max<int64_t>(nqp, h->hist_cap + h->hist_cap / 2);
     h->hist = h->order = h->diff = h->pred = nullptr;
     h->hist_cap = 0;
     h->hist_n = -1;
-    CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)nqp * sizeof(int)));
-    CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)nqp * sizeof(int)));
-    CCC_HIP_CHECK(hipMalloc(&h->diff, (size_t)nqp * sizeof(int)));
-    CCC_HIP_CHECK(hipMalloc(&h->pred, (size_t)nqp * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->hist, (size_t)cap * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->order, (size_t)cap * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->diff, (size_t)cap * sizeof(int)));
+    CCC_HIP_CHECK(hipMalloc(&h->pred, (size_t)cap * sizeof(int)));
     if(!h->order_scratch) CCC_HIP_CHECK(hipMalloc(&h->order_scratch, (size_t)kOrderScratchInts * sizeof(int)));
     if(!h->trust_host)
     {
@@ -1294,7 +1297,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
       *h->trust_host = 1;
       CCC_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->trust_dev), h->trust_host, 0));
     }
-    h->hist_cap = nqp;
+    h->hist_cap = cap;
   }
   if(sched_ok && h->env_history)
   {
