@@ -4,7 +4,12 @@ Tolerance.  The QP Hessian H = B'WB + 1e-5 I has condition number 1e6..1e7 (thin
 tracking term), so two exact solvers agree only to about cond * eps: even an exact KKT solve on the oracle's own
 active set moves its force scales by 5e-10 relative.  The planned force scales are therefore compared to 1e-7 relative
 to the largest force scale of the instance, the total wrench of the first step (what the reference's control loop
-consumes) to 1e-8 relative to the robot's weight, and the vertical force -- an equality constraint -- to 1e-10."""
+consumes) to 5e-9 relative to the robot's weight, and the vertical force -- an equality constraint -- to 1e-10.
+
+Measured (profiles/r06_xy_parity_measured.json, the largest value over the 84 cases of this module; written by running
+it with CCC_TEST_REPORT=<file>): force scales 7.5e-8 (head) / 7.0e-8 (whole horizon) against the ORACLE -- the same
+kernels sit 2.2e-9 from the long-double golden vectors, so most of that distance is the oracle's own -- total force
+1.1e-9, total moment 1.7e-9, 40-step horizons 2.2e-6 (bound 5e-6: the oracle's accuracy there, see the test)."""
 import numpy as np
 import pytest
 
@@ -26,8 +31,31 @@ def _xy_path(request, monkeypatch):
     yield
 
 LAM_RTOL = 1e-7
+_MEASURED = {}
+
+
+def _within(value, tol, what):
+    """assert value <= tol, and remember the largest value seen per tolerance (written at module teardown when
+    CCC_TEST_REPORT names a file: how the tolerances of this header were sized)."""
+    value = float(value)
+    _MEASURED[what] = max(_MEASURED.get(what, 0.0), value)
+    assert value <= tol, (what, value, tol)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report_measured():
+    yield
+    import json
+    import os
+
+    path = os.environ.get("CCC_TEST_REPORT")
+    if path:
+        with open(path, "w") as f:
+            json.dump(_MEASURED, f, indent=1, sort_keys=True)
+
+
 WIDE_GOLDEN_RTOL = 1e-7  # measured: 2.2e-9 (30 steps x 32 ridges), 2.7e-8 (40 steps); the oracle reaches 1.2e-6 there
-WRENCH_RTOL = 1e-8
+WRENCH_RTOL = 5e-9
 
 
 def _oracle():
@@ -39,14 +67,14 @@ def _oracle():
 def _compare(prob, r, o, N):
     assert np.all(r["status"] == 0) and np.all(o["status"] == 0)
     scale = np.abs(o["u0"]).max(axis=1, keepdims=True) + 1.0
-    assert (np.abs(r["u0"] - o["u0"]) / scale).max() <= LAM_RTOL
+    _within((np.abs(r["u0"] - o["u0"]) / scale).max(), LAM_RTOL, "u0")
     # total force / moment (about the origin) of the planned first-step forces
     for k in range(len(scale)):
         m0 = prob["dim"][k, 0]
         mg, fg = fd.total_wrench(prob["vertex"][k, 0], prob["ridge"][k, 0], r["u0"][k, :m0], np.zeros(3))
         mo, fo = fd.total_wrench(prob["vertex"][k, 0], prob["ridge"][k, 0], o["u0"][k, :m0], np.zeros(3))
-        assert np.abs(fg - fo).max() <= WRENCH_RTOL * (1.0 + np.abs(fo).max())
-        assert np.abs(mg - mo).max() <= WRENCH_RTOL * (1.0 + np.abs(fo).max())
+        _within(np.abs(fg - fo).max() / (1.0 + np.abs(fo).max()), WRENCH_RTOL, "force")
+        _within(np.abs(mg - mo).max() / (1.0 + np.abs(fo).max()), WRENCH_RTOL, "moment")
         assert abs(fg[2] - prob["total_force_z"][k, 0]) <= 1e-10 * prob["total_force_z"][k, 0]
 
 
@@ -85,7 +113,7 @@ def test_parity_with_oracle(N, dt):
     for k in range(96):
         lam_o = o["lam"][k, :dims[k].sum()]
         lam_g = np.concatenate([r["lam"][k, i, :dims[k, i]] for i in range(N)])
-        assert np.abs(lam_g - lam_o).max() <= LAM_RTOL * (1.0 + np.abs(lam_o).max())
+        _within(np.abs(lam_g - lam_o).max() / (1.0 + np.abs(lam_o).max()), LAM_RTOL, "lam")
 
 
 def test_active_bounds_and_friction_limits():
@@ -158,7 +186,7 @@ def test_random_contact_dimensions_and_weights():
     for k in sel:
         lam_o = o["lam"][k, :prob["dim"][k].sum()]
         lam_g = np.concatenate([r["lam"][k, i, :prob["dim"][k, i]] for i in range(N)])
-        assert np.abs(lam_g - lam_o).max() <= LAM_RTOL * (1.0 + np.abs(lam_o).max())
+        _within(np.abs(lam_g - lam_o).max() / (1.0 + np.abs(lam_o).max()), LAM_RTOL, "lam")
         assert np.all(r["lam"][k][prob["dim"][k][:, None] <= np.arange(16)[None, :]] == 0.0)
 
 
@@ -402,7 +430,7 @@ def test_double_support_and_long_horizons_against_the_oracle(N, M, n):
     for k in range(n):
         lam = np.concatenate([r["lam"][k, i, :prob["dim"][k, i]] for i in range(N)])
         ref = o["lam"][k][:len(lam)]
-        assert np.abs(lam - ref).max() <= 5e-6 * (1.0 + np.abs(ref).max())
+        _within(np.abs(lam - ref).max() / (1.0 + np.abs(ref).max()), 5e-6, "lam_long_horizon")
         assert lam.min() >= 3.0 - 1e-9 and lam.max() <= 3.0 * 100.0 * 9.80665 + 1e-6
 
 
@@ -439,7 +467,7 @@ def test_safeguard_rounds_take_the_instances_that_cycle(monkeypatch):
     _compare(prob, starved, o, 20)
     assert np.all(starved["status"] == 0) and starved["pivots"].mean() > full["pivots"].mean()
     scale = 1.0 + np.abs(full["lam"]).max(axis=(1, 2), keepdims=True)
-    assert (np.abs(starved["lam"] - full["lam"]) / scale).max() <= LAM_RTOL
+    _within((np.abs(starved["lam"] - full["lam"]) / scale).max(), LAM_RTOL, "lam_starved_vs_full")
 
 
 def test_more_than_two_contacts_per_step_64_ridge_slots():
