@@ -56,7 +56,7 @@ def source_hash():
 # the profile summaries the bench lines replay counters from, and a bench line refuses counters of another build
 KERNEL_UNITS = dict(
     # (common.hip holds the order_by_count kernels of the ordered schedules, which run inside the timed and profiled launches)
-    zmp=["zmp.hip", "zmp_k1.inc", "zmp_k2r.inc", "sym_tableau.h", "wave_group.h", "common.h", "common.hip"],
+    zmp=["zmp.hip", "zmp_k1.inc", "zmp_k2r.inc", "zmp_stage.inc", "sym_tableau.h", "wave_group.h", "common.h", "common.hip"],
     xy=["xy.hip", "wave_group.h", "common.h", "common.hip"],
     ddp=["ddp.hip", "ddp_tile.hip", "ddp_tile_body.inc", "ddp_tile.h", "ddp_batch.h", "w64.h", "common.h"],
 )

@@ -48,6 +48,10 @@ struct ZmpDev
   const int * order;
   int * hist;
   int * diff; // (when given: |trips now - trips of the last call| per QP -> order_by_count's verdict on the history)
+  // K3 (zmp_stage.inc) and the exact kernels behind it: the QPs K3 does not certify.  K3 appends to fb_list / fb_count; a
+  // block / sym / reg kernel launched with them set solves fb_list[0 .. *fb_count) instead of [0, nqp)
+  int * fb_list;
+  int * fb_count;
 };
 
 constexpr double kInf = __builtin_huge_val();
@@ -583,11 +587,11 @@ __device__ __forceinline__ void block_argmin(double v, BlockRed * red, double & 
 
 // PARTS threads per row: thread (part, i) updates its share of column i in the rank-1 update (more wavefronts in flight
 // hide the LDS latency); thread (0, i) owns row i (bounds, multiplier, flags).
-template<int NP, bool HBM, int PARTS>
-__global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
-                                                            const double * __restrict__ zlim, double control_dt,
-                                                            double * __restrict__ zmp, double * __restrict__ jerk,
-                                                            int * __restrict__ status, double * __restrict__ ws)
+template<int NP, bool HBM, int PARTS, bool LIST>
+__device__ __forceinline__ void zmp_plan_block_body(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                    const double * __restrict__ zlim, double control_dt,
+                                                    double * __restrict__ zmp, double * __restrict__ jerk,
+                                                    int * __restrict__ status, double * __restrict__ ws)
 {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int TS = HBM ? NP : NP + 1; // row stride of T; odd in LDS, so that column writes are bank-conflict free
@@ -603,8 +607,10 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
   const double bi = P.b[i];
   const int maxpass = 20 * N + 100;
 
-  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  const long ntodo = LIST ? (long)*P.fb_count : nqp;
+  for(long todo = blockIdx.x; todo < ntodo; todo += gridDim.x)
   {
+    const long qp = LIST ? (long)P.fb_list[todo] : todo;
     const bool row = lead && i < N;
     const double px = x0[qp * 3 + 0], vx = x0[qp * 3 + 1], ax = x0[qp * 3 + 2];
     double zl = 0, zh = 0;
@@ -829,13 +835,32 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
     (void)bi;
   }
 }
+
+template<int NP, bool HBM, int PARTS>
+__global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                            const double * __restrict__ zlim, double control_dt,
+                                                            double * __restrict__ zmp, double * __restrict__ jerk,
+                                                            int * __restrict__ status, double * __restrict__ ws)
+{
+  zmp_plan_block_body<NP, HBM, PARTS, false>(P, nqp, x0, zlim, control_dt, zmp, jerk, status, ws);
+}
+
+// (the QPs K3 hands over, zmp_stage.inc: P.fb_list[0 .. *P.fb_count))
+template<int NP, bool HBM, int PARTS>
+__global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_list_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
+                                                                 const double * __restrict__ zlim, double control_dt,
+                                                                 double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                 int * __restrict__ status, double * __restrict__ ws)
+{
+  zmp_plan_block_body<NP, HBM, PARTS, true>(P, nqp, x0, zlim, control_dt, zmp, jerk, status, ws);
+}
 // K2.  32 < N <= 200 (the reference test's 2 s @ 20 ms = 100 steps; BASELINE configs[0] as worded, 2 s @ 10 ms = 200):
 // one QP per workgroup, the sweep tableau PACKED (lower triangle in 4 x 4 tiles -- 2 x 2 at 200 rows --, sym_tableau.h)
 // in LDS; thread t updates the tiles t, t + NT, ..., thread i < NP owns row i (bounds, multiplier, flags).  One to
 // twelve workgroups share a CU (7 KB at 40 rows ... 160 KB at 200), one workgroup is one to sixteen wavefronts.
 // GS = row stride of P.G.
-template<int NP, int TS, int TPT>
-__global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kMinWaves)) void zmp_plan_sym_kernel(ZmpDev P, int GS, long nqp,
+template<int NP, int TS, int TPT, bool LIST>
+__device__ __forceinline__ void zmp_plan_sym_body(ZmpDev P, int GS, long nqp,
                                                                       const double * __restrict__ x0,
                                                                       const double * __restrict__ zlim, double control_dt,
                                                                       double * __restrict__ zmp, double * __restrict__ jerk,
@@ -856,8 +881,10 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
   const double a0 = lead ? P.A[i * 3 + 0] : 0.0, a1 = lead ? P.A[i * 3 + 1] : 0.0, a2 = lead ? P.A[i * 3 + 2] : 0.0;
   const int maxpass = 20 * N + 100;
 
-  for(long qp = blockIdx.x; qp < nqp; qp += gridDim.x)
+  const long ntodo = LIST ? (long)*P.fb_count : nqp;
+  for(long todo = blockIdx.x; todo < ntodo; todo += gridDim.x)
   {
+    const long qp = LIST ? (long)P.fb_list[todo] : todo;
 #ifdef CCC_ZMP_PROF
     const long long rtq = wall_clock64();
 #endif
@@ -1086,7 +1113,29 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
   }
 }
 
+template<int NP, int TS, int TPT>
+__global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kMinWaves)) void zmp_plan_sym_kernel(ZmpDev P, int GS, long nqp,
+                                                                      const double * __restrict__ x0,
+                                                                      const double * __restrict__ zlim, double control_dt,
+                                                                      double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                      int * __restrict__ status)
+{
+  zmp_plan_sym_body<NP, TS, TPT, false>(P, GS, nqp, x0, zlim, control_dt, zmp, jerk, status);
+}
+
+// (the QPs K3 hands over, zmp_stage.inc)
+template<int NP, int TS, int TPT>
+__global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kMinWaves)) void zmp_plan_sym_list_kernel(ZmpDev P, int GS, long nqp,
+                                                                      const double * __restrict__ x0,
+                                                                      const double * __restrict__ zlim, double control_dt,
+                                                                      double * __restrict__ zmp, double * __restrict__ jerk,
+                                                                      int * __restrict__ status)
+{
+  zmp_plan_sym_body<NP, TS, TPT, true>(P, GS, nqp, x0, zlim, control_dt, zmp, jerk, status);
+}
+
 #include "zmp_k2r.inc"
+#include "zmp_stage.inc"
 
 } // namespace ccc_amd
 
@@ -1154,6 +1203,11 @@ struct ccc_zmp
   bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
                                          //  about the next)
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
+  // K3 (zmp_stage.inc): per-wavefront stage records, and the list of the QPs it hands over to the exact kernel
+  double * ws_stage = nullptr;
+  int64_t ws_stage_blocks = 0;
+  int *fb_list = nullptr, *fb_count = nullptr;
+  int64_t fb_cap = 0;
   int num_cu = 0;
   // per-handle (= per-device) launch state: function attributes set, resident workgroups per CU of the queue kernel
   bool attr_set = false, attr_dyn = false;
@@ -1180,6 +1234,12 @@ struct ccc_zmp
                                 //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
                                 //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
+  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (K3), 1 = for every N > 32 and batch;
+                                //                < 0: the measured default (N > 64, from env_stage_min QPs)
+  int64_t env_stage_min = -1;   // CCC_ZMP_STAGE_MIN: QPs from which K3 runs (< 0: the measured default)
+  int env_stage_iters = 0;      // CCC_ZMP_STAGE_ITERS: K3's iteration limit before a QP is handed over (0: the default)
+  int env_stage_waves = 0;      // CCC_ZMP_STAGE_WAVES: K3's wavefronts per SIMD at most (0: the default)
+  int env_stage_pen = -1;       // CCC_ZMP_STAGE_PEN: K3's iterations on the penalised problem at most (< 0: the default)
   const char * last_kernel = "none"; // the kernel the last plan call launched (ccc_zmp_last_kernel)
   const char * last_order = "none";  // ... and what its schedule came from (CCC_ZMP_DEBUG prints it)
 };
@@ -1391,11 +1451,20 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   if(P.hist) h->hist_n = nqp;
   return CCC_OK;
 }
-int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
-                 double * jerk, int32_t * status, hipStream_t stream)
+// the exact (dual active set) kernels of N > 32.  from_list: solve the QPs K3 handed over (h->fb_list[0 .. *h->fb_count),
+// both known on the device only) with a grid sized for a few per cent of the batch; blocks beyond the count return at once
+int launch_exact(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
+                 double * jerk, int32_t * status, hipStream_t stream, bool from_list)
 {
   const int64_t nqp = 2 * n;
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  if(from_list)
+  {
+    P.fb_list = h->fb_list;
+    P.fb_count = h->fb_count;
+  }
+  const int64_t grid_qp = from_list ? std::min<int64_t>(nqp, (int64_t)h->num_cu * 12) : nqp; // (one workgroup per QP)
+  const char * const stage_name = h->last_kernel;
   h->last_kernel = h->N > 200 ? "zmp_plan_block_kernel" : "zmp_plan_sym_kernel";
   if(h->N > 200) // beyond the LDS: the tableau in HBM
   {
@@ -1407,14 +1476,21 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
       CCC_HIP_CHECK(hipMalloc(&h->ws_big, (size_t)blocks * NPb * NPb * sizeof(double)));
     }
     const size_t lds = (size_t)NPb * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
-    const int grid = (int)std::min<int64_t>(nqp, blocks);
-    if(NPb == kBigNP)
+    const int grid = (int)std::min<int64_t>(grid_qp, blocks);
+    if(NPb == kBigNP && !from_list)
       hipLaunchKernelGGL((zmp_plan_block_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P, (long)nqp,
                          x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
-    else
+    else if(NPb == kBigNP)
+      hipLaunchKernelGGL((zmp_plan_block_list_kernel<kBigNP, true, 2>), dim3(grid), dim3(kBigNP * 2), lds, stream, P,
+                         (long)nqp, x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
+    else if(!from_list)
       hipLaunchKernelGGL((zmp_plan_block_kernel<kHugeNP, true, 2>), dim3(grid), dim3(kHugeNP * 2), lds, stream, P, (long)nqp,
                          x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
+    else
+      hipLaunchKernelGGL((zmp_plan_block_list_kernel<kHugeNP, true, 2>), dim3(grid), dim3(kHugeNP * 2), lds, stream, P,
+                         (long)nqp, x0, zlim, control_dt, zmp, jerk, status, h->ws_big);
     CCC_HIP_CHECK(hipGetLastError());
+    if(from_list) h->last_kernel = stage_name;
     return CCC_OK;
   }
   // K1w: one QP per wavefront, the rows in register tuples (zmp_plan_kernel_w), 32 < N <= 64
@@ -1434,7 +1510,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     CCC_HIP_CHECK(hipGetLastError());
     return CCC_OK;
   };
-  if(h->N <= 64 && h->env_kw != 0)
+  if(h->N <= 64 && h->env_kw != 0 && !from_list)
   {
     if(h->N <= 48) return h->env_kw == 2 ? go_w(&zmp_plan_kernel_w<48, 4, 2>, 48, 4) : go_w(&zmp_plan_kernel_w<48, 4, 3>, 48, 4);
     return go_w(&zmp_plan_kernel_w<64, 4, 2>, 64, 4);
@@ -1443,7 +1519,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   auto go_reg = [&](auto kernel, auto rt) -> int {
     using RT = decltype(rt);
     const size_t lds = RT::lds_bytes();
-    const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
+    const int grid = (int)std::min<int64_t>(grid_qp, (int64_t)1 << 22);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     if(h->env_debug)
@@ -1455,7 +1531,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(RT::NT), lds, stream, P, h->NP, (long)nqp, x0, zlim, control_dt, zmp, jerk,
                        status);
-    h->last_kernel = "zmp_plan_reg_kernel";
+    h->last_kernel = from_list ? stage_name : "zmp_plan_reg_kernel";
     return CCC_OK;
   };
   // measured (round 5, batch 32768, one MI355X; solves/s K2 -> K2r with two | three tiles per thread): N = 40 29.9 -> 27.6 M
@@ -1464,12 +1540,14 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   // 2.15 | 1.37 M, 128 1.11 -> 0.67 | 1.15 M.  What a pivot costs at these sizes is the per-wavefront selection / staging /
   // ratio-test code around the update (~300 vector and ~280 scalar instructions per pivot and wavefront for 16 FMAs per
   // tile), so fewer, fatter wavefronts per QP win until the registers run out.
-  const bool use_reg = h->env_k2 > 0 || (h->env_k2 < 0 && h->N > 48);
+  const bool use_reg = h->env_k2 > 0 || (h->env_k2 < 0 && h->N > 48) || (from_list && h->env_k2 != 0);
   if(use_reg && h->N <= 128)
   {
     int rcr;
     const bool three = h->env_k2 == 13 || (h->env_k2 != 12 && ((h->N > 56 && h->N <= 64) || h->N > 112));
-#define CCC_ZMP_REG(NR, TPT) rcr = go_reg(&zmp_plan_reg_kernel<NR, TPT>, RegTab<NR, TPT>{})
+#define CCC_ZMP_REG(NR, TPT)                                                   \
+  rcr = from_list ? go_reg(&zmp_plan_reg_list_kernel<NR, TPT>, RegTab<NR, TPT>{}) \
+                  : go_reg(&zmp_plan_reg_kernel<NR, TPT>, RegTab<NR, TPT>{})
 #define CCC_ZMP_REG23(NR) \
   do                      \
   {                       \
@@ -1501,7 +1579,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     const size_t lds = ((size_t)ST::kDoubles + ST::NB * ST::TS_) * sizeof(double) + sizeof(BlockRed) + sizeof(SelRed);
     // one workgroup per QP: the pivot count varies severalfold between QPs, so the balancing is left to the hardware
     // dispatcher (a QP takes ~100 us, the launch of a workgroup ~1 us)
-    const int grid = (int)std::min<int64_t>(nqp, (int64_t)1 << 22);
+    const int grid = (int)std::min<int64_t>(grid_qp, (int64_t)1 << 22);
     CCC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
     if(h->env_debug)
@@ -1516,7 +1594,9 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
     return CCC_OK;
   };
   int rc;
-#define CCC_ZMP_SYM(NR, TS, TPT) rc = go(&zmp_plan_sym_kernel<NR, TS, TPT>, SymTab<NR, TS, TPT>{})
+#define CCC_ZMP_SYM(NR, TS, TPT)                                                             \
+  rc = from_list ? go(&zmp_plan_sym_list_kernel<NR, TS, TPT>, SymTab<NR, TS, TPT>{}) \
+                 : go(&zmp_plan_sym_kernel<NR, TS, TPT>, SymTab<NR, TS, TPT>{})
   const int N = h->N;
   if(N <= 40) CCC_ZMP_SYM(40, 4, 2);
   else if(N <= 48) CCC_ZMP_SYM(48, 4, 2);
@@ -1534,7 +1614,74 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 #undef CCC_ZMP_SYM
   if(rc != CCC_OK) return rc;
   CCC_HIP_CHECK(hipGetLastError());
+  if(from_list) h->last_kernel = stage_name;
   return CCC_OK;
+}
+
+// N > 32: K3 (zmp_stage.inc) on large batches of long horizons, the exact kernels on what it hands over; otherwise the
+// exact kernels alone
+int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
+                 double * jerk, int32_t * status, hipStream_t stream)
+{
+  const int64_t nqp = 2 * n;
+  // measured default: see DESIGN.md section 3 (K3 against K2r by horizon and batch)
+  const int64_t stage_min = h->env_stage_min >= 0 ? h->env_stage_min : 8192;
+  const bool use_stage = nqp < ((int64_t)1 << 31) && h->N <= 256
+                         && (h->env_stage > 0 || (h->env_stage < 0 && h->N > 64 && nqp >= stage_min));
+  if(!use_stage) return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, false);
+  constexpr int kChunk = 8;
+  const int waves = h->env_stage_waves > 0 ? h->env_stage_waves : 1; // per SIMD at most (the kernel is built for one)
+  const int64_t blocks = std::min<int64_t>((nqp + 63) / 64, (int64_t)h->num_cu * 4 * waves);
+  const size_t per_block = StageWs<kChunk>::doubles(h->N) * sizeof(double);
+  if(blocks > h->ws_stage_blocks || nqp > h->fb_cap)
+  {
+    CCC_NO_CAPTURE(stream, "ccc_zmp_plan_batch_device");
+    if(blocks > h->ws_stage_blocks)
+    {
+      const int64_t cap = std::min<int64_t>(std::max<int64_t>(blocks, h->ws_stage_blocks * 3 / 2), (int64_t)h->num_cu * 4 * waves);
+      if(h->ws_stage) h->retired.push_back(h->ws_stage);
+      h->ws_stage = nullptr;
+      h->ws_stage_blocks = 0;
+      CCC_HIP_CHECK(hipMalloc(&h->ws_stage, (size_t)cap * per_block));
+      h->ws_stage_blocks = cap;
+    }
+    if(nqp > h->fb_cap)
+    {
+      if(h->fb_list) h->retired.push_back(h->fb_list);
+      h->fb_list = nullptr;
+      const int64_t cap = std::max<int64_t>(nqp, h->fb_cap * 3 / 2);
+      CCC_HIP_CHECK(hipMalloc(&h->fb_list, (size_t)cap * sizeof(int)));
+      h->fb_cap = cap;
+    }
+    if(!h->fb_count) CCC_HIP_CHECK(hipMalloc(&h->fb_count, 64));
+  }
+  ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
+  P.fb_list = h->fb_list;
+  P.fb_count = h->fb_count;
+  CCC_HIP_CHECK(hipMemsetAsync(h->fb_count, 0, sizeof(int), stream));
+  // iteration limits (numpy model, bench workload at N = 100: 11.5 iterations on average, 99 % within 21, 0.3 % cycle) and
+  // the penalty of the first iterations, 30 w^6 (w^2 = g / h: jerk^2 against ZMP^2; flat between 10 and 100)
+  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 24;
+  const int pen_iters = h->env_stage_pen >= 0 ? h->env_stage_pen : 12;
+  const double w2 = -1.0 / h->c2, rho = 30.0 * w2 * w2 * w2;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if(h->N <= 128)
+    hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10);
+  else
+    hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10);
+  CCC_HIP_CHECK(hipGetLastError());
+  h->last_kernel = "zmp_plan_stage_kernel";
+  if(h->env_debug && !(stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone))
+  {
+    int handed = -1;
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(&handed, h->fb_count, sizeof(int), hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "zmp stage kernel: %d workgroups, %d iterations at most (%d penalised), %d of %lld QPs handed over\n",
+                 (int)blocks, iters, pen_iters, handed, (long long)nqp);
+  }
+  return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, true);
 }
 } // namespace
 
@@ -1577,6 +1724,11 @@ extern "C" int ccc_zmp_create(double com_height, double horizon_duration, double
   if(const char * k2 = std::getenv("CCC_ZMP_K2")) h->env_k2 = std::atoi(k2);
   if(const char * kw = std::getenv("CCC_ZMP_KW")) h->env_kw = std::atoi(kw);
   if(const char * ce = std::getenv("CCC_ZMP_HOST_CHUNK")) h->env_host_chunk = std::atoll(ce);
+  if(const char * e = std::getenv("CCC_ZMP_STAGE")) h->env_stage = std::atoi(e);
+  if(const char * e = std::getenv("CCC_ZMP_STAGE_MIN")) h->env_stage_min = std::atoll(e);
+  if(const char * e = std::getenv("CCC_ZMP_STAGE_ITERS")) h->env_stage_iters = std::atoi(e);
+  if(const char * e = std::getenv("CCC_ZMP_STAGE_WAVES")) h->env_stage_waves = std::atoi(e);
+  if(const char * e = std::getenv("CCC_ZMP_STAGE_PEN")) h->env_stage_pen = std::atoi(e);
   build_model(h);
   hipDeviceProp_t prop;
   hipError_t e = hipGetDeviceProperties(&prop, device);
@@ -1612,6 +1764,9 @@ extern "C" void ccc_zmp_destroy(ccc_zmp_t * h)
   if(h->dA) (void)hipFree(h->dA);
   if(h->db) (void)hipFree(h->db);
   if(h->ws_big) (void)hipFree(h->ws_big);
+  if(h->ws_stage) (void)hipFree(h->ws_stage);
+  if(h->fb_list) (void)hipFree(h->fb_list);
+  if(h->fb_count) (void)hipFree(h->fb_count);
   if(h->d_in) (void)hipFree(h->d_in);
   if(h->d_out) (void)hipFree(h->d_out);
   if(h->d_status) (void)hipFree(h->d_status);

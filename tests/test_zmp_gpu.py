@@ -284,6 +284,119 @@ def test_horizon_sizes_against_oracle(N):
     assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
 
 
+def _stage_handle(monkeypatch, T, dt, **env):
+    """A handle whose N > 32 calls take K3 (csrc/zmp_stage.inc) whatever the batch (development switches are read at create)."""
+    monkeypatch.setenv("CCC_ZMP_STAGE", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    mpc = LinearMpcZmp(1.0, T, dt)
+    monkeypatch.delenv("CCC_ZMP_STAGE")
+    for k in env:
+        monkeypatch.delenv(k)
+    return mpc
+
+
+def test_stage_kernel_golden_vectors_and_oracle_n100(golden_zmp, monkeypatch):
+    """K3 (round 6, csrc/zmp_stage.inc): the QP in its state-space form -- Riccati recursion per guessed set of clamped
+    stages, primal-dual active set on the guess, one QP per lane -- at the reference test's horizon (2 s @ 20 ms,
+    tests/src/TestLinearMpcZmp.cpp:17-19).  Golden vectors and the oracle on 1200 QPs, the jerks of the whole horizon."""
+    mpc = _stage_handle(monkeypatch, 2.0, 0.02)
+    r = mpc.planOnceBatch(golden_zmp["n100_x0"], golden_zmp["n100_zlim"], 0.005, want_jerk=True)
+    assert mpc.last_kernel() == "zmp_plan_stage_kernel"
+    assert np.all(r["status"] == _lib.CCC_STATUS_SOLVED)
+    assert np.abs(r["zmp"] - golden_zmp["n100_zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], golden_zmp["n100_jerk"]) <= JERK_RTOL
+    b = fx.make_zmp_batch(600, 100, 0.02, seed=31)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert np.all(r["status"] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+    # the exact kernel alone gives the same plan (its own route to the same minimiser)
+    monkeypatch.setenv("CCC_ZMP_STAGE", "0")
+    ex = LinearMpcZmp(1.0, 2.0, 0.02)
+    monkeypatch.delenv("CCC_ZMP_STAGE")
+    r0 = ex.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    assert ex.last_kernel() == "zmp_plan_reg_kernel"
+    assert np.abs(r["zmp"] - r0["zmp"]).max() <= 1e-11 and _jerk_err(r["jerk"], r0["jerk"]) <= 1e-9
+
+
+@pytest.mark.parametrize("iters", [1, 3, 12])
+def test_stage_kernel_hands_over_what_it_does_not_finish(iters, monkeypatch):
+    """Starved of iterations K3 hands most QPs to the exact kernel in the same call (the list and its length stay on the
+    device): every QP comes back solved with the same plan, whoever solved it."""
+    b = fx.make_zmp_batch(500, 100, 0.02, seed=7)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    mpc = _stage_handle(monkeypatch, 2.0, 0.02, CCC_ZMP_STAGE_ITERS=iters)
+    for _ in range(2):  # (the second call reuses the list)
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+        assert mpc.last_kernel() == "zmp_plan_stage_kernel"
+        assert np.all(r["status"] == 0)
+        assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+        assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+
+
+def test_stage_kernel_certificate_on_a_long_horizon(monkeypatch):
+    """5 s of horizon (100 steps of 50 ms): the cost-to-go of a run of clamped stages grows like exp(2 w T) = 4e13 and the
+    recursion's gains lose their digits.  K3 returns only what passes its certificate (limits, multiplier signs,
+    stationarity residual, all measured on the point itself); the rest is the exact kernel's: parity as everywhere."""
+    b = fx.make_zmp_batch(400, 100, 0.05, seed=5)
+    ref = _oracle().LinearMpcZmp(1.0, 5.0, 0.05).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    mpc = _stage_handle(monkeypatch, 5.0, 0.05)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+    ok = ref["status"] == 0
+    assert np.all(r["status"][ok] == 0)
+    assert np.abs(r["zmp"] - ref["zmp"])[ok].max() <= ZMP_TOL
+    assert _jerk_err(r["jerk"][ok], ref["jerk"][ok]) <= JERK_RTOL
+
+
+@pytest.mark.parametrize("N", [40, 72, 128, 160, 256])
+def test_stage_kernel_other_horizons_and_their_exact_kernels(N, monkeypatch):
+    """K3 takes any horizon; what it hands over goes to the exact kernel of that size (register tiles to 128 rows, the LDS
+    tableau to 200, the HBM tableau beyond).  CCC_ZMP_STAGE_ITERS=6 makes sure each of them gets work."""
+    dt = 2.0 / N
+    n = 96 if N > 128 else 256
+    b = fx.make_zmp_batch(n, N, dt, seed=300 + N)
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
+    for env in ({}, {"CCC_ZMP_STAGE_ITERS": 6}):
+        mpc = _stage_handle(monkeypatch, 2.0, dt, **env)
+        assert mpc.horizon_steps_ == N
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
+        assert mpc.last_kernel() == "zmp_plan_stage_kernel"
+        assert np.all(r["status"] == 0)
+        assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+        assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL
+
+
+def test_stage_kernel_flags_an_infeasible_qp_and_ragged_batches(monkeypatch):
+    """lo > hi at one stage: INFEASIBLE for that axis alone; batches that do not fill a wavefront."""
+    mpc = _stage_handle(monkeypatch, 2.0, 0.02)
+    for n in (1, 31, 33, 97):
+        b = fx.make_zmp_batch(n, 100, 0.02, seed=n)
+        ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005)
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005)
+        assert np.all(r["status"] == 0) and np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL
+    b = fx.make_zmp_batch(5, 100, 0.02, seed=2)
+    b["zlim"][2, 1, 0, 40] = b["zlim"][2, 1, 1, 40] + 0.1
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005)
+    assert r["status"][2, 1] != 0 and r["status"][2, 0] == 0 and ref["status"][2] != 0
+    keep = [0, 1, 3, 4]
+    assert np.all(r["status"][keep] == 0) and np.abs(r["zmp"][keep] - ref["zmp"][keep]).max() <= ZMP_TOL
+
+
+def test_stage_kernel_is_the_default_for_large_batches_of_long_horizons():
+    mpc = LinearMpcZmp(1.0, 2.0, 0.02)
+    b = fx.make_zmp_batch(8192, 100, 0.02, seed=77)
+    r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005)
+    assert mpc.last_kernel() == "zmp_plan_stage_kernel" and np.all(r["status"] == 0)
+    s = fx.make_zmp_batch(64, 100, 0.02, seed=78)
+    mpc.planOnceBatch(s["x0"], s["zlim"], 0.005)
+    assert mpc.last_kernel() == "zmp_plan_reg_kernel"
+    ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"][:512], b["zlim"][:512], 0.005, nthreads=8)
+    assert np.abs(r["zmp"][:512] - ref["zmp"]).max() <= ZMP_TOL
+
+
 def test_reference_scenario_n100_closed_loop():
     """BASELINE.json configs[0]: TestLinearMpcZmp.cpp:15-126 exactly (2 s horizon @ 20 ms, sim_dt 5 ms, 10 s, two
     kicks) through planOnce(callback, ...): the reference's per-cycle and final property assertions, and the
