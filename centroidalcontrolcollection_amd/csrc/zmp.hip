@@ -1234,8 +1234,9 @@ struct ccc_zmp
                                 //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
                                 //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
-  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (K3), 1 = for every N > 32 and batch;
-                                //                < 0: the measured default (N > 64, from env_stage_min QPs)
+  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (K3), 1 = for every 32 < N <= 256 and
+                                //                batch; < 0: the measured default (40 <= N <= 256, from a batch size that
+                                //                depends on the horizon: launch_block)
   int64_t env_stage_min = -1;   // CCC_ZMP_STAGE_MIN: QPs from which K3 runs (< 0: the measured default)
   int env_stage_iters = 0;      // CCC_ZMP_STAGE_ITERS: K3's iteration limit before a QP is handed over (0: the default)
   int env_stage_waves = 0;      // CCC_ZMP_STAGE_WAVES: K3's wavefronts per SIMD at most (0: the default)
@@ -1625,11 +1626,22 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 {
   const int64_t nqp = 2 * n;
   // measured default: see DESIGN.md section 3 (K3 against K2r by horizon and batch)
-  const int64_t stage_min = h->env_stage_min >= 0 ? h->env_stage_min : 8192;
+  // K3's time is flat in the batch up to one QP per lane (65536 on 256 CUs: ~20 iterations of 0.55 us x N, + 0.5 ms), the
+  // exact kernels' is proportional to it: K3 from where the two cross (measured, solves/s at 32768 instances K3 | exact:
+  // N = 40 40.1 | 37.1 M, 48 38.2 | 31.8 M, 56 30.8 | 19.5 M, 64 28.6 | 17.4 M, 72 21.8 | 7.0 M, 100 16.5 | 3.25 M,
+  // 128 11.8 | 1.2 M, 200 3.5 | 0.27 M; crossovers at 8192 / 4500 / 2200 / 800 instances for N = 72 / 100 / 128 / 200)
+  const int Nh = h->N;
+  const int64_t stage_min = h->env_stage_min >= 0 ? h->env_stage_min
+                            : Nh <= 48  ? 57344
+                            : Nh <= 64  ? 36864
+                            : Nh <= 80  ? 14336
+                            : Nh <= 112 ? 10240
+                            : Nh <= 128 ? 4608
+                                        : 2048;
   const bool use_stage = nqp < ((int64_t)1 << 31) && h->N <= 256
-                         && (h->env_stage > 0 || (h->env_stage < 0 && h->N > 64 && nqp >= stage_min));
+                         && (h->env_stage > 0 || (h->env_stage < 0 && h->N >= 40 && nqp >= stage_min));
   if(!use_stage) return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, false);
-  constexpr int kChunk = 8;
+  constexpr int kChunk = 13; // stages per checkpoint (N = 100: eight chunks)
   const int waves = h->env_stage_waves > 0 ? h->env_stage_waves : 1; // per SIMD at most (the kernel is built for one)
   const int64_t blocks = std::min<int64_t>((nqp + 63) / 64, (int64_t)h->num_cu * 4 * waves);
   const size_t per_block = StageWs<kChunk>::doubles(h->N) * sizeof(double);
@@ -1661,16 +1673,19 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   CCC_HIP_CHECK(hipMemsetAsync(h->fb_count, 0, sizeof(int), stream));
   // iteration limits (numpy model, bench workload at N = 100: 11.5 iterations on average, 99 % within 21, 0.3 % cycle) and
   // the penalty of the first iterations, 30 w^6 (w^2 = g / h: jerk^2 against ZMP^2; flat between 10 and 100)
-  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 24;
+  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 20;
   const int pen_iters = h->env_stage_pen >= 0 ? h->env_stage_pen : 12;
   const double w2 = -1.0 / h->c2, rho = 30.0 * w2 * w2 * w2;
+  // the certificate's bound on the stationarity residual: planned ZMP = ... + c2 cdt u_0 and |du_0| <= |r|_2 <= sqrt(N) r_max
+  const double cdt = control_dt < 0 ? h->horizon_dt : control_dt;
+  const double cert_abs = 1e-10 / (std::fabs(h->c2) * std::max(cdt, 1e-4) * std::sqrt((double)h->N));
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if(h->N <= 128)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
   else
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
   CCC_HIP_CHECK(hipGetLastError());
   h->last_kernel = "zmp_plan_stage_kernel";
   if(h->env_debug && !(stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone))

@@ -337,17 +337,26 @@ def test_stage_kernel_hands_over_what_it_does_not_finish(iters, monkeypatch):
 
 
 def test_stage_kernel_certificate_on_a_long_horizon(monkeypatch):
-    """5 s of horizon (100 steps of 50 ms): the cost-to-go of a run of clamped stages grows like exp(2 w T) = 4e13 and the
-    recursion's gains lose their digits.  K3 returns only what passes its certificate (limits, multiplier signs,
-    stationarity residual, all measured on the point itself); the rest is the exact kernel's: parity as everywhere."""
+    """5 s of horizon (100 steps of 50 ms): the cost-to-go of a run of clamped stages grows like exp(2 w T) = 4e13, the
+    recursion's gains lose their digits, and the QP itself is that badly conditioned (jerks to 5e6 in this batch: holding
+    the ZMP for 5 s of the inverted pendulum's exp(w t)).  K3 returns only what passes its certificate (limits, multiplier
+    signs, stationarity residual, all measured on the point itself): those answers are held to the usual 1e-9 of the
+    oracle.  What it hands over is the exact kernel's, and there the exact kernel and the oracle -- two dual active sets
+    on the same 1e13-conditioned tableau -- agree to 2.5e-6 (measured on this batch with K3 off; not K3's doing)."""
     b = fx.make_zmp_batch(400, 100, 0.05, seed=5)
     ref = _oracle().LinearMpcZmp(1.0, 5.0, 0.05).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
     mpc = _stage_handle(monkeypatch, 5.0, 0.05)
     r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
-    ok = ref["status"] == 0
+    ok = (ref["status"] == 0)[:, None] & np.ones((1, 2), bool)
     assert np.all(r["status"][ok] == 0)
-    assert np.abs(r["zmp"] - ref["zmp"])[ok].max() <= ZMP_TOL
-    assert _jerk_err(r["jerk"][ok], ref["jerk"][ok]) <= JERK_RTOL
+    certified = ok & (r["pivots"] <= 20)  # (K3's iteration limit; the exact kernel needs ~100 pivots on these)
+    print("certified by K3: %d of %d QPs" % (certified.sum(), ok.sum()))
+    assert certified.sum() >= 0.25 * ok.sum()
+    err = np.abs(r["zmp"] - ref["zmp"])
+    assert err[certified].max() <= ZMP_TOL
+    scale = np.maximum(1.0, np.abs(ref["jerk"]).max(axis=-1))
+    assert (np.abs(r["jerk"] - ref["jerk"]).max(axis=-1) / scale)[certified].max() <= JERK_RTOL
+    assert err[ok].max() <= 1e-5
 
 
 @pytest.mark.parametrize("N", [40, 72, 128, 160, 256])
