@@ -7,7 +7,7 @@ one launch of the dual active-set kernel (csrc/zmp.hip) through the C-ABI (ccc_z
 plus -- for N > 1 GPUs -- the RCCL all-gather of the planned ZMPs (north_star).  Weak scaling: every rank
 solves its own batch of 65536 instances (seed = 20250928 + rank); value = all ranks' solves / max-over-ranks time.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--workload zmp|xy|ddp|srb|ism|z|ddpzmp]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--workload zmp|zmp100|xy|ddp|srb|ism|z|ddpzmp]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 Rank 0 prints ONE JSON line.
@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the `secondary` entries (configs 3, 4, 5: xy 65536, ddp 4096, srb 32768, 20 timed "
                          "steps each over rotating batches, each with roofline / cpu_baseline / parity) the default one-GPU command appends")
-    ap.add_argument("--workload", choices=["zmp", "xy", "ddp", "srb", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
+    ap.add_argument("--workload", choices=["zmp", "zmp100", "xy", "ddp", "srb", "walk", "multi", "xywalk", "ism", "z", "ddpzmp"], default="zmp",
                     help="zmp (default) = the headline metric; the others measure the remaining classes with the same "
                          "protocol (bench_secondary.py)")
     args = ap.parse_args()
@@ -664,7 +664,7 @@ def main():
 
         torch.cuda.empty_cache()
         secondary = []
-        for wl, (k_steps, k_warm) in (("xy", (20, 2)), ("ddp", (20, 2)), ("srb", (20, 2))):
+        for wl, (k_steps, k_warm) in (("xy", (20, 2)), ("ddp", (20, 2)), ("srb", (20, 2)), ("zmp100", (20, 2))):
             secondary.append(bench_secondary.measure(wl, bench_secondary.DEFAULT_BATCH[wl], k_steps, k_warm, rank, world,
                                                      local_rank, dist, cpu=not args.no_cpu_baseline, dinfo=None,
                                                      live=not args.no_live_counters and not args.inner))

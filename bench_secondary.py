@@ -272,6 +272,56 @@ def _ddp_valu(S, M, N, iters, walking):
                      "structured kernel performs fewer): orientation only, in no fraction of the peak")
 
 
+def _zmp100(n, dev, rank):
+    """LinearMpcZmp at the reference test's own horizon (TestLinearMpcZmp.cpp:17-19: 2 s @ 20 ms = 100 steps): the
+    state-space kernel KS (csrc/zmp_stage.inc) with the exact dual active set behind it.  RING distinct batches."""
+    from centroidalcontrolcollection_amd import LinearMpcZmp, fixtures as fx
+    N, dt, base = 100, 0.02, min(n, 4096)
+    # RING distinct draws (seed 20250928 + 8 rank + k), each tiled to the batch (KS keeps no schedule: a repeated instance
+    # costs what a fresh one does); entry 0 is the one the CPU leg checks
+    bs = [_tile(fx.make_zmp_batch(base, N, dt, seed=20250928 + 8 * rank + k), n, base) for k in range(RING)]
+    mpc = LinearMpcZmp(1.0, 2.0, dt, device=dev.index)
+    ring = [(_dev(b["x0"], dev), _dev(b["zlim"], dev)) for b in bs]
+    out = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    st = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    turn = [0]
+
+    def step(stream):
+        x0, zl = ring[turn[0] % RING]
+        turn[0] += 1
+        mpc.plan_batch_device(x0, zl, 0.005, out, None, st, stream=stream)
+
+    def rebase(stream):
+        mpc.plan_batch_device(ring[0][0], ring[0][1], 0.005, out, None, st, stream=stream)
+
+    def cpu(cores, ns=None):
+        from oracle import oracle
+        ns = min(n, ns or 4096)
+        o = oracle.LinearMpcZmp(1.0, 2.0, dt)
+        t0 = time.perf_counter()
+        r = o.plan_batch(bs[0]["x0"][:ns], bs[0]["zlim"][:ns], 0.005, want_jerk=False, nthreads=cores)
+        t = time.perf_counter() - t0
+        return ns / t, ns, float(np.abs(out.cpu().numpy()[:ns] - r["zmp"]).max()), "max |d ZMP| [m]"
+
+    C = 13
+    npad, nc = (N + C - 1) // C * C, (N + C - 1) // C
+
+    def stream_bytes(status):  # per instance (two QPs): limits transposed once, then per iteration the limits twice + checkpoints
+        it = (status >> 8).astype(np.float64).reshape(-1)
+        it = np.where(it <= 20, it, 20.0)  # (a handed-over QP carries the exact kernel's pivot count: KS spent its limit on it)
+        pad = (-len(it)) % 64
+        wave = np.concatenate([it, np.zeros(pad)]).reshape(-1, 64).max(axis=1) + 2.0  # a wavefront sweeps until its last lane
+        per_qp = 2 * npad * 16 + wave * (npad * 32 + nc * 144)                        # is done (+ the stored-jerk sweep and
+        return float(per_qp.sum() * 64 / len(it) * 2)                                 # the costate pass); per instance: 2 QPs
+
+    return dict(name="LinearMpcZmp planOnce() solves/sec (N=100, the reference test's horizon, fp64, inputs resident in HBM)",
+                step=step, rebase=rebase, out=out, status=st, ring=RING,
+                workload="LinearMpcZmp N=100 (2 s horizon @ 20 ms, TestLinearMpcZmp.cpp:17-19), random 6-step footstep "
+                         "sequences, batch=%d per GPU" % n,
+                algo_bytes=2 * (24 + 2 * N * 8) + 16, stream_bytes=stream_bytes, kernel="zmp_plan_stage_kernel", cpu=cpu,
+                keep=(mpc, ring), parity_tol=1e-9)
+
+
 def _ism(n, dev, rank):
     from centroidalcontrolcollection_amd import IntrinsicallyStableMpc, fixtures as fx
     N, dt, base = 100, 0.02, min(n, 1024)
@@ -369,13 +419,13 @@ def _ddpzmp(n, dev, rank):
                 keep=(d, tr, tx, tu, u))
 
 
-DEFAULT_BATCH = dict(xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, multi=2048, xywalk=32768)
-DEFAULT_STEPS = dict(xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
+DEFAULT_BATCH = dict(zmp100=32768, xy=65536, ddp=4096, srb=32768, ism=65536, z=65536, ddpzmp=65536, walk=4096, multi=2048, xywalk=32768)
+DEFAULT_STEPS = dict(zmp100=(20, 3), xy=(5, 1), ddp=(3, 1), srb=(2, 1), ism=(20, 3), z=(50, 5), ddpzmp=(20, 3),
                      walk=(3, 1), multi=(3, 1), xywalk=(3, 1))
 
 
 # sample of the 1-thread leg of cpu_baseline (instances; ~1 s each on one core of the GPU box's host)
-ONE_THREAD_SAMPLE = dict(xy=64, xywalk=16, ddp=128, srb=256, walk=96, multi=64, ism=1024, z=8192, ddpzmp=4096)
+ONE_THREAD_SAMPLE = dict(zmp100=512, xy=64, xywalk=16, ddp=128, srb=256, walk=96, multi=64, ism=1024, z=8192, ddpzmp=4096)
 
 
 def replayed_counters(workload, n):
@@ -466,7 +516,7 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
     ones bracketed by barrier + synchronize, max over ranks.  Also what bench.py's default command appends to the headline
     line as `secondary` (configs 3, 4, 5: VERDICT r4 item 2)."""
     dev = torch.device("cuda", local_rank)
-    make = dict(xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
+    make = dict(zmp100=_zmp100, xy=_xy, xywalk=lambda a, b, c: _xy(a, b, c, True), ism=_ism, z=_z, ddpzmp=_ddpzmp, ddp=lambda a, b, c: _ddp(a, b, c, False), srb=lambda a, b, c: _ddp(a, b, c, True),
                 walk=lambda a, b, c: _ddp(a, b, c, False, True), multi=lambda a, b, c: _ddp(a, b, c, False, "multi"))
     w = make[workload](n, dev, rank)
     stream = torch.cuda.current_stream(dev)

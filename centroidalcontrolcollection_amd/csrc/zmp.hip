@@ -23,6 +23,9 @@
 // (one planOnce() per wavefront), the tableau in registers.  32 < N <= 200 (K2, zmp_plan_sym_kernel): one QP per
 // workgroup, the tableau packed (lower triangle, sym_tableau.h) in LDS.  200 < N <= 256 (K3, zmp_plan_block_kernel):
 // the full tableau in an HBM workspace; 256 < N <= 512: the same kernel at 512 rows (1024 threads per workgroup).
+// Round 5: K1w (zmp_plan_kernel_w, 32 < N <= 64, one QP per wavefront) and K2r (zmp_k2r.inc, the packed tableau in register
+// tiles, to 128 rows).  Round 6: KS (zmp_stage.inc), the same QP in its state-space form -- O(N) per iteration, one QP per
+// lane -- on large batches of 40 <= N <= 256, with the kernels above as the exact solver of what it does not certify.
 #include "common.h"
 #include "sym_tableau.h"
 #include "wave_group.h"
@@ -48,7 +51,7 @@ struct ZmpDev
   const int * order;
   int * hist;
   int * diff; // (when given: |trips now - trips of the last call| per QP -> order_by_count's verdict on the history)
-  // K3 (zmp_stage.inc) and the exact kernels behind it: the QPs K3 does not certify.  K3 appends to fb_list / fb_count; a
+  // KS (zmp_stage.inc) and the exact kernels behind it: the QPs KS does not certify.  KS appends to fb_list / fb_count; a
   // block / sym / reg kernel launched with them set solves fb_list[0 .. *fb_count) instead of [0, nqp)
   int * fb_list;
   int * fb_count;
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_kernel(ZmpDev P, lo
   zmp_plan_block_body<NP, HBM, PARTS, false>(P, nqp, x0, zlim, control_dt, zmp, jerk, status, ws);
 }
 
-// (the QPs K3 hands over, zmp_stage.inc: P.fb_list[0 .. *P.fb_count))
+// (the QPs KS hands over, zmp_stage.inc: P.fb_list[0 .. *P.fb_count))
 template<int NP, bool HBM, int PARTS>
 __global__ __launch_bounds__(NP * PARTS) void zmp_plan_block_list_kernel(ZmpDev P, long nqp, const double * __restrict__ x0,
                                                                  const double * __restrict__ zlim, double control_dt,
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kM
   zmp_plan_sym_body<NP, TS, TPT, false>(P, GS, nqp, x0, zlim, control_dt, zmp, jerk, status);
 }
 
-// (the QPs K3 hands over, zmp_stage.inc)
+// (the QPs KS hands over, zmp_stage.inc)
 template<int NP, int TS, int TPT>
 __global__ __launch_bounds__((SymTab<NP, TS, TPT>::NT), (SymTab<NP, TS, TPT>::kMinWaves)) void zmp_plan_sym_list_kernel(ZmpDev P, int GS, long nqp,
                                                                       const double * __restrict__ x0,
@@ -1203,7 +1206,7 @@ struct ccc_zmp
   bool skip_history = false;             // (set by the host entry while it feeds CHUNKS of one batch: a chunk says nothing
                                          //  about the next)
   double * ws_big = nullptr; // HBM tableaus of the 128 < N <= 256 kernel
-  // K3 (zmp_stage.inc): per-wavefront stage records, and the list of the QPs it hands over to the exact kernel
+  // KS (zmp_stage.inc): per-wavefront stage records, and the list of the QPs it hands over to the exact kernel
   double * ws_stage = nullptr;
   int64_t ws_stage_blocks = 0;
   int *fb_list = nullptr, *fb_count = nullptr;
@@ -1234,13 +1237,13 @@ struct ccc_zmp
                                 //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
                                 //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
-  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (K3), 1 = for every 32 < N <= 256 and
+  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (KS), 1 = for every 32 < N <= 256 and
                                 //                batch; < 0: the measured default (40 <= N <= 256, from a batch size that
                                 //                depends on the horizon: launch_block)
-  int64_t env_stage_min = -1;   // CCC_ZMP_STAGE_MIN: QPs from which K3 runs (< 0: the measured default)
-  int env_stage_iters = 0;      // CCC_ZMP_STAGE_ITERS: K3's iteration limit before a QP is handed over (0: the default)
-  int env_stage_waves = 0;      // CCC_ZMP_STAGE_WAVES: K3's wavefronts per SIMD at most (0: the default)
-  int env_stage_pen = -1;       // CCC_ZMP_STAGE_PEN: K3's iterations on the penalised problem at most (< 0: the default)
+  int64_t env_stage_min = -1;   // CCC_ZMP_STAGE_MIN: QPs from which KS runs (< 0: the measured default)
+  int env_stage_iters = 0;      // CCC_ZMP_STAGE_ITERS: KS's iteration limit before a QP is handed over (0: the default)
+  int env_stage_waves = 0;      // CCC_ZMP_STAGE_WAVES: KS's wavefronts per SIMD at most (0: the default)
+  int env_stage_pen = -1;       // CCC_ZMP_STAGE_PEN: KS's iterations on the penalised problem at most (< 0: the default)
   const char * last_kernel = "none"; // the kernel the last plan call launched (ccc_zmp_last_kernel)
   const char * last_order = "none";  // ... and what its schedule came from (CCC_ZMP_DEBUG prints it)
 };
@@ -1452,7 +1455,7 @@ int launch(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, doubl
   if(P.hist) h->hist_n = nqp;
   return CCC_OK;
 }
-// the exact (dual active set) kernels of N > 32.  from_list: solve the QPs K3 handed over (h->fb_list[0 .. *h->fb_count),
+// the exact (dual active set) kernels of N > 32.  from_list: solve the QPs KS handed over (h->fb_list[0 .. *h->fb_count),
 // both known on the device only) with a grid sized for a few per cent of the batch; blocks beyond the count return at once
 int launch_exact(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
                  double * jerk, int32_t * status, hipStream_t stream, bool from_list)
@@ -1619,15 +1622,15 @@ int launch_exact(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   return CCC_OK;
 }
 
-// N > 32: K3 (zmp_stage.inc) on large batches of long horizons, the exact kernels on what it hands over; otherwise the
+// N > 32: KS (zmp_stage.inc) on large batches of long horizons, the exact kernels on what it hands over; otherwise the
 // exact kernels alone
 int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim, double control_dt, double * zmp,
                  double * jerk, int32_t * status, hipStream_t stream)
 {
   const int64_t nqp = 2 * n;
-  // measured default: see DESIGN.md section 3 (K3 against K2r by horizon and batch)
-  // K3's time is flat in the batch up to one QP per lane (65536 on 256 CUs: ~20 iterations of 0.55 us x N, + 0.5 ms), the
-  // exact kernels' is proportional to it: K3 from where the two cross (measured, solves/s at 32768 instances K3 | exact:
+
+  // KS's time is flat in the batch up to one QP per lane (65536 on 256 CUs: ~20 iterations of 0.55 us x N, + 0.5 ms), the
+  // exact kernels' is proportional to it: KS from where the two cross (measured, solves/s at 32768 instances KS | exact:
   // N = 40 40.1 | 37.1 M, 48 38.2 | 31.8 M, 56 30.8 | 19.5 M, 64 28.6 | 17.4 M, 72 21.8 | 7.0 M, 100 16.5 | 3.25 M,
   // 128 11.8 | 1.2 M, 200 3.5 | 0.27 M; crossovers at 8192 / 4500 / 2200 / 800 instances for N = 72 / 100 / 128 / 200)
   const int Nh = h->N;

@@ -16,11 +16,12 @@
  * device -- enqueue them on one stream (or order the streams); use one handle per concurrent stream.
  * hipGraph: every "_device" call may be captured (hipStreamBeginCapture on the stream it is given) once the handle has
  * run one call of at least that batch size eagerly -- workspaces are allocated, synchronously, when a batch size is
- * first seen; a call enqueues only kernels (and, LinearMpcXY, an event fork/join with a stream the handle owns).
+ * first seen; a call enqueues only kernels and counter resets (and, LinearMpcXY, an event fork/join with a stream the
+ * handle owns).
  * A captured graph holds the addresses of the handle's workspaces: it stays valid until a LATER call with a larger batch
  * makes a workspace grow (the old one is freed) -- capture at the largest batch the handle will see.  LinearMpcZmp handles
- * for N <= 32 have no such workspace (their scheduling buffers are retired, not freed, when outgrown): graphs of theirs stay
- * valid for the life of the handle.
+ * retire what a larger batch outgrows instead of freeing it (scheduling buffers, the state-space kernel's
+ * stage records and hand-over list): graphs of theirs stay valid for the life of the handle.
  */
 #ifndef CCC_AMD_H
 #define CCC_AMD_H

@@ -47,6 +47,34 @@ def test_zmp_graph_replay(n):
         assert np.array_equal(zmp.cpu().numpy(), eager["zmp"]) and np.all((st.cpu().numpy() & 0xff) == 0)
 
 
+def test_zmp_stage_kernel_graph_replay():
+    """KS + the exact kernel behind it (csrc/zmp_stage.inc, N = 100): the counter reset, KS and the list kernel are three
+    capturable operations; the hand-over list's ORDER depends on the race for its slots, the answers do not (each QP's
+    solve is its own).  A later larger eager call retires KS's workspace and list instead of freeing them."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n = 6000  # (12000 QPs: above the batch size KS takes N = 100 from)
+    mpc = LinearMpcZmp(1.0, 2.0, 0.02)
+    a, b = fx.make_zmp_batch(n, 100, 0.02, seed=3), fx.make_zmp_batch(n, 100, 0.02, seed=4)
+    x0, zlim = torch.from_numpy(a["x0"]).to(dev), torch.from_numpy(a["zlim"]).to(dev)
+    zmp = torch.zeros((n, 2), dtype=torch.float64, device=dev)
+    st = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    g = _capture(lambda s: mpc.plan_batch_device(x0, zlim, 0.005, zmp, None, st, s))
+    assert mpc.last_kernel() == "zmp_plan_stage_kernel"
+    big = fx.make_zmp_batch(3 * n, 100, 0.02, seed=5)
+    mpc.planOnceBatch(big["x0"], big["zlim"], 0.005)  # (grows the workspace and the list: the graph keeps the old ones)
+    for batch in (b, a, b):
+        x0.copy_(torch.from_numpy(batch["x0"]))
+        zlim.copy_(torch.from_numpy(batch["zlim"]))
+        zmp.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        eager = mpc.planOnceBatch(batch["x0"], batch["zlim"], 0.005)
+        assert np.array_equal(zmp.cpu().numpy(), eager["zmp"]) and np.all((st.cpu().numpy() & 0xff) == 0)
+        assert (st.cpu().numpy() >> 8).max() > 20  # (some QPs went through the list: the exact kernel's pivot counts)
+
+
 def test_a_zmp_graph_survives_a_later_larger_eager_call():
     """the scheduling buffers of a LinearMpcZmp handle (last call's counts, predicted counts, the order
     made from them) grow with the batch; a hipGraph captured at a smaller size has their addresses baked into its launches.

@@ -285,7 +285,7 @@ def test_horizon_sizes_against_oracle(N):
 
 
 def _stage_handle(monkeypatch, T, dt, **env):
-    """A handle whose N > 32 calls take K3 (csrc/zmp_stage.inc) whatever the batch (development switches are read at create)."""
+    """A handle whose N > 32 calls take KS (csrc/zmp_stage.inc) whatever the batch (development switches are read at create)."""
     monkeypatch.setenv("CCC_ZMP_STAGE", "1")
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -297,7 +297,7 @@ def _stage_handle(monkeypatch, T, dt, **env):
 
 
 def test_stage_kernel_golden_vectors_and_oracle_n100(golden_zmp, monkeypatch):
-    """K3 (round 6, csrc/zmp_stage.inc): the QP in its state-space form -- Riccati recursion per guessed set of clamped
+    """KS (round 6, csrc/zmp_stage.inc): the QP in its state-space form -- Riccati recursion per guessed set of clamped
     stages, primal-dual active set on the guess, one QP per lane -- at the reference test's horizon (2 s @ 20 ms,
     tests/src/TestLinearMpcZmp.cpp:17-19).  Golden vectors and the oracle on 1200 QPs, the jerks of the whole horizon."""
     mpc = _stage_handle(monkeypatch, 2.0, 0.02)
@@ -323,7 +323,7 @@ def test_stage_kernel_golden_vectors_and_oracle_n100(golden_zmp, monkeypatch):
 
 @pytest.mark.parametrize("iters", [1, 3, 12])
 def test_stage_kernel_hands_over_what_it_does_not_finish(iters, monkeypatch):
-    """Starved of iterations K3 hands most QPs to the exact kernel in the same call (the list and its length stay on the
+    """Starved of iterations KS hands most QPs to the exact kernel in the same call (the list and its length stay on the
     device): every QP comes back solved with the same plan, whoever solved it."""
     b = fx.make_zmp_batch(500, 100, 0.02, seed=7)
     ref = _oracle().LinearMpcZmp(1.0, 2.0, 0.02).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
@@ -339,18 +339,18 @@ def test_stage_kernel_hands_over_what_it_does_not_finish(iters, monkeypatch):
 def test_stage_kernel_certificate_on_a_long_horizon(monkeypatch):
     """5 s of horizon (100 steps of 50 ms): the cost-to-go of a run of clamped stages grows like exp(2 w T) = 4e13, the
     recursion's gains lose their digits, and the QP itself is that badly conditioned (jerks to 5e6 in this batch: holding
-    the ZMP for 5 s of the inverted pendulum's exp(w t)).  K3 returns only what passes its certificate (limits, multiplier
+    the ZMP for 5 s of the inverted pendulum's exp(w t)).  KS returns only what passes its certificate (limits, multiplier
     signs, stationarity residual, all measured on the point itself): those answers are held to the usual 1e-9 of the
     oracle.  What it hands over is the exact kernel's, and there the exact kernel and the oracle -- two dual active sets
-    on the same 1e13-conditioned tableau -- agree to 2.5e-6 (measured on this batch with K3 off; not K3's doing)."""
+    on the same 1e13-conditioned tableau -- agree to 2.5e-6 (measured on this batch with KS off; not KS's doing)."""
     b = fx.make_zmp_batch(400, 100, 0.05, seed=5)
     ref = _oracle().LinearMpcZmp(1.0, 5.0, 0.05).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
     mpc = _stage_handle(monkeypatch, 5.0, 0.05)
     r = mpc.planOnceBatch(b["x0"], b["zlim"], 0.005, want_jerk=True)
     ok = (ref["status"] == 0)[:, None] & np.ones((1, 2), bool)
     assert np.all(r["status"][ok] == 0)
-    certified = ok & (r["pivots"] <= 20)  # (K3's iteration limit; the exact kernel needs ~100 pivots on these)
-    print("certified by K3: %d of %d QPs" % (certified.sum(), ok.sum()))
+    certified = ok & (r["pivots"] <= 20)  # (KS's iteration limit; the exact kernel needs ~100 pivots on these)
+    print("certified by KS: %d of %d QPs" % (certified.sum(), ok.sum()))
     assert certified.sum() >= 0.25 * ok.sum()
     err = np.abs(r["zmp"] - ref["zmp"])
     assert err[certified].max() <= ZMP_TOL
@@ -361,7 +361,7 @@ def test_stage_kernel_certificate_on_a_long_horizon(monkeypatch):
 
 @pytest.mark.parametrize("N", [40, 72, 128, 160, 256])
 def test_stage_kernel_other_horizons_and_their_exact_kernels(N, monkeypatch):
-    """K3 takes any horizon; what it hands over goes to the exact kernel of that size (register tiles to 128 rows, the LDS
+    """KS takes any horizon; what it hands over goes to the exact kernel of that size (register tiles to 128 rows, the LDS
     tableau to 200, the HBM tableau beyond).  CCC_ZMP_STAGE_ITERS=6 makes sure each of them gets work."""
     dt = 2.0 / N
     n = 96 if N > 128 else 256

@@ -1,4 +1,4 @@
-"""Numpy model of K3 (csrc/zmp_stage.inc), kept as evidence for its iteration limits: LinearMpcZmp's QP in
+"""Numpy model of KS (csrc/zmp_stage.inc), kept as evidence for its iteration limits: LinearMpcZmp's QP in
 state-space form, Riccati recursion per guessed set of clamped stages, a few iterations on the penalised problem and then the
 primal-dual active set, multipliers taken from the value function, certificate by a costate recursion -- vectorised over
 the batch, stage by stage.  Not used by the product or the tests.
