@@ -25,7 +25,7 @@
 // the full tableau in an HBM workspace; 256 < N <= 512: the same kernel at 512 rows (1024 threads per workgroup).
 // Round 5: K1w (zmp_plan_kernel_w, 32 < N <= 64, one QP per wavefront) and K2r (zmp_k2r.inc, the packed tableau in register
 // tiles, to 128 rows).  Round 6: KS (zmp_stage.inc), the same QP in its state-space form -- O(N) per iteration, one QP per
-// lane -- on large batches of 40 <= N <= 256, with the kernels above as the exact solver of what it does not certify.
+// lane -- on large batches of N >= 40, with the kernels above as the exact solver of what it does not certify.
 #include "common.h"
 #include "sym_tableau.h"
 #include "wave_group.h"
@@ -1237,8 +1237,8 @@ struct ccc_zmp
                                 //             wherever they are built (12 / 13: with two / three tiles per thread); < 0: the
                                 //             measured default per size
   int64_t env_host_chunk = 0;   // CCC_ZMP_HOST_CHUNK: staging chunk of the host entry (0: the default)
-  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (KS), 1 = for every 32 < N <= 256 and
-                                //                batch; < 0: the measured default (40 <= N <= 256, from a batch size that
+  int env_stage = -1;           // CCC_ZMP_STAGE: 0 = never the stage-recursion kernel (KS), 1 = for every N > 32 and
+                                //                batch; < 0: the measured default (N >= 40, from a batch size that
                                 //                depends on the horizon: launch_block)
   int64_t env_stage_min = -1;   // CCC_ZMP_STAGE_MIN: QPs from which KS runs (< 0: the measured default)
   int env_stage_iters = 0;      // CCC_ZMP_STAGE_ITERS: KS's iteration limit before a QP is handed over (0: the default)
@@ -1641,7 +1641,7 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
                             : Nh <= 112 ? 10240
                             : Nh <= 128 ? 4608
                                         : 2048;
-  const bool use_stage = nqp < ((int64_t)1 << 31) && h->N <= 256
+  const bool use_stage = nqp < ((int64_t)1 << 31) && h->N <= 512
                          && (h->env_stage > 0 || (h->env_stage < 0 && h->N >= 40 && nqp >= stage_min));
   if(!use_stage) return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, false);
   constexpr int kChunk = 13; // stages per checkpoint (N = 100: eight chunks)
@@ -1676,7 +1676,10 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   CCC_HIP_CHECK(hipMemsetAsync(h->fb_count, 0, sizeof(int), stream));
   // iteration limits (numpy model, bench workload at N = 100: 11.5 iterations on average, 99 % within 21, 0.3 % cycle) and
   // the penalty of the first iterations, 30 w^6 (w^2 = g / h: jerk^2 against ZMP^2; flat between 10 and 100)
-  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 20;
+  // (the limit grows with the horizon -- what is left of the creeping is counted in stages -- and what it costs to hand a QP
+  //  over grows faster; measured best, 32768 instances: 14 at N = 48 (41.6 M solves/s), 16 at 64 (29.8 M), 20 at 100, 24-26
+  //  at 128 (11.3 M), 32 at 200 (5.1 M; 3.5 M with 24), 72 at N = 400 (207 k against 2.8 k for the HBM tableau alone))
+  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 8 + (h->N <= 256 ? h->N / 8 : h->N / 6);
   const int pen_iters = h->env_stage_pen >= 0 ? h->env_stage_pen : 12;
   const double w2 = -1.0 / h->c2, rho = 30.0 * w2 * w2 * w2;
   // the certificate's bound on the stationarity residual: planned ZMP = ... + c2 cdt u_0 and |du_0| <= |r|_2 <= sqrt(N) r_max
@@ -1686,8 +1689,11 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   if(h->N <= 128)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
                        control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
-  else
+  else if(h->N <= 256)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
+  else
+    hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 8>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
                        control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
   CCC_HIP_CHECK(hipGetLastError());
   h->last_kernel = "zmp_plan_stage_kernel";

@@ -7,7 +7,7 @@ from centroidalcontrolcollection_amd import LinearMpcZmp, fixtures as fx
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cycles = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 tl = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in fx.make_zmp_timelines(n, seed=1).items()}
-mpc = LinearMpcZmp(1.0, 2.0, 0.0625)
+mpc = LinearMpcZmp(1.0, 2.0, float(os.environ.get("CCC_LOOP_DT", "0.0625")))  # (CCC_LOOP_DT=0.02: the reference test's own 100-step horizon)
 rng = np.random.default_rng(0)
 com0 = np.zeros((n, 2, 2)); com0[:, :, 0] = rng.uniform(-0.02, 0.02, size=(n, 2)); com0[:, :, 1] = rng.uniform(-0.05, 0.05, size=(n, 2))
 for rep in range(2):

@@ -359,12 +359,12 @@ def test_stage_kernel_certificate_on_a_long_horizon(monkeypatch):
     assert err[ok].max() <= 1e-5
 
 
-@pytest.mark.parametrize("N", [40, 72, 128, 160, 256])
+@pytest.mark.parametrize("N", [40, 72, 128, 160, 256, 400])
 def test_stage_kernel_other_horizons_and_their_exact_kernels(N, monkeypatch):
     """KS takes any horizon; what it hands over goes to the exact kernel of that size (register tiles to 128 rows, the LDS
     tableau to 200, the HBM tableau beyond).  CCC_ZMP_STAGE_ITERS=6 makes sure each of them gets work."""
     dt = 2.0 / N
-    n = 96 if N > 128 else 256
+    n = (48 if N > 256 else 96) if N > 128 else 256
     b = fx.make_zmp_batch(n, N, dt, seed=300 + N)
     ref = _oracle().LinearMpcZmp(1.0, 2.0, dt).plan_batch(b["x0"], b["zlim"], 0.005, nthreads=8)
     for env in ({}, {"CCC_ZMP_STAGE_ITERS": 6}):
