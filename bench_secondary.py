@@ -569,7 +569,7 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
     # kernel sources (replayed_counters above); null otherwise
     traffic, traffic_src = replayed_counters(workload, n)
     live_res = None
-    if live and world == 1 and workload in ("xy", "ddp", "srb"):
+    if live and world == 1 and workload in ("xy", "ddp", "srb", "zmp100"):
         live_res, live_src = live_secondary(workload, n, w["kernel"])
         if live_res is not None:
             traffic, traffic_src = live_res["hbm_bytes_per_step"], live_src

@@ -63,6 +63,7 @@ KERNEL_UNITS = dict(
 for _alias in ("srb", "walk", "multi"):
     KERNEL_UNITS[_alias] = KERNEL_UNITS["ddp"]
 KERNEL_UNITS["xywalk"] = KERNEL_UNITS["xy"]
+KERNEL_UNITS["zmp100"] = KERNEL_UNITS["zmp"]  # (LinearMpcZmp at N = 100: zmp_stage.inc + zmp_k2r.inc)
 
 
 def kernel_hash(workload):

@@ -35,7 +35,7 @@ def test_committed_summaries_belong_to_the_tree():
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert d.get("kernel_hash") == build.kernel_hash("zmp"), name
     tr = json.load(open(os.path.join(ROOT, "profiles", "r06_hbm_traffic.json")))
-    for w in ("xy", "ddp", "srb", "walk", "multi"):
+    for w in ("xy", "ddp", "srb", "walk", "multi", "zmp100"):
         assert tr[w]["kernel_hash"] == build.kernel_hash(w), w
     assert json.load(open(os.path.join(ROOT, "profiles", "r06_ddp_valu_counters.json")))["kernel_hash"] == build.kernel_hash("ddp")
 
