@@ -303,16 +303,16 @@ def _zmp100(n, dev, rank):
         t = time.perf_counter() - t0
         return ns / t, ns, float(np.abs(out.cpu().numpy()[:ns] - r["zmp"]).max()), "max |d ZMP| [m]"
 
-    C = 13
+    C = 8  # (stages per checkpoint, csrc/zmp.hip CCC_ZMP_STAGE_CHUNK)
     npad, nc = (N + C - 1) // C * C, (N + C - 1) // C
 
     def stream_bytes(status):  # per instance (two QPs): limits transposed once, then per iteration the limits twice + checkpoints
         it = (status >> 8).astype(np.float64).reshape(-1)
         it = np.where(it <= 20, it, 20.0)  # (a handed-over QP carries the exact kernel's pivot count: KS spent its limit on it)
         pad = (-len(it)) % 64
-        wave = np.concatenate([it, np.zeros(pad)]).reshape(-1, 64).max(axis=1) + 2.0  # a wavefront sweeps until its last lane
-        per_qp = 2 * npad * 16 + wave * (npad * 32 + nc * 144)                        # is done (+ the stored-jerk sweep and
-        return float(per_qp.sum() * 64 / len(it) * 2)                                 # the costate pass); per instance: 2 QPs
+        wave = np.concatenate([it, np.zeros(pad)]).reshape(-1, 64).max(axis=1) + 0.5  # a wavefront sweeps until its last lane
+        per_qp = 2 * npad * 16 + wave * (npad * 40 + nc * 144)                        # is done (+ the costate pass over the
+        return float(per_qp.sum() * 64 / len(it) * 2)                                 # stored jerks); per instance: 2 QPs
 
     return dict(name="LinearMpcZmp planOnce() solves/sec (N=100, the reference test's horizon, fp64, inputs resident in HBM)",
                 step=step, rebase=rebase, out=out, status=st, ring=RING,

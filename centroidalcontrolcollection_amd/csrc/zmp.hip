@@ -1644,7 +1644,12 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   const bool use_stage = nqp < ((int64_t)1 << 31) && h->N <= 512
                          && (h->env_stage > 0 || (h->env_stage < 0 && h->N >= 40 && nqp >= stage_min));
   if(!use_stage) return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, false);
-  constexpr int kChunk = 13; // stages per checkpoint (N = 100: eight chunks)
+#ifndef CCC_ZMP_STAGE_CHUNK
+#define CCC_ZMP_STAGE_CHUNK 8
+#endif
+  // stages per checkpoint.  (8 | 10 | 13: N = 100 1.93 | 1.94 | 1.94 ms, N = 64 1.03 | 1.11 | 1.10 ms per 32768 instances -- the
+  //  kernel is bound by its fp64 operations, not by the 132 accumulation registers 13 stages spill to: 8 needs none)
+  constexpr int kChunk = CCC_ZMP_STAGE_CHUNK;
   const int waves = h->env_stage_waves > 0 ? h->env_stage_waves : 1; // per SIMD at most (the kernel is built for one)
   const int64_t blocks = std::min<int64_t>((nqp + 63) / 64, (int64_t)h->num_cu * 4 * waves);
   const size_t per_block = StageWs<kChunk>::doubles(h->N) * sizeof(double);
