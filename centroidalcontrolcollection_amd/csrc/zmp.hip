@@ -1648,7 +1648,9 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 #define CCC_ZMP_STAGE_CHUNK 8
 #endif
   // stages per checkpoint.  (8 | 10 | 13: N = 100 1.93 | 1.94 | 1.94 ms, N = 64 1.03 | 1.11 | 1.10 ms per 32768 instances -- the
-  //  kernel is bound by its fp64 operations, not by the 132 accumulation registers 13 stages spill to: 8 needs none)
+  //  kernel is bound by its fp64 operations, not by the accumulation registers it spills to (46 | 132 at 8 | 13) nor by the
+  //  checkpoint traffic.  One wavefront per SIMD: built for two -- CCC_ZMP_STAGE_OCC=2, 256 VGPRs and 188 B of scratch -- 65536
+  //  instances take 3.87 ms against 3.50 ms)
   constexpr int kChunk = CCC_ZMP_STAGE_CHUNK;
   const int waves = h->env_stage_waves > 0 ? h->env_stage_waves : 1; // per SIMD at most (the kernel is built for one)
   const int64_t blocks = std::min<int64_t>((nqp + 63) / 64, (int64_t)h->num_cu * 4 * waves);
@@ -1691,24 +1693,27 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   const double cdt = control_dt < 0 ? h->horizon_dt : control_dt;
   const double cert_abs = 1e-10 / (std::fabs(h->c2) * std::max(cdt, 1e-4) * std::sqrt((double)h->N));
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  int * const stats = h->env_debug && !capturing ? h->fb_count + 4 : nullptr; // (fb_count is a 64-byte allocation)
+  if(stats) CCC_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(int), stream));
   if(h->N <= 128)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
   else if(h->N <= 256)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
   else
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 8>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
   CCC_HIP_CHECK(hipGetLastError());
   h->last_kernel = "zmp_plan_stage_kernel";
-  if(h->env_debug && !(stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone))
+  if(stats)
   {
-    int handed = -1;
+    int got[5] = {-1, 0, 0, 0, 0};
     (void)hipStreamSynchronize(stream);
-    (void)hipMemcpy(&handed, h->fb_count, sizeof(int), hipMemcpyDeviceToHost);
-    std::fprintf(stderr, "zmp stage kernel: %d workgroups, %d iterations at most (%d penalised), %d of %lld QPs handed over\n",
-                 (int)blocks, iters, pen_iters, handed, (long long)nqp);
+    (void)hipMemcpy(got, h->fb_count, sizeof(got), hipMemcpyDeviceToHost);
+    std::fprintf(stderr, "zmp stage kernel: %d workgroups, %d iterations at most (%d penalised), %d of %lld QPs handed over, "
+                         "sweeps of the slowest QP %d\n", (int)blocks, iters, pen_iters, got[0], (long long)nqp, got[4]);
   }
   return launch_exact(h, n, x0, zlim, control_dt, zmp, jerk, status, stream, true);
 }

@@ -27,6 +27,9 @@ EXPECT = {
     "void ccc_amd::zmp_plan_kernel_w<48, 4, 3>": ("zmp", 168, 3, 128, None),   # (28 spilled dwords at three waves per SIMD:
     #                                                                             faster than two waves without, measured)
     "void ccc_amd::zmp_plan_reg_kernel<104, 2>": ("zmp", 168, 3, 160, None),
+    # round 6: the state-space kernel (csrc/zmp_stage.inc), one QP per lane, ONE wavefront per SIMD by design (bound by its
+    # fp64 operations; built for two it spills 188 B and is slower: csrc/zmp.hip launch_block) -- no scratch
+    "void ccc_amd::zmp_plan_stage_kernel<8, 2>": ("zmp", 512, 1, 0, None),
     # DDP kernel (round 4: structured backward step -- no M x M object, LDS independent of the ridge stride; bound by
     # instruction issue, so the register budget is set for NO spills rather than for occupancy: csrc/ddp_tile.hip)
     # (<9, 1>, round 5: two loop-invariant doubles of the prologue stored once and reloaded in four places, since the rollouts
