@@ -1680,7 +1680,8 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   ZmpDev P{h->N, h->dG, h->dA, h->db, h->c2, h->horizon_dt};
   P.fb_list = h->fb_list;
   P.fb_count = h->fb_count;
-  CCC_HIP_CHECK(hipMemsetAsync(h->fb_count, 0, sizeof(int), stream));
+  // (one 64-byte block: [0] the hand-over count, [4] debug statistics, [8..9] KS's 64-bit ticket counter)
+  CCC_HIP_CHECK(hipMemsetAsync(h->fb_count, 0, 64, stream));
   // iteration limits (numpy model, bench workload at N = 100: 11.5 iterations on average, 99 % within 21, 0.3 % cycle) and
   // the penalty of the first iterations, 30 w^6 (w^2 = g / h: jerk^2 against ZMP^2; flat between 10 and 100)
   // (the limit grows with the horizon -- what is left of the creeping is counted in stages -- and what it costs to hand a QP
@@ -1695,16 +1696,19 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   int * const stats = h->env_debug && !capturing ? h->fb_count + 4 : nullptr; // (fb_count is a 64-byte allocation)
-  if(stats) CCC_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(int), stream));
+  unsigned long long * const ticket = reinterpret_cast<unsigned long long *>(h->fb_count + 8);
   if(h->N <= 128)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, ticket,
+                       stats);
   else if(h->N <= 256)
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, ticket,
+                       stats);
   else
     hipLaunchKernelGGL((zmp_plan_stage_kernel<kChunk, 8>), dim3((unsigned)blocks), dim3(64), 0, stream, P, (long)nqp, x0, zlim,
-                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, stats);
+                       control_dt, zmp, jerk, status, h->ws_stage, iters, pen_iters, rho, 1e-10, cert_abs, ticket,
+                       stats);
   CCC_HIP_CHECK(hipGetLastError());
   h->last_kernel = "zmp_plan_stage_kernel";
   if(stats)
