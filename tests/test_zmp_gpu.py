@@ -394,6 +394,30 @@ def test_stage_kernel_flags_an_infeasible_qp_and_ragged_batches(monkeypatch):
     assert np.all(r["status"][keep] == 0) and np.abs(r["zmp"][keep] - ref["zmp"][keep]).max() <= ZMP_TOL
 
 
+def test_stage_kernel_random_horizons_heights_and_control_periods(monkeypatch):
+    """Twenty random (horizon, CoM height, control period, seed) combinations through KS: ZMP and jerk parity with the oracle
+    (the model constants, the penalty 30 (g / h)^3, the certificate's bound and the flag words all depend on them), ragged
+    batches that leave lanes of the last wavefront without a QP."""
+    rng = np.random.default_rng(777)
+    for _ in range(20):
+        N = int(rng.integers(33, 257))
+        h = float(rng.uniform(0.5, 1.4))
+        dt = 2.0 / N
+        cdt = float(rng.choice([-1.0, 0.002, 0.005, dt]))
+        n = int(rng.integers(40, 200))
+        monkeypatch.setenv("CCC_ZMP_STAGE", "1")
+        mpc = LinearMpcZmp(h, 2.0, dt)
+        monkeypatch.delenv("CCC_ZMP_STAGE")
+        N = mpc.horizon_steps_
+        b = fx.make_zmp_batch(n, N, dt, com_height=h, seed=int(rng.integers(1, 10**6)))
+        ref = _oracle().LinearMpcZmp(h, 2.0, dt).plan_batch(b["x0"], b["zlim"], cdt, nthreads=8)
+        r = mpc.planOnceBatch(b["x0"], b["zlim"], cdt, want_jerk=True)
+        assert mpc.last_kernel() == "zmp_plan_stage_kernel", (N, h)
+        assert np.all(r["status"] == 0), (N, h, cdt)
+        assert np.abs(r["zmp"] - ref["zmp"]).max() <= ZMP_TOL, (N, h, cdt)
+        assert _jerk_err(r["jerk"], ref["jerk"]) <= JERK_RTOL, (N, h, cdt)
+
+
 def test_stage_kernel_is_the_default_for_large_batches_of_long_horizons():
     mpc = LinearMpcZmp(1.0, 2.0, 0.02)
     b = fx.make_zmp_batch(8192, 100, 0.02, seed=77)
