@@ -1629,10 +1629,10 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
 {
   const int64_t nqp = 2 * n;
 
-  // KS's time is flat in the batch up to one QP per lane (65536 on 256 CUs: ~20 iterations of 0.55 us x N, + 0.5 ms), the
+  // KS's time is flat in the batch up to one QP per lane (65536 on 256 CUs: its iteration limit x 0.62 us x N, + 0.5 ms), the
   // exact kernels' is proportional to it: KS from where the two cross (measured, solves/s at 32768 instances KS | exact:
-  // N = 40 40.1 | 37.1 M, 48 38.2 | 31.8 M, 56 30.8 | 19.5 M, 64 28.6 | 17.4 M, 72 21.8 | 7.0 M, 100 16.5 | 3.25 M,
-  // 128 11.8 | 1.2 M, 200 3.5 | 0.27 M; crossovers at 8192 / 4500 / 2200 / 800 instances for N = 72 / 100 / 128 / 200)
+  // N = 48 48.7 | 31.8 M, 64 35.9 | 17.4 M, 72 21.8 | 7.0 M, 100 17.5 | 3.25 M, 128 12.5 | 1.2 M, 200 5.1 | 0.27 M;
+  // crossovers at 8192 / 4500 / 2200 / 800 instances for N = 72 / 100 / 128 / 200)
   const int Nh = h->N;
   const int64_t stage_min = h->env_stage_min >= 0 ? h->env_stage_min
                             : Nh <= 48  ? 57344
