@@ -303,6 +303,31 @@ def _zmp100(n, dev, rank):
         t = time.perf_counter() - t0
         return ns / t, ns, float(np.abs(out.cpu().numpy()[:ns] - r["zmp"]).max()), "max |d ZMP| [m]"
 
+    def valu_replay():
+        """The state-space kernel is bound by its own vector instructions on one wavefront per SIMD: the share of the SIMD's
+        VALU cycles it keeps busy, from the newest committed PMC summary made from the same kernel sources (replayed)."""
+        import glob
+
+        from centroidalcontrolcollection_amd import build as _b
+
+        here, mine, src = os.path.dirname(os.path.abspath(__file__)), _b.kernel_hash("zmp100"), None
+        for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_zmp100_valu_counters.json")), reverse=True):
+            with open(path) as f:
+                d = json.load(f)
+            rel = "profiles/" + os.path.basename(path)
+            if d.get("kernel_hash") != mine:
+                src = src or "%s refused: profiled build %s, this build %s" % (rel, d.get("kernel_hash"), mine)
+                continue
+            return dict(simd_valu_busy_frac=d["simd_valu_busy_frac"], wait_frac=d["wait_frac"],
+                        valu_insts_per_wavefront=d["valu_insts_per_wavefront"],
+                        salu_insts_per_wavefront=d["salu_insts_per_wavefront"], effective_clock_ghz=d["effective_clock_ghz"],
+                        counters_source="%s (replayed; kernel_hash %s = this build)" % (rel, mine),
+                        what="simd_valu_busy_frac = SQ_ACTIVE_INST_VALU x wavefronts per SIMD / SQ_WAVE_CYCLES of "
+                             "zmp_plan_stage_kernel: one wavefront per SIMD, which issues its scalar bookkeeping and waits for "
+                             "its loads itself (DESIGN.md 4.1; scripts/fp64_rate_probe.hip: one wavefront with four independent "
+                             "fp64 chains reaches 59 of the 62 TFLOP/s the part sustains)")
+        return dict(simd_valu_busy_frac=None, counters_source=src)
+
     C = 8  # (stages per checkpoint, csrc/zmp.hip CCC_ZMP_STAGE_CHUNK)
     npad, nc = (N + C - 1) // C * C, (N + C - 1) // C
 
@@ -319,7 +344,7 @@ def _zmp100(n, dev, rank):
                 workload="LinearMpcZmp N=100 (2 s horizon @ 20 ms, TestLinearMpcZmp.cpp:17-19), random 6-step footstep "
                          "sequences, batch=%d per GPU" % n,
                 algo_bytes=2 * (24 + 2 * N * 8) + 16, stream_bytes=stream_bytes, kernel="zmp_plan_stage_kernel", cpu=cpu,
-                keep=(mpc, ring), parity_tol=1e-9)
+                keep=(mpc, ring), parity_tol=1e-9, valu_replay=valu_replay)
 
 
 def _ism(n, dev, rank):
@@ -616,6 +641,12 @@ def measure(workload, n, steps, warmup, rank, world, local_rank, dist, strong=Fa
         out["roofline"]["valu"] = dict(achieved=v["simd_valu_busy_frac"], peak=1.0, unit="share of SIMD VALU cycles busy",
                                        frac=v["simd_valu_busy_frac"],
                                        dense_equivalent_tflops=v["dense_equivalent_flop_per_solve"] * n / kavg / 1e12, **v)
+    if "valu_replay" in w:
+        v = w["valu_replay"]()
+        if v.get("simd_valu_busy_frac") is not None:
+            out["roofline"]["bound"] = "valu"
+        out["roofline"]["valu"] = dict(achieved=v.get("simd_valu_busy_frac"), peak=1.0, unit="share of SIMD VALU cycles busy",
+                                       frac=v.get("simd_valu_busy_frac"), **v)
     if world == 1 and history_leg and "other" in w:
         # `value` rotates through w["ring"] distinct batches on a default handle.  Beside it: the same rotation on a handle
         # that keeps no history at all, and ONE batch repeated on a fresh handle (the schedule's best case)

@@ -30,3 +30,17 @@ traffic["zmp100"] = dict(batch=32768, kernel="zmp_plan_stage_kernel + zmp_plan_r
                               "MI355X_MICROARCH.md, separate --pmc passes")
 json.dump(traffic, open(path, "w"), indent=1)
 print(json.dumps(traffic["zmp100"], indent=1))
+# what the state-space kernel is bound by: its own vector instructions on one wavefront per SIMD
+c = {r["counter"]: float(r["avg_per_dispatch"]) for r in csv.DictReader(open(os.path.join(prof, "%s_zmp100_counters.csv" % tag)))}
+ms = None
+for r in csv.DictReader(open(os.path.join(prof, "%s_zmp100_kernel_stats.csv" % tag))):
+    if "zmp_plan_stage_kernel" in r["Name"]:
+        ms = float(r["AverageNs"]) * 1e-6
+valu = dict(kernel_hash=kh, batch=32768, kernel="zmp_plan_stage_kernel", kernel_ms=ms,
+            simd_valu_busy_frac=c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] * c["SQ_WAVES"] / 1024.0,
+            wait_frac=c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], waves_per_simd=c["SQ_WAVES"] / 1024.0,
+            valu_insts_per_wavefront=c["SQ_INSTS_VALU"] / c["SQ_WAVES"], salu_insts_per_wavefront=c["SQ_INSTS_SALU"] / c["SQ_WAVES"],
+            effective_clock_ghz=c["SQ_WAVE_CYCLES"] * 4.0 / c["SQ_WAVES"] / (ms * 1e6),
+            source="profiles/%s_zmp100_counters.csv + %s_zmp100_kernel_stats.csv (batch 32768)" % (tag, tag))
+json.dump(valu, open(os.path.join(prof, "%s_zmp100_valu_counters.json" % tag), "w"), indent=1)
+print(json.dumps(valu, indent=1))

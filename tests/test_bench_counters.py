@@ -38,6 +38,7 @@ def test_committed_summaries_belong_to_the_tree():
     for w in ("xy", "ddp", "srb", "walk", "multi", "zmp100"):
         assert tr[w]["kernel_hash"] == build.kernel_hash(w), w
     assert json.load(open(os.path.join(ROOT, "profiles", "r06_ddp_valu_counters.json")))["kernel_hash"] == build.kernel_hash("ddp")
+    assert json.load(open(os.path.join(ROOT, "profiles", "r06_zmp100_valu_counters.json")))["kernel_hash"] == build.kernel_hash("zmp100")
 
 
 def test_counters_of_another_build_are_refused(monkeypatch):
