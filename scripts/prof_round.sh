@@ -12,3 +12,4 @@ bash scripts/prof_kernel.sh $TAG srb python scripts/ddp_bench.py 32768 2 srb
 bash scripts/prof_kernel.sh $TAG walk python bench.py --workload walk --no-cpu-baseline --no-history-leg --no-live-counters --steps 2 --warmup 1
 bash scripts/prof_kernel.sh $TAG multi python bench.py --workload multi --no-cpu-baseline --no-history-leg --no-live-counters --steps 2 --warmup 1
 bash scripts/prof_kernel.sh $TAG xy python bench.py --workload xy --no-cpu-baseline --no-history-leg --no-live-counters --steps 5 --warmup 1
+bash scripts/prof_zmp100.sh $TAG > gpurun_out/${TAG}_prof_zmp100.log 2>&1   # -> python scripts/summarize_zmp100.py $TAG (after summarize_round.py)
