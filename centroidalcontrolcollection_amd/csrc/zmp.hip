@@ -1687,7 +1687,11 @@ int launch_block(ccc_zmp * h, int64_t n, const double * x0, const double * zlim,
   // (the limit grows with the horizon -- what is left of the creeping is counted in stages -- and what it costs to hand a QP
   //  over grows faster; measured best, 32768 instances: 14 at N = 48 (41.6 M solves/s), 16 at 64 (29.8 M), 20 at 100, 24-26
   //  at 128 (11.3 M), 32 at 200 (5.1 M; 3.5 M with 24), 72 at N = 400 (207 k against 2.8 k for the HBM tableau alone))
-  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters : 8 + (h->N <= 256 ? h->N / 8 : h->N / 6);
+  // (beyond four QPs per lane a slow QP holds up its own lane only -- the others draw their next -- and what is handed over is
+  //  the exact kernel's at 6.5 M QPs/s: a fifth more sweeps, N = 100 at 262144 instances 10.9 -> 10.0 ms, 131072 5.90 -> 5.78)
+  const int base_iters = 8 + (h->N <= 256 ? h->N / 8 : h->N / 6);
+  const int iters = h->env_stage_iters > 0 ? h->env_stage_iters
+                                           : (nqp >= 4 * (int64_t)h->num_cu * 256 ? base_iters + base_iters / 5 : base_iters);
   const int pen_iters = h->env_stage_pen >= 0 ? h->env_stage_pen : 12;
   const double w2 = -1.0 / h->c2, rho = 30.0 * w2 * w2 * w2;
   // the certificate's bound on the stationarity residual: planned ZMP = ... + c2 cdt u_0 and |du_0| <= |r|_2 <= sqrt(N) r_max
