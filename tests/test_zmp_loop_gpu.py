@@ -120,3 +120,35 @@ def test_batched_closed_loop_matches_per_instance_host_loops():
                 s.addDisturb((0.03, 0.03))
     assert worst <= 1e-9
     assert np.abs(com.cpu().numpy()[:, :, 0] - np.array([s.pos() for s in sims])).max() <= 1e-9
+
+
+def test_closed_loop_at_the_reference_horizon_through_the_state_space_kernel(monkeypatch):
+    """TestLinearMpcZmp's own horizon (2 s @ 20 ms = 100 steps) on 6000 random timelines, 40 control cycles of 5 ms with a
+    kick: a batch that size takes the state-space kernel (csrc/zmp_stage.inc) with the exact kernel on its hand-overs; the
+    trajectories are those of a handle held to the exact kernels alone (planned ZMP of every cycle within 1e-9, no limit
+    violated that the other does not violate)."""
+    import torch
+
+    n, dt, sim_dt, cycles = 6000, 0.02, 0.005, 40
+    tl = fx.make_zmp_timelines(n, seed=21)
+    rng = np.random.default_rng(8)
+    com0 = np.zeros((n, 2, 2))
+    com0[:, :, 0] = rng.uniform(-0.02, 0.02, size=(n, 2))
+    com0[:, :, 1] = rng.uniform(-0.05, 0.05, size=(n, 2))
+    out = {}
+    for stage in ("1", "0"):
+        monkeypatch.setenv("CCC_ZMP_STAGE", stage)
+        mpc = LinearMpcZmp(1.0, 2.0, dt)
+        monkeypatch.delenv("CCC_ZMP_STAGE")
+        com = torch.from_numpy(com0.copy()).to("cuda:0")
+        zmp = torch.from_numpy(com0[:, :, 0].copy()).to("cuda:0")
+        tz = torch.zeros((cycles, n, 2), dtype=torch.float64, device="cuda:0")
+        viol = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        mpc.closed_loop_device(_to_dev(tl), com, zmp, 0.3, sim_dt, cycles, disturb_times=(0.4,), disturb_impulse=0.03,
+                               violations=viol, traj_zmp=tz)
+        torch.cuda.synchronize()
+        out[stage] = (tz.cpu().numpy(), com.cpu().numpy(), viol.cpu().numpy(), mpc.last_kernel())
+    assert out["1"][3] == "zmp_plan_stage_kernel" and out["0"][3] == "zmp_plan_reg_kernel"
+    assert np.abs(out["1"][0] - out["0"][0]).max() <= 1e-9
+    assert np.abs(out["1"][1] - out["0"][1]).max() <= 1e-8
+    assert np.array_equal(out["1"][2] > 0, out["0"][2] > 0)
